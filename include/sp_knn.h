@@ -1,0 +1,142 @@
+/*
+ * sp_knn.h — C ABI of libsimilaripy_hip.so: the MI355X (gfx950) replacement for
+ * the one native kernel of bogliosimone/similaripy.
+ *
+ * What it replaces in the reference
+ * ---------------------------------
+ *   s_plus::compute_similarities_parallel<int,float>   similaripy/cython_code/s_plus.h:265-453
+ *   declared to Cython at                               similaripy/cython_code/s_plus.pyx:51-91
+ *   called (GIL released) at                            similaripy/cython_code/s_plus.pyx:359-384
+ *
+ * sp_knn_f32_i32() takes the same arguments with the same meaning (CSR m1, CSR
+ * m2, the six normalisation vectors, the nine scalars, k, the two column
+ * selectors, the three flat output arrays of n_targets*k entries).  Because a
+ * device copy needs sizes the reference never passes, the struct additionally
+ * carries n_rows_m1 / n_rows_m2 / nnz counts.  Output convention is the
+ * reference's (s_plus.h:444-450): slot i owns [k*i, k*i+k); the first n_i <= k
+ * entries hold (row = targets[i], col, value) in unspecified order and the tail
+ * is zero.  Unlike the reference the callee zero-fills the tail itself, so the
+ * caller need not pre-zero.
+ *
+ * No torch / scipy / C++ types cross this boundary: plain pointers and sizes.
+ * All functions return 0 on success or a negative SP_E* code; sp_last_error()
+ * gives the thread's last message.  (The reference kernel is `void`, has no
+ * error path and is UB on bad input — s_plus.pyx:51; here bad input is
+ * reported instead.)
+ */
+#ifndef SP_KNN_H_
+#define SP_KNN_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* column selector modes — s_plus.h:24-28 (enum SelectionMode) */
+#define SP_SEL_NONE   0
+#define SP_SEL_ARRAY  1   /* pre-applied to m2 by the host; the kernel treats it as NONE (s_plus.h:160-162) */
+#define SP_SEL_MATRIX 2   /* per-row sorted column lists, indexed by ABSOLUTE m1 row id (s_plus.h:165-169) */
+
+/* error codes */
+#define SP_OK            0
+#define SP_EINVAL       -1   /* bad argument / struct size mismatch */
+#define SP_ENODEVICE    -2   /* no HIP device: the product path never falls back to CPU */
+#define SP_EHIP         -3   /* a HIP runtime call failed (see sp_last_error) */
+#define SP_ENOMEM       -4
+#define SP_EWORKSPACE   -5   /* caller workspace too small */
+
+/* flags */
+#define SP_FLAG_TIME_KERNEL   1u  /* bracket device work with hipEvents on `stream`, sync, fill kernel_ms */
+#define SP_FLAG_NO_ROWS_OUT   2u  /* device mode: `rows` may be NULL and is not written */
+#define SP_FLAG_STATIC_SCHED  4u  /* round-robin rows over workgroups instead of the work-sorted atomic queue */
+
+typedef struct sp_knn_args {
+    uint32_t struct_size;      /* = sizeof(sp_knn_args); checked */
+    uint32_t flags;            /* SP_FLAG_* */
+    int32_t  on_device;        /* 0: every pointer below is host memory (the drop-in call: H2D, compute, D2H)
+                                  1: every pointer is device memory on `device`, resident before the call */
+    int32_t  device;           /* HIP device ordinal */
+
+    /* problem shape (the reference infers these from NumPy arrays it never passes down) */
+    int32_t  n_targets;        /* s_plus.h: n_targets */
+    int32_t  n_rows_m1;        /* rows of m1 (length of m1_indptr - 1, of X* vectors, of selector indptr - 1) */
+    int32_t  n_rows_m2;        /* rows of m2 == columns of m1 */
+    int32_t  n_output_cols;    /* columns of m2 (length of Y* vectors) */
+    int64_t  nnz_m1;
+    int64_t  nnz_m2;
+
+    const int32_t *targets;    /* [n_targets] absolute m1 row ids, any order (s_plus.pyx:191-196) */
+    const float   *m1_data;    const int32_t *m1_indices;   const int32_t *m1_indptr;
+    const float   *m2_data;    const int32_t *m2_indices;   const int32_t *m2_indptr;
+                               /* m2 rows must have ascending column ids whenever n_output_cols exceeds the
+                                  accumulator tile (multi-pass), the same requirement the reference's blocked
+                                  path has (s_plus.h:385-394).  The host layer guarantees it. */
+
+    /* normalisation vectors; each pair is read only if the matching weight is non-zero
+       (s_plus.h:134-139) and may be NULL / dangling otherwise (s_plus.pyx:248-256) */
+    const float *Xtversky, *Ytversky;   /* l1 != 0 : sum x^2 per m1 row / per m2 column */
+    const float *Xcosine,  *Ycosine;    /* l2 != 0 : (sum x^2 + additive_shrink)^c */
+    const float *Xdepop,   *Ydepop;     /* l3 != 0 : w^p */
+
+    float a1, l1, l2, l3, t1, t2;
+    float stabilized_shrink, bayesian_shrink, threshold;
+
+    int32_t k;                 /* 1 <= k */
+    int32_t filter_mode;       /* SP_SEL_* */
+    const int32_t *filter_m_indptr;      /* [n_rows_m1+1] when MATRIX */
+    const int32_t *filter_m_indices;     /* sorted within a row */
+    int64_t filter_nnz;
+    int32_t target_col_mode;
+    int32_t _pad0;
+    const int32_t *target_col_m_indptr;
+    const int32_t *target_col_m_indices;
+    int64_t target_col_nnz;
+
+    /* outputs, n_targets*k each (64-bit offsets inside: n_targets*k may exceed 2^31) */
+    int32_t *rows;
+    int32_t *cols;
+    float   *values;
+    int32_t *out_counts;       /* optional [n_targets]: n_i per slot (the reference returns none) */
+
+    /* device-mode plumbing */
+    void    *stream;           /* hipStream_t; NULL = the null stream */
+    void    *workspace;        /* device scratch of >= sp_knn_workspace_bytes(); NULL = allocate internally */
+    int64_t  workspace_bytes;
+
+    /* tuning, 0 = auto */
+    int32_t table_slots;       /* LDS accumulator slots per workgroup (power of two) */
+    int32_t threads_per_wg;    /* 256 / 512 / 1024 */
+    int32_t num_wgs;           /* persistent workgroups */
+    int32_t load_pct;          /* hash fill target in percent (default 50) */
+
+    /* results */
+    float   kernel_ms;         /* OUT when SP_FLAG_TIME_KERNEL */
+    int32_t passes_total;      /* OUT (debug, only with SP_FLAG_TIME_KERNEL): accumulate+drain passes summed over rows */
+    int64_t reserved[4];
+} sp_knn_args;
+
+/* The hot path.  Replaces compute_similarities_parallel<int,float> (s_plus.h:265). */
+int sp_knn_f32_i32(sp_knn_args *args);
+
+/* Device scratch the call needs for these args (device mode with caller workspace). */
+int64_t sp_knn_workspace_bytes(const sp_knn_args *args);
+
+/* Number of usable HIP devices (0 when there is none).  Counterpart of
+   get_num_threads() -> omp_get_max_threads()  (similaripy/cython_code/utils.pyx:18-25). */
+int sp_device_count(void);
+
+/* Human-readable backend description ("gfx950 ... 256 CUs ..."); returns bytes written or <0. */
+int sp_backend_info(int device, char *buf, int buflen);
+
+/* Last error message of the calling thread ("" if none). */
+const char *sp_last_error(void);
+
+/* ABI version of this header. */
+#define SP_KNN_ABI_VERSION 1
+int sp_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SP_KNN_H_ */

@@ -1,0 +1,228 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/splus_port.c header).
+
+Python access to the two CPU implementations of the hot-path kernel:
+
+  kind="port"       oracle/libsplus_port.so      our plain-C restatement of s_plus.h:39-453
+  kind="reference"  oracle/_ref/libsplus_ref.so  the reference header itself, compiled in place
+                                                 from /root/reference by oracle/Makefile
+
+plus small helpers to canonicalise slot outputs for comparison and an independent float64
+dense definition of the similarity (restating tests/test_similarity.py:32-209 of the reference)
+for definition-level checks.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+Nothing under similaripy_amd/ does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import scipy.sparse as sp
+
+HERE = Path(__file__).resolve().parent
+PORT_LIB = HERE / "libsplus_port.so"
+REF_LIB = HERE / "_ref" / "libsplus_ref.so"
+
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+_ARGTYPES = (
+    [C.c_int, _i32p]
+    + [_f32p, _i32p, _i32p] * 2
+    + [_f32p] * 6
+    + [C.c_float] * 9
+    + [C.c_int, C.c_int]
+    + [C.c_int, _i32p, _i32p]
+    + [C.c_int, _i32p, _i32p]
+    + [_i32p, _i32p, _f32p]
+    + [C.c_int, C.c_int]
+)
+
+_libs = {}
+
+
+def build(ref: bool = True) -> None:
+    """make -C oracle port [ref]; `ref` is a no-op where /root/reference is absent."""
+    subprocess.run(["make", "-s", "-C", str(HERE), "port"] + (["ref"] if ref else []), check=True)
+
+
+def available(kind: str) -> bool:
+    return (PORT_LIB if kind == "port" else REF_LIB).exists()
+
+
+def load(kind: str = "port"):
+    if kind in _libs:
+        return _libs[kind]
+    if kind == "port":
+        if not PORT_LIB.exists():
+            build(ref=False)
+        lib = C.CDLL(str(PORT_LIB))
+        fn, thr = lib.splus_port_compute, lib.splus_port_max_threads
+    elif kind == "reference":
+        if not REF_LIB.exists():
+            raise FileNotFoundError(f"{REF_LIB} not built (needs /root/reference; run make -C oracle ref)")
+        lib = C.CDLL(str(REF_LIB))
+        fn, thr = lib.splus_ref_compute, lib.splus_ref_max_threads
+    else:
+        raise ValueError(kind)
+    fn.argtypes = _ARGTYPES
+    fn.restype = None
+    thr.argtypes = []
+    thr.restype = C.c_int
+    _libs[kind] = (fn, thr)
+    return _libs[kind]
+
+
+def max_threads(kind: str = "port") -> int:
+    return int(load(kind)[1]())
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a if a.size else np.zeros(1, dtype=np.float32)
+
+
+def _i32(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a if a.size else np.zeros(1, dtype=np.int32)
+
+
+def run_kernel(call, kind: str = "port", num_threads: int = 0, block_size: int = 0):
+    """Run compute_similarities_parallel semantics on a KernelCall-like object (duck-typed: the
+    attributes of similaripy_amd._host.KernelCall).  block_size follows s_plus.h:309-311
+    (0 = blocking off).  Returns (rows, cols, values) flat arrays of n_targets*k, pre-zeroed as
+    the reference's caller does (s_plus.pyx:351-353)."""
+    fn, _ = load(kind)
+    n, k = int(call.targets.shape[0]), int(call.k)
+    rows = np.zeros(max(n * k, 1), dtype=np.int32)
+    cols = np.zeros(max(n * k, 1), dtype=np.int32)
+    values = np.zeros(max(n * k, 1), dtype=np.float32)
+    if n > 0:
+        fn(n, _i32(call.targets),
+           _f32(call.m1_data), _i32(call.m1_indices), _i32(call.m1_indptr),
+           _f32(call.m2_data), _i32(call.m2_indices), _i32(call.m2_indptr),
+           _f32(call.Xtversky), _f32(call.Ytversky), _f32(call.Xcosine), _f32(call.Ycosine),
+           _f32(call.Xdepop), _f32(call.Ydepop),
+           call.a1, call.l1, call.l2, call.l3, call.t1, call.t2,
+           call.stabilized_shrink, call.bayesian_shrink, call.threshold,
+           k, int(call.n_output_cols),
+           int(call.filter_mode), _i32(call.filter_m_indptr), _i32(call.filter_m_indices),
+           int(call.target_col_mode), _i32(call.target_col_m_indptr), _i32(call.target_col_m_indices),
+           rows, cols, values, int(num_threads), int(block_size))
+    return rows[: n * k], cols[: n * k], values[: n * k]
+
+
+# --------------------------------------------------------------------------------------------
+# comparison helpers
+# --------------------------------------------------------------------------------------------
+def slot_counts(rows, cols, values, targets, k):
+    """Entries per slot. Padding is the (0,0,0.0) tail of a slot: an entry is real
+    iff its row equals the slot's target, except that for target 0 a trailing (0,0,0.0) is padding."""
+    n = targets.shape[0]
+    r = rows.reshape(n, k)
+    c = cols.reshape(n, k)
+    v = values.reshape(n, k)
+    real = r == targets[:, None]
+    zero_target = (targets == 0)[:, None]
+    real &= ~(zero_target & (c == 0) & (v == 0))
+    return real.sum(axis=1).astype(np.int32), real
+
+
+def canonical(rows, cols, values, targets, k):
+    """Per-slot (cols, values) sorted by column, padding stripped."""
+    n = targets.shape[0]
+    _, real = slot_counts(rows, cols, values, targets, k)
+    c = cols.reshape(n, k)
+    v = values.reshape(n, k)
+    out = []
+    for i in range(n):
+        ci, vi = c[i][real[i]], v[i][real[i]]
+        o = np.argsort(ci, kind="stable")
+        out.append((ci[o].copy(), vi[o].copy()))
+    return out
+
+
+def compare_topk(got, want, k, rtol=1e-5, atol=1e-7, what=""):
+    """Tie-aware comparison of two canonical() results.
+
+    A column present on one side only is accepted iff its value equals (within tolerance) the
+    smallest kept value of the other side — i.e. it sits exactly on the k-th place tie, which both
+    the reference's heap and any other exact selection resolve arbitrarily.  Common columns must
+    agree to `rtol`.  Returns the number of boundary-tie substitutions seen."""
+    assert len(got) == len(want), f"{what}: slot count {len(got)} != {len(want)}"
+    ties = 0
+    for i, ((gc, gv), (wc, wv)) in enumerate(zip(got, want)):
+        assert gc.shape[0] == wc.shape[0], f"{what}: slot {i}: kept {gc.shape[0]} entries, expected {wc.shape[0]}"
+        if gc.shape[0] == 0:
+            continue
+        common, gi, wi = np.intersect1d(gc, wc, assume_unique=True, return_indices=True)
+        np.testing.assert_allclose(gv[gi], wv[wi], rtol=rtol, atol=atol, err_msg=f"{what}: slot {i} values")
+        if common.shape[0] != gc.shape[0]:
+            g_only = np.setdiff1d(np.arange(gc.shape[0]), gi)
+            w_only = np.setdiff1d(np.arange(wc.shape[0]), wi)
+            assert gc.shape[0] == k, f"{what}: slot {i}: different columns although fewer than k were kept"
+            bound = min(gv.min(), wv.min())
+            tol = rtol * abs(bound) + atol
+            assert np.all(np.abs(gv[g_only] - bound) <= tol) and np.all(np.abs(wv[w_only] - bound) <= tol), (
+                f"{what}: slot {i}: column sets differ away from the k-th place tie: "
+                f"got-only {gc[g_only]}={gv[g_only]}, want-only {wc[w_only]}={wv[w_only]}, bound {bound}")
+            ties += g_only.shape[0]
+    return ties
+
+
+# --------------------------------------------------------------------------------------------
+# definition-level oracle (float64, dense) — independent of both C implementations
+# --------------------------------------------------------------------------------------------
+def dense_similarity(m1, m2=None, *, l1=0.0, l2=0.0, l3=0.0, t1=1.0, t2=1.0, c1=0.5, c2=0.5, a1=1.0,
+                     w1=None, w2=None, p1=0.0, p2=0.0, stabilized=0.0, bayesian=0.0, additive=0.0,
+                     binary=False):
+    """Similarity of every (row of m1, column of m2) pair straight from the formulas
+    (docs/similarity.md:76-123) in float64.  Returns (S, candidate_mask): the mask is
+    the structural pattern of m1 @ m2 (the reference only scores touched columns)."""
+    A = sp.csr_array(m1, dtype=np.float64)
+    B = sp.csr_array(m1.T if m2 is None else m2, dtype=np.float64)
+    A.eliminate_zeros()
+    B.eliminate_zeros()
+    if binary:
+        A.data[:] = 1.0
+        B.data[:] = 1.0
+    xy = (A @ B).toarray()
+    pat = ((abs(A) > 0).astype(np.float64) @ (abs(B) > 0).astype(np.float64)).toarray() > 0
+    x2 = np.asarray(A.multiply(A).sum(axis=1)).ravel()
+    y2 = np.asarray(B.multiply(B).sum(axis=0)).ravel()
+    den = np.zeros_like(xy)
+    if l1 != 0:
+        den += l1 * (t1 * (x2[:, None] - xy) + t2 * (y2[None, :] - xy) + xy)
+    if l2 != 0:
+        den += l2 * np.power(x2 + additive, c1)[:, None] * np.power(y2 + additive, c2)[None, :]
+    if l3 != 0:
+        xd = np.ones(A.shape[0]) if w1 is None else np.power(np.asarray(w1, dtype=np.float64), p1)
+        yd = np.ones(B.shape[1]) if w2 is None else np.power(np.asarray(w2, dtype=np.float64), p2)
+        den += l3 * xd[:, None] * yd[None, :]
+    num = np.power(xy, a1) if a1 != 1 else xy
+    if l1 != 0 or l2 != 0 or l3 != 0 or stabilized != 0 or bayesian != 0:
+        den = den + stabilized
+        with np.errstate(divide="ignore", invalid="ignore"):
+            S = np.where(den != 0, num / den, 0.0)
+            if bayesian != 0:
+                S = S * (num / (num + bayesian))
+    else:
+        S = xy
+    return S, pat
+
+
+def dense_topk(S, mask, k, threshold=0.0):
+    """canonical()-shaped top-k of a dense score matrix restricted to `mask` and >= threshold."""
+    out = []
+    for i in range(S.shape[0]):
+        c = np.flatnonzero(mask[i] & (S[i] >= threshold))
+        v = S[i, c]
+        if c.shape[0] > k:
+            sel = np.argsort(-v, kind="stable")[:k]
+            c, v = c[sel], v[sel]
+        o = np.argsort(c)
+        out.append((c[o].astype(np.int32), v[o].astype(np.float32)))
+    return out

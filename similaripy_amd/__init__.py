@@ -1,0 +1,34 @@
+"""similaripy_amd — MI355X-native top-k sparse similarity, drop-in for similaripy's hot path.
+
+Public surface mirrors similaripy/__init__.py:8-19 for what is on the hot path.
+Compute happens only in libsimilaripy_hip.so (hand-written HIP for gfx950); importing the
+package needs no GPU, calling a similarity function does.
+"""
+from .normalization import normalize
+from .similarity import (
+    asymmetric_cosine,
+    cosine,
+    dice,
+    dot_product,
+    jaccard,
+    p3alpha,
+    rp3beta,
+    s_plus,
+    tversky,
+)
+
+__version__ = "0.1.0"
+
+__all__ = [
+    "__version__",
+    "normalize",
+    "dot_product",
+    "cosine",
+    "asymmetric_cosine",
+    "jaccard",
+    "dice",
+    "tversky",
+    "p3alpha",
+    "rp3beta",
+    "s_plus",
+]

@@ -1,0 +1,204 @@
+"""ctypes binding of include/sp_knn.h (libsimilaripy_hip.so).
+
+This is the only way the Python layer reaches compute.  There is no CPU fallback:
+if the library is missing, cannot be loaded, or sees no HIP device, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+from . import _build
+
+SP_SEL_NONE, SP_SEL_ARRAY, SP_SEL_MATRIX = 0, 1, 2
+SP_FLAG_TIME_KERNEL = 1
+SP_FLAG_NO_ROWS_OUT = 2
+SP_FLAG_STATIC_SCHED = 4
+
+_c_f32p = C.POINTER(C.c_float)
+_c_i32p = C.POINTER(C.c_int32)
+
+
+class SpKnnArgs(C.Structure):
+    """Mirror of ``struct sp_knn_args`` (include/sp_knn.h) — keep field order identical."""
+
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("flags", C.c_uint32),
+        ("on_device", C.c_int32),
+        ("device", C.c_int32),
+        ("n_targets", C.c_int32),
+        ("n_rows_m1", C.c_int32),
+        ("n_rows_m2", C.c_int32),
+        ("n_output_cols", C.c_int32),
+        ("nnz_m1", C.c_int64),
+        ("nnz_m2", C.c_int64),
+        ("targets", C.c_void_p),
+        ("m1_data", C.c_void_p),
+        ("m1_indices", C.c_void_p),
+        ("m1_indptr", C.c_void_p),
+        ("m2_data", C.c_void_p),
+        ("m2_indices", C.c_void_p),
+        ("m2_indptr", C.c_void_p),
+        ("Xtversky", C.c_void_p),
+        ("Ytversky", C.c_void_p),
+        ("Xcosine", C.c_void_p),
+        ("Ycosine", C.c_void_p),
+        ("Xdepop", C.c_void_p),
+        ("Ydepop", C.c_void_p),
+        ("a1", C.c_float),
+        ("l1", C.c_float),
+        ("l2", C.c_float),
+        ("l3", C.c_float),
+        ("t1", C.c_float),
+        ("t2", C.c_float),
+        ("stabilized_shrink", C.c_float),
+        ("bayesian_shrink", C.c_float),
+        ("threshold", C.c_float),
+        ("k", C.c_int32),
+        ("filter_mode", C.c_int32),
+        ("filter_m_indptr", C.c_void_p),
+        ("filter_m_indices", C.c_void_p),
+        ("filter_nnz", C.c_int64),
+        ("target_col_mode", C.c_int32),
+        ("_pad0", C.c_int32),
+        ("target_col_m_indptr", C.c_void_p),
+        ("target_col_m_indices", C.c_void_p),
+        ("target_col_nnz", C.c_int64),
+        ("rows", C.c_void_p),
+        ("cols", C.c_void_p),
+        ("values", C.c_void_p),
+        ("out_counts", C.c_void_p),
+        ("stream", C.c_void_p),
+        ("workspace", C.c_void_p),
+        ("workspace_bytes", C.c_int64),
+        ("table_slots", C.c_int32),
+        ("threads_per_wg", C.c_int32),
+        ("num_wgs", C.c_int32),
+        ("load_pct", C.c_int32),
+        ("kernel_ms", C.c_float),
+        ("passes_total", C.c_int32),
+        ("reserved", C.c_int64 * 4),
+    ]
+
+
+# every symbol include/sp_knn.h declares; tests check the library exports all of them
+EXPORTED_SYMBOLS = (
+    "sp_knn_f32_i32",
+    "sp_knn_workspace_bytes",
+    "sp_device_count",
+    "sp_backend_info",
+    "sp_last_error",
+    "sp_abi_version",
+)
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def library_path() -> Path:
+    return Path(os.environ.get("SIMILARIPY_AMD_LIB", str(_build.LIB_PATH)))
+
+
+def load(build_if_missing: bool = True):
+    """Load (building first if needed) libsimilaripy_hip.so. Raises HipLibraryError on failure."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if build_if_missing and "SIMILARIPY_AMD_LIB" not in os.environ:
+        try:
+            if _build.is_stale():
+                _build.build()
+        except Exception as exc:  # no hipcc on the box: use what travelled with the snapshot
+            if not path.exists():
+                raise HipLibraryError(f"libsimilaripy_hip.so is not built and cannot be built here: {exc}") from exc
+    if not path.exists():
+        raise HipLibraryError(f"{path} not found: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    # torch ships its own libamdhip64.so.7; importing it first makes the HIP runtime a single
+    # shared instance, so torch device pointers / streams are valid inside this library.
+    import torch  # noqa: F401
+
+    try:
+        lib = C.CDLL(str(path), mode=C.RTLD_GLOBAL)
+    except OSError as exc:
+        raise HipLibraryError(f"cannot load {path}: {exc}") from exc
+
+    lib.sp_knn_f32_i32.argtypes = [C.POINTER(SpKnnArgs)]
+    lib.sp_knn_f32_i32.restype = C.c_int
+    lib.sp_knn_workspace_bytes.argtypes = [C.POINTER(SpKnnArgs)]
+    lib.sp_knn_workspace_bytes.restype = C.c_int64
+    lib.sp_device_count.argtypes = []
+    lib.sp_device_count.restype = C.c_int
+    lib.sp_backend_info.argtypes = [C.c_int, C.c_char_p, C.c_int]
+    lib.sp_backend_info.restype = C.c_int
+    lib.sp_last_error.argtypes = []
+    lib.sp_last_error.restype = C.c_char_p
+    lib.sp_abi_version.argtypes = []
+    lib.sp_abi_version.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().sp_last_error().decode("utf-8", "replace")
+
+
+def device_count() -> int:
+    return int(load().sp_device_count())
+
+
+def require_device() -> int:
+    n = device_count()
+    if n <= 0:
+        raise HipLibraryError(
+            "no HIP device visible: similaripy_amd runs only on an AMD GPU (gfx950) and has no CPU fallback"
+        )
+    return n
+
+
+def backend_info(device: int = 0) -> str:
+    buf = C.create_string_buffer(512)
+    n = load().sp_backend_info(device, buf, len(buf))
+    if n < 0:
+        raise HipLibraryError(last_error())
+    return buf.value.decode()
+
+
+def _ptr(a):
+    """Address of a numpy array (kept alive by the caller) or 0."""
+    if a is None:
+        return None
+    return a.ctypes.data
+
+
+def call_knn(args: SpKnnArgs) -> None:
+    lib = load()
+    args.struct_size = C.sizeof(SpKnnArgs)
+    rc = lib.sp_knn_f32_i32(C.byref(args))
+    if rc != 0:
+        raise HipLibraryError(f"sp_knn_f32_i32 failed ({rc}): {last_error()}")
+
+
+def workspace_bytes(args: SpKnnArgs) -> int:
+    lib = load()
+    args.struct_size = C.sizeof(SpKnnArgs)
+    n = lib.sp_knn_workspace_bytes(C.byref(args))
+    if n < 0:
+        raise HipLibraryError(f"sp_knn_workspace_bytes failed ({n}): {last_error()}")
+    return int(n)
+
+
+def as_f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def as_i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)

@@ -1,0 +1,474 @@
+"""Host-side orchestration of the top-k similarity call.
+
+Mirror of the reference's Cython orchestrator and its NumPy-level helpers:
+
+    similaripy/cython_code/s_plus.pyx:95-433        def s_plus(...)            -> s_plus()
+    similaripy/cython_code/s_plus_utils.pyx:19-125  validate_s_plus_inputs     -> validate_inputs()
+    similaripy/cython_code/s_plus_utils.pyx:128-166 csr_sum                    -> csr_sum()
+    similaripy/cython_code/s_plus_utils.pyx:169-278 norm builders              -> build_*()
+    similaripy/cython_code/s_plus_utils.pyx:311-490 selectors / column filter  -> build_column_selector() ...
+    similaripy/cython_code/utils.pyx:43-173         COO / CSR assembly         -> build_coo() / build_csr()
+
+The work is split in three so tests can drive the kernel boundary directly:
+
+    prepare(...)  -> KernelCall   every array/scalar compute_similarities_parallel receives
+    run_hip(call) -> rows, cols, values, counts   (ctypes -> libsimilaripy_hip.so, HIP only)
+    finish(...)   -> scipy.sparse output
+
+Not reproduced on purpose: `_reorder_columns_by_popularity` (s_plus_utils.pyx:493-618) — a CPU
+cache optimisation that only permutes slot order; `block_size` / `num_threads`
+are accepted and ignored (results do not depend on them — tests/test_similarity.py:505).
+"""
+from __future__ import annotations
+
+import os
+import sys
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _abi
+
+MODE_NONE, MODE_ARRAY, MODE_MATRIX = _abi.SP_SEL_NONE, _abi.SP_SEL_ARRAY, _abi.SP_SEL_MATRIX
+
+_EMPTY_F32 = np.zeros(0, dtype=np.float32)
+_EMPTY_I32 = np.zeros(0, dtype=np.int32)
+
+
+# --------------------------------------------------------------------------------------------
+# the kernel boundary
+# --------------------------------------------------------------------------------------------
+@dataclass
+class KernelCall:
+    """Arguments of compute_similarities_parallel<int,float> (s_plus.h:265-303) + the sizes a
+    device copy needs.  All arrays are C-contiguous float32 / int32."""
+
+    targets: np.ndarray
+    m1_data: np.ndarray
+    m1_indices: np.ndarray
+    m1_indptr: np.ndarray
+    m2_data: np.ndarray
+    m2_indices: np.ndarray
+    m2_indptr: np.ndarray
+    n_rows_m1: int
+    n_rows_m2: int
+    n_output_cols: int
+    k: int
+    Xtversky: np.ndarray = field(default_factory=lambda: _EMPTY_F32)
+    Ytversky: np.ndarray = field(default_factory=lambda: _EMPTY_F32)
+    Xcosine: np.ndarray = field(default_factory=lambda: _EMPTY_F32)
+    Ycosine: np.ndarray = field(default_factory=lambda: _EMPTY_F32)
+    Xdepop: np.ndarray = field(default_factory=lambda: _EMPTY_F32)
+    Ydepop: np.ndarray = field(default_factory=lambda: _EMPTY_F32)
+    a1: float = 1.0
+    l1: float = 0.0
+    l2: float = 0.0
+    l3: float = 0.0
+    t1: float = 1.0
+    t2: float = 1.0
+    stabilized_shrink: float = 0.0
+    bayesian_shrink: float = 0.0
+    threshold: float = 0.0
+    filter_mode: int = MODE_NONE
+    filter_m_indptr: np.ndarray = field(default_factory=lambda: _EMPTY_I32)
+    filter_m_indices: np.ndarray = field(default_factory=lambda: _EMPTY_I32)
+    target_col_mode: int = MODE_NONE
+    target_col_m_indptr: np.ndarray = field(default_factory=lambda: _EMPTY_I32)
+    target_col_m_indices: np.ndarray = field(default_factory=lambda: _EMPTY_I32)
+
+    @property
+    def n_targets(self) -> int:
+        return int(self.targets.shape[0])
+
+
+# --------------------------------------------------------------------------------------------
+# validation (s_plus_utils.pyx:19-125) — same checks, same exception types
+# --------------------------------------------------------------------------------------------
+def validate_inputs(matrix1, matrix2, weight_depop_matrix1, weight_depop_matrix2, k,
+                    target_rows, filter_cols, target_cols, verbose, format_output) -> None:
+    if not sp.issparse(matrix1):
+        raise TypeError('matrix1 must be a sparse matrix')
+    if not sp.issparse(matrix2):
+        raise TypeError('matrix2 must be a sparse matrix')
+    if matrix1.shape[1] != matrix2.shape[0]:
+        raise ValueError(
+            f'Incompatible matrix shapes: matrix1.shape[1]={matrix1.shape[1]} '
+            f'must equal matrix2.shape[0]={matrix2.shape[0]}')
+    if k < 1:
+        raise ValueError(f'k must be >= 1, got {k}')
+
+    def _check_weights(w, n, name):
+        ok = False
+        if isinstance(w, str):
+            # the reference evaluates len('none') first; only the outcome is kept
+            ok = w in ('none', 'sum') or len(w) == n
+        else:
+            ok = len(w) == n
+        if not ok:
+            raise ValueError(f'{name} must be array of length {n} or one of ("none", "sum"), got length {len(w)}')
+
+    _check_weights(weight_depop_matrix1, matrix1.shape[0], 'weight_depop_matrix1')
+    _check_weights(weight_depop_matrix2, matrix2.shape[1], 'weight_depop_matrix2')
+
+    if target_rows is not None and len(target_rows) > matrix1.shape[0]:
+        raise ValueError(
+            f'target_rows length ({len(target_rows)}) cannot exceed matrix1.shape[0] ({matrix1.shape[0]})')
+
+    expected = (matrix1.shape[0], matrix2.shape[1])
+    for name, sel in (('filter_cols', filter_cols), ('target_cols', target_cols)):
+        if sel is None:
+            continue
+        if not (sp.issparse(sel) or isinstance(sel, (list, np.ndarray))):
+            raise TypeError(f'{name} must be a sparse matrix, list, numpy array, or None')
+        if sp.issparse(sel) and sel.data.shape[0] != 0 and sel.shape != expected:
+            raise ValueError(f'{name} shape {sel.shape} does not match expected shape {expected}')
+
+    if not isinstance(verbose, bool):
+        raise TypeError(f'verbose must be boolean, got {type(verbose).__name__}')
+    if format_output not in ('coo', 'csr'):
+        raise ValueError(f"format_output must be 'coo' or 'csr', got '{format_output}'")
+
+
+# --------------------------------------------------------------------------------------------
+# NumPy-level preprocessing (s_plus_utils.pyx:128-490)
+# --------------------------------------------------------------------------------------------
+def csr_sum(data: np.ndarray, indices: np.ndarray, indptr: np.ndarray, n_cols: int, axis: int) -> np.ndarray:
+    """Row sums (axis=1: float32 np.add.reduceat, empty rows forced to 0) or column sums
+    (axis=0: float64 np.bincount cast to float32) of a float32 CSR — s_plus_utils.pyx:128-166."""
+    if axis == 1:
+        n_rows = indptr.shape[0] - 1
+        out = np.zeros(n_rows, dtype=np.float32)
+        if data.shape[0] == 0:
+            return out
+        # reduce over the non-empty rows only: their starts are strictly increasing and < nnz, so
+        # every segment is exactly one row (the reference reduces over all starts and then zeroes
+        # the empty rows, :155-158 — same values; trailing empty rows would make that call raise)
+        nonempty = np.diff(indptr) > 0
+        out[nonempty] = np.add.reduceat(data, indptr[:-1][nonempty])
+        return out
+    if axis == 0:
+        return np.bincount(indices, weights=data, minlength=n_cols).astype(np.float32, copy=False)
+    raise ValueError(f"axis must be 0 or 1, got {axis}")
+
+
+def build_squared_norms(m1_data, m1_indices, m1_indptr, n_cols_m1, m2_data, m2_indices, m2_indptr, n_cols_m2):
+    """(sum x^2 per m1 row, sum y^2 per m2 column) — s_plus_utils.pyx:169-201."""
+    sq1 = np.square(m1_data, dtype=np.float32)
+    sq2 = np.square(m2_data, dtype=np.float32)
+    return (csr_sum(sq1, m1_indices, m1_indptr, n_cols_m1, axis=1),
+            csr_sum(sq2, m2_indices, m2_indptr, n_cols_m2, axis=0))
+
+
+def build_cosine_normalization(m1_sq, m2_sq, c1, c2, additive_shrink):
+    """X=(sq1+add)^c1, Y=(sq2+add)^c2 in float32 — s_plus_utils.pyx:204-228."""
+    c1, c2, add = float(np.float32(c1)), float(np.float32(c2)), float(np.float32(additive_shrink))
+    return (np.power(m1_sq + add, c1, dtype=np.float32),
+            np.power(m2_sq + add, c2, dtype=np.float32))
+
+
+def build_depop_normalization(m1, m2, n_rows_m1, n_cols_m2, weight_spec1, weight_spec2, p1, p2):
+    """w^p, 'none' -> ones, 'sum' -> csr_sum^p — s_plus_utils.pyx:231-278.
+    m1/m2 are (data, indices, indptr, n_cols) tuples of the float32 (or binarised) matrices."""
+    p1, p2 = float(np.float32(p1)), float(np.float32(p2))
+
+    def one(spec, p, which):
+        if isinstance(spec, (list, np.ndarray)):
+            return np.power(spec, p, dtype=np.float32)
+        if spec == 'none':
+            return np.ones(n_rows_m1 if which == 1 else n_cols_m2, dtype=np.float32)
+        if spec == 'sum':
+            d, i, ptr, nc = m1 if which == 1 else m2
+            return np.power(csr_sum(d, i, ptr, nc, axis=1 if which == 1 else 0), p, dtype=np.float32)
+        raise ValueError(f"Invalid weight_spec{which}: {spec}")
+
+    return one(weight_spec1, p1, 1), one(weight_spec2, p2, 2)
+
+
+def build_column_selector(cols):
+    """(mode, indptr, indices): sparse with data -> MATRIX (CSR, zeros removed, sorted rows);
+    non-empty list/array -> ARRAY; else NONE — s_plus_utils.pyx:311-361."""
+    if sp.issparse(cols) and cols.data.shape[0] != 0:
+        m = cols.tocsr()
+        if m is cols:
+            m = m.copy()
+        m.eliminate_zeros()
+        m.sort_indices()
+        return MODE_MATRIX, np.array(m.indptr, dtype=np.int32), np.array(m.indices, dtype=np.int32)
+    if isinstance(cols, (list, np.ndarray)) and len(cols) != 0:
+        return MODE_ARRAY, _EMPTY_I32, _EMPTY_I32
+    return MODE_NONE, _EMPTY_I32, _EMPTY_I32
+
+
+def compute_target_columns(filter_cols, target_cols, n_cols: int) -> np.ndarray:
+    """Columns that survive array-style target/filter lists — s_plus_utils.pyx:364-421.
+    Out-of-range ids are silently dropped (:411,:418)."""
+    def is_empty(c):
+        return c is None or (isinstance(c, (list, np.ndarray)) and len(c) == 0)
+
+    def is_matrix(c):
+        return sp.issparse(c) and c.data.shape[0] != 0
+
+    f_empty, t_empty = is_empty(filter_cols), is_empty(target_cols)
+    f_mat, t_mat = is_matrix(filter_cols), is_matrix(target_cols)
+    if (f_empty and t_empty) or (f_mat and t_mat) or (f_mat and t_empty) or (t_mat and f_empty):
+        return np.arange(n_cols, dtype=np.int32)
+    if not t_empty and not t_mat:
+        mask = np.zeros(n_cols, dtype=bool)
+        idx = np.asarray(target_cols, dtype=np.int32)
+        mask[idx[(idx >= 0) & (idx < n_cols)]] = True
+    else:
+        mask = np.ones(n_cols, dtype=bool)
+    if not f_empty and not f_mat:
+        idx = np.asarray(filter_cols, dtype=np.int32)
+        mask[idx[(idx >= 0) & (idx < n_cols)]] = False
+    return np.flatnonzero(mask).astype(np.int32, copy=False)
+
+
+def filter_matrix_columns(data, indices, indptr, n_cols: int, keep_cols: np.ndarray):
+    """Drop CSR entries whose column is not in keep_cols; column ids are preserved
+    (s_plus_utils.pyx:424-490, the two typed loops become one mask + cumulative count)."""
+    mask = np.zeros(n_cols, dtype=bool)
+    kc = np.asarray(keep_cols, dtype=np.int32)
+    mask[kc[(kc >= 0) & (kc < n_cols)]] = True
+    keep = mask[indices]
+    csum = np.concatenate(([0], np.cumsum(keep, dtype=np.int64)))
+    new_indptr = csum[indptr].astype(np.int32)
+    return (np.ascontiguousarray(data[keep], dtype=np.float32),
+            np.ascontiguousarray(indices[keep], dtype=np.int32),
+            new_indptr)
+
+
+# --------------------------------------------------------------------------------------------
+# output assembly (utils.pyx:43-173, coo_to_csr.h:28-71)
+# --------------------------------------------------------------------------------------------
+def build_coo(rows, cols, values, n_rows: int, n_cols: int) -> sp.coo_array:
+    """COO over the raw slot arrays, zero padding included (utils.pyx:43-64)."""
+    return sp.coo_array((values, (rows, cols)), shape=(n_rows, n_cols), dtype=np.float32)
+
+
+def build_csr(targets, cols, values, counts, k: int, n_rows: int, n_cols: int) -> sp.csr_array:
+    """CSR with padding and genuine zeros removed, rows not in `targets` empty, entries of a
+    row in slot order (utils.pyx:141-173 -> coo_to_csr.h:28-71 -> eliminate_zeros, s_plus.pyx:424).
+    The reference counting-sorts n_targets*k triples incl. padding; the per-slot counts the
+    kernel returns let us skip the padding up front — same result."""
+    n_targets = targets.shape[0]
+    total = n_targets * k
+    idx_dtype = np.int32 if max(total, n_cols) <= np.iinfo(np.int32).max else np.int64
+    counts = counts.astype(np.int64, copy=False)
+    if n_targets == 0:
+        return sp.csr_array((n_rows, n_cols), dtype=np.float32)
+    valid = (np.arange(k, dtype=np.int64)[None, :] < counts[:, None]).ravel()
+    v = values[valid]
+    c = cols[valid]
+    row_nnz = np.zeros(n_rows, dtype=np.int64)
+    strictly_increasing = n_targets == 1 or bool(np.all(targets[1:] > targets[:-1]))
+    if strictly_increasing:
+        row_nnz[targets] = counts
+    else:
+        # general (unsorted / repeated target_rows): stable counting sort by row id
+        r = np.repeat(targets.astype(np.int64), counts)
+        order = np.argsort(r, kind='stable')
+        v, c = v[order], c[order]
+        np.add.at(row_nnz, targets, counts)
+    indptr = np.zeros(n_rows + 1, dtype=idx_dtype)
+    np.cumsum(row_nnz, out=indptr[1:])
+    res = sp.csr_array((v, c.astype(idx_dtype, copy=False), indptr), shape=(n_rows, n_cols), dtype=np.float32)
+    res.eliminate_zeros()
+    return res
+
+
+# --------------------------------------------------------------------------------------------
+# prepare / run / finish
+# --------------------------------------------------------------------------------------------
+def _say(verbose: bool, msg: str) -> None:
+    # the reference drives a C++ progress bar on stderr (s_plus.pyx:199-202); a per-row host
+    # callback has no device analogue, so only the phase names are reported
+    if verbose:
+        print(f"[similaripy_amd] {msg}", file=sys.stderr, flush=True)
+
+
+def _csr_f32_i32(m, binary: bool):
+    """CSR view with zeros eliminated, float32 data (ones if `binary`), int32 indices/indptr.
+    Unlike the reference (s_plus.pyx:210-211) the caller's matrix is never modified."""
+    m = m.tocsr()
+    if m.data.shape[0] and np.count_nonzero(m.data) != m.data.shape[0]:
+        m = m.copy()
+        m.eliminate_zeros()
+    if m.nnz > np.iinfo(np.int32).max:
+        raise ValueError("matrix has more than 2^31-1 stored entries (int32 index limit, s_plus.pyx:241-244)")
+    if binary:
+        data = np.ones(m.data.shape[0], dtype=np.float32)
+    else:
+        data = np.ascontiguousarray(m.data, dtype=np.float32)
+    return m, data, np.ascontiguousarray(m.indices, dtype=np.int32), np.ascontiguousarray(m.indptr, dtype=np.int32)
+
+
+def prepare(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_matrix2='none',
+            p1=0.0, p2=0.0, a1=1.0, l1=0.0, l2=0.0, l3=0.0, t1=1.0, t2=1.0, c1=0.5, c2=0.5, k=100,
+            stabilized_shrink=0.0, bayesian_shrink=0.0, additive_shrink=0.0, threshold=0.0,
+            binary=False, target_rows=None, filter_cols=None, target_cols=None,
+            verbose=False, format_output='csr') -> KernelCall:
+    """Everything s_plus.pyx does before the `with nogil:` block (:168-353)."""
+    if matrix2 is None:
+        matrix2 = matrix1.T
+    k = int(k)
+    validate_inputs(matrix1, matrix2, weight_depop_matrix1, weight_depop_matrix2, k,
+                    target_rows, filter_cols, target_cols, verbose, format_output)
+    if k > matrix2.shape[1]:
+        k = matrix2.shape[1]                                   # s_plus.pyx:187-188
+
+    if target_rows is None:
+        targets = np.arange(matrix1.shape[0], dtype=np.int32)
+    else:
+        targets = np.ascontiguousarray(np.asarray(target_rows, dtype=np.int32))
+        if targets.size and (targets.min() < 0 or targets.max() >= matrix1.shape[0]):
+            # the reference does not check (s_plus.pyx:191-196: out-of-range is UB there)
+            raise ValueError("target_rows contains row ids outside matrix1")
+
+    m1, m1_data, m1_indices, m1_indptr = _csr_f32_i32(matrix1, binary)
+    m2, m2_data, m2_indices, m2_indptr = _csr_f32_i32(matrix2, binary)
+    n_rows_m1, n_rows_m2 = m1.shape
+    n_output_cols = m2.shape[1]
+
+    # all scalar parameters are C floats in the reference (s_plus.pyx:100-113)
+    f32 = lambda x: float(np.float32(x))  # noqa: E731
+    a1, l1, l2, l3, t1, t2 = map(f32, (a1, l1, l2, l3, t1, t2))
+    stabilized_shrink, bayesian_shrink, threshold = map(f32, (stabilized_shrink, bayesian_shrink, threshold))
+
+    call = KernelCall(
+        targets=targets, m1_data=m1_data, m1_indices=m1_indices, m1_indptr=m1_indptr,
+        m2_data=m2_data, m2_indices=m2_indices, m2_indptr=m2_indptr,
+        n_rows_m1=n_rows_m1, n_rows_m2=n_rows_m2, n_output_cols=n_output_cols, k=k,
+        a1=a1, l1=l1, l2=l2, l3=l3, t1=t1, t2=t2,
+        stabilized_shrink=stabilized_shrink, bayesian_shrink=bayesian_shrink, threshold=threshold)
+
+    if l1 != 0 or l2 != 0:
+        sq1, sq2 = build_squared_norms(m1_data, m1_indices, m1_indptr, n_rows_m2,
+                                       m2_data, m2_indices, m2_indptr, n_output_cols)
+        if l1 != 0:
+            call.Xtversky, call.Ytversky = sq1, sq2
+        if l2 != 0:
+            call.Xcosine, call.Ycosine = build_cosine_normalization(sq1, sq2, c1, c2, additive_shrink)
+    if l3 != 0:
+        call.Xdepop, call.Ydepop = build_depop_normalization(
+            (m1_data, m1_indices, m1_indptr, n_rows_m2), (m2_data, m2_indices, m2_indptr, n_output_cols),
+            n_rows_m1, n_output_cols, weight_depop_matrix1, weight_depop_matrix2, p1, p2)
+        call.Xdepop = np.ascontiguousarray(call.Xdepop, dtype=np.float32)
+        call.Ydepop = np.ascontiguousarray(call.Ydepop, dtype=np.float32)
+
+    call.filter_mode, call.filter_m_indptr, call.filter_m_indices = build_column_selector(filter_cols)
+    call.target_col_mode, call.target_col_m_indptr, call.target_col_m_indices = build_column_selector(target_cols)
+    if call.filter_mode == MODE_ARRAY or call.target_col_mode == MODE_ARRAY:
+        keep = compute_target_columns(filter_cols, target_cols, n_output_cols)
+        call.m2_data, call.m2_indices, call.m2_indptr = filter_matrix_columns(
+            m2_data, m2_indices, m2_indptr, n_output_cols, keep)
+
+    # The kernel windows the columns when they exceed its LDS tile and then needs ascending column
+    # ids inside each m2 row — what the reference's blocked path gets from sort_indices()
+    # (s_plus_utils.pyx:562).  Transposes and scipy-built CSR already are.
+    if not _rows_sorted(call.m2_indices, call.m2_indptr):
+        tmp = sp.csr_array((call.m2_data.copy(), call.m2_indices.copy(), call.m2_indptr.copy()),
+                           shape=(n_rows_m2, n_output_cols))
+        tmp.sort_indices()
+        call.m2_data = np.ascontiguousarray(tmp.data, dtype=np.float32)
+        call.m2_indices = np.ascontiguousarray(tmp.indices, dtype=np.int32)
+        call.m2_indptr = np.ascontiguousarray(tmp.indptr, dtype=np.int32)
+    return call
+
+
+def _rows_sorted(indices: np.ndarray, indptr: np.ndarray) -> bool:
+    if indices.shape[0] < 2:
+        return True
+    bad = indices[1:] <= indices[:-1]          # also flags duplicates: harmless, just a re-sort
+    if not bad.any():
+        return True
+    # a descent is only legal exactly at a row boundary
+    starts = np.zeros(indices.shape[0], dtype=bool)
+    s = indptr[1:-1]
+    starts[s[s < indices.shape[0]]] = True
+    return not np.any(bad & ~starts[1:])
+
+
+def selected_device() -> int:
+    return int(os.environ.get("SIMILARIPY_AMD_DEVICE", "0"))
+
+
+def run_hip(call: KernelCall, device: Optional[int] = None, table_slots: int = 0, threads_per_wg: int = 0,
+            num_wgs: int = 0, load_pct: int = 0, time_kernel: bool = False, static_sched: bool = False):
+    """The `with nogil:` block of s_plus.pyx:359-384, on the GPU: host buffers in, host buffers out
+    through the C ABI (include/sp_knn.h).  Returns rows, cols, values, counts[, info]."""
+    _abi.require_device()
+    n, k = call.n_targets, call.k
+    rows = np.empty(n * k, dtype=np.int32)
+    cols = np.empty(n * k, dtype=np.int32)
+    values = np.empty(n * k, dtype=np.float32)
+    counts = np.empty(n, dtype=np.int32)
+
+    a = _abi.SpKnnArgs()
+    a.flags = (_abi.SP_FLAG_TIME_KERNEL if time_kernel else 0) | (_abi.SP_FLAG_STATIC_SCHED if static_sched else 0)
+    a.on_device = 0
+    a.device = selected_device() if device is None else int(device)
+    a.n_targets, a.n_rows_m1, a.n_rows_m2, a.n_output_cols = n, call.n_rows_m1, call.n_rows_m2, call.n_output_cols
+    a.nnz_m1, a.nnz_m2 = int(call.m1_data.shape[0]), int(call.m2_data.shape[0])
+    keep = []  # keep converted arrays alive across the call
+
+    def f32(x):
+        x = _abi.as_f32(x); keep.append(x); return x.ctypes.data if x.size else None
+
+    def i32(x):
+        x = _abi.as_i32(x); keep.append(x); return x.ctypes.data if x.size else None
+
+    a.targets = i32(call.targets)
+    a.m1_data, a.m1_indices, a.m1_indptr = f32(call.m1_data), i32(call.m1_indices), i32(call.m1_indptr)
+    a.m2_data, a.m2_indices, a.m2_indptr = f32(call.m2_data), i32(call.m2_indices), i32(call.m2_indptr)
+    a.Xtversky, a.Ytversky = f32(call.Xtversky), f32(call.Ytversky)
+    a.Xcosine, a.Ycosine = f32(call.Xcosine), f32(call.Ycosine)
+    a.Xdepop, a.Ydepop = f32(call.Xdepop), f32(call.Ydepop)
+    a.a1, a.l1, a.l2, a.l3, a.t1, a.t2 = call.a1, call.l1, call.l2, call.l3, call.t1, call.t2
+    a.stabilized_shrink, a.bayesian_shrink, a.threshold = call.stabilized_shrink, call.bayesian_shrink, call.threshold
+    a.k = k
+    a.filter_mode = call.filter_mode
+    a.filter_m_indptr, a.filter_m_indices = i32(call.filter_m_indptr), i32(call.filter_m_indices)
+    a.filter_nnz = int(call.filter_m_indices.shape[0])
+    a.target_col_mode = call.target_col_mode
+    a.target_col_m_indptr, a.target_col_m_indices = i32(call.target_col_m_indptr), i32(call.target_col_m_indices)
+    a.target_col_nnz = int(call.target_col_m_indices.shape[0])
+    a.rows, a.cols, a.values, a.out_counts = rows.ctypes.data, cols.ctypes.data, values.ctypes.data, counts.ctypes.data
+    a.table_slots, a.threads_per_wg, a.num_wgs, a.load_pct = table_slots, threads_per_wg, num_wgs, load_pct
+    if n > 0:
+        _abi.call_knn(a)
+    if time_kernel:
+        return rows, cols, values, counts, {"kernel_ms": float(a.kernel_ms), "passes_total": int(a.passes_total)}
+    return rows, cols, values, counts
+
+
+def finish(call: KernelCall, rows, cols, values, counts, format_output: str):
+    """Everything after the kernel in s_plus.pyx:386-433."""
+    if format_output == 'coo':
+        return build_coo(rows, cols, values, call.n_rows_m1, call.n_output_cols)
+    return build_csr(call.targets, cols, values, counts, call.k, call.n_rows_m1, call.n_output_cols)
+
+
+def s_plus(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_matrix2='none',
+           p1=0.0, p2=0.0, a1=1.0, l1=0.0, l2=0.0, l3=0.0, t1=1.0, t2=1.0, c1=0.5, c2=0.5, k=100,
+           stabilized_shrink=0.0, bayesian_shrink=0.0, additive_shrink=0.0, threshold=0.0,
+           binary=False, target_rows=None, filter_cols=None, target_cols=None,
+           verbose=True, format_output='csr', num_threads=0, block_size=0):
+    """Top-K similarity between the rows of two sparse matrices — same signature, defaults and
+    result as ``similaripy.cython_code.s_plus.s_plus`` (s_plus.pyx:95-123), computed on the GPU.
+
+    ``num_threads`` and ``block_size`` are CPU tuning knobs of the reference; they are accepted
+    and ignored (they never change the result).
+    """
+    _say(verbose if isinstance(verbose, bool) else False, "Preprocessing")
+    call = prepare(matrix1, matrix2, weight_depop_matrix1, weight_depop_matrix2, p1, p2, a1, l1, l2, l3,
+                   t1, t2, c1, c2, k, stabilized_shrink, bayesian_shrink, additive_shrink, threshold,
+                   binary, target_rows, filter_cols, target_cols, verbose, format_output)
+    _say(verbose, "Computing")
+    rows, cols, values, counts = run_hip(call)
+    _say(verbose, f"Building {format_output} matrix")
+    res = finish(call, rows, cols, values, counts, format_output)
+    _say(verbose, "Done")
+    return res

@@ -1,0 +1,99 @@
+"""Shared fixtures.
+
+Markers
+-------
+gpu   the test needs a real MI355X: it goes through libsimilaripy_hip.so (HIP kernels).
+      Everything else runs on CPU: oracle vs golden vectors, host logic, ABI loading, gloo.
+
+The oracle (oracle/) is the checker in both tiers; it is never what is being shipped.
+"""
+from __future__ import annotations
+
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+ROOT = Path(__file__).resolve().parent.parent
+GOLDEN_DIR = ROOT / "tests" / "golden"
+for p in (str(ROOT), str(GOLDEN_DIR)):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs an AMD GPU (gfx950); runs the HIP kernels through the C ABI")
+
+
+def _has_gpu() -> bool:
+    try:
+        from similaripy_amd import _abi
+        return _abi.device_count() > 0
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def has_gpu() -> bool:
+    return _has_gpu()
+
+
+def pytest_collection_modifyitems(config, items):
+    # `-m gpu` on a box without a GPU must fail loudly, not skip silently: leave the tests alone.
+    # A plain `pytest tests/` run on the CPU container skips them.
+    if config.getoption("-m"):
+        return
+    if _has_gpu():
+        return
+    skip = pytest.mark.skip(reason="no HIP device (run with -m gpu on an MI355X)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+class Golden:
+    def __init__(self):
+        self.z = np.load(GOLDEN_DIR / "splus_golden.npz")
+        self.manifest = json.loads((GOLDEN_DIR / "splus_golden_manifest.json").read_text())
+        self.entries = {e["name"]: e for e in self.manifest["cases"]}
+        self.inputs = {}
+        names = sorted({k.split("/")[1] for k in self.z.files if k.startswith("in/")})
+        for n in names:
+            if f"in/{n}/array" in self.z.files:
+                self.inputs[n] = self.z[f"in/{n}/array"]
+            else:
+                shape = tuple(int(x) for x in self.z[f"in/{n}/shape"])
+                self.inputs[n] = sp.csr_array(
+                    (self.z[f"in/{n}/data"], self.z[f"in/{n}/indices"], self.z[f"in/{n}/indptr"]), shape=shape)
+
+    def expected(self, name):
+        """canonical per-slot list [(cols, vals)] of a COO case, plus counts."""
+        counts = self.z[f"out/{name}/counts"]
+        cols, vals = self.z[f"out/{name}/cols"], self.z[f"out/{name}/vals"]
+        off = np.concatenate(([0], np.cumsum(counts)))
+        return [(cols[off[i]:off[i + 1]], vals[off[i]:off[i + 1]]) for i in range(counts.shape[0])], counts
+
+
+@pytest.fixture(scope="session")
+def golden() -> Golden:
+    return Golden()
+
+
+@pytest.fixture()
+def oracle_backend(monkeypatch):
+    """Route similaripy_amd's kernel call to the CPU oracle port — CPU-tier tests only, to pin the
+    HOST logic (wrappers, preprocessing, output assembly) against the reference's golden vectors.
+    The product never does this."""
+    from oracle import splus_oracle as so
+    from similaripy_amd import _host
+
+    def run(call, *a, **kw):
+        rows, cols, values = so.run_kernel(call, "port")
+        counts, _ = so.slot_counts(rows, cols, values, call.targets, call.k) if call.n_targets else (np.zeros(0, np.int32), None)
+        return rows, cols, values, counts
+
+    monkeypatch.setattr(_host, "run_hip", run)
+    return run
