@@ -1,0 +1,248 @@
+"""GPU tier: the HIP kernels, called through the C ABI, against the oracle and the golden vectors.
+
+Bar (BASELINE.json north_star): identical top-k index sets wherever values are not tied at the
+k-th place, float32 values within 1e-5 relative.  Accumulation order differs from the CPU
+(LDS atomics), so comparisons are tie-aware (oracle.splus_oracle.compare_topk).
+"""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import cases as C
+import similaripy_amd as sim
+from oracle import splus_oracle as so
+from similaripy_amd import _abi, _host
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5   # north_star: float32 values within 1e-5 relative
+ATOL = 1e-7
+
+
+def _rand(shape, density, seed, dtype=np.float32):
+    return sp.random_array(shape, density=density, format="csr", dtype=dtype,
+                           random_state=np.random.default_rng(seed))
+
+
+def _check(call, what, **tuning):
+    rows, cols, vals, counts = _host.run_hip(call, **tuning)
+    k = call.k
+    got = so.canonical(rows, cols, vals, call.targets, k)
+    want_raw = so.run_kernel(call, "port")
+    want = so.canonical(*want_raw, call.targets, k)
+    # counts returned by the kernel == entries actually written
+    for i, (gc, _) in enumerate(got):
+        # a genuine (0, 0, 0.0) entry in a slot of target 0 is indistinguishable from padding
+        assert counts[i] >= gc.shape[0]
+    so.compare_topk(got, want, k, rtol=RTOL, atol=ATOL, what=what)
+    # padding: tail of every slot is (0,0,0.0)
+    n = call.n_targets
+    r, c, v = rows.reshape(n, k), cols.reshape(n, k), vals.reshape(n, k)
+    pad = np.arange(k)[None, :] >= counts[:, None]
+    assert not r[pad].any() and not c[pad].any() and not v[pad].any(), f"{what}: padding not zero"
+    assert np.all(r[~pad] == np.broadcast_to(call.targets[:, None], r.shape)[~pad]), f"{what}: rows != target"
+    return counts
+
+
+def test_device_visible():
+    assert _abi.device_count() >= 1
+    info = _abi.backend_info(0)
+    assert "gfx950" in info, info
+
+
+ALL_CASES = C.build_cases()
+
+
+@pytest.mark.parametrize("case", ALL_CASES, ids=[c["name"] for c in ALL_CASES])
+def test_golden_cases_through_wrappers(case, golden):
+    """Every golden vector of the reference, through the public API on the GPU."""
+    m1, kw = C.call_kwargs(case, golden.inputs)
+    entry = golden.entries[case["name"]]
+    res = getattr(sim, case["fn"])(m1, **kw)
+    assert res.dtype == np.float32 and list(res.shape) == entry["shape"]
+    k = entry["k_eff"]
+    name = case["name"]
+    if entry["format"] == "coo":
+        assert isinstance(res, sp.coo_array) and res.nnz == entry["stored_nnz"]
+        targets = np.asarray(kw.get("target_rows", np.arange(m1.shape[0])), dtype=np.int32)
+        rows, cols, vals = res.row.astype(np.int32), res.col.astype(np.int32), res.data.astype(np.float32)
+        got = so.canonical(rows, cols, vals, targets, k)
+        want, want_counts = golden.expected(name)
+        np.testing.assert_array_equal(so.slot_counts(rows, cols, vals, targets, k)[0], want_counts)
+        so.compare_topk(got, want, k, rtol=RTOL, atol=ATOL, what=name)
+    else:
+        assert isinstance(res, sp.csr_array)
+        r = res.copy()
+        r.sort_indices()
+        np.testing.assert_array_equal(r.indptr, golden.z[f"out/{name}/indptr"])
+        np.testing.assert_array_equal(r.indices, golden.z[f"out/{name}/cols"])
+        np.testing.assert_allclose(r.data, golden.z[f"out/{name}/vals"], rtol=RTOL)
+
+
+KERNEL_PARAMS = [
+    ("dot", {}),
+    ("cosine", dict(l2=1)),
+    ("asym", dict(l2=1, c1=0.2, c2=0.8)),
+    ("tversky", dict(l1=1, t1=0.8, t2=0.4)),
+    ("splus", dict(l1=0.5, l2=0.5, l3=1, weight_depop_matrix2="sum", stabilized_shrink=10)),
+    ("pow_bayes", dict(l2=1, a1=0.7, bayesian_shrink=3)),
+    ("thr", dict(l2=1, threshold=0.08)),
+]
+
+
+@pytest.mark.parametrize("name,kw", KERNEL_PARAMS, ids=[p[0] for p in KERNEL_PARAMS])
+def test_kernel_vs_oracle_single_window(name, kw):
+    """n_output_cols <= accumulator tile: one direct-indexed window (reference's unblocked path)."""
+    m = _rand((1500, 900), 0.03, 5)
+    _check(_host.prepare(m, k=40, **kw), name)
+
+
+@pytest.mark.parametrize("threads", [256, 512, 1024])
+def test_kernel_workgroup_sizes(threads):
+    m = _rand((800, 600), 0.04, 6)
+    _check(_host.prepare(m, k=30, l2=1), f"threads={threads}", threads_per_wg=threads)
+
+
+@pytest.mark.parametrize("name,kw", KERNEL_PARAMS[:5], ids=[p[0] for p in KERNEL_PARAMS[:5]])
+def test_kernel_vs_oracle_dense_windows(name, kw):
+    """n_output_cols > tile, heavy rows: several direct-indexed column windows with the top-k state
+    carried across them (the reference's blocked path, s_plus.h:350-410)."""
+    m = _rand((5000, 400), 0.1, 7)          # m2 = m.T: 400 x 5000, every row sees ~5000 candidates
+    _check(_host.prepare(m, k=64, **kw), name, table_slots=1024)
+
+
+@pytest.mark.parametrize("name,kw", KERNEL_PARAMS[:5], ids=[p[0] for p in KERNEL_PARAMS[:5]])
+def test_kernel_vs_oracle_hash_windows(name, kw):
+    """n_output_cols >> tile, light rows: hashed accumulator, single and multiple windows."""
+    m = _rand((30000, 2000), 0.004, 8)      # ~8 nnz/row, m2 rows ~120 nnz -> ~1k candidates of 30k cols
+    call = _host.prepare(m, k=50, target_rows=np.arange(0, 30000, 7), **kw)
+    _check(call, name + "/T4096", table_slots=4096)       # mostly one hash window
+    _check(call, name + "/T1024", table_slots=1024)       # several hash windows
+
+
+def test_hash_overflow_retry():
+    """Candidates concentrated in a narrow column range defeat the MACs-based window estimate: the
+    hashed window overflows its probe budget, is discarded, halved and retried (several times, down
+    to a direct-indexed window).  Results must not change."""
+    rng = np.random.default_rng(9)
+    top = sp.random_array((8000, 200), density=0.1, format="csr", dtype=np.float32, random_state=rng)
+    m = sp.vstack([top, sp.csr_array((192000, 200), dtype=np.float32)]).tocsr()   # m2 = m.T: cols < 8000 only
+    targets = np.concatenate([np.arange(0, 8000, 400), [8000, 150000, 199999]]).astype(np.int32)
+    call = _host.prepare(m, k=40, l2=1, target_rows=targets)
+    assert call.n_output_cols == 200000
+    _check(call, "overflow T1024", table_slots=1024)
+    _check(call, "overflow T4096/90%", table_slots=4096, load_pct=90)
+    _check(call, "overflow default")
+
+
+def test_large_k_candidate_buffers():
+    """k == n_cols keeps every candidate; k too large for LDS moves the candidate buffer to global
+    scratch (and still has to select when candidates > k)."""
+    m = _rand((600, 400), 0.2, 10)
+    call = _host.prepare(m, k=4000, l2=1)     # clamped to 600 by prepare (s_plus.pyx:187-188)
+    assert call.k == 600
+    _check(call, "k=ncols")
+    m = _rand((9000, 300), 0.1, 11)           # ~27k MACs/row, ~8.5k distinct candidates
+    _check(_host.prepare(m, k=5000, target_rows=[0, 17, 8999, 4000]), "k=5000 global buffer")
+    _check(_host.prepare(m, k=3000, l2=1, target_rows=[1, 2, 3]), "k=3000")
+
+
+def test_matrix_selectors_and_target_rows():
+    urm = _rand((300, 1500), 0.03, 1)
+    w = _rand((1500, 1500), 0.2, 2)
+    for kw in (dict(filter_cols=urm), dict(target_cols=urm), dict(filter_cols=urm, target_rows=[5, 3, 100, 299, 0]),
+               dict(filter_cols=urm, target_cols=list(range(0, 1500, 3)))):
+        _check(_host.prepare(urm, w, k=25, **kw), f"selectors {sorted(kw)}")
+        _check(_host.prepare(urm, w, k=25, **kw), f"selectors windows {sorted(kw)}", table_slots=1024, threads_per_wg=256)
+
+
+def test_empty_and_ragged_inputs():
+    m = _rand((500, 300), 0.02, 12).tolil()
+    m[[0, 1, 250, 499], :] = 0                # empty rows, incl. first and last
+    m[:, [0, 299]] = 0                        # empty columns
+    m = sp.csr_array(m.tocsr())
+    counts = _check(_host.prepare(m, k=20, l2=1), "ragged")
+    assert counts[0] == 0 and counts[499] == 0
+    # one very long row among short ones
+    dense_row = sp.csr_array(np.random.default_rng(3).random((1, 300), dtype=np.float32))
+    m2 = sp.vstack([m, dense_row]).tocsr()
+    _check(_host.prepare(m2, k=20, l1=1), "one dense row")
+    # all-empty matrix
+    z = sp.csr_array((50, 40), dtype=np.float32)
+    res = sim.cosine(z, k=5, verbose=False)
+    assert res.nnz == 50 * 5 and not res.data.any()
+    # no target rows
+    res = sim.cosine(m, k=5, target_rows=[], verbose=False, format_output="csr")
+    assert res.nnz == 0 and res.shape == (500, 500)
+
+
+def test_negative_values_and_threshold():
+    m = _rand((800, 500), 0.04, 13)
+    m.data = (m.data - 0.5).astype(np.float32)
+    _check(_host.prepare(m, k=30, threshold=-0.2), "negative threshold")
+    _check(_host.prepare(m, k=30, threshold=0.0), "threshold 0 on signed data")
+    _check(_host.prepare(m, k=30, l2=1, threshold=-1.0), "cosine signed")
+
+
+def test_run_to_run_value_stability():
+    """Atomic accumulation order may vary; values must stay within the parity tolerance and the
+    kept sets identical away from ties."""
+    m = _rand((2000, 1500), 0.02, 14)
+    call = _host.prepare(m, k=50, l2=1)
+    a = _host.run_hip(call)
+    b = _host.run_hip(call)
+    so.compare_topk(so.canonical(*a[:3], call.targets, 50), so.canonical(*b[:3], call.targets, 50), 50,
+                    rtol=RTOL, atol=ATOL, what="rerun")
+
+
+def test_scheduling_modes_agree():
+    m = _rand((3000, 800), 0.02, 15)
+    call = _host.prepare(m, k=20, l2=1)
+    a = _host.run_hip(call, static_sched=True, num_wgs=37)
+    b = _host.run_hip(call, static_sched=False)
+    so.compare_topk(so.canonical(*a[:3], call.targets, 20), so.canonical(*b[:3], call.targets, 20), 20,
+                    rtol=RTOL, atol=ATOL, what="sched")
+
+
+def test_reference_check_sum_suite():
+    """The reference's own comparator (tests/test_similarity.py:8-14 check_sum, :289-300) at its
+    own size, against the float64 dense definition."""
+    m = _rand((1000, 800), 0.025, 42)
+    k = 50
+
+    def check_sum(x):
+        return float(np.sum(np.power(np.asarray(x.sum(axis=1)).ravel().astype(np.float64), 2)))
+
+    def dense_sum(S, mask):
+        tot = 0.0
+        for cols, vals in so.dense_topk(S, mask, k):
+            tot += float(vals.astype(np.float64).sum()) ** 2
+        return tot
+
+    pop = np.asarray(m.sum(axis=1)).ravel()
+    table = [
+        (sim.dot_product(m, k=k, verbose=False), so.dense_similarity(m)),
+        (sim.cosine(m, k=k, verbose=False), so.dense_similarity(m, l2=1)),
+        (sim.asymmetric_cosine(m, alpha=0.2, k=k, verbose=False), so.dense_similarity(m, l2=1, c1=0.2, c2=0.8)),
+        (sim.jaccard(m, k=k, verbose=False), so.dense_similarity(m, l1=1)),
+        (sim.dice(m, k=k, verbose=False), so.dense_similarity(m, l1=1, t1=0.5, t2=0.5)),
+        (sim.tversky(m, alpha=0.8, beta=0.4, k=k, verbose=False), so.dense_similarity(m, l1=1, t1=0.8, t2=0.4)),
+        (sim.s_plus(m, l1=0.5, l2=0.5, l3=1, pop2="sum", k=k, verbose=False),
+         so.dense_similarity(m, l1=0.5, l2=0.5, l3=1, w2=pop, p2=0.0)),
+    ]
+    for got, (S, mask) in table:
+        np.testing.assert_allclose(check_sum(got), dense_sum(S, mask), rtol=1e-4)
+
+
+def test_library_refuses_bad_arguments():
+    m = _rand((50, 40), 0.1, 1)
+    call = _host.prepare(m, k=5)
+    with pytest.raises(_abi.HipLibraryError):
+        _host.run_hip(call, table_slots=1000)      # not a power of two
+    with pytest.raises(_abi.HipLibraryError):
+        _host.run_hip(call, threads_per_wg=128)
+    call.targets = np.array([0, 77], dtype=np.int32)   # out of range row id
+    with pytest.raises(_abi.HipLibraryError):
+        _host.run_hip(call)
