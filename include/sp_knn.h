@@ -113,6 +113,10 @@ typedef struct sp_knn_args {
     /* results */
     float   kernel_ms;         /* OUT when SP_FLAG_TIME_KERNEL */
     int32_t passes_total;      /* OUT (debug, only with SP_FLAG_TIME_KERNEL): accumulate+drain passes summed over rows */
+    int64_t phase_cycles[6];   /* OUT with SP_FLAG_TIME_KERNEL: shader cycles summed over workgroups (lane 0) spent in
+                                  setup / segment search+scan / accumulate / drain / top-k select / output */
+    int32_t num_wgs_used;      /* OUT with SP_FLAG_TIME_KERNEL */
+    int32_t _pad1;
     int64_t reserved[4];
 } sp_knn_args;
 

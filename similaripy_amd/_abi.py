@@ -81,6 +81,9 @@ class SpKnnArgs(C.Structure):
         ("load_pct", C.c_int32),
         ("kernel_ms", C.c_float),
         ("passes_total", C.c_int32),
+        ("phase_cycles", C.c_int64 * 6),
+        ("num_wgs_used", C.c_int32),
+        ("_pad1", C.c_int32),
         ("reserved", C.c_int64 * 4),
     ]
 

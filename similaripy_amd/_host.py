@@ -440,7 +440,7 @@ def run_hip(call: KernelCall, device: Optional[int] = None, table_slots: int = 0
     if n > 0:
         _abi.call_knn(a)
     if time_kernel:
-        return rows, cols, values, counts, {"kernel_ms": float(a.kernel_ms), "passes_total": int(a.passes_total)}
+        return rows, cols, values, counts, {"kernel_ms": float(a.kernel_ms), "passes_total": int(a.passes_total), "phase_cycles": [int(x) for x in a.phase_cycles], "num_wgs": int(a.num_wgs_used), "debug_counters": [int(x) for x in a.reserved]}
     return rows, cols, values, counts
 
 

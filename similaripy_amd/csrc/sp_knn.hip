@@ -11,7 +11,9 @@
 //   * one persistent 64-lane-wave workgroup per CU slot pulls target rows from a queue
 //     (the analogue of `omp for schedule(dynamic)`, s_plus.h:337);
 //   * the per-thread dense `sums[]` array of the reference (n_cols*4 B, cache-hostile) becomes an
-//     LDS-resident accumulator tile of T slots fed with ds_add_f32 / ds_cmpst atomics:
+//     LDS-resident accumulator tile of T 64-bit {column, partial sum} slots updated with
+//     ds_cmpst_rtn_b64 only (measured on gfx950: ds_add_f32 retires 0.33 lanes/clk/CU whatever the
+//     address pattern, compare-and-swap 3-6 lanes/clk — scripts/lds_atomics_bench.hip):
 //       - direct-indexed ("dense") when the current column window is <= T columns,
 //       - open-addressing hash (multiplicative hash, linear probing) otherwise;
 //     rows whose candidates do not fit are processed in several column windows, exactly the
@@ -44,11 +46,17 @@ typedef unsigned long long u64;
 namespace {
 
 constexpr int EMPTY = -1;        // key of a free accumulator slot (column ids are >= 0)
-constexpr int DRAIN_UNROLL = 2;  // slots per thread between two capacity checks of the candidate buffer
+constexpr u64 EMPTY64 = 0xFFFFFFFF00000000ull;   // free slot: key EMPTY, partial sum +0.0f
+constexpr u64 NOSLOT64 = 0xFFFFFFFF7FC0DEADull;  // never stored (EMPTY key with a non-zero sum): a CAS expecting it is a no-op
+// table slots per thread per drain iteration (their Y gathers fly together); 1024-thread workgroups have
+// half the VGPR budget (128), where 8 would spill
+#define DRAIN_UNROLL (NT >= 1024 ? 4 : 8)
+constexpr int ACC_UNROLL = 4;    // m2 elements per lane kept in flight in the accumulate loop
+constexpr int U_SLACK = 1024;    // candidate-buffer entries beyond k (room between two selections)
 constexpr int MAX_PROBE = 128;   // linear-probe budget before a window is declared overflowed
 
 // scalar slots in LDS
-enum { SH_CNT = 0, SH_OVF, SH_SEL, SH_NEED, SH_EQ, SH_CNT2, SH_NEXT, SH_TOTAL, SH_N };
+enum { SH_CNT = 0, SH_OVF, SH_SEL, SH_NEED, SH_EQ, SH_CNT2, SH_NEXT, SH_RETRY, SH_N };
 
 struct KParams {
     int n_targets;
@@ -65,14 +73,21 @@ struct KParams {
     // configuration
     int T;                 // accumulator slots (power of two)
     int logT;
-    int cap;               // candidate buffer capacity (>= k + NT*DRAIN_UNROLL)
+    int cap;               // candidate buffer capacity (> k)
     u64 *gU;               // candidate buffers in global memory (only when they do not fit LDS)
     unsigned int *queue;   // [0] = next slot index (dynamic scheduling), [1] = pass counter (debug)
     const int *order;      // optional: slot visiting order (descending work); NULL = identity
     int hash_fill;         // slots' worth of MACs one hash window may receive (= T * load_pct / 100)
     int static_sched;
     int count_passes;
+    unsigned long long *phase_cycles;  // optional [PH_N]: s_memtime cycles of workgroup lane 0 per phase
+    int dbg;               // ablation bits for profiling only (results are WRONG when non-zero):
+                           // 1 = accumulate: no LDS inserts, 2 = accumulate: no global loads, 4 = drain: no Y gathers
 };
+
+// phases timed by lane 0 of every workgroup when KParams::phase_cycles != NULL
+enum { PH_SETUP = 0, PH_SEGMENTS, PH_ACCUM, PH_DRAIN, PH_SELECT, PH_OUTPUT, PH_N,
+       CT_ROUNDS = PH_N, CT_ITERS, CT_OVF, CT_SWEEPS, CT_N };
 
 // order-preserving float <-> uint map (so radix-select works for negative thresholds too)
 __device__ __forceinline__ unsigned fkey(float f) {
@@ -113,11 +128,13 @@ struct Epi {
     float xtv, xcos, xdep;  // row terms
     const float *Ytv, *Ycos, *Ydep;
     bool any;
-    __device__ __forceinline__ float operator()(int col, float xy) const {
+    // ytv / ycos / ydep: the column terms Ytv[col] / Ycos[col] / Ydep[col], gathered by the caller so
+    // that the loads of several candidates are in flight together (0 where the weight is 0)
+    __device__ __forceinline__ float operator()(float xy, float ytv, float ycos, float ydep) const {
         float vt = 0.f, vc = 0.f, vd = 0.f, val = xy;
-        if (l1 != 0.f) vt = l1 * (t1 * (xtv - xy) + t2 * (Ytv[col] - xy) + xy);
-        if (l2 != 0.f) vc = l2 * (xcos * Ycos[col]);
-        if (l3 != 0.f) vd = l3 * (xdep * Ydep[col]);
+        if (l1 != 0.f) vt = l1 * (t1 * (xtv - xy) + t2 * (ytv - xy) + xy);
+        if (l2 != 0.f) vc = l2 * (xcos * ycos);
+        if (l3 != 0.f) vd = l3 * (xdep * ydep);
         if (a1 != 1.f) xy = powf(xy, a1);
         if (any) {
             float den = vt + vc + vd + stab;
@@ -209,26 +226,32 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
     const int T = p.T;
 
     // ---- LDS carve-up (single dynamic array; everything 8-byte aligned) ----
-    int *keys = (int *)smem;                    // [T]
-    float *vals = (float *)(keys + T);          // [T]
-    int *seg_lo = (int *)(vals + T);            // [NT]   start of the window's slice of m2 row u
+    u64 *tab = (u64 *)smem;                     // [T]  {column id : partial dot product}
+    int *seg_lo = (int *)(tab + T);             // [NT]   start of the window's slice of m2 row u
     int *seg_pre = seg_lo + NT;                 // [NT+64] exclusive prefix of slice lengths
     float *seg_v1 = (float *)(seg_pre + NT + 64);  // [NT] m1 value of the segment
-    int *hist = (int *)(seg_v1 + NT);           // [256]
+    int *seg_hi = (int *)(seg_v1 + NT);         // [NT]   end of the slice (= start of the next window's)
+    int *hist = seg_hi + NT;                    // [256]
     int *wsum = hist + 256;                     // [64]
     int *sh = wsum + 64;                        // [SH_N .. 16]
     u64 *U = U_LDS ? (u64 *)(sh + 16) : (p.gU + (size_t)blockIdx.x * (size_t)p.cap);
 
-    for (int i = tid; i < T; i += NT) { keys[i] = EMPTY; vals[i] = 0.f; }
+    for (int i = tid; i < T; i += NT) tab[i] = EMPTY64;
     if (tid == 0) {
         sh[SH_CNT] = 0;
         sh[SH_OVF] = 0;
+        sh[SH_RETRY] = 0;
         sh[SH_NEXT] = p.static_sched ? (int)blockIdx.x : (int)atomicAdd(&p.queue[0], 1u);
     }
     __syncthreads();
 
     const bool any_norm = (p.l1 != 0.f || p.l2 != 0.f || p.l3 != 0.f || p.stab != 0.f || p.bayes != 0.f);
     unsigned local_passes = 0;
+    // phase timers (lane 0 only; s_memtime ticks are shader cycles)
+    const bool timing = (p.phase_cycles != nullptr) && tid == 0;
+    u64 ph[CT_N] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    u64 tmark = timing ? (u64)clock64() : 0;
+#define PHASE_END(which) do { if (timing) { const u64 _n = (u64)clock64(); ph[which] += _n - tmark; tmark = _n; } } while (0)
 
     for (;;) {
         const int qi = sh[SH_NEXT];
@@ -267,10 +290,11 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
         u64 macs = 0;
         for (int w = 0; w < NW; ++w) macs += ((u64 *)wsum)[w];
         __syncthreads();
+        PHASE_END(PH_SETUP);
 
         bool have_thr = false;
         unsigned thr_key = 0;
-        int ub = 0;  // upper bound of the candidate count, see drain
+        bool retry_window = false;  // the current window repeats the previous lo (after an overflow)
 
         // ---- choose the column window width ----
         // dense windows can never overflow (one slot per column); hash windows are sized from the
@@ -306,16 +330,23 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
             const unsigned hmask = (unsigned)t_eff - 1u;
 
             // ================= accumulate =================
+            // Window slices chain (hi of window w == lo of window w+1), so when the m1 row fits one
+            // batch the previous slice end is kept in LDS and only one lower_bound per window is run.
+            const bool carry = (n1 <= NT);
             for (int b0 = 0; b0 < n1; b0 += NT) {
                 const int nb = min(NT, n1 - b0);
                 int len = 0;
                 if (tid < nb) {
                     const int u = p.m1_indices[s1 + b0 + tid];
                     int r0 = p.m2_indptr[u], r1 = p.m2_indptr[u + 1];
-                    if (!whole && r0 < r1) {
+                    if (!whole) {
                         // slice of the sorted m2 row inside [wlo, whi)  (s_plus.h:385-394)
-                        r0 = lower_bound_g(p.m2_indices, r0, r1, wlo);
-                        r1 = lower_bound_g(p.m2_indices, r0, r1, whi);
+                        if (wlo != 0) {
+                            if (carry) r0 = retry_window ? seg_lo[tid] : seg_hi[tid];
+                            else r0 = lower_bound_g(p.m2_indices, r0, r1, wlo);
+                        }
+                        if (whi < p.n_cols) r1 = lower_bound_g(p.m2_indices, r0, r1, whi);
+                        if (carry) seg_hi[tid] = r1;
                     }
                     seg_lo[tid] = r0;
                     seg_v1[tid] = p.m1_data[s1 + b0 + tid];
@@ -327,53 +358,125 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
                 int woff = 0, total = 0;
 #pragma unroll
                 for (int w = 0; w < NW; ++w) {
-                    const int s = wsum[w];
-                    if (w < wave) woff += s;
-                    total += s;
+                    const int sw = wsum[w];
+                    if (w < wave) woff += sw;
+                    total += sw;
                 }
                 seg_pre[tid] = woff + incl - len;
                 if (tid == 0) seg_pre[NT] = total;
                 __syncthreads();
+                PHASE_END(PH_SEGMENTS);
 
-                // flat element space [0,total): wave w owns a contiguous, 64-aligned chunk
+                // flat element space [0,total): wave w owns a contiguous, 64-aligned chunk; every lane
+                // keeps ACC_UNROLL coalesced (stride-64) index/value loads in flight
                 const int chunk = ((total + NW * 64 - 1) / (NW * 64)) * 64;
                 const int e0 = wave * chunk;
                 const int e1 = min(e0 + chunk, total);
                 if (e0 < e1) {
-                    // segment of this lane's first element: last s in [0,nb) with seg_pre[s] <= e
                     int e = e0 + lane;
-                    int sl = 0, sr = nb;  // invariant: seg_pre[sl] <= e (seg_pre[0] = 0)
+                    int sl = 0, sr = nb;  // last s in [0,nb) with seg_pre[s] <= e (seg_pre[0] = 0)
                     while (sr - sl > 1) {
                         const int mid = (sl + sr) >> 1;
                         if (seg_pre[mid] <= e) sl = mid; else sr = mid;
                     }
                     int seg = sl;
-                    for (; e < e1; e += 64) {
-                        while (seg + 1 < nb && e >= seg_pre[seg + 1]) ++seg;
-                        const int j = seg_lo[seg] + (e - seg_pre[seg]);
-                        const int c = p.m2_indices[j];
-                        const float x = p.m2_data[j] * seg_v1[seg];
-                        if (dense) {
-                            const int s = c - wlo;
-                            keys[s] = c;  // "touched" mark; all writers store the same value
-                            atomicAdd(&vals[s], x);
-                        } else {
-                            unsigned s = ((unsigned)c * 2654435761u) >> hshift;
-                            int probe = 0;
-                            for (; probe < MAX_PROBE; ++probe) {
-                                int cur = ((volatile int *)keys)[s];
-                                if (cur == EMPTY) {
-                                    const int prev = atomicCAS(&keys[s], EMPTY, c);
-                                    cur = (prev == EMPTY) ? c : prev;
-                                }
-                                if (cur == c) { atomicAdd(&vals[s], x); break; }
-                                s = (s + 1) & hmask;
+                    for (; e < e1; e += 64 * ACC_UNROLL) {
+                        int idx[ACC_UNROLL];
+                        float v1[ACC_UNROLL];
+#pragma unroll
+                        for (int j = 0; j < ACC_UNROLL; ++j) {
+                            const int ej = e + 64 * j;
+                            if (ej < e1) {
+                                while (seg + 1 < nb && ej >= seg_pre[seg + 1]) ++seg;
+                                idx[j] = seg_lo[seg] + (ej - seg_pre[seg]);
+                                v1[j] = seg_v1[seg];
+                            } else {
+                                // padding: repeat the lane's first element with weight 0 — it goes through
+                                // the same (branch-free) insert path and adds exactly 0.0 to an existing key
+                                idx[j] = idx[0];
+                                v1[j] = 0.f;
                             }
-                            if (probe == MAX_PROBE) sh[SH_OVF] = 1;
+                        }
+                        int c[ACC_UNROLL];
+                        float x[ACC_UNROLL];
+                        if (p.dbg & 2) {
+#pragma unroll
+                            for (int j = 0; j < ACC_UNROLL; ++j) { c[j] = wlo + (int)(((unsigned)idx[j] * 40503u) % (unsigned)(whi - wlo)); x[j] = 1.f; }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < ACC_UNROLL; ++j) { c[j] = p.m2_indices[idx[j]]; x[j] = p.m2_data[idx[j]]; }
+                        }
+#pragma unroll
+                        for (int j = 0; j < ACC_UNROLL; ++j) x[j] *= v1[j];
+                        if (p.dbg & 1) {
+                            float sink = 0.f;
+#pragma unroll
+                            for (int j = 0; j < ACC_UNROLL; ++j) sink += x[j] + (float)c[j];
+                            if (sink == 123.456f) sh[SH_OVF] = 2;  // keeps the loads alive, never true in practice
+                        } else if (dense) {
+                            // direct-indexed window: every column owns its slot, no claim needed — mark the key
+                            // half (all writers store the same value) and add into the sum half
+#pragma unroll
+                            for (int j = 0; j < ACC_UNROLL; ++j) {
+                                unsigned *slot32 = (unsigned *)&tab[c[j] - wlo];
+                                slot32[1] = (unsigned)c[j];
+                                atomicAdd((float *)slot32, x[j]);
+                            }
+                        } else {
+                            // Hashed window.  One 64-bit compare-and-swap claims a free slot for a new column AND
+                            // deposits its first product; finding the same column already there turns into a
+                            // hardware float add on the sum half (slow on gfx950, 3 clk/lane, but immune to
+                            // contention on hot columns); finding another column means linear probing.
+                            // Round 1 issues the ACC_UNROLL claims back to back; the few leftovers are then walked
+                            // one element per lane per round, so later rounds are sparse instructions.
+                            unsigned hs[ACC_UNROLL];
+                            u64 prev[ACC_UNROLL];
+#pragma unroll
+                            for (int j = 0; j < ACC_UNROLL; ++j) hs[j] = ((unsigned)c[j] * 2654435761u) >> hshift;
+                            if (p.dbg & 32) {   // ablation: collision-free slots (every claim succeeds)
+#pragma unroll
+                                for (int j = 0; j < ACC_UNROLL; ++j) hs[j] = (unsigned)(e + 64 * j) & hmask;
+                            }
+#pragma unroll
+                            for (int j = 0; j < ACC_UNROLL; ++j)
+                                prev[j] = atomicCAS(&tab[hs[j]], EMPTY64, ((u64)(unsigned)c[j] << 32) | (u64)__float_as_uint(x[j]));
+                            unsigned pend = 0;
+#pragma unroll
+                            for (int j = 0; j < ACC_UNROLL; ++j) {
+                                const bool hit = ((int)(prev[j] >> 32) == c[j]);
+                                if (hit && !(p.dbg & 16)) atomicAdd((float *)&tab[hs[j]], x[j]);
+                                if (prev[j] != EMPTY64 && !hit) pend |= 1u << j;
+                            }
+                            if (p.dbg & 8) pend = 0;   // ablation: no probing beyond the home slot
+                            int probes = 1, plen = 0;
+                            while (__ballot(pend != 0)) {   // wave-uniform trip count
+                                ++probes;
+                                if (!pend) continue;
+                                const unsigned bit = pend & (0u - pend);  // this lane's current element
+                                int cc = c[0];
+                                float xx = x[0];
+                                unsigned hh = hs[0];
+#pragma unroll
+                                for (int j = 1; j < ACC_UNROLL; ++j)
+                                    if (bit == (1u << j)) { cc = c[j]; xx = x[j]; hh = hs[j]; }
+                                // double hashing: an odd, key-dependent stride visits every slot of the
+                                // power-of-two table and avoids the long clusters of linear probing
+                                hh = (hh + ((((unsigned)cc * 0x85EBCA6Bu) >> 15) | 1u)) & hmask;
+                                const u64 pv = atomicCAS(&tab[hh], EMPTY64, ((u64)(unsigned)cc << 32) | (u64)__float_as_uint(xx));
+                                const bool hit = ((int)(pv >> 32) == cc);
+                                if (hit) atomicAdd((float *)&tab[hh], xx);
+                                if (pv == EMPTY64 || hit) { pend &= ~bit; plen = 0; }
+                                else if (++plen >= MAX_PROBE) { sh[SH_OVF] = 1; break; }
+#pragma unroll
+                                for (int j = 0; j < ACC_UNROLL; ++j)
+                                    if (bit == (1u << j)) hs[j] = hh;
+                            }
+                            if (timing) { ph[CT_ROUNDS] += probes; ph[CT_ITERS] += 1; }
                         }
                     }
                 }
                 __syncthreads();  // seg_* are rewritten by the next batch
+                PHASE_END(PH_ACCUM);
             }
 
             // ================= overflow: discard the window, halve it, retry =================
@@ -381,72 +484,133 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
                 const int ovf = sh[SH_OVF];
                 __syncthreads();
                 if (ovf) {
-                    for (int i = tid; i < t_eff; i += NT) { keys[i] = EMPTY; vals[i] = 0.f; }
+                    if (timing) ph[CT_OVF] += 1;
+                    for (int i = tid; i < t_eff; i += NT) tab[i] = EMPTY64;
                     if (tid == 0) sh[SH_OVF] = 0;
                     width = max((long long)T, (width + 1) / 2);
+                    retry_window = true;  // same lo again: slice starts are still in seg_lo
                     __syncthreads();
                     continue;
                 }
             }
+            retry_window = false;
             ++local_passes;
 
             // ================= drain: selectors, epilogue, threshold, running top-k =================
-            for (int base = 0; base < t_eff; base += NT * DRAIN_UNROLL) {
-                // `ub` is a register-resident (hence workgroup-uniform) upper bound of SH_CNT; the exact
-                // count is only consulted, between two barriers, when the bound says the buffer may fill.
-                if (ub + NT * DRAIN_UNROLL > p.cap) {
-                    __syncthreads();
-                    const int n_now = sh[SH_CNT];
-                    __syncthreads();
-                    if (n_now + NT * DRAIN_UNROLL > p.cap) {
-                        compact_topk<NT>(U, hist, sh, p.k, have_thr, thr_key);
-                        ub = min(n_now, p.k);
-                    } else {
-                        ub = n_now;
-                    }
-                }
-                ub += NT * DRAIN_UNROLL;
+            // One barrier-free sweep over the table.  Survivors of the running threshold are appended to
+            // U; a survivor that finds U full leaves its slot in place and raises SH_RETRY, after which
+            // the workgroup selects the k best of U (raising the threshold) and sweeps the leftovers.
+            for (;;) {
+                if (timing) ph[CT_SWEEPS] += 1;
+                for (int base = 0; base < t_eff; base += NT * DRAIN_UNROLL) {
+                    int c[DRAIN_UNROLL];
+                    float xy[DRAIN_UNROLL];
+                    unsigned occ = 0, pass = 0;
 #pragma unroll
-                for (int un = 0; un < DRAIN_UNROLL; ++un) {
-                    const int s = base + un * NT + tid;
-                    bool want = false;
-                    u64 item = 0;
-                    if (s < t_eff) {
-                        const int c = keys[s];
-                        if (c != EMPTY) {
-                            const float xy = vals[s];
-                            keys[s] = EMPTY;
-                            vals[s] = 0.f;
-                            bool pass = true;
-                            if (p.filter_mode == SP_SEL_MATRIX) pass = !range_has(p.f_indices, f0, f1, c);
-                            if (pass && p.target_mode == SP_SEL_MATRIX) pass = range_has(p.t_indices, g0, g1, c);
-                            if (pass) {
-                                const float val = epi(c, xy);
-                                if (val >= p.threshold) {
-                                    const unsigned key = fkey(val);
-                                    if (!have_thr || key > thr_key) {
-                                        want = true;
-                                        item = ((u64)key << 32) | (u64)(unsigned)c;
-                                    }
+                    for (int j = 0; j < DRAIN_UNROLL; ++j) {
+                        const int sidx = base + j * NT + tid;
+                        c[j] = EMPTY;
+                        xy[j] = 0.f;
+                        if (sidx < t_eff) {
+                            const u64 slot = tab[sidx];
+                            c[j] = (int)(slot >> 32);
+                            xy[j] = __uint_as_float((unsigned)slot);
+                        }
+                        if (c[j] != EMPTY) occ |= 1u << j;
+                    }
+                    pass = occ;
+                    if (p.filter_mode == SP_SEL_MATRIX) {
+#pragma unroll
+                        for (int j = 0; j < DRAIN_UNROLL; ++j)
+                            if ((pass & (1u << j)) && range_has(p.f_indices, f0, f1, c[j])) pass &= ~(1u << j);
+                    }
+                    if (p.target_mode == SP_SEL_MATRIX) {
+#pragma unroll
+                        for (int j = 0; j < DRAIN_UNROLL; ++j)
+                            if ((pass & (1u << j)) && !range_has(p.t_indices, g0, g1, c[j])) pass &= ~(1u << j);
+                    }
+                    // gather the column terms of all DRAIN_UNROLL slots first (loads in flight together);
+                    // slots that are empty / filtered read column 0 (one hot line)
+                    float ytv[DRAIN_UNROLL], ycos[DRAIN_UNROLL], ydep[DRAIN_UNROLL];
+                    int gc[DRAIN_UNROLL];
+#pragma unroll
+                    for (int j = 0; j < DRAIN_UNROLL; ++j) {
+                        gc[j] = ((pass & (1u << j)) && !(p.dbg & 4)) ? c[j] : 0;
+                        ytv[j] = 0.f; ycos[j] = 0.f; ydep[j] = 0.f;
+                    }
+                    if (p.l1 != 0.f) {
+#pragma unroll
+                        for (int j = 0; j < DRAIN_UNROLL; ++j) ytv[j] = p.Ytv[gc[j]];
+                    }
+                    if (p.l2 != 0.f) {
+#pragma unroll
+                        for (int j = 0; j < DRAIN_UNROLL; ++j) ycos[j] = p.Ycos[gc[j]];
+                    }
+                    if (p.l3 != 0.f) {
+#pragma unroll
+                        for (int j = 0; j < DRAIN_UNROLL; ++j) ydep[j] = p.Ydep[gc[j]];
+                    }
+                    float val[DRAIN_UNROLL];
+#pragma unroll
+                    for (int j = 0; j < DRAIN_UNROLL; ++j) val[j] = epi(xy[j], ytv[j], ycos[j], ydep[j]);
+                    // survivors of (threshold, running k-th value) in this lane's DRAIN_UNROLL slots
+                    unsigned want = 0;
+                    unsigned key[DRAIN_UNROLL];
+#pragma unroll
+                    for (int j = 0; j < DRAIN_UNROLL; ++j) {
+                        key[j] = fkey(val[j]);
+                        if ((pass & (1u << j)) && (val[j] >= p.threshold) && (!have_thr || key[j] > thr_key)) want |= 1u << j;
+                    }
+                    // one aggregated reservation per wave: lane counts -> wave scan -> single LDS atomic
+                    unsigned stored = 0;
+                    if (__ballot(want != 0)) {
+                        const int mine = __popc(want);
+                        const int incl = wave_incl_scan(mine);
+                        int wbase = 0;
+                        if (lane == 63) wbase = atomicAdd(&sh[SH_CNT], incl);
+                        wbase = __shfl(wbase, 63, 64);
+                        int pos = wbase + incl - mine;
+#pragma unroll
+                        for (int j = 0; j < DRAIN_UNROLL; ++j) {
+                            if (want & (1u << j)) {
+                                if (pos < p.cap) {
+                                    U[pos] = ((u64)key[j] << 32) | (u64)(unsigned)c[j];
+                                    stored |= 1u << j;
+                                } else {
+                                    sh[SH_RETRY] = 1;  // U is full: keep the slot for the sweep after the selection
                                 }
+                                ++pos;
                             }
                         }
                     }
-                    const u64 m = __ballot(want);
-                    if (m) {
-                        int wbase = 0;
-                        if (lane == 0) wbase = atomicAdd(&sh[SH_CNT], __popcll(m));
-                        wbase = __shfl(wbase, 0, 64);
-                        if (want) U[wbase + __popcll(m & ((1ull << lane) - 1ull))] = item;
-                    }
+                    // free every visited slot except survivors that found U full
+                    const unsigned clear = occ & (~want | stored);
+#pragma unroll
+                    for (int j = 0; j < DRAIN_UNROLL; ++j)
+                        if (clear & (1u << j)) tab[base + j * NT + tid] = EMPTY64;
                 }
+                __syncthreads();  // sweep complete (also orders the slot clears before the next window)
+                const int retry = sh[SH_RETRY];
+                if (!retry) break;  // uniform
+                __syncthreads();    // everyone has seen the flag
+                if (tid == 0) {
+                    sh[SH_RETRY] = 0;
+                    if (sh[SH_CNT] > p.cap) sh[SH_CNT] = p.cap;  // failed appends over-counted
+                }
+                __syncthreads();
+                PHASE_END(PH_DRAIN);
+                compact_topk<NT>(U, hist, sh, p.k, have_thr, thr_key);
+                PHASE_END(PH_SELECT);
             }
+            PHASE_END(PH_DRAIN);
             lo = hi;
         }
 
         // ================= final selection + write-out =================
         __syncthreads();
+        PHASE_END(PH_DRAIN);
         if (sh[SH_CNT] > p.k) compact_topk<NT>(U, hist, sh, p.k, have_thr, thr_key);
+        PHASE_END(PH_SELECT);
         const int n_out = sh[SH_CNT];
         const long long o = (long long)slot_i * (long long)p.k;
         for (int j = tid; j < p.k; j += NT) {
@@ -469,8 +633,14 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
         __syncthreads();
         if (tid == 0) sh[SH_CNT] = 0;
         __syncthreads();
+        PHASE_END(PH_OUTPUT);
     }
     if (p.count_passes && tid == 0 && local_passes) atomicAdd(&p.queue[1], local_passes);
+    if (timing) {
+#pragma unroll
+        for (int i = 0; i < CT_N; ++i) atomicAdd(&p.phase_cycles[i], ph[i]);
+    }
+#undef PHASE_END
 }
 
 // Work-sorted visiting order: key = MACs(t) clamped to 32 bits, computed per slot.
@@ -527,8 +697,8 @@ constexpr size_t WS_QUEUE_BYTES = 256;
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
 size_t lds_fixed_bytes(int T, int NT) {
-    // keys + vals + seg_lo + seg_pre(+64) + seg_v1 + hist + wsum + sh
-    return (size_t)T * 8 + (size_t)NT * 4 + (size_t)(NT + 64) * 4 + (size_t)NT * 4 + 256 * 4 + 64 * 4 + 16 * 4;
+    // keys + vals + seg_lo + seg_pre(+64) + seg_v1 + seg_hi + hist + wsum + sh
+    return (size_t)T * 8 + (size_t)NT * 4 + (size_t)(NT + 64) * 4 + (size_t)NT * 4 + (size_t)NT * 4 + 256 * 4 + 64 * 4 + 16 * 4;
 }
 
 int make_config(const sp_knn_args *a, int n_cus, Config *c) {
@@ -540,7 +710,7 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
     while ((1 << logT) < T) ++logT;
     const int load = a->load_pct > 0 ? std::min(a->load_pct, 90) : 50;
 
-    const long long need_cap = (long long)a->k + (long long)NT * DRAIN_UNROLL;
+    const long long need_cap = (long long)a->k + U_SLACK;
     size_t fixed = lds_fixed_bytes(T, NT);
     if (fixed + 8 * 1024 > LDS_LIMIT) return fail(SP_EINVAL, "table_slots=%d does not fit the 160 KiB LDS", T);
     // candidate buffer: LDS if (k + NT*UNROLL) entries fit beside the table, else global scratch
@@ -663,6 +833,8 @@ int run_device(sp_knn_args *a) {
     kp.hash_fill = c.hash_fill;
     kp.static_sched = (a->flags & SP_FLAG_STATIC_SCHED) ? 1 : 0;
     kp.count_passes = timed ? 1 : 0;
+    kp.phase_cycles = timed ? (unsigned long long *)(ws + 64) : nullptr;   // inside the zeroed queue block
+    kp.dbg = (int)a->reserved[0];
 
     if (c.NT == 256) rc = c.u_lds ? launch_rows<256, true>(kp, c, stream) : launch_rows<256, false>(kp, c, stream);
     else if (c.NT == 512) rc = c.u_lds ? launch_rows<512, true>(kp, c, stream) : launch_rows<512, false>(kp, c, stream);
@@ -675,9 +847,13 @@ int run_device(sp_knn_args *a) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
         a->kernel_ms = ms;
-        unsigned q[2] = {0, 0};
-        HIP_TRY(hipMemcpy(q, ws, sizeof(q), hipMemcpyDeviceToHost));
-        a->passes_total = (int32_t)q[1];
+        unsigned char qb[WS_QUEUE_BYTES];
+        HIP_TRY(hipMemcpy(qb, ws, sizeof(qb), hipMemcpyDeviceToHost));
+        a->passes_total = (int32_t)((unsigned *)qb)[1];
+        const unsigned long long *phc = (const unsigned long long *)(qb + 64);
+        for (int i = 0; i < PH_N && i < 6; ++i) a->phase_cycles[i] = (int64_t)phc[i];
+        for (int i = 0; i < 4; ++i) a->reserved[i] = (int64_t)phc[PH_N + i];   // debug counters: probe rounds, iterations, overflows, sweeps
+        a->num_wgs_used = c.num_wgs;
         (void)hipEventDestroy(ev0);
         (void)hipEventDestroy(ev1);
     }

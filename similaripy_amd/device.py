@@ -74,6 +74,7 @@ class DeviceProblem:
         a.threads_per_wg = int(tuning.get("threads_per_wg", 0))
         a.num_wgs = int(tuning.get("num_wgs", 0))
         a.load_pct = int(tuning.get("load_pct", 0))
+        a.reserved[0] = int(tuning.get("dbg", 0))      # profiling ablations only
         return a
 
     def alloc_outputs(self, n_targets: Optional[int] = None, with_rows: bool = False):
@@ -104,4 +105,4 @@ class DeviceProblem:
                 self._ws = torch.empty(max(need, 4096), dtype=torch.uint8, device=self.device)
             a.workspace, a.workspace_bytes = self._ws.data_ptr(), self._ws.numel()
             _abi.call_knn(a)
-        return {"kernel_ms": float(a.kernel_ms), "passes_total": int(a.passes_total)}
+        return {"kernel_ms": float(a.kernel_ms), "passes_total": int(a.passes_total), "phase_cycles": [int(x) for x in a.phase_cycles], "num_wgs": int(a.num_wgs_used), "debug_counters": [int(x) for x in a.reserved]}
