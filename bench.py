@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--num-wgs", type=int, default=0)
     ap.add_argument("--load-pct", type=int, default=0)
     ap.add_argument("--static-sched", action="store_true")
+    ap.add_argument("--no-sparse-path", action="store_true", help="force the generic windowed path (A/B)")
     ap.add_argument("--dbg", type=int, default=0, help="kernel ablation bits (profiling only; results invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -133,7 +134,8 @@ def main():
 
     prob = DeviceProblem(call, dev)
     cols, vals, counts, _ = prob.alloc_outputs()
-    tuning = dict(table_slots=args.table_slots, threads_per_wg=args.threads, num_wgs=args.num_wgs, load_pct=args.load_pct, dbg=args.dbg)
+    tuning = dict(table_slots=args.table_slots, threads_per_wg=args.threads, num_wgs=args.num_wgs, load_pct=args.load_pct, dbg=args.dbg,
+                  no_sparse_path=args.no_sparse_path)
 
     gathered = None
     if world > 1 and rank == 0:
@@ -229,12 +231,13 @@ def main():
 
 def phase_share(info) -> dict:
     """Share of workgroup-lane-0 shader cycles per kernel phase (in-kernel s_memtime counters)."""
-    names = ("setup", "segments", "accumulate", "drain", "select", "output")
-    cyc = info.get("phase_cycles", [0] * 6)
-    tot = float(sum(cyc)) or 1.0
-    d = {n: round(c / tot, 4) for n, c in zip(names, cyc)}
+    names = ("setup", "segments", "accumulate", "drain", "select", "output", "sweep1", "sweep2", "csdrain")
+    cyc = info.get("phase_cycles", [0] * 12)
+    tot = float(sum(cyc[:9])) or 1.0
+    d = {n: round(c / tot, 4) for n, c in zip(names, cyc[:9])}
     d["cycles_per_wg"] = tot / max(1, info.get("num_wgs", 1))
-    d["dbg_rounds_iters_ovf_sweeps"] = info.get("debug_counters")
+    d["rows_sparse_path"], d["generic_windows"] = cyc[9], cyc[11]
+    d["rows_fallback_cs_full"], d["rows_fallback_u_overflow"] = cyc[10] & 0xFFFFFFFF, cyc[10] >> 32
     return d
 
 

@@ -49,7 +49,8 @@ extern "C" {
 /* flags */
 #define SP_FLAG_TIME_KERNEL   1u  /* bracket device work with hipEvents on `stream`, sync, fill kernel_ms */
 #define SP_FLAG_NO_ROWS_OUT   2u  /* device mode: `rows` may be NULL and is not written */
-#define SP_FLAG_STATIC_SCHED  4u  /* round-robin rows over workgroups instead of the work-sorted atomic queue */
+#define SP_FLAG_STATIC_SCHED  4u  /* round-robin rows over workgroups instead of the atomic row queue */
+#define SP_FLAG_NO_SPARSE_PATH 8u /* never use the bitmap + collision-set path for sparse rows (A/B testing) */
 
 typedef struct sp_knn_args {
     uint32_t struct_size;      /* = sizeof(sp_knn_args); checked */
@@ -113,8 +114,10 @@ typedef struct sp_knn_args {
     /* results */
     float   kernel_ms;         /* OUT when SP_FLAG_TIME_KERNEL */
     int32_t passes_total;      /* OUT (debug, only with SP_FLAG_TIME_KERNEL): accumulate+drain passes summed over rows */
-    int64_t phase_cycles[6];   /* OUT with SP_FLAG_TIME_KERNEL: shader cycles summed over workgroups (lane 0) spent in
-                                  setup / segment search+scan / accumulate / drain / top-k select / output */
+    int64_t phase_cycles[12];  /* OUT with SP_FLAG_TIME_KERNEL: shader cycles summed over workgroups (lane 0) spent in
+                                  setup / segment search+scan / accumulate / drain / top-k select / output /
+                                  sparse sweep 1 / sparse sweep 2 / collision-set drain, then event counts:
+                                  rows on the sparse path / sparse rows that fell back / generic windows */
     int32_t num_wgs_used;      /* OUT with SP_FLAG_TIME_KERNEL */
     int32_t _pad1;
     int64_t reserved[4];

@@ -17,6 +17,7 @@ SP_SEL_NONE, SP_SEL_ARRAY, SP_SEL_MATRIX = 0, 1, 2
 SP_FLAG_TIME_KERNEL = 1
 SP_FLAG_NO_ROWS_OUT = 2
 SP_FLAG_STATIC_SCHED = 4
+SP_FLAG_NO_SPARSE_PATH = 8
 
 _c_f32p = C.POINTER(C.c_float)
 _c_i32p = C.POINTER(C.c_int32)
@@ -81,7 +82,7 @@ class SpKnnArgs(C.Structure):
         ("load_pct", C.c_int32),
         ("kernel_ms", C.c_float),
         ("passes_total", C.c_int32),
-        ("phase_cycles", C.c_int64 * 6),
+        ("phase_cycles", C.c_int64 * 12),
         ("num_wgs_used", C.c_int32),
         ("_pad1", C.c_int32),
         ("reserved", C.c_int64 * 4),

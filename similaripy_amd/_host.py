@@ -396,7 +396,8 @@ def selected_device() -> int:
 
 
 def run_hip(call: KernelCall, device: Optional[int] = None, table_slots: int = 0, threads_per_wg: int = 0,
-            num_wgs: int = 0, load_pct: int = 0, time_kernel: bool = False, static_sched: bool = False):
+            num_wgs: int = 0, load_pct: int = 0, time_kernel: bool = False, static_sched: bool = False,
+            no_sparse_path: bool = False):
     """The `with nogil:` block of s_plus.pyx:359-384, on the GPU: host buffers in, host buffers out
     through the C ABI (include/sp_knn.h).  Returns rows, cols, values, counts[, info]."""
     _abi.require_device()
@@ -407,7 +408,8 @@ def run_hip(call: KernelCall, device: Optional[int] = None, table_slots: int = 0
     counts = np.empty(n, dtype=np.int32)
 
     a = _abi.SpKnnArgs()
-    a.flags = (_abi.SP_FLAG_TIME_KERNEL if time_kernel else 0) | (_abi.SP_FLAG_STATIC_SCHED if static_sched else 0)
+    a.flags = ((_abi.SP_FLAG_TIME_KERNEL if time_kernel else 0) | (_abi.SP_FLAG_STATIC_SCHED if static_sched else 0)
+               | (_abi.SP_FLAG_NO_SPARSE_PATH if no_sparse_path else 0))
     a.on_device = 0
     a.device = selected_device() if device is None else int(device)
     a.n_targets, a.n_rows_m1, a.n_rows_m2, a.n_output_cols = n, call.n_rows_m1, call.n_rows_m2, call.n_output_cols
@@ -440,7 +442,7 @@ def run_hip(call: KernelCall, device: Optional[int] = None, table_slots: int = 0
     if n > 0:
         _abi.call_knn(a)
     if time_kernel:
-        return rows, cols, values, counts, {"kernel_ms": float(a.kernel_ms), "passes_total": int(a.passes_total), "phase_cycles": [int(x) for x in a.phase_cycles], "num_wgs": int(a.num_wgs_used), "debug_counters": [int(x) for x in a.reserved]}
+        return rows, cols, values, counts, {"kernel_ms": float(a.kernel_ms), "passes_total": int(a.passes_total), "phase_cycles": [int(x) for x in a.phase_cycles], "num_wgs": int(a.num_wgs_used)}
     return rows, cols, values, counts
 
 

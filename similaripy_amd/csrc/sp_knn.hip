@@ -8,26 +8,35 @@
 //   keep the k largest val[c] >= threshold that pass the column selectors (s_plus.h:192-215, 39-64)
 //
 // MI355X mapping:
-//   * one persistent 64-lane-wave workgroup per CU slot pulls target rows from a queue
-//     (the analogue of `omp for schedule(dynamic)`, s_plus.h:337);
-//   * the per-thread dense `sums[]` array of the reference (n_cols*4 B, cache-hostile) becomes an
-//     LDS-resident accumulator tile of T 64-bit {column, partial sum} slots updated with
-//     ds_cmpst_rtn_b64 only (measured on gfx950: ds_add_f32 retires 0.33 lanes/clk/CU whatever the
-//     address pattern, compare-and-swap 3-6 lanes/clk — scripts/lds_atomics_bench.hip):
-//       - direct-indexed ("dense") when the current column window is <= T columns,
-//       - open-addressing hash (multiplicative hash, linear probing) otherwise;
-//     rows whose candidates do not fit are processed in several column windows, exactly the
-//     reference's blocked path (s_plus.h:350-410: window = [cb_start, cb_end), sub-range of each
-//     sorted m2 row found by lower_bound), with the top-k state carried across windows;
-//   * m2 rows are streamed with lane-contiguous (coalesced) index/value loads: the nnz1(t)
-//     segments of a window are flattened through an LDS prefix array so all 64 lanes stay busy
-//     whatever the segment lengths;
-//   * the std::push_heap/pop_heap TopK becomes a workgroup-wide selection: survivors of a running
-//     threshold are appended to an LDS candidate buffer and, when it fills, an MSD radix-select
-//     (4 x 8-bit passes over an order-preserving key) keeps exactly k.
+//   * persistent workgroups (one per CU) pull target rows from an atomic queue — the analogue of
+//     `omp for schedule(dynamic)` (s_plus.h:337);
+//   * m2 rows are streamed with lane-contiguous (coalesced) index/value loads: the nnz1(t) row
+//     slices are flattened through an LDS prefix array so all 64 lanes stay busy whatever the slice
+//     lengths, ACC_UNROLL loads per lane in flight;
+//   * the per-thread dense `sums[]` array of the reference (n_cols*4 B, cache-hostile) becomes LDS
+//     state, in one of two shapes chosen per row from MACs(t) = sum_u nnz(m2 row u):
+//       SPARSE rows (few products share a column — the recommender/KNN shape the headline benchmark
+//       has): two sweeps over the row's products.  Sweep 1 sets one hashed bit per column in an LDS
+//       bitmap (ds_or_rtn_b32); a product that finds its bit already set enters its column in a small
+//       bucketed "collision set".  Sweep 2 looks every product up in that set with ONE ds_read_b128:
+//       members accumulate there, every other product is provably the only one of its column and goes
+//       straight to epilogue -> threshold -> top-k buffer.  No column windows, no probing loops.
+//       GENERIC rows: accumulator tile of T 64-bit {column, partial sum} slots, direct-indexed when
+//       the column window is <= T wide, otherwise open addressing (one ds_cmpst_rtn_b64 claims a
+//       slot and deposits the first product); rows whose candidates do not fit are processed in
+//       several column windows, exactly the reference's blocked path (s_plus.h:350-410), top-k state
+//       carried across windows.  A sparse row that overflows its collision set falls back to this.
+//     (measured on gfx950, scripts/lds_atomics_bench.hip: ds_add_f32 retires 0.33 lanes/clk/CU whatever
+//      the address pattern, ds_cmpst_rtn_b64 3.3, ds_or/add_rtn_u32 ~10 — hence no float atomics on
+//      the common path);
+//   * candidates are pruned before any gather of the column terms Y*[c] by an upper bound of the
+//     epilogue computed from per-launch minima of the Y vectors;
+//   * the std::push_heap/pop_heap TopK becomes a workgroup-wide selection: survivors of the running
+//     k-th value are appended to an LDS buffer and, when it fills, an MSD radix-select (4 x 8 bit over
+//     an order-preserving key) keeps exactly k.
 // HBM-bound integer/float streaming work: no MFMA on purpose.
 //
-// Everything below is written for gfx950 only (wave64, 160 KiB LDS, ds_add_f32).
+// Everything below is written for gfx950 only (wave64, 160 KiB LDS).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -45,18 +54,22 @@ typedef unsigned long long u64;
 // ---------------------------------------------------------------------------------------------
 namespace {
 
-constexpr int EMPTY = -1;        // key of a free accumulator slot (column ids are >= 0)
-constexpr u64 EMPTY64 = 0xFFFFFFFF00000000ull;   // free slot: key EMPTY, partial sum +0.0f
-constexpr u64 NOSLOT64 = 0xFFFFFFFF7FC0DEADull;  // never stored (EMPTY key with a non-zero sum): a CAS expecting it is a no-op
+constexpr int EMPTY = -1;                        // key of a free slot (column ids are >= 0)
+constexpr u64 EMPTY64 = 0xFFFFFFFF00000000ull;   // free accumulator slot: key EMPTY, partial sum +0.0f
+constexpr int MAX_PROBE = 128;   // probe budget of one element before a hashed window is declared overflowed
+constexpr int ACC_UNROLL = 4;    // m2 elements per lane kept in flight
+constexpr int U_SLACK = 1024;    // candidate-buffer entries beyond k (room between two selections)
+constexpr int CS_TRIES = 8;      // buckets searched in the collision set before giving up (-> generic path)
 // table slots per thread per drain iteration (their Y gathers fly together); 1024-thread workgroups have
 // half the VGPR budget (128), where 8 would spill
 #define DRAIN_UNROLL (NT >= 1024 ? 4 : 8)
-constexpr int ACC_UNROLL = 4;    // m2 elements per lane kept in flight in the accumulate loop
-constexpr int U_SLACK = 1024;    // candidate-buffer entries beyond k (room between two selections)
-constexpr int MAX_PROBE = 128;   // linear-probe budget before a window is declared overflowed
 
 // scalar slots in LDS
 enum { SH_CNT = 0, SH_OVF, SH_SEL, SH_NEED, SH_EQ, SH_CNT2, SH_NEXT, SH_RETRY, SH_N };
+
+// phases timed by lane 0 of every workgroup when KParams::phase_cycles != NULL, then event counters
+enum { PH_SETUP = 0, PH_SEGMENTS, PH_ACCUM, PH_DRAIN, PH_SELECT, PH_OUTPUT, PH_SWEEP1, PH_SWEEP2, PH_CSDRAIN,
+       CT_ROWS_SPARSE, CT_ROWS_FALLBACK, CT_PASSES, PH_N };
 
 struct KParams {
     int n_targets;
@@ -71,23 +84,21 @@ struct KParams {
     int target_mode; const int *t_indptr; const int *t_indices;
     int *rows; int *cols; float *values; int *counts;
     // configuration
-    int T;                 // accumulator slots (power of two)
+    int T;                 // accumulator slots (power of two); the table region is T*8 bytes
     int logT;
     int cap;               // candidate buffer capacity (> k)
     u64 *gU;               // candidate buffers in global memory (only when they do not fit LDS)
-    unsigned int *queue;   // [0] = next slot index (dynamic scheduling), [1] = pass counter (debug)
+    unsigned int *queue;   // [0] = next slot index (dynamic scheduling)
     const int *order;      // optional: slot visiting order (descending work); NULL = identity
     int hash_fill;         // slots' worth of MACs one hash window may receive (= T * load_pct / 100)
     int static_sched;
-    int count_passes;
-    unsigned long long *phase_cycles;  // optional [PH_N]: s_memtime cycles of workgroup lane 0 per phase
+    const float *ymin;     // [3] minima of Ytv / Ycos / Ydep over all columns (valid iff bound_ok)
+    int bound_ok;          // weights/shrinks are all >= 0: the epilogue upper bound is sound
+    int sparse_path;       // 1 = rows with few expected collisions take the bitmap path
+    unsigned long long *phase_cycles;  // optional [PH_N]
     int dbg;               // ablation bits for profiling only (results are WRONG when non-zero):
-                           // 1 = accumulate: no LDS inserts, 2 = accumulate: no global loads, 4 = drain: no Y gathers
+                           // 1 = generic accumulate: no LDS inserts, 2 = no global loads, 4 = no Y gathers
 };
-
-// phases timed by lane 0 of every workgroup when KParams::phase_cycles != NULL
-enum { PH_SETUP = 0, PH_SEGMENTS, PH_ACCUM, PH_DRAIN, PH_SELECT, PH_OUTPUT, PH_N,
-       CT_ROUNDS = PH_N, CT_ITERS, CT_OVF, CT_SWEEPS, CT_N };
 
 // order-preserving float <-> uint map (so radix-select works for negative thresholds too)
 __device__ __forceinline__ unsigned fkey(float f) {
@@ -124,10 +135,13 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
 // Epilogue of s_plus.h:129-156: Tversky uses the RAW xy, pow only if a1 != 1,
 // raw dot returned when no normalisation/shrink is active, den == 0 -> 0.
 struct Epi {
-    float a1, l1, l2, l3, t1, t2, stab, bayes;
+    float a1, l1, l2, l3, t1, t2, stab, bayes, threshold;
     float xtv, xcos, xdep;  // row terms
-    const float *Ytv, *Ycos, *Ydep;
     bool any;
+    // upper bound without column terms: den >= bA + bB*xy for every column (valid iff bound)
+    bool bound;
+    float bA, bB;
+
     // ytv / ycos / ydep: the column terms Ytv[col] / Ycos[col] / Ydep[col], gathered by the caller so
     // that the loads of several candidates are in flight together (0 where the weight is 0)
     __device__ __forceinline__ float operator()(float xy, float ytv, float ycos, float ydep) const {
@@ -143,16 +157,35 @@ struct Epi {
         }
         return val;
     }
+
+    // A value the similarity of a candidate with raw dot xy cannot exceed whatever its column is
+    // (+inf when nothing can be said).  Uses only row terms and the per-launch minima of the column
+    // terms, so candidates can be discarded before any gather.
+    __device__ __forceinline__ float upper(float xy) const {
+        if (!any) return xy;                                   // raw dot: exact
+        if (!bound) return __builtin_inff();
+        const float den = bA + bB * xy;                        // <= true denominator
+        if (!(den > 0.f)) return __builtin_inff();
+        const float num = (a1 != 1.f) ? powf(xy, a1) : xy;
+        if (!(num >= 0.f)) {
+            // negative numerator over a positive denominator: the value is negative (NaN stays NaN and is
+            // dropped by the threshold test later); only prunable when no Bayesian factor can flip the sign
+            return (bayes == 0.f && threshold >= 0.f && num < 0.f) ? -__builtin_inff() : __builtin_inff();
+        }
+        float v = __fdividef(num, den) * 1.00002f + 1e-30f;    // slack for the few roundings that differ
+        return v;                                              // Bayesian factor num/(num+bayes) is <= 1
+    }
 };
 
 // Keep exactly the k largest of U[0..n) (n > k), in place.  MSD radix-select on the 32-bit key in
 // the high half of each entry.  Must be entered by the whole workgroup right after a barrier.
+// Returns the key of the k-th largest entry (the new running threshold), or -1 if n <= k (nothing done).
 template <int NT>
-__device__ void compact_topk(u64 *U, int *hist, int *sh, int k, bool &have_thr, unsigned &thr_key) {
+__device__ long long compact_topk(u64 *U, int *hist, int *sh, int k) {
     const int tid = threadIdx.x;
     const int n = sh[SH_CNT];
     __syncthreads();     // nobody may append (and change SH_CNT) before everyone has read n
-    if (n <= k) return;  // uniform
+    if (n <= k) return -1;  // uniform
 
     unsigned prefix = 0;
     int need = k;
@@ -212,8 +245,101 @@ __device__ void compact_topk(u64 *U, int *hist, int *sh, int k, bool &have_thr, 
     __syncthreads();
     if (tid == 0) sh[SH_CNT] = sh[SH_CNT2];
     __syncthreads();
-    have_thr = true;
-    thr_key = prefix;
+    return (long long)prefix;
+}
+
+// Row-constant state needed to judge candidates.
+struct RowCtx {
+    Epi epi;
+    int row;               // absolute m1 row id (selector rows are indexed by it, s_plus.h:165-169)
+    int f0, f1, g0, g1;    // selector row ranges
+    bool have_thr;
+    unsigned thr_key;
+};
+
+// Judge N candidates (column c[j], raw dot xy[j]; bit j of `occ` = slot j holds one) held per lane and
+// append the survivors to the top-k buffer U.  Order of work: gather-free upper bound -> column selectors
+// -> batched gathers of the column terms -> epilogue -> threshold / running k-th value -> one aggregated
+// reservation per wave.  Must be called from wave-uniform control flow.
+// Returns the candidates that are finished (rejected or stored).  A survivor that finds U full is not in
+// the returned mask and SH_RETRY is raised: the caller keeps it and re-offers it after a selection.
+template <int N>
+__device__ __forceinline__ unsigned emit_candidates(const KParams &p, const RowCtx &rc, const int (&c)[N], const float (&xy)[N],
+                                                    unsigned occ, u64 *U, int *sh) {
+    const int lane = threadIdx.x & 63;
+    unsigned live = 0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        if (occ & (1u << j)) {
+            const float ub = rc.epi.upper(xy[j]);
+            // NaN bounds compare false on `<` and therefore stay live (the exact path drops them)
+            const bool dead = (ub < p.threshold) || (rc.have_thr && fkey(ub) <= rc.thr_key && !(ub != ub));
+            if (!dead) live |= 1u << j;
+        }
+    }
+    if (!__ballot(live != 0)) return occ;  // nothing in this wave can survive: no gathers, no epilogue
+
+    if (p.filter_mode == SP_SEL_MATRIX) {
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+            if ((live & (1u << j)) && range_has(p.f_indices, rc.f0, rc.f1, c[j])) live &= ~(1u << j);
+    }
+    if (p.target_mode == SP_SEL_MATRIX) {
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+            if ((live & (1u << j)) && !range_has(p.t_indices, rc.g0, rc.g1, c[j])) live &= ~(1u << j);
+    }
+    // gather the column terms of all N candidates first (loads in flight together); dead ones read column 0
+    float ytv[N], ycos[N], ydep[N];
+    int gc[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        gc[j] = ((live & (1u << j)) && !(p.dbg & 4)) ? c[j] : 0;
+        ytv[j] = 0.f; ycos[j] = 0.f; ydep[j] = 0.f;
+    }
+    if (p.l1 != 0.f) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) ytv[j] = p.Ytv[gc[j]];
+    }
+    if (p.l2 != 0.f) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) ycos[j] = p.Ycos[gc[j]];
+    }
+    if (p.l3 != 0.f) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) ydep[j] = p.Ydep[gc[j]];
+    }
+    unsigned want = 0;
+    unsigned key[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const float val = rc.epi(xy[j], ytv[j], ycos[j], ydep[j]);
+        key[j] = fkey(val);
+        if ((live & (1u << j)) && (val >= p.threshold) && (!rc.have_thr || key[j] > rc.thr_key)) want |= 1u << j;
+    }
+    // one aggregated reservation per wave: lane counts -> wave scan -> single LDS atomic
+    unsigned stored = 0;
+    if (__ballot(want != 0)) {
+        const int mine = __popc(want);
+        const int incl = wave_incl_scan(mine);
+        int wbase = 0;
+        if (lane == 63) wbase = atomicAdd(&sh[SH_CNT], incl);
+        wbase = __shfl(wbase, 63, 64);
+        int pos = wbase + incl - mine;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            if (want & (1u << j)) {
+                if (pos < p.cap) {
+                    U[pos] = ((u64)key[j] << 32) | (u64)(unsigned)c[j];
+                    stored |= 1u << j;
+                } else {
+                    sh[SH_RETRY] = 1;  // U is full
+                }
+                ++pos;
+            }
+        }
+    }
+    return occ & (~want | stored);
 }
 
 template <int NT, bool U_LDS>
@@ -225,18 +351,29 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
     const int wave = tid >> 6;
     const int T = p.T;
 
-    // ---- LDS carve-up (single dynamic array; everything 8-byte aligned) ----
-    u64 *tab = (u64 *)smem;                     // [T]  {column id : partial dot product}
-    int *seg_lo = (int *)(tab + T);             // [NT]   start of the window's slice of m2 row u
+    // ---- LDS carve-up (single dynamic array; everything 16-byte aligned at the table) ----
+    u64 *tab = (u64 *)smem;                     // [T]  generic path: {column id : partial dot product}
+    int *seg_lo = (int *)(tab + T);             // [NT]   start of the (window's) slice of m2 row u
     int *seg_pre = seg_lo + NT;                 // [NT+64] exclusive prefix of slice lengths
     float *seg_v1 = (float *)(seg_pre + NT + 64);  // [NT] m1 value of the segment
     int *seg_hi = (int *)(seg_v1 + NT);         // [NT]   end of the slice (= start of the next window's)
     int *hist = seg_hi + NT;                    // [256]
     int *wsum = hist + 256;                     // [64]
     int *sh = wsum + 64;                        // [SH_N .. 16]
-    u64 *U = U_LDS ? (u64 *)(sh + 16) : (p.gU + (size_t)blockIdx.x * (size_t)p.cap);
+    u64 *ph = (u64 *)(sh + 16);                 // [PH_N .. 16] phase timers / event counters (lane 0 only)
+    u64 *U = U_LDS ? (u64 *)(ph + 16) : (p.gU + (size_t)blockIdx.x * (size_t)p.cap);
+    // sparse path: the same T*8 bytes hold a bitmap of 32*T bits, then T/2 keys and T/2 sums of the
+    // collision set (buckets of 4 keys = one ds_read_b128)
+    unsigned *bm = (unsigned *)smem;            // [T] words
+    int *cskeys = (int *)(bm + T);              // [T/2]
+    float *cssums = (float *)(cskeys + T / 2);  // [T/2]
+    const int cs_slots = T / 2;
+    const unsigned cs_mask = (unsigned)cs_slots - 1u;
+    const int bm_shift = 32 - (p.logT + 5);     // hashed column -> bit index
+    const int cs_shift = 32 - (p.logT - 3);     // hashed column -> bucket index (cs_slots/4 buckets)
 
     for (int i = tid; i < T; i += NT) tab[i] = EMPTY64;
+    int lds_mode = 0;  // 0: table region is generic-clean (all EMPTY64), 1: sparse-clean (bitmap 0, keys EMPTY, sums 0)
     if (tid == 0) {
         sh[SH_CNT] = 0;
         sh[SH_OVF] = 0;
@@ -246,12 +383,73 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
     __syncthreads();
 
     const bool any_norm = (p.l1 != 0.f || p.l2 != 0.f || p.l3 != 0.f || p.stab != 0.f || p.bayes != 0.f);
-    unsigned local_passes = 0;
+    float ymin_tv = 0.f, ymin_cos = 0.f, ymin_dep = 0.f;
+    if (p.bound_ok) { ymin_tv = p.ymin[0]; ymin_cos = p.ymin[1]; ymin_dep = p.ymin[2]; }
+
     // phase timers (lane 0 only; s_memtime ticks are shader cycles)
     const bool timing = (p.phase_cycles != nullptr) && tid == 0;
-    u64 ph[CT_N] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (tid < 16) ph[tid] = 0;
+    __syncthreads();
     u64 tmark = timing ? (u64)clock64() : 0;
 #define PHASE_END(which) do { if (timing) { const u64 _n = (u64)clock64(); ph[which] += _n - tmark; tmark = _n; } } while (0)
+
+    // Visit the flat element space [eb, ee) of the current segment list (nb segments, prefix in seg_pre):
+    // wave w owns a contiguous 64-aligned chunk, every lane handles ACC_UNROLL stride-64 elements per
+    // trip (coalesced loads), and all lanes of a wave make the same number of trips.
+    // body(idx[], v1[], valid): idx = position in the m2 arrays, v1 = m1 value of the element's segment;
+    // padding elements (bit clear in `valid`) repeat a real element of the lane with v1 = 0.
+    auto for_elements = [&](int eb, int ee, int nb, auto &&body) {
+        const int span = ee - eb;
+        if (span <= 0) return;
+        const int chunk = ((span + NW * 64 - 1) / (NW * 64)) * 64;
+        const int e0 = eb + wave * chunk;
+        const int e1 = min(e0 + chunk, ee);
+        if (e0 >= e1) return;  // wave-uniform
+        const int efirst = min(e0 + lane, e1 - 1);
+        int sl = 0, sr = nb;  // last s in [0,nb) with seg_pre[s] <= efirst (seg_pre[0] = 0)
+        while (sr - sl > 1) {
+            const int mid = (sl + sr) >> 1;
+            if (seg_pre[mid] <= efirst) sl = mid; else sr = mid;
+        }
+        int seg = sl;
+        const int idx_safe = seg_lo[seg] + (efirst - seg_pre[seg]);
+        for (int ebase = e0; ebase < e1; ebase += 64 * ACC_UNROLL) {
+            int idx[ACC_UNROLL];
+            float v1[ACC_UNROLL];
+            unsigned valid = 0;
+#pragma unroll
+            for (int j = 0; j < ACC_UNROLL; ++j) {
+                const int ej = ebase + 64 * j + lane;
+                if (ej < e1) {
+                    while (seg + 1 < nb && ej >= seg_pre[seg + 1]) ++seg;
+                    idx[j] = seg_lo[seg] + (ej - seg_pre[seg]);
+                    v1[j] = seg_v1[seg];
+                    valid |= 1u << j;
+                } else {
+                    idx[j] = idx_safe;
+                    v1[j] = 0.f;
+                }
+            }
+            body(idx, v1, valid);
+        }
+    };
+
+    // Turn per-thread slice lengths into the flat prefix array; returns the total.  Two barriers.
+    auto scan_segments = [&](int len) -> int {
+        const int incl = wave_incl_scan(len);
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int woff = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const int sw = wsum[w];
+            if (w < wave) woff += sw;
+            total += sw;
+        }
+        seg_pre[tid] = woff + incl - len;
+        __syncthreads();
+        return total;
+    };
 
     for (;;) {
         const int qi = sh[SH_NEXT];
@@ -265,17 +463,25 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
         int next_q = 0;
         if (tid == 0) next_q = p.static_sched ? qi + (int)gridDim.x : (int)atomicAdd(&p.queue[0], 1u);
 
-        Epi epi;
+        RowCtx rc;
+        rc.row = t;
+        rc.have_thr = false;
+        rc.thr_key = 0;
+        Epi &epi = rc.epi;
         epi.a1 = p.a1; epi.l1 = p.l1; epi.l2 = p.l2; epi.l3 = p.l3; epi.t1 = p.t1; epi.t2 = p.t2;
-        epi.stab = p.stab; epi.bayes = p.bayes; epi.any = any_norm;
+        epi.stab = p.stab; epi.bayes = p.bayes; epi.threshold = p.threshold; epi.any = any_norm;
         epi.xtv = (p.l1 != 0.f) ? p.Xtv[t] : 0.f;
         epi.xcos = (p.l2 != 0.f) ? p.Xcos[t] : 0.f;
         epi.xdep = (p.l3 != 0.f) ? p.Xdep[t] : 0.f;
-        epi.Ytv = p.Ytv; epi.Ycos = p.Ycos; epi.Ydep = p.Ydep;
+        // den = l1*(t1*(X-xy) + t2*(Y-xy) + xy) + l2*Xc*Yc + l3*Xd*Yd + stab  >=  bA + bB*xy  when the
+        // column terms are replaced by their minima and their multipliers are non-negative
+        epi.bound = p.bound_ok && !(epi.xcos < 0.f) && !(epi.xdep < 0.f);
+        epi.bA = p.l1 * (p.t1 * epi.xtv + p.t2 * ymin_tv) + p.l2 * epi.xcos * ymin_cos + p.l3 * epi.xdep * ymin_dep + p.stab;
+        epi.bB = p.l1 * (1.f - p.t1 - p.t2);
 
-        int f0 = 0, f1 = 0, g0 = 0, g1 = 0;
-        if (p.filter_mode == SP_SEL_MATRIX) { f0 = p.f_indptr[t]; f1 = p.f_indptr[t + 1]; }
-        if (p.target_mode == SP_SEL_MATRIX) { g0 = p.t_indptr[t]; g1 = p.t_indptr[t + 1]; }
+        rc.f0 = rc.f1 = rc.g0 = rc.g1 = 0;
+        if (p.filter_mode == SP_SEL_MATRIX) { rc.f0 = p.f_indptr[t]; rc.f1 = p.f_indptr[t + 1]; }
+        if (p.target_mode == SP_SEL_MATRIX) { rc.g0 = p.t_indptr[t]; rc.g1 = p.t_indptr[t + 1]; }
 
         // ---- work estimate: MACs(t) = sum_u nnz(m2 row u) (upper bound on distinct candidates) ----
         u64 macs_local = 0;
@@ -292,111 +498,283 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
         __syncthreads();
         PHASE_END(PH_SETUP);
 
-        bool have_thr = false;
-        unsigned thr_key = 0;
-        bool retry_window = false;  // the current window repeats the previous lo (after an overflow)
-
-        // ---- choose the column window width ----
-        // dense windows can never overflow (one slot per column); hash windows are sized from the
-        // MACs bound and split on overflow.  Window width w; windows are [lo, lo+w).
-        long long width;
-        if (p.n_cols <= T) {
-            width = p.n_cols;
-        } else {
-            const long long p_dense = ((long long)p.n_cols + T - 1) / T;
-            const long long p_hash = (long long)((macs + (u64)p.hash_fill - 1) / (u64)p.hash_fill);
-            if (p_hash < 1 || p_dense <= p_hash) width = T;
-            else width = ((long long)p.n_cols + p_hash - 1) / p_hash;
+        // =========================================================================================
+        // SPARSE path: expected colliding products (true + bitmap aliasing) fit the collision set
+        // =========================================================================================
+        bool row_done = (macs == 0);
+        bool sparse_ok = false;
+        if (!row_done && p.sparse_path && n1 <= NT && p.n_cols > T && macs < (1ull << 30)) {
+            const float m = (float)macs;
+            const float expect = 0.5f * m * m * (1.f / (float)p.n_cols + 1.f / (32.f * (float)T));
+            sparse_ok = expect <= 0.40f * (float)cs_slots;
         }
-
-        long long lo = 0;
-        if (macs == 0) lo = p.n_cols;  // nothing to accumulate: empty output row
-
-        while (lo < (long long)p.n_cols) {
-            long long hi = lo + width;
-            if (hi > p.n_cols) hi = p.n_cols;
-            const int wlo = (int)lo, whi = (int)hi;
-            const bool dense = (hi - lo) <= (long long)T;
-            const bool whole = (wlo == 0 && whi == p.n_cols);
-            int t_eff = dense ? (whi - wlo) : T;
-            int hshift = 32 - p.logT;
-            if (!dense && whole) {
-                // single hash window over a small row: shrink the table so the drain scans less
-                int lg = 10;
-                while (lg < p.logT && (1ull << lg) < 2ull * macs) ++lg;
-                t_eff = 1 << lg;
-                hshift = 32 - lg;
+        if (sparse_ok) {
+            if (lds_mode != 1) {
+                for (int i = tid; i < T; i += NT) bm[i] = 0u;
+                for (int i = tid; i < cs_slots; i += NT) { cskeys[i] = EMPTY; cssums[i] = 0.f; }
+                lds_mode = 1;
+                __syncthreads();
             }
-            const unsigned hmask = (unsigned)t_eff - 1u;
-
-            // ================= accumulate =================
-            // Window slices chain (hi of window w == lo of window w+1), so when the m1 row fits one
-            // batch the previous slice end is kept in LDS and only one lower_bound per window is run.
-            const bool carry = (n1 <= NT);
-            for (int b0 = 0; b0 < n1; b0 += NT) {
-                const int nb = min(NT, n1 - b0);
-                int len = 0;
-                if (tid < nb) {
-                    const int u = p.m1_indices[s1 + b0 + tid];
-                    int r0 = p.m2_indptr[u], r1 = p.m2_indptr[u + 1];
-                    if (!whole) {
-                        // slice of the sorted m2 row inside [wlo, whi)  (s_plus.h:385-394)
-                        if (wlo != 0) {
-                            if (carry) r0 = retry_window ? seg_lo[tid] : seg_hi[tid];
-                            else r0 = lower_bound_g(p.m2_indices, r0, r1, wlo);
+            // whole m2 rows, one segment per m1 entry — visited in descending |m1 value| order: the products
+            // are offered to the top-k filter segment by segment, and each segment scales its m2 row by its own
+            // m1 value, so putting the heavy segments first makes the running k-th value rise early and the
+            // survivor rate fall monotonically (an unordered row could flood the candidate buffer late)
+            int len = 0;
+            {
+                int r0 = 0, mylen = 0;
+                float v = 0.f;
+                if (tid < n1) {
+                    const int u = p.m1_indices[s1 + tid];
+                    r0 = p.m2_indptr[u];
+                    mylen = p.m2_indptr[u + 1] - r0;
+                    v = p.m1_data[s1 + tid];
+                }
+                int slot = tid;
+                if (n1 <= 256) {
+                    if (tid < n1) seg_pre[tid] = (int)(__float_as_uint(v) & 0x7FFFFFFFu);   // |v| orders as an integer
+                    __syncthreads();
+                    if (tid < n1) {
+                        const int key = seg_pre[tid];
+                        int rank = 0;
+                        for (int j = 0; j < n1; ++j) {
+                            const int kj = seg_pre[j];   // same address across the wave: broadcast read
+                            rank += (kj > key) || (kj == key && j < tid);
                         }
-                        if (whi < p.n_cols) r1 = lower_bound_g(p.m2_indices, r0, r1, whi);
-                        if (carry) seg_hi[tid] = r1;
+                        slot = rank;
                     }
-                    seg_lo[tid] = r0;
-                    seg_v1[tid] = p.m1_data[s1 + b0 + tid];
-                    len = r1 - r0;
+                    __syncthreads();   // ranks computed before seg_pre is reused by the scan
                 }
-                const int incl = wave_incl_scan(len);
-                if (lane == 63) wsum[wave] = incl;
+                if (tid < n1) { seg_lo[slot] = r0; seg_v1[slot] = v; seg_hi[slot] = mylen; }
                 __syncthreads();
-                int woff = 0, total = 0;
-#pragma unroll
-                for (int w = 0; w < NW; ++w) {
-                    const int sw = wsum[w];
-                    if (w < wave) woff += sw;
-                    total += sw;
-                }
-                seg_pre[tid] = woff + incl - len;
-                if (tid == 0) seg_pre[NT] = total;
-                __syncthreads();
-                PHASE_END(PH_SEGMENTS);
+                if (tid < n1) len = seg_hi[tid];
+            }
+            const int total = scan_segments(len);
+            PHASE_END(PH_SEGMENTS);
 
-                // flat element space [0,total): wave w owns a contiguous, 64-aligned chunk; every lane
-                // keeps ACC_UNROLL coalesced (stride-64) index/value loads in flight
-                const int chunk = ((total + NW * 64 - 1) / (NW * 64)) * 64;
-                const int e0 = wave * chunk;
-                const int e1 = min(e0 + chunk, total);
-                if (e0 < e1) {
-                    int e = e0 + lane;
-                    int sl = 0, sr = nb;  // last s in [0,nb) with seg_pre[s] <= e (seg_pre[0] = 0)
-                    while (sr - sl > 1) {
-                        const int mid = (sl + sr) >> 1;
-                        if (seg_pre[mid] <= e) sl = mid; else sr = mid;
+            // ---- sweep 1: column ids only.  First product of a column sets its bit; a product that finds
+            // the bit set (a second product of the column, or an aliasing column) enters its column in the
+            // collision set.  Every column with >= 2 products ends up in the set. ----
+            for_elements(0, total, n1, [&](const int (&idx)[ACC_UNROLL], const float (&)[ACC_UNROLL], unsigned valid) {
+                int c[ACC_UNROLL];
+#pragma unroll
+                for (int j = 0; j < ACC_UNROLL; ++j) c[j] = p.m2_indices[idx[j]];
+                unsigned old[ACC_UNROLL], bit[ACC_UNROLL];
+#pragma unroll
+                for (int j = 0; j < ACC_UNROLL; ++j) {
+                    const unsigned b = ((unsigned)c[j] * 2654435761u) >> bm_shift;
+                    bit[j] = 1u << (b & 31u);
+                    // padding elements repeat a real element of this lane: OR-ing 0 leaves the bitmap alone
+                    old[j] = atomicOr(&bm[b >> 5], (valid & (1u << j)) ? bit[j] : 0u);
+                }
+#pragma unroll
+                for (int j = 0; j < ACC_UNROLL; ++j) {
+                    if ((valid & (1u << j)) && (old[j] & bit[j])) {
+                        unsigned bk = ((((unsigned)c[j] * 0x85EBCA6Bu) >> cs_shift) << 2) & cs_mask;
+                        int tries = 0;
+                        for (; tries < 2 * CS_TRIES; ++tries) {
+                            const int4 k4 = *(const int4 *)&cskeys[bk];
+                            if (k4.x == c[j] || k4.y == c[j] || k4.z == c[j] || k4.w == c[j]) break;  // already a member
+                            const int pos = (k4.x == EMPTY) ? 0 : (k4.y == EMPTY) ? 1 : (k4.z == EMPTY) ? 2 : (k4.w == EMPTY) ? 3 : -1;
+                            if (pos < 0) { bk = (bk + 4u) & cs_mask; continue; }          // bucket full: next one
+                            const int prev = atomicCAS(&cskeys[bk + pos], EMPTY, c[j]);
+                            if (prev == EMPTY || prev == c[j]) break;
+                            // lost the slot to another column: look at the same bucket again
+                        }
+                        if (tries == 2 * CS_TRIES) sh[SH_OVF] = 1;
                     }
-                    int seg = sl;
-                    for (; e < e1; e += 64 * ACC_UNROLL) {
-                        int idx[ACC_UNROLL];
-                        float v1[ACC_UNROLL];
+                }
+            });
+            __syncthreads();
+            const int ovf1 = sh[SH_OVF];
+            __syncthreads();
+            PHASE_END(PH_SWEEP1);
+
+            bool failed = (ovf1 != 0);
+            if (!failed) {
+                // ---- sweep 2: ids + values.  Members of the collision set accumulate there; every other
+                // product is the only one of its column and is judged on the spot. ----
+                auto sweep2 = [&](int eb, int ee) {
+                    for_elements(eb, ee, n1, [&](const int (&idx)[ACC_UNROLL], const float (&v1)[ACC_UNROLL], unsigned valid) {
+                        int c[ACC_UNROLL];
+                        float x[ACC_UNROLL];
+#pragma unroll
+                        for (int j = 0; j < ACC_UNROLL; ++j) { c[j] = p.m2_indices[idx[j]]; x[j] = p.m2_data[idx[j]]; }
+                        int4 k4[ACC_UNROLL];
+                        unsigned bk[ACC_UNROLL];
 #pragma unroll
                         for (int j = 0; j < ACC_UNROLL; ++j) {
-                            const int ej = e + 64 * j;
-                            if (ej < e1) {
-                                while (seg + 1 < nb && ej >= seg_pre[seg + 1]) ++seg;
-                                idx[j] = seg_lo[seg] + (ej - seg_pre[seg]);
-                                v1[j] = seg_v1[seg];
-                            } else {
-                                // padding: repeat the lane's first element with weight 0 — it goes through
-                                // the same (branch-free) insert path and adds exactly 0.0 to an existing key
-                                idx[j] = idx[0];
-                                v1[j] = 0.f;
+                            x[j] *= v1[j];
+                            bk[j] = ((((unsigned)c[j] * 0x85EBCA6Bu) >> cs_shift) << 2) & cs_mask;
+                            k4[j] = *(const int4 *)&cskeys[bk[j]];
+                        }
+                        unsigned single = 0;
+#pragma unroll
+                        for (int j = 0; j < ACC_UNROLL; ++j) {
+                            if (!(valid & (1u << j))) continue;
+                            int4 kk = k4[j];
+                            unsigned b = bk[j];
+                            for (int tries = 0;; ++tries) {
+                                const int pos = (kk.x == c[j]) ? 0 : (kk.y == c[j]) ? 1 : (kk.z == c[j]) ? 2 : (kk.w == c[j]) ? 3 : -1;
+                                if (pos >= 0) { atomicAdd(&cssums[b + pos], x[j]); break; }    // collision column
+                                if (kk.x == EMPTY || kk.y == EMPTY || kk.z == EMPTY || kk.w == EMPTY || tries >= 2 * CS_TRIES) {
+                                    single |= 1u << j;                                          // not a member
+                                    break;
+                                }
+                                b = (b + 4u) & cs_mask;                                         // full bucket: chain on
+                                kk = *(const int4 *)&cskeys[b];
                             }
                         }
+                        (void)emit_candidates<ACC_UNROLL>(p, rc, c, x, single, U, sh);
+                    });
+                };
+                // The products are offered in growing chunks with a selection after each: the first chunk is
+                // small enough that accepting everything cannot overflow U; once the k-th best of n products
+                // is known, about k*m/n of the next m survive, so a chunk of n*(cap-k)/(2k) keeps the expected
+                // survivors at half the free room.  (An adversarial order can still overflow: -> generic path.)
+                const int room = p.cap - min(p.k, p.cap - 1);
+                int pos = 0;
+                long long chunk = room;
+                while (pos < total) {
+                    const int end = (int)min((long long)total, (long long)pos + chunk);
+                    sweep2(pos, end);
+                    __syncthreads();
+                    const int n_now = sh[SH_CNT];
+                    const int retry = sh[SH_RETRY];
+                    __syncthreads();
+                    if (retry) { failed = true; break; }   // U overflowed mid-chunk: dropped products cannot be re-offered
+                    pos = end;
+                    if (pos < total && n_now > p.k) {
+                        PHASE_END(PH_SWEEP2);
+                        { const long long thr_new = compact_topk<NT>(U, hist, sh, p.k); if (thr_new >= 0) { rc.have_thr = true; rc.thr_key = (unsigned)thr_new; } }
+                        PHASE_END(PH_SELECT);
+                    }
+                    chunk = rc.have_thr ? max((long long)room, (long long)pos * (long long)room / (2ll * (long long)p.k)) : (long long)room;
+                }
+                PHASE_END(PH_SWEEP2);
+            }
+
+            if (!failed) {
+                // ---- drain the collision set (also resets it), with the usual overflow-retry ----
+                for (;;) {
+                    for (int base = 0; base < cs_slots; base += NT * DRAIN_UNROLL) {
+                        int c[DRAIN_UNROLL];
+                        float xy[DRAIN_UNROLL];
+                        unsigned occ = 0;
+#pragma unroll
+                        for (int j = 0; j < DRAIN_UNROLL; ++j) {
+                            const int sidx = base + j * NT + tid;
+                            c[j] = (sidx < cs_slots) ? cskeys[sidx] : EMPTY;
+                            xy[j] = (sidx < cs_slots) ? cssums[sidx] : 0.f;
+                            if (c[j] != EMPTY) occ |= 1u << j;
+                        }
+                        const unsigned done = emit_candidates<DRAIN_UNROLL>(p, rc, c, xy, occ, U, sh);
+#pragma unroll
+                        for (int j = 0; j < DRAIN_UNROLL; ++j) {
+                            if (done & (1u << j)) {
+                                const int sidx = base + j * NT + tid;
+                                cskeys[sidx] = EMPTY;
+                                cssums[sidx] = 0.f;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                    const int retry = sh[SH_RETRY];
+                    if (!retry) break;  // uniform
+                    __syncthreads();
+                    if (tid == 0) {
+                        sh[SH_RETRY] = 0;
+                        if (sh[SH_CNT] > p.cap) sh[SH_CNT] = p.cap;
+                    }
+                    __syncthreads();
+                    PHASE_END(PH_CSDRAIN);
+                    { const long long thr_new = compact_topk<NT>(U, hist, sh, p.k); if (thr_new >= 0) { rc.have_thr = true; rc.thr_key = (unsigned)thr_new; } }
+                    PHASE_END(PH_SELECT);
+                }
+                for (int i = tid; i < T; i += NT) bm[i] = 0u;   // bitmap back to clean
+                __syncthreads();
+                PHASE_END(PH_CSDRAIN);
+                row_done = true;
+                if (timing) ph[CT_ROWS_SPARSE] += 1;
+            } else {
+                // collision set or candidate buffer overflowed: forget this attempt, take the generic path
+                for (int i = tid; i < T; i += NT) tab[i] = EMPTY64;
+                lds_mode = 0;
+                if (tid == 0) { sh[SH_CNT] = 0; sh[SH_OVF] = 0; sh[SH_RETRY] = 0; }
+                rc.have_thr = false;
+                rc.thr_key = 0;
+                __syncthreads();
+                if (timing) ph[CT_ROWS_FALLBACK] += (ovf1 != 0) ? 1ull : (1ull << 32);   // low word: collision set full, high word: U overflow
+            }
+        }
+
+        // =========================================================================================
+        // GENERIC path: accumulator tile + column windows
+        // =========================================================================================
+        if (!row_done) {
+            if (lds_mode != 0) {
+                for (int i = tid; i < T; i += NT) tab[i] = EMPTY64;
+                lds_mode = 0;
+                __syncthreads();
+            }
+            bool retry_window = false;  // the current window repeats the previous lo (after an overflow)
+
+            // dense windows can never overflow (one slot per column); hash windows are sized from the
+            // MACs bound and split on overflow.  Window width w; windows are [lo, lo+w).
+            long long width;
+            if (p.n_cols <= T) {
+                width = p.n_cols;
+            } else {
+                const long long p_dense = ((long long)p.n_cols + T - 1) / T;
+                const long long p_hash = (long long)((macs + (u64)p.hash_fill - 1) / (u64)p.hash_fill);
+                if (p_hash < 1 || p_dense <= p_hash) width = T;
+                else width = ((long long)p.n_cols + p_hash - 1) / p_hash;
+            }
+
+            long long lo = 0;
+            while (lo < (long long)p.n_cols) {
+                long long hi = lo + width;
+                if (hi > p.n_cols) hi = p.n_cols;
+                const int wlo = (int)lo, whi = (int)hi;
+                const bool dense = (hi - lo) <= (long long)T;
+                const bool whole = (wlo == 0 && whi == p.n_cols);
+                int t_eff = dense ? (whi - wlo) : T;
+                int hshift = 32 - p.logT;
+                if (!dense && whole) {
+                    // single hash window over a small row: shrink the table so the drain scans less
+                    int lg = 10;
+                    while (lg < p.logT && (1ull << lg) < 2ull * macs) ++lg;
+                    t_eff = 1 << lg;
+                    hshift = 32 - lg;
+                }
+                const unsigned hmask = (unsigned)t_eff - 1u;
+
+                // ================= accumulate =================
+                // Window slices chain (hi of window w == lo of window w+1), so when the m1 row fits one
+                // batch the previous slice end is kept in LDS and only one lower_bound per window is run.
+                const bool carry = (n1 <= NT);
+                for (int b0 = 0; b0 < n1; b0 += NT) {
+                    const int nb = min(NT, n1 - b0);
+                    int len = 0;
+                    if (tid < nb) {
+                        const int u = p.m1_indices[s1 + b0 + tid];
+                        int r0 = p.m2_indptr[u], r1 = p.m2_indptr[u + 1];
+                        if (!whole) {
+                            // slice of the sorted m2 row inside [wlo, whi)  (s_plus.h:385-394)
+                            if (wlo != 0) {
+                                if (carry) r0 = retry_window ? seg_lo[tid] : seg_hi[tid];
+                                else r0 = lower_bound_g(p.m2_indices, r0, r1, wlo);
+                            }
+                            if (whi < p.n_cols) r1 = lower_bound_g(p.m2_indices, r0, r1, whi);
+                            if (carry) seg_hi[tid] = r1;
+                        }
+                        seg_lo[tid] = r0;
+                        seg_v1[tid] = p.m1_data[s1 + b0 + tid];
+                        len = r1 - r0;
+                    }
+                    const int total = scan_segments(len);
+                    PHASE_END(PH_SEGMENTS);
+
+                    for_elements(0, total, nb, [&](const int (&idx)[ACC_UNROLL], const float (&v1)[ACC_UNROLL], unsigned valid) {
                         int c[ACC_UNROLL];
                         float x[ACC_UNROLL];
                         if (p.dbg & 2) {
@@ -407,7 +785,7 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
                             for (int j = 0; j < ACC_UNROLL; ++j) { c[j] = p.m2_indices[idx[j]]; x[j] = p.m2_data[idx[j]]; }
                         }
 #pragma unroll
-                        for (int j = 0; j < ACC_UNROLL; ++j) x[j] *= v1[j];
+                        for (int j = 0; j < ACC_UNROLL; ++j) x[j] *= v1[j];   // padding elements carry 0
                         if (p.dbg & 1) {
                             float sink = 0.f;
 #pragma unroll
@@ -426,17 +804,13 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
                             // Hashed window.  One 64-bit compare-and-swap claims a free slot for a new column AND
                             // deposits its first product; finding the same column already there turns into a
                             // hardware float add on the sum half (slow on gfx950, 3 clk/lane, but immune to
-                            // contention on hot columns); finding another column means linear probing.
+                            // contention on hot columns); finding another column means double-hash probing.
                             // Round 1 issues the ACC_UNROLL claims back to back; the few leftovers are then walked
-                            // one element per lane per round, so later rounds are sparse instructions.
+                            // one element per lane per round.
                             unsigned hs[ACC_UNROLL];
                             u64 prev[ACC_UNROLL];
 #pragma unroll
                             for (int j = 0; j < ACC_UNROLL; ++j) hs[j] = ((unsigned)c[j] * 2654435761u) >> hshift;
-                            if (p.dbg & 32) {   // ablation: collision-free slots (every claim succeeds)
-#pragma unroll
-                                for (int j = 0; j < ACC_UNROLL; ++j) hs[j] = (unsigned)(e + 64 * j) & hmask;
-                            }
 #pragma unroll
                             for (int j = 0; j < ACC_UNROLL; ++j)
                                 prev[j] = atomicCAS(&tab[hs[j]], EMPTY64, ((u64)(unsigned)c[j] << 32) | (u64)__float_as_uint(x[j]));
@@ -444,13 +818,11 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
 #pragma unroll
                             for (int j = 0; j < ACC_UNROLL; ++j) {
                                 const bool hit = ((int)(prev[j] >> 32) == c[j]);
-                                if (hit && !(p.dbg & 16)) atomicAdd((float *)&tab[hs[j]], x[j]);
+                                if (hit) atomicAdd((float *)&tab[hs[j]], x[j]);
                                 if (prev[j] != EMPTY64 && !hit) pend |= 1u << j;
                             }
-                            if (p.dbg & 8) pend = 0;   // ablation: no probing beyond the home slot
-                            int probes = 1, plen = 0;
+                            int plen = 0;
                             while (__ballot(pend != 0)) {   // wave-uniform trip count
-                                ++probes;
                                 if (!pend) continue;
                                 const unsigned bit = pend & (0u - pend);  // this lane's current element
                                 int cc = c[0];
@@ -466,150 +838,79 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
                                 const bool hit = ((int)(pv >> 32) == cc);
                                 if (hit) atomicAdd((float *)&tab[hh], xx);
                                 if (pv == EMPTY64 || hit) { pend &= ~bit; plen = 0; }
-                                else if (++plen >= MAX_PROBE) { sh[SH_OVF] = 1; break; }
+                                else if (++plen >= MAX_PROBE) { sh[SH_OVF] = 1; pend = 0; }
 #pragma unroll
                                 for (int j = 0; j < ACC_UNROLL; ++j)
                                     if (bit == (1u << j)) hs[j] = hh;
                             }
-                            if (timing) { ph[CT_ROUNDS] += probes; ph[CT_ITERS] += 1; }
                         }
-                    }
+                    });
+                    __syncthreads();  // seg_* are rewritten by the next batch
+                    PHASE_END(PH_ACCUM);
                 }
-                __syncthreads();  // seg_* are rewritten by the next batch
-                PHASE_END(PH_ACCUM);
-            }
 
-            // ================= overflow: discard the window, halve it, retry =================
-            if (!dense) {
-                const int ovf = sh[SH_OVF];
-                __syncthreads();
-                if (ovf) {
-                    if (timing) ph[CT_OVF] += 1;
-                    for (int i = tid; i < t_eff; i += NT) tab[i] = EMPTY64;
-                    if (tid == 0) sh[SH_OVF] = 0;
-                    width = max((long long)T, (width + 1) / 2);
-                    retry_window = true;  // same lo again: slice starts are still in seg_lo
+                // ================= overflow: discard the window, halve it, retry =================
+                if (!dense) {
+                    const int ovf = sh[SH_OVF];
                     __syncthreads();
-                    continue;
+                    if (ovf) {
+                        for (int i = tid; i < t_eff; i += NT) tab[i] = EMPTY64;
+                        if (tid == 0) sh[SH_OVF] = 0;
+                        width = max((long long)T, (width + 1) / 2);
+                        retry_window = true;  // same lo again: slice starts are still in seg_lo
+                        __syncthreads();
+                        continue;
+                    }
                 }
-            }
-            retry_window = false;
-            ++local_passes;
+                retry_window = false;
+                if (timing) ph[CT_PASSES] += 1;
 
-            // ================= drain: selectors, epilogue, threshold, running top-k =================
-            // One barrier-free sweep over the table.  Survivors of the running threshold are appended to
-            // U; a survivor that finds U full leaves its slot in place and raises SH_RETRY, after which
-            // the workgroup selects the k best of U (raising the threshold) and sweeps the leftovers.
-            for (;;) {
-                if (timing) ph[CT_SWEEPS] += 1;
-                for (int base = 0; base < t_eff; base += NT * DRAIN_UNROLL) {
-                    int c[DRAIN_UNROLL];
-                    float xy[DRAIN_UNROLL];
-                    unsigned occ = 0, pass = 0;
-#pragma unroll
-                    for (int j = 0; j < DRAIN_UNROLL; ++j) {
-                        const int sidx = base + j * NT + tid;
-                        c[j] = EMPTY;
-                        xy[j] = 0.f;
-                        if (sidx < t_eff) {
-                            const u64 slot = tab[sidx];
-                            c[j] = (int)(slot >> 32);
-                            xy[j] = __uint_as_float((unsigned)slot);
-                        }
-                        if (c[j] != EMPTY) occ |= 1u << j;
-                    }
-                    pass = occ;
-                    if (p.filter_mode == SP_SEL_MATRIX) {
-#pragma unroll
-                        for (int j = 0; j < DRAIN_UNROLL; ++j)
-                            if ((pass & (1u << j)) && range_has(p.f_indices, f0, f1, c[j])) pass &= ~(1u << j);
-                    }
-                    if (p.target_mode == SP_SEL_MATRIX) {
-#pragma unroll
-                        for (int j = 0; j < DRAIN_UNROLL; ++j)
-                            if ((pass & (1u << j)) && !range_has(p.t_indices, g0, g1, c[j])) pass &= ~(1u << j);
-                    }
-                    // gather the column terms of all DRAIN_UNROLL slots first (loads in flight together);
-                    // slots that are empty / filtered read column 0 (one hot line)
-                    float ytv[DRAIN_UNROLL], ycos[DRAIN_UNROLL], ydep[DRAIN_UNROLL];
-                    int gc[DRAIN_UNROLL];
-#pragma unroll
-                    for (int j = 0; j < DRAIN_UNROLL; ++j) {
-                        gc[j] = ((pass & (1u << j)) && !(p.dbg & 4)) ? c[j] : 0;
-                        ytv[j] = 0.f; ycos[j] = 0.f; ydep[j] = 0.f;
-                    }
-                    if (p.l1 != 0.f) {
-#pragma unroll
-                        for (int j = 0; j < DRAIN_UNROLL; ++j) ytv[j] = p.Ytv[gc[j]];
-                    }
-                    if (p.l2 != 0.f) {
-#pragma unroll
-                        for (int j = 0; j < DRAIN_UNROLL; ++j) ycos[j] = p.Ycos[gc[j]];
-                    }
-                    if (p.l3 != 0.f) {
-#pragma unroll
-                        for (int j = 0; j < DRAIN_UNROLL; ++j) ydep[j] = p.Ydep[gc[j]];
-                    }
-                    float val[DRAIN_UNROLL];
-#pragma unroll
-                    for (int j = 0; j < DRAIN_UNROLL; ++j) val[j] = epi(xy[j], ytv[j], ycos[j], ydep[j]);
-                    // survivors of (threshold, running k-th value) in this lane's DRAIN_UNROLL slots
-                    unsigned want = 0;
-                    unsigned key[DRAIN_UNROLL];
-#pragma unroll
-                    for (int j = 0; j < DRAIN_UNROLL; ++j) {
-                        key[j] = fkey(val[j]);
-                        if ((pass & (1u << j)) && (val[j] >= p.threshold) && (!have_thr || key[j] > thr_key)) want |= 1u << j;
-                    }
-                    // one aggregated reservation per wave: lane counts -> wave scan -> single LDS atomic
-                    unsigned stored = 0;
-                    if (__ballot(want != 0)) {
-                        const int mine = __popc(want);
-                        const int incl = wave_incl_scan(mine);
-                        int wbase = 0;
-                        if (lane == 63) wbase = atomicAdd(&sh[SH_CNT], incl);
-                        wbase = __shfl(wbase, 63, 64);
-                        int pos = wbase + incl - mine;
+                // ================= drain: one barrier-free sweep, overflow-retry =================
+                for (;;) {
+                    for (int base = 0; base < t_eff; base += NT * DRAIN_UNROLL) {
+                        int c[DRAIN_UNROLL];
+                        float xy[DRAIN_UNROLL];
+                        unsigned occ = 0;
 #pragma unroll
                         for (int j = 0; j < DRAIN_UNROLL; ++j) {
-                            if (want & (1u << j)) {
-                                if (pos < p.cap) {
-                                    U[pos] = ((u64)key[j] << 32) | (u64)(unsigned)c[j];
-                                    stored |= 1u << j;
-                                } else {
-                                    sh[SH_RETRY] = 1;  // U is full: keep the slot for the sweep after the selection
-                                }
-                                ++pos;
+                            const int sidx = base + j * NT + tid;
+                            c[j] = EMPTY;
+                            xy[j] = 0.f;
+                            if (sidx < t_eff) {
+                                const u64 slot = tab[sidx];
+                                c[j] = (int)(slot >> 32);
+                                xy[j] = __uint_as_float((unsigned)slot);
                             }
+                            if (c[j] != EMPTY) occ |= 1u << j;
                         }
-                    }
-                    // free every visited slot except survivors that found U full
-                    const unsigned clear = occ & (~want | stored);
+                        const unsigned done = emit_candidates<DRAIN_UNROLL>(p, rc, c, xy, occ, U, sh);
 #pragma unroll
-                    for (int j = 0; j < DRAIN_UNROLL; ++j)
-                        if (clear & (1u << j)) tab[base + j * NT + tid] = EMPTY64;
+                        for (int j = 0; j < DRAIN_UNROLL; ++j)
+                            if (done & (1u << j)) tab[base + j * NT + tid] = EMPTY64;
+                    }
+                    __syncthreads();  // sweep complete (also orders the slot clears before the next window)
+                    const int retry = sh[SH_RETRY];
+                    if (!retry) break;  // uniform
+                    __syncthreads();    // everyone has seen the flag
+                    if (tid == 0) {
+                        sh[SH_RETRY] = 0;
+                        if (sh[SH_CNT] > p.cap) sh[SH_CNT] = p.cap;  // failed appends over-counted
+                    }
+                    __syncthreads();
+                    PHASE_END(PH_DRAIN);
+                    { const long long thr_new = compact_topk<NT>(U, hist, sh, p.k); if (thr_new >= 0) { rc.have_thr = true; rc.thr_key = (unsigned)thr_new; } }
+                    PHASE_END(PH_SELECT);
                 }
-                __syncthreads();  // sweep complete (also orders the slot clears before the next window)
-                const int retry = sh[SH_RETRY];
-                if (!retry) break;  // uniform
-                __syncthreads();    // everyone has seen the flag
-                if (tid == 0) {
-                    sh[SH_RETRY] = 0;
-                    if (sh[SH_CNT] > p.cap) sh[SH_CNT] = p.cap;  // failed appends over-counted
-                }
-                __syncthreads();
                 PHASE_END(PH_DRAIN);
-                compact_topk<NT>(U, hist, sh, p.k, have_thr, thr_key);
-                PHASE_END(PH_SELECT);
+                lo = hi;
             }
-            PHASE_END(PH_DRAIN);
-            lo = hi;
         }
 
         // ================= final selection + write-out =================
         __syncthreads();
-        PHASE_END(PH_DRAIN);
-        if (sh[SH_CNT] > p.k) compact_topk<NT>(U, hist, sh, p.k, have_thr, thr_key);
+        const int n_fin = sh[SH_CNT];
+        __syncthreads();
+        if (n_fin > p.k) { const long long thr_new = compact_topk<NT>(U, hist, sh, p.k); if (thr_new >= 0) { rc.have_thr = true; rc.thr_key = (unsigned)thr_new; } }
         PHASE_END(PH_SELECT);
         const int n_out = sh[SH_CNT];
         const long long o = (long long)slot_i * (long long)p.k;
@@ -635,30 +936,36 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
         __syncthreads();
         PHASE_END(PH_OUTPUT);
     }
-    if (p.count_passes && tid == 0 && local_passes) atomicAdd(&p.queue[1], local_passes);
     if (timing) {
 #pragma unroll
-        for (int i = 0; i < CT_N; ++i) atomicAdd(&p.phase_cycles[i], ph[i]);
+        for (int i = 0; i < PH_N; ++i) atomicAdd(&p.phase_cycles[i], ph[i]);
     }
 #undef PHASE_END
 }
 
-// Work-sorted visiting order: key = MACs(t) clamped to 32 bits, computed per slot.
-__global__ void sp_row_work_kernel(int n_targets, const int *targets, const int *m1_indices, const int *m1_indptr,
-                                   const int *m2_indptr, unsigned *work) {
-    const int gw = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6);
-    const int lane = threadIdx.x & 63;
-    if (gw >= n_targets) return;
-    const int t = targets[gw];
-    const int s = m1_indptr[t], e = m1_indptr[t + 1];
-    u64 acc = 0;
-    for (int j = s + lane; j < e; j += 64) {
-        const int u = m1_indices[j];
-        acc += (u64)(m2_indptr[u + 1] - m2_indptr[u]);
+// Minima of the three column-term vectors over all columns (one workgroup; feeds Epi::upper).
+__global__ __launch_bounds__(1024) void sp_colterm_min_kernel(int n_cols, const float *Ytv, const float *Ycos, const float *Ydep, float *out) {
+    __shared__ float red[3][16];
+    const float inf = __builtin_inff();
+    float m0 = inf, m1 = inf, m2 = inf;
+    for (int i = threadIdx.x; i < n_cols; i += 1024) {
+        if (Ytv) m0 = fminf(m0, Ytv[i]);
+        if (Ycos) m1 = fminf(m1, Ycos[i]);
+        if (Ydep) m2 = fminf(m2, Ydep[i]);
     }
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
-    if (lane == 0) work[gw] = acc > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)acc;
+    for (int d = 32; d > 0; d >>= 1) {
+        m0 = fminf(m0, __shfl_xor(m0, d, 64));
+        m1 = fminf(m1, __shfl_xor(m1, d, 64));
+        m2 = fminf(m2, __shfl_xor(m2, d, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = m0; red[1][threadIdx.x >> 6] = m1; red[2][threadIdx.x >> 6] = m2; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float m = inf;
+        for (int w = 0; w < 16; ++w) m = fminf(m, red[threadIdx.x][w]);
+        out[threadIdx.x] = (m == inf) ? 0.f : m;   // vector not in use (or empty): its weight is 0 anyway
+    }
 }
 
 }  // namespace
@@ -693,12 +1000,15 @@ struct Config {
     size_t ws_total;        // queue + gU (+ order/work when sorted scheduling is on)
 };
 
-constexpr size_t WS_QUEUE_BYTES = 256;
+constexpr size_t WS_QUEUE_BYTES = 256;   // [0,8) row queue | [64,160) phase counters | [176,188) column-term minima
+constexpr size_t WS_PHASE_OFFSET = 64;
+constexpr size_t WS_YMIN_OFFSET = 176;
+static_assert(WS_PHASE_OFFSET + PH_N * 8 <= WS_YMIN_OFFSET && WS_YMIN_OFFSET + 12 <= WS_QUEUE_BYTES, "workspace header layout");
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
 size_t lds_fixed_bytes(int T, int NT) {
-    // keys + vals + seg_lo + seg_pre(+64) + seg_v1 + seg_hi + hist + wsum + sh
-    return (size_t)T * 8 + (size_t)NT * 4 + (size_t)(NT + 64) * 4 + (size_t)NT * 4 + (size_t)NT * 4 + 256 * 4 + 64 * 4 + 16 * 4;
+    // table + seg_lo + seg_pre(+64) + seg_v1 + seg_hi + hist + wsum + sh + ph
+    return (size_t)T * 8 + (size_t)NT * 4 + (size_t)(NT + 64) * 4 + (size_t)NT * 4 + (size_t)NT * 4 + 256 * 4 + 64 * 4 + 16 * 4 + 16 * 8;
 }
 
 int make_config(const sp_knn_args *a, int n_cus, Config *c) {
@@ -813,6 +1123,18 @@ int run_device(sp_knn_args *a) {
 
     HIP_TRY(hipMemsetAsync(ws, 0, WS_QUEUE_BYTES, stream));
 
+    // minima of the column-term vectors feed the gather-free upper bound (Epi::upper); it is sound only
+    // when every weight / shrink is non-negative (NaN parameters fail the comparisons and disable it)
+    const bool bound_ok = (a->l1 >= 0.f) && (a->l2 >= 0.f) && (a->l3 >= 0.f) && (a->t1 >= 0.f) && (a->t2 >= 0.f) &&
+                          (a->stabilized_shrink >= 0.f) && (a->bayesian_shrink >= 0.f);
+    float *ymin_dev = (float *)(ws + WS_YMIN_OFFSET);
+    if (bound_ok && (a->l1 != 0.f || a->l2 != 0.f || a->l3 != 0.f)) {
+        hipLaunchKernelGGL(sp_colterm_min_kernel, dim3(1), dim3(1024), 0, stream, a->n_output_cols,
+                           a->l1 != 0.f ? a->Ytversky : nullptr, a->l2 != 0.f ? a->Ycosine : nullptr,
+                           a->l3 != 0.f ? a->Ydepop : nullptr, ymin_dev);
+        HIP_TRY(hipGetLastError());
+    }
+
     KParams kp;
     memset(&kp, 0, sizeof(kp));
     kp.n_targets = a->n_targets; kp.targets = a->targets;
@@ -832,8 +1154,10 @@ int run_device(sp_knn_args *a) {
     kp.order = nullptr;
     kp.hash_fill = c.hash_fill;
     kp.static_sched = (a->flags & SP_FLAG_STATIC_SCHED) ? 1 : 0;
-    kp.count_passes = timed ? 1 : 0;
-    kp.phase_cycles = timed ? (unsigned long long *)(ws + 64) : nullptr;   // inside the zeroed queue block
+    kp.ymin = ymin_dev;
+    kp.bound_ok = bound_ok ? 1 : 0;
+    kp.sparse_path = (a->flags & SP_FLAG_NO_SPARSE_PATH) ? 0 : 1;
+    kp.phase_cycles = timed ? (unsigned long long *)(ws + WS_PHASE_OFFSET) : nullptr;   // inside the zeroed queue block
     kp.dbg = (int)a->reserved[0];
 
     if (c.NT == 256) rc = c.u_lds ? launch_rows<256, true>(kp, c, stream) : launch_rows<256, false>(kp, c, stream);
@@ -849,10 +1173,10 @@ int run_device(sp_knn_args *a) {
         a->kernel_ms = ms;
         unsigned char qb[WS_QUEUE_BYTES];
         HIP_TRY(hipMemcpy(qb, ws, sizeof(qb), hipMemcpyDeviceToHost));
-        a->passes_total = (int32_t)((unsigned *)qb)[1];
-        const unsigned long long *phc = (const unsigned long long *)(qb + 64);
-        for (int i = 0; i < PH_N && i < 6; ++i) a->phase_cycles[i] = (int64_t)phc[i];
-        for (int i = 0; i < 4; ++i) a->reserved[i] = (int64_t)phc[PH_N + i];   // debug counters: probe rounds, iterations, overflows, sweeps
+        const unsigned long long *phc = (const unsigned long long *)(qb + WS_PHASE_OFFSET);
+        static_assert(PH_N == 12, "sp_knn_args::phase_cycles has 12 entries");
+        for (int i = 0; i < PH_N; ++i) a->phase_cycles[i] = (int64_t)phc[i];
+        a->passes_total = (int32_t)phc[CT_PASSES];
         a->num_wgs_used = c.num_wgs;
         (void)hipEventDestroy(ev0);
         (void)hipEventDestroy(ev1);
