@@ -1,0 +1,33 @@
+#!/bin/bash
+# bash scripts/pmc_gpu.sh <tag> "<counters pass 1>" "<counters pass 2>" ... -- [bench args]
+# Each quoted group is one rocprofv3 --pmc pass (hardware limits: SQ 8, TCC 4 per pass).
+set -u
+TAG=$1; shift
+REPO=$(pwd); OUT=$REPO/gpurun_out/pmc_$TAG; mkdir -p "$OUT"
+export TMPDIR=/tmp; cd /tmp
+PMCG=()
+while [ $# -gt 0 ] && [ "$1" != "--" ]; do PMCG+=("$1"); shift; done
+[ $# -gt 0 ] && shift
+BENCH="python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline $*"
+i=0
+for G in "${PMCG[@]}"; do
+  i=$((i+1))
+  rocprofv3 --pmc $G --kernel-trace --output-format csv -d /tmp/rp_${TAG}_$i -o pmc -- $BENCH > /dev/null 2> "$OUT/pass$i.log"
+  f=$(find /tmp/rp_${TAG}_$i -name "*counter_collection.csv" | head -1)
+  if [ -n "$f" ]; then (head -1 "$f"; grep sp_knn_rows "$f") > "$OUT/pass$i.csv"; fi
+done
+python - "$OUT" <<'PY'
+import csv, sys, glob, collections
+out = sys.argv[1]
+tot = collections.OrderedDict()
+for f in sorted(glob.glob(out + "/pass*.csv")):
+    rows = list(csv.DictReader(open(f)))
+    # one row per (dispatch, counter); keep the LAST dispatch of the kernel (the timed step)
+    if not rows: continue
+    last = max(int(r["Dispatch_Id"]) for r in rows)
+    for r in rows:
+        if int(r["Dispatch_Id"]) == last:
+            tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+for k, v in tot.items():
+    print(f"{k:32s} {v:20.0f}")
+PY

@@ -43,6 +43,7 @@
 #include <string.h>
 #include <stdarg.h>
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/sp_knn.h"
@@ -57,15 +58,16 @@ namespace {
 constexpr int EMPTY = -1;                        // key of a free slot (column ids are >= 0)
 constexpr u64 EMPTY64 = 0xFFFFFFFF00000000ull;   // free accumulator slot: key EMPTY, partial sum +0.0f
 constexpr int MAX_PROBE = 128;   // probe budget of one element before a hashed window is declared overflowed
-constexpr int ACC_UNROLL = 4;    // m2 elements per lane kept in flight
+// m2 elements per lane and trip (two trips are in flight); 1024-thread workgroups have half the VGPR budget
+#define ACC_UNROLL (NT >= 1024 ? 2 : 8)
 constexpr int U_SLACK = 1024;    // candidate-buffer entries beyond k (room between two selections)
 constexpr int CS_TRIES = 8;      // buckets searched in the collision set before giving up (-> generic path)
 // table slots per thread per drain iteration (their Y gathers fly together); 1024-thread workgroups have
 // half the VGPR budget (128), where 8 would spill
-#define DRAIN_UNROLL (NT >= 1024 ? 4 : 8)
+#define DRAIN_UNROLL (NT >= 1024 ? 2 : 8)
 
 // scalar slots in LDS
-enum { SH_CNT = 0, SH_OVF, SH_SEL, SH_NEED, SH_EQ, SH_CNT2, SH_NEXT, SH_RETRY, SH_N };
+enum { SH_CNT = 0, SH_OVF, SH_SEL, SH_NEED, SH_EQ, SH_CNT2, SH_NEXT, SH_RETRY, SH_QCNT, SH_N };   // SH_CNT2/SEL/NEED/EQ belong to compact_topk
 
 // phases timed by lane 0 of every workgroup when KParams::phase_cycles != NULL, then event counters
 enum { PH_SETUP = 0, PH_SEGMENTS, PH_ACCUM, PH_DRAIN, PH_SELECT, PH_OUTPUT, PH_SWEEP1, PH_SWEEP2, PH_CSDRAIN,
@@ -97,7 +99,7 @@ struct KParams {
     int sparse_path;       // 1 = rows with few expected collisions take the bitmap path
     unsigned long long *phase_cycles;  // optional [PH_N]
     int dbg;               // ablation bits for profiling only (results are WRONG when non-zero):
-                           // 1 = generic accumulate: no LDS inserts, 2 = no global loads, 4 = no Y gathers
+                           // 1 = generic accumulate: no LDS inserts, 4 = no Y gathers
 };
 
 // order-preserving float <-> uint map (so radix-select works for negative thresholds too)
@@ -238,7 +240,7 @@ __device__ long long compact_topk(u64 *U, int *hist, int *sh, int k) {
         if (m) {
             int wbase = 0;
             if (lane == 0) wbase = atomicAdd(&sh[SH_CNT2], __popcll(m));
-            wbase = __shfl(wbase, 0, 64);
+            wbase = __builtin_amdgcn_readfirstlane(wbase);
             if (keep) U[wbase + __popcll(m & ((1ull << lane) - 1ull))] = it;
         }
     }
@@ -248,6 +250,13 @@ __device__ long long compact_topk(u64 *U, int *hist, int *sh, int k) {
     return (long long)prefix;
 }
 
+// Top `32 - shift` bits of a multiplicative (Fibonacci) hash of a column id.  A 24-bit multiply would be full
+// rate on CDNA but aliases 4-5x more often on uniformly random columns (simulated), which the bitmap path
+// pays for directly; one quarter-rate v_mul_lo_u32 per hash is the better trade.
+__device__ __forceinline__ unsigned hash_bits(int c, unsigned k, int shift) {
+    return ((unsigned)c * k) >> shift;
+}
+
 // Row-constant state needed to judge candidates.
 struct RowCtx {
     Epi epi;
@@ -255,7 +264,74 @@ struct RowCtx {
     int f0, f1, g0, g1;    // selector row ranges
     bool have_thr;
     unsigned thr_key;
+    float xy_cut;          // a candidate whose raw dot is <= xy_cut cannot enter the top-k (see set_cut)
+
+    // Invert the gather-free upper bound once per (row, running k-th value): the per-product test in the
+    // streaming loops becomes ONE float compare.  Conservative: -inf whenever the inversion is not obviously
+    // sound, in which case everything stays live and is judged exactly later.
+    __device__ __forceinline__ void set_cut(float threshold) {
+        const float ninf = -__builtin_inff();
+        // the value a candidate must beat: > running k-th value (strict) and >= threshold
+        const float below_thr = __uint_as_float(funkey_inv_below(threshold));
+        float t = below_thr;
+        if (have_thr) t = fmaxf(t, funkey(thr_key));
+        xy_cut = ninf;
+        if (!epi.any) { xy_cut = t; return; }                        // value == raw dot, exact
+        if (!epi.bound || epi.a1 != 1.f || !(t >= 0.f) || !(epi.bA > 0.f)) return;
+        // ub(xy) = s*xy / (bA + bB*xy) > t   <=>   xy * (s - t*bB) > t*bA      (denominator > 0 region, s = 1.00002)
+        const float s = 1.00002f;
+        const float d = s - t * epi.bB;
+        if (!(d > 0.f)) return;
+        xy_cut = (t * epi.bA) / d * 0.99998f;                        // shave: roundings of this formula itself
+    }
+    // largest float strictly below x, as the order-preserving key mapped back (helper for set_cut)
+    static __device__ __forceinline__ unsigned funkey_inv_below(float x) {
+        if (!(x == x)) return __float_as_uint(-__builtin_inff());
+        unsigned k = fkey(x);
+        k = (k == 0u) ? 0u : k - 1u;
+        unsigned b = (k & 0x80000000u) ? (k ^ 0x80000000u) : ~k;
+        if (b == 0x80000000u) b = 0x80000001u;   // -0.0 compares equal to +0.0: step on to the next float below
+        return b;
+    }
 };
+
+// Can a candidate with raw dot xy still enter the top-k?  Gather-free: row terms + per-launch column minima.
+__device__ __forceinline__ bool candidate_live(const KParams &p, const RowCtx &rc, float xy) {
+    const float ub = rc.epi.upper(xy);
+    // NaN bounds compare false on `<` and therefore stay live (the exact path drops them)
+    const bool dead = (ub < p.threshold) || (rc.have_thr && fkey(ub) <= rc.thr_key && !(ub != ub));
+    return !dead;
+}
+
+// Append the items flagged in `mask` (bit j = this lane's item j) to an LDS/global list: lane counts ->
+// wave scan -> ONE atomic on the list counter per wave.  store(j, pos) writes item j at list position pos;
+// items that do not fit raise *full_flag.  Must be called from wave-uniform control flow.
+template <int N, typename Store>
+__device__ __forceinline__ void wave_push(unsigned mask, int *counter, int capacity, int *full_flag, Store &&store) {
+    // per-item ballots give every lane its rank without any cross-lane data movement (s_bcnt1 / v_mbcnt),
+    // the reservation is one returning atomic by lane 0, broadcast with v_readfirstlane
+    const int lane = threadIdx.x & 63;
+    u64 m[N];
+    int off[N];
+    int tot = 0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        m[j] = __ballot((mask >> j) & 1u);
+        off[j] = tot;
+        tot += __popcll(m[j]);
+    }
+    if (tot == 0) return;  // wave-uniform
+    int wbase = 0;
+    if (lane == 0) wbase = atomicAdd(counter, tot);
+    wbase = __builtin_amdgcn_readfirstlane(wbase);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        if (mask & (1u << j)) {
+            const int pos = wbase + off[j] + __popcll(m[j] & ((1ull << lane) - 1ull));
+            if (pos < capacity) store(j, pos); else *full_flag = 1;
+        }
+    }
+}
 
 // Judge N candidates (column c[j], raw dot xy[j]; bit j of `occ` = slot j holds one) held per lane and
 // append the survivors to the top-k buffer U.  Order of work: gather-free upper bound -> column selectors
@@ -266,17 +342,10 @@ struct RowCtx {
 template <int N>
 __device__ __forceinline__ unsigned emit_candidates(const KParams &p, const RowCtx &rc, const int (&c)[N], const float (&xy)[N],
                                                     unsigned occ, u64 *U, int *sh) {
-    const int lane = threadIdx.x & 63;
     unsigned live = 0;
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-        if (occ & (1u << j)) {
-            const float ub = rc.epi.upper(xy[j]);
-            // NaN bounds compare false on `<` and therefore stay live (the exact path drops them)
-            const bool dead = (ub < p.threshold) || (rc.have_thr && fkey(ub) <= rc.thr_key && !(ub != ub));
-            if (!dead) live |= 1u << j;
-        }
-    }
+    for (int j = 0; j < N; ++j)
+        if ((occ & (1u << j)) && candidate_live(p, rc, xy[j])) live |= 1u << j;
     if (!__ballot(live != 0)) return occ;  // nothing in this wave can survive: no gathers, no epilogue
 
     if (p.filter_mode == SP_SEL_MATRIX) {
@@ -317,28 +386,12 @@ __device__ __forceinline__ unsigned emit_candidates(const KParams &p, const RowC
         key[j] = fkey(val);
         if ((live & (1u << j)) && (val >= p.threshold) && (!rc.have_thr || key[j] > rc.thr_key)) want |= 1u << j;
     }
-    // one aggregated reservation per wave: lane counts -> wave scan -> single LDS atomic
+    // one aggregated reservation per wave
     unsigned stored = 0;
-    if (__ballot(want != 0)) {
-        const int mine = __popc(want);
-        const int incl = wave_incl_scan(mine);
-        int wbase = 0;
-        if (lane == 63) wbase = atomicAdd(&sh[SH_CNT], incl);
-        wbase = __shfl(wbase, 63, 64);
-        int pos = wbase + incl - mine;
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-            if (want & (1u << j)) {
-                if (pos < p.cap) {
-                    U[pos] = ((u64)key[j] << 32) | (u64)(unsigned)c[j];
-                    stored |= 1u << j;
-                } else {
-                    sh[SH_RETRY] = 1;  // U is full
-                }
-                ++pos;
-            }
-        }
-    }
+    wave_push<N>(want, &sh[SH_CNT], p.cap, &sh[SH_RETRY], [&](int j, int pos) {
+        U[pos] = ((u64)key[j] << 32) | (u64)(unsigned)c[j];
+        stored |= 1u << j;
+    });
     return occ & (~want | stored);
 }
 
@@ -395,10 +448,17 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
 
     // Visit the flat element space [eb, ee) of the current segment list (nb segments, prefix in seg_pre):
     // wave w owns a contiguous 64-aligned chunk, every lane handles ACC_UNROLL stride-64 elements per
-    // trip (coalesced loads), and all lanes of a wave make the same number of trips.
-    // body(idx[], v1[], valid): idx = position in the m2 arrays, v1 = m1 value of the element's segment;
-    // padding elements (bit clear in `valid`) repeat a real element of the lane with v1 = 0.
-    auto for_elements = [&](int eb, int ee, int nb, auto &&body) {
+    // trip (coalesced loads), all lanes of a wave make the same number of trips, and the loads of trip
+    // i+1 are issued before trip i is processed (two register sets, no copies).
+    // Per lane the current segment is cached in registers (end of segment, flat->m2 index delta, m1 value):
+    // the common element costs one compare and one add.  m2 is addressed with 32-bit byte offsets from the
+    // scalar base pointers (the host only launches this kernel for nnz(m2) < 2^30).
+    // body(c[], x[], v1[], valid): c = column id, x = m2 value (0 unless loadx), v1 = m1 value of the
+    // element's segment; padding elements (bit clear in `valid`) repeat a real element of the lane, v1 = 0.
+    const char *m2i_bytes = (const char *)p.m2_indices;
+    const char *m2d_bytes = (const char *)p.m2_data;
+    auto for_elements = [&](auto loadx, int eb, int ee, int nb, auto &&body) {
+        constexpr bool LOADX = decltype(loadx)::value;
         const int span = ee - eb;
         if (span <= 0) return;
         const int chunk = ((span + NW * 64 - 1) / (NW * 64)) * 64;
@@ -412,25 +472,47 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
             if (seg_pre[mid] <= efirst) sl = mid; else sr = mid;
         }
         int seg = sl;
-        const int idx_safe = seg_lo[seg] + (efirst - seg_pre[seg]);
-        for (int ebase = e0; ebase < e1; ebase += 64 * ACC_UNROLL) {
-            int idx[ACC_UNROLL];
-            float v1[ACC_UNROLL];
-            unsigned valid = 0;
+        int seg_end = (seg + 1 < nb) ? seg_pre[seg + 1] : 0x7FFFFFFF;   // first flat index beyond the segment
+        int delta = seg_lo[seg] - seg_pre[seg];                          // m2 position = flat index + delta
+        float segv = seg_v1[seg];
+        const int idx_safe = efirst + delta;
+        auto fetch = [&](int ebase, int (&c)[ACC_UNROLL], float (&x)[ACC_UNROLL], float (&v1)[ACC_UNROLL], unsigned &valid) {
+            unsigned off[ACC_UNROLL];
+            valid = 0;
 #pragma unroll
             for (int j = 0; j < ACC_UNROLL; ++j) {
                 const int ej = ebase + 64 * j + lane;
-                if (ej < e1) {
-                    while (seg + 1 < nb && ej >= seg_pre[seg + 1]) ++seg;
-                    idx[j] = seg_lo[seg] + (ej - seg_pre[seg]);
-                    v1[j] = seg_v1[seg];
-                    valid |= 1u << j;
-                } else {
-                    idx[j] = idx_safe;
-                    v1[j] = 0.f;
+                const bool ok = ej < e1;
+                if (ok && ej >= seg_end) {                 // rare: crossed into a later segment (skips empty ones)
+                    do {
+                        ++seg;
+                        seg_end = (seg + 1 < nb) ? seg_pre[seg + 1] : 0x7FFFFFFF;
+                    } while (ej >= seg_end);
+                    delta = seg_lo[seg] - seg_pre[seg];
+                    segv = seg_v1[seg];
                 }
+                off[j] = (unsigned)(ok ? ej + delta : idx_safe) << 2;
+                v1[j] = ok ? segv : 0.f;
+                valid |= ok ? (1u << j) : 0u;
             }
-            body(idx, v1, valid);
+#pragma unroll
+            for (int j = 0; j < ACC_UNROLL; ++j) c[j] = *(const int *)(m2i_bytes + off[j]);
+#pragma unroll
+            for (int j = 0; j < ACC_UNROLL; ++j) x[j] = LOADX ? *(const float *)(m2d_bytes + off[j]) : 0.f;
+        };
+        constexpr int STEP = 64 * ACC_UNROLL;
+        int cA[ACC_UNROLL], cB[ACC_UNROLL];
+        float xA[ACC_UNROLL], xB[ACC_UNROLL], vA[ACC_UNROLL], vB[ACC_UNROLL];
+        unsigned validA = 0, validB = 0;
+        fetch(e0, cA, xA, vA, validA);
+        for (int ebase = e0; ebase < e1; ebase += 2 * STEP) {
+            const bool hasB = ebase + STEP < e1;          // wave-uniform
+            if (hasB) fetch(ebase + STEP, cB, xB, vB, validB);
+            body(cA, xA, vA, validA);
+            if (hasB) {
+                if (ebase + 2 * STEP < e1) fetch(ebase + 2 * STEP, cA, xA, vA, validA);
+                body(cB, xB, vB, validB);
+            }
         }
     };
 
@@ -479,6 +561,7 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
         epi.bA = p.l1 * (p.t1 * epi.xtv + p.t2 * ymin_tv) + p.l2 * epi.xcos * ymin_cos + p.l3 * epi.xdep * ymin_dep + p.stab;
         epi.bB = p.l1 * (1.f - p.t1 - p.t2);
 
+        rc.set_cut(p.threshold);
         rc.f0 = rc.f1 = rc.g0 = rc.g1 = 0;
         if (p.filter_mode == SP_SEL_MATRIX) { rc.f0 = p.f_indptr[t]; rc.f1 = p.f_indptr[t + 1]; }
         if (p.target_mode == SP_SEL_MATRIX) { rc.g0 = p.t_indptr[t]; rc.g1 = p.t_indptr[t + 1]; }
@@ -520,6 +603,7 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
             // m1 value, so putting the heavy segments first makes the running k-th value rise early and the
             // survivor rate fall monotonically (an unordered row could flood the candidate buffer late)
             int len = 0;
+            if (tid == 0) sh[SH_QCNT] = 0;   // counter of the sweep-1 queue (barriers below publish it)
             {
                 int r0 = 0, mylen = 0;
                 float v = 0.f;
@@ -552,85 +636,124 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
             PHASE_END(PH_SEGMENTS);
 
             // ---- sweep 1: column ids only.  First product of a column sets its bit; a product that finds
-            // the bit set (a second product of the column, or an aliasing column) enters its column in the
-            // collision set.  Every column with >= 2 products ends up in the set. ----
-            for_elements(0, total, n1, [&](const int (&idx)[ACC_UNROLL], const float (&)[ACC_UNROLL], unsigned valid) {
-                int c[ACC_UNROLL];
-#pragma unroll
-                for (int j = 0; j < ACC_UNROLL; ++j) c[j] = p.m2_indices[idx[j]];
+            // the bit set (a second product of the column, or an aliasing column) has its column queued for
+            // the collision set.  Every column with >= 2 products ends up queued at least once.
+            // The queue borrows the (still empty) candidate buffer U; inserting from it afterwards keeps the
+            // streaming loop free of divergent probe loops. ----
+            int *duplist = (int *)U;
+            const int dupcap = 2 * p.cap;
+            for_elements(std::false_type{}, 0, total, n1,
+                         [&](const int (&c)[ACC_UNROLL], const float (&)[ACC_UNROLL], const float (&)[ACC_UNROLL], unsigned valid) {
                 unsigned old[ACC_UNROLL], bit[ACC_UNROLL];
 #pragma unroll
                 for (int j = 0; j < ACC_UNROLL; ++j) {
-                    const unsigned b = ((unsigned)c[j] * 2654435761u) >> bm_shift;
-                    bit[j] = 1u << (b & 31u);
-                    // padding elements repeat a real element of this lane: OR-ing 0 leaves the bitmap alone
-                    old[j] = atomicOr(&bm[b >> 5], (valid & (1u << j)) ? bit[j] : 0u);
+                    const unsigned b = hash_bits(c[j], 2654435761u, bm_shift);
+                    bit[j] = (valid & (1u << j)) ? (1u << (b & 31u)) : 0u;     // padding ORs nothing
+                    old[j] = atomicOr(&bm[b >> 5], bit[j]);
                 }
+                unsigned dup = 0;
 #pragma unroll
-                for (int j = 0; j < ACC_UNROLL; ++j) {
-                    if ((valid & (1u << j)) && (old[j] & bit[j])) {
-                        unsigned bk = ((((unsigned)c[j] * 0x85EBCA6Bu) >> cs_shift) << 2) & cs_mask;
-                        int tries = 0;
-                        for (; tries < 2 * CS_TRIES; ++tries) {
-                            const int4 k4 = *(const int4 *)&cskeys[bk];
-                            if (k4.x == c[j] || k4.y == c[j] || k4.z == c[j] || k4.w == c[j]) break;  // already a member
-                            const int pos = (k4.x == EMPTY) ? 0 : (k4.y == EMPTY) ? 1 : (k4.z == EMPTY) ? 2 : (k4.w == EMPTY) ? 3 : -1;
-                            if (pos < 0) { bk = (bk + 4u) & cs_mask; continue; }          // bucket full: next one
-                            const int prev = atomicCAS(&cskeys[bk + pos], EMPTY, c[j]);
-                            if (prev == EMPTY || prev == c[j]) break;
-                            // lost the slot to another column: look at the same bucket again
-                        }
-                        if (tries == 2 * CS_TRIES) sh[SH_OVF] = 1;
-                    }
-                }
+                for (int j = 0; j < ACC_UNROLL; ++j) dup |= (old[j] & bit[j]) ? (1u << j) : 0u;
+                wave_push<ACC_UNROLL>(dup, &sh[SH_QCNT], dupcap, &sh[SH_OVF], [&](int j, int pos) { duplist[pos] = c[j]; });
             });
             __syncthreads();
-            const int ovf1 = sh[SH_OVF];
+            const int n_dup = sh[SH_QCNT];
+            int ovf1 = sh[SH_OVF];
+            __syncthreads();
+            if (timing) ph[PH_ACCUM] += (u64)n_dup;   // (profiling: queued duplicate sightings; generic-path timer unused here)
+            if (!ovf1) {
+                // dense insertion of the queued columns (duplicates in the queue find themselves already there).
+                // Buckets fill front to back, so "has room" <=> last key empty.
+                for (int i = tid; i < n_dup; i += NT) {
+                    const int cc = duplist[i];
+                    unsigned bk = hash_bits(cc, 0x85EBCA6Bu, cs_shift) << 2;
+                    int tries = 0;
+                    for (; tries < 2 * CS_TRIES; ++tries) {
+                        const int4 k4 = *(const int4 *)&cskeys[bk];
+                        if (k4.x == cc || k4.y == cc || k4.z == cc || k4.w == cc) break;  // already a member
+                        const int pos = (k4.x == EMPTY) ? 0 : (k4.y == EMPTY) ? 1 : (k4.z == EMPTY) ? 2 : (k4.w == EMPTY) ? 3 : -1;
+                        if (pos < 0) { bk = (bk + 4u) & cs_mask; continue; }          // bucket full: next one
+                        const int prev = atomicCAS(&cskeys[bk + pos], EMPTY, cc);
+                        if (prev == EMPTY || prev == cc) break;
+                        // lost the slot to another column: look at the same bucket again
+                    }
+                    if (tries == 2 * CS_TRIES) sh[SH_OVF] = 1;
+                }
+                __syncthreads();
+                ovf1 = sh[SH_OVF];
+                __syncthreads();
+            }
+            if (tid == 0) sh[SH_QCNT] = 0;   // the same counter now serves the survivor queue
             __syncthreads();
             PHASE_END(PH_SWEEP1);
 
             bool failed = (ovf1 != 0);
             if (!failed) {
                 // ---- sweep 2: ids + values.  Members of the collision set accumulate there; every other
-                // product is the only one of its column and is judged on the spot. ----
+                // product is the only one of its column: if the gather-free bound says it can still make the
+                // top-k it is queued (the bitmap's storage is free now) and judged densely after the chunk. ----
+                u64 *Q = (u64 *)bm;
+                const int qcap = T / 2;
                 auto sweep2 = [&](int eb, int ee) {
-                    for_elements(eb, ee, n1, [&](const int (&idx)[ACC_UNROLL], const float (&v1)[ACC_UNROLL], unsigned valid) {
-                        int c[ACC_UNROLL];
+                    for_elements(std::true_type{}, eb, ee, n1,
+                                 [&](const int (&c)[ACC_UNROLL], const float (&xr)[ACC_UNROLL], const float (&v1)[ACC_UNROLL], unsigned valid) {
                         float x[ACC_UNROLL];
-#pragma unroll
-                        for (int j = 0; j < ACC_UNROLL; ++j) { c[j] = p.m2_indices[idx[j]]; x[j] = p.m2_data[idx[j]]; }
                         int4 k4[ACC_UNROLL];
                         unsigned bk[ACC_UNROLL];
 #pragma unroll
                         for (int j = 0; j < ACC_UNROLL; ++j) {
-                            x[j] *= v1[j];
-                            bk[j] = ((((unsigned)c[j] * 0x85EBCA6Bu) >> cs_shift) << 2) & cs_mask;
+                            x[j] = xr[j] * v1[j];
+                            bk[j] = hash_bits(c[j], 0x85EBCA6Bu, cs_shift) << 2;
                             k4[j] = *(const int4 *)&cskeys[bk[j]];
                         }
-                        unsigned single = 0;
+                        // common cases without branches: member of the home bucket / not a member and the home
+                        // bucket has room (so it cannot be further down the chain) / full bucket without a match
+                        unsigned member = 0, chain = 0, live = 0;
 #pragma unroll
                         for (int j = 0; j < ACC_UNROLL; ++j) {
-                            if (!(valid & (1u << j))) continue;
-                            int4 kk = k4[j];
-                            unsigned b = bk[j];
-                            for (int tries = 0;; ++tries) {
-                                const int pos = (kk.x == c[j]) ? 0 : (kk.y == c[j]) ? 1 : (kk.z == c[j]) ? 2 : (kk.w == c[j]) ? 3 : -1;
-                                if (pos >= 0) { atomicAdd(&cssums[b + pos], x[j]); break; }    // collision column
-                                if (kk.x == EMPTY || kk.y == EMPTY || kk.z == EMPTY || kk.w == EMPTY || tries >= 2 * CS_TRIES) {
-                                    single |= 1u << j;                                          // not a member
-                                    break;
+                            const bool hit = (k4[j].x == c[j]) | (k4[j].y == c[j]) | (k4[j].z == c[j]) | (k4[j].w == c[j]);
+                            const bool ok = (valid >> j) & 1u;
+                            member |= (ok && hit) ? (1u << j) : 0u;
+                            chain |= (ok && !hit && k4[j].w != EMPTY) ? (1u << j) : 0u;
+                            // single product of its column: queue it unless its raw dot is below the cutoff
+                            live |= (ok && !hit && k4[j].w == EMPTY && !(x[j] <= rc.xy_cut)) ? (1u << j) : 0u;
+                        }
+                        if (__ballot(member != 0)) {          // ~a few lanes per trip: accumulate in the set
+#pragma unroll
+                            for (int j = 0; j < ACC_UNROLL; ++j) {
+                                if (member & (1u << j)) {
+                                    const int pos = (k4[j].x == c[j]) ? 0 : (k4[j].y == c[j]) ? 1 : (k4[j].z == c[j]) ? 2 : 3;
+                                    atomicAdd(&cssums[bk[j] + pos], x[j]);
                                 }
-                                b = (b + 4u) & cs_mask;                                         // full bucket: chain on
-                                kk = *(const int4 *)&cskeys[b];
                             }
                         }
-                        (void)emit_candidates<ACC_UNROLL>(p, rc, c, x, single, U, sh);
+                        if (__ballot(chain != 0)) {           // rare: home bucket full, walk the chain
+#pragma unroll
+                            for (int j = 0; j < ACC_UNROLL; ++j) {
+                                if (chain & (1u << j)) {
+                                    unsigned b = bk[j];
+                                    for (int tries = 0; tries < 2 * CS_TRIES; ++tries) {
+                                        b = (b + 4u) & cs_mask;
+                                        const int4 kk = *(const int4 *)&cskeys[b];
+                                        const int pos = (kk.x == c[j]) ? 0 : (kk.y == c[j]) ? 1 : (kk.z == c[j]) ? 2 : (kk.w == c[j]) ? 3 : -1;
+                                        if (pos >= 0) { atomicAdd(&cssums[b + pos], x[j]); break; }
+                                        if (kk.w == EMPTY || tries == 2 * CS_TRIES - 1) {
+                                            if (!(x[j] <= rc.xy_cut)) live |= 1u << j;   // not a member after all
+                                            break;
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                        wave_push<ACC_UNROLL>(live, &sh[SH_QCNT], qcap, &sh[SH_RETRY],
+                                              [&](int j, int pos) { Q[pos] = ((u64)(unsigned)c[j] << 32) | (u64)__float_as_uint(x[j]); });
                     });
                 };
                 // The products are offered in growing chunks with a selection after each: the first chunk is
                 // small enough that accepting everything cannot overflow U; once the k-th best of n products
-                // is known, about k*m/n of the next m survive, so a chunk of n*(cap-k)/(2k) keeps the expected
-                // survivors at half the free room.  (An adversarial order can still overflow: -> generic path.)
+                // is known, about k*m/n of the next m survive (fewer: segments come in descending weight), so a
+                // chunk of n*(cap-k)/(2k) keeps the expected survivors at half the free room.
+                // (An adversarial order can still overflow U or the queue: -> generic path.)
                 const int room = p.cap - min(p.k, p.cap - 1);
                 int pos = 0;
                 long long chunk = room;
@@ -638,15 +761,41 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
                     const int end = (int)min((long long)total, (long long)pos + chunk);
                     sweep2(pos, end);
                     __syncthreads();
-                    const int n_now = sh[SH_CNT];
-                    const int retry = sh[SH_RETRY];
+                    const int n_q = sh[SH_QCNT];
+                    int retry = sh[SH_RETRY];
                     __syncthreads();
-                    if (retry) { failed = true; break; }   // U overflowed mid-chunk: dropped products cannot be re-offered
+                    if (retry) { failed = true; break; }   // queue overflowed: dropped products cannot be re-offered
+                    PHASE_END(PH_SWEEP2);
+                    if (timing) ph[CT_PASSES] += (u64)n_q;   // (profiling) queue entries judged
+                    // judge the queued single-product candidates densely: gathers, epilogue, append to U
+                    for (int base = 0; base < n_q; base += NT * ACC_UNROLL) {
+                        int c[ACC_UNROLL];
+                        float xy[ACC_UNROLL];
+                        unsigned occ = 0;
+#pragma unroll
+                        for (int j = 0; j < ACC_UNROLL; ++j) {
+                            const int qi2 = base + j * NT + tid;
+                            const u64 it = (qi2 < n_q) ? Q[qi2] : 0ull;
+                            c[j] = (int)(it >> 32);
+                            xy[j] = __uint_as_float((unsigned)it);
+                            if (qi2 < n_q) occ |= 1u << j;
+                        }
+                        (void)emit_candidates<ACC_UNROLL>(p, rc, c, xy, occ, U, sh);
+                    }
+                    __syncthreads();
+                    const int n_now = sh[SH_CNT];
+                    retry = sh[SH_RETRY];
+                    __syncthreads();
+                    if (retry) { failed = true; break; }   // U overflowed
+                    PHASE_END(PH_DRAIN);                   // (sparse path: time spent judging the queue)
+                    if (tid == 0) sh[SH_QCNT] = 0;
                     pos = end;
                     if (pos < total && n_now > p.k) {
                         PHASE_END(PH_SWEEP2);
-                        { const long long thr_new = compact_topk<NT>(U, hist, sh, p.k); if (thr_new >= 0) { rc.have_thr = true; rc.thr_key = (unsigned)thr_new; } }
+                        { const long long thr_new = compact_topk<NT>(U, hist, sh, p.k); if (thr_new >= 0) { rc.have_thr = true; rc.thr_key = (unsigned)thr_new; rc.set_cut(p.threshold); } }
                         PHASE_END(PH_SELECT);
+                    } else {
+                        __syncthreads();   // counter reset visible before the next chunk pushes
                     }
                     chunk = rc.have_thr ? max((long long)room, (long long)pos * (long long)room / (2ll * (long long)p.k)) : (long long)room;
                 }
@@ -687,7 +836,7 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
                     }
                     __syncthreads();
                     PHASE_END(PH_CSDRAIN);
-                    { const long long thr_new = compact_topk<NT>(U, hist, sh, p.k); if (thr_new >= 0) { rc.have_thr = true; rc.thr_key = (unsigned)thr_new; } }
+                    { const long long thr_new = compact_topk<NT>(U, hist, sh, p.k); if (thr_new >= 0) { rc.have_thr = true; rc.thr_key = (unsigned)thr_new; rc.set_cut(p.threshold); } }
                     PHASE_END(PH_SELECT);
                 }
                 for (int i = tid; i < T; i += NT) bm[i] = 0u;   // bitmap back to clean
@@ -702,6 +851,7 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
                 if (tid == 0) { sh[SH_CNT] = 0; sh[SH_OVF] = 0; sh[SH_RETRY] = 0; }
                 rc.have_thr = false;
                 rc.thr_key = 0;
+                rc.set_cut(p.threshold);
                 __syncthreads();
                 if (timing) ph[CT_ROWS_FALLBACK] += (ovf1 != 0) ? 1ull : (1ull << 32);   // low word: collision set full, high word: U overflow
             }
@@ -774,18 +924,11 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
                     const int total = scan_segments(len);
                     PHASE_END(PH_SEGMENTS);
 
-                    for_elements(0, total, nb, [&](const int (&idx)[ACC_UNROLL], const float (&v1)[ACC_UNROLL], unsigned valid) {
-                        int c[ACC_UNROLL];
+                    for_elements(std::true_type{}, 0, total, nb,
+                                 [&](const int (&c)[ACC_UNROLL], const float (&xr)[ACC_UNROLL], const float (&v1)[ACC_UNROLL], unsigned) {
                         float x[ACC_UNROLL];
-                        if (p.dbg & 2) {
 #pragma unroll
-                            for (int j = 0; j < ACC_UNROLL; ++j) { c[j] = wlo + (int)(((unsigned)idx[j] * 40503u) % (unsigned)(whi - wlo)); x[j] = 1.f; }
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < ACC_UNROLL; ++j) { c[j] = p.m2_indices[idx[j]]; x[j] = p.m2_data[idx[j]]; }
-                        }
-#pragma unroll
-                        for (int j = 0; j < ACC_UNROLL; ++j) x[j] *= v1[j];   // padding elements carry 0
+                        for (int j = 0; j < ACC_UNROLL; ++j) x[j] = xr[j] * v1[j];   // padding elements carry 0
                         if (p.dbg & 1) {
                             float sink = 0.f;
 #pragma unroll
@@ -898,7 +1041,7 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
                     }
                     __syncthreads();
                     PHASE_END(PH_DRAIN);
-                    { const long long thr_new = compact_topk<NT>(U, hist, sh, p.k); if (thr_new >= 0) { rc.have_thr = true; rc.thr_key = (unsigned)thr_new; } }
+                    { const long long thr_new = compact_topk<NT>(U, hist, sh, p.k); if (thr_new >= 0) { rc.have_thr = true; rc.thr_key = (unsigned)thr_new; rc.set_cut(p.threshold); } }
                     PHASE_END(PH_SELECT);
                 }
                 PHASE_END(PH_DRAIN);
@@ -910,7 +1053,7 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
         __syncthreads();
         const int n_fin = sh[SH_CNT];
         __syncthreads();
-        if (n_fin > p.k) { const long long thr_new = compact_topk<NT>(U, hist, sh, p.k); if (thr_new >= 0) { rc.have_thr = true; rc.thr_key = (unsigned)thr_new; } }
+        if (n_fin > p.k) { const long long thr_new = compact_topk<NT>(U, hist, sh, p.k); if (thr_new >= 0) { rc.have_thr = true; rc.thr_key = (unsigned)thr_new; rc.set_cut(p.threshold); } }
         PHASE_END(PH_SELECT);
         const int n_out = sh[SH_CNT];
         const long long o = (long long)slot_i * (long long)p.k;
@@ -1056,6 +1199,9 @@ int validate(const sp_knn_args *a) {
     if (a->k < 1) return fail(SP_EINVAL, "k must be >= 1, got %d", a->k);
     if (a->nnz_m1 < 0 || a->nnz_m2 < 0 || a->nnz_m1 > 0x7FFFFFFFLL || a->nnz_m2 > 0x7FFFFFFFLL)
         return fail(SP_EINVAL, "nnz must fit int32 indptr (reference limit, s_plus.pyx:241-244)");
+    if (a->nnz_m2 >= (1LL << 30))
+        return fail(SP_EINVAL, "nnz(m2) = %lld: this build addresses m2 with 32-bit byte offsets and needs nnz(m2) < 2^30",
+                    (long long)a->nnz_m2);
     if (a->n_targets > 0) {
         if (!a->targets || !a->m1_indptr || !a->m2_indptr || !a->cols || !a->values)
             return fail(SP_EINVAL, "NULL input/output pointer");
@@ -1271,6 +1417,8 @@ int run_host(sp_knn_args *a) {
     if (a->out_counts) HIP_TRY(hipMemcpy(a->out_counts, d.out_counts, nt * sizeof(int32_t), hipMemcpyDeviceToHost));
     a->kernel_ms = d.kernel_ms;
     a->passes_total = d.passes_total;
+    a->num_wgs_used = d.num_wgs_used;
+    memcpy(a->phase_cycles, d.phase_cycles, sizeof(a->phase_cycles));
     return SP_OK;
 }
 
