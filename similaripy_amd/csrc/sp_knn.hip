@@ -59,12 +59,12 @@ constexpr int EMPTY = -1;                        // key of a free slot (column i
 constexpr u64 EMPTY64 = 0xFFFFFFFF00000000ull;   // free accumulator slot: key EMPTY, partial sum +0.0f
 constexpr int MAX_PROBE = 128;   // probe budget of one element before a hashed window is declared overflowed
 // m2 elements per lane and trip (two trips are in flight); 1024-thread workgroups have half the VGPR budget
-#define ACC_UNROLL (NT >= 1024 ? 2 : 8)
+#define ACC_UNROLL (NT >= 1024 ? 2 : NT >= 768 ? 4 : 8)
 constexpr int U_SLACK = 1024;    // candidate-buffer entries beyond k (room between two selections)
 constexpr int CS_TRIES = 8;      // buckets searched in the collision set before giving up (-> generic path)
 // table slots per thread per drain iteration (their Y gathers fly together); 1024-thread workgroups have
 // half the VGPR budget (128), where 8 would spill
-#define DRAIN_UNROLL (NT >= 1024 ? 2 : 8)
+#define DRAIN_UNROLL (NT >= 1024 ? 2 : NT >= 768 ? 4 : 8)
 
 // scalar slots in LDS
 enum { SH_CNT = 0, SH_OVF, SH_SEL, SH_NEED, SH_EQ, SH_CNT2, SH_NEXT, SH_RETRY, SH_QCNT, SH_N };   // SH_CNT2/SEL/NEED/EQ belong to compact_topk
@@ -751,8 +751,8 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
                 };
                 // The products are offered in growing chunks with a selection after each: the first chunk is
                 // small enough that accepting everything cannot overflow U; once the k-th best of n products
-                // is known, about k*m/n of the next m survive (fewer: segments come in descending weight), so a
-                // chunk of n*(cap-k)/(2k) keeps the expected survivors at half the free room.
+                // is known, about k*m/n of the next m would survive in an exchangeable stream — far fewer here,
+                // because segments come in descending weight — so the next chunk may be 4*n*(cap-k)/k long.
                 // (An adversarial order can still overflow U or the queue: -> generic path.)
                 const int room = p.cap - min(p.k, p.cap - 1);
                 int pos = 0;
@@ -797,7 +797,7 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
                     } else {
                         __syncthreads();   // counter reset visible before the next chunk pushes
                     }
-                    chunk = rc.have_thr ? max((long long)room, (long long)pos * (long long)room / (2ll * (long long)p.k)) : (long long)room;
+                    chunk = rc.have_thr ? max((long long)room, 4ll * (long long)pos * (long long)room / (long long)p.k) : (long long)room;
                 }
                 PHASE_END(PH_SWEEP2);
             }
@@ -1155,8 +1155,8 @@ size_t lds_fixed_bytes(int T, int NT) {
 }
 
 int make_config(const sp_knn_args *a, int n_cus, Config *c) {
-    int NT = a->threads_per_wg ? a->threads_per_wg : 512;
-    if (NT != 256 && NT != 512 && NT != 1024) return fail(SP_EINVAL, "threads_per_wg must be 256, 512 or 1024 (got %d)", NT);
+    int NT = a->threads_per_wg ? a->threads_per_wg : 1024;   // measured best on MI355X (16 waves/CU hide the LDS/HBM round trips)
+    if (NT != 256 && NT != 512 && NT != 768 && NT != 1024) return fail(SP_EINVAL, "threads_per_wg must be 256, 512, 768 or 1024 (got %d)", NT);
     int T = a->table_slots ? a->table_slots : 16384;
     if (T < 1024 || (T & (T - 1))) return fail(SP_EINVAL, "table_slots must be a power of two >= 1024 (got %d)", T);
     int logT = 0;
@@ -1308,6 +1308,7 @@ int run_device(sp_knn_args *a) {
 
     if (c.NT == 256) rc = c.u_lds ? launch_rows<256, true>(kp, c, stream) : launch_rows<256, false>(kp, c, stream);
     else if (c.NT == 512) rc = c.u_lds ? launch_rows<512, true>(kp, c, stream) : launch_rows<512, false>(kp, c, stream);
+    else if (c.NT == 768) rc = c.u_lds ? launch_rows<768, true>(kp, c, stream) : launch_rows<768, false>(kp, c, stream);
     else rc = c.u_lds ? launch_rows<1024, true>(kp, c, stream) : launch_rows<1024, false>(kp, c, stream);
     if (rc) { if (own_ws) (void)hipFree(ws); return rc; }
 
