@@ -1,0 +1,100 @@
+"""CPU tier: the C-ABI shared library loads and exports every symbol include/sp_knn.h declares.
+No compute calls (no GPU here); argument validation and the 'no device' refusal are exercised."""
+from __future__ import annotations
+
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from similaripy_amd import _abi, _host
+
+ROOT = Path(__file__).resolve().parent.parent
+HEADER = (ROOT / "include" / "sp_knn.h").read_text()
+
+
+def test_library_builds_and_loads():
+    lib = _abi.load()
+    assert lib.sp_abi_version() == 1
+
+
+def test_every_declared_symbol_is_exported():
+    # function declarations of the header: `<ret> name(args);` at top level
+    declared = set(re.findall(r"^\s*(?:const\s+char\s*\*\s*|int64_t\s+|int\s+)(sp_[a-z0-9_]+)\s*\(", HEADER, flags=re.M))
+    assert declared, "no declarations parsed"
+    assert declared == set(_abi.EXPORTED_SYMBOLS), (declared, _abi.EXPORTED_SYMBOLS)
+    lib = _abi.load()
+    for sym in declared:
+        assert getattr(lib, sym) is not None
+
+
+def test_struct_layout_matches_header_field_order():
+    # every struct field of the header appears, in order, in the ctypes mirror
+    body = HEADER[HEADER.index("typedef struct sp_knn_args {") + len("typedef struct sp_knn_args {"):HEADER.index("} sp_knn_args;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for stmt in body.split(";"):
+        stmt = stmt.strip()
+        if not stmt:
+            continue
+        # "const float *Xtversky, *Ytversky" / "float a1, l1" / "int64_t reserved[4]"
+        first, *rest = stmt.split(",")
+        names.append(re.sub(r"\[.*\]", "", first.split()[-1].lstrip("*")))
+        names += [re.sub(r"\[.*\]", "", r.strip().lstrip("*")) for r in rest]
+    mirror = [f[0] for f in _abi.SpKnnArgs._fields_]
+    assert names == mirror
+
+
+def test_struct_size_is_checked():
+    lib = _abi.load()
+    a = _abi.SpKnnArgs()
+    a.struct_size = 8
+    assert lib.sp_knn_f32_i32(C.byref(a)) == -1          # SP_EINVAL
+    assert b"size mismatch" in lib.sp_last_error()
+
+
+def _call(**kw):
+    m = sp.random_array((30, 20), density=0.2, format="csr", dtype=np.float32, random_state=np.random.default_rng(0))
+    return _host.prepare(m, k=5, **kw)
+
+
+def test_argument_validation_without_device():
+    lib = _abi.load()
+    a = _abi.SpKnnArgs()
+    a.struct_size = C.sizeof(_abi.SpKnnArgs)
+    a.k = 0
+    assert lib.sp_knn_f32_i32(C.byref(a)) == -1 and b"k must be >= 1" in lib.sp_last_error()
+    a.k = 3
+    a.n_targets = 4                                      # but no pointers
+    assert lib.sp_knn_f32_i32(C.byref(a)) == -1 and b"NULL" in lib.sp_last_error()
+
+
+@pytest.mark.skipif(_abi.device_count() > 0, reason="only meaningful on a box without a GPU")
+def test_no_cpu_fallback():
+    """The product path must fail loudly when there is no HIP device."""
+    assert _abi.device_count() == 0
+    with pytest.raises(_abi.HipLibraryError, match="no HIP device"):
+        _host.run_hip(_call())
+    import similaripy_amd as sim
+    m = sp.random_array((30, 20), density=0.2, format="csr", dtype=np.float32, random_state=np.random.default_rng(0))
+    with pytest.raises(_abi.HipLibraryError):
+        sim.cosine(m, k=3, verbose=False)
+
+
+def test_workspace_query():
+    lib = _abi.load()
+    a = _abi.SpKnnArgs()
+    a.k = 100
+    a.n_targets = 0
+    n = _abi.workspace_bytes(a)
+    assert n >= 256
+    a.k = 100000                                          # candidate buffers no longer fit LDS -> global scratch
+    a.n_targets = 1000
+    # pointers are not dereferenced by the query, but validate() wants them non-NULL
+    dummy = np.zeros(4, dtype=np.int32)
+    for f in ("targets", "m1_indptr", "m2_indptr", "cols", "values", "rows"):
+        setattr(a, f, dummy.ctypes.data)
+    assert _abi.workspace_bytes(a) > n

@@ -1,0 +1,192 @@
+"""CPU tier: the Python mirror of the reference's host-side steps, against intermediates captured from
+the reference itself (tests/golden, 'mid/*') and against its documented error behaviour."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import similaripy_amd as sim
+from oracle import splus_oracle as so
+from similaripy_amd import _host
+from similaripy_amd.normalization import normalize
+
+
+def _csr(m):
+    m = m.tocsr()
+    return np.asarray(m.data, np.float32), np.asarray(m.indices, np.int32), np.asarray(m.indptr, np.int32)
+
+
+def test_squared_norms_and_cosine_terms(golden):
+    A = golden.inputs["A"]
+    d1, i1, p1 = _csr(A)
+    d2, i2, p2 = _csr(A.T)
+    sq1, sq2 = _host.build_squared_norms(d1, i1, p1, A.shape[1], d2, i2, p2, A.shape[0])
+    np.testing.assert_allclose(sq1, golden.z["mid/A/sq1"], rtol=1e-6)
+    np.testing.assert_allclose(sq2, golden.z["mid/A/sq2"], rtol=1e-6)
+    xc, yc = _host.build_cosine_normalization(sq1, sq2, 0.2, 0.8, 10.0)
+    np.testing.assert_allclose(xc, golden.z["mid/A/xcos_c0.2_add10"], rtol=1e-6)
+    np.testing.assert_allclose(yc, golden.z["mid/A/ycos_c0.8_add10"], rtol=1e-6)
+    np.testing.assert_allclose(_host.csr_sum(d1, i1, p1, A.shape[1], 1), golden.z["mid/A/rowsum"], rtol=1e-6)
+    np.testing.assert_allclose(_host.csr_sum(d1, i1, p1, A.shape[1], 0), golden.z["mid/A/colsum"], rtol=1e-6)
+
+
+def test_depop_terms(golden):
+    A = golden.inputs["A"]
+    d1, i1, p1 = _csr(A)
+    d2, i2, p2 = _csr(A.T)
+    xd, yd = _host.build_depop_normalization((d1, i1, p1, A.shape[1]), (d2, i2, p2, A.shape[0]),
+                                             A.shape[0], A.shape[0], 'sum', golden.inputs["pop2"], 0.7, 0.3)
+    np.testing.assert_allclose(xd, golden.z["mid/A/xdep_sum_p0.7"], rtol=1e-6)
+    np.testing.assert_allclose(yd, golden.z["mid/A/ydep_pop2_p0.3"], rtol=1e-6)
+    ones, _ = _host.build_depop_normalization((d1, i1, p1, 0), (d2, i2, p2, 0), 7, 9, 'none', 'none', 3.0, 2.0)
+    assert ones.dtype == np.float32 and ones.shape == (7,) and (ones == 1).all()
+    with pytest.raises(ValueError):
+        _host.build_depop_normalization((d1, i1, p1, 0), (d2, i2, p2, 0), 7, 9, 'bogus', 'none', 1, 1)
+
+
+def test_array_selectors(golden):
+    tc = _host.compute_target_columns([2, 3, 400, -1], [1, 2, 3, 4, 5, 6, 299, 300], 300)
+    np.testing.assert_array_equal(tc, golden.z["mid/target_columns"])
+    A = golden.inputs["A"]
+    d2, i2, p2 = _csr(A.T)
+    fd, fi, fp = _host.filter_matrix_columns(d2, i2, p2, 300, tc)
+    np.testing.assert_array_equal(fp, golden.z["mid/AT_filtered/indptr"])
+    np.testing.assert_array_equal(fi, golden.z["mid/AT_filtered/indices"])
+    np.testing.assert_array_equal(fd, golden.z["mid/AT_filtered/data"])
+    # both None / both matrices -> everything
+    np.testing.assert_array_equal(_host.compute_target_columns(None, None, 5), np.arange(5))
+    np.testing.assert_array_equal(_host.compute_target_columns(A, A, 5), np.arange(5))
+
+
+def test_matrix_selector(golden):
+    mode, ip, ix = _host.build_column_selector(golden.inputs["URM"])
+    assert mode == golden.manifest["URM_selector_mode"] == _host.MODE_MATRIX
+    np.testing.assert_array_equal(ip, golden.z["mid/URM_selector/indptr"])
+    np.testing.assert_array_equal(ix, golden.z["mid/URM_selector/indices"])
+    assert _host.build_column_selector(None)[0] == _host.MODE_NONE
+    assert _host.build_column_selector([])[0] == _host.MODE_NONE
+    assert _host.build_column_selector(sp.csr_array((3, 3)))[0] == _host.MODE_NONE      # sparse without data
+    assert _host.build_column_selector([1, 2])[0] == _host.MODE_ARRAY
+    assert _host.build_column_selector(np.array([4]))[0] == _host.MODE_ARRAY
+
+
+@pytest.mark.parametrize("norm", ["l1", "l2", "max"])
+@pytest.mark.parametrize("axis", [0, 1])
+def test_normalize_matches_reference(golden, norm, axis):
+    r = normalize(golden.inputs["E"], norm=norm, axis=axis)
+    r.sort_indices()
+    np.testing.assert_array_equal(r.indptr, golden.z[f"mid/E_norm_{norm}_ax{axis}/indptr"])
+    np.testing.assert_array_equal(r.indices, golden.z[f"mid/E_norm_{norm}_ax{axis}/indices"])
+    np.testing.assert_allclose(r.data, golden.z[f"mid/E_norm_{norm}_ax{axis}/data"], rtol=2e-6)
+
+
+def test_normalize_l1_reference_own_test():
+    """tests/test_normalization.py:12-22 of the reference, restated."""
+    X = sp.random_array((100, 50), density=0.05, format="csr", dtype=np.float32, random_state=np.random.default_rng(42))
+    Xn = normalize(X, norm="l1")
+    expected = X.copy()
+    rs = np.asarray(expected.sum(axis=1)).ravel()
+    rs[rs == 0] = 1
+    expected.data /= np.repeat(rs, np.diff(expected.indptr))
+    np.testing.assert_allclose(Xn.toarray(), expected.toarray(), rtol=1e-5)
+    assert X is not Xn and not np.shares_memory(X.data, Xn.data)          # inplace=False copies
+    with pytest.raises(ValueError):
+        normalize(X, norm="l3")
+    with pytest.raises(ValueError):
+        normalize(X, axis=2)
+    with pytest.raises(TypeError):
+        normalize(np.zeros((3, 3)))
+
+
+def test_validation_errors_match_reference():
+    """s_plus_utils.pyx:19-125: same exception types for the same mistakes."""
+    m = sp.random_array((20, 10), density=0.3, format="csr", dtype=np.float32, random_state=np.random.default_rng(1))
+    with pytest.raises(TypeError):
+        sim.cosine(m.toarray(), verbose=False)
+    with pytest.raises(TypeError):
+        sim.cosine(m, matrix2=m.T.toarray(), verbose=False)
+    with pytest.raises(ValueError, match="Incompatible matrix shapes"):
+        sim.cosine(m, matrix2=m, verbose=False)
+    with pytest.raises(ValueError, match="k must be >= 1"):
+        sim.cosine(m, k=0, verbose=False)
+    with pytest.raises(ValueError):
+        sim.s_plus(m, pop1=np.ones(3), verbose=False)
+    with pytest.raises(ValueError):
+        sim.s_plus(m, pop2="avg", l3=1, verbose=False)
+    with pytest.raises(ValueError, match="target_rows length"):
+        sim.cosine(m, target_rows=list(range(21)), verbose=False)
+    with pytest.raises(TypeError):
+        sim.cosine(m, filter_cols=(1, 2), verbose=False)
+    with pytest.raises(ValueError, match="does not match expected"):
+        sim.cosine(m, filter_cols=sp.csr_array(np.ones((3, 3), np.float32)), verbose=False)
+    with pytest.raises(TypeError, match="verbose must be boolean"):
+        sim.cosine(m, verbose=1)
+    with pytest.raises(ValueError, match="format_output"):
+        sim.cosine(m, format_output="csc", verbose=False)
+    with pytest.raises(ValueError, match="shrink_type"):
+        sim.cosine(m, shrink=1, shrink_type="nope", verbose=False)
+
+
+def test_prepare_does_not_touch_callers_matrices():
+    m = sp.random_array((40, 30), density=0.2, format="csr", dtype=np.float64, random_state=np.random.default_rng(2))
+    m.data[5] = 0.0                                   # explicit zero
+    before = (m.data.copy(), m.indices.copy(), m.indptr.copy())
+    call = _host.prepare(m, k=7, l2=1, binary=True)
+    assert m.data.dtype == np.float64 and np.array_equal(m.data, before[0]) and np.array_equal(m.indices, before[1])
+    assert call.m1_data.dtype == np.float32 and (call.m1_data == 1).all()
+    assert call.m1_data.shape[0] == m.nnz - 1          # the explicit zero is gone from the kernel's view
+    assert call.k == 7 and call.n_output_cols == 40 and call.n_rows_m2 == 30
+
+
+def test_k_clamped_and_targets_dtype():
+    m = sp.random_array((12, 9), density=0.4, format="csr", dtype=np.float32, random_state=np.random.default_rng(3))
+    call = _host.prepare(m, k=500, target_rows=[3, 1])
+    assert call.k == 12 and call.targets.dtype == np.int32 and call.targets.tolist() == [3, 1]
+    with pytest.raises(ValueError):
+        _host.prepare(m, k=3, target_rows=[12])
+
+
+def test_unsorted_m2_rows_get_sorted():
+    m2 = sp.csr_array((np.array([1, 2, 3, 4], np.float32), np.array([5, 1, 3, 0], np.int32), np.array([0, 2, 4], np.int32)), shape=(2, 8))
+    m1 = sp.csr_array(np.ones((3, 2), np.float32))
+    call = _host.prepare(m1, m2, k=4)
+    assert _host._rows_sorted(call.m2_indices, call.m2_indptr)
+    np.testing.assert_array_equal(call.m2_indices, [1, 5, 0, 3])
+    np.testing.assert_array_equal(call.m2_data, [2, 1, 4, 3])
+
+
+def test_trailing_empty_rows_do_not_raise(oracle_backend):
+    """The reference raises IndexError in csr_sum for a trailing empty row (np.add.reduceat index == nnz,
+    s_plus_utils.pyx:154); here the row simply has no neighbours."""
+    m = sp.random_array((30, 20), density=0.2, format="csr", dtype=np.float32, random_state=np.random.default_rng(4)).tolil()
+    m[29, :] = 0
+    m[0, :] = 0
+    m = sp.csr_array(m.tocsr())
+    res = sim.cosine(m, k=5, verbose=False, format_output="csr")
+    assert res[[29], :].nnz == 0 and res[[0], :].nnz == 0
+    S, mask = so.dense_similarity(m, l2=1)
+    got = []
+    for i in range(30):
+        row = res[[i], :].tocoo()
+        o = np.argsort(row.col)
+        got.append((row.col[o].astype(np.int32), row.data[o].astype(np.float32)))
+    so.compare_topk(got, so.dense_topk(S, mask, 5), 5, rtol=3e-5)
+
+
+def test_csr_and_coo_assembly():
+    targets = np.array([4, 1, 1], dtype=np.int32)           # unsorted, repeated
+    k = 3
+    cols = np.array([7, 2, 0, 5, 0, 0, 9, 8, 6], np.int32)
+    vals = np.array([.5, .25, 0, .75, 0, 0, .1, 0.0, .3], np.float32)   # slot 2 holds a genuine zero value
+    counts = np.array([2, 1, 3], np.int32)
+    rows = np.array([4, 4, 0, 1, 0, 0, 1, 1, 1], np.int32)
+    csr = _host.build_csr(targets, cols, vals, counts, k, 6, 10)
+    assert isinstance(csr, sp.csr_array) and csr.shape == (6, 10) and csr.dtype == np.float32
+    dense = np.zeros((6, 10), np.float32)
+    dense[4, 7], dense[4, 2], dense[1, 5], dense[1, 9], dense[1, 6] = .5, .25, .75, .1, .3
+    np.testing.assert_array_equal(csr.toarray(), dense)
+    assert csr.nnz == 5                                       # padding and the genuine zero are eliminated
+    coo = _host.build_coo(rows, cols, vals, 6, 10)
+    assert isinstance(coo, sp.coo_array) and coo.nnz == 9     # padding kept
+    np.testing.assert_array_equal(coo.toarray(), dense)
