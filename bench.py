@@ -212,7 +212,7 @@ def main():
             "rows_per_gpu": n_rows, "cols": n_cols, "nnz_per_row": nnz_row, "k": k,
             "macs_per_row": macs / n_rows,
             "parallelism": f"row-sharded x{world}" + (", gather to rank 0 in the step" if world > 1 else ""),
-            "kept_entries": n_kept, "passes_per_row": info["passes_total"] / n_rows,
+            "kept_entries": n_kept, "generic_windows_per_row": info["passes_total"] / n_rows,
             "phase_share": phase_share(info),
         },
         "roofline": {

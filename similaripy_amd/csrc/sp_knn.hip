@@ -660,7 +660,6 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
             const int n_dup = sh[SH_QCNT];
             int ovf1 = sh[SH_OVF];
             __syncthreads();
-            if (timing) ph[PH_ACCUM] += (u64)n_dup;   // (profiling: queued duplicate sightings; generic-path timer unused here)
             if (!ovf1) {
                 // dense insertion of the queued columns (duplicates in the queue find themselves already there).
                 // Buckets fill front to back, so "has room" <=> last key empty.
@@ -766,7 +765,6 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
                     __syncthreads();
                     if (retry) { failed = true; break; }   // queue overflowed: dropped products cannot be re-offered
                     PHASE_END(PH_SWEEP2);
-                    if (timing) ph[CT_PASSES] += (u64)n_q;   // (profiling) queue entries judged
                     // judge the queued single-product candidates densely: gathers, epilogue, append to U
                     for (int base = 0; base < n_q; base += NT * ACC_UNROLL) {
                         int c[ACC_UNROLL];
