@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--load-pct", type=int, default=0)
     ap.add_argument("--static-sched", action="store_true")
     ap.add_argument("--no-sparse-path", action="store_true", help="force the generic windowed path (A/B)")
+    ap.add_argument("--no-fold", action="store_true", help="do not fold the column term into the m2 stream (A/B)")
     ap.add_argument("--dbg", type=int, default=0, help="kernel ablation bits (profiling only; results invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -135,7 +136,7 @@ def main():
     prob = DeviceProblem(call, dev)
     cols, vals, counts, _ = prob.alloc_outputs()
     tuning = dict(table_slots=args.table_slots, threads_per_wg=args.threads, num_wgs=args.num_wgs, load_pct=args.load_pct, dbg=args.dbg,
-                  no_sparse_path=args.no_sparse_path)
+                  no_sparse_path=args.no_sparse_path, no_fold=args.no_fold)
 
     gathered = None
     if world > 1 and rank == 0:

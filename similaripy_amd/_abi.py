@@ -18,6 +18,7 @@ SP_FLAG_TIME_KERNEL = 1
 SP_FLAG_NO_ROWS_OUT = 2
 SP_FLAG_STATIC_SCHED = 4
 SP_FLAG_NO_SPARSE_PATH = 8
+SP_FLAG_NO_FOLD = 16
 
 _c_f32p = C.POINTER(C.c_float)
 _c_i32p = C.POINTER(C.c_int32)

@@ -97,6 +97,7 @@ struct KParams {
     const float *ymin;     // [3] minima of Ytv / Ycos / Ydep over all columns (valid iff bound_ok)
     int bound_ok;          // weights/shrinks are all >= 0: the epilogue upper bound is sound
     int sparse_path;       // 1 = rows with few expected collisions take the bitmap path
+    int fold;              // 1 = the single active column term (Ycos or Ydep) is already divided into m2_data: treat it as 1
     unsigned long long *phase_cycles;  // optional [PH_N]
     int dbg;               // ablation bits for profiling only (results are WRONG when non-zero):
                            // 1 = generic accumulate: no LDS inserts, 4 = no Y gathers
@@ -372,11 +373,11 @@ __device__ __forceinline__ unsigned emit_candidates(const KParams &p, const RowC
     }
     if (p.l2 != 0.f) {
 #pragma unroll
-        for (int j = 0; j < N; ++j) ycos[j] = p.Ycos[gc[j]];
+        for (int j = 0; j < N; ++j) ycos[j] = p.fold ? 1.f : p.Ycos[gc[j]];
     }
     if (p.l3 != 0.f) {
 #pragma unroll
-        for (int j = 0; j < N; ++j) ydep[j] = p.Ydep[gc[j]];
+        for (int j = 0; j < N; ++j) ydep[j] = p.fold ? 1.f : p.Ydep[gc[j]];
     }
     unsigned want = 0;
     unsigned key[N];
@@ -437,7 +438,10 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
 
     const bool any_norm = (p.l1 != 0.f || p.l2 != 0.f || p.l3 != 0.f || p.stab != 0.f || p.bayes != 0.f);
     float ymin_tv = 0.f, ymin_cos = 0.f, ymin_dep = 0.f;
-    if (p.bound_ok) { ymin_tv = p.ymin[0]; ymin_cos = p.ymin[1]; ymin_dep = p.ymin[2]; }
+    if (p.bound_ok) {
+        if (p.fold) { ymin_cos = 1.f; ymin_dep = 1.f; }     // folded column term: exactly 1 for every column
+        else { ymin_tv = p.ymin[0]; ymin_cos = p.ymin[1]; ymin_dep = p.ymin[2]; }
+    }
 
     // phase timers (lane 0 only; s_memtime ticks are shader cycles)
     const bool timing = (p.phase_cycles != nullptr) && tid == 0;
@@ -1109,6 +1113,17 @@ __global__ __launch_bounds__(1024) void sp_colterm_min_kernel(int n_cols, const 
     }
 }
 
+// Fold the column term of a product-form epilogue into the m2 stream:  out[i] = data[i] / Y[indices[i]]
+// (0 where Y is 0: the reference returns 0 for a zero denominator, s_plus.h:147-150).  One streaming pass.
+__global__ __launch_bounds__(256) void sp_fold_colterm_kernel(long long nnz, const int *__restrict__ indices,
+                                                               const float *__restrict__ data, const float *__restrict__ Y,
+                                                               float *__restrict__ out) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nnz; i += (long long)gridDim.x * blockDim.x) {
+        const float y = Y[indices[i]];
+        out[i] = (y != 0.f) ? data[i] / y : 0.f;
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -1138,7 +1153,9 @@ struct Config {
     bool u_lds;
     size_t lds_bytes;
     size_t ws_gu_bytes;     // candidate buffers in global memory (0 when in LDS)
-    size_t ws_total;        // queue + gU (+ order/work when sorted scheduling is on)
+    size_t ws_fold_bytes;   // scaled copy of m2_data when the column term is folded in (0 otherwise)
+    size_t ws_total;        // header + gU + fold scratch
+    bool fold;
 };
 
 constexpr size_t WS_QUEUE_BYTES = 256;   // [0,8) row queue | [64,160) phase counters | [176,188) column-term minima
@@ -1184,7 +1201,12 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
     num_wgs = std::max(1, std::min(num_wgs, std::max(1, a->n_targets)));
     c->num_wgs = num_wgs;
     c->ws_gu_bytes = u_lds ? 0 : (size_t)num_wgs * (size_t)cap * 8;
-    c->ws_total = WS_QUEUE_BYTES + c->ws_gu_bytes;
+    // product-form epilogue  val = xy / (l * X[t] * Y[c])  (cosine, asymmetric cosine, rp3beta without shrink):
+    // Y is divided into the m2 values once per call, the kernel then needs no column-term gathers at all
+    c->fold = !(a->flags & SP_FLAG_NO_FOLD) && a->l1 == 0.f && a->a1 == 1.f && a->stabilized_shrink == 0.f &&
+              a->bayesian_shrink == 0.f && ((a->l2 != 0.f) != (a->l3 != 0.f)) && a->nnz_m2 > 0;
+    c->ws_fold_bytes = c->fold ? (((size_t)a->nnz_m2 * 4 + 255) & ~(size_t)255) : 0;
+    c->ws_total = WS_QUEUE_BYTES + ((c->ws_gu_bytes + 255) & ~(size_t)255) + c->ws_fold_bytes;
     return SP_OK;
 }
 
@@ -1272,7 +1294,13 @@ int run_device(sp_knn_args *a) {
     const bool bound_ok = (a->l1 >= 0.f) && (a->l2 >= 0.f) && (a->l3 >= 0.f) && (a->t1 >= 0.f) && (a->t2 >= 0.f) &&
                           (a->stabilized_shrink >= 0.f) && (a->bayesian_shrink >= 0.f);
     float *ymin_dev = (float *)(ws + WS_YMIN_OFFSET);
-    if (bound_ok && (a->l1 != 0.f || a->l2 != 0.f || a->l3 != 0.f)) {
+    float *folded = nullptr;
+    if (c.fold) {
+        folded = (float *)(ws + WS_QUEUE_BYTES + ((c.ws_gu_bytes + 255) & ~(size_t)255));
+        hipLaunchKernelGGL(sp_fold_colterm_kernel, dim3(256 * 8), dim3(256), 0, stream, (long long)a->nnz_m2, a->m2_indices,
+                           a->m2_data, a->l2 != 0.f ? a->Ycosine : a->Ydepop, folded);
+        HIP_TRY(hipGetLastError());
+    } else if (bound_ok && (a->l1 != 0.f || a->l2 != 0.f || a->l3 != 0.f)) {
         hipLaunchKernelGGL(sp_colterm_min_kernel, dim3(1), dim3(1024), 0, stream, a->n_output_cols,
                            a->l1 != 0.f ? a->Ytversky : nullptr, a->l2 != 0.f ? a->Ycosine : nullptr,
                            a->l3 != 0.f ? a->Ydepop : nullptr, ymin_dev);
@@ -1301,6 +1329,8 @@ int run_device(sp_knn_args *a) {
     kp.ymin = ymin_dev;
     kp.bound_ok = bound_ok ? 1 : 0;
     kp.sparse_path = (a->flags & SP_FLAG_NO_SPARSE_PATH) ? 0 : 1;
+    kp.fold = c.fold ? 1 : 0;
+    if (c.fold) kp.m2_data = folded;
     kp.phase_cycles = timed ? (unsigned long long *)(ws + WS_PHASE_OFFSET) : nullptr;   // inside the zeroed queue block
     kp.dbg = (int)a->reserved[0];
 

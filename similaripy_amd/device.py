@@ -99,6 +99,8 @@ class DeviceProblem:
         flags = (_abi.SP_FLAG_TIME_KERNEL if time_kernel else 0) | (_abi.SP_FLAG_STATIC_SCHED if static_sched else 0)
         if tuning.get("no_sparse_path"):
             flags |= _abi.SP_FLAG_NO_SPARSE_PATH
+        if tuning.get("no_fold"):
+            flags |= _abi.SP_FLAG_NO_FOLD
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream().cuda_stream
             a = self._args(targets_t, n, cols, vals, counts, rows, stream, flags, tuning)
