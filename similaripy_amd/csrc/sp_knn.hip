@@ -60,6 +60,8 @@ constexpr u64 EMPTY64 = 0xFFFFFFFF00000000ull;   // free accumulator slot: key E
 constexpr int MAX_PROBE = 128;   // probe budget of one element before a hashed window is declared overflowed
 // m2 elements per lane and trip (two trips are in flight); 1024-thread workgroups have half the VGPR budget
 #define ACC_UNROLL (NT >= 1024 ? 2 : NT >= 768 ? 4 : 8)
+// the sparse sweeps are lighter on registers than the generic accumulate: they can keep more elements in flight
+#define SPARSE_UNROLL (NT >= 768 ? 4 : 8)
 constexpr int U_SLACK = 1024;    // candidate-buffer entries beyond k (room between two selections)
 constexpr int CS_TRIES = 8;      // buckets searched in the collision set before giving up (-> generic path)
 // table slots per thread per drain iteration (their Y gathers fly together); 1024-thread workgroups have
@@ -461,12 +463,13 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
     // element's segment; padding elements (bit clear in `valid`) repeat a real element of the lane, v1 = 0.
     const char *m2i_bytes = (const char *)p.m2_indices;
     const char *m2d_bytes = (const char *)p.m2_data;
-    auto for_elements = [&](auto loadx, int eb, int ee, int nb, auto &&body) {
+    auto for_elements = [&](auto loadx, auto unroll, int eb, int ee, int nb, auto &&body) __attribute__((always_inline)) {
         constexpr bool LOADX = decltype(loadx)::value;
+        constexpr int AU = decltype(unroll)::value;
         const int span = ee - eb;
         if (span <= 0) return;
         const int chunk = ((span + NW * 64 - 1) / (NW * 64)) * 64;
-        const int e0 = eb + wave * chunk;
+        const int e0 = eb + __builtin_amdgcn_readfirstlane(wave) * chunk;
         const int e1 = min(e0 + chunk, ee);
         if (e0 >= e1) return;  // wave-uniform
         const int efirst = min(e0 + lane, e1 - 1);
@@ -480,11 +483,11 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
         int delta = seg_lo[seg] - seg_pre[seg];                          // m2 position = flat index + delta
         float segv = seg_v1[seg];
         const int idx_safe = efirst + delta;
-        auto fetch = [&](int ebase, int (&c)[ACC_UNROLL], float (&x)[ACC_UNROLL], float (&v1)[ACC_UNROLL], unsigned &valid) {
-            unsigned off[ACC_UNROLL];
+        auto fetch = [&](int ebase, int (&c)[AU], float (&x)[AU], float (&v1)[AU], unsigned &valid) {
+            unsigned off[AU];
             valid = 0;
 #pragma unroll
-            for (int j = 0; j < ACC_UNROLL; ++j) {
+            for (int j = 0; j < AU; ++j) {
                 const int ej = ebase + 64 * j + lane;
                 const bool ok = ej < e1;
                 if (ok && ej >= seg_end) {                 // rare: crossed into a later segment (skips empty ones)
@@ -500,13 +503,13 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
                 valid |= ok ? (1u << j) : 0u;
             }
 #pragma unroll
-            for (int j = 0; j < ACC_UNROLL; ++j) c[j] = *(const int *)(m2i_bytes + off[j]);
+            for (int j = 0; j < AU; ++j) c[j] = *(const int *)(m2i_bytes + off[j]);
 #pragma unroll
-            for (int j = 0; j < ACC_UNROLL; ++j) x[j] = LOADX ? *(const float *)(m2d_bytes + off[j]) : 0.f;
+            for (int j = 0; j < AU; ++j) x[j] = LOADX ? *(const float *)(m2d_bytes + off[j]) : 0.f;
         };
-        constexpr int STEP = 64 * ACC_UNROLL;
-        int cA[ACC_UNROLL], cB[ACC_UNROLL];
-        float xA[ACC_UNROLL], xB[ACC_UNROLL], vA[ACC_UNROLL], vB[ACC_UNROLL];
+        constexpr int STEP = 64 * AU;
+        int cA[AU], cB[AU];
+        float xA[AU], xB[AU], vA[AU], vB[AU];
         unsigned validA = 0, validB = 0;
         fetch(e0, cA, xA, vA, validA);
         for (int ebase = e0; ebase < e1; ebase += 2 * STEP) {
@@ -534,16 +537,18 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
         }
         seg_pre[tid] = woff + incl - len;
         __syncthreads();
-        return total;
+        return __builtin_amdgcn_readfirstlane(total);
     };
 
     for (;;) {
-        const int qi = sh[SH_NEXT];
+        // row-constant values are wave-uniform: v_readfirstlane moves them to scalar registers, which frees
+        // vector registers for the streaming loops
+        const int qi = __builtin_amdgcn_readfirstlane(sh[SH_NEXT]);
         if (qi >= p.n_targets) break;
-        const int slot_i = p.order ? p.order[qi] : qi;
-        const int t = p.targets[slot_i];
-        const int s1 = p.m1_indptr[t];
-        const int n1 = p.m1_indptr[t + 1] - s1;
+        const int slot_i = p.order ? __builtin_amdgcn_readfirstlane(p.order[qi]) : qi;
+        const int t = __builtin_amdgcn_readfirstlane(p.targets[slot_i]);
+        const int s1 = __builtin_amdgcn_readfirstlane(p.m1_indptr[t]);
+        const int n1 = __builtin_amdgcn_readfirstlane(p.m1_indptr[t + 1]) - s1;
 
         // prefetch the next queue entry early; it is consumed at the bottom of the loop
         int next_q = 0;
@@ -556,9 +561,12 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
         Epi &epi = rc.epi;
         epi.a1 = p.a1; epi.l1 = p.l1; epi.l2 = p.l2; epi.l3 = p.l3; epi.t1 = p.t1; epi.t2 = p.t2;
         epi.stab = p.stab; epi.bayes = p.bayes; epi.threshold = p.threshold; epi.any = any_norm;
-        epi.xtv = (p.l1 != 0.f) ? p.Xtv[t] : 0.f;
-        epi.xcos = (p.l2 != 0.f) ? p.Xcos[t] : 0.f;
-        epi.xdep = (p.l3 != 0.f) ? p.Xdep[t] : 0.f;
+        auto rflf = [](float v) __attribute__((always_inline)) {
+            return __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v)));
+        };
+        epi.xtv = (p.l1 != 0.f) ? rflf(p.Xtv[t]) : 0.f;
+        epi.xcos = (p.l2 != 0.f) ? rflf(p.Xcos[t]) : 0.f;
+        epi.xdep = (p.l3 != 0.f) ? rflf(p.Xdep[t]) : 0.f;
         // den = l1*(t1*(X-xy) + t2*(Y-xy) + xy) + l2*Xc*Yc + l3*Xd*Yd + stab  >=  bA + bB*xy  when the
         // column terms are replaced by their minima and their multipliers are non-negative
         epi.bound = p.bound_ok && !(epi.xcos < 0.f) && !(epi.xdep < 0.f);
@@ -567,8 +575,8 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
 
         rc.set_cut(p.threshold);
         rc.f0 = rc.f1 = rc.g0 = rc.g1 = 0;
-        if (p.filter_mode == SP_SEL_MATRIX) { rc.f0 = p.f_indptr[t]; rc.f1 = p.f_indptr[t + 1]; }
-        if (p.target_mode == SP_SEL_MATRIX) { rc.g0 = p.t_indptr[t]; rc.g1 = p.t_indptr[t + 1]; }
+        if (p.filter_mode == SP_SEL_MATRIX) { rc.f0 = __builtin_amdgcn_readfirstlane(p.f_indptr[t]); rc.f1 = __builtin_amdgcn_readfirstlane(p.f_indptr[t + 1]); }
+        if (p.target_mode == SP_SEL_MATRIX) { rc.g0 = __builtin_amdgcn_readfirstlane(p.t_indptr[t]); rc.g1 = __builtin_amdgcn_readfirstlane(p.t_indptr[t + 1]); }
 
         // ---- work estimate: MACs(t) = sum_u nnz(m2 row u) (upper bound on distinct candidates) ----
         u64 macs_local = 0;
@@ -582,6 +590,7 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
         __syncthreads();
         u64 macs = 0;
         for (int w = 0; w < NW; ++w) macs += ((u64 *)wsum)[w];
+        macs = ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(macs >> 32)) << 32) | (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)macs);
         __syncthreads();
         PHASE_END(PH_SETUP);
 
@@ -646,19 +655,19 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
             // streaming loop free of divergent probe loops. ----
             int *duplist = (int *)U;
             const int dupcap = 2 * p.cap;
-            for_elements(std::false_type{}, 0, total, n1,
-                         [&](const int (&c)[ACC_UNROLL], const float (&)[ACC_UNROLL], const float (&)[ACC_UNROLL], unsigned valid) {
-                unsigned old[ACC_UNROLL], bit[ACC_UNROLL];
+            for_elements(std::false_type{}, std::integral_constant<int, SPARSE_UNROLL>{}, 0, total, n1,
+                         [&](const int (&c)[SPARSE_UNROLL], const float (&)[SPARSE_UNROLL], const float (&)[SPARSE_UNROLL], unsigned valid) __attribute__((always_inline)) {
+                unsigned old[SPARSE_UNROLL], bit[SPARSE_UNROLL];
 #pragma unroll
-                for (int j = 0; j < ACC_UNROLL; ++j) {
+                for (int j = 0; j < SPARSE_UNROLL; ++j) {
                     const unsigned b = hash_bits(c[j], 2654435761u, bm_shift);
                     bit[j] = (valid & (1u << j)) ? (1u << (b & 31u)) : 0u;     // padding ORs nothing
                     old[j] = atomicOr(&bm[b >> 5], bit[j]);
                 }
                 unsigned dup = 0;
 #pragma unroll
-                for (int j = 0; j < ACC_UNROLL; ++j) dup |= (old[j] & bit[j]) ? (1u << j) : 0u;
-                wave_push<ACC_UNROLL>(dup, &sh[SH_QCNT], dupcap, &sh[SH_OVF], [&](int j, int pos) { duplist[pos] = c[j]; });
+                for (int j = 0; j < SPARSE_UNROLL; ++j) dup |= (old[j] & bit[j]) ? (1u << j) : 0u;
+                wave_push<SPARSE_UNROLL>(dup, &sh[SH_QCNT], dupcap, &sh[SH_OVF], [&](int j, int pos) { duplist[pos] = c[j]; });
             });
             __syncthreads();
             const int n_dup = sh[SH_QCNT];
@@ -698,13 +707,13 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
                 u64 *Q = (u64 *)bm;
                 const int qcap = T / 2;
                 auto sweep2 = [&](int eb, int ee) {
-                    for_elements(std::true_type{}, eb, ee, n1,
-                                 [&](const int (&c)[ACC_UNROLL], const float (&xr)[ACC_UNROLL], const float (&v1)[ACC_UNROLL], unsigned valid) {
-                        float x[ACC_UNROLL];
-                        int4 k4[ACC_UNROLL];
-                        unsigned bk[ACC_UNROLL];
+                    for_elements(std::true_type{}, std::integral_constant<int, SPARSE_UNROLL>{}, eb, ee, n1,
+                                 [&](const int (&c)[SPARSE_UNROLL], const float (&xr)[SPARSE_UNROLL], const float (&v1)[SPARSE_UNROLL], unsigned valid) __attribute__((always_inline)) {
+                        float x[SPARSE_UNROLL];
+                        int4 k4[SPARSE_UNROLL];
+                        unsigned bk[SPARSE_UNROLL];
 #pragma unroll
-                        for (int j = 0; j < ACC_UNROLL; ++j) {
+                        for (int j = 0; j < SPARSE_UNROLL; ++j) {
                             x[j] = xr[j] * v1[j];
                             bk[j] = hash_bits(c[j], 0x85EBCA6Bu, cs_shift) << 2;
                             k4[j] = *(const int4 *)&cskeys[bk[j]];
@@ -713,7 +722,7 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
                         // bucket has room (so it cannot be further down the chain) / full bucket without a match
                         unsigned member = 0, chain = 0, live = 0;
 #pragma unroll
-                        for (int j = 0; j < ACC_UNROLL; ++j) {
+                        for (int j = 0; j < SPARSE_UNROLL; ++j) {
                             const bool hit = (k4[j].x == c[j]) | (k4[j].y == c[j]) | (k4[j].z == c[j]) | (k4[j].w == c[j]);
                             const bool ok = (valid >> j) & 1u;
                             member |= (ok && hit) ? (1u << j) : 0u;
@@ -723,7 +732,7 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
                         }
                         if (__ballot(member != 0)) {          // ~a few lanes per trip: accumulate in the set
 #pragma unroll
-                            for (int j = 0; j < ACC_UNROLL; ++j) {
+                            for (int j = 0; j < SPARSE_UNROLL; ++j) {
                                 if (member & (1u << j)) {
                                     const int pos = (k4[j].x == c[j]) ? 0 : (k4[j].y == c[j]) ? 1 : (k4[j].z == c[j]) ? 2 : 3;
                                     atomicAdd(&cssums[bk[j] + pos], x[j]);
@@ -732,7 +741,7 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
                         }
                         if (__ballot(chain != 0)) {           // rare: home bucket full, walk the chain
 #pragma unroll
-                            for (int j = 0; j < ACC_UNROLL; ++j) {
+                            for (int j = 0; j < SPARSE_UNROLL; ++j) {
                                 if (chain & (1u << j)) {
                                     unsigned b = bk[j];
                                     for (int tries = 0; tries < 2 * CS_TRIES; ++tries) {
@@ -748,7 +757,7 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
                                 }
                             }
                         }
-                        wave_push<ACC_UNROLL>(live, &sh[SH_QCNT], qcap, &sh[SH_RETRY],
+                        wave_push<SPARSE_UNROLL>(live, &sh[SH_QCNT], qcap, &sh[SH_RETRY],
                                               [&](int j, int pos) { Q[pos] = ((u64)(unsigned)c[j] << 32) | (u64)__float_as_uint(x[j]); });
                     });
                 };
@@ -770,19 +779,19 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
                     if (retry) { failed = true; break; }   // queue overflowed: dropped products cannot be re-offered
                     PHASE_END(PH_SWEEP2);
                     // judge the queued single-product candidates densely: gathers, epilogue, append to U
-                    for (int base = 0; base < n_q; base += NT * ACC_UNROLL) {
-                        int c[ACC_UNROLL];
-                        float xy[ACC_UNROLL];
+                    for (int base = 0; base < n_q; base += NT * SPARSE_UNROLL) {
+                        int c[SPARSE_UNROLL];
+                        float xy[SPARSE_UNROLL];
                         unsigned occ = 0;
 #pragma unroll
-                        for (int j = 0; j < ACC_UNROLL; ++j) {
+                        for (int j = 0; j < SPARSE_UNROLL; ++j) {
                             const int qi2 = base + j * NT + tid;
                             const u64 it = (qi2 < n_q) ? Q[qi2] : 0ull;
                             c[j] = (int)(it >> 32);
                             xy[j] = __uint_as_float((unsigned)it);
                             if (qi2 < n_q) occ |= 1u << j;
                         }
-                        (void)emit_candidates<ACC_UNROLL>(p, rc, c, xy, occ, U, sh);
+                        (void)emit_candidates<SPARSE_UNROLL>(p, rc, c, xy, occ, U, sh);
                     }
                     __syncthreads();
                     const int n_now = sh[SH_CNT];
@@ -794,7 +803,7 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
                     pos = end;
                     if (pos < total && n_now > p.k) {
                         PHASE_END(PH_SWEEP2);
-                        { const long long thr_new = compact_topk<NT>(U, hist, sh, p.k); if (thr_new >= 0) { rc.have_thr = true; rc.thr_key = (unsigned)thr_new; rc.set_cut(p.threshold); } }
+                        { const long long thr_new = compact_topk<NT>(U, hist, sh, p.k); if (thr_new >= 0) { rc.have_thr = true; rc.thr_key = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)thr_new); rc.set_cut(p.threshold); } }
                         PHASE_END(PH_SELECT);
                     } else {
                         __syncthreads();   // counter reset visible before the next chunk pushes
@@ -838,7 +847,7 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
                     }
                     __syncthreads();
                     PHASE_END(PH_CSDRAIN);
-                    { const long long thr_new = compact_topk<NT>(U, hist, sh, p.k); if (thr_new >= 0) { rc.have_thr = true; rc.thr_key = (unsigned)thr_new; rc.set_cut(p.threshold); } }
+                    { const long long thr_new = compact_topk<NT>(U, hist, sh, p.k); if (thr_new >= 0) { rc.have_thr = true; rc.thr_key = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)thr_new); rc.set_cut(p.threshold); } }
                     PHASE_END(PH_SELECT);
                 }
                 for (int i = tid; i < T; i += NT) bm[i] = 0u;   // bitmap back to clean
@@ -926,7 +935,7 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
                     const int total = scan_segments(len);
                     PHASE_END(PH_SEGMENTS);
 
-                    for_elements(std::true_type{}, 0, total, nb,
+                    for_elements(std::true_type{}, std::integral_constant<int, ACC_UNROLL>{}, 0, total, nb,
                                  [&](const int (&c)[ACC_UNROLL], const float (&xr)[ACC_UNROLL], const float (&v1)[ACC_UNROLL], unsigned) {
                         float x[ACC_UNROLL];
 #pragma unroll
@@ -1043,7 +1052,7 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
                     }
                     __syncthreads();
                     PHASE_END(PH_DRAIN);
-                    { const long long thr_new = compact_topk<NT>(U, hist, sh, p.k); if (thr_new >= 0) { rc.have_thr = true; rc.thr_key = (unsigned)thr_new; rc.set_cut(p.threshold); } }
+                    { const long long thr_new = compact_topk<NT>(U, hist, sh, p.k); if (thr_new >= 0) { rc.have_thr = true; rc.thr_key = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)thr_new); rc.set_cut(p.threshold); } }
                     PHASE_END(PH_SELECT);
                 }
                 PHASE_END(PH_DRAIN);
@@ -1055,7 +1064,7 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
         __syncthreads();
         const int n_fin = sh[SH_CNT];
         __syncthreads();
-        if (n_fin > p.k) { const long long thr_new = compact_topk<NT>(U, hist, sh, p.k); if (thr_new >= 0) { rc.have_thr = true; rc.thr_key = (unsigned)thr_new; rc.set_cut(p.threshold); } }
+        if (n_fin > p.k) { const long long thr_new = compact_topk<NT>(U, hist, sh, p.k); if (thr_new >= 0) { rc.have_thr = true; rc.thr_key = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)thr_new); rc.set_cut(p.threshold); } }
         PHASE_END(PH_SELECT);
         const int n_out = sh[SH_CNT];
         const long long o = (long long)slot_i * (long long)p.k;
