@@ -69,7 +69,7 @@ constexpr int CS_TRIES = 8;      // buckets searched in the collision set before
 #define DRAIN_UNROLL (NT >= 1024 ? 2 : NT >= 768 ? 4 : 8)
 
 // scalar slots in LDS
-enum { SH_CNT = 0, SH_OVF, SH_SEL, SH_NEED, SH_EQ, SH_CNT2, SH_NEXT, SH_RETRY, SH_QCNT, SH_N };   // SH_CNT2/SEL/NEED/EQ belong to compact_topk
+enum { SH_CNT = 0, SH_OVF, SH_SEL, SH_NEED, SH_EQ, SH_CNT2, SH_NEXT, SH_RETRY, SH_QCNT, SH_MCNT, SH_N };   // SH_CNT2/SEL/NEED/EQ belong to compact_topk
 
 // phases timed by lane 0 of every workgroup when KParams::phase_cycles != NULL, then event counters
 enum { PH_SETUP = 0, PH_SEGMENTS, PH_ACCUM, PH_DRAIN, PH_SELECT, PH_OUTPUT, PH_SWEEP1, PH_SWEEP2, PH_CSDRAIN,
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
             // m1 value, so putting the heavy segments first makes the running k-th value rise early and the
             // survivor rate fall monotonically (an unordered row could flood the candidate buffer late)
             int len = 0;
-            if (tid == 0) sh[SH_QCNT] = 0;   // counter of the sweep-1 queue (barriers below publish it)
+            if (tid == 0) { sh[SH_QCNT] = 0; sh[SH_MCNT] = 0; }   // queue / member-list counters (barriers below publish them)
             {
                 int r0 = 0, mylen = 0;
                 float v = 0.f;
@@ -673,23 +673,32 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
             const int n_dup = sh[SH_QCNT];
             int ovf1 = sh[SH_OVF];
             __syncthreads();
+            // slots claimed below are listed in the second half of the bitmap's storage (the bitmap is dead
+            // after sweep 1; the first half becomes the survivor queue): the set is drained from that list
+            int *mlist = (int *)(bm + T / 2);
             if (!ovf1) {
                 // dense insertion of the queued columns (duplicates in the queue find themselves already there).
                 // Buckets fill front to back, so "has room" <=> last key empty.
-                for (int i = tid; i < n_dup; i += NT) {
-                    const int cc = duplist[i];
-                    unsigned bk = hash_bits(cc, 0x85EBCA6Bu, cs_shift) << 2;
-                    int tries = 0;
-                    for (; tries < 2 * CS_TRIES; ++tries) {
-                        const int4 k4 = *(const int4 *)&cskeys[bk];
-                        if (k4.x == cc || k4.y == cc || k4.z == cc || k4.w == cc) break;  // already a member
-                        const int pos = (k4.x == EMPTY) ? 0 : (k4.y == EMPTY) ? 1 : (k4.z == EMPTY) ? 2 : (k4.w == EMPTY) ? 3 : -1;
-                        if (pos < 0) { bk = (bk + 4u) & cs_mask; continue; }          // bucket full: next one
-                        const int prev = atomicCAS(&cskeys[bk + pos], EMPTY, cc);
-                        if (prev == EMPTY || prev == cc) break;
-                        // lost the slot to another column: look at the same bucket again
+                for (int base = 0; base < n_dup; base += NT) {          // uniform trip count (wave_push below)
+                    const int i = base + tid;
+                    int claimed = -1;
+                    if (i < n_dup) {
+                        const int cc = duplist[i];
+                        unsigned bk = hash_bits(cc, 0x85EBCA6Bu, cs_shift) << 2;
+                        int tries = 0;
+                        for (; tries < 2 * CS_TRIES; ++tries) {
+                            const int4 k4 = *(const int4 *)&cskeys[bk];
+                            if (k4.x == cc || k4.y == cc || k4.z == cc || k4.w == cc) break;  // already a member
+                            const int pos = (k4.x == EMPTY) ? 0 : (k4.y == EMPTY) ? 1 : (k4.z == EMPTY) ? 2 : (k4.w == EMPTY) ? 3 : -1;
+                            if (pos < 0) { bk = (bk + 4u) & cs_mask; continue; }          // bucket full: next one
+                            const int prev = atomicCAS(&cskeys[bk + pos], EMPTY, cc);
+                            if (prev == EMPTY) { claimed = (int)bk + pos; break; }
+                            if (prev == cc) break;
+                            // lost the slot to another column: look at the same bucket again
+                        }
+                        if (tries == 2 * CS_TRIES) sh[SH_OVF] = 1;
                     }
-                    if (tries == 2 * CS_TRIES) sh[SH_OVF] = 1;
+                    wave_push<1>(claimed >= 0 ? 1u : 0u, &sh[SH_MCNT], cs_slots, &sh[SH_OVF], [&](int, int pos) { mlist[pos] = claimed; });
                 }
                 __syncthreads();
                 ovf1 = sh[SH_OVF];
@@ -705,7 +714,7 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
                 // product is the only one of its column: if the gather-free bound says it can still make the
                 // top-k it is queued (the bitmap's storage is free now) and judged densely after the chunk. ----
                 u64 *Q = (u64 *)bm;
-                const int qcap = T / 2;
+                const int qcap = T / 4;          // first half of the bitmap's storage; the member list sits in the second
                 auto sweep2 = [&](int eb, int ee) {
                     for_elements(std::true_type{}, std::integral_constant<int, SPARSE_UNROLL>{}, eb, ee, n1,
                                  [&](const int (&c)[SPARSE_UNROLL], const float (&xr)[SPARSE_UNROLL], const float (&v1)[SPARSE_UNROLL], unsigned valid) __attribute__((always_inline)) {
@@ -814,26 +823,27 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
             }
 
             if (!failed) {
-                // ---- drain the collision set (also resets it), with the usual overflow-retry ----
+                // ---- drain the collision set through its member list (also resets it), overflow-retry as usual ----
+                const int n_mem = sh[SH_MCNT];
                 for (;;) {
-                    for (int base = 0; base < cs_slots; base += NT * DRAIN_UNROLL) {
-                        int c[DRAIN_UNROLL];
+                    for (int base = 0; base < n_mem; base += NT * DRAIN_UNROLL) {
+                        int c[DRAIN_UNROLL], slot[DRAIN_UNROLL];
                         float xy[DRAIN_UNROLL];
                         unsigned occ = 0;
 #pragma unroll
                         for (int j = 0; j < DRAIN_UNROLL; ++j) {
-                            const int sidx = base + j * NT + tid;
-                            c[j] = (sidx < cs_slots) ? cskeys[sidx] : EMPTY;
-                            xy[j] = (sidx < cs_slots) ? cssums[sidx] : 0.f;
+                            const int mi = base + j * NT + tid;
+                            slot[j] = (mi < n_mem) ? mlist[mi] : 0;
+                            c[j] = (mi < n_mem) ? cskeys[slot[j]] : EMPTY;     // EMPTY: already emitted in an earlier sweep
+                            xy[j] = cssums[slot[j]];
                             if (c[j] != EMPTY) occ |= 1u << j;
                         }
                         const unsigned done = emit_candidates<DRAIN_UNROLL>(p, rc, c, xy, occ, U, sh);
 #pragma unroll
                         for (int j = 0; j < DRAIN_UNROLL; ++j) {
                             if (done & (1u << j)) {
-                                const int sidx = base + j * NT + tid;
-                                cskeys[sidx] = EMPTY;
-                                cssums[sidx] = 0.f;
+                                cskeys[slot[j]] = EMPTY;
+                                cssums[slot[j]] = 0.f;
                             }
                         }
                     }
@@ -850,7 +860,7 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
                     { const long long thr_new = compact_topk<NT>(U, hist, sh, p.k); if (thr_new >= 0) { rc.have_thr = true; rc.thr_key = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)thr_new); rc.set_cut(p.threshold); } }
                     PHASE_END(PH_SELECT);
                 }
-                for (int i = tid; i < T; i += NT) bm[i] = 0u;   // bitmap back to clean
+                for (int i = tid; i < T / 4; i += NT) ((int4 *)bm)[i] = make_int4(0, 0, 0, 0);   // bitmap back to clean (16-B stores)
                 __syncthreads();
                 PHASE_END(PH_CSDRAIN);
                 row_done = true;
