@@ -52,6 +52,7 @@ extern "C" {
 #define SP_FLAG_STATIC_SCHED  4u  /* round-robin rows over workgroups instead of the atomic row queue */
 #define SP_FLAG_NO_SPARSE_PATH 8u /* never use the bitmap + collision-set path for sparse rows (A/B testing) */
 #define SP_FLAG_NO_FOLD       16u /* never divide the column term into the m2 stream (A/B testing) */
+#define SP_FLAG_NO_ROW_ORDER  32u /* queue rows in target order instead of descending work (A/B testing) */
 
 typedef struct sp_knn_args {
     uint32_t struct_size;      /* = sizeof(sp_knn_args); checked */

@@ -22,6 +22,10 @@ def make_urm(n_users, n_items, nnz, seed=0):
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 0.25
 n_users, n_items, nnz = int(200948 * scale), int(84432 * scale), int(32_000_204 * scale)
 urm = make_urm(n_users, n_items, nnz)
+if len(sys.argv) > 2 and sys.argv[2] == 'shuffle':      # real catalogues are not sorted by popularity
+    perm = np.random.default_rng(5).permutation(n_items)
+    urm = urm[:, perm].tocsr()
+NO_ORDER = len(sys.argv) > 3 and sys.argv[3] == 'noorder'
 m1 = urm.T.tocsr()
 print(f"URM {urm.shape} nnz {urm.nnz}; item-item on m1 {m1.shape}", flush=True)
 k = 200
@@ -40,8 +44,8 @@ for name, prep in (("cosine", lambda: _host.prepare(m1, k=k, l2=1)),
     macs = cs[call.m1_indptr[1:]] - cs[call.m1_indptr[:-1]]
     prob = DeviceProblem(call)
     cols, vals, counts, _ = prob.alloc_outputs()
-    prob.run(cols, vals, counts); torch.cuda.synchronize()
-    info = prob.run(cols, vals, counts, time_kernel=True)
+    prob.run(cols, vals, counts, no_row_order=NO_ORDER); torch.cuda.synchronize()
+    info = prob.run(cols, vals, counts, time_kernel=True, no_row_order=NO_ORDER)
     ms = info["kernel_ms"]
     nbytes = 16 * call.m1_data.shape[0] + 8 * int(macs.sum()) + 8 * k * call.n_targets
     ph = info["phase_cycles"]

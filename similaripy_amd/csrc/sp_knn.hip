@@ -94,6 +94,7 @@ struct KParams {
     u64 *gU;               // candidate buffers in global memory (only when they do not fit LDS)
     unsigned int *queue;   // [0] = next slot index (dynamic scheduling)
     const int *order;      // optional: slot visiting order (descending work); NULL = identity
+    const unsigned *use_order;   // device flag written by the ordering prepass: 0 = ignore `order`
     int hash_fill;         // slots' worth of MACs one hash window may receive (= T * load_pct / 100)
     int static_sched;
     const float *ymin;     // [3] minima of Ytv / Ycos / Ydep over all columns (valid iff bound_ok)
@@ -438,6 +439,7 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
     }
     __syncthreads();
 
+    const bool use_order = (p.order != nullptr) && (p.use_order[0] != 0u);
     const bool any_norm = (p.l1 != 0.f || p.l2 != 0.f || p.l3 != 0.f || p.stab != 0.f || p.bayes != 0.f);
     float ymin_tv = 0.f, ymin_cos = 0.f, ymin_dep = 0.f;
     if (p.bound_ok) {
@@ -545,7 +547,7 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
         // vector registers for the streaming loops
         const int qi = __builtin_amdgcn_readfirstlane(sh[SH_NEXT]);
         if (qi >= p.n_targets) break;
-        const int slot_i = p.order ? __builtin_amdgcn_readfirstlane(p.order[qi]) : qi;
+        const int slot_i = use_order ? __builtin_amdgcn_readfirstlane(p.order[qi]) : qi;
         const int t = __builtin_amdgcn_readfirstlane(p.targets[slot_i]);
         const int s1 = __builtin_amdgcn_readfirstlane(p.m1_indptr[t]);
         const int n1 = __builtin_amdgcn_readfirstlane(p.m1_indptr[t + 1]) - s1;
@@ -1116,6 +1118,73 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
 #undef PHASE_END
 }
 
+// ---- work-ordered row queue (longest-processing-time-first, to within a factor 2) ----
+// Rows are visited in descending MACs(t) buckets (bucket = floor(log2(work))), so that one huge row at the end of
+// the target list cannot become the tail of the launch on skewed (power-law) matrices.
+__global__ __launch_bounds__(256) void sp_row_work_kernel(int n_targets, const int *targets, const int *m1_indices,
+                                                           const int *m1_indptr, const int *m2_indptr, unsigned *work,
+                                                           unsigned *bucket_count) {
+    __shared__ unsigned hist[32];
+    if (threadIdx.x < 32) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int gw = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6);
+    const int lane = threadIdx.x & 63;
+    if (gw < n_targets) {
+        const int t = targets[gw];
+        const int s = m1_indptr[t], e = m1_indptr[t + 1];
+        u64 acc = 0;
+        for (int j = s + lane; j < e; j += 64) {
+            const int u = m1_indices[j];
+            acc += (u64)(m2_indptr[u + 1] - m2_indptr[u]);
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+        if (lane == 0) {
+            const unsigned w = acc > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)acc;
+            work[gw] = w;
+            atomicAdd(&hist[31 - __clz((int)(w | 1u))], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 32 && hist[threadIdx.x]) atomicAdd(&bucket_count[threadIdx.x], hist[threadIdx.x]);
+}
+
+// bucket_count[0..32) -> bucket_base[0..32): start of each bucket when buckets are laid out heaviest first
+// bucket_base[32] = 1 when the work spans at least a factor ~4 (otherwise the target order is kept: nothing to gain)
+__global__ void sp_bucket_base_kernel(const unsigned *bucket_count, unsigned *bucket_base) {
+    if (threadIdx.x == 0) {
+        unsigned run = 0;
+        int hi = -1, lo = 32;
+        for (int b = 31; b >= 0; --b) {
+            bucket_base[b] = run;
+            run += bucket_count[b];
+            if (bucket_count[b]) { if (hi < 0) hi = b; lo = b; }
+        }
+        bucket_base[32] = (hi - lo >= 2) ? 1u : 0u;
+    }
+}
+
+__global__ __launch_bounds__(256) void sp_row_order_kernel(int n_targets, const unsigned *work, unsigned *bucket_base, int *order) {
+    if (bucket_base[32] == 0) return;   // uniform work: the main kernel keeps the target order
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool live = i < n_targets;
+    const int b = live ? 31 - __clz((int)(work[i] | 1u)) : -1;
+    // one atomic per (wave, bucket): rows of similar work share a bucket, and a single global word only
+    // sustains ~88 atomics/us — a per-row atomic would cost ~11 ms for 1M equal rows
+    u64 todo = __ballot(live);
+    while (todo) {
+        const int leader = (int)__builtin_ctzll(todo);
+        const int b0 = __shfl(b, leader, 64);
+        const u64 same = __ballot(live && b == b0);
+        unsigned base = 0;
+        if (lane == leader) base = atomicAdd(&bucket_base[b0], (unsigned)__popcll(same));
+        base = __shfl(base, leader, 64);
+        if (live && b == b0) order[base + __popcll(same & ((1ull << lane) - 1ull))] = i;
+        todo &= ~same;
+    }
+}
+
 // Minima of the three column-term vectors over all columns (one workgroup; feeds Epi::upper).
 __global__ __launch_bounds__(1024) void sp_colterm_min_kernel(int n_cols, const float *Ytv, const float *Ycos, const float *Ydep, float *out) {
     __shared__ float red[3][16];
@@ -1182,8 +1251,10 @@ struct Config {
     size_t lds_bytes;
     size_t ws_gu_bytes;     // candidate buffers in global memory (0 when in LDS)
     size_t ws_fold_bytes;   // scaled copy of m2_data when the column term is folded in (0 otherwise)
-    size_t ws_total;        // header + gU + fold scratch
+    size_t ws_order_bytes;  // work[n] + order[n] + 64 bucket counters when rows are visited by descending work
+    size_t ws_total;        // header + gU + fold scratch + order scratch
     bool fold;
+    bool ordered;
 };
 
 constexpr size_t WS_QUEUE_BYTES = 256;   // [0,8) row queue | [64,160) phase counters | [176,188) column-term minima
@@ -1234,7 +1305,9 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
     c->fold = !(a->flags & SP_FLAG_NO_FOLD) && a->l1 == 0.f && a->a1 == 1.f && a->stabilized_shrink == 0.f &&
               a->bayesian_shrink == 0.f && ((a->l2 != 0.f) != (a->l3 != 0.f)) && a->nnz_m2 > 0;
     c->ws_fold_bytes = c->fold ? (((size_t)a->nnz_m2 * 4 + 255) & ~(size_t)255) : 0;
-    c->ws_total = WS_QUEUE_BYTES + ((c->ws_gu_bytes + 255) & ~(size_t)255) + c->ws_fold_bytes;
+    c->ordered = !(a->flags & (SP_FLAG_STATIC_SCHED | SP_FLAG_NO_ROW_ORDER)) && a->n_targets > num_wgs;
+    c->ws_order_bytes = c->ordered ? ((((size_t)a->n_targets * 8 + 512) + 255) & ~(size_t)255) : 0;
+    c->ws_total = WS_QUEUE_BYTES + ((c->ws_gu_bytes + 255) & ~(size_t)255) + c->ws_fold_bytes + c->ws_order_bytes;
     return SP_OK;
 }
 
@@ -1352,6 +1425,22 @@ int run_device(sp_knn_args *a) {
     kp.queue = (unsigned int *)ws;
     kp.gU = c.u_lds ? nullptr : (u64 *)(ws + WS_QUEUE_BYTES);
     kp.order = nullptr;
+    if (c.ordered) {
+        unsigned char *ob = ws + WS_QUEUE_BYTES + ((c.ws_gu_bytes + 255) & ~(size_t)255) + c.ws_fold_bytes;
+        unsigned *bucket_count = (unsigned *)ob;            // [32]
+        unsigned *bucket_base = bucket_count + 32;          // [32] + [1] flag
+        unsigned *work = (unsigned *)(ob + 512);            // [n]
+        int *order = (int *)(work + a->n_targets);          // [n]
+        HIP_TRY(hipMemsetAsync(ob, 0, 512, stream));
+        const int waves_per_block = 256 / 64;
+        hipLaunchKernelGGL(sp_row_work_kernel, dim3((a->n_targets + waves_per_block - 1) / waves_per_block), dim3(256), 0, stream,
+                           a->n_targets, a->targets, a->m1_indices, a->m1_indptr, a->m2_indptr, work, bucket_count);
+        hipLaunchKernelGGL(sp_bucket_base_kernel, dim3(1), dim3(64), 0, stream, bucket_count, bucket_base);
+        hipLaunchKernelGGL(sp_row_order_kernel, dim3((a->n_targets + 255) / 256), dim3(256), 0, stream, a->n_targets, work, bucket_base, order);
+        HIP_TRY(hipGetLastError());
+        kp.order = order;
+        kp.use_order = bucket_base + 32;
+    }
     kp.hash_fill = c.hash_fill;
     kp.static_sched = (a->flags & SP_FLAG_STATIC_SCHED) ? 1 : 0;
     kp.ymin = ymin_dev;

@@ -101,6 +101,8 @@ class DeviceProblem:
             flags |= _abi.SP_FLAG_NO_SPARSE_PATH
         if tuning.get("no_fold"):
             flags |= _abi.SP_FLAG_NO_FOLD
+        if tuning.get("no_row_order"):
+            flags |= _abi.SP_FLAG_NO_ROW_ORDER
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream().cuda_stream
             a = self._args(targets_t, n, cols, vals, counts, rows, stream, flags, tuning)
