@@ -60,16 +60,13 @@ constexpr u64 EMPTY64 = 0xFFFFFFFF00000000ull;   // free accumulator slot: key E
 constexpr int MAX_PROBE = 128;   // probe budget of one element before a hashed window is declared overflowed
 // m2 elements per lane and trip (two trips are in flight); 1024-thread workgroups have half the VGPR budget
 #define ACC_UNROLL (NT >= 1024 ? 2 : NT >= 768 ? 4 : 8)
-// the sparse sweeps are lighter on registers than the generic accumulate: they can keep more elements in flight
-#define SPARSE_UNROLL (NT >= 768 ? 4 : 8)
 constexpr int U_SLACK = 1024;    // candidate-buffer entries beyond k (room between two selections)
-constexpr int CS_TRIES = 8;      // buckets searched in the collision set before giving up (-> generic path)
 // table slots per thread per drain iteration (their Y gathers fly together); 1024-thread workgroups have
 // half the VGPR budget (128), where 8 would spill
 #define DRAIN_UNROLL (NT >= 1024 ? 2 : NT >= 768 ? 4 : 8)
 
 // scalar slots in LDS
-enum { SH_CNT = 0, SH_OVF, SH_SEL, SH_NEED, SH_EQ, SH_CNT2, SH_NEXT, SH_RETRY, SH_QCNT, SH_MCNT, SH_N };   // SH_CNT2/SEL/NEED/EQ belong to compact_topk
+enum { SH_CNT = 0, SH_OVF, SH_SEL, SH_NEED, SH_EQ, SH_CNT2, SH_RETRY, SH_QA, SH_QB, SH_DCTR, SH_PCTR, SH_NITEMS, SH_N };   // SH_CNT2/SEL/NEED/EQ belong to the selections
 
 // phases timed by lane 0 of every workgroup when KParams::phase_cycles != NULL, then event counters
 enum { PH_SETUP = 0, PH_SEGMENTS, PH_ACCUM, PH_DRAIN, PH_SELECT, PH_OUTPUT, PH_SWEEP1, PH_SWEEP2, PH_CSDRAIN,
@@ -92,9 +89,10 @@ struct KParams {
     int logT;
     int cap;               // candidate buffer capacity (> k)
     u64 *gU;               // candidate buffers in global memory (only when they do not fit LDS)
-    unsigned int *queue;   // [0] = next slot index (dynamic scheduling)
-    const int *order;      // optional: slot visiting order (descending work); NULL = identity
-    const unsigned *use_order;   // device flag written by the ordering prepass: 0 = ignore `order`
+    unsigned int *queue;   // [0] = next queue position (dynamic scheduling)
+    const int4 *desc;      // [2*n_targets] row descriptors in queue order: {slot, m1 row, m1 start, m1 length}, {MACs (saturated), 0, 0, 0}
+    unsigned m2_bytes;     // nnz(m2) * 4: extent of the m2 index / value buffers (buffer-load range check)
+    int nb_log2;           // log2 of the sparse path's column bitmap size in bits (<= log2(T*64))
     int hash_fill;         // slots' worth of MACs one hash window may receive (= T * load_pct / 100)
     int static_sched;
     const float *ymin;     // [3] minima of Ytv / Ycos / Ydep over all columns (valid iff bound_ok)
@@ -399,47 +397,200 @@ __device__ __forceinline__ unsigned emit_candidates(const KParams &p, const RowC
     return occ & (~want | stored);
 }
 
+// ---------------------------------------------------------------------------------------------
+// helpers of the sparse path
+// ---------------------------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int ITEM = 256;         // m2 elements per work item: one 16-byte load per lane
+constexpr int ITEM_CAP = 768;     // work items per row (LDS: 16 B each)
+constexpr int POOL_BLK = 64;      // pool entries a wave reserves at a time (>= 64: one trip always fits a fresh block)
+constexpr int CS_MAXPROBE = 64;   // linear-probe budget in the collision set
+constexpr int SORT_MAX = 256;     // m1 rows up to this many entries are visited in descending |value| order
+
+__device__ __forceinline__ int mbcnt64(u64 m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
+// Wave-private window [pos, end) into a shared LDS pool: entries are appended with no atomic at all until
+// the window is used up, then ONE returning atomic reserves the next POOL_BLK entries.  Abandoned tails stay
+// zero ("hole"); consumers skip zeros.  pos/end are wave-uniform (scalar registers).
+struct WavePool { int pos, end; };
+
+template <typename W>
+__device__ __forceinline__ void pool_push(WavePool &wp, bool pred, int *ctr, int cap, int *ovf, W &&write) {
+    const u64 m = __ballot(pred);
+    if (m == 0) return;                        // wave-uniform
+    const int n = __popcll(m);
+    if (wp.pos + n > wp.end) {
+        int base = 0;
+        if ((threadIdx.x & 63) == 0) base = atomicAdd(ctr, POOL_BLK);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base + POOL_BLK > cap) {           // pool exhausted: the row is redone on the generic path
+            if ((threadIdx.x & 63) == 0) *ovf = 1;
+            wp.pos = 0; wp.end = -1;
+            return;
+        }
+        wp.pos = base; wp.end = base + POOL_BLK;
+    }
+    if (pred) write(wp.pos + mbcnt64(m));
+    wp.pos += n;
+}
+
+// inclusive wave64 scan on the DPP crossbar (row_shr 1/2/4/8, row_bcast 15/31): no LDS round trips
+__device__ __forceinline__ int wave_incl_scan_dpp(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
+    return v;
+}
+
+// Selection for candidate buffers of at most 2*NT entries: every thread keeps its (<= 2) entries in registers,
+// one LDS histogram per radix pass (hist4 = 4 x 256 counters, zero on entry and on exit), every wave scans the
+// histogram redundantly (no broadcast barrier), 1 barrier per pass.
+//   exact:  keeps exactly k entries; returns the key of the k-th largest.
+//   !exact: stops after two passes (sign, exponent, 7 mantissa bits) when that already removes most of the
+//           surplus: keeps every entry >= the lower edge of the 16-bit bin holding the k-th largest and returns
+//           that edge — a valid (conservative) running cutoff, cheaper than the exact one.
+// Must be entered by the whole workgroup.  Returns -1 when n <= k (nothing done).
+template <int NT>
+__device__ long long select_fast(u64 *U, int *hist4, int *sh, int k, bool exact) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int n = sh[SH_CNT];
+    if (tid == 0) { sh[SH_CNT2] = 0; sh[SH_EQ] = 0; }   // (the generic path's selection leaves them dirty)
+    __syncthreads();
+    if (n <= k) return -1;
+    u64 e[2];
+    unsigned key[2];
+    bool has[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int i = tid + j * NT;
+        has[j] = i < n;
+        e[j] = has[j] ? U[i] : 0ull;
+        key[j] = (unsigned)(e[j] >> 32);
+    }
+    unsigned prefix = 0;
+    int need = k;
+    int passes = 0;
+    for (int ps = 0; ps < 4; ++ps) {
+        const int shift = 24 - 8 * ps;
+        const unsigned hmask = (ps == 0) ? 0u : (0xFFFFFFFFu << (shift + 8));
+        int *h = hist4 + ps * 256;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if (has[j] && ((key[j] ^ prefix) & hmask) == 0u) atomicAdd(&h[(key[j] >> shift) & 255u], 1);
+        __syncthreads();
+        // lane L owns bins 255-4L .. 252-4L (lanes ascend as digits descend)
+        const int4 c4 = *(const int4 *)&h[252 - 4 * lane];
+        const int c0 = c4.w, c1 = c4.z, c2 = c4.y, c3 = c4.x;
+        const int s = c0 + c1 + c2 + c3;
+        const int incl = wave_incl_scan_dpp(s);
+        const int excl = incl - s;
+        const bool mine = excl < need && need <= incl;
+        int d = 0, r = 0, cb = 0;
+        if (mine) {
+            const int b0 = 255 - 4 * lane;
+            r = need - excl;
+            if (r <= c0) { d = b0; cb = c0; }
+            else if (r <= c0 + c1) { d = b0 - 1; r -= c0; cb = c1; }
+            else if (r <= c0 + c1 + c2) { d = b0 - 2; r -= c0 + c1; cb = c2; }
+            else { d = b0 - 3; r -= c0 + c1 + c2; cb = c3; }
+        }
+        const int leader = (int)__builtin_ctzll(__ballot(mine));
+        d = __builtin_amdgcn_readlane(d, leader);
+        r = __builtin_amdgcn_readlane(r, leader);
+        cb = __builtin_amdgcn_readlane(cb, leader);
+        const int above = need - r;            // entries of this pass's population that lie above the chosen bin
+        prefix |= (unsigned)d << shift;
+        passes = ps + 1;
+        if (!exact && ps == 1) {
+            // keeping the whole bin leaves (k - r) + cb entries: good enough when that is at most half the surplus
+            const int kept = (k - r) + cb;
+            (void)above;
+            if (2 * (kept - k) <= (n - k)) { need = r; break; }
+        }
+        need = r;
+    }
+    const bool all_passes = (passes == 4);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        bool keep = false;
+        if (has[j]) {
+            if (key[j] > prefix) keep = true;
+            else if (key[j] == prefix) keep = all_passes ? (atomicAdd(&sh[SH_EQ], 1) < need) : true;
+            else if (!all_passes) keep = (key[j] >= prefix);     // prefix has its low bits clear: the bin's lower edge
+        }
+        const u64 m = __ballot(keep);
+        if (m) {
+            int wbase = 0;
+            if (lane == 0) wbase = atomicAdd(&sh[SH_CNT2], __popcll(m));
+            wbase = __builtin_amdgcn_readfirstlane(wbase);
+            if (keep) U[wbase + mbcnt64(m)] = e[j];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < passes * 256; i += NT) hist4[i] = 0;
+    if (tid == 0) sh[SH_CNT] = sh[SH_CNT2];
+    __syncthreads();
+    return (long long)prefix;
+}
+
 template <int NT, bool U_LDS>
 __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NW = NT / 64;
+    constexpr int XB = (16 * NT + 256) > (ITEM_CAP * 16 + 4096) ? (16 * NT + 256) : (ITEM_CAP * 16 + 4096);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = p.T;
+    const int A_bytes = T * 8;
 
-    // ---- LDS carve-up (single dynamic array; everything 16-byte aligned at the table) ----
-    u64 *tab = (u64 *)smem;                     // [T]  generic path: {column id : partial dot product}
-    int *seg_lo = (int *)(tab + T);             // [NT]   start of the (window's) slice of m2 row u
+    // ---- LDS carve-up (single dynamic array) ----
+    // region A  [0, T*8)      generic path: accumulator tile of T {column : partial dot} slots
+    //                         sparse path : sweep 1: column bitmap (nb_bits);  sweep 2: [0,A/4) collision bitmap,
+    //                                       [A/4,A/2) collision set, [A/2,A) survivor / member-product pool
+    // region X  [.., +XB)     generic path: segment arrays;  sparse path: work items + 4 radix histograms
+    // then hist / wsum / sh / ph, then the candidate buffer U (sparse sweep 1 borrows it for the duplicate pool)
+    u64 *tab = (u64 *)smem;
+    unsigned char *X = smem + A_bytes;
+    int *seg_lo = (int *)X;                     // [NT]   start of the (window's) slice of m2 row u
     int *seg_pre = seg_lo + NT;                 // [NT+64] exclusive prefix of slice lengths
     float *seg_v1 = (float *)(seg_pre + NT + 64);  // [NT] m1 value of the segment
     int *seg_hi = (int *)(seg_v1 + NT);         // [NT]   end of the slice (= start of the next window's)
-    int *hist = seg_hi + NT;                    // [256]
+    int4 *items = (int4 *)X;                    // [ITEM_CAP] {m2 offset, count, m1 value bits, flat start}
+    int *hist4 = (int *)(X + ITEM_CAP * 16);    // [4][256]
+    int *hist = (int *)(X + XB);                // [256]
     int *wsum = hist + 256;                     // [64]
-    int *sh = wsum + 64;                        // [SH_N .. 16]
-    u64 *ph = (u64 *)(sh + 16);                 // [PH_N .. 16] phase timers / event counters (lane 0 only)
+    int *sh = wsum + 64;                        // [32]
+    u64 *ph = (u64 *)(sh + 32);                 // [16] phase timers / event counters (lane 0 only)
     u64 *U = U_LDS ? (u64 *)(ph + 16) : (p.gU + (size_t)blockIdx.x * (size_t)p.cap);
-    // sparse path: the same T*8 bytes hold a bitmap of 32*T bits, then T/2 keys and T/2 sums of the
-    // collision set (buckets of 4 keys = one ds_read_b128)
-    unsigned *bm = (unsigned *)smem;            // [T] words
-    int *cskeys = (int *)(bm + T);              // [T/2]
-    float *cssums = (float *)(cskeys + T / 2);  // [T/2]
-    const int cs_slots = T / 2;
-    const unsigned cs_mask = (unsigned)cs_slots - 1u;
-    const int bm_shift = 32 - (p.logT + 5);     // hashed column -> bit index
-    const int cs_shift = 32 - (p.logT - 3);     // hashed column -> bucket index (cs_slots/4 buckets)
+
+    // sparse path geometry
+    const unsigned amask = (unsigned)((1u << (p.nb_log2 - 3)) - 1u) & ~3u;      // column -> byte of its bitmap word
+    const int nb_bytes = 1 << (p.nb_log2 - 3);
+    unsigned char *cbm = smem;
+    const unsigned cmask = (unsigned)(A_bytes / 4 - 1) & ~3u;                   // column -> byte of its collision-bitmap word
+    u64 *cs = (u64 *)(smem + A_bytes / 4);
+    const int CSN = A_bytes / 32;
+    const int cs_shift = 32 - (p.logT - 2);                                     // log2(CSN) = logT + 3 - 5
+    u64 *pool = (u64 *)(smem + A_bytes / 2);
+    const int pcap = A_bytes / 16;
+    unsigned *dpool = (unsigned *)U;
+    const int dcap = 2 * p.cap;
+    const __amdgpu_buffer_rsrc_t rs_idx = __builtin_amdgcn_make_buffer_rsrc((void *)p.m2_indices, 0, (int)p.m2_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_val = __builtin_amdgcn_make_buffer_rsrc((void *)p.m2_data, 0, (int)p.m2_bytes, 0x00020000);
 
     for (int i = tid; i < T; i += NT) tab[i] = EMPTY64;
-    int lds_mode = 0;  // 0: table region is generic-clean (all EMPTY64), 1: sparse-clean (bitmap 0, keys EMPTY, sums 0)
-    if (tid == 0) {
-        sh[SH_CNT] = 0;
-        sh[SH_OVF] = 0;
-        sh[SH_RETRY] = 0;
-        sh[SH_NEXT] = p.static_sched ? (int)blockIdx.x : (int)atomicAdd(&p.queue[0], 1u);
-    }
+    int lds_mode = 0;  // 0: region A is generic-clean (all EMPTY64), 1: sparse-clean (all zero, hist4 zero)
+    if (tid < 32) sh[tid] = 0;
+    if (tid < 16) ph[tid] = 0;
     __syncthreads();
 
-    const bool use_order = (p.order != nullptr) && (p.use_order[0] != 0u);
     const bool any_norm = (p.l1 != 0.f || p.l2 != 0.f || p.l3 != 0.f || p.stab != 0.f || p.bayes != 0.f);
     float ymin_tv = 0.f, ymin_cos = 0.f, ymin_dep = 0.f;
     if (p.bound_ok) {
@@ -449,15 +600,13 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
 
     // phase timers (lane 0 only; s_memtime ticks are shader cycles)
     const bool timing = (p.phase_cycles != nullptr) && tid == 0;
-    if (tid < 16) ph[tid] = 0;
-    __syncthreads();
     u64 tmark = timing ? (u64)clock64() : 0;
 #define PHASE_END(which) do { if (timing) { const u64 _n = (u64)clock64(); ph[which] += _n - tmark; tmark = _n; } } while (0)
 
-    // Visit the flat element space [eb, ee) of the current segment list (nb segments, prefix in seg_pre):
-    // wave w owns a contiguous 64-aligned chunk, every lane handles ACC_UNROLL stride-64 elements per
-    // trip (coalesced loads), all lanes of a wave make the same number of trips, and the loads of trip
-    // i+1 are issued before trip i is processed (two register sets, no copies).
+    // Generic path streaming front end.  Visit the flat element space [eb, ee) of the current segment list
+    // (nb segments, prefix in seg_pre): wave w owns a contiguous 64-aligned chunk, every lane handles AU
+    // stride-64 elements per trip (coalesced loads), all lanes of a wave make the same number of trips, and the
+    // loads of trip i+1 are issued before trip i is processed (two register sets, no copies).
     // Per lane the current segment is cached in registers (end of segment, flat->m2 index delta, m1 value):
     // the common element costs one compare and one add.  m2 is addressed with 32-bit byte offsets from the
     // scalar base pointers (the host only launches this kernel for nnz(m2) < 2^30).
@@ -471,7 +620,7 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
         const int span = ee - eb;
         if (span <= 0) return;
         const int chunk = ((span + NW * 64 - 1) / (NW * 64)) * 64;
-        const int e0 = eb + __builtin_amdgcn_readfirstlane(wave) * chunk;
+        const int e0 = eb + wave * chunk;
         const int e1 = min(e0 + chunk, ee);
         if (e0 >= e1) return;  // wave-uniform
         const int efirst = min(e0 + lane, e1 - 1);
@@ -542,19 +691,86 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
         return __builtin_amdgcn_readfirstlane(total);
     };
 
+    // ---- row pipeline ----
+    // The chain  queue -> descriptor {slot, row, m1 start, m1 length, MACs} -> m1 entries -> m2 row bounds  is four
+    // dependent global loads (~1 us each under load).  It is software-pipelined across rows: while row r is
+    // processed, the queue slot of row r+3 is claimed, the descriptor of row r+2 is loaded, the m1 entries of
+    // row r+1 are loaded (top of the row) and its m2 row bounds fetched (middle of the row).
+    const int4 *desc = p.desc;
+    auto load_desc = [&](int q, int4 &d0, int &work) {
+        d0 = make_int4(-1, 0, 0, 0);
+        work = 0;
+        if (q < p.n_targets) { d0 = desc[2 * (size_t)q]; work = desc[2 * (size_t)q + 1].x; }
+    };
+    int q_nn = 0;      // queue index two rows ahead (static schedule: computed; dynamic: through LDS)
+    int pend_q = 0;    // (tid 0) claimed queue index three rows ahead
+    int4 dC, dN;       // descriptors of the current and the next row
+    int wC = 0, wN = 0;
+    if (p.static_sched) {
+        load_desc((int)blockIdx.x, dC, wC);
+        load_desc((int)(blockIdx.x + gridDim.x), dN, wN);
+        q_nn = (int)(blockIdx.x + 2 * gridDim.x);
+    } else {
+        if (tid == 0) {
+            sh[SH_QA] = (int)atomicAdd(&p.queue[0], 1u);
+            sh[SH_QB] = (int)atomicAdd(&p.queue[0], 1u);
+            pend_q = (int)atomicAdd(&p.queue[0], 1u);
+        }
+        __syncthreads();
+        load_desc(sh[SH_QA], dC, wC);
+        load_desc(sh[SH_QB], dN, wN);
+        __syncthreads();
+    }
+    // m1 entries / m2 row bounds held per thread (segment `tid` of the row) for rows with at most NT entries
+    int my_r0 = 0, my_len = 0;
+    float my_v = 0.f;
+    if (dC.x >= 0 && tid < dC.w && dC.w <= NT) {
+        const int u = p.m1_indices[dC.z + tid];
+        my_v = p.m1_data[dC.z + tid];
+        my_r0 = p.m2_indptr[u];
+        my_len = p.m2_indptr[u + 1] - my_r0;
+    }
+
     for (;;) {
         // row-constant values are wave-uniform: v_readfirstlane moves them to scalar registers, which frees
         // vector registers for the streaming loops
-        const int qi = __builtin_amdgcn_readfirstlane(sh[SH_NEXT]);
-        if (qi >= p.n_targets) break;
-        const int slot_i = use_order ? __builtin_amdgcn_readfirstlane(p.order[qi]) : qi;
-        const int t = __builtin_amdgcn_readfirstlane(p.targets[slot_i]);
-        const int s1 = __builtin_amdgcn_readfirstlane(p.m1_indptr[t]);
-        const int n1 = __builtin_amdgcn_readfirstlane(p.m1_indptr[t + 1]) - s1;
+        const int slot_i = __builtin_amdgcn_readfirstlane(dC.x);
+        if (slot_i < 0) break;
+        const int t = __builtin_amdgcn_readfirstlane(dC.y);
+        const int s1 = __builtin_amdgcn_readfirstlane(dC.z);
+        const int n1 = __builtin_amdgcn_readfirstlane(dC.w);
+        const unsigned macs32 = (unsigned)__builtin_amdgcn_readfirstlane(wC);
+        const u64 macs = (u64)macs32;   // saturated at 2^32-1 by the work prepass
 
-        // prefetch the next queue entry early; it is consumed at the bottom of the loop
-        int next_q = 0;
-        if (tid == 0) next_q = p.static_sched ? qi + (int)gridDim.x : (int)atomicAdd(&p.queue[0], 1u);
+        // prefetch: queue slot three rows ahead, m1 entries of the next row
+        if (!p.static_sched && tid == 0) {
+            sh[SH_QA] = pend_q;
+            pend_q = (int)atomicAdd(&p.queue[0], 1u);
+        }
+        const bool nx_regs = dN.x >= 0 && dN.w <= NT;
+        int nx_u = 0;
+        float nx_v = 0.f;
+        if (nx_regs && tid < dN.w) {
+            nx_u = p.m1_indices[dN.z + tid];
+            nx_v = p.m1_data[dN.z + tid];
+        }
+        int nx_r0 = 0, nx_len = 0;
+        bool b2_done = false;
+        auto fetch_next_bounds = [&]() __attribute__((always_inline)) {
+            if (!b2_done) {
+                if (nx_regs && tid < dN.w) {
+                    nx_r0 = p.m2_indptr[nx_u];
+                    nx_len = p.m2_indptr[nx_u + 1] - nx_r0;
+                }
+                b2_done = true;
+            }
+        };
+        __syncthreads();
+        int4 dNN;
+        int wNN;
+        if (!p.static_sched) q_nn = sh[SH_QA];
+        load_desc(q_nn, dNN, wNN);
+        if (p.static_sched) q_nn += (int)gridDim.x;
 
         RowCtx rc;
         rc.row = t;
@@ -580,272 +796,347 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
         if (p.filter_mode == SP_SEL_MATRIX) { rc.f0 = __builtin_amdgcn_readfirstlane(p.f_indptr[t]); rc.f1 = __builtin_amdgcn_readfirstlane(p.f_indptr[t + 1]); }
         if (p.target_mode == SP_SEL_MATRIX) { rc.g0 = __builtin_amdgcn_readfirstlane(p.t_indptr[t]); rc.g1 = __builtin_amdgcn_readfirstlane(p.t_indptr[t + 1]); }
 
-        // ---- work estimate: MACs(t) = sum_u nnz(m2 row u) (upper bound on distinct candidates) ----
-        u64 macs_local = 0;
-        for (int j = tid; j < n1; j += NT) {
-            const int u = p.m1_indices[s1 + j];
-            macs_local += (u64)(p.m2_indptr[u + 1] - p.m2_indptr[u]);
-        }
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) macs_local += __shfl_xor(macs_local, d, 64);
-        if (lane == 0) ((u64 *)wsum)[wave] = macs_local;  // wsum is 8-byte aligned, NW <= 16 -> 128 B
-        __syncthreads();
-        u64 macs = 0;
-        for (int w = 0; w < NW; ++w) macs += ((u64 *)wsum)[w];
-        macs = ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(macs >> 32)) << 32) | (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)macs);
-        __syncthreads();
-        PHASE_END(PH_SETUP);
+        // running k-th value after a selection
+        auto took_threshold = [&](long long thr_new) __attribute__((always_inline)) {
+            if (thr_new >= 0) {
+                rc.have_thr = true;
+                rc.thr_key = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)thr_new);
+                rc.set_cut(p.threshold);
+            }
+        };
+        // selection on the sparse path (hist4 lives in region X, which the generic path uses for its segments)
+        auto select_sparse = [&](bool exact) __attribute__((always_inline)) {
+            if (p.cap <= 2 * NT) took_threshold(select_fast<NT>(U, hist4, sh, p.k, exact));
+            else took_threshold(compact_topk<NT>(U, hist, sh, p.k));
+        };
 
         // =========================================================================================
-        // SPARSE path: expected colliding products (true + bitmap aliasing) fit the collision set
+        // SPARSE path: few products share a column (the KNN / recommender shape)
+        //   sweep 1 (column ids): one bit per column in an LDS bitmap (exact while n_cols <= bits); a product
+        //     that finds its bit set has its column appended to a duplicate pool;
+        //   the bitmap is cleared, the duplicate columns become a small collision set + a collision bitmap;
+        //   sweep 2 (ids + values): ONE bit test per product — columns of the collision set have their product
+        //     appended to a pool (accumulated densely afterwards), every other product is the only one of its
+        //     column and is appended only if its raw dot can still beat the running k-th value;
+        //   pools are consumed by dense phases: epilogue -> threshold -> top-k buffer -> selection.
+        // Work is handed out in items of <= 256 consecutive elements of one m2 row: the row base, the count
+        // and the m1 value are scalars, one 16-byte buffer load per lane fetches a whole item.
         // =========================================================================================
         bool row_done = (macs == 0);
         bool sparse_ok = false;
-        if (!row_done && p.sparse_path && n1 <= NT && p.n_cols > T && macs < (1ull << 30)) {
-            const float m = (float)macs;
-            const float expect = 0.5f * m * m * (1.f / (float)p.n_cols + 1.f / (32.f * (float)T));
-            sparse_ok = expect <= 0.40f * (float)cs_slots;
+        if (!row_done && p.sparse_path && n1 <= SORT_MAX && n1 <= NT && p.n_cols > T && macs32 < (1u << 30)) {
+            const float m = (float)macs32;
+            const float alias = (p.nb_log2 < 31 && (1 << p.nb_log2) < p.n_cols) ? 1.f / (float)(1 << p.nb_log2) : 0.f;
+            const float expect = 0.5f * m * m * (1.f / (float)p.n_cols + alias);
+            sparse_ok = expect <= 0.30f * (float)CSN && expect <= 0.40f * (float)dcap;
         }
+        int n_items = 0, my_ib = 0, my_fs = 0;
         if (sparse_ok) {
             if (lds_mode != 1) {
-                for (int i = tid; i < T; i += NT) bm[i] = 0u;
-                for (int i = tid; i < cs_slots; i += NT) { cskeys[i] = EMPTY; cssums[i] = 0.f; }
+                for (int i = tid; i < T / 2; i += NT) ((int4 *)smem)[i] = make_int4(0, 0, 0, 0);
+                for (int i = tid; i < 1024; i += NT) hist4[i] = 0;
                 lds_mode = 1;
-                __syncthreads();
             }
-            // whole m2 rows, one segment per m1 entry — visited in descending |m1 value| order: the products
-            // are offered to the top-k filter segment by segment, and each segment scales its m2 row by its own
-            // m1 value, so putting the heavy segments first makes the running k-th value rise early and the
-            // survivor rate fall monotonically (an unordered row could flood the candidate buffer late)
-            int len = 0;
-            if (tid == 0) { sh[SH_QCNT] = 0; sh[SH_MCNT] = 0; }   // queue / member-list counters (barriers below publish them)
+            // the duplicate pool borrows U's storage (empty until sweep 2); holes must read zero
+            for (int i = tid; i < p.cap / 2; i += NT) ((int4 *)U)[i] = make_int4(0, 0, 0, 0);
+            if (tid == 0) { sh[SH_DCTR] = 0; sh[SH_PCTR] = 0; sh[SH_NITEMS] = 0; }
+            // Segments are visited in descending |m1 value| order: each segment scales its m2 row by its own m1
+            // value, so the heavy segments first make the running k-th value rise early and the survivor rate
+            // fall monotonically.  Rank, first item and flat start of every segment come from one all-pairs pass
+            // spread over the whole workgroup (n1 <= 256).
+            int *keyS = (int *)items, *lenS = keyS + SORT_MAX, *ibS = lenS + SORT_MAX, *fsS = ibS + SORT_MAX;
+            if (tid < SORT_MAX) { ibS[tid] = 0; fsS[tid] = 0; }
+            if (tid < n1) { keyS[tid] = (int)(__float_as_uint(my_v) & 0x7FFFFFFFu); lenS[tid] = my_len; }
+            __syncthreads();
             {
-                int r0 = 0, mylen = 0;
-                float v = 0.f;
-                if (tid < n1) {
-                    const int u = p.m1_indices[s1 + tid];
-                    r0 = p.m2_indptr[u];
-                    mylen = p.m2_indptr[u + 1] - r0;
-                    v = p.m1_data[s1 + tid];
-                }
-                int slot = tid;
-                if (n1 <= 256) {
-                    if (tid < n1) seg_pre[tid] = (int)(__float_as_uint(v) & 0x7FFFFFFFu);   // |v| orders as an integer
-                    __syncthreads();
-                    if (tid < n1) {
-                        const int key = seg_pre[tid];
-                        int rank = 0;
-                        for (int j = 0; j < n1; ++j) {
-                            const int kj = seg_pre[j];   // same address across the wave: broadcast read
-                            rank += (kj > key) || (kj == key && j < tid);
-                        }
-                        slot = rank;
+                const int n1p = (n1 + 63) & ~63;
+                const int parts = NT / n1p;
+                const int seg = tid % n1p, part = tid / n1p;
+                if (seg < n1 && part < parts) {
+                    const int key = keyS[seg];
+                    int ib = 0, fs = 0;
+                    for (int j = part; j < n1; j += parts) {
+                        const int kj = keyS[j], lj = lenS[j];     // same address across the wave: broadcast reads
+                        const bool before = (kj > key) || (kj == key && j < seg);
+                        ib += before ? (lj + ITEM - 1) / ITEM : 0;
+                        fs += before ? lj : 0;
                     }
-                    __syncthreads();   // ranks computed before seg_pre is reused by the scan
+                    if (ib) atomicAdd(&ibS[seg], ib);
+                    if (fs) atomicAdd(&fsS[seg], fs);
                 }
-                if (tid < n1) { seg_lo[slot] = r0; seg_v1[slot] = v; seg_hi[slot] = mylen; }
-                __syncthreads();
-                if (tid < n1) len = seg_hi[tid];
+                if (tid < n1 && my_len > 0) atomicAdd(&sh[SH_NITEMS], (my_len + ITEM - 1) / ITEM);
             }
-            const int total = scan_segments(len);
-            PHASE_END(PH_SEGMENTS);
+            __syncthreads();
+            if (tid < n1) { my_ib = ibS[tid]; my_fs = fsS[tid]; }
+            n_items = sh[SH_NITEMS];
+            __syncthreads();                    // scratch read before the items overwrite it
+            if (n_items > ITEM_CAP) sparse_ok = false;
+        }
+        if (sparse_ok) {
+            if (tid < n1) {
+                int q = 0;
+                for (int o = 0; o < my_len; o += ITEM, ++q)
+                    items[my_ib + q] = make_int4(my_r0 + o, min(ITEM, my_len - o), (int)__float_as_uint(my_v), my_fs + o);
+            }
+            __syncthreads();
+            PHASE_END(PH_SETUP);
 
-            // ---- sweep 1: column ids only.  First product of a column sets its bit; a product that finds
-            // the bit set (a second product of the column, or an aliasing column) has its column queued for
-            // the collision set.  Every column with >= 2 products ends up queued at least once.
-            // The queue borrows the (still empty) candidate buffer U; inserting from it afterwards keeps the
-            // streaming loop free of divergent probe loops. ----
-            int *duplist = (int *)U;
-            const int dupcap = 2 * p.cap;
-            for_elements(std::false_type{}, std::integral_constant<int, SPARSE_UNROLL>{}, 0, total, n1,
-                         [&](const int (&c)[SPARSE_UNROLL], const float (&)[SPARSE_UNROLL], const float (&)[SPARSE_UNROLL], unsigned valid) __attribute__((always_inline)) {
-                unsigned old[SPARSE_UNROLL], bit[SPARSE_UNROLL];
+            // ---- sweep 1: column ids only ----
+            {
+                WavePool wp{0, -1};
+                auto ld = [&](int it, unsigned (&c)[4], int &cnt) __attribute__((always_inline)) {
+                    const int4 d = items[it];
+                    const int off = __builtin_amdgcn_readfirstlane(d.x);
+                    cnt = __builtin_amdgcn_readfirstlane(d.y);
+                    if (cnt == ITEM) {
+                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, lane * 16, off * 4, 0);
+                        c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
+                    } else {
 #pragma unroll
-                for (int j = 0; j < SPARSE_UNROLL; ++j) {
-                    const unsigned b = hash_bits(c[j], 2654435761u, bm_shift);
-                    bit[j] = (valid & (1u << j)) ? (1u << (b & 31u)) : 0u;     // padding ORs nothing
-                    old[j] = atomicOr(&bm[b >> 5], bit[j]);
-                }
-                unsigned dup = 0;
-#pragma unroll
-                for (int j = 0; j < SPARSE_UNROLL; ++j) dup |= (old[j] & bit[j]) ? (1u << j) : 0u;
-                wave_push<SPARSE_UNROLL>(dup, &sh[SH_QCNT], dupcap, &sh[SH_OVF], [&](int j, int pos) { duplist[pos] = c[j]; });
-            });
-            __syncthreads();
-            const int n_dup = sh[SH_QCNT];
-            int ovf1 = sh[SH_OVF];
-            __syncthreads();
-            // slots claimed below are listed in the second half of the bitmap's storage (the bitmap is dead
-            // after sweep 1; the first half becomes the survivor queue): the set is drained from that list
-            int *mlist = (int *)(bm + T / 2);
-            if (!ovf1) {
-                // dense insertion of the queued columns (duplicates in the queue find themselves already there).
-                // Buckets fill front to back, so "has room" <=> last key empty.
-                for (int base = 0; base < n_dup; base += NT) {          // uniform trip count (wave_push below)
-                    const int i = base + tid;
-                    int claimed = -1;
-                    if (i < n_dup) {
-                        const int cc = duplist[i];
-                        unsigned bk = hash_bits(cc, 0x85EBCA6Bu, cs_shift) << 2;
-                        int tries = 0;
-                        for (; tries < 2 * CS_TRIES; ++tries) {
-                            const int4 k4 = *(const int4 *)&cskeys[bk];
-                            if (k4.x == cc || k4.y == cc || k4.z == cc || k4.w == cc) break;  // already a member
-                            const int pos = (k4.x == EMPTY) ? 0 : (k4.y == EMPTY) ? 1 : (k4.z == EMPTY) ? 2 : (k4.w == EMPTY) ? 3 : -1;
-                            if (pos < 0) { bk = (bk + 4u) & cs_mask; continue; }          // bucket full: next one
-                            const int prev = atomicCAS(&cskeys[bk + pos], EMPTY, cc);
-                            if (prev == EMPTY) { claimed = (int)bk + pos; break; }
-                            if (prev == cc) break;
-                            // lost the slot to another column: look at the same bucket again
-                        }
-                        if (tries == 2 * CS_TRIES) sh[SH_OVF] = 1;
+                        for (int j = 0; j < 4; ++j) c[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_idx, (j * 64 + lane) * 4, off * 4, 0);
                     }
-                    wave_push<1>(claimed >= 0 ? 1u : 0u, &sh[SH_MCNT], cs_slots, &sh[SH_OVF], [&](int, int pos) { mlist[pos] = claimed; });
+                };
+                auto body = [&](const unsigned (&c)[4], int cnt) __attribute__((always_inline)) {
+                    unsigned old[4], bit[4];
+                    if (cnt == ITEM) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            bit[j] = 1u << (c[j] & 31u);
+                            old[j] = atomicOr((unsigned *)(smem + ((c[j] >> 3) & amask)), bit[j]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            bit[j] = (j * 64 + lane < cnt) ? (1u << (c[j] & 31u)) : 0u;     // padding ORs nothing
+                            old[j] = atomicOr((unsigned *)(smem + ((c[j] >> 3) & amask)), bit[j]);
+                        }
+                    }
+                    bool dup[4];
+                    bool any = false;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { dup[j] = (old[j] & bit[j]) != 0u; any |= dup[j]; }
+                    if (__ballot(any)) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            pool_push(wp, dup[j], &sh[SH_DCTR], dcap, &sh[SH_OVF], [&](int pos) { dpool[pos] = ~c[j]; });
+                    }
+                };
+                unsigned cA[4], cB[4];
+                int nA = 0, nB = 0;
+                int it = wave;
+                if (it < n_items) ld(it, cA, nA);
+                while (it < n_items) {
+                    const int it2 = it + NW;
+                    if (it2 < n_items) ld(it2, cB, nB);
+                    body(cA, nA);
+                    if (it2 >= n_items) break;
+                    const int it3 = it2 + NW;
+                    if (it3 < n_items) ld(it3, cA, nA);
+                    body(cB, nB);
+                    it = it3;
                 }
-                __syncthreads();
-                ovf1 = sh[SH_OVF];
-                __syncthreads();
             }
-            if (tid == 0) sh[SH_QCNT] = 0;   // the same counter now serves the survivor queue
             __syncthreads();
-            PHASE_END(PH_SWEEP1);
-
+            const int ovf1 = sh[SH_OVF];
+            const int dext = min(sh[SH_DCTR], dcap);
+            fetch_next_bounds();
+            // the bitmap has done its job: back to zero (16-byte stores), then the collision structures go there
+            for (int i = tid; i < (nb_bytes >> 4); i += NT) ((int4 *)smem)[i] = make_int4(0, 0, 0, 0);
+            __syncthreads();
             bool failed = (ovf1 != 0);
             if (!failed) {
-                // ---- sweep 2: ids + values.  Members of the collision set accumulate there; every other
-                // product is the only one of its column: if the gather-free bound says it can still make the
-                // top-k it is queued (the bitmap's storage is free now) and judged densely after the chunk. ----
-                u64 *Q = (u64 *)bm;
-                const int qcap = T / 4;          // first half of the bitmap's storage; the member list sits in the second
-                auto sweep2 = [&](int eb, int ee) {
-                    for_elements(std::true_type{}, std::integral_constant<int, SPARSE_UNROLL>{}, eb, ee, n1,
-                                 [&](const int (&c)[SPARSE_UNROLL], const float (&xr)[SPARSE_UNROLL], const float (&v1)[SPARSE_UNROLL], unsigned valid) __attribute__((always_inline)) {
-                        float x[SPARSE_UNROLL];
-                        int4 k4[SPARSE_UNROLL];
-                        unsigned bk[SPARSE_UNROLL];
-#pragma unroll
-                        for (int j = 0; j < SPARSE_UNROLL; ++j) {
-                            x[j] = xr[j] * v1[j];
-                            bk[j] = hash_bits(c[j], 0x85EBCA6Bu, cs_shift) << 2;
-                            k4[j] = *(const int4 *)&cskeys[bk[j]];
+                for (int i = tid; i < dext; i += NT) {
+                    const unsigned nc = dpool[i];
+                    if (nc != 0u) {
+                        const unsigned c = ~nc;
+                        unsigned h = hash_bits((int)c, 2654435761u, cs_shift);
+                        int tries = 0;
+                        for (; tries < CS_MAXPROBE; ++tries) {
+                            const u64 prev = atomicCAS(&cs[h], 0ull, (u64)nc << 32);     // {~column : +0.0f}
+                            if (prev == 0ull) { atomicOr((unsigned *)(cbm + ((c >> 3) & cmask)), 1u << (c & 31u)); break; }
+                            if ((unsigned)(prev >> 32) == nc) break;                     // already a member
+                            h = (h + 1u) & (unsigned)(CSN - 1);
                         }
-                        // common cases without branches: member of the home bucket / not a member and the home
-                        // bucket has room (so it cannot be further down the chain) / full bucket without a match
-                        unsigned member = 0, chain = 0, live = 0;
+                        if (tries == CS_MAXPROBE) sh[SH_OVF] = 1;
+                    }
+                }
+                __syncthreads();
+                failed = (sh[SH_OVF] != 0);
+            }
+            PHASE_END(PH_SWEEP1);
+
+            if (!failed) {
+                // ---- sweep 2 over items [i0, i1) ----
+                auto sweep2 = [&](int i0, int i1) __attribute__((always_inline)) {
+                    WavePool wp{0, -1};
+                    auto ld = [&](int it, unsigned (&c)[4], float (&v)[4], int &cnt, float &segv) __attribute__((always_inline)) {
+                        const int4 d = items[it];
+                        const int off = __builtin_amdgcn_readfirstlane(d.x);
+                        cnt = __builtin_amdgcn_readfirstlane(d.y);
+                        segv = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane(d.z));
+                        if (cnt == ITEM) {
+                            const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, lane * 16, off * 4, 0);
+                            const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs_val, lane * 16, off * 4, 0);
+                            c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w;
+                            v[0] = __uint_as_float(b.x); v[1] = __uint_as_float(b.y); v[2] = __uint_as_float(b.z); v[3] = __uint_as_float(b.w);
+                        } else {
 #pragma unroll
-                        for (int j = 0; j < SPARSE_UNROLL; ++j) {
-                            const bool hit = (k4[j].x == c[j]) | (k4[j].y == c[j]) | (k4[j].z == c[j]) | (k4[j].w == c[j]);
-                            const bool ok = (valid >> j) & 1u;
-                            member |= (ok && hit) ? (1u << j) : 0u;
-                            chain |= (ok && !hit && k4[j].w != EMPTY) ? (1u << j) : 0u;
-                            // single product of its column: queue it unless its raw dot is below the cutoff
-                            live |= (ok && !hit && k4[j].w == EMPTY && !(x[j] <= rc.xy_cut)) ? (1u << j) : 0u;
+                            for (int j = 0; j < 4; ++j) c[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_idx, (j * 64 + lane) * 4, off * 4, 0);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_val, (j * 64 + lane) * 4, off * 4, 0));
                         }
-                        if (__ballot(member != 0)) {          // ~a few lanes per trip: accumulate in the set
+                    };
+                    auto body = [&](const unsigned (&c)[4], const float (&v)[4], int cnt, float segv) __attribute__((always_inline)) {
+                        unsigned w[4];
+                        float x[4];
 #pragma unroll
-                            for (int j = 0; j < SPARSE_UNROLL; ++j) {
-                                if (member & (1u << j)) {
-                                    const int pos = (k4[j].x == c[j]) ? 0 : (k4[j].y == c[j]) ? 1 : (k4[j].z == c[j]) ? 2 : 3;
-                                    atomicAdd(&cssums[bk[j] + pos], x[j]);
-                                }
+                        for (int j = 0; j < 4; ++j) {
+                            x[j] = v[j] * segv;
+                            w[j] = *(const unsigned *)(cbm + ((c[j] >> 3) & cmask));
+                        }
+                        bool mem[4], push[4];
+                        bool any = false;
+                        const bool full = (cnt == ITEM);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const bool ok = full || (j * 64 + lane < cnt);
+                            mem[j] = ok && (((w[j] >> (c[j] & 31u)) & 1u) != 0u);
+                            // a product outside the collision set is the only one of its column: keep it only if
+                            // its raw dot can still enter the top-k (NaN stays: the exact judge drops it)
+                            push[j] = mem[j] || (ok && !(x[j] <= rc.xy_cut));
+                            any |= push[j];
+                        }
+                        if (__ballot(any)) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                pool_push(wp, push[j], &sh[SH_PCTR], pcap, &sh[SH_OVF], [&](int pos) {
+                                    pool[pos] = ((u64)((c[j] + 1u) | (mem[j] ? 0x80000000u : 0u)) << 32) | (u64)__float_as_uint(x[j]);
+                                });
+                        }
+                    };
+                    unsigned cA[4], cB[4];
+                    float vA[4], vB[4];
+                    int nA = 0, nB = 0;
+                    float sA = 0.f, sB = 0.f;
+                    int it = i0 + wave;
+                    if (it < i1) ld(it, cA, vA, nA, sA);
+                    while (it < i1) {
+                        const int it2 = it + NW;
+                        if (it2 < i1) ld(it2, cB, vB, nB, sB);
+                        body(cA, vA, nA, sA);
+                        if (it2 >= i1) break;
+                        const int it3 = it2 + NW;
+                        if (it3 < i1) ld(it3, cA, vA, nA, sA);
+                        body(cB, vB, nB, sB);
+                        it = it3;
+                    }
+                };
+                // ---- dense consumer of the pool: member products accumulate in the collision set, single
+                // products are judged (column terms, epilogue, threshold) and appended to U; a full U triggers a
+                // selection and another pass over what is left.  Leaves the pool all zero. ----
+                auto consume_pool = [&]() __attribute__((always_inline)) {
+                    const int ext = min(sh[SH_PCTR], pcap);
+                    for (;;) {
+                        for (int base = 0; base < ext; base += NT * DRAIN_UNROLL) {
+                            u64 e[DRAIN_UNROLL];
+                            int c[DRAIN_UNROLL];
+                            float xy[DRAIN_UNROLL];
+                            unsigned occ = 0;
+#pragma unroll
+                            for (int j = 0; j < DRAIN_UNROLL; ++j) {
+                                const int idx = base + j * NT + tid;
+                                e[j] = (idx < ext) ? pool[idx] : 0ull;
                             }
-                        }
-                        if (__ballot(chain != 0)) {           // rare: home bucket full, walk the chain
 #pragma unroll
-                            for (int j = 0; j < SPARSE_UNROLL; ++j) {
-                                if (chain & (1u << j)) {
-                                    unsigned b = bk[j];
-                                    for (int tries = 0; tries < 2 * CS_TRIES; ++tries) {
-                                        b = (b + 4u) & cs_mask;
-                                        const int4 kk = *(const int4 *)&cskeys[b];
-                                        const int pos = (kk.x == c[j]) ? 0 : (kk.y == c[j]) ? 1 : (kk.z == c[j]) ? 2 : (kk.w == c[j]) ? 3 : -1;
-                                        if (pos >= 0) { atomicAdd(&cssums[b + pos], x[j]); break; }
-                                        if (kk.w == EMPTY || tries == 2 * CS_TRIES - 1) {
-                                            if (!(x[j] <= rc.xy_cut)) live |= 1u << j;   // not a member after all
-                                            break;
+                            for (int j = 0; j < DRAIN_UNROLL; ++j) {
+                                const unsigned hi = (unsigned)(e[j] >> 32);
+                                c[j] = (int)((hi & 0x7FFFFFFFu) - 1u);
+                                xy[j] = __uint_as_float((unsigned)e[j]);
+                                if (e[j] != 0ull) {
+                                    bool single = (hi >> 31) == 0u;
+                                    if (!single) {
+                                        const unsigned nc = ~(unsigned)c[j];
+                                        unsigned h = hash_bits(c[j], 2654435761u, cs_shift);
+                                        single = true;            // bit aliasing: flagged but not in the set
+                                        for (int tries = 0; tries < CS_MAXPROBE; ++tries) {
+                                            const u64 s = cs[h];
+                                            if ((unsigned)(s >> 32) == nc) { atomicAdd((float *)&cs[h], xy[j]); single = false; break; }
+                                            if (s == 0ull) break;
+                                            h = (h + 1u) & (unsigned)(CSN - 1);
                                         }
                                     }
+                                    if (single && !(xy[j] <= rc.xy_cut)) occ |= 1u << j;
                                 }
                             }
-                        }
-                        wave_push<SPARSE_UNROLL>(live, &sh[SH_QCNT], qcap, &sh[SH_RETRY],
-                                              [&](int j, int pos) { Q[pos] = ((u64)(unsigned)c[j] << 32) | (u64)__float_as_uint(x[j]); });
-                    });
-                };
-                // The products are offered in growing chunks with a selection after each: the first chunk is
-                // small enough that accepting everything cannot overflow U; once the k-th best of n products
-                // is known, about k*m/n of the next m would survive in an exchangeable stream — far fewer here,
-                // because segments come in descending weight — so the next chunk may be 4*n*(cap-k)/k long.
-                // (An adversarial order can still overflow U or the queue: -> generic path.)
-                const int room = p.cap - min(p.k, p.cap - 1);
-                int pos = 0;
-                long long chunk = room;
-                while (pos < total) {
-                    const int end = (int)min((long long)total, (long long)pos + chunk);
-                    sweep2(pos, end);
-                    __syncthreads();
-                    const int n_q = sh[SH_QCNT];
-                    int retry = sh[SH_RETRY];
-                    __syncthreads();
-                    if (retry) { failed = true; break; }   // queue overflowed: dropped products cannot be re-offered
-                    PHASE_END(PH_SWEEP2);
-                    // judge the queued single-product candidates densely: gathers, epilogue, append to U
-                    for (int base = 0; base < n_q; base += NT * SPARSE_UNROLL) {
-                        int c[SPARSE_UNROLL];
-                        float xy[SPARSE_UNROLL];
-                        unsigned occ = 0;
+                            const unsigned done = emit_candidates<DRAIN_UNROLL>(p, rc, c, xy, occ, U, sh);
 #pragma unroll
-                        for (int j = 0; j < SPARSE_UNROLL; ++j) {
-                            const int qi2 = base + j * NT + tid;
-                            const u64 it = (qi2 < n_q) ? Q[qi2] : 0ull;
-                            c[j] = (int)(it >> 32);
-                            xy[j] = __uint_as_float((unsigned)it);
-                            if (qi2 < n_q) occ |= 1u << j;
+                            for (int j = 0; j < DRAIN_UNROLL; ++j)
+                                if (e[j] != 0ull && (!(occ & (1u << j)) || (done & (1u << j)))) pool[base + j * NT + tid] = 0ull;
                         }
-                        (void)emit_candidates<SPARSE_UNROLL>(p, rc, c, xy, occ, U, sh);
-                    }
-                    __syncthreads();
-                    const int n_now = sh[SH_CNT];
-                    retry = sh[SH_RETRY];
-                    __syncthreads();
-                    if (retry) { failed = true; break; }   // U overflowed
-                    PHASE_END(PH_DRAIN);                   // (sparse path: time spent judging the queue)
-                    if (tid == 0) sh[SH_QCNT] = 0;
-                    pos = end;
-                    if (pos < total && n_now > p.k) {
-                        PHASE_END(PH_SWEEP2);
-                        { const long long thr_new = compact_topk<NT>(U, hist, sh, p.k); if (thr_new >= 0) { rc.have_thr = true; rc.thr_key = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)thr_new); rc.set_cut(p.threshold); } }
+                        __syncthreads();
+                        const int retry = sh[SH_RETRY];
+                        if (!retry) break;  // uniform
+                        __syncthreads();
+                        if (tid == 0) {
+                            sh[SH_RETRY] = 0;
+                            if (sh[SH_CNT] > p.cap) sh[SH_CNT] = p.cap;   // failed appends over-counted
+                        }
+                        __syncthreads();
+                        PHASE_END(PH_DRAIN);
+                        select_sparse(false);
                         PHASE_END(PH_SELECT);
-                    } else {
-                        __syncthreads();   // counter reset visible before the next chunk pushes
                     }
-                    chunk = rc.have_thr ? max((long long)room, 4ll * (long long)pos * (long long)room / (long long)p.k) : (long long)room;
+                    if (tid == 0) sh[SH_PCTR] = 0;
+                };
+
+                // The products are offered in growing chunks with a selection after each: the first chunk is
+                // small enough that accepting everything cannot overflow U; once the k-th best of n products is
+                // known, about k*m/n of the next m would survive in an exchangeable stream — far fewer here,
+                // because segments come in descending weight — so the next chunk may be 4*n*(cap-k)/k long.
+                const int room = p.cap - min(p.k, p.cap - 1);
+                int i0 = 0;
+                long long chunk = room;
+                while (i0 < n_items) {
+                    const int i1 = (int)min((long long)n_items, (long long)i0 + max(1ll, chunk / ITEM));
+                    sweep2(i0, i1);
+                    __syncthreads();
+                    if (sh[SH_OVF]) { failed = true; break; }     // pool overflowed: dropped products cannot be re-offered
+                    PHASE_END(PH_SWEEP2);
+                    consume_pool();
+                    i0 = i1;
+                    const long long pos = (i0 < n_items) ? (long long)items[i0].w : (long long)macs32;
+                    const int n_now = sh[SH_CNT];
+                    __syncthreads();                               // SH_PCTR reset / SH_CNT read before anything moves on
+                    PHASE_END(PH_DRAIN);
+                    if (i0 < n_items && n_now > p.k) {
+                        select_sparse(false);
+                        PHASE_END(PH_SELECT);
+                    }
+                    chunk = rc.have_thr ? max((long long)room, 4ll * pos * (long long)room / (long long)p.k) : (long long)room;
                 }
-                PHASE_END(PH_SWEEP2);
             }
 
             if (!failed) {
-                // ---- drain the collision set through its member list (also resets it), overflow-retry as usual ----
-                const int n_mem = sh[SH_MCNT];
+                // ---- drain the collision set (complete sums now), clearing it and its bitmap bits ----
                 for (;;) {
-                    for (int base = 0; base < n_mem; base += NT * DRAIN_UNROLL) {
-                        int c[DRAIN_UNROLL], slot[DRAIN_UNROLL];
+                    for (int base = 0; base < CSN; base += NT * DRAIN_UNROLL) {
+                        int c[DRAIN_UNROLL];
                         float xy[DRAIN_UNROLL];
                         unsigned occ = 0;
 #pragma unroll
                         for (int j = 0; j < DRAIN_UNROLL; ++j) {
-                            const int mi = base + j * NT + tid;
-                            slot[j] = (mi < n_mem) ? mlist[mi] : 0;
-                            c[j] = (mi < n_mem) ? cskeys[slot[j]] : EMPTY;     // EMPTY: already emitted in an earlier sweep
-                            xy[j] = cssums[slot[j]];
-                            if (c[j] != EMPTY) occ |= 1u << j;
+                            const int idx = base + j * NT + tid;
+                            const u64 s = (idx < CSN) ? cs[idx] : 0ull;
+                            c[j] = (int)~(unsigned)(s >> 32);
+                            xy[j] = __uint_as_float((unsigned)s);
+                            if (s != 0ull) occ |= 1u << j;
                         }
                         const unsigned done = emit_candidates<DRAIN_UNROLL>(p, rc, c, xy, occ, U, sh);
 #pragma unroll
                         for (int j = 0; j < DRAIN_UNROLL; ++j) {
                             if (done & (1u << j)) {
-                                cskeys[slot[j]] = EMPTY;
-                                cssums[slot[j]] = 0.f;
+                                cs[base + j * NT + tid] = 0ull;
+                                atomicAnd((unsigned *)(cbm + (((unsigned)c[j] >> 3) & cmask)), ~(1u << ((unsigned)c[j] & 31u)));
                             }
                         }
                     }
@@ -859,24 +1150,22 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
                     }
                     __syncthreads();
                     PHASE_END(PH_CSDRAIN);
-                    { const long long thr_new = compact_topk<NT>(U, hist, sh, p.k); if (thr_new >= 0) { rc.have_thr = true; rc.thr_key = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)thr_new); rc.set_cut(p.threshold); } }
+                    select_sparse(false);
                     PHASE_END(PH_SELECT);
                 }
-                for (int i = tid; i < T / 4; i += NT) ((int4 *)bm)[i] = make_int4(0, 0, 0, 0);   // bitmap back to clean (16-B stores)
-                __syncthreads();
                 PHASE_END(PH_CSDRAIN);
                 row_done = true;
                 if (timing) ph[CT_ROWS_SPARSE] += 1;
             } else {
-                // collision set or candidate buffer overflowed: forget this attempt, take the generic path
+                // a pool or the collision set overflowed: forget this attempt, take the generic path
                 for (int i = tid; i < T; i += NT) tab[i] = EMPTY64;
                 lds_mode = 0;
-                if (tid == 0) { sh[SH_CNT] = 0; sh[SH_OVF] = 0; sh[SH_RETRY] = 0; }
+                if (tid == 0) { sh[SH_CNT] = 0; sh[SH_OVF] = 0; sh[SH_RETRY] = 0; sh[SH_CNT2] = 0; sh[SH_EQ] = 0; }
                 rc.have_thr = false;
                 rc.thr_key = 0;
                 rc.set_cut(p.threshold);
                 __syncthreads();
-                if (timing) ph[CT_ROWS_FALLBACK] += (ovf1 != 0) ? 1ull : (1ull << 32);   // low word: collision set full, high word: U overflow
+                if (timing) ph[CT_ROWS_FALLBACK] += 1;
             }
         }
 
@@ -1073,7 +1362,7 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
                     }
                     __syncthreads();
                     PHASE_END(PH_DRAIN);
-                    { const long long thr_new = compact_topk<NT>(U, hist, sh, p.k); if (thr_new >= 0) { rc.have_thr = true; rc.thr_key = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)thr_new); rc.set_cut(p.threshold); } }
+                    took_threshold(compact_topk<NT>(U, hist, sh, p.k));
                     PHASE_END(PH_SELECT);
                 }
                 PHASE_END(PH_DRAIN);
@@ -1082,10 +1371,14 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
         }
 
         // ================= final selection + write-out =================
+        fetch_next_bounds();
         __syncthreads();
         const int n_fin = sh[SH_CNT];
         __syncthreads();
-        if (n_fin > p.k) { const long long thr_new = compact_topk<NT>(U, hist, sh, p.k); if (thr_new >= 0) { rc.have_thr = true; rc.thr_key = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)thr_new); rc.set_cut(p.threshold); } }
+        if (n_fin > p.k) {
+            if (lds_mode == 1) select_sparse(true);
+            else took_threshold(compact_topk<NT>(U, hist, sh, p.k));
+        }
         PHASE_END(PH_SELECT);
         const int n_out = sh[SH_CNT];
         const long long o = (long long)slot_i * (long long)p.k;
@@ -1102,12 +1395,13 @@ __global__ __launch_bounds__(NT) void sp_knn_rows_kernel(const KParams p) {
             p.cols[o + j] = c;
             p.values[o + j] = v;
         }
-        if (tid == 0) {
-            if (p.counts) p.counts[slot_i] = n_out;
-            sh[SH_NEXT] = next_q;
-        }
+        if (tid == 0 && p.counts) p.counts[slot_i] = n_out;
         __syncthreads();
         if (tid == 0) sh[SH_CNT] = 0;
+        // rotate the row pipeline
+        dC = dN; wC = wN;
+        dN = dNN; wN = wNN;
+        my_r0 = nx_r0; my_len = nx_len; my_v = nx_v;
         __syncthreads();
         PHASE_END(PH_OUTPUT);
     }
@@ -1185,6 +1479,19 @@ __global__ __launch_bounds__(256) void sp_row_order_kernel(int n_targets, const 
     }
 }
 
+// Row descriptors in queue order: what the main kernel needs to start a row, one 32-byte record per queue
+// position, so that its dependent-load chain is queue -> descriptor -> m1 entries -> m2 row bounds.
+__global__ __launch_bounds__(256) void sp_row_desc_kernel(int n_targets, const int *targets, const int *m1_indptr, const unsigned *work,
+                                                           const unsigned *ordered_flag, const int *order, int4 *desc) {
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= n_targets) return;
+    const int slot = (ordered_flag != nullptr && ordered_flag[0] != 0u) ? order[pos] : pos;
+    const int t = targets[slot];
+    const int s = m1_indptr[t], e = m1_indptr[t + 1];
+    desc[2 * (size_t)pos] = make_int4(slot, t, s, e - s);
+    desc[2 * (size_t)pos + 1] = make_int4((int)work[slot], 0, 0, 0);
+}
+
 // Minima of the three column-term vectors over all columns (one workgroup; feeds Epi::upper).
 __global__ __launch_bounds__(1024) void sp_colterm_min_kernel(int n_cols, const float *Ytv, const float *Ycos, const float *Ydep, float *out) {
     __shared__ float red[3][16];
@@ -1251,7 +1558,9 @@ struct Config {
     size_t lds_bytes;
     size_t ws_gu_bytes;     // candidate buffers in global memory (0 when in LDS)
     size_t ws_fold_bytes;   // scaled copy of m2_data when the column term is folded in (0 otherwise)
-    size_t ws_order_bytes;  // work[n] + order[n] + 64 bucket counters when rows are visited by descending work
+    size_t ws_order_bytes;  // bucket counters + work[n] + order[n] + row descriptors
+    size_t ws_desc_offset;  // of the descriptors inside that block
+    int nb_log2;            // sparse path bitmap bits (log2)
     size_t ws_total;        // header + gU + fold scratch + order scratch
     bool fold;
     bool ordered;
@@ -1264,8 +1573,9 @@ static_assert(WS_PHASE_OFFSET + PH_N * 8 <= WS_YMIN_OFFSET && WS_YMIN_OFFSET + 1
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
 size_t lds_fixed_bytes(int T, int NT) {
-    // table + seg_lo + seg_pre(+64) + seg_v1 + seg_hi + hist + wsum + sh + ph
-    return (size_t)T * 8 + (size_t)NT * 4 + (size_t)(NT + 64) * 4 + (size_t)NT * 4 + (size_t)NT * 4 + 256 * 4 + 64 * 4 + 16 * 4 + 16 * 8;
+    // region A (table / bitmap) + region X (segment arrays | work items + 4 histograms) + hist + wsum + sh + ph
+    const size_t xb = std::max<size_t>((size_t)16 * NT + 256, (size_t)ITEM_CAP * 16 + 4096);
+    return (size_t)T * 8 + xb + 256 * 4 + 64 * 4 + 32 * 4 + 16 * 8;
 }
 
 int make_config(const sp_knn_args *a, int n_cus, Config *c) {
@@ -1289,6 +1599,7 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
     } else {
         cap = need_cap + 1024;
     }
+    cap &= ~1LL;   // the kernel clears the buffer with 16-byte stores
     if (cap > 0x7FFFFFF0LL) return fail(SP_EINVAL, "k too large");
     c->T = T; c->logT = logT; c->NT = NT; c->cap = (int)cap; c->u_lds = u_lds;
     c->hash_fill = std::max(1, (int)((long long)T * load / 100));
@@ -1306,7 +1617,13 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
               a->bayesian_shrink == 0.f && ((a->l2 != 0.f) != (a->l3 != 0.f)) && a->nnz_m2 > 0;
     c->ws_fold_bytes = c->fold ? (((size_t)a->nnz_m2 * 4 + 255) & ~(size_t)255) : 0;
     c->ordered = !(a->flags & (SP_FLAG_STATIC_SCHED | SP_FLAG_NO_ROW_ORDER)) && a->n_targets > num_wgs;
-    c->ws_order_bytes = c->ordered ? ((((size_t)a->n_targets * 8 + 512) + 255) & ~(size_t)255) : 0;
+    // 512 B of bucket counters | work[n] | order[n] | (32-byte aligned) desc[n] of 32 B
+    c->ws_desc_offset = (512 + (size_t)a->n_targets * 8 + 31) & ~(size_t)31;
+    c->ws_order_bytes = (c->ws_desc_offset + (size_t)a->n_targets * 32 + 255) & ~(size_t)255;
+    // sparse path: one bit per column while the columns fit region A, else columns alias modulo the bitmap size
+    int nb = 10;
+    while (nb < logT + 6 && (1LL << nb) < (long long)a->n_output_cols) ++nb;
+    c->nb_log2 = nb;
     c->ws_total = WS_QUEUE_BYTES + ((c->ws_gu_bytes + 255) & ~(size_t)255) + c->ws_fold_bytes + c->ws_order_bytes;
     return SP_OK;
 }
@@ -1424,23 +1741,28 @@ int run_device(sp_knn_args *a) {
     kp.T = c.T; kp.logT = c.logT; kp.cap = c.cap;
     kp.queue = (unsigned int *)ws;
     kp.gU = c.u_lds ? nullptr : (u64 *)(ws + WS_QUEUE_BYTES);
-    kp.order = nullptr;
-    if (c.ordered) {
+    {
         unsigned char *ob = ws + WS_QUEUE_BYTES + ((c.ws_gu_bytes + 255) & ~(size_t)255) + c.ws_fold_bytes;
         unsigned *bucket_count = (unsigned *)ob;            // [32]
         unsigned *bucket_base = bucket_count + 32;          // [32] + [1] flag
         unsigned *work = (unsigned *)(ob + 512);            // [n]
         int *order = (int *)(work + a->n_targets);          // [n]
+        int4 *desc = (int4 *)(ob + c.ws_desc_offset);       // [2n]
         HIP_TRY(hipMemsetAsync(ob, 0, 512, stream));
         const int waves_per_block = 256 / 64;
         hipLaunchKernelGGL(sp_row_work_kernel, dim3((a->n_targets + waves_per_block - 1) / waves_per_block), dim3(256), 0, stream,
                            a->n_targets, a->targets, a->m1_indices, a->m1_indptr, a->m2_indptr, work, bucket_count);
-        hipLaunchKernelGGL(sp_bucket_base_kernel, dim3(1), dim3(64), 0, stream, bucket_count, bucket_base);
-        hipLaunchKernelGGL(sp_row_order_kernel, dim3((a->n_targets + 255) / 256), dim3(256), 0, stream, a->n_targets, work, bucket_base, order);
+        if (c.ordered) {
+            hipLaunchKernelGGL(sp_bucket_base_kernel, dim3(1), dim3(64), 0, stream, bucket_count, bucket_base);
+            hipLaunchKernelGGL(sp_row_order_kernel, dim3((a->n_targets + 255) / 256), dim3(256), 0, stream, a->n_targets, work, bucket_base, order);
+        }
+        hipLaunchKernelGGL(sp_row_desc_kernel, dim3((a->n_targets + 255) / 256), dim3(256), 0, stream, a->n_targets, a->targets,
+                           a->m1_indptr, work, c.ordered ? bucket_base + 32 : nullptr, order, desc);
         HIP_TRY(hipGetLastError());
-        kp.order = order;
-        kp.use_order = bucket_base + 32;
+        kp.desc = desc;
     }
+    kp.m2_bytes = (unsigned)((size_t)a->nnz_m2 * 4);
+    kp.nb_log2 = c.nb_log2;
     kp.hash_fill = c.hash_fill;
     kp.static_sched = (a->flags & SP_FLAG_STATIC_SCHED) ? 1 : 0;
     kp.ymin = ymin_dev;
