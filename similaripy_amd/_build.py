@@ -17,8 +17,8 @@ CSRC_DIR = PKG_DIR / "csrc"
 LIB_DIR = PKG_DIR / "lib"
 LIB_PATH = LIB_DIR / "libsimilaripy_hip.so"
 
-SOURCES = [CSRC_DIR / "sp_knn.hip", CSRC_DIR / "sp_prep.hip"]
-HEADERS = [REPO_DIR / "include" / "sp_knn.h"]
+SOURCES = [CSRC_DIR / "sp_knn.hip"]
+HEADERS = [REPO_DIR / "include" / "sp_knn.h", *sorted(CSRC_DIR.glob("*.hpp"))]
 
 HIPCC_FLAGS = [
     "--offload-arch=gfx950",

@@ -1,0 +1,503 @@
+// sp_common.hpp — device-side vocabulary shared by the kernels of libsimilaripy_hip.so (gfx950 only).
+// Epilogue, candidate filter, top-k buffer primitives, selections.  Reference: similaripy/cython_code/s_plus.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+#include "../../include/sp_knn.h"
+
+typedef unsigned long long u64;
+
+namespace {
+
+
+constexpr int EMPTY = -1;                        // key of a free slot (column ids are >= 0)
+constexpr u64 EMPTY64 = 0xFFFFFFFF00000000ull;   // free accumulator slot: key EMPTY, partial sum +0.0f
+constexpr int MAX_PROBE = 128;   // probe budget of one element before a hashed window is declared overflowed
+// m2 elements per lane and trip (two trips are in flight); 1024-thread workgroups have half the VGPR budget
+#define ACC_UNROLL (NT >= 1024 ? 2 : NT >= 768 ? 4 : 8)
+constexpr int U_SLACK = 1024;    // candidate-buffer entries beyond k (room between two selections)
+// table slots per thread per drain iteration (their Y gathers fly together); 1024-thread workgroups have
+// half the VGPR budget (128), where 8 would spill
+#define DRAIN_UNROLL (NT >= 1024 ? 2 : NT >= 768 ? 4 : 8)
+
+// scalar slots in LDS
+enum { SH_CNT = 0, SH_OVF, SH_SEL, SH_NEED, SH_EQ, SH_CNT2, SH_RETRY, SH_QA, SH_QB, SH_DCTR, SH_PCTR, SH_NITEMS, SH_N };   // SH_CNT2/SEL/NEED/EQ belong to the selections
+
+// phases timed by lane 0 of every workgroup when KParams::phase_cycles != NULL, then event counters
+enum { PH_SETUP = 0, PH_SEGMENTS, PH_ACCUM, PH_DRAIN, PH_SELECT, PH_OUTPUT, PH_SWEEP1, PH_SWEEP2, PH_CSDRAIN,
+       CT_ROWS_SPARSE, CT_ROWS_FALLBACK, CT_PASSES, PH_N };
+
+struct KParams {
+    int n_targets;
+    const int *targets;
+    const float *m1_data; const int *m1_indices; const int *m1_indptr;
+    const float *m2_data; const int *m2_indices; const int *m2_indptr;
+    const float *Xtv, *Ytv, *Xcos, *Ycos, *Xdep, *Ydep;
+    float a1, l1, l2, l3, t1, t2, stab, bayes, threshold;
+    int k;
+    int n_cols;
+    int filter_mode; const int *f_indptr; const int *f_indices;
+    int target_mode; const int *t_indptr; const int *t_indices;
+    int *rows; int *cols; float *values; int *counts;
+    // configuration
+    int T;                 // accumulator slots (power of two); the table region is T*8 bytes
+    int logT;
+    int cap;               // candidate buffer capacity (> k)
+    u64 *gU, *gU_g;        // candidate buffers in global memory (only when they do not fit LDS): sparse / generic kernel
+    unsigned int *queue;   // [0] / [1] = next queue position of the sparse / generic kernel (dynamic scheduling)
+    unsigned int *qcount;  // [0] / [1] = rows in the sparse / generic queue (the sparse kernel appends its give-ups to [1])
+    const int4 *desc;      // sparse queue: two int4 per row {slot, m1 row, m1 start, m1 length}, {MACs (saturated), Xtv[row], Xcos[row], Xdep[row]}
+    int4 *desc_g;          // generic queue, same records
+    unsigned m2_bytes;     // nnz(m2) * 4: extent of the m2 index / value buffers (buffer-load range check)
+    int nb_log2;           // log2 of the sparse path's column bitmap size in bits (<= log2(T*64))
+    int hash_fill;         // slots' worth of MACs one hash window may receive (= T * load_pct / 100)
+    int static_sched;
+    const float *ymin;     // [3] minima of Ytv / Ycos / Ydep over all columns (valid iff bound_ok)
+    int bound_ok;          // weights/shrinks are all >= 0: the epilogue upper bound is sound
+    int sparse_path;       // 1 = rows with few expected collisions take the bitmap path
+    int fold;              // 1 = the single active column term (Ycos or Ydep) is already divided into m2_data: treat it as 1
+    unsigned long long *phase_cycles;  // optional [PH_N]
+    int dbg;               // ablation bits for profiling only (results are WRONG when non-zero):
+                           // 1 = generic accumulate: no LDS inserts, 4 = no Y gathers
+};
+
+// order-preserving float <-> uint map (so radix-select works for negative thresholds too)
+__device__ __forceinline__ unsigned fkey(float f) {
+    unsigned b = __float_as_uint(f);
+    return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float funkey(unsigned k) {
+    unsigned b = (k & 0x80000000u) ? (k ^ 0x80000000u) : ~k;
+    return __uint_as_float(b);
+}
+
+__device__ __forceinline__ int lower_bound_g(const int *__restrict__ a, int lo, int hi, int x) {
+    while (lo < hi) {
+        int mid = lo + ((hi - lo) >> 1);
+        if (a[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+__device__ __forceinline__ bool range_has(const int *__restrict__ a, int lo, int hi, int x) {
+    int p = lower_bound_g(a, lo, hi, x);
+    return p < hi && a[p] == x;
+}
+
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// Epilogue of s_plus.h:129-156: Tversky uses the RAW xy, pow only if a1 != 1,
+// raw dot returned when no normalisation/shrink is active, den == 0 -> 0.
+struct Epi {
+    float a1, l1, l2, l3, t1, t2, stab, bayes, threshold;
+    float xtv, xcos, xdep;  // row terms
+    bool any;
+    // upper bound without column terms: den >= bA + bB*xy for every column (valid iff bound)
+    bool bound;
+    float bA, bB;
+
+    // ytv / ycos / ydep: the column terms Ytv[col] / Ycos[col] / Ydep[col], gathered by the caller so
+    // that the loads of several candidates are in flight together (0 where the weight is 0)
+    __device__ __forceinline__ float operator()(float xy, float ytv, float ycos, float ydep) const {
+        float vt = 0.f, vc = 0.f, vd = 0.f, val = xy;
+        if (l1 != 0.f) vt = l1 * (t1 * (xtv - xy) + t2 * (ytv - xy) + xy);
+        if (l2 != 0.f) vc = l2 * (xcos * ycos);
+        if (l3 != 0.f) vd = l3 * (xdep * ydep);
+        if (a1 != 1.f) xy = powf(xy, a1);
+        if (any) {
+            float den = vt + vc + vd + stab;
+            val = (den != 0.f) ? xy / den : 0.f;
+            if (bayes != 0.f) val = val * (xy / (xy + bayes));
+        }
+        return val;
+    }
+
+    // A value the similarity of a candidate with raw dot xy cannot exceed whatever its column is
+    // (+inf when nothing can be said).  Uses only row terms and the per-launch minima of the column
+    // terms, so candidates can be discarded before any gather.
+    __device__ __forceinline__ float upper(float xy) const {
+        if (!any) return xy;                                   // raw dot: exact
+        if (!bound) return __builtin_inff();
+        const float den = bA + bB * xy;                        // <= true denominator
+        if (!(den > 0.f)) return __builtin_inff();
+        const float num = (a1 != 1.f) ? powf(xy, a1) : xy;
+        if (!(num >= 0.f)) {
+            // negative numerator over a positive denominator: the value is negative (NaN stays NaN and is
+            // dropped by the threshold test later); only prunable when no Bayesian factor can flip the sign
+            return (bayes == 0.f && threshold >= 0.f && num < 0.f) ? -__builtin_inff() : __builtin_inff();
+        }
+        float v = __fdividef(num, den) * 1.00002f + 1e-30f;    // slack for the few roundings that differ
+        return v;                                              // Bayesian factor num/(num+bayes) is <= 1
+    }
+};
+
+// Keep exactly the k largest of U[0..n) (n > k), in place.  MSD radix-select on the 32-bit key in
+// the high half of each entry.  Must be entered by the whole workgroup right after a barrier.
+// Returns the key of the k-th largest entry (the new running threshold), or -1 if n <= k (nothing done).
+template <int NT>
+__device__ long long compact_topk(u64 *U, int *hist, int *sh, int k) {
+    const int tid = threadIdx.x;
+    const int n = sh[SH_CNT];
+    __syncthreads();     // nobody may append (and change SH_CNT) before everyone has read n
+    if (n <= k) return -1;  // uniform
+
+    unsigned prefix = 0;
+    int need = k;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const unsigned hmask = (shift == 24) ? 0u : (0xFFFFFFFFu << (shift + 8));
+        for (int i = tid; i < n; i += NT) {
+            unsigned key = (unsigned)(U[i] >> 32);
+            if ((key & hmask) == (prefix & hmask)) atomicAdd(&hist[(key >> shift) & 255], 1);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            // lane L owns bins 255-4L .. 252-4L, i.e. lanes ascend as digits descend
+            const int b0 = 255 - 4 * tid;
+            const int c0 = hist[b0], c1 = hist[b0 - 1], c2 = hist[b0 - 2], c3 = hist[b0 - 3];
+            const int s = c0 + c1 + c2 + c3;
+            const int incl = wave_incl_scan(s);
+            const int excl = incl - s;
+            if (excl < need && need <= incl) {
+                int r = need - excl, d;
+                if (r <= c0) { d = b0; }
+                else if (r <= c0 + c1) { d = b0 - 1; r -= c0; }
+                else if (r <= c0 + c1 + c2) { d = b0 - 2; r -= c0 + c1; }
+                else { d = b0 - 3; r -= c0 + c1 + c2; }
+                sh[SH_SEL] = d;
+                sh[SH_NEED] = r;
+            }
+        }
+        __syncthreads();
+        prefix |= (unsigned)sh[SH_SEL] << shift;
+        need = sh[SH_NEED];
+    }
+    // prefix = k-th largest key; `need` entries equal to it are kept, everything larger is kept.
+    if (tid == 0) { sh[SH_CNT2] = 0; sh[SH_EQ] = 0; }
+    __syncthreads();
+    const int lane = tid & 63;
+    for (int base = 0; base < n; base += NT) {
+        const int i = base + tid;
+        u64 it = 0;
+        bool keep = false;
+        if (i < n) {
+            it = U[i];
+            unsigned key = (unsigned)(it >> 32);
+            if (key > prefix) keep = true;
+            else if (key == prefix) keep = atomicAdd(&sh[SH_EQ], 1) < need;
+        }
+        __syncthreads();  // every read of this chunk precedes the writes below (dest <= src index)
+        const u64 m = __ballot(keep);
+        if (m) {
+            int wbase = 0;
+            if (lane == 0) wbase = atomicAdd(&sh[SH_CNT2], __popcll(m));
+            wbase = __builtin_amdgcn_readfirstlane(wbase);
+            if (keep) U[wbase + __popcll(m & ((1ull << lane) - 1ull))] = it;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) sh[SH_CNT] = sh[SH_CNT2];
+    __syncthreads();
+    return (long long)prefix;
+}
+
+// Top `32 - shift` bits of a multiplicative (Fibonacci) hash of a column id.  A 24-bit multiply would be full
+// rate on CDNA but aliases 4-5x more often on uniformly random columns (simulated), which the bitmap path
+// pays for directly; one quarter-rate v_mul_lo_u32 per hash is the better trade.
+__device__ __forceinline__ unsigned hash_bits(int c, unsigned k, int shift) {
+    return ((unsigned)c * k) >> shift;
+}
+
+// Row-constant state needed to judge candidates.
+struct RowCtx {
+    Epi epi;
+    int row;               // absolute m1 row id (selector rows are indexed by it, s_plus.h:165-169)
+    int f0, f1, g0, g1;    // selector row ranges
+    bool have_thr;
+    unsigned thr_key;
+    float xy_cut;          // a candidate whose raw dot is <= xy_cut cannot enter the top-k (see set_cut)
+
+    // Invert the gather-free upper bound once per (row, running k-th value): the per-product test in the
+    // streaming loops becomes ONE float compare.  Conservative: -inf whenever the inversion is not obviously
+    // sound, in which case everything stays live and is judged exactly later.
+    __device__ __forceinline__ void set_cut(float threshold) {
+        const float ninf = -__builtin_inff();
+        // the value a candidate must beat: > running k-th value (strict) and >= threshold
+        const float below_thr = __uint_as_float(funkey_inv_below(threshold));
+        float t = below_thr;
+        if (have_thr) t = fmaxf(t, funkey(thr_key));
+        xy_cut = ninf;
+        if (!epi.any) { xy_cut = t; return; }                        // value == raw dot, exact
+        if (!epi.bound || epi.a1 != 1.f || !(t >= 0.f) || !(epi.bA > 0.f)) return;
+        // ub(xy) = s*xy / (bA + bB*xy) > t   <=>   xy * (s - t*bB) > t*bA      (denominator > 0 region, s = 1.00002)
+        const float s = 1.00002f;
+        const float d = s - t * epi.bB;
+        if (!(d > 0.f)) return;
+        xy_cut = (t * epi.bA) / d * 0.99998f;                        // shave: roundings of this formula itself
+    }
+    // largest float strictly below x, as the order-preserving key mapped back (helper for set_cut)
+    static __device__ __forceinline__ unsigned funkey_inv_below(float x) {
+        if (!(x == x)) return __float_as_uint(-__builtin_inff());
+        unsigned k = fkey(x);
+        k = (k == 0u) ? 0u : k - 1u;
+        unsigned b = (k & 0x80000000u) ? (k ^ 0x80000000u) : ~k;
+        if (b == 0x80000000u) b = 0x80000001u;   // -0.0 compares equal to +0.0: step on to the next float below
+        return b;
+    }
+};
+
+// Can a candidate with raw dot xy still enter the top-k?  Gather-free: row terms + per-launch column minima.
+__device__ __forceinline__ bool candidate_live(const KParams &p, const RowCtx &rc, float xy) {
+    const float ub = rc.epi.upper(xy);
+    // NaN bounds compare false on `<` and therefore stay live (the exact path drops them)
+    const bool dead = (ub < p.threshold) || (rc.have_thr && fkey(ub) <= rc.thr_key && !(ub != ub));
+    return !dead;
+}
+
+// Append the items flagged in `mask` (bit j = this lane's item j) to an LDS/global list: lane counts ->
+// wave scan -> ONE atomic on the list counter per wave.  store(j, pos) writes item j at list position pos;
+// items that do not fit raise *full_flag.  Must be called from wave-uniform control flow.
+template <int N, typename Store>
+__device__ __forceinline__ void wave_push(unsigned mask, int *counter, int capacity, int *full_flag, Store &&store) {
+    // per-item ballots give every lane its rank without any cross-lane data movement (s_bcnt1 / v_mbcnt),
+    // the reservation is one returning atomic by lane 0, broadcast with v_readfirstlane
+    const int lane = threadIdx.x & 63;
+    u64 m[N];
+    int off[N];
+    int tot = 0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        m[j] = __ballot((mask >> j) & 1u);
+        off[j] = tot;
+        tot += __popcll(m[j]);
+    }
+    if (tot == 0) return;  // wave-uniform
+    int wbase = 0;
+    if (lane == 0) wbase = atomicAdd(counter, tot);
+    wbase = __builtin_amdgcn_readfirstlane(wbase);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        if (mask & (1u << j)) {
+            const int pos = wbase + off[j] + __popcll(m[j] & ((1ull << lane) - 1ull));
+            if (pos < capacity) store(j, pos); else *full_flag = 1;
+        }
+    }
+}
+
+// Judge N candidates (column c[j], raw dot xy[j]; bit j of `occ` = slot j holds one) held per lane and
+// append the survivors to the top-k buffer U.  Order of work: gather-free upper bound -> column selectors
+// -> batched gathers of the column terms -> epilogue -> threshold / running k-th value -> one aggregated
+// reservation per wave.  Must be called from wave-uniform control flow.
+// Returns the candidates that are finished (rejected or stored).  A survivor that finds U full is not in
+// the returned mask and SH_RETRY is raised: the caller keeps it and re-offers it after a selection.
+template <int N>
+__device__ __forceinline__ unsigned emit_candidates(const KParams &p, const RowCtx &rc, const int (&c)[N], const float (&xy)[N],
+                                                    unsigned occ, u64 *U, int *sh) {
+    unsigned live = 0;
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+        if ((occ & (1u << j)) && candidate_live(p, rc, xy[j])) live |= 1u << j;
+    if (!__ballot(live != 0)) return occ;  // nothing in this wave can survive: no gathers, no epilogue
+
+    if (p.filter_mode == SP_SEL_MATRIX) {
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+            if ((live & (1u << j)) && range_has(p.f_indices, rc.f0, rc.f1, c[j])) live &= ~(1u << j);
+    }
+    if (p.target_mode == SP_SEL_MATRIX) {
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+            if ((live & (1u << j)) && !range_has(p.t_indices, rc.g0, rc.g1, c[j])) live &= ~(1u << j);
+    }
+    // gather the column terms of all N candidates first (loads in flight together); dead ones read column 0
+    float ytv[N], ycos[N], ydep[N];
+    int gc[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        gc[j] = ((live & (1u << j)) && !(p.dbg & 4)) ? c[j] : 0;
+        ytv[j] = 0.f; ycos[j] = 0.f; ydep[j] = 0.f;
+    }
+    if (p.l1 != 0.f) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) ytv[j] = p.Ytv[gc[j]];
+    }
+    if (p.l2 != 0.f) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) ycos[j] = p.fold ? 1.f : p.Ycos[gc[j]];
+    }
+    if (p.l3 != 0.f) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) ydep[j] = p.fold ? 1.f : p.Ydep[gc[j]];
+    }
+    unsigned want = 0;
+    unsigned key[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const float val = rc.epi(xy[j], ytv[j], ycos[j], ydep[j]);
+        key[j] = fkey(val);
+        if ((live & (1u << j)) && (val >= p.threshold) && (!rc.have_thr || key[j] > rc.thr_key)) want |= 1u << j;
+    }
+    // one aggregated reservation per wave
+    unsigned stored = 0;
+    wave_push<N>(want, &sh[SH_CNT], p.cap, &sh[SH_RETRY], [&](int j, int pos) {
+        U[pos] = ((u64)key[j] << 32) | (u64)(unsigned)c[j];
+        stored |= 1u << j;
+    });
+    return occ & (~want | stored);
+}
+
+// ---------------------------------------------------------------------------------------------
+// helpers of the sparse path
+// ---------------------------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int ITEM = 256;         // m2 elements per work item: one 16-byte load per lane
+constexpr int ITEM_CAP = 768;     // work items per row (LDS: 16 B each)
+constexpr int POOL_BLK = 64;      // pool entries a wave reserves at a time (>= 64: one trip always fits a fresh block)
+constexpr int CS_MAXPROBE = 64;   // linear-probe budget in the collision set
+constexpr unsigned OOB_SOFFSET = 0xFFFFF000u;   // buffer-load scalar offset beyond any m2 extent: every lane out of range
+constexpr int SORT_MAX = 256;     // m1 rows up to this many entries are visited in descending |value| order
+
+__device__ __forceinline__ int mbcnt64(u64 m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
+// Wave-private window [pos, end) into a shared LDS pool: entries are appended with no atomic at all until
+// the window is used up, then ONE returning atomic reserves the next POOL_BLK entries.  Abandoned tails stay
+// zero ("hole"); consumers skip zeros.  pos/end are wave-uniform (scalar registers).
+struct WavePool { int pos, end; };
+
+template <typename W>
+__device__ __forceinline__ void pool_push(WavePool &wp, bool pred, int *ctr, int cap, int *ovf, W &&write) {
+    const u64 m = __ballot(pred);
+    if (m == 0) return;                        // wave-uniform
+    const int n = __popcll(m);
+    if (wp.pos + n > wp.end) {
+        int base = 0;
+        if ((threadIdx.x & 63) == 0) base = atomicAdd(ctr, POOL_BLK);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base + POOL_BLK > cap) {           // pool exhausted: the row is redone on the generic path
+            if ((threadIdx.x & 63) == 0) *ovf = 1;
+            wp.pos = 0; wp.end = -1;
+            return;
+        }
+        wp.pos = base; wp.end = base + POOL_BLK;
+    }
+    if (pred) write(wp.pos + mbcnt64(m));
+    wp.pos += n;
+}
+
+// inclusive wave64 scan on the DPP crossbar (row_shr 1/2/4/8, row_bcast 15/31): no LDS round trips
+__device__ __forceinline__ int wave_incl_scan_dpp(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
+    return v;
+}
+
+// Selection for candidate buffers of at most 2*NT entries: every thread keeps its (<= 2) entries in registers,
+// one LDS histogram per radix pass (hist4 = 4 x 256 counters, zero on entry and on exit), every wave scans the
+// histogram redundantly (no broadcast barrier), 1 barrier per pass.
+//   exact:  keeps exactly k entries; returns the key of the k-th largest.
+//   !exact: stops after two passes (sign, exponent, 7 mantissa bits) when that already removes most of the
+//           surplus: keeps every entry >= the lower edge of the 16-bit bin holding the k-th largest and returns
+//           that edge — a valid (conservative) running cutoff, cheaper than the exact one.
+// Must be entered by the whole workgroup.  Returns -1 when n <= k (nothing done).
+template <int NT>
+__device__ long long select_fast(u64 *U, int *hist4, int *sh, int k, bool exact) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int n = sh[SH_CNT];
+    if (tid == 0) { sh[SH_CNT2] = 0; sh[SH_EQ] = 0; }   // (the generic path's selection leaves them dirty)
+    __syncthreads();
+    if (n <= k) return -1;
+    u64 e[2];
+    unsigned key[2];
+    bool has[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int i = tid + j * NT;
+        has[j] = i < n;
+        e[j] = has[j] ? U[i] : 0ull;
+        key[j] = (unsigned)(e[j] >> 32);
+    }
+    unsigned prefix = 0;
+    int need = k;
+    int passes = 0;
+    for (int ps = 0; ps < 4; ++ps) {
+        const int shift = 24 - 8 * ps;
+        const unsigned hmask = (ps == 0) ? 0u : (0xFFFFFFFFu << (shift + 8));
+        int *h = hist4 + ps * 256;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if (has[j] && ((key[j] ^ prefix) & hmask) == 0u) atomicAdd(&h[(key[j] >> shift) & 255u], 1);
+        __syncthreads();
+        // lane L owns bins 255-4L .. 252-4L (lanes ascend as digits descend)
+        const int4 c4 = *(const int4 *)&h[252 - 4 * lane];
+        const int c0 = c4.w, c1 = c4.z, c2 = c4.y, c3 = c4.x;
+        const int s = c0 + c1 + c2 + c3;
+        const int incl = wave_incl_scan_dpp(s);
+        const int excl = incl - s;
+        const bool mine = excl < need && need <= incl;
+        int d = 0, r = 0, cb = 0;
+        if (mine) {
+            const int b0 = 255 - 4 * lane;
+            r = need - excl;
+            if (r <= c0) { d = b0; cb = c0; }
+            else if (r <= c0 + c1) { d = b0 - 1; r -= c0; cb = c1; }
+            else if (r <= c0 + c1 + c2) { d = b0 - 2; r -= c0 + c1; cb = c2; }
+            else { d = b0 - 3; r -= c0 + c1 + c2; cb = c3; }
+        }
+        const int leader = (int)__builtin_ctzll(__ballot(mine));
+        d = __builtin_amdgcn_readlane(d, leader);
+        r = __builtin_amdgcn_readlane(r, leader);
+        cb = __builtin_amdgcn_readlane(cb, leader);
+        const int above = need - r;            // entries of this pass's population that lie above the chosen bin
+        prefix |= (unsigned)d << shift;
+        passes = ps + 1;
+        if (!exact && ps == 1) {
+            // keeping the whole bin leaves (k - r) + cb entries: good enough when that is at most half the surplus
+            const int kept = (k - r) + cb;
+            (void)above;
+            if (2 * (kept - k) <= (n - k)) { need = r; break; }
+        }
+        need = r;
+    }
+    const bool all_passes = (passes == 4);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        bool keep = false;
+        if (has[j]) {
+            if (key[j] > prefix) keep = true;
+            else if (key[j] == prefix) keep = all_passes ? (atomicAdd(&sh[SH_EQ], 1) < need) : true;
+            else if (!all_passes) keep = (key[j] >= prefix);     // prefix has its low bits clear: the bin's lower edge
+        }
+        const u64 m = __ballot(keep);
+        if (m) {
+            int wbase = 0;
+            if (lane == 0) wbase = atomicAdd(&sh[SH_CNT2], __popcll(m));
+            wbase = __builtin_amdgcn_readfirstlane(wbase);
+            if (keep) U[wbase + mbcnt64(m)] = e[j];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < passes * 256; i += NT) hist4[i] = 0;
+    if (tid == 0) sh[SH_CNT] = sh[SH_CNT2];
+    __syncthreads();
+    return (long long)prefix;
+}
+
+
+}  // namespace

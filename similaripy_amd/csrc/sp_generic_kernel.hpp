@@ -1,0 +1,425 @@
+// sp_generic_kernel.hpp — rows that are NOT sparse (dense / colliding rows, tiny matrices, huge k) and rows the
+// sparse kernel gave up on: LDS accumulator tile of T {column, partial dot} slots, direct-indexed when the column
+// window is <= T wide, hashed (64-bit compare-and-swap claims a slot and deposits the first product) otherwise;
+// rows whose candidates do not fit one tile are processed in column windows exactly like the reference's blocked
+// path (s_plus.h:350-410), the top-k state carried across windows.
+#pragma once
+#include "sp_common.hpp"
+
+namespace {
+
+template <int NT, bool U_LDS>
+__global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NW = NT / 64;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = p.T;
+
+    // ---- LDS carve-up (single dynamic array) ----
+    u64 *tab = (u64 *)smem;                     // [T]  {column id : partial dot product}
+    int *seg_lo = (int *)(tab + T);             // [NT]   start of the (window's) slice of m2 row u
+    int *seg_pre = seg_lo + NT;                 // [NT+64] exclusive prefix of slice lengths
+    float *seg_v1 = (float *)(seg_pre + NT + 64);  // [NT] m1 value of the segment
+    int *seg_hi = (int *)(seg_v1 + NT);         // [NT]   end of the slice (= start of the next window's)
+    int *hist = seg_hi + NT;                    // [256]
+    int *wsum = hist + 256;                     // [64]
+    int *sh = wsum + 64;                        // [32]
+    u64 *ph = (u64 *)(sh + 32);                 // [16] phase timers / event counters (lane 0 only)
+    u64 *U = U_LDS ? (u64 *)(ph + 16) : (p.gU_g + (size_t)blockIdx.x * (size_t)p.cap);
+
+    for (int i = tid; i < T; i += NT) tab[i] = EMPTY64;
+    if (tid < 32) sh[tid] = 0;
+    if (tid < 16) ph[tid] = 0;
+    __syncthreads();
+
+    const bool any_norm = (p.l1 != 0.f || p.l2 != 0.f || p.l3 != 0.f || p.stab != 0.f || p.bayes != 0.f);
+    float ymin_tv = 0.f, ymin_cos = 0.f, ymin_dep = 0.f;
+    if (p.bound_ok) {
+        if (p.fold) { ymin_cos = 1.f; ymin_dep = 1.f; }     // folded column term: exactly 1 for every column
+        else { ymin_tv = p.ymin[0]; ymin_cos = p.ymin[1]; ymin_dep = p.ymin[2]; }
+    }
+
+    // phase timers (lane 0 only; s_memtime ticks are shader cycles)
+    const bool timing = (p.phase_cycles != nullptr) && tid == 0;
+    u64 tmark = timing ? (u64)clock64() : 0;
+#define PHASE_END(which) do { if (timing) { const u64 _n = (u64)clock64(); ph[which] += _n - tmark; tmark = _n; } } while (0)
+
+    // Generic path streaming front end.  Visit the flat element space [eb, ee) of the current segment list
+    // (nb segments, prefix in seg_pre): wave w owns a contiguous 64-aligned chunk, every lane handles AU
+    // stride-64 elements per trip (coalesced loads), all lanes of a wave make the same number of trips, and the
+    // loads of trip i+1 are issued before trip i is processed (two register sets, no copies).
+    // Per lane the current segment is cached in registers (end of segment, flat->m2 index delta, m1 value):
+    // the common element costs one compare and one add.  m2 is addressed with 32-bit byte offsets from the
+    // scalar base pointers (the host only launches this kernel for nnz(m2) < 2^30).
+    // body(c[], x[], v1[], valid): c = column id, x = m2 value (0 unless loadx), v1 = m1 value of the
+    // element's segment; padding elements (bit clear in `valid`) repeat a real element of the lane, v1 = 0.
+    const char *m2i_bytes = (const char *)p.m2_indices;
+    const char *m2d_bytes = (const char *)p.m2_data;
+    auto for_elements = [&](auto loadx, auto unroll, int eb, int ee, int nb, auto &&body) __attribute__((always_inline)) {
+        constexpr bool LOADX = decltype(loadx)::value;
+        constexpr int AU = decltype(unroll)::value;
+        const int span = ee - eb;
+        if (span <= 0) return;
+        const int chunk = ((span + NW * 64 - 1) / (NW * 64)) * 64;
+        const int e0 = eb + wave * chunk;
+        const int e1 = min(e0 + chunk, ee);
+        if (e0 >= e1) return;  // wave-uniform
+        const int efirst = min(e0 + lane, e1 - 1);
+        int sl = 0, sr = nb;  // last s in [0,nb) with seg_pre[s] <= efirst (seg_pre[0] = 0)
+        while (sr - sl > 1) {
+            const int mid = (sl + sr) >> 1;
+            if (seg_pre[mid] <= efirst) sl = mid; else sr = mid;
+        }
+        int seg = sl;
+        int seg_end = (seg + 1 < nb) ? seg_pre[seg + 1] : 0x7FFFFFFF;   // first flat index beyond the segment
+        int delta = seg_lo[seg] - seg_pre[seg];                          // m2 position = flat index + delta
+        float segv = seg_v1[seg];
+        const int idx_safe = efirst + delta;
+        auto fetch = [&](int ebase, int (&c)[AU], float (&x)[AU], float (&v1)[AU], unsigned &valid) {
+            unsigned off[AU];
+            valid = 0;
+#pragma unroll
+            for (int j = 0; j < AU; ++j) {
+                const int ej = ebase + 64 * j + lane;
+                const bool ok = ej < e1;
+                if (ok && ej >= seg_end) {                 // rare: crossed into a later segment (skips empty ones)
+                    do {
+                        ++seg;
+                        seg_end = (seg + 1 < nb) ? seg_pre[seg + 1] : 0x7FFFFFFF;
+                    } while (ej >= seg_end);
+                    delta = seg_lo[seg] - seg_pre[seg];
+                    segv = seg_v1[seg];
+                }
+                off[j] = (unsigned)(ok ? ej + delta : idx_safe) << 2;
+                v1[j] = ok ? segv : 0.f;
+                valid |= ok ? (1u << j) : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < AU; ++j) c[j] = *(const int *)(m2i_bytes + off[j]);
+#pragma unroll
+            for (int j = 0; j < AU; ++j) x[j] = LOADX ? *(const float *)(m2d_bytes + off[j]) : 0.f;
+        };
+        constexpr int STEP = 64 * AU;
+        int cA[AU], cB[AU];
+        float xA[AU], xB[AU], vA[AU], vB[AU];
+        unsigned validA = 0, validB = 0;
+        fetch(e0, cA, xA, vA, validA);
+        for (int ebase = e0; ebase < e1; ebase += 2 * STEP) {
+            const bool hasB = ebase + STEP < e1;          // wave-uniform
+            if (hasB) fetch(ebase + STEP, cB, xB, vB, validB);
+            body(cA, xA, vA, validA);
+            if (hasB) {
+                if (ebase + 2 * STEP < e1) fetch(ebase + 2 * STEP, cA, xA, vA, validA);
+                body(cB, xB, vB, validB);
+            }
+        }
+    };
+
+    // Turn per-thread slice lengths into the flat prefix array; returns the total.  Two barriers.
+    auto scan_segments = [&](int len) -> int {
+        const int incl = wave_incl_scan(len);
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int woff = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const int sw = wsum[w];
+            if (w < wave) woff += sw;
+            total += sw;
+        }
+        seg_pre[tid] = woff + incl - len;
+        __syncthreads();
+        return __builtin_amdgcn_readfirstlane(total);
+    };
+
+    // rows of this kernel: descriptors [0, n_rows) of the generic queue (filled by the classification prepass and
+    // by the sparse kernel's give-ups, both complete before this launch starts)
+    const int n_rows = (int)p.qcount[1];
+    const int4 *desc = p.desc_g;
+    int qi = 0;
+    if (tid == 0) sh[SH_QA] = p.static_sched ? (int)blockIdx.x : (int)atomicAdd(&p.queue[1], 1u);
+    __syncthreads();
+
+    for (;;) {
+        qi = __builtin_amdgcn_readfirstlane(sh[SH_QA]);
+        if (qi >= n_rows) break;
+        const int4 dC = desc[2 * (size_t)qi], wC = desc[2 * (size_t)qi + 1];
+        // row-constant values are wave-uniform: v_readfirstlane moves them to scalar registers
+        const int slot_i = __builtin_amdgcn_readfirstlane(dC.x);
+        const int t = __builtin_amdgcn_readfirstlane(dC.y);
+        const int s1 = __builtin_amdgcn_readfirstlane(dC.z);
+        const int n1 = __builtin_amdgcn_readfirstlane(dC.w);
+        const u64 macs = (u64)(unsigned)__builtin_amdgcn_readfirstlane(wC.x);   // saturated at 2^32-1 by the work prepass
+        // claim the next queue position early; it is published at the bottom of the loop
+        int next_q = 0;
+        if (tid == 0) next_q = p.static_sched ? qi + (int)gridDim.x : (int)atomicAdd(&p.queue[1], 1u);
+
+        RowCtx rc;
+        rc.row = t;
+        rc.have_thr = false;
+        rc.thr_key = 0;
+        Epi &epi = rc.epi;
+        epi.a1 = p.a1; epi.l1 = p.l1; epi.l2 = p.l2; epi.l3 = p.l3; epi.t1 = p.t1; epi.t2 = p.t2;
+        epi.stab = p.stab; epi.bayes = p.bayes; epi.threshold = p.threshold; epi.any = any_norm;
+        epi.xtv = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane(wC.y));    // row terms travel in the descriptor
+        epi.xcos = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane(wC.z));
+        epi.xdep = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane(wC.w));
+        // den = l1*(t1*(X-xy) + t2*(Y-xy) + xy) + l2*Xc*Yc + l3*Xd*Yd + stab  >=  bA + bB*xy  when the
+        // column terms are replaced by their minima and their multipliers are non-negative
+        epi.bound = p.bound_ok && !(epi.xcos < 0.f) && !(epi.xdep < 0.f);
+        epi.bA = p.l1 * (p.t1 * epi.xtv + p.t2 * ymin_tv) + p.l2 * epi.xcos * ymin_cos + p.l3 * epi.xdep * ymin_dep + p.stab;
+        epi.bB = p.l1 * (1.f - p.t1 - p.t2);
+
+        rc.set_cut(p.threshold);
+        rc.f0 = rc.f1 = rc.g0 = rc.g1 = 0;
+        if (p.filter_mode == SP_SEL_MATRIX) { rc.f0 = __builtin_amdgcn_readfirstlane(p.f_indptr[t]); rc.f1 = __builtin_amdgcn_readfirstlane(p.f_indptr[t + 1]); }
+        if (p.target_mode == SP_SEL_MATRIX) { rc.g0 = __builtin_amdgcn_readfirstlane(p.t_indptr[t]); rc.g1 = __builtin_amdgcn_readfirstlane(p.t_indptr[t + 1]); }
+
+        // running k-th value after a selection
+        auto took_threshold = [&](long long thr_new) __attribute__((always_inline)) {
+            if (thr_new >= 0) {
+                rc.have_thr = true;
+                rc.thr_key = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)thr_new);
+                rc.set_cut(p.threshold);
+            }
+        };
+        const bool row_done = (macs == 0);
+        PHASE_END(PH_SETUP);
+
+        // =========================================================================================
+        // GENERIC path: accumulator tile + column windows
+        // =========================================================================================
+        if (!row_done) {
+            bool retry_window = false;  // the current window repeats the previous lo (after an overflow)
+
+            // dense windows can never overflow (one slot per column); hash windows are sized from the
+            // MACs bound and split on overflow.  Window width w; windows are [lo, lo+w).
+            long long width;
+            if (p.n_cols <= T) {
+                width = p.n_cols;
+            } else {
+                const long long p_dense = ((long long)p.n_cols + T - 1) / T;
+                const long long p_hash = (long long)((macs + (u64)p.hash_fill - 1) / (u64)p.hash_fill);
+                if (p_hash < 1 || p_dense <= p_hash) width = T;
+                else width = ((long long)p.n_cols + p_hash - 1) / p_hash;
+            }
+
+            long long lo = 0;
+            while (lo < (long long)p.n_cols) {
+                long long hi = lo + width;
+                if (hi > p.n_cols) hi = p.n_cols;
+                const int wlo = (int)lo, whi = (int)hi;
+                const bool dense = (hi - lo) <= (long long)T;
+                const bool whole = (wlo == 0 && whi == p.n_cols);
+                int t_eff = dense ? (whi - wlo) : T;
+                int hshift = 32 - p.logT;
+                if (!dense && whole) {
+                    // single hash window over a small row: shrink the table so the drain scans less
+                    int lg = 10;
+                    while (lg < p.logT && (1ull << lg) < 2ull * macs) ++lg;
+                    t_eff = 1 << lg;
+                    hshift = 32 - lg;
+                }
+                const unsigned hmask = (unsigned)t_eff - 1u;
+
+                // ================= accumulate =================
+                // Window slices chain (hi of window w == lo of window w+1), so when the m1 row fits one
+                // batch the previous slice end is kept in LDS and only one lower_bound per window is run.
+                const bool carry = (n1 <= NT);
+                for (int b0 = 0; b0 < n1; b0 += NT) {
+                    const int nb = min(NT, n1 - b0);
+                    int len = 0;
+                    if (tid < nb) {
+                        const int u = p.m1_indices[s1 + b0 + tid];
+                        int r0 = p.m2_indptr[u], r1 = p.m2_indptr[u + 1];
+                        if (!whole) {
+                            // slice of the sorted m2 row inside [wlo, whi)  (s_plus.h:385-394)
+                            if (wlo != 0) {
+                                if (carry) r0 = retry_window ? seg_lo[tid] : seg_hi[tid];
+                                else r0 = lower_bound_g(p.m2_indices, r0, r1, wlo);
+                            }
+                            if (whi < p.n_cols) r1 = lower_bound_g(p.m2_indices, r0, r1, whi);
+                            if (carry) seg_hi[tid] = r1;
+                        }
+                        seg_lo[tid] = r0;
+                        seg_v1[tid] = p.m1_data[s1 + b0 + tid];
+                        len = r1 - r0;
+                    }
+                    const int total = scan_segments(len);
+                    PHASE_END(PH_SEGMENTS);
+
+                    for_elements(std::true_type{}, std::integral_constant<int, ACC_UNROLL>{}, 0, total, nb,
+                                 [&](const int (&c)[ACC_UNROLL], const float (&xr)[ACC_UNROLL], const float (&v1)[ACC_UNROLL], unsigned) {
+                        float x[ACC_UNROLL];
+#pragma unroll
+                        for (int j = 0; j < ACC_UNROLL; ++j) x[j] = xr[j] * v1[j];   // padding elements carry 0
+                        if (p.dbg & 1) {
+                            float sink = 0.f;
+#pragma unroll
+                            for (int j = 0; j < ACC_UNROLL; ++j) sink += x[j] + (float)c[j];
+                            if (sink == 123.456f) sh[SH_OVF] = 2;  // keeps the loads alive, never true in practice
+                        } else if (dense) {
+                            // direct-indexed window: every column owns its slot.  Optimistic update: read the
+                            // slot, then ONE 64-bit compare-and-swap writes {column, sum + x} (ds_cmpst_rtn_b64:
+                            // 3.3 lanes/clk against 0.33 for ds_add_f32); the lanes of a wave instruction hold 64
+                            // distinct columns of one m2 row, so only another wave can interfere — a lost race
+                            // falls back to the hardware float add on the sum half (the key half is already set
+                            // by whoever won), which cannot livelock on hot columns.
+                            u64 cur[ACC_UNROLL], prev[ACC_UNROLL];
+#pragma unroll
+                            for (int j = 0; j < ACC_UNROLL; ++j) cur[j] = tab[c[j] - wlo];
+#pragma unroll
+                            for (int j = 0; j < ACC_UNROLL; ++j) {
+                                const float sum = __uint_as_float((unsigned)cur[j]) + x[j];
+                                prev[j] = atomicCAS(&tab[c[j] - wlo], cur[j], ((u64)(unsigned)c[j] << 32) | (u64)__float_as_uint(sum));
+                            }
+#pragma unroll
+                            for (int j = 0; j < ACC_UNROLL; ++j)
+                                if (prev[j] != cur[j]) atomicAdd((float *)&tab[c[j] - wlo], x[j]);
+                        } else {
+                            // Hashed window.  One 64-bit compare-and-swap claims a free slot for a new column AND
+                            // deposits its first product; finding the same column already there turns into a
+                            // hardware float add on the sum half (slow on gfx950, 3 clk/lane, but immune to
+                            // contention on hot columns); finding another column means double-hash probing.
+                            // Round 1 issues the ACC_UNROLL claims back to back; the few leftovers are then walked
+                            // one element per lane per round.
+                            unsigned hs[ACC_UNROLL];
+                            u64 prev[ACC_UNROLL];
+#pragma unroll
+                            for (int j = 0; j < ACC_UNROLL; ++j) hs[j] = ((unsigned)c[j] * 2654435761u) >> hshift;
+#pragma unroll
+                            for (int j = 0; j < ACC_UNROLL; ++j)
+                                prev[j] = atomicCAS(&tab[hs[j]], EMPTY64, ((u64)(unsigned)c[j] << 32) | (u64)__float_as_uint(x[j]));
+                            unsigned pend = 0;
+#pragma unroll
+                            for (int j = 0; j < ACC_UNROLL; ++j) {
+                                const bool hit = ((int)(prev[j] >> 32) == c[j]);
+                                if (hit) atomicAdd((float *)&tab[hs[j]], x[j]);
+                                if (prev[j] != EMPTY64 && !hit) pend |= 1u << j;
+                            }
+                            int plen = 0;
+                            while (__ballot(pend != 0)) {   // wave-uniform trip count
+                                if (!pend) continue;
+                                const unsigned bit = pend & (0u - pend);  // this lane's current element
+                                int cc = c[0];
+                                float xx = x[0];
+                                unsigned hh = hs[0];
+#pragma unroll
+                                for (int j = 1; j < ACC_UNROLL; ++j)
+                                    if (bit == (1u << j)) { cc = c[j]; xx = x[j]; hh = hs[j]; }
+                                // double hashing: an odd, key-dependent stride visits every slot of the
+                                // power-of-two table and avoids the long clusters of linear probing
+                                hh = (hh + ((((unsigned)cc * 0x85EBCA6Bu) >> 15) | 1u)) & hmask;
+                                const u64 pv = atomicCAS(&tab[hh], EMPTY64, ((u64)(unsigned)cc << 32) | (u64)__float_as_uint(xx));
+                                const bool hit = ((int)(pv >> 32) == cc);
+                                if (hit) atomicAdd((float *)&tab[hh], xx);
+                                if (pv == EMPTY64 || hit) { pend &= ~bit; plen = 0; }
+                                else if (++plen >= MAX_PROBE) { sh[SH_OVF] = 1; pend = 0; }
+#pragma unroll
+                                for (int j = 0; j < ACC_UNROLL; ++j)
+                                    if (bit == (1u << j)) hs[j] = hh;
+                            }
+                        }
+                    });
+                    __syncthreads();  // seg_* are rewritten by the next batch
+                    PHASE_END(PH_ACCUM);
+                }
+
+                // ================= overflow: discard the window, halve it, retry =================
+                if (!dense) {
+                    const int ovf = sh[SH_OVF];
+                    __syncthreads();
+                    if (ovf) {
+                        for (int i = tid; i < t_eff; i += NT) tab[i] = EMPTY64;
+                        if (tid == 0) sh[SH_OVF] = 0;
+                        width = max((long long)T, (width + 1) / 2);
+                        retry_window = true;  // same lo again: slice starts are still in seg_lo
+                        __syncthreads();
+                        continue;
+                    }
+                }
+                retry_window = false;
+                if (timing) ph[CT_PASSES] += 1;
+
+                // ================= drain: one barrier-free sweep, overflow-retry =================
+                for (;;) {
+                    for (int base = 0; base < t_eff; base += NT * DRAIN_UNROLL) {
+                        int c[DRAIN_UNROLL];
+                        float xy[DRAIN_UNROLL];
+                        unsigned occ = 0;
+#pragma unroll
+                        for (int j = 0; j < DRAIN_UNROLL; ++j) {
+                            const int sidx = base + j * NT + tid;
+                            c[j] = EMPTY;
+                            xy[j] = 0.f;
+                            if (sidx < t_eff) {
+                                const u64 slot = tab[sidx];
+                                c[j] = (int)(slot >> 32);
+                                xy[j] = __uint_as_float((unsigned)slot);
+                            }
+                            if (c[j] != EMPTY) occ |= 1u << j;
+                        }
+                        const unsigned done = emit_candidates<DRAIN_UNROLL>(p, rc, c, xy, occ, U, sh);
+#pragma unroll
+                        for (int j = 0; j < DRAIN_UNROLL; ++j)
+                            if (done & (1u << j)) tab[base + j * NT + tid] = EMPTY64;
+                    }
+                    __syncthreads();  // sweep complete (also orders the slot clears before the next window)
+                    const int retry = sh[SH_RETRY];
+                    if (!retry) break;  // uniform
+                    __syncthreads();    // everyone has seen the flag
+                    if (tid == 0) {
+                        sh[SH_RETRY] = 0;
+                        if (sh[SH_CNT] > p.cap) sh[SH_CNT] = p.cap;  // failed appends over-counted
+                    }
+                    __syncthreads();
+                    PHASE_END(PH_DRAIN);
+                    took_threshold(compact_topk<NT>(U, hist, sh, p.k));
+                    PHASE_END(PH_SELECT);
+                }
+                PHASE_END(PH_DRAIN);
+                lo = hi;
+            }
+        }
+
+
+        // ================= final selection + write-out =================
+        __syncthreads();
+        const int n_fin = sh[SH_CNT];
+        __syncthreads();
+        if (n_fin > p.k) took_threshold(compact_topk<NT>(U, hist, sh, p.k));
+        PHASE_END(PH_SELECT);
+        const int n_out = sh[SH_CNT];
+        const long long o = (long long)slot_i * (long long)p.k;
+        for (int j = tid; j < p.k; j += NT) {
+            int r = 0, c = 0;
+            float v = 0.f;
+            if (j < n_out) {
+                const u64 it = U[j];
+                r = t;
+                c = (int)(unsigned)(it & 0xFFFFFFFFull);
+                v = funkey((unsigned)(it >> 32));
+            }
+            if (p.rows) p.rows[o + j] = r;
+            p.cols[o + j] = c;
+            p.values[o + j] = v;
+        }
+        if (tid == 0) {
+            if (p.counts) p.counts[slot_i] = n_out;
+            sh[SH_QA] = next_q;
+        }
+        __syncthreads();
+        if (tid == 0) sh[SH_CNT] = 0;
+        __syncthreads();
+        PHASE_END(PH_OUTPUT);
+    }
+    if (timing) {
+#pragma unroll
+        for (int i = 0; i < PH_N; ++i) atomicAdd(&p.phase_cycles[i], ph[i]);
+    }
+#undef PHASE_END
+}
+
+}  // namespace

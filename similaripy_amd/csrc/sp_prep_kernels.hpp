@@ -1,0 +1,165 @@
+// sp_prep_kernels.hpp — the small launches in front of the row kernels: work per row, work-ordered queue,
+// classified row descriptors, column-term minima, column term folded into the m2 stream.
+#pragma once
+#include "sp_common.hpp"
+
+namespace {
+
+
+// ---- work-ordered row queue (longest-processing-time-first, to within a factor 2) ----
+// Rows are visited in descending MACs(t) buckets (bucket = floor(log2(work))), so that one huge row at the end of
+// the target list cannot become the tail of the launch on skewed (power-law) matrices.
+__global__ __launch_bounds__(256) void sp_row_work_kernel(int n_targets, const int *targets, const int *m1_indices,
+                                                           const int *m1_indptr, const int *m2_indptr, unsigned *work,
+                                                           unsigned *bucket_count) {
+    __shared__ unsigned hist[32];
+    if (threadIdx.x < 32) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int gw = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6);
+    const int lane = threadIdx.x & 63;
+    if (gw < n_targets) {
+        const int t = targets[gw];
+        const int s = m1_indptr[t], e = m1_indptr[t + 1];
+        u64 acc = 0;
+        for (int j = s + lane; j < e; j += 64) {
+            const int u = m1_indices[j];
+            acc += (u64)(m2_indptr[u + 1] - m2_indptr[u]);
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+        if (lane == 0) {
+            const unsigned w = acc > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)acc;
+            work[gw] = w;
+            atomicAdd(&hist[31 - __clz((int)(w | 1u))], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 32 && hist[threadIdx.x]) atomicAdd(&bucket_count[threadIdx.x], hist[threadIdx.x]);
+}
+
+// bucket_count[0..32) -> bucket_base[0..32): start of each bucket when buckets are laid out heaviest first
+// bucket_base[32] = 1 when the work spans at least a factor ~4 (otherwise the target order is kept: nothing to gain)
+__global__ void sp_bucket_base_kernel(const unsigned *bucket_count, unsigned *bucket_base) {
+    if (threadIdx.x == 0) {
+        unsigned run = 0;
+        int hi = -1, lo = 32;
+        for (int b = 31; b >= 0; --b) {
+            bucket_base[b] = run;
+            run += bucket_count[b];
+            if (bucket_count[b]) { if (hi < 0) hi = b; lo = b; }
+        }
+        bucket_base[32] = (hi - lo >= 2) ? 1u : 0u;
+    }
+}
+
+__global__ __launch_bounds__(256) void sp_row_order_kernel(int n_targets, const unsigned *work, unsigned *bucket_base, int *order) {
+    if (bucket_base[32] == 0) return;   // uniform work: the main kernel keeps the target order
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool live = i < n_targets;
+    const int b = live ? 31 - __clz((int)(work[i] | 1u)) : -1;
+    // one atomic per (wave, bucket): rows of similar work share a bucket, and a single global word only
+    // sustains ~88 atomics/us — a per-row atomic would cost ~11 ms for 1M equal rows
+    u64 todo = __ballot(live);
+    while (todo) {
+        const int leader = (int)__builtin_ctzll(todo);
+        const int b0 = __shfl(b, leader, 64);
+        const u64 same = __ballot(live && b == b0);
+        unsigned base = 0;
+        if (lane == leader) base = atomicAdd(&bucket_base[b0], (unsigned)__popcll(same));
+        base = __shfl(base, leader, 64);
+        if (live && b == b0) order[base + __popcll(same & ((1ull << lane) - 1ull))] = i;
+        todo &= ~same;
+    }
+}
+
+// Row descriptors, classified: what a kernel needs to start a row, one 32-byte record per queue position, so that
+// its dependent-load chain is queue -> descriptor -> m1 entries -> m2 row bounds.  Rows the sparse kernel can
+// take (few expected column collisions, few m1 entries) go to the sparse queue, everything else to the generic
+// queue; positions are claimed with one atomic per wave and class, which keeps the (descending work) order of
+// the input up to wave granularity.
+struct ClassifyParams {
+    int sparse_path;       // 0: everything is generic
+    int n_cols, T;
+    int nb_log2;           // sparse bitmap bits
+    int cs_slots, dup_cap; // collision-set slots / duplicate-pool entries of the sparse kernel
+};
+
+__global__ __launch_bounds__(256) void sp_row_desc_kernel(int n_targets, const int *targets, const int *m1_indptr, const unsigned *work,
+                                                           const unsigned *ordered_flag, const int *order, const float *Xtv,
+                                                           const float *Xcos, const float *Xdep, ClassifyParams cp,
+                                                           unsigned *qcount, int4 *desc_s, int4 *desc_g) {
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool valid = pos < n_targets;
+    int4 d0 = make_int4(0, 0, 0, 0), d1 = d0;
+    bool sparse = false;
+    if (valid) {
+        const int slot = (ordered_flag != nullptr && ordered_flag[0] != 0u) ? order[pos] : pos;
+        const int t = targets[slot];
+        const int s = m1_indptr[t], e = m1_indptr[t + 1];
+        const unsigned macs = work[slot];
+        d0 = make_int4(slot, t, s, e - s);
+        d1 = make_int4((int)macs, Xtv ? (int)__float_as_uint(Xtv[t]) : 0, Xcos ? (int)__float_as_uint(Xcos[t]) : 0,
+                       Xdep ? (int)__float_as_uint(Xdep[t]) : 0);
+        if (cp.sparse_path && macs > 0u && macs < (1u << 30) && (e - s) <= SORT_MAX && cp.n_cols > cp.T) {
+            // expected number of products that find their bit set: true collisions + bitmap aliasing
+            const float m = (float)macs;
+            const float alias = (cp.nb_log2 < 31 && (1 << cp.nb_log2) < cp.n_cols) ? 1.f / (float)(1 << cp.nb_log2) : 0.f;
+            const float expect = 0.5f * m * m * (1.f / (float)cp.n_cols + alias);
+            sparse = expect <= 0.30f * (float)cp.cs_slots && expect <= 0.40f * (float)cp.dup_cap;
+        }
+    }
+    const u64 ms = __ballot(valid && sparse), mg = __ballot(valid && !sparse);
+    unsigned bs = 0, bg = 0;
+    if (lane == 0) {
+        if (ms) bs = atomicAdd(&qcount[0], (unsigned)__popcll(ms));
+        if (mg) bg = atomicAdd(&qcount[1], (unsigned)__popcll(mg));
+    }
+    bs = (unsigned)__builtin_amdgcn_readfirstlane((int)bs);
+    bg = (unsigned)__builtin_amdgcn_readfirstlane((int)bg);
+    if (valid) {
+        const u64 below = (1ull << lane) - 1ull;
+        int4 *dst = sparse ? desc_s + 2 * (size_t)(bs + (unsigned)__popcll(ms & below)) : desc_g + 2 * (size_t)(bg + (unsigned)__popcll(mg & below));
+        dst[0] = d0;
+        dst[1] = d1;
+    }
+}
+
+// Minima of the three column-term vectors over all columns (one workgroup; feeds Epi::upper).
+__global__ __launch_bounds__(1024) void sp_colterm_min_kernel(int n_cols, const float *Ytv, const float *Ycos, const float *Ydep, float *out) {
+    __shared__ float red[3][16];
+    const float inf = __builtin_inff();
+    float m0 = inf, m1 = inf, m2 = inf;
+    for (int i = threadIdx.x; i < n_cols; i += 1024) {
+        if (Ytv) m0 = fminf(m0, Ytv[i]);
+        if (Ycos) m1 = fminf(m1, Ycos[i]);
+        if (Ydep) m2 = fminf(m2, Ydep[i]);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        m0 = fminf(m0, __shfl_xor(m0, d, 64));
+        m1 = fminf(m1, __shfl_xor(m1, d, 64));
+        m2 = fminf(m2, __shfl_xor(m2, d, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = m0; red[1][threadIdx.x >> 6] = m1; red[2][threadIdx.x >> 6] = m2; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float m = inf;
+        for (int w = 0; w < 16; ++w) m = fminf(m, red[threadIdx.x][w]);
+        out[threadIdx.x] = (m == inf) ? 0.f : m;   // vector not in use (or empty): its weight is 0 anyway
+    }
+}
+
+// Fold the column term of a product-form epilogue into the m2 stream:  out[i] = data[i] / Y[indices[i]]
+// (0 where Y is 0: the reference returns 0 for a zero denominator, s_plus.h:147-150).  One streaming pass.
+__global__ __launch_bounds__(256) void sp_fold_colterm_kernel(long long nnz, const int *__restrict__ indices,
+                                                               const float *__restrict__ data, const float *__restrict__ Y,
+                                                               float *__restrict__ out) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nnz; i += (long long)gridDim.x * blockDim.x) {
+        const float y = Y[indices[i]];
+        out[i] = (y != 0.f) ? data[i] / y : 0.f;
+    }
+}
+
+}  // namespace
