@@ -23,7 +23,7 @@ constexpr int U_SLACK = 1024;    // candidate-buffer entries beyond k (room betw
 #define DRAIN_UNROLL (NT >= 1024 ? 2 : NT >= 768 ? 4 : 8)
 
 // scalar slots in LDS
-enum { SH_CNT = 0, SH_OVF, SH_SEL, SH_NEED, SH_EQ, SH_CNT2, SH_RETRY, SH_QA, SH_QB, SH_DCTR, SH_PCTR, SH_NITEMS, SH_N };   // SH_CNT2/SEL/NEED/EQ belong to the selections
+enum { SH_CNT = 0, SH_OVF, SH_SEL, SH_NEED, SH_EQ, SH_CNT2, SH_RETRY, SH_QA, SH_QB, SH_PCTR, SH_NITEMS, SH_N };   // SH_CNT2/SEL/NEED/EQ belong to the selections
 
 // phases timed by lane 0 of every workgroup when KParams::phase_cycles != NULL, then event counters
 enum { PH_SETUP = 0, PH_SEGMENTS, PH_ACCUM, PH_DRAIN, PH_SELECT, PH_OUTPUT, PH_SWEEP1, PH_SWEEP2, PH_CSDRAIN,
@@ -44,7 +44,8 @@ struct KParams {
     // configuration
     int T;                 // accumulator slots (power of two); the table region is T*8 bytes
     int logT;
-    int cap;               // candidate buffer capacity (> k)
+    int cap;               // candidate buffer capacity (> k) of the generic kernel
+    int cap_s;             // ... of the sparse kernel
     u64 *gU, *gU_g;        // candidate buffers in global memory (only when they do not fit LDS): sparse / generic kernel
     unsigned int *queue;   // [0] / [1] = next queue position of the sparse / generic kernel (dynamic scheduling)
     unsigned int *qcount;  // [0] / [1] = rows in the sparse / generic queue (the sparse kernel appends its give-ups to [1])
@@ -302,7 +303,7 @@ __device__ __forceinline__ void wave_push(unsigned mask, int *counter, int capac
 // the returned mask and SH_RETRY is raised: the caller keeps it and re-offers it after a selection.
 template <int N>
 __device__ __forceinline__ unsigned emit_candidates(const KParams &p, const RowCtx &rc, const int (&c)[N], const float (&xy)[N],
-                                                    unsigned occ, u64 *U, int *sh) {
+                                                    unsigned occ, u64 *U, int *sh, int cap) {
     unsigned live = 0;
 #pragma unroll
     for (int j = 0; j < N; ++j)
@@ -349,7 +350,7 @@ __device__ __forceinline__ unsigned emit_candidates(const KParams &p, const RowC
     }
     // one aggregated reservation per wave
     unsigned stored = 0;
-    wave_push<N>(want, &sh[SH_CNT], p.cap, &sh[SH_RETRY], [&](int j, int pos) {
+    wave_push<N>(want, &sh[SH_CNT], cap, &sh[SH_RETRY], [&](int j, int pos) {
         U[pos] = ((u64)key[j] << 32) | (u64)(unsigned)c[j];
         stored |= 1u << j;
     });
@@ -362,7 +363,8 @@ __device__ __forceinline__ unsigned emit_candidates(const KParams &p, const RowC
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int ITEM = 256;         // m2 elements per work item: one 16-byte load per lane
-constexpr int ITEM_CAP = 768;     // work items per row (LDS: 16 B each)
+constexpr int ITEM_CAP = 752;     // work items per row (LDS: 16 B each)
+constexpr int CBM_BYTES = 16384;  // collision bitmap of the sparse kernel (128k bits)
 constexpr int POOL_BLK = 64;      // pool entries a wave reserves at a time (>= 64: one trip always fits a fresh block)
 constexpr int CS_MAXPROBE = 64;   // linear-probe budget in the collision set
 constexpr unsigned OOB_SOFFSET = 0xFFFFF000u;   // buffer-load scalar offset beyond any m2 extent: every lane out of range
@@ -377,24 +379,22 @@ __device__ __forceinline__ int mbcnt64(u64 m) {
 // zero ("hole"); consumers skip zeros.  pos/end are wave-uniform (scalar registers).
 struct WavePool { int pos, end; };
 
-template <typename W>
-__device__ __forceinline__ void pool_push(WavePool &wp, bool pred, int *ctr, int cap, int *ovf, W &&write) {
-    const u64 m = __ballot(pred);
-    if (m == 0) return;                        // wave-uniform
-    const int n = __popcll(m);
-    if (wp.pos + n > wp.end) {
-        int base = 0;
-        if ((threadIdx.x & 63) == 0) base = atomicAdd(ctr, POOL_BLK);
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (base + POOL_BLK > cap) {           // pool exhausted: the row is redone on the generic path
-            if ((threadIdx.x & 63) == 0) *ovf = 1;
-            wp.pos = 0; wp.end = -1;
-            return;
-        }
-        wp.pos = base; wp.end = base + POOL_BLK;
+// Make room for `tot` (<= 256) more entries in the wave's window: nothing to do while the current block lasts, else
+// ONE returning atomic reserves a fresh block (a multiple of POOL_BLK entries).  Returns false when the pool is
+// exhausted (flag raised: the row is redone on the generic path).  Wave-uniform.
+__device__ __forceinline__ bool pool_reserve(WavePool &wp, int tot, int *ctr, int cap, int *ovf) {
+    if (wp.pos + tot <= wp.end) return true;
+    const int blk = (tot + POOL_BLK - 1) & ~(POOL_BLK - 1);
+    int base = 0;
+    if ((threadIdx.x & 63) == 0) base = atomicAdd(ctr, blk);
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (base + blk > cap) {
+        if ((threadIdx.x & 63) == 0) *ovf = 1;
+        wp.pos = 0; wp.end = -1;
+        return false;
     }
-    if (pred) write(wp.pos + mbcnt64(m));
-    wp.pos += n;
+    wp.pos = base; wp.end = base + blk;
+    return true;
 }
 
 // inclusive wave64 scan on the DPP crossbar (row_shr 1/2/4/8, row_bcast 15/31): no LDS round trips

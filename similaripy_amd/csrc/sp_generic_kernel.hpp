@@ -361,7 +361,7 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                             }
                             if (c[j] != EMPTY) occ |= 1u << j;
                         }
-                        const unsigned done = emit_candidates<DRAIN_UNROLL>(p, rc, c, xy, occ, U, sh);
+                        const unsigned done = emit_candidates<DRAIN_UNROLL>(p, rc, c, xy, occ, U, sh, p.cap);
 #pragma unroll
                         for (int j = 0; j < DRAIN_UNROLL; ++j)
                             if (done & (1u << j)) tab[base + j * NT + tid] = EMPTY64;

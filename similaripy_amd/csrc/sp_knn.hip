@@ -56,10 +56,12 @@ int fail(int code, const char *fmt, ...) {
 
 struct Config {
     int T, logT, NT, cap, hash_fill;
+    int cap_s;                     // sparse kernel's candidate buffer capacity
     int wgs_sparse, wgs_generic;   // persistent workgroups of the two row kernels
-    bool u_lds;
+    bool u_lds, u_lds_s;           // candidate buffer in LDS: generic / sparse kernel
     size_t lds_sparse, lds_generic;
     size_t ws_gu_bytes;     // candidate buffers in global memory for both kernels (0 when they live in LDS)
+    size_t ws_gu_s_bytes;   // the sparse kernel's part of it (first)
     size_t ws_fold_bytes;   // scaled copy of m2_data when the column term is folded in (0 otherwise)
     size_t ws_rows_bytes;   // bucket counters + work[n] + order[n] + the two descriptor queues
     size_t ws_desc_offset;  // of the sparse queue inside that block (the generic queue follows it)
@@ -78,7 +80,7 @@ static_assert(WS_PHASE_OFFSET + PH_N * 8 <= WS_YMIN_OFFSET && WS_YMIN_OFFSET + 1
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
 // LDS of the two kernels without the candidate buffer (see their carve-ups)
-size_t lds_fixed_sparse(int T) { return (size_t)T * 8 + (size_t)ITEM_CAP * 16 + 4096 + 32 * 4 + 16 * 8; }
+size_t lds_fixed_sparse(int T) { return (size_t)T * 8 + (size_t)ITEM_CAP * 16 + 4096 + CBM_BYTES + 32 * 4 + 16 * 8; }   // (its candidate buffer lives inside region A)
 size_t lds_fixed_generic(int T, int NT) { return (size_t)T * 8 + (size_t)16 * NT + 256 + 256 * 4 + 64 * 4 + 32 * 4 + 16 * 8; }
 
 int make_config(const sp_knn_args *a, int n_cus, Config *c) {
@@ -91,9 +93,9 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
     const int load = a->load_pct > 0 ? std::min(a->load_pct, 90) : 50;
 
     const long long need_cap = (long long)a->k + U_SLACK;
-    const size_t fixed = std::max(lds_fixed_sparse(T), lds_fixed_generic(T, NT));
-    if (fixed + 8 * 1024 > LDS_LIMIT) return fail(SP_EINVAL, "table_slots=%d does not fit the 160 KiB LDS", T);
-    // candidate buffer: LDS if k + slack entries fit beside the table in both kernels, else global scratch
+    const size_t fixed = lds_fixed_generic(T, NT);
+    if (std::max(fixed + 8 * 1024, lds_fixed_sparse(T)) > LDS_LIMIT) return fail(SP_EINVAL, "table_slots=%d does not fit the 160 KiB LDS", T);
+    // generic kernel's candidate buffer: LDS if k + slack entries fit beside the table, else global scratch
     long long cap_lds = (long long)((LDS_LIMIT - fixed) / 8);
     bool u_lds = need_cap <= cap_lds;
     long long cap;
@@ -102,11 +104,14 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
     } else {
         cap = need_cap + 1024;
     }
-    cap &= ~1LL;   // the sparse kernel clears the buffer with 16-byte stores
     if (cap > 0x7FFFFFF0LL) return fail(SP_EINVAL, "k too large");
-    c->T = T; c->logT = logT; c->NT = NT; c->cap = (int)cap; c->u_lds = u_lds;
+    // sparse kernel's candidate buffer: the last quarter of region A when 2*NT entries (what its register-resident
+    // selection handles) fit there and leave room above k; else global scratch
+    const bool u_lds_s = ((size_t)2 * NT * 8 <= (size_t)T * 2) && ((long long)a->k + 512 <= 2LL * NT);
+    const long long cap_s = u_lds_s ? 2LL * NT : ((need_cap + 1024) & ~1LL);
+    c->T = T; c->logT = logT; c->NT = NT; c->cap = (int)cap; c->u_lds = u_lds; c->cap_s = (int)cap_s; c->u_lds_s = u_lds_s;
     c->hash_fill = std::max(1, (int)((long long)T * load / 100));
-    c->lds_sparse = lds_fixed_sparse(T) + (u_lds ? (size_t)cap * 8 : 0);
+    c->lds_sparse = lds_fixed_sparse(T);
     c->lds_generic = lds_fixed_generic(T, NT) + (u_lds ? (size_t)cap * 8 : 0);
     auto wgs_for = [&](size_t lds) {
         int per_cu = (int)std::max<size_t>(1, LDS_LIMIT / lds);
@@ -117,7 +122,8 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
     };
     c->wgs_sparse = wgs_for(c->lds_sparse);
     c->wgs_generic = wgs_for(c->lds_generic);
-    c->ws_gu_bytes = u_lds ? 0 : (((size_t)(c->wgs_sparse + c->wgs_generic) * (size_t)cap * 8 + 255) & ~(size_t)255);
+    c->ws_gu_s_bytes = u_lds_s ? 0 : (((size_t)c->wgs_sparse * (size_t)cap_s * 8 + 255) & ~(size_t)255);
+    c->ws_gu_bytes = c->ws_gu_s_bytes + (u_lds ? 0 : (((size_t)c->wgs_generic * (size_t)cap * 8 + 255) & ~(size_t)255));
     // product-form epilogue  val = xy / (l * X[t] * Y[c])  (cosine, asymmetric cosine, rp3beta without shrink):
     // Y is divided into the m2 values once per call, the kernels then need no column-term gathers at all
     c->fold = !(a->flags & SP_FLAG_NO_FOLD) && a->l1 == 0.f && a->a1 == 1.f && a->stabilized_shrink == 0.f &&
@@ -174,17 +180,17 @@ int device_cus(int device, int *n_cus) {
     return SP_OK;
 }
 
-template <int NT, bool U_LDS>
+template <int NT>
 int launch_rows(const KParams &kp, const Config &c, hipStream_t stream) {
-    auto ks = sp_knn_sparse_kernel<NT, U_LDS>;
-    auto kg = sp_knn_generic_kernel<NT, U_LDS>;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds_sparse));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds_generic));
     // sparse rows first; what it cannot finish joins the generic queue, which the second launch drains
     if (kp.sparse_path) {
+        auto ks = c.u_lds_s ? sp_knn_sparse_kernel<NT, true> : sp_knn_sparse_kernel<NT, false>;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds_sparse));
         hipLaunchKernelGGL(ks, dim3(c.wgs_sparse), dim3(NT), c.lds_sparse, stream, kp);
         HIP_TRY(hipGetLastError());
     }
+    auto kg = c.u_lds ? sp_knn_generic_kernel<NT, true> : sp_knn_generic_kernel<NT, false>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds_generic));
     hipLaunchKernelGGL(kg, dim3(c.wgs_generic), dim3(NT), c.lds_generic, stream, kp);
     HIP_TRY(hipGetLastError());
     return SP_OK;
@@ -258,8 +264,9 @@ int run_device(sp_knn_args *a) {
     kp.T = c.T; kp.logT = c.logT; kp.cap = c.cap;
     kp.queue = (unsigned int *)ws;
     kp.qcount = (unsigned int *)(ws + 8);
-    kp.gU = c.u_lds ? nullptr : (u64 *)ws_gu;
-    kp.gU_g = c.u_lds ? nullptr : (u64 *)ws_gu + (size_t)c.wgs_sparse * (size_t)c.cap;
+    kp.cap_s = c.cap_s;
+    kp.gU = c.u_lds_s ? nullptr : (u64 *)ws_gu;
+    kp.gU_g = c.u_lds ? nullptr : (u64 *)(ws_gu + c.ws_gu_s_bytes);
     kp.sparse_path = (a->flags & SP_FLAG_NO_SPARSE_PATH) ? 0 : 1;
     {
         // work per row -> (optionally) descending-work order -> classified descriptor queues
@@ -280,7 +287,7 @@ int run_device(sp_knn_args *a) {
         ClassifyParams cp;
         cp.sparse_path = kp.sparse_path;
         cp.n_cols = a->n_output_cols; cp.T = c.T; cp.nb_log2 = c.nb_log2;
-        cp.cs_slots = c.T / 4; cp.dup_cap = 2 * c.cap;
+        cp.cs_slots = c.T / 4;
         hipLaunchKernelGGL(sp_row_desc_kernel, dim3((a->n_targets + 255) / 256), dim3(256), 0, stream, a->n_targets, a->targets,
                            a->m1_indptr, work, c.ordered ? bucket_base + 32 : nullptr, order, a->l1 != 0.f ? a->Xtversky : nullptr,
                            a->l2 != 0.f ? a->Xcosine : nullptr, a->l3 != 0.f ? a->Xdepop : nullptr, cp, kp.qcount, desc_s, desc_g);
@@ -299,10 +306,10 @@ int run_device(sp_knn_args *a) {
     kp.phase_cycles = timed ? (unsigned long long *)(ws + WS_PHASE_OFFSET) : nullptr;   // inside the zeroed header
     kp.dbg = (int)a->reserved[0];
 
-    if (c.NT == 256) rc = c.u_lds ? launch_rows<256, true>(kp, c, stream) : launch_rows<256, false>(kp, c, stream);
-    else if (c.NT == 512) rc = c.u_lds ? launch_rows<512, true>(kp, c, stream) : launch_rows<512, false>(kp, c, stream);
-    else if (c.NT == 768) rc = c.u_lds ? launch_rows<768, true>(kp, c, stream) : launch_rows<768, false>(kp, c, stream);
-    else rc = c.u_lds ? launch_rows<1024, true>(kp, c, stream) : launch_rows<1024, false>(kp, c, stream);
+    if (c.NT == 256) rc = launch_rows<256>(kp, c, stream);
+    else if (c.NT == 512) rc = launch_rows<512>(kp, c, stream);
+    else if (c.NT == 768) rc = launch_rows<768>(kp, c, stream);
+    else rc = launch_rows<1024>(kp, c, stream);
     if (rc) { if (own_ws) (void)hipFree(ws); return rc; }
 
     if (timed) {

@@ -82,7 +82,7 @@ struct ClassifyParams {
     int sparse_path;       // 0: everything is generic
     int n_cols, T;
     int nb_log2;           // sparse bitmap bits
-    int cs_slots, dup_cap; // collision-set slots / duplicate-pool entries of the sparse kernel
+    int cs_slots;          // collision-set slots of the sparse kernel
 };
 
 __global__ __launch_bounds__(256) void sp_row_desc_kernel(int n_targets, const int *targets, const int *m1_indptr, const unsigned *work,
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void sp_row_desc_kernel(int n_targets, const i
             const float m = (float)macs;
             const float alias = (cp.nb_log2 < 31 && (1 << cp.nb_log2) < cp.n_cols) ? 1.f / (float)(1 << cp.nb_log2) : 0.f;
             const float expect = 0.5f * m * m * (1.f / (float)cp.n_cols + alias);
-            sparse = expect <= 0.30f * (float)cp.cs_slots && expect <= 0.40f * (float)cp.dup_cap;
+            sparse = expect <= 0.30f * (float)cp.cs_slots;
         }
     }
     const u64 ms = __ballot(valid && sparse), mg = __ballot(valid && !sparse);

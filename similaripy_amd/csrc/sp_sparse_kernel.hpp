@@ -4,17 +4,17 @@
 // Replaces the per-thread dense `sums[]` array of s_plus.h:71-127 by a column BITMAP in LDS and two sweeps over
 // the row's products:
 //   sweep 1 (column ids only): one bit per column (exact while n_cols <= bitmap bits, else columns alias modulo
-//     the bitmap size); a product that finds its bit set has its column appended to a duplicate pool;
-//   the bitmap is cleared and the duplicate columns become a small collision set + a collision bitmap;
-//   sweep 2 (ids + values): ONE bit test per product — products of collision-set columns are appended to a pool
-//     and accumulated densely afterwards, every other product is provably the only one of its column and is
-//     appended only if its raw dot can still beat the running k-th value;
-//   the pool is consumed by dense phases: column terms, epilogue (s_plus.h:129-156), threshold, top-k buffer,
-//     selection (replaces the heap of s_plus.h:39-64).
+//     the bitmap size); a product that finds its bit set marks its column in a second, small "collision bitmap";
+//   the big bitmap is cleared; its storage becomes the collision set, the survivor pool and the top-k buffer;
+//   sweep 2 (ids + values): ONE bit test per product — products of marked columns accumulate in the collision
+//     set right away (find-or-insert with 64-bit compare-and-swap), every other product is provably the only one
+//     of its column and is appended to the pool only if its raw dot can still beat the running k-th value;
+//   the pool (and at the end the collision set) is consumed by a dense phase: column terms, epilogue
+//     (s_plus.h:129-156), threshold, top-k buffer, selection (replaces the heap of s_plus.h:39-64).
 // Work is handed out in ITEMS of <= 256 consecutive elements of one m2 row: row base, count and m1 value are
 // scalars, one 16-byte buffer load per lane fetches a whole item (fully coalesced 1 KiB per wave instruction),
 // and the loads of the next item are in flight while the current one is processed.
-// Rows whose pools overflow are handed to the generic kernel through its queue (never to a CPU path).
+// Rows whose collision set or pool overflow are handed to the generic kernel through its queue (never to a CPU path).
 #pragma once
 #include "sp_common.hpp"
 
@@ -30,32 +30,34 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
     const int A_bytes = p.T * 8;
 
     // ---- LDS carve-up (single dynamic array) ----
-    // region A [0, T*8)   sweep 1: column bitmap (nb bits);
-    //                     sweep 2: [0,A/4) collision bitmap, [A/4,A/2) collision set, [A/2,A) survivor / member pool
+    // cbm[CBM_BYTES]      collision bitmap (columns seen twice in sweep 1), alive through both sweeps; at offset 0 so
+    //                     that its reads need no base add
+    // region A [.., +T*8) sweep 1: column bitmap (nb bits, from the start);
+    //                     afterwards: [0,A/4) collision set, [A/4,3A/4) survivor pool, [3A/4,A) candidate buffer U
     // items[ITEM_CAP]     {m2 byte offset, count, m1 value bits, flat start};  hist4[4][256] radix histograms
-    // sh[32], ph[16]      scalars, phase timers;   U[cap] candidate buffer (sweep 1 borrows it for the duplicate pool)
-    int4 *items = (int4 *)(smem + A_bytes);
+    // sh[32], ph[16]      scalars, phase timers
+    unsigned char *cbm = smem;
+    unsigned char *rA = smem + CBM_BYTES;
+    int4 *items = (int4 *)(rA + A_bytes);
     int *hist4 = (int *)(items + ITEM_CAP);
     int *sh = hist4 + 1024;
     u64 *ph = (u64 *)(sh + 32);
-    u64 *U = U_LDS ? (u64 *)(ph + 16) : (p.gU + (size_t)blockIdx.x * (size_t)p.cap);
+    u64 *U = U_LDS ? (u64 *)(rA + (A_bytes / 4) * 3) : (p.gU + (size_t)blockIdx.x * (size_t)p.cap_s);
+    const int cap = p.cap_s;
 
     const unsigned amask = (unsigned)((1u << (p.nb_log2 - 3)) - 1u) & ~3u;      // column -> byte of its bitmap word
     const int nb_bytes = 1 << (p.nb_log2 - 3);
-    unsigned char *cbm = smem;
-    const unsigned cmask = (unsigned)(A_bytes / 4 - 1) & ~3u;                   // column -> byte of its collision-bitmap word
-    u64 *cs = (u64 *)(smem + A_bytes / 4);
+    const unsigned cmask = (unsigned)(CBM_BYTES - 1) & ~3u;                     // column -> byte of its collision-bitmap word
+    u64 *cs = (u64 *)rA;
     const int CSN = A_bytes / 32;
     const int cs_shift = 32 - (p.logT - 2);                                     // log2(CSN) = logT + 3 - 5
-    u64 *pool = (u64 *)(smem + A_bytes / 2);
+    u64 *pool = (u64 *)(rA + A_bytes / 4);
     const int pcap = A_bytes / 16;
-    unsigned *dpool = (unsigned *)U;
-    const int dcap = 2 * p.cap;
     const __amdgpu_buffer_rsrc_t rs_idx = __builtin_amdgcn_make_buffer_rsrc((void *)p.m2_indices, 0, (int)p.m2_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_val = __builtin_amdgcn_make_buffer_rsrc((void *)p.m2_data, 0, (int)p.m2_bytes, 0x00020000);
 
-    // region A all zero, histograms zero
-    for (int i = tid; i < A_bytes / 16; i += NT) ((int4 *)smem)[i] = make_int4(0, 0, 0, 0);
+    // collision bitmap + region A all zero, histograms zero
+    for (int i = tid; i < (CBM_BYTES + A_bytes) / 16; i += NT) ((int4 *)smem)[i] = make_int4(0, 0, 0, 0);
     for (int i = tid; i < 1024; i += NT) hist4[i] = 0;
     if (tid < 32) sh[tid] = 0;
     if (tid < 16) ph[tid] = 0;
@@ -133,9 +135,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         }
         int nx_r0 = 0, nx_len = 0;
 
-        // the duplicate pool borrows U's storage (empty until sweep 2); holes must read zero
-        for (int i = tid; i < p.cap / 2; i += NT) ((int4 *)U)[i] = make_int4(0, 0, 0, 0);
-        if (tid == 0) { sh[SH_DCTR] = 0; sh[SH_PCTR] = 0; sh[SH_NITEMS] = 0; sh[SH_CNT] = 0; }
+        if (tid == 0) { sh[SH_PCTR] = 0; sh[SH_NITEMS] = 0; sh[SH_CNT] = 0; }
         // Segments are visited in descending |m1 value| order: each segment scales its m2 row by its own m1 value,
         // so the heavy segments first make the running k-th value rise early and the survivor rate fall
         // monotonically.  First item and flat start of every segment come from one all-pairs pass spread over the
@@ -204,9 +204,10 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             __syncthreads();
             PHASE_END(PH_SEGMENTS);
 
-            // ---- sweep 1: column ids only ----
+            // ---- sweep 1: column ids only.  Branch-free: every product ORs its bit into the bitmap; the returned
+            // word tells whether the column was there already, in which case (only then a non-zero operand) the
+            // column's bit is ORed into the collision bitmap as well. ----
             {
-                WavePool wp{0, -1};
                 // One 16-byte buffer load per lane fetches a whole item (lane l: elements 4l..4l+3); the range check
                 // of the buffer resource is per dword (scripts/buffer_oob_probe.hip), so an item at the very end of
                 // the array is safe, and a prefetch past the last item reads the sentinel: an all-out-of-range load
@@ -219,78 +220,60 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
                 };
                 auto body = [&](const unsigned (&c)[4], int cnt) __attribute__((always_inline)) {
-                    unsigned old[4], bit[4];
+                    if (cnt == 0) return;                  // sentinel (wave-uniform)
+                    unsigned seen[4];
                     if (cnt == ITEM) {
+                        unsigned old[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            bit[j] = 1u << (c[j] & 31u);
-                            old[j] = atomicOr((unsigned *)(smem + ((c[j] >> 3) & amask)), bit[j]);
-                        }
+                        for (int j = 0; j < 4; ++j) old[j] = atomicOr((unsigned *)(rA + ((c[j] >> 3) & amask)), 1u << (c[j] & 31u));
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) seen[j] = (old[j] >> (c[j] & 31u)) & 1u;
                     } else {
+                        unsigned old[4], ok[4];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            bit[j] = (4 * lane + j < cnt) ? (1u << (c[j] & 31u)) : 0u;     // padding ORs nothing
-                            old[j] = atomicOr((unsigned *)(smem + ((c[j] >> 3) & amask)), bit[j]);
+                            ok[j] = (4 * lane + j < cnt) ? 1u : 0u;                         // padding ORs nothing
+                            old[j] = atomicOr((unsigned *)(rA + ((c[j] >> 3) & amask)), ok[j] << (c[j] & 31u));
                         }
-                    }
-                    bool dup[4];
-                    bool any = false;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { dup[j] = (old[j] & bit[j]) != 0u; any |= dup[j]; }
-                    if (__ballot(any)) {
+                        for (int j = 0; j < 4; ++j) seen[j] = (old[j] >> (c[j] & 31u)) & ok[j];
+                    }
+                    // ~2 % of the products find their column already there: mark it in the collision bitmap
+                    if (__ballot((seen[0] | seen[1] | seen[2] | seen[3]) != 0u)) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            pool_push(wp, dup[j], &sh[SH_DCTR], dcap, &sh[SH_OVF], [&](int pos) { dpool[pos] = ~c[j]; });
+                            if (seen[j]) atomicOr((unsigned *)(cbm + ((c[j] >> 3) & cmask)), 1u << (c[j] & 31u));
                     }
                 };
-                unsigned cA[4], cB[4];
-                int nA = 0, nB = 0;
+                unsigned cA[4], cB[4], cC[4];
+                int nA = 0, nB = 0, nC = 0;
                 int it = wave;
                 ld(it, cA, nA);
-                while (it < n_items) {
-                    ld(it + NW, cB, nB);
-                    __builtin_amdgcn_sched_barrier(0);     // the prefetch is issued before the current item is waited for
+                ld(it + NW, cB, nB);
+                while (it < n_items) {      // three items in flight per wave; bodies skip the sentinel
+                    ld(it + 2 * NW, cC, nC);
+                    __builtin_amdgcn_sched_barrier(0);     // the prefetch is issued before the oldest item is waited for
                     body(cA, nA);
-                    if (it + NW >= n_items) break;
-                    ld(it + 2 * NW, cA, nA);
+                    ld(it + 3 * NW, cA, nA);
                     __builtin_amdgcn_sched_barrier(0);
                     body(cB, nB);
-                    it += 2 * NW;
+                    ld(it + 4 * NW, cB, nB);
+                    __builtin_amdgcn_sched_barrier(0);
+                    body(cC, nC);
+                    it += 3 * NW;
                 }
             }
             __syncthreads();
-            const int ovf1 = sh[SH_OVF];
-            const int dext = min(sh[SH_DCTR], dcap);
             PHASE_END(PH_SWEEP1);
             // next row's m2 row bounds (its m1 entries were requested at the top of this row)
             if (dN.x >= 0 && tid < dN.w) {
                 nx_r0 = p.m2_indptr[nx_u];
                 nx_len = p.m2_indptr[nx_u + 1] - nx_r0;
             }
-            // the bitmap has done its job: back to zero (16-byte stores), then the collision structures go there
-            for (int i = tid; i < (nb_bytes >> 4); i += NT) ((int4 *)smem)[i] = make_int4(0, 0, 0, 0);
+            // the bitmap has done its job: back to zero (16-byte stores); its storage now serves sweep 2
+            for (int i = tid; i < (nb_bytes >> 4); i += NT) ((int4 *)rA)[i] = make_int4(0, 0, 0, 0);
             __syncthreads();
-            failed = (ovf1 != 0);
-            if (!failed) {
-                for (int i = tid; i < dext; i += NT) {
-                    const unsigned nc = dpool[i];
-                    if (nc != 0u) {
-                        const unsigned c = ~nc;
-                        unsigned h = hash_bits((int)c, 2654435761u, cs_shift);
-                        int tries = 0;
-                        for (; tries < CS_MAXPROBE; ++tries) {
-                            const u64 prev = atomicCAS(&cs[h], 0ull, (u64)nc << 32);     // {~column : +0.0f}
-                            if (prev == 0ull) { atomicOr((unsigned *)(cbm + ((c >> 3) & cmask)), 1u << (c & 31u)); break; }
-                            if ((unsigned)(prev >> 32) == nc) break;                     // already a member
-                            h = (h + 1u) & (unsigned)(CSN - 1);
-                        }
-                        if (tries == CS_MAXPROBE) sh[SH_OVF] = 1;
-                    }
-                }
-                __syncthreads();
-                failed = (sh[SH_OVF] != 0);
-            }
-            PHASE_END(PH_ACCUM);     // (bitmap clear + collision-set build)
+            PHASE_END(PH_SEGMENTS);  // (bitmap clear)
         } else {
             if (dN.x >= 0 && tid < dN.w) {
                 nx_r0 = p.m2_indptr[nx_u];
@@ -299,21 +282,20 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         }
 
         if (!failed) {
-            // Stages: sweep 2 over a chunk of items, or (last stage) the collision set itself turned into pool
-            // entries; then ONE dense consumer: member products accumulate in the collision set, single products
-            // are judged (column terms, epilogue, threshold) and appended to U; a full U triggers a selection and
-            // another pass over what is left of the pool.
+            // Stages.  A stage is a sweep 2 over a chunk of items; the last one additionally turns the collision
+            // set (complete sums by then) into pool entries.  Then ONE dense consumer judges the pool (column
+            // terms, epilogue, threshold) into U; a full U triggers a selection and another pass over what is left.
             // The products are offered in growing chunks with a selection after each: the first chunk is small
             // enough that accepting everything cannot overflow U; once the k-th best of n products is known, about
             // k*m/n of the next m would survive in an exchangeable stream — far fewer here, because segments come
             // in descending weight — so the next chunk may be 4*n*(cap-k)/k long.
-            const int room = p.cap - min(p.k, p.cap - 1);
+            const int room = cap - min(p.k, cap - 1);
             int i0 = 0;
             long long chunk = room;
-            for (;;) {
-                const bool last_stage = (i0 >= n_items);     // uniform
+            bool last_stage = false;
+            while (!last_stage) {
                 int ext = 0;
-                if (!last_stage) {
+                if (i0 < n_items) {
                     const int i1 = (int)min((long long)n_items, (long long)i0 + max(1ll, chunk / ITEM));
                     // ---- sweep 2 over items [i0, i1) ----
                     WavePool wp{0, -1};
@@ -328,6 +310,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                         v[0] = __uint_as_float(b.x); v[1] = __uint_as_float(b.y); v[2] = __uint_as_float(b.z); v[3] = __uint_as_float(b.w);
                     };
                     auto body = [&](const unsigned (&c)[4], const float (&v)[4], int cnt, float segv) __attribute__((always_inline)) {
+                        if (cnt == 0) return;                  // sentinel (wave-uniform)
                         unsigned w[4];
                         float x[4];
 #pragma unroll
@@ -335,49 +318,102 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                             x[j] = v[j] * segv;
                             w[j] = *(const unsigned *)(cbm + ((c[j] >> 3) & cmask));
                         }
-                        bool mem[4], push[4];
-                        bool any = false;
-                        const bool full = (cnt == ITEM);
+                        // mem: product of a marked column (it accumulates in the collision set in the dense phase);
+                        // otherwise the product is the only one of its column and matters only if its raw dot can
+                        // still enter the top-k (NaN stays: the exact judge drops it)
+                        unsigned mem[4];
+                        bool push[4];
+                        if (cnt == ITEM) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const bool ok = full || (4 * lane + j < cnt);
-                            mem[j] = ok && (((w[j] >> (c[j] & 31u)) & 1u) != 0u);
-                            // a product outside the collision set is the only one of its column: keep it only if
-                            // its raw dot can still enter the top-k (NaN stays: the exact judge drops it)
-                            push[j] = mem[j] || (ok && !(x[j] <= rc.xy_cut));
-                            any |= push[j];
+                            for (int j = 0; j < 4; ++j) {
+                                mem[j] = (w[j] >> (c[j] & 31u)) & 1u;
+                                push[j] = (mem[j] != 0u) | !(x[j] <= rc.xy_cut);
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const bool ok = 4 * lane + j < cnt;
+                                mem[j] = ok ? ((w[j] >> (c[j] & 31u)) & 1u) : 0u;
+                                push[j] = (mem[j] != 0u) | (ok & !(x[j] <= rc.xy_cut));
+                            }
                         }
-                        if (__ballot(any)) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                pool_push(wp, push[j], &sh[SH_PCTR], pcap, &sh[SH_OVF], [&](int pos) {
-                                    pool[pos] = ((u64)((c[j] + 1u) | (mem[j] ? 0x80000000u : 0u)) << 32) | (u64)__float_as_uint(x[j]);
-                                });
+                        const u64 P0 = __ballot(push[0]), P1 = __ballot(push[1]), P2 = __ballot(push[2]), P3 = __ballot(push[3]);
+                        if ((P0 | P1) | (P2 | P3)) {
+                            const int n0 = __popcll(P0), n1 = __popcll(P1), n2 = __popcll(P2), n3 = __popcll(P3);
+                            if (pool_reserve(wp, n0 + n1 + n2 + n3, &sh[SH_PCTR], pcap, &sh[SH_OVF])) {
+                                int pos = wp.pos;
+                                if (push[0]) pool[pos + mbcnt64(P0)] = ((u64)((c[0] + 1u) | (mem[0] << 31)) << 32) | (u64)__float_as_uint(x[0]);
+                                pos += n0;
+                                if (push[1]) pool[pos + mbcnt64(P1)] = ((u64)((c[1] + 1u) | (mem[1] << 31)) << 32) | (u64)__float_as_uint(x[1]);
+                                pos += n1;
+                                if (push[2]) pool[pos + mbcnt64(P2)] = ((u64)((c[2] + 1u) | (mem[2] << 31)) << 32) | (u64)__float_as_uint(x[2]);
+                                pos += n2;
+                                if (push[3]) pool[pos + mbcnt64(P3)] = ((u64)((c[3] + 1u) | (mem[3] << 31)) << 32) | (u64)__float_as_uint(x[3]);
+                                wp.pos = pos + n3;
+                            }
                         }
                     };
-                    unsigned cA[4], cB[4];
-                    float vA[4], vB[4];
-                    int nA = 0, nB = 0;
-                    float sA = 0.f, sB = 0.f;
+                    unsigned cA[4], cB[4], cC[4];
+                    float vA[4], vB[4], vC[4];
+                    int nA = 0, nB = 0, nC = 0;
+                    float sA = 0.f, sB = 0.f, sC = 0.f;
                     int it = i0 + wave;
                     ld(it, cA, vA, nA, sA);
-                    while (it < i1) {
-                        ld(it + NW, cB, vB, nB, sB);
-                        __builtin_amdgcn_sched_barrier(0);     // the prefetch is issued before the current item is waited for
+                    ld(it + NW, cB, vB, nB, sB);
+                    while (it < i1) {      // three items in flight per wave; bodies skip the sentinel
+                        ld(it + 2 * NW, cC, vC, nC, sC);
+                        __builtin_amdgcn_sched_barrier(0);     // the prefetch is issued before the oldest item is waited for
                         body(cA, vA, nA, sA);
-                        if (it + NW >= i1) break;
-                        ld(it + 2 * NW, cA, vA, nA, sA);
+                        ld(it + 3 * NW, cA, vA, nA, sA);
                         __builtin_amdgcn_sched_barrier(0);
                         body(cB, vB, nB, sB);
-                        it += 2 * NW;
+                        ld(it + 4 * NW, cB, vB, nB, sB);
+                        __builtin_amdgcn_sched_barrier(0);
+                        body(cC, vC, nC, sC);
+                        it += 3 * NW;
                     }
                     i0 = i1;
                     __syncthreads();
                     ext = min(sh[SH_PCTR], pcap);
-                    if (sh[SH_OVF]) { failed = true; break; }     // pool overflowed: dropped products cannot be re-offered
+                    if (sh[SH_OVF]) { failed = true; break; }     // pool or collision set overflowed
                     PHASE_END(PH_SWEEP2);
-                } else {
-                    // ---- last stage: the collision set (complete sums now) becomes pool entries; set and bitmap bits cleared ----
+                }
+                // ---- products of marked columns (flagged entries): find-or-insert in the collision set.  {~column : sum}
+                // slots, 0 = free; ONE 64-bit compare-and-swap claims a free slot with the product in it, a second one
+                // adds to the sum of a slot the column already owns (ds_cmpst_rtn_b64 retires 10x the lanes of
+                // ds_add_f32 on gfx950). ----
+                for (int i = tid; i < ext; i += NT) {
+                    const u64 e = pool[i];
+                    if (e >> 63) {
+                        const unsigned cc = ((unsigned)(e >> 32) & 0x7FFFFFFFu) - 1u;
+                        const float xx = __uint_as_float((unsigned)e);
+                        const unsigned nc = ~cc;
+                        unsigned h = hash_bits((int)cc, 2654435761u, cs_shift);
+                        int tries = 0;
+                        for (; tries < CS_MAXPROBE; ++tries) {
+                            u64 cur = atomicCAS(&cs[h], 0ull, ((u64)nc << 32) | (u64)__float_as_uint(xx));
+                            if (cur == 0ull) break;                    // claimed, product deposited
+                            if ((unsigned)(cur >> 32) == nc) {
+                                for (;;) {
+                                    const u64 want = (cur & 0xFFFFFFFF00000000ull) | (u64)__float_as_uint(__uint_as_float((unsigned)cur) + xx);
+                                    const u64 got = atomicCAS(&cs[h], cur, want);
+                                    if (got == cur) break;
+                                    cur = got;
+                                }
+                                break;
+                            }
+                            h = (h + 1u) & (unsigned)(CSN - 1);
+                        }
+                        if (tries == CS_MAXPROBE) sh[SH_OVF] = 1;
+                        pool[i] = 0ull;
+                    }
+                }
+                __syncthreads();
+                if (sh[SH_OVF]) { failed = true; break; }         // collision set full
+                PHASE_END(PH_ACCUM);
+                if (i0 >= n_items && ext <= pcap - CSN) {
+                    // ---- last stage: the collision set becomes pool entries (back part of the pool), and is cleared
+                    // together with its collision-bitmap bits ----
                     for (int idx = tid; idx < CSN; idx += NT) {
                         const u64 s = cs[idx];
                         u64 e = 0ull;
@@ -387,62 +423,38 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                             cs[idx] = 0ull;
                             atomicAnd((unsigned *)(cbm + ((c >> 3) & cmask)), ~(1u << (c & 31u)));
                         }
-                        pool[idx] = e;
+                        pool[pcap - CSN + idx] = e;
                     }
-                    ext = CSN;
+                    last_stage = true;
                     __syncthreads();
                     PHASE_END(PH_CSDRAIN);
                 }
 
-                // ---- dense consumer (leaves the pool all zero) ----
+                // ---- dense consumer over pool[0, ext) and, in the last stage, pool[pcap-CSN, pcap); leaves them zero ----
+                const int n_ent = ext + (last_stage ? CSN : 0);
                 for (;;) {
-                    for (int base = 0; base < ext; base += NT * DRAIN_UNROLL) {
+                    for (int base = 0; base < n_ent; base += NT * DRAIN_UNROLL) {
                         u64 e[DRAIN_UNROLL];
+                        int pidx[DRAIN_UNROLL];
                         int c[DRAIN_UNROLL];
                         float xy[DRAIN_UNROLL];
                         unsigned occ = 0;
 #pragma unroll
                         for (int j = 0; j < DRAIN_UNROLL; ++j) {
-                            const int idx = base + j * NT + tid;
-                            e[j] = (idx < ext) ? pool[idx] : 0ull;
+                            const int i = base + j * NT + tid;
+                            pidx[j] = (i < ext) ? i : (pcap - CSN + (i - ext));
+                            e[j] = (i < n_ent) ? pool[pidx[j]] : 0ull;
                         }
 #pragma unroll
                         for (int j = 0; j < DRAIN_UNROLL; ++j) {
-                            const unsigned hi = (unsigned)(e[j] >> 32);
-                            c[j] = (int)((hi & 0x7FFFFFFFu) - 1u);
+                            c[j] = (int)((unsigned)(e[j] >> 32) - 1u);
                             xy[j] = __uint_as_float((unsigned)e[j]);
-                            if (e[j] != 0ull) {
-                                bool single = (hi >> 31) == 0u;
-                                if (!single) {
-                                    const unsigned nc = ~(unsigned)c[j];
-                                    unsigned h = hash_bits(c[j], 2654435761u, cs_shift);
-                                    single = true;            // bit aliasing: flagged but not in the set
-                                    for (int tries = 0; tries < CS_MAXPROBE; ++tries) {
-                                        const u64 s = cs[h];
-                                        if ((unsigned)(s >> 32) == nc) {
-                                            // optimistic 64-bit compare-and-swap of {key : sum + x} (ds_cmpst_rtn_b64 retires
-                                            // 10x the lanes of ds_add_f32 on gfx950); a lost race re-reads
-                                            u64 cur = s;
-                                            for (;;) {
-                                                const u64 want = (cur & 0xFFFFFFFF00000000ull) | (u64)__float_as_uint(__uint_as_float((unsigned)cur) + xy[j]);
-                                                const u64 got = atomicCAS(&cs[h], cur, want);
-                                                if (got == cur) break;
-                                                cur = got;
-                                            }
-                                            single = false;
-                                            break;
-                                        }
-                                        if (s == 0ull) break;
-                                        h = (h + 1u) & (unsigned)(CSN - 1);
-                                    }
-                                }
-                                if (single && !(xy[j] <= rc.xy_cut)) occ |= 1u << j;
-                            }
+                            if (e[j] != 0ull && !(xy[j] <= rc.xy_cut)) occ |= 1u << j;
                         }
-                        const unsigned done = emit_candidates<DRAIN_UNROLL>(p, rc, c, xy, occ, U, sh);
+                        const unsigned done = emit_candidates<DRAIN_UNROLL>(p, rc, c, xy, occ, U, sh, cap);
 #pragma unroll
                         for (int j = 0; j < DRAIN_UNROLL; ++j)
-                            if (e[j] != 0ull && (!(occ & (1u << j)) || (done & (1u << j)))) pool[base + j * NT + tid] = 0ull;
+                            if (e[j] != 0ull && (!(occ & (1u << j)) || (done & (1u << j)))) pool[pidx[j]] = 0ull;
                     }
                     __syncthreads();
                     const int retry = sh[SH_RETRY];
@@ -450,17 +462,15 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     __syncthreads();
                     if (tid == 0) {
                         sh[SH_PCTR] = 0;
-                        if (retry) { sh[SH_RETRY] = 0; if (n_now > p.cap) sh[SH_CNT] = p.cap; }   // failed appends over-counted
+                        if (retry) { sh[SH_RETRY] = 0; if (n_now > cap) sh[SH_CNT] = cap; }   // failed appends over-counted
                     }
                     __syncthreads();         // counter fix-ups visible before the next pushes / the selection
                     PHASE_END(PH_DRAIN);
-                    // selection: forced when U overflowed; after the last stage exact (final top-k); between stages
-                    // whenever it can raise the running k-th value, except right before the last stage if U has room
-                    const bool before_last = (i0 >= n_items) && !last_stage;
-                    const bool want_sel = retry || (last_stage ? (n_now > p.k) : (n_now > p.k && (!before_last || 2 * n_now > p.cap + p.k)));
-                    if (want_sel) {
+                    // selection: forced when U overflowed; exact after the last stage (final top-k); between stages
+                    // whenever it can raise the running k-th value
+                    if (retry || n_now > p.k) {
                         long long thr_new;
-                        if (p.cap <= 2 * NT) thr_new = select_fast<NT>(U, hist4, sh, p.k, last_stage && !retry);
+                        if (cap <= 2 * NT) thr_new = select_fast<NT>(U, hist4, sh, p.k, last_stage && !retry);
                         else thr_new = compact_topk<NT>(U, hist4, sh, p.k);
                         if (thr_new >= 0) {
                             rc.have_thr = true;
@@ -471,7 +481,6 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     }
                     if (!retry) break;  // uniform
                 }
-                if (last_stage) break;
                 const long long pos = (i0 < n_items) ? (long long)items[i0].w : (long long)macs32;
                 chunk = rc.have_thr ? max((long long)room, 4ll * pos * (long long)room / (long long)p.k) : (long long)room;
             }
@@ -496,6 +505,10 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 p.values[o + j] = v;
             }
             if (tid == 0 && p.counts) p.counts[slot_i] = n_out;
+            if (U_LDS) {
+                __syncthreads();     // U read before it is cleared: its storage is part of the next row's bitmap
+                for (int i = tid; i < cap / 2; i += NT) ((int4 *)U)[i] = make_int4(0, 0, 0, 0);
+            }
             if (timing) ph[CT_ROWS_SPARSE] += 1;
         } else {
             // a pool or the collision set overflowed (or the row has too many items): hand the row to the generic
@@ -507,7 +520,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 p.desc_g[2 * (size_t)g + 1] = wC;
                 sh[SH_OVF] = 0; sh[SH_RETRY] = 0; sh[SH_CNT2] = 0; sh[SH_EQ] = 0;
             }
-            for (int i = tid; i < A_bytes / 16; i += NT) ((int4 *)smem)[i] = make_int4(0, 0, 0, 0);
+            for (int i = tid; i < (CBM_BYTES + A_bytes) / 16; i += NT) ((int4 *)smem)[i] = make_int4(0, 0, 0, 0);
             for (int i = tid; i < 1024; i += NT) hist4[i] = 0;
             if (timing) ph[CT_ROWS_FALLBACK] += 1;
         }
