@@ -23,7 +23,7 @@ constexpr int U_SLACK = 1024;    // candidate-buffer entries beyond k (room betw
 #define DRAIN_UNROLL (NT >= 1024 ? 2 : NT >= 768 ? 4 : 8)
 
 // scalar slots in LDS
-enum { SH_CNT = 0, SH_OVF, SH_SEL, SH_NEED, SH_EQ, SH_CNT2, SH_RETRY, SH_QA, SH_QB, SH_PCTR, SH_NITEMS, SH_N };   // SH_CNT2/SEL/NEED/EQ belong to the selections
+enum { SH_CNT = 0, SH_OVF, SH_SEL, SH_NEED, SH_EQ, SH_CNT2, SH_RETRY, SH_QA, SH_QB, SH_PCTR, SH_MCTR, SH_NITEMS, SH_N };   // SH_CNT2/SEL/NEED/EQ belong to the selections
 
 // phases timed by lane 0 of every workgroup when KParams::phase_cycles != NULL, then event counters
 enum { PH_SETUP = 0, PH_SEGMENTS, PH_ACCUM, PH_DRAIN, PH_SELECT, PH_OUTPUT, PH_SWEEP1, PH_SWEEP2, PH_CSDRAIN,
@@ -416,10 +416,12 @@ __device__ __forceinline__ int wave_incl_scan_dpp(int v) {
 //           surplus: keeps every entry >= the lower edge of the 16-bit bin holding the k-th largest and returns
 //           that edge — a valid (conservative) running cutoff, cheaper than the exact one.
 // Must be entered by the whole workgroup.  Returns -1 when n <= k (nothing done).
-template <int NT>
+// ZERO_TAIL: the buffer is used with block-wise reservations (holes = zero entries): positions beyond the kept
+// entries are zeroed so that a later reservation never exposes stale entries.
+template <int NT, bool ZERO_TAIL = false>
 __device__ long long select_fast(u64 *U, int *hist4, int *sh, int k, bool exact) {
     const int tid = threadIdx.x, lane = tid & 63;
-    const int n = sh[SH_CNT];
+    const int n = min(sh[SH_CNT], 2 * NT);
     if (tid == 0) { sh[SH_CNT2] = 0; sh[SH_EQ] = 0; }   // (the generic path's selection leaves them dirty)
     __syncthreads();
     if (n <= k) return -1;
@@ -493,6 +495,14 @@ __device__ long long select_fast(u64 *U, int *hist4, int *sh, int k, bool exact)
         }
     }
     __syncthreads();
+    if (ZERO_TAIL) {
+        const int kept = sh[SH_CNT2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = tid + j * NT;
+            if (has[j] && i >= kept) U[i] = 0ull;
+        }
+    }
     for (int i = tid; i < passes * 256; i += NT) hist4[i] = 0;
     if (tid == 0) sh[SH_CNT] = sh[SH_CNT2];
     __syncthreads();

@@ -68,6 +68,7 @@ struct Config {
     int nb_log2;            // sparse kernel: bitmap bits (log2)
     size_t ws_total;
     bool fold;
+    bool mono;              // the sparse kernel's monotone variant applies (val = xy / den or the raw dot, no row selectors)
     bool ordered;
 };
 
@@ -128,6 +129,8 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
     // Y is divided into the m2 values once per call, the kernels then need no column-term gathers at all
     c->fold = !(a->flags & SP_FLAG_NO_FOLD) && a->l1 == 0.f && a->a1 == 1.f && a->stabilized_shrink == 0.f &&
               a->bayesian_shrink == 0.f && ((a->l2 != 0.f) != (a->l3 != 0.f)) && a->nnz_m2 > 0;
+    const bool any_norm = a->l1 != 0.f || a->l2 != 0.f || a->l3 != 0.f || a->stabilized_shrink != 0.f || a->bayesian_shrink != 0.f;
+    c->mono = (c->fold || !any_norm) && a->filter_mode != SP_SEL_MATRIX && a->target_col_mode != SP_SEL_MATRIX;
     c->ws_fold_bytes = c->fold ? (((size_t)a->nnz_m2 * 4 + 255) & ~(size_t)255) : 0;
     c->ordered = !(a->flags & (SP_FLAG_STATIC_SCHED | SP_FLAG_NO_ROW_ORDER)) && a->n_targets > std::min(c->wgs_sparse, c->wgs_generic);
     // 512 B of bucket counters | work[n] | order[n] | (32-byte aligned) sparse queue n x 32 B | generic queue n x 32 B
@@ -184,7 +187,8 @@ template <int NT>
 int launch_rows(const KParams &kp, const Config &c, hipStream_t stream) {
     // sparse rows first; what it cannot finish joins the generic queue, which the second launch drains
     if (kp.sparse_path) {
-        auto ks = c.u_lds_s ? sp_knn_sparse_kernel<NT, true> : sp_knn_sparse_kernel<NT, false>;
+        auto ks = c.mono ? (c.u_lds_s ? sp_knn_sparse_kernel<NT, true, true> : sp_knn_sparse_kernel<NT, false, true>)
+                         : (c.u_lds_s ? sp_knn_sparse_kernel<NT, true, false> : sp_knn_sparse_kernel<NT, false, false>);
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds_sparse));
         hipLaunchKernelGGL(ks, dim3(c.wgs_sparse), dim3(NT), c.lds_sparse, stream, kp);
         HIP_TRY(hipGetLastError());
@@ -288,6 +292,9 @@ int run_device(sp_knn_args *a) {
         cp.sparse_path = kp.sparse_path;
         cp.n_cols = a->n_output_cols; cp.T = c.T; cp.nb_log2 = c.nb_log2;
         cp.cs_slots = c.T / 4;
+        cp.mono = c.mono ? 1 : 0;
+        cp.any_norm = (a->l1 != 0.f || a->l2 != 0.f || a->l3 != 0.f || a->stabilized_shrink != 0.f || a->bayesian_shrink != 0.f) ? 1 : 0;
+        cp.l2 = a->l2; cp.l3 = a->l3;
         hipLaunchKernelGGL(sp_row_desc_kernel, dim3((a->n_targets + 255) / 256), dim3(256), 0, stream, a->n_targets, a->targets,
                            a->m1_indptr, work, c.ordered ? bucket_base + 32 : nullptr, order, a->l1 != 0.f ? a->Xtversky : nullptr,
                            a->l2 != 0.f ? a->Xcosine : nullptr, a->l3 != 0.f ? a->Xdepop : nullptr, cp, kp.qcount, desc_s, desc_g);

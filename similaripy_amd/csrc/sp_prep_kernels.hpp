@@ -83,6 +83,9 @@ struct ClassifyParams {
     int n_cols, T;
     int nb_log2;           // sparse bitmap bits
     int cs_slots;          // collision-set slots of the sparse kernel
+    int mono;              // the monotone sparse kernel runs: descriptor word 1.y carries den (val = xy / den), rows
+    int any_norm;          //   with a normalised epilogue need den > 0 to be sparse
+    float l2, l3;
 };
 
 __global__ __launch_bounds__(256) void sp_row_desc_kernel(int n_targets, const int *targets, const int *m1_indptr, const unsigned *work,
@@ -102,7 +105,15 @@ __global__ __launch_bounds__(256) void sp_row_desc_kernel(int n_targets, const i
         d0 = make_int4(slot, t, s, e - s);
         d1 = make_int4((int)macs, Xtv ? (int)__float_as_uint(Xtv[t]) : 0, Xcos ? (int)__float_as_uint(Xcos[t]) : 0,
                        Xdep ? (int)__float_as_uint(Xdep[t]) : 0);
-        if (cp.sparse_path && macs > 0u && macs < (1u << 30) && (e - s) <= SORT_MAX && cp.n_cols > cp.T) {
+        bool den_ok = true;
+        if (cp.mono) {
+            // the epilogue's denominator with the column term folded away (s_plus.h:134-150): l2 * Xcos[t] or l3 * Xdep[t]
+            float den = 1.f;
+            if (cp.any_norm) den = Xcos ? cp.l2 * (Xcos[t] * 1.f) : (Xdep ? cp.l3 * (Xdep[t] * 1.f) : 0.f);
+            d1.y = (int)__float_as_uint(den);
+            den_ok = !cp.any_norm || den > 0.f;
+        }
+        if (cp.sparse_path && den_ok && macs > 0u && macs < (1u << 30) && (e - s) <= SORT_MAX && cp.n_cols > cp.T) {
             // expected number of products that find their bit set: true collisions + bitmap aliasing
             const float m = (float)macs;
             const float alias = (cp.nb_log2 < 31 && (1 << cp.nb_log2) < cp.n_cols) ? 1.f / (float)(1 << cp.nb_log2) : 0.f;

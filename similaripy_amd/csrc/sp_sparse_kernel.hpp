@@ -20,7 +20,12 @@
 
 namespace {
 
-template <int NT, bool U_LDS>
+// MONO: the similarity is a monotone function of the raw dot alone — val = xy / den with a per-row den > 0 (cosine-type
+// epilogues whose column term is folded into the m2 stream) or val = xy (no normalisation) — and no per-row column
+// selector is active.  Then the whole top-k runs on the raw dot: survivors go straight from the sweep into the
+// candidate buffer (no survivor pool, no judge phase), the running k-th raw dot IS the cutoff, and the epilogue is
+// applied to the k winners at write-out.
+template <int NT, bool U_LDS, bool MONO>
 __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NW = NT / 64;
@@ -33,7 +38,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
     // cbm[CBM_BYTES]      collision bitmap (columns seen twice in sweep 1), alive through both sweeps; at offset 0 so
     //                     that its reads need no base add
     // region A [.., +T*8) sweep 1: column bitmap (nb bits, from the start);
-    //                     afterwards: [0,A/4) collision set, [A/4,3A/4) survivor pool, [3A/4,A) candidate buffer U
+    //                     afterwards: [0,A/4) collision set, [A/4,A/2) survivor pool, [A/2,3A/4) member pool, [3A/4,A) candidate buffer U
     // items[ITEM_CAP]     {m2 byte offset, count, m1 value bits, flat start};  hist4[4][256] radix histograms
     // sh[32], ph[16]      scalars, phase timers
     unsigned char *cbm = smem;
@@ -51,14 +56,17 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
     u64 *cs = (u64 *)rA;
     const int CSN = A_bytes / 32;
     const int cs_shift = 32 - (p.logT - 2);                                     // log2(CSN) = logT + 3 - 5
-    u64 *pool = (u64 *)(rA + A_bytes / 4);
-    const int pcap = A_bytes / 16;
+    u64 *spool = (u64 *)(rA + A_bytes / 4);      // surviving single products of a stage
+    const int spcap = A_bytes / 32;
+    u64 *mpool = (u64 *)(rA + A_bytes / 2);      // products of marked columns, all stages
+    const int mpcap = A_bytes / 32;
     const __amdgpu_buffer_rsrc_t rs_idx = __builtin_amdgcn_make_buffer_rsrc((void *)p.m2_indices, 0, (int)p.m2_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_val = __builtin_amdgcn_make_buffer_rsrc((void *)p.m2_data, 0, (int)p.m2_bytes, 0x00020000);
 
     // collision bitmap + region A all zero, histograms zero
     for (int i = tid; i < (CBM_BYTES + A_bytes) / 16; i += NT) ((int4 *)smem)[i] = make_int4(0, 0, 0, 0);
     for (int i = tid; i < 1024; i += NT) hist4[i] = 0;
+    if (MONO && !U_LDS) { for (int i = tid; i < cap / 2; i += NT) ((int4 *)U)[i] = make_int4(0, 0, 0, 0); }
     if (tid < 32) sh[tid] = 0;
     if (tid < 16) ph[tid] = 0;
     __syncthreads();
@@ -135,7 +143,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         }
         int nx_r0 = 0, nx_len = 0;
 
-        if (tid == 0) { sh[SH_PCTR] = 0; sh[SH_NITEMS] = 0; sh[SH_CNT] = 0; }
+        if (tid == 0) { sh[SH_PCTR] = 0; sh[SH_MCTR] = 0; sh[SH_NITEMS] = 0; sh[SH_CNT] = 0; }
         // Segments are visited in descending |m1 value| order: each segment scales its m2 row by its own m1 value,
         // so the heavy segments first make the running k-th value rise early and the survivor rate fall
         // monotonically.  First item and flat start of every segment come from one all-pairs pass spread over the
@@ -174,24 +182,39 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         PHASE_END(PH_SETUP);
 
         RowCtx rc;
-        rc.row = t;
         rc.have_thr = false;
         rc.thr_key = 0;
-        Epi &epi = rc.epi;
-        epi.a1 = p.a1; epi.l1 = p.l1; epi.l2 = p.l2; epi.l3 = p.l3; epi.t1 = p.t1; epi.t2 = p.t2;
-        epi.stab = p.stab; epi.bayes = p.bayes; epi.threshold = p.threshold; epi.any = any_norm;
-        epi.xtv = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane(wC.y));    // row terms travel in the descriptor
-        epi.xcos = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane(wC.z));
-        epi.xdep = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane(wC.w));
-        // den = l1*(t1*(X-xy) + t2*(Y-xy) + xy) + l2*Xc*Yc + l3*Xd*Yd + stab  >=  bA + bB*xy  when the
-        // column terms are replaced by their minima and their multipliers are non-negative
-        epi.bound = p.bound_ok && !(epi.xcos < 0.f) && !(epi.xdep < 0.f);
-        epi.bA = p.l1 * (p.t1 * epi.xtv + p.t2 * ymin_tv) + p.l2 * epi.xcos * ymin_cos + p.l3 * epi.xdep * ymin_dep + p.stab;
-        epi.bB = p.l1 * (1.f - p.t1 - p.t2);
-        rc.set_cut(p.threshold);
-        rc.f0 = rc.f1 = rc.g0 = rc.g1 = 0;
-        if (p.filter_mode == SP_SEL_MATRIX) { rc.f0 = __builtin_amdgcn_readfirstlane(p.f_indptr[t]); rc.f1 = __builtin_amdgcn_readfirstlane(p.f_indptr[t + 1]); }
-        if (p.target_mode == SP_SEL_MATRIX) { rc.g0 = __builtin_amdgcn_readfirstlane(p.t_indptr[t]); rc.g1 = __builtin_amdgcn_readfirstlane(p.t_indptr[t + 1]); }
+        float cutx = -__builtin_inff();    // MONO: a single product / a column sum <= cutx cannot enter the top-k
+        float cutx0 = cutx;                // MONO: the part of it that comes from the `threshold` parameter
+        const float den = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane(wC.y));   // MONO: val = xy / den (desc)
+        if constexpr (MONO) {
+            // x <= cutx0  =>  val(x) < threshold for sure (the exact test is repeated on the winners at write-out)
+            if (!any_norm) {
+                cutx0 = __uint_as_float(RowCtx::funkey_inv_below(p.threshold));
+            } else {
+                const float c0 = p.threshold * den;
+                cutx0 = c0 - fabsf(c0) * 2e-6f - 1e-37f;
+                if (!(c0 == c0)) cutx0 = -__builtin_inff();      // NaN threshold: nothing is pruned here, all dropped at write-out
+            }
+            cutx = cutx0;
+        } else {
+            rc.row = t;
+            Epi &epi = rc.epi;
+            epi.a1 = p.a1; epi.l1 = p.l1; epi.l2 = p.l2; epi.l3 = p.l3; epi.t1 = p.t1; epi.t2 = p.t2;
+            epi.stab = p.stab; epi.bayes = p.bayes; epi.threshold = p.threshold; epi.any = any_norm;
+            epi.xtv = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane(wC.y));    // row terms travel in the descriptor
+            epi.xcos = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane(wC.z));
+            epi.xdep = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane(wC.w));
+            // den = l1*(t1*(X-xy) + t2*(Y-xy) + xy) + l2*Xc*Yc + l3*Xd*Yd + stab  >=  bA + bB*xy  when the
+            // column terms are replaced by their minima and their multipliers are non-negative
+            epi.bound = p.bound_ok && !(epi.xcos < 0.f) && !(epi.xdep < 0.f);
+            epi.bA = p.l1 * (p.t1 * epi.xtv + p.t2 * ymin_tv) + p.l2 * epi.xcos * ymin_cos + p.l3 * epi.xdep * ymin_dep + p.stab;
+            epi.bB = p.l1 * (1.f - p.t1 - p.t2);
+            rc.set_cut(p.threshold);
+            rc.f0 = rc.f1 = rc.g0 = rc.g1 = 0;
+            if (p.filter_mode == SP_SEL_MATRIX) { rc.f0 = __builtin_amdgcn_readfirstlane(p.f_indptr[t]); rc.f1 = __builtin_amdgcn_readfirstlane(p.f_indptr[t + 1]); }
+            if (p.target_mode == SP_SEL_MATRIX) { rc.g0 = __builtin_amdgcn_readfirstlane(p.t_indptr[t]); rc.g1 = __builtin_amdgcn_readfirstlane(p.t_indptr[t + 1]); }
+        }
 
         if (!failed) {
             // sentinel item behind the last one: a prefetch past the end loads nothing (every lane out of range)
@@ -282,23 +305,25 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         }
 
         if (!failed) {
-            // Stages.  A stage is a sweep 2 over a chunk of items; the last one additionally turns the collision
-            // set (complete sums by then) into pool entries.  Then ONE dense consumer judges the pool (column
-            // terms, epilogue, threshold) into U; a full U triggers a selection and another pass over what is left.
+            // Stages.  A stage is a sweep 2 over a chunk of items: products of marked columns go to the member pool,
+            // surviving single products to the survivor pool.  After every stage ONE dense consumer judges the
+            // survivor pool (column terms, epilogue, threshold) into U; after the last stage the member pool is first
+            // accumulated into the collision set (find-or-insert) and the set's slots are judged with the pool; a
+            // full U triggers a selection and another pass over what is left.
             // The products are offered in growing chunks with a selection after each: the first chunk is small
             // enough that accepting everything cannot overflow U; once the k-th best of n products is known, about
             // k*m/n of the next m would survive in an exchangeable stream — far fewer here, because segments come
             // in descending weight — so the next chunk may be 4*n*(cap-k)/k long.
             const int room = cap - min(p.k, cap - 1);
             int i0 = 0;
-            long long chunk = room;
+            long long chunk = MONO ? room : min(room, spcap - 2 * ITEM);
             bool last_stage = false;
+            WavePool wpm{0, -1};      // member-pool window: lives across the stages of the row
             while (!last_stage) {
-                int ext = 0;
-                if (i0 < n_items) {
-                    const int i1 = (int)min((long long)n_items, (long long)i0 + max(1ll, chunk / ITEM));
+                const int i1 = (int)min((long long)n_items, (long long)i0 + max(1ll, chunk / ITEM));
+                {
                     // ---- sweep 2 over items [i0, i1) ----
-                    WavePool wp{0, -1};
+                    WavePool wps{0, -1};
                     auto ld = [&](int it, unsigned (&c)[4], float (&v)[4], int &cnt, float &segv) __attribute__((always_inline)) {
                         const int4 d = items[(it < i1) ? it : n_items];     // beyond this chunk: the sentinel item
                         const int off = __builtin_amdgcn_readfirstlane(d.x);
@@ -309,6 +334,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                         c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w;
                         v[0] = __uint_as_float(b.x); v[1] = __uint_as_float(b.y); v[2] = __uint_as_float(b.z); v[3] = __uint_as_float(b.w);
                     };
+                    const float cut = MONO ? cutx : rc.xy_cut;
                     auto body = [&](const unsigned (&c)[4], const float (&v)[4], int cnt, float segv) __attribute__((always_inline)) {
                         if (cnt == 0) return;                  // sentinel (wave-uniform)
                         unsigned w[4];
@@ -318,143 +344,163 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                             x[j] = v[j] * segv;
                             w[j] = *(const unsigned *)(cbm + ((c[j] >> 3) & cmask));
                         }
-                        // mem: product of a marked column (it accumulates in the collision set in the dense phase);
-                        // otherwise the product is the only one of its column and matters only if its raw dot can
-                        // still enter the top-k (NaN stays: the exact judge drops it)
-                        unsigned mem[4];
-                        bool push[4];
+                        // mem: product of a marked column; otherwise the product is the only one of its column and
+                        // matters only if its raw dot can still enter the top-k (NaN stays: the exact judge drops it)
+                        bool mem[4], sur[4];
                         if (cnt == ITEM) {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
-                                mem[j] = (w[j] >> (c[j] & 31u)) & 1u;
-                                push[j] = (mem[j] != 0u) | !(x[j] <= rc.xy_cut);
+                                mem[j] = ((w[j] >> (c[j] & 31u)) & 1u) != 0u;
+                                sur[j] = !mem[j] & !(x[j] <= cut);
                             }
                         } else {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
                                 const bool ok = 4 * lane + j < cnt;
-                                mem[j] = ok ? ((w[j] >> (c[j] & 31u)) & 1u) : 0u;
-                                push[j] = (mem[j] != 0u) | (ok & !(x[j] <= rc.xy_cut));
+                                mem[j] = ok & (((w[j] >> (c[j] & 31u)) & 1u) != 0u);
+                                sur[j] = ok & !mem[j] & !(x[j] <= cut);
                             }
                         }
-                        const u64 P0 = __ballot(push[0]), P1 = __ballot(push[1]), P2 = __ballot(push[2]), P3 = __ballot(push[3]);
-                        if ((P0 | P1) | (P2 | P3)) {
-                            const int n0 = __popcll(P0), n1 = __popcll(P1), n2 = __popcll(P2), n3 = __popcll(P3);
-                            if (pool_reserve(wp, n0 + n1 + n2 + n3, &sh[SH_PCTR], pcap, &sh[SH_OVF])) {
-                                int pos = wp.pos;
-                                if (push[0]) pool[pos + mbcnt64(P0)] = ((u64)((c[0] + 1u) | (mem[0] << 31)) << 32) | (u64)__float_as_uint(x[0]);
+                        const u64 M0 = __ballot(mem[0]), M1 = __ballot(mem[1]), M2 = __ballot(mem[2]), M3 = __ballot(mem[3]);
+                        if ((M0 | M1) | (M2 | M3)) {
+                            const int n0 = __popcll(M0), n1 = __popcll(M1), n2 = __popcll(M2), n3 = __popcll(M3);
+                            if (pool_reserve(wpm, n0 + n1 + n2 + n3, &sh[SH_MCTR], mpcap, &sh[SH_OVF])) {
+                                int pos = wpm.pos;
+                                if (mem[0]) mpool[pos + mbcnt64(M0)] = ((u64)(c[0] + 1u) << 32) | (u64)__float_as_uint(x[0]);
                                 pos += n0;
-                                if (push[1]) pool[pos + mbcnt64(P1)] = ((u64)((c[1] + 1u) | (mem[1] << 31)) << 32) | (u64)__float_as_uint(x[1]);
+                                if (mem[1]) mpool[pos + mbcnt64(M1)] = ((u64)(c[1] + 1u) << 32) | (u64)__float_as_uint(x[1]);
                                 pos += n1;
-                                if (push[2]) pool[pos + mbcnt64(P2)] = ((u64)((c[2] + 1u) | (mem[2] << 31)) << 32) | (u64)__float_as_uint(x[2]);
+                                if (mem[2]) mpool[pos + mbcnt64(M2)] = ((u64)(c[2] + 1u) << 32) | (u64)__float_as_uint(x[2]);
                                 pos += n2;
-                                if (push[3]) pool[pos + mbcnt64(P3)] = ((u64)((c[3] + 1u) | (mem[3] << 31)) << 32) | (u64)__float_as_uint(x[3]);
-                                wp.pos = pos + n3;
+                                if (mem[3]) mpool[pos + mbcnt64(M3)] = ((u64)(c[3] + 1u) << 32) | (u64)__float_as_uint(x[3]);
+                                wpm.pos = pos + n3;
+                            }
+                        }
+                        const u64 S0 = __ballot(sur[0]), S1 = __ballot(sur[1]), S2 = __ballot(sur[2]), S3 = __ballot(sur[3]);
+                        if ((S0 | S1) | (S2 | S3)) {
+                            const int n0 = __popcll(S0), n1 = __popcll(S1), n2 = __popcll(S2), n3 = __popcll(S3);
+                            if constexpr (MONO) {
+                                // straight into the candidate buffer, keyed by the raw dot
+                                if (pool_reserve(wps, n0 + n1 + n2 + n3, &sh[SH_CNT], cap, &sh[SH_OVF])) {
+                                    int pos = wps.pos;
+                                    if (sur[0]) U[pos + mbcnt64(S0)] = ((u64)fkey(x[0]) << 32) | (u64)c[0];
+                                    pos += n0;
+                                    if (sur[1]) U[pos + mbcnt64(S1)] = ((u64)fkey(x[1]) << 32) | (u64)c[1];
+                                    pos += n1;
+                                    if (sur[2]) U[pos + mbcnt64(S2)] = ((u64)fkey(x[2]) << 32) | (u64)c[2];
+                                    pos += n2;
+                                    if (sur[3]) U[pos + mbcnt64(S3)] = ((u64)fkey(x[3]) << 32) | (u64)c[3];
+                                    wps.pos = pos + n3;
+                                }
+                            } else {
+                                if (pool_reserve(wps, n0 + n1 + n2 + n3, &sh[SH_PCTR], spcap, &sh[SH_OVF])) {
+                                    int pos = wps.pos;
+                                    if (sur[0]) spool[pos + mbcnt64(S0)] = ((u64)(c[0] + 1u) << 32) | (u64)__float_as_uint(x[0]);
+                                    pos += n0;
+                                    if (sur[1]) spool[pos + mbcnt64(S1)] = ((u64)(c[1] + 1u) << 32) | (u64)__float_as_uint(x[1]);
+                                    pos += n1;
+                                    if (sur[2]) spool[pos + mbcnt64(S2)] = ((u64)(c[2] + 1u) << 32) | (u64)__float_as_uint(x[2]);
+                                    pos += n2;
+                                    if (sur[3]) spool[pos + mbcnt64(S3)] = ((u64)(c[3] + 1u) << 32) | (u64)__float_as_uint(x[3]);
+                                    wps.pos = pos + n3;
+                                }
                             }
                         }
                     };
-                    unsigned cA[4], cB[4], cC[4];
-                    float vA[4], vB[4], vC[4];
-                    int nA = 0, nB = 0, nC = 0;
-                    float sA = 0.f, sB = 0.f, sC = 0.f;
+                    unsigned cA[4], cB[4];
+                    float vA[4], vB[4];
+                    int nA = 0, nB = 0;
+                    float sA = 0.f, sB = 0.f;
                     int it = i0 + wave;
                     ld(it, cA, vA, nA, sA);
-                    ld(it + NW, cB, vB, nB, sB);
-                    while (it < i1) {      // three items in flight per wave; bodies skip the sentinel
-                        ld(it + 2 * NW, cC, vC, nC, sC);
-                        __builtin_amdgcn_sched_barrier(0);     // the prefetch is issued before the oldest item is waited for
+                    while (it < i1) {      // two items (4 KiB) in flight per wave; bodies skip the sentinel
+                        ld(it + NW, cB, vB, nB, sB);
+                        __builtin_amdgcn_sched_barrier(0);     // the prefetch is issued before the current item is waited for
                         body(cA, vA, nA, sA);
-                        ld(it + 3 * NW, cA, vA, nA, sA);
+                        ld(it + 2 * NW, cA, vA, nA, sA);
                         __builtin_amdgcn_sched_barrier(0);
                         body(cB, vB, nB, sB);
-                        ld(it + 4 * NW, cB, vB, nB, sB);
-                        __builtin_amdgcn_sched_barrier(0);
-                        body(cC, vC, nC, sC);
-                        it += 3 * NW;
-                    }
-                    i0 = i1;
-                    __syncthreads();
-                    ext = min(sh[SH_PCTR], pcap);
-                    if (sh[SH_OVF]) { failed = true; break; }     // pool or collision set overflowed
-                    PHASE_END(PH_SWEEP2);
-                }
-                // ---- products of marked columns (flagged entries): find-or-insert in the collision set.  {~column : sum}
-                // slots, 0 = free; ONE 64-bit compare-and-swap claims a free slot with the product in it, a second one
-                // adds to the sum of a slot the column already owns (ds_cmpst_rtn_b64 retires 10x the lanes of
-                // ds_add_f32 on gfx950). ----
-                for (int i = tid; i < ext; i += NT) {
-                    const u64 e = pool[i];
-                    if (e >> 63) {
-                        const unsigned cc = ((unsigned)(e >> 32) & 0x7FFFFFFFu) - 1u;
-                        const float xx = __uint_as_float((unsigned)e);
-                        const unsigned nc = ~cc;
-                        unsigned h = hash_bits((int)cc, 2654435761u, cs_shift);
-                        int tries = 0;
-                        for (; tries < CS_MAXPROBE; ++tries) {
-                            u64 cur = atomicCAS(&cs[h], 0ull, ((u64)nc << 32) | (u64)__float_as_uint(xx));
-                            if (cur == 0ull) break;                    // claimed, product deposited
-                            if ((unsigned)(cur >> 32) == nc) {
-                                for (;;) {
-                                    const u64 want = (cur & 0xFFFFFFFF00000000ull) | (u64)__float_as_uint(__uint_as_float((unsigned)cur) + xx);
-                                    const u64 got = atomicCAS(&cs[h], cur, want);
-                                    if (got == cur) break;
-                                    cur = got;
-                                }
-                                break;
-                            }
-                            h = (h + 1u) & (unsigned)(CSN - 1);
-                        }
-                        if (tries == CS_MAXPROBE) sh[SH_OVF] = 1;
-                        pool[i] = 0ull;
+                        it += 2 * NW;
                     }
                 }
+                i0 = i1;
+                last_stage = (i0 >= n_items);
                 __syncthreads();
-                if (sh[SH_OVF]) { failed = true; break; }         // collision set full
-                PHASE_END(PH_ACCUM);
-                if (i0 >= n_items && ext <= pcap - CSN) {
-                    // ---- last stage: the collision set becomes pool entries (back part of the pool), and is cleared
-                    // together with its collision-bitmap bits ----
-                    for (int idx = tid; idx < CSN; idx += NT) {
-                        const u64 s = cs[idx];
-                        u64 e = 0ull;
-                        if (s != 0ull) {
-                            const unsigned c = ~(unsigned)(s >> 32);
-                            e = ((u64)(c + 1u) << 32) | (s & 0xFFFFFFFFull);
-                            cs[idx] = 0ull;
-                            atomicAnd((unsigned *)(cbm + ((c >> 3) & cmask)), ~(1u << (c & 31u)));
+                const int ext = min(sh[SH_PCTR], spcap);
+                const int mext = min(sh[SH_MCTR], mpcap);
+                if (sh[SH_OVF]) { failed = true; break; }     // a pool overflowed
+                PHASE_END(PH_SWEEP2);
+                if (last_stage) {
+                    // ---- products of marked columns: find-or-insert in the collision set.  {column+1 : sum} slots,
+                    // 0 = free; ONE 64-bit compare-and-swap claims a free slot with the product in it, a second one adds
+                    // to the sum of a slot the column already owns (ds_cmpst_rtn_b64 retires 10x the lanes of
+                    // ds_add_f32 on gfx950). ----
+                    for (int i = tid; i < mext; i += NT) {
+                        const u64 e = mpool[i];
+                        if (e != 0ull) {
+                            const unsigned key = (unsigned)(e >> 32);
+                            const float xx = __uint_as_float((unsigned)e);
+                            unsigned h = hash_bits((int)key, 2654435761u, cs_shift);
+                            int tries = 0;
+                            for (; tries < CS_MAXPROBE; ++tries) {
+                                u64 cur = atomicCAS(&cs[h], 0ull, e);
+                                if (cur == 0ull) break;                    // claimed, product deposited
+                                if ((unsigned)(cur >> 32) == key) {
+                                    for (;;) {
+                                        const u64 want = (cur & 0xFFFFFFFF00000000ull) | (u64)__float_as_uint(__uint_as_float((unsigned)cur) + xx);
+                                        const u64 got = atomicCAS(&cs[h], cur, want);
+                                        if (got == cur) break;
+                                        cur = got;
+                                    }
+                                    break;
+                                }
+                                h = (h + 1u) & (unsigned)(CSN - 1);
+                            }
+                            if (tries == CS_MAXPROBE) sh[SH_OVF] = 1;
+                            mpool[i] = 0ull;
                         }
-                        pool[pcap - CSN + idx] = e;
                     }
-                    last_stage = true;
                     __syncthreads();
-                    PHASE_END(PH_CSDRAIN);
+                    if (sh[SH_OVF]) { failed = true; break; }     // collision set full
+                    PHASE_END(PH_ACCUM);
                 }
 
-                // ---- dense consumer over pool[0, ext) and, in the last stage, pool[pcap-CSN, pcap); leaves them zero ----
-                const int n_ent = ext + (last_stage ? CSN : 0);
+                // ---- dense consumer.  General: spool[0, ext) and, in the last stage, the collision set's slots (same
+                // entry format) are judged into U.  MONO: only the collision set is left to do — sums above the cutoff
+                // go straight into U.  Consumed entries are zeroed (and the set's collision-bitmap bits cleared). ----
+                const int n_ent = (MONO ? 0 : ext) + (last_stage ? CSN : 0);
                 for (;;) {
-                    for (int base = 0; base < n_ent; base += NT * DRAIN_UNROLL) {
-                        u64 e[DRAIN_UNROLL];
-                        int pidx[DRAIN_UNROLL];
-                        int c[DRAIN_UNROLL];
-                        float xy[DRAIN_UNROLL];
-                        unsigned occ = 0;
-#pragma unroll
-                        for (int j = 0; j < DRAIN_UNROLL; ++j) {
-                            const int i = base + j * NT + tid;
-                            pidx[j] = (i < ext) ? i : (pcap - CSN + (i - ext));
-                            e[j] = (i < n_ent) ? pool[pidx[j]] : 0ull;
+                    for (int base = 0; base < n_ent; base += NT) {
+                        const int i = base + tid;
+                        u64 *src = (!MONO && i < ext) ? &spool[i] : &cs[i - (MONO ? 0 : ext)];
+                        const u64 e = (i < n_ent) ? *src : 0ull;
+                        const unsigned col = (unsigned)(e >> 32) - 1u;
+                        const float xv = __uint_as_float((unsigned)e);
+                        bool finished = true;
+                        if constexpr (MONO) {
+                            const bool want = (e != 0ull) && !(xv <= cutx);
+                            const u64 m = __ballot(want);
+                            if (m) {
+                                int wbase = 0;
+                                if (lane == 0) wbase = atomicAdd(&sh[SH_CNT], __popcll(m));
+                                wbase = __builtin_amdgcn_readfirstlane(wbase);
+                                if (want) {
+                                    const int pos = wbase + mbcnt64(m);
+                                    if (pos < cap) U[pos] = ((u64)fkey(xv) << 32) | (u64)col;
+                                    else { sh[SH_RETRY] = 1; finished = false; }
+                                }
+                            }
+                        } else {
+                            int c[1] = {(int)col};
+                            float xy[1] = {xv};
+                            const unsigned occ = (e != 0ull && !(xv <= rc.xy_cut)) ? 1u : 0u;
+                            const unsigned done = emit_candidates<1>(p, rc, c, xy, occ, U, sh, cap);
+                            finished = !occ || done;
                         }
-#pragma unroll
-                        for (int j = 0; j < DRAIN_UNROLL; ++j) {
-                            c[j] = (int)((unsigned)(e[j] >> 32) - 1u);
-                            xy[j] = __uint_as_float((unsigned)e[j]);
-                            if (e[j] != 0ull && !(xy[j] <= rc.xy_cut)) occ |= 1u << j;
+                        if (e != 0ull && finished) {
+                            *src = 0ull;
+                            if (MONO || i >= ext) atomicAnd((unsigned *)(cbm + ((col >> 3) & cmask)), ~(1u << (col & 31u)));
                         }
-                        const unsigned done = emit_candidates<DRAIN_UNROLL>(p, rc, c, xy, occ, U, sh, cap);
-#pragma unroll
-                        for (int j = 0; j < DRAIN_UNROLL; ++j)
-                            if (e[j] != 0ull && (!(occ & (1u << j)) || (done & (1u << j)))) pool[pidx[j]] = 0ull;
                     }
                     __syncthreads();
                     const int retry = sh[SH_RETRY];
@@ -462,51 +508,103 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     __syncthreads();
                     if (tid == 0) {
                         sh[SH_PCTR] = 0;
+                        if (last_stage) sh[SH_MCTR] = 0;
                         if (retry) { sh[SH_RETRY] = 0; if (n_now > cap) sh[SH_CNT] = cap; }   // failed appends over-counted
                     }
                     __syncthreads();         // counter fix-ups visible before the next pushes / the selection
                     PHASE_END(PH_DRAIN);
                     // selection: forced when U overflowed; exact after the last stage (final top-k); between stages
-                    // whenever it can raise the running k-th value
-                    if (retry || n_now > p.k) {
+                    // when U is filling up (it raises the running k-th value, which is the cutoff of the next stage)
+                    const int n_eff = min(n_now, cap);
+                    const bool want_sel = retry || (last_stage ? (n_eff > p.k) : (n_eff > p.k && (!rc.have_thr || 2 * n_eff > cap + p.k)));
+                    if (want_sel) {
                         long long thr_new;
-                        if (cap <= 2 * NT) thr_new = select_fast<NT>(U, hist4, sh, p.k, last_stage && !retry);
-                        else thr_new = compact_topk<NT>(U, hist4, sh, p.k);
+                        if (cap <= 2 * NT) thr_new = select_fast<NT, MONO>(U, hist4, sh, p.k, last_stage && !retry);
+                        else {
+                            thr_new = compact_topk<NT>(U, hist4, sh, p.k);
+                            if constexpr (MONO) {     // block-wise reservations: nothing stale may stay behind the kept entries
+                                if (thr_new >= 0) {
+                                    for (int i = sh[SH_CNT] + tid; i < n_eff; i += NT) U[i] = 0ull;
+                                    __syncthreads();
+                                }
+                            }
+                        }
                         if (thr_new >= 0) {
                             rc.have_thr = true;
                             rc.thr_key = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)thr_new);
-                            rc.set_cut(p.threshold);
+                            if constexpr (MONO) cutx = fmaxf(cutx0, funkey(rc.thr_key));
+                            else rc.set_cut(p.threshold);
                         }
                         PHASE_END(PH_SELECT);
                     }
                     if (!retry) break;  // uniform
                 }
+                // next chunk: with the k-th best of `pos` products as cutoff, an exchangeable stream lets k*m/pos of the
+                // next m products through; keep that below half of the room left in U (far fewer pass when the
+                // segments come in descending weight)
                 const long long pos = (i0 < n_items) ? (long long)items[i0].w : (long long)macs32;
-                chunk = rc.have_thr ? max((long long)room, 4ll * pos * (long long)room / (long long)p.k) : (long long)room;
+                const long long left = max(64, cap - min(sh[SH_CNT], cap));
+                chunk = rc.have_thr ? max((long long)ITEM, pos * left / (2ll * (long long)p.k)) : (long long)room;
+                if (!MONO) chunk = max(chunk, (long long)room);
             }
         }
 
         if (!failed) {
             // ================= write-out =================
             __syncthreads();
-            const int n_out = min(sh[SH_CNT], p.k);
+            const int n_sel = min(sh[SH_CNT], p.k);
             const long long o = (long long)slot_i * (long long)p.k;
-            for (int j = tid; j < p.k; j += NT) {
-                int r = 0, c = 0;
-                float v = 0.f;
-                if (j < n_out) {
-                    const u64 it = U[j];
-                    r = t;
-                    c = (int)(unsigned)(it & 0xFFFFFFFFull);
-                    v = funkey((unsigned)(it >> 32));
+            int n_out = n_sel;
+            if constexpr (MONO) {
+                // epilogue on the winners (s_plus.h:129-156 with the column term already folded in: val = xy / den, or
+                // the raw dot), exact threshold test, compaction of what passes to the front of the slot
+                if (tid == 0) sh[SH_SEL] = 0;
+                __syncthreads();
+                for (int base = 0; base < n_sel; base += NT) {
+                    const int j = base + tid;
+                    const u64 it = (j < n_sel) ? U[j] : 0ull;
+                    const float xv = funkey((unsigned)(it >> 32));
+                    float val = xv;
+                    if (any_norm) val = (den != 0.f) ? xv / den : 0.f;
+                    const bool keep = (it != 0ull) && (val >= p.threshold);
+                    const u64 m = __ballot(keep);
+                    if (m) {
+                        int wbase = 0;
+                        if (lane == 0) wbase = atomicAdd(&sh[SH_SEL], __popcll(m));
+                        wbase = __builtin_amdgcn_readfirstlane(wbase);
+                        if (keep) {
+                            const long long q = o + wbase + mbcnt64(m);
+                            if (p.rows) p.rows[q] = t;
+                            p.cols[q] = (int)(unsigned)(it & 0xFFFFFFFFull);
+                            p.values[q] = val;
+                        }
+                    }
                 }
-                if (p.rows) p.rows[o + j] = r;
-                p.cols[o + j] = c;
-                p.values[o + j] = v;
+                __syncthreads();
+                n_out = sh[SH_SEL];
+                for (int j = n_out + tid; j < p.k; j += NT) {
+                    if (p.rows) p.rows[o + j] = 0;
+                    p.cols[o + j] = 0;
+                    p.values[o + j] = 0.f;
+                }
+            } else {
+                for (int j = tid; j < p.k; j += NT) {
+                    int r = 0, c = 0;
+                    float v = 0.f;
+                    if (j < n_out) {
+                        const u64 it = U[j];
+                        r = t;
+                        c = (int)(unsigned)(it & 0xFFFFFFFFull);
+                        v = funkey((unsigned)(it >> 32));
+                    }
+                    if (p.rows) p.rows[o + j] = r;
+                    p.cols[o + j] = c;
+                    p.values[o + j] = v;
+                }
             }
             if (tid == 0 && p.counts) p.counts[slot_i] = n_out;
-            if (U_LDS) {
-                __syncthreads();     // U read before it is cleared: its storage is part of the next row's bitmap
+            if (U_LDS || MONO) {
+                __syncthreads();     // U read before it is cleared: its storage is part of the next row's bitmap (LDS) / holes must read zero (MONO)
                 for (int i = tid; i < cap / 2; i += NT) ((int4 *)U)[i] = make_int4(0, 0, 0, 0);
             }
             if (timing) ph[CT_ROWS_SPARSE] += 1;
@@ -522,11 +620,15 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             }
             for (int i = tid; i < (CBM_BYTES + A_bytes) / 16; i += NT) ((int4 *)smem)[i] = make_int4(0, 0, 0, 0);
             for (int i = tid; i < 1024; i += NT) hist4[i] = 0;
+            if (MONO && !U_LDS) { for (int i = tid; i < cap / 2; i += NT) ((int4 *)U)[i] = make_int4(0, 0, 0, 0); }
             if (timing) ph[CT_ROWS_FALLBACK] += 1;
         }
-        // rotate the row pipeline
+        // rotate the row pipeline (descriptors are wave-uniform: keep them in scalar registers)
         dC = dN; wC = wN;
-        dN = dNN; wN = wNN;
+        dN = make_int4(__builtin_amdgcn_readfirstlane(dNN.x), __builtin_amdgcn_readfirstlane(dNN.y),
+                       __builtin_amdgcn_readfirstlane(dNN.z), __builtin_amdgcn_readfirstlane(dNN.w));
+        wN = make_int4(__builtin_amdgcn_readfirstlane(wNN.x), __builtin_amdgcn_readfirstlane(wNN.y),
+                       __builtin_amdgcn_readfirstlane(wNN.z), __builtin_amdgcn_readfirstlane(wNN.w));
         my_r0 = nx_r0; my_len = nx_len; my_v = nx_v;
         __syncthreads();
         PHASE_END(PH_OUTPUT);
