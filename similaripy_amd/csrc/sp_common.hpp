@@ -23,7 +23,7 @@ constexpr int U_SLACK = 1024;    // candidate-buffer entries beyond k (room betw
 #define DRAIN_UNROLL (NT >= 1024 ? 2 : NT >= 768 ? 4 : 8)
 
 // scalar slots in LDS
-enum { SH_CNT = 0, SH_OVF, SH_SEL, SH_NEED, SH_EQ, SH_CNT2, SH_RETRY, SH_QA, SH_QB, SH_PCTR, SH_MCTR, SH_NITEMS, SH_N };   // SH_CNT2/SEL/NEED/EQ belong to the selections
+enum { SH_CNT = 0, SH_OVF, SH_SEL, SH_NEED, SH_EQ, SH_CNT2, SH_RETRY, SH_QA, SH_QB, SH_PCTR, SH_MCTR, SH_NITEMS, SH_STOP, SH_WSUM, SH_N = SH_WSUM + 16 };   // SH_CNT2/SEL/NEED/EQ belong to the selections
 
 // phases timed by lane 0 of every workgroup when KParams::phase_cycles != NULL, then event counters
 enum { PH_SETUP = 0, PH_SEGMENTS, PH_ACCUM, PH_DRAIN, PH_SELECT, PH_OUTPUT, PH_SWEEP1, PH_SWEEP2, PH_CSDRAIN,
@@ -363,8 +363,9 @@ __device__ __forceinline__ unsigned emit_candidates(const KParams &p, const RowC
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int ITEM = 256;         // m2 elements per work item: one 16-byte load per lane
-constexpr int ITEM_CAP = 752;     // work items per row (LDS: 16 B each)
-constexpr int CBM_BYTES = 16384;  // collision bitmap of the sparse kernel (128k bits)
+constexpr int ITEM_CAP = 1008;    // work items per row (LDS: 16 B each)
+constexpr int CBM_BYTES = 8192;   // collision bitmap of the sparse kernel (64k bits = 2048 words)
+constexpr int PRE_BYTES = 4096;   // per-word exclusive popcount prefix of the collision bitmap (u16 each)
 constexpr int POOL_BLK = 64;      // pool entries a wave reserves at a time (>= 64: one trip always fits a fresh block)
 constexpr int CS_MAXPROBE = 64;   // linear-probe budget in the collision set
 constexpr unsigned OOB_SOFFSET = 0xFFFFF000u;   // buffer-load scalar offset beyond any m2 extent: every lane out of range
@@ -446,36 +447,34 @@ __device__ long long select_fast(u64 *U, int *hist4, int *sh, int k, bool exact)
         for (int j = 0; j < 2; ++j)
             if (has[j] && ((key[j] ^ prefix) & hmask) == 0u) atomicAdd(&h[(key[j] >> shift) & 255u], 1);
         __syncthreads();
-        // lane L owns bins 255-4L .. 252-4L (lanes ascend as digits descend)
-        const int4 c4 = *(const int4 *)&h[252 - 4 * lane];
-        const int c0 = c4.w, c1 = c4.z, c2 = c4.y, c3 = c4.x;
-        const int s = c0 + c1 + c2 + c3;
-        const int incl = wave_incl_scan_dpp(s);
-        const int excl = incl - s;
-        const bool mine = excl < need && need <= incl;
-        int d = 0, r = 0, cb = 0;
-        if (mine) {
-            const int b0 = 255 - 4 * lane;
-            r = need - excl;
-            if (r <= c0) { d = b0; cb = c0; }
-            else if (r <= c0 + c1) { d = b0 - 1; r -= c0; cb = c1; }
-            else if (r <= c0 + c1 + c2) { d = b0 - 2; r -= c0 + c1; cb = c2; }
-            else { d = b0 - 3; r -= c0 + c1 + c2; cb = c3; }
+        // ONE wave walks the histogram (the others would only repeat the same instructions) and publishes the digit
+        if (tid < 64) {
+            // lane L owns bins 255-4L .. 252-4L (lanes ascend as digits descend)
+            const int4 c4 = *(const int4 *)&h[252 - 4 * lane];
+            const int c0 = c4.w, c1 = c4.z, c2 = c4.y, c3 = c4.x;
+            const int s = c0 + c1 + c2 + c3;
+            const int incl = wave_incl_scan_dpp(s);
+            const int excl = incl - s;
+            if (excl < need && need <= incl) {         // exactly one lane
+                const int b0 = 255 - 4 * lane;
+                int r = need - excl, d, cb;
+                if (r <= c0) { d = b0; cb = c0; }
+                else if (r <= c0 + c1) { d = b0 - 1; r -= c0; cb = c1; }
+                else if (r <= c0 + c1 + c2) { d = b0 - 2; r -= c0 + c1; cb = c2; }
+                else { d = b0 - 3; r -= c0 + c1 + c2; cb = c3; }
+                // !exact: keeping the whole bin leaves (k - r) + cb entries: good enough after the second pass when that
+                // removes at least half of the surplus
+                const int kept = (k - r) + cb;
+                sh[SH_SEL] = d;
+                sh[SH_NEED] = r;
+                sh[SH_STOP] = (!exact && ps == 1 && 2 * (kept - k) <= (n - k)) ? 1 : 0;
+            }
         }
-        const int leader = (int)__builtin_ctzll(__ballot(mine));
-        d = __builtin_amdgcn_readlane(d, leader);
-        r = __builtin_amdgcn_readlane(r, leader);
-        cb = __builtin_amdgcn_readlane(cb, leader);
-        const int above = need - r;            // entries of this pass's population that lie above the chosen bin
-        prefix |= (unsigned)d << shift;
+        __syncthreads();
+        prefix |= (unsigned)sh[SH_SEL] << shift;
+        need = sh[SH_NEED];
         passes = ps + 1;
-        if (!exact && ps == 1) {
-            // keeping the whole bin leaves (k - r) + cb entries: good enough when that is at most half the surplus
-            const int kept = (k - r) + cb;
-            (void)above;
-            if (2 * (kept - k) <= (n - k)) { need = r; break; }
-        }
-        need = r;
+        if (sh[SH_STOP]) break;     // uniform
     }
     const bool all_passes = (passes == 4);
 #pragma unroll

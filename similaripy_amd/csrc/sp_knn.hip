@@ -81,7 +81,7 @@ static_assert(WS_PHASE_OFFSET + PH_N * 8 <= WS_YMIN_OFFSET && WS_YMIN_OFFSET + 1
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
 // LDS of the two kernels without the candidate buffer (see their carve-ups)
-size_t lds_fixed_sparse(int T) { return (size_t)T * 8 + (size_t)ITEM_CAP * 16 + 4096 + CBM_BYTES + 32 * 4 + 16 * 8; }   // (its candidate buffer lives inside region A)
+size_t lds_fixed_sparse(int T) { return (size_t)T * 8 + (size_t)ITEM_CAP * 16 + 4096 + CBM_BYTES + PRE_BYTES + 32 * 4 + 16 * 8; }   // (its candidate buffer lives inside region A)
 size_t lds_fixed_generic(int T, int NT) { return (size_t)T * 8 + (size_t)16 * NT + 256 + 256 * 4 + 64 * 4 + 32 * 4 + 16 * 8; }
 
 int make_config(const sp_knn_args *a, int n_cus, Config *c) {

@@ -36,13 +36,14 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
 
     // ---- LDS carve-up (single dynamic array) ----
     // cbm[CBM_BYTES]      collision bitmap (columns seen twice in sweep 1), alive through both sweeps; at offset 0 so
-    //                     that its reads need no base add
+    //                     that its reads need no base add;  pre16[]: its per-word popcount prefix (rank of a marked column)
     // region A [.., +T*8) sweep 1: column bitmap (nb bits, from the start);
     //                     afterwards: [0,A/4) collision set, [A/4,A/2) survivor pool, [A/2,3A/4) member pool, [3A/4,A) candidate buffer U
     // items[ITEM_CAP]     {m2 byte offset, count, m1 value bits, flat start};  hist4[4][256] radix histograms
     // sh[32], ph[16]      scalars, phase timers
     unsigned char *cbm = smem;
-    unsigned char *rA = smem + CBM_BYTES;
+    unsigned short *pre16 = (unsigned short *)(smem + CBM_BYTES);      // [CBM_BYTES/4] marked columns below each bitmap word
+    unsigned char *rA = smem + CBM_BYTES + PRE_BYTES;
     int4 *items = (int4 *)(rA + A_bytes);
     int *hist4 = (int *)(items + ITEM_CAP);
     int *sh = hist4 + 1024;
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
     const __amdgpu_buffer_rsrc_t rs_val = __builtin_amdgcn_make_buffer_rsrc((void *)p.m2_data, 0, (int)p.m2_bytes, 0x00020000);
 
     // collision bitmap + region A all zero, histograms zero
-    for (int i = tid; i < (CBM_BYTES + A_bytes) / 16; i += NT) ((int4 *)smem)[i] = make_int4(0, 0, 0, 0);
+    for (int i = tid; i < (CBM_BYTES + PRE_BYTES + A_bytes) / 16; i += NT) ((int4 *)smem)[i] = make_int4(0, 0, 0, 0);
     for (int i = tid; i < 1024; i += NT) hist4[i] = 0;
     if (MONO && !U_LDS) { for (int i = tid; i < cap / 2; i += NT) ((int4 *)U)[i] = make_int4(0, 0, 0, 0); }
     if (tid < 32) sh[tid] = 0;
@@ -295,7 +296,37 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             }
             // the bitmap has done its job: back to zero (16-byte stores); its storage now serves sweep 2
             for (int i = tid; i < (nb_bytes >> 4); i += NT) ((int4 *)rA)[i] = make_int4(0, 0, 0, 0);
-            __syncthreads();
+            // rank structure of the collision bitmap: pre16[w] = marked columns in the words below w.  The rank of a
+            // marked column is its slot in the collision set: no hashing, no probing (columns that alias to one bit
+            // share a rank and are told apart by their key; the loser probes an overflow area).
+            {
+                int carry = 0;
+                for (int base = 0; base < CBM_BYTES / 16; base += NT) {            // 4 words per thread and trip
+                    const int i = base + tid;
+                    const int4 w4 = (i < CBM_BYTES / 16) ? ((const int4 *)cbm)[i] : make_int4(0, 0, 0, 0);
+                    const int p0 = __popc((unsigned)w4.x), p1 = p0 + __popc((unsigned)w4.y), p2 = p1 + __popc((unsigned)w4.z);
+                    const int tot = p2 + __popc((unsigned)w4.w);
+                    const int incl = wave_incl_scan_dpp(tot);
+                    if (lane == 63) sh[SH_WSUM + wave] = incl;
+                    __syncthreads();
+                    int woff = carry, all = 0;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) {
+                        const int sw = sh[SH_WSUM + w];
+                        if (w < wave) woff += sw;
+                        all += sw;
+                    }
+                    const int ex = woff + incl - tot;
+                    if (i < CBM_BYTES / 16) {
+                        const u64 packed = (u64)(unsigned)(ex & 0xFFFF) | ((u64)(unsigned)((ex + p0) & 0xFFFF) << 16) |
+                                           ((u64)(unsigned)((ex + p1) & 0xFFFF) << 32) | ((u64)(unsigned)((ex + p2) & 0xFFFF) << 48);
+                        ((u64 *)pre16)[i] = packed;
+                    }
+                    carry += all;
+                    __syncthreads();
+                }
+                if (carry > CSN / 2) failed = true;      // more marked columns than direct slots (uniform)
+            }
             PHASE_END(PH_SEGMENTS);  // (bitmap clear)
         } else {
             if (dN.x >= 0 && tid < dN.w) {
@@ -432,32 +463,48 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 PHASE_END(PH_SWEEP2);
                 if (last_stage) {
                     // ---- products of marked columns: find-or-insert in the collision set.  {column+1 : sum} slots,
-                    // 0 = free; ONE 64-bit compare-and-swap claims a free slot with the product in it, a second one adds
-                    // to the sum of a slot the column already owns (ds_cmpst_rtn_b64 retires 10x the lanes of
-                    // ds_add_f32 on gfx950). ----
-                    for (int i = tid; i < mext; i += NT) {
-                        const u64 e = mpool[i];
-                        if (e != 0ull) {
-                            const unsigned key = (unsigned)(e >> 32);
-                            const float xx = __uint_as_float((unsigned)e);
-                            unsigned h = hash_bits((int)key, 2654435761u, cs_shift);
-                            int tries = 0;
-                            for (; tries < CS_MAXPROBE; ++tries) {
-                                u64 cur = atomicCAS(&cs[h], 0ull, e);
-                                if (cur == 0ull) break;                    // claimed, product deposited
-                                if ((unsigned)(cur >> 32) == key) {
-                                    for (;;) {
-                                        const u64 want = (cur & 0xFFFFFFFF00000000ull) | (u64)__float_as_uint(__uint_as_float((unsigned)cur) + xx);
-                                        const u64 got = atomicCAS(&cs[h], cur, want);
-                                        if (got == cur) break;
-                                        cur = got;
-                                    }
-                                    break;
-                                }
-                                h = (h + 1u) & (unsigned)(CSN - 1);
+                    // 0 = free; see below. ----
+                    // a slot taken by another column (bit aliasing): hashed start in the overflow half, then linear
+                    auto next_slot = [&](unsigned h, unsigned key) __attribute__((always_inline)) -> unsigned {
+                        const unsigned half = (unsigned)(CSN / 2);
+                        return (h < half) ? half + (hash_bits((int)key, 2654435761u, cs_shift + 1)) : half + ((h + 1u) & (half - 1u));
+                    };
+                    // Lock-step, two entries per thread: every round issues ONE 64-bit compare-and-swap per live entry
+                    // that claims a free slot with the product in it; a slot that already belongs to the column gets
+                    // the product through the hardware float add (slow on gfx950, 3 clk per lane, but a column with
+                    // many products — the row itself in m * m^T — would make a compare-and-swap add retry once per
+                    // product); another column's slot sends the entry to the next slot.
+                    for (int base = 0; base < mext; base += 2 * NT) {
+                        const int i0m = base + tid, i1m = base + NT + tid;
+                        const u64 e0 = (i0m < mext) ? mpool[i0m] : 0ull;
+                        const u64 e1 = (i1m < mext) ? mpool[i1m] : 0ull;
+                        if (e0 != 0ull) mpool[i0m] = 0ull;
+                        if (e1 != 0ull) mpool[i1m] = 0ull;
+                        const unsigned k0 = (unsigned)(e0 >> 32), k1 = (unsigned)(e1 >> 32);
+                        const float x0 = __uint_as_float((unsigned)e0), x1 = __uint_as_float((unsigned)e1);
+                        // direct slot = rank of the column's bit in the collision bitmap
+                        const unsigned c0m = k0 - 1u, c1m = k1 - 1u;
+                        const unsigned wi0 = (c0m >> 5) & (unsigned)(CBM_BYTES / 4 - 1), wi1 = (c1m >> 5) & (unsigned)(CBM_BYTES / 4 - 1);
+                        const unsigned bw0 = ((const unsigned *)cbm)[wi0], bw1 = ((const unsigned *)cbm)[wi1];
+                        unsigned h0 = (unsigned)pre16[wi0] + (unsigned)__popc(bw0 & ((1u << (c0m & 31u)) - 1u));
+                        unsigned h1 = (unsigned)pre16[wi1] + (unsigned)__popc(bw1 & ((1u << (c1m & 31u)) - 1u));
+                        bool a0 = (e0 != 0ull), a1 = (e1 != 0ull);
+                        int rounds = 0;
+                        while (__ballot(a0 | a1)) {
+                            u64 r0 = 0ull, r1 = 0ull;
+                            if (a0) r0 = atomicCAS(&cs[h0], 0ull, e0);
+                            if (a1) r1 = atomicCAS(&cs[h1], 0ull, e1);
+                            if (a0) {
+                                if (r0 == 0ull) a0 = false;                                                     // claimed, product deposited
+                                else if ((unsigned)(r0 >> 32) == k0) { atomicAdd((float *)&cs[h0], x0); a0 = false; }   // the column's slot: add
+                                else h0 = next_slot(h0, k0);                                                    // another column's slot
                             }
-                            if (tries == CS_MAXPROBE) sh[SH_OVF] = 1;
-                            mpool[i] = 0ull;
+                            if (a1) {
+                                if (r1 == 0ull) a1 = false;
+                                else if ((unsigned)(r1 >> 32) == k1) { atomicAdd((float *)&cs[h1], x1); a1 = false; }
+                                else h1 = next_slot(h1, k1);
+                            }
+                            if (++rounds > 4 * CS_MAXPROBE) { sh[SH_OVF] = 1; break; }     // set full
                         }
                     }
                     __syncthreads();
@@ -470,36 +517,57 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 // go straight into U.  Consumed entries are zeroed (and the set's collision-bitmap bits cleared). ----
                 const int n_ent = (MONO ? 0 : ext) + (last_stage ? CSN : 0);
                 for (;;) {
-                    for (int base = 0; base < n_ent; base += NT) {
-                        const int i = base + tid;
-                        u64 *src = (!MONO && i < ext) ? &spool[i] : &cs[i - (MONO ? 0 : ext)];
-                        const u64 e = (i < n_ent) ? *src : 0ull;
-                        const unsigned col = (unsigned)(e >> 32) - 1u;
-                        const float xv = __uint_as_float((unsigned)e);
-                        bool finished = true;
-                        if constexpr (MONO) {
-                            const bool want = (e != 0ull) && !(xv <= cutx);
-                            const u64 m = __ballot(want);
-                            if (m) {
-                                int wbase = 0;
-                                if (lane == 0) wbase = atomicAdd(&sh[SH_CNT], __popcll(m));
+                    if constexpr (MONO) {
+                        // four slots per thread in flight, one reservation in U per wave and trip
+                        for (int base = 0; base < n_ent; base += 4 * NT) {
+                            u64 e[4];
+                            bool want[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int i = base + j * NT + tid;
+                                e[j] = (i < n_ent) ? cs[i] : 0ull;
+                            }
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) want[j] = (e[j] != 0ull) && !(__uint_as_float((unsigned)e[j]) <= cutx);
+                            const u64 m0 = __ballot(want[0]), m1 = __ballot(want[1]), m2 = __ballot(want[2]), m3 = __ballot(want[3]);
+                            const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
+                            int wbase = 0;
+                            if ((m0 | m1) | (m2 | m3)) {
+                                if (lane == 0) wbase = atomicAdd(&sh[SH_CNT], n0 + n1 + n2 + n3);
                                 wbase = __builtin_amdgcn_readfirstlane(wbase);
-                                if (want) {
-                                    const int pos = wbase + mbcnt64(m);
-                                    if (pos < cap) U[pos] = ((u64)fkey(xv) << 32) | (u64)col;
-                                    else { sh[SH_RETRY] = 1; finished = false; }
+                            }
+                            const int off[4] = {0, n0, n0 + n1, n0 + n1 + n2};
+                            const u64 mm[4] = {m0, m1, m2, m3};
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                if (e[j] != 0ull) {
+                                    const unsigned col = (unsigned)(e[j] >> 32) - 1u;
+                                    bool finished = true;
+                                    if (want[j]) {
+                                        const int pos = wbase + off[j] + mbcnt64(mm[j]);
+                                        if (pos < cap) U[pos] = ((u64)fkey(__uint_as_float((unsigned)e[j])) << 32) | (u64)col;
+                                        else { sh[SH_RETRY] = 1; finished = false; }
+                                    }
+                                    if (finished) {
+                                        cs[base + j * NT + tid] = 0ull;
+                                        atomicAnd((unsigned *)(cbm + ((col >> 3) & cmask)), ~(1u << (col & 31u)));
+                                    }
                                 }
                             }
-                        } else {
-                            int c[1] = {(int)col};
-                            float xy[1] = {xv};
-                            const unsigned occ = (e != 0ull && !(xv <= rc.xy_cut)) ? 1u : 0u;
-                            const unsigned done = emit_candidates<1>(p, rc, c, xy, occ, U, sh, cap);
-                            finished = !occ || done;
                         }
-                        if (e != 0ull && finished) {
-                            *src = 0ull;
-                            if (MONO || i >= ext) atomicAnd((unsigned *)(cbm + ((col >> 3) & cmask)), ~(1u << (col & 31u)));
+                    } else {
+                        for (int base = 0; base < n_ent; base += NT) {
+                            const int i = base + tid;
+                            u64 *src = (i < ext) ? &spool[i] : &cs[i - ext];
+                            const u64 e = (i < n_ent) ? *src : 0ull;
+                            int c[1] = {(int)((unsigned)(e >> 32) - 1u)};
+                            float xy[1] = {__uint_as_float((unsigned)e)};
+                            const unsigned occ = (e != 0ull && !(xy[0] <= rc.xy_cut)) ? 1u : 0u;
+                            const unsigned done = emit_candidates<1>(p, rc, c, xy, occ, U, sh, cap);
+                            if (e != 0ull && (!occ || done)) {
+                                *src = 0ull;
+                                if (i >= ext) atomicAnd((unsigned *)(cbm + (((unsigned)c[0] >> 3) & cmask)), ~(1u << ((unsigned)c[0] & 31u)));
+                            }
                         }
                     }
                     __syncthreads();
@@ -618,7 +686,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 p.desc_g[2 * (size_t)g + 1] = wC;
                 sh[SH_OVF] = 0; sh[SH_RETRY] = 0; sh[SH_CNT2] = 0; sh[SH_EQ] = 0;
             }
-            for (int i = tid; i < (CBM_BYTES + A_bytes) / 16; i += NT) ((int4 *)smem)[i] = make_int4(0, 0, 0, 0);
+            for (int i = tid; i < (CBM_BYTES + PRE_BYTES + A_bytes) / 16; i += NT) ((int4 *)smem)[i] = make_int4(0, 0, 0, 0);
             for (int i = tid; i < 1024; i += NT) hist4[i] = 0;
             if (MONO && !U_LDS) { for (int i = tid; i < cap / 2; i += NT) ((int4 *)U)[i] = make_int4(0, 0, 0, 0); }
             if (timing) ph[CT_ROWS_FALLBACK] += 1;
