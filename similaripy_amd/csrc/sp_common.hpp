@@ -398,6 +398,138 @@ __device__ __forceinline__ bool pool_reserve(WavePool &wp, int tot, int *ctr, in
     return true;
 }
 
+// ---- hand-scheduled cores of the two sweeps (inline asm: the compiler's own code for these few lines carries two to
+// three times the instructions — address re-materialisation, bool <-> mask conversions, redundant masking) ----
+
+// Sweep 1, four columns per lane: OR each column's bit into the bitmap (LDS byte offset BM_OFF, `amask` = byte mask of
+// its words) and report whether it was there already.  `one[j]` = 1 for a real element, 0 for padding (ORs nothing).
+template <int BM_OFF, bool MASKED>
+__device__ __forceinline__ void s1_core(const unsigned (&c)[4], const unsigned (&one)[4], unsigned amask, unsigned (&seen)[4]) {
+    unsigned a0, a1, a2, a3, b0, b1, b2, b3;
+    if (!MASKED) {
+        asm volatile(
+            "v_lshrrev_b32 %[a0], 3, %[c0]\n\t"
+            "v_lshrrev_b32 %[a1], 3, %[c1]\n\t"
+            "v_lshrrev_b32 %[a2], 3, %[c2]\n\t"
+            "v_lshrrev_b32 %[a3], 3, %[c3]\n\t"
+            "v_lshlrev_b32_e64 %[b0], %[c0], 1\n\t"
+            "v_lshlrev_b32_e64 %[b1], %[c1], 1\n\t"
+            "v_lshlrev_b32_e64 %[b2], %[c2], 1\n\t"
+            "v_lshlrev_b32_e64 %[b3], %[c3], 1\n\t"
+            "v_and_b32 %[a0], %[am], %[a0]\n\t"
+            "v_and_b32 %[a1], %[am], %[a1]\n\t"
+            "v_and_b32 %[a2], %[am], %[a2]\n\t"
+            "v_and_b32 %[a3], %[am], %[a3]\n\t"
+            "ds_or_rtn_b32 %[b0], %[a0], %[b0] offset:%[off]\n\t"
+            "ds_or_rtn_b32 %[b1], %[a1], %[b1] offset:%[off]\n\t"
+            "ds_or_rtn_b32 %[b2], %[a2], %[b2] offset:%[off]\n\t"
+            "ds_or_rtn_b32 %[b3], %[a3], %[b3] offset:%[off]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_bfe_u32 %[b0], %[b0], %[c0], 1\n\t"
+            "v_bfe_u32 %[b1], %[b1], %[c1], 1\n\t"
+            "v_bfe_u32 %[b2], %[b2], %[c2], 1\n\t"
+            "v_bfe_u32 %[b3], %[b3], %[c3], 1\n\t"
+            : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [b0] "=&v"(b0), [b1] "=&v"(b1), [b2] "=&v"(b2), [b3] "=&v"(b3)
+            : [c0] "v"(c[0]), [c1] "v"(c[1]), [c2] "v"(c[2]), [c3] "v"(c[3]), [am] "s"(amask), [off] "i"(BM_OFF)
+            : "memory");
+    } else {
+        asm volatile(
+            "v_lshrrev_b32 %[a0], 3, %[c0]\n\t"
+            "v_lshrrev_b32 %[a1], 3, %[c1]\n\t"
+            "v_lshrrev_b32 %[a2], 3, %[c2]\n\t"
+            "v_lshrrev_b32 %[a3], 3, %[c3]\n\t"
+            "v_lshlrev_b32 %[b0], %[c0], %[o0]\n\t"
+            "v_lshlrev_b32 %[b1], %[c1], %[o1]\n\t"
+            "v_lshlrev_b32 %[b2], %[c2], %[o2]\n\t"
+            "v_lshlrev_b32 %[b3], %[c3], %[o3]\n\t"
+            "v_and_b32 %[a0], %[am], %[a0]\n\t"
+            "v_and_b32 %[a1], %[am], %[a1]\n\t"
+            "v_and_b32 %[a2], %[am], %[a2]\n\t"
+            "v_and_b32 %[a3], %[am], %[a3]\n\t"
+            "ds_or_rtn_b32 %[b0], %[a0], %[b0] offset:%[off]\n\t"
+            "ds_or_rtn_b32 %[b1], %[a1], %[b1] offset:%[off]\n\t"
+            "ds_or_rtn_b32 %[b2], %[a2], %[b2] offset:%[off]\n\t"
+            "ds_or_rtn_b32 %[b3], %[a3], %[b3] offset:%[off]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_bfe_u32 %[b0], %[b0], %[c0], 1\n\t"
+            "v_bfe_u32 %[b1], %[b1], %[c1], 1\n\t"
+            "v_bfe_u32 %[b2], %[b2], %[c2], 1\n\t"
+            "v_bfe_u32 %[b3], %[b3], %[c3], 1\n\t"
+            "v_and_b32 %[b0], %[b0], %[o0]\n\t"
+            "v_and_b32 %[b1], %[b1], %[o1]\n\t"
+            "v_and_b32 %[b2], %[b2], %[o2]\n\t"
+            "v_and_b32 %[b3], %[b3], %[o3]\n\t"
+            : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [b0] "=&v"(b0), [b1] "=&v"(b1), [b2] "=&v"(b2), [b3] "=&v"(b3)
+            : [c0] "v"(c[0]), [c1] "v"(c[1]), [c2] "v"(c[2]), [c3] "v"(c[3]), [o0] "v"(one[0]), [o1] "v"(one[1]), [o2] "v"(one[2]), [o3] "v"(one[3]),
+              [am] "s"(amask), [off] "i"(BM_OFF)
+            : "memory");
+    }
+    seen[0] = b0; seen[1] = b1; seen[2] = b2; seen[3] = b3;
+}
+
+// Sweep 2, four products per lane: x = value * segv, M[j] = lanes whose column is marked in the collision bitmap
+// (LDS offset 0, CBM_BYTES long), L[j] = lanes with !(x <= cut)  (NaN counts as above the cutoff).
+__device__ __forceinline__ void s2_core(const unsigned (&c)[4], const float (&v)[4], float segv, float cut, float (&x)[4], u64 (&M)[4], u64 (&L)[4]) {
+    unsigned a0, a1, a2, a3;
+    static_assert(CBM_BYTES == 8192, "the literal below is CBM_BYTES - 4");
+    asm volatile(
+        "v_lshrrev_b32 %[a0], 3, %[c0]\n\t"
+        "v_lshrrev_b32 %[a1], 3, %[c1]\n\t"
+        "v_lshrrev_b32 %[a2], 3, %[c2]\n\t"
+        "v_lshrrev_b32 %[a3], 3, %[c3]\n\t"
+        "v_and_b32 %[a0], 0x1ffc, %[a0]\n\t"
+        "v_and_b32 %[a1], 0x1ffc, %[a1]\n\t"
+        "v_and_b32 %[a2], 0x1ffc, %[a2]\n\t"
+        "v_and_b32 %[a3], 0x1ffc, %[a3]\n\t"
+        "ds_read_b32 %[a0], %[a0]\n\t"
+        "ds_read_b32 %[a1], %[a1]\n\t"
+        "ds_read_b32 %[a2], %[a2]\n\t"
+        "ds_read_b32 %[a3], %[a3]\n\t"
+        "v_mul_f32 %[x0], %[sv], %[v0]\n\t"
+        "v_mul_f32 %[x1], %[sv], %[v1]\n\t"
+        "v_mul_f32 %[x2], %[sv], %[v2]\n\t"
+        "v_mul_f32 %[x3], %[sv], %[v3]\n\t"
+        "v_cmp_nle_f32_e64 %[L0], %[x0], %[cut]\n\t"
+        "v_cmp_nle_f32_e64 %[L1], %[x1], %[cut]\n\t"
+        "v_cmp_nle_f32_e64 %[L2], %[x2], %[cut]\n\t"
+        "v_cmp_nle_f32_e64 %[L3], %[x3], %[cut]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_bfe_u32 %[a0], %[a0], %[c0], 1\n\t"
+        "v_bfe_u32 %[a1], %[a1], %[c1], 1\n\t"
+        "v_bfe_u32 %[a2], %[a2], %[c2], 1\n\t"
+        "v_bfe_u32 %[a3], %[a3], %[c3], 1\n\t"
+        "v_cmp_ne_u32_e64 %[M0], 0, %[a0]\n\t"
+        "v_cmp_ne_u32_e64 %[M1], 0, %[a1]\n\t"
+        "v_cmp_ne_u32_e64 %[M2], 0, %[a2]\n\t"
+        "v_cmp_ne_u32_e64 %[M3], 0, %[a3]\n\t"
+        : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3),
+          [x0] "=&v"(x[0]), [x1] "=&v"(x[1]), [x2] "=&v"(x[2]), [x3] "=&v"(x[3]),
+          [M0] "=&s"(M[0]), [M1] "=&s"(M[1]), [M2] "=&s"(M[2]), [M3] "=&s"(M[3]),
+          [L0] "=&s"(L[0]), [L1] "=&s"(L[1]), [L2] "=&s"(L[2]), [L3] "=&s"(L[3])
+        : [c0] "v"(c[0]), [c1] "v"(c[1]), [c2] "v"(c[2]), [c3] "v"(c[3]),
+          [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]), [sv] "s"(segv), [cut] "s"(cut)
+        : "memory");
+}
+
+// Append the 8-byte entries {lo, hi} of the lanes in `m` to an LDS list at byte offset `base_off` (wave-uniform),
+// starting at entry `pos` (wave-uniform): lane rank by v_mbcnt, exec narrowed to `m` around the two stores.
+__device__ __forceinline__ void lds_push64(u64 m, unsigned lo, unsigned hi, int pos, unsigned base_off) {
+    unsigned t;
+    u64 sv;
+    asm volatile(
+        "v_mbcnt_lo_u32_b32 %[t], %[mlo], 0\n\t"
+        "v_mbcnt_hi_u32_b32 %[t], %[mhi], %[t]\n\t"
+        "v_add_u32 %[t], %[pos], %[t]\n\t"
+        "v_lshl_add_u32 %[t], %[t], 3, %[base]\n\t"
+        "s_and_saveexec_b64 %[sv], %[m]\n\t"
+        "ds_write_b32 %[t], %[lo]\n\t"
+        "ds_write_b32 %[t], %[hi] offset:4\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        : [t] "=&v"(t), [sv] "=&s"(sv)
+        : [mlo] "s"((unsigned)m), [mhi] "s"((unsigned)(m >> 32)), [m] "s"(m), [pos] "s"(pos), [base] "s"(base_off), [lo] "v"(lo), [hi] "v"(hi)
+        : "memory");
+}
+
 // inclusive wave64 scan on the DPP crossbar (row_shr 1/2/4/8, row_bcast 15/31): no LDS round trips
 __device__ __forceinline__ int wave_incl_scan_dpp(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);

@@ -61,6 +61,11 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
     const int spcap = A_bytes / 32;
     u64 *mpool = (u64 *)(rA + A_bytes / 2);      // products of marked columns, all stages
     const int mpcap = A_bytes / 32;
+    // LDS byte addresses for the hand-written cores (they assume the dynamic LDS segment starts at address 0)
+    const unsigned mpool_off = (unsigned)(CBM_BYTES + PRE_BYTES + A_bytes / 2);
+    const unsigned spool_off = (unsigned)(CBM_BYTES + PRE_BYTES + A_bytes / 4);
+    const unsigned u_off = (unsigned)(CBM_BYTES + PRE_BYTES + (A_bytes / 4) * 3);
+    if ((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();
     const __amdgpu_buffer_rsrc_t rs_idx = __builtin_amdgcn_make_buffer_rsrc((void *)p.m2_indices, 0, (int)p.m2_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_val = __builtin_amdgcn_make_buffer_rsrc((void *)p.m2_data, 0, (int)p.m2_bytes, 0x00020000);
 
@@ -247,20 +252,12 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     if (cnt == 0) return;                  // sentinel (wave-uniform)
                     unsigned seen[4];
                     if (cnt == ITEM) {
-                        unsigned old[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) old[j] = atomicOr((unsigned *)(rA + ((c[j] >> 3) & amask)), 1u << (c[j] & 31u));
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) seen[j] = (old[j] >> (c[j] & 31u)) & 1u;
+                        s1_core<CBM_BYTES + PRE_BYTES, false>(c, c, amask, seen);
                     } else {
-                        unsigned old[4], ok[4];
+                        unsigned one[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            ok[j] = (4 * lane + j < cnt) ? 1u : 0u;                         // padding ORs nothing
-                            old[j] = atomicOr((unsigned *)(rA + ((c[j] >> 3) & amask)), ok[j] << (c[j] & 31u));
-                        }
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) seen[j] = (old[j] >> (c[j] & 31u)) & ok[j];
+                        for (int j = 0; j < 4; ++j) one[j] = (4 * lane + j < cnt) ? 1u : 0u;      // padding ORs nothing
+                        s1_core<CBM_BYTES + PRE_BYTES, true>(c, one, amask, seen);
                     }
                     // ~2 % of the products find their column already there: mark it in the collision bitmap
                     if (__ballot((seen[0] | seen[1] | seen[2] | seen[3]) != 0u)) {
@@ -368,71 +365,61 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     const float cut = MONO ? cutx : rc.xy_cut;
                     auto body = [&](const unsigned (&c)[4], const float (&v)[4], int cnt, float segv) __attribute__((always_inline)) {
                         if (cnt == 0) return;                  // sentinel (wave-uniform)
-                        unsigned w[4];
-                        float x[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            x[j] = v[j] * segv;
-                            w[j] = *(const unsigned *)(cbm + ((c[j] >> 3) & cmask));
-                        }
-                        // mem: product of a marked column; otherwise the product is the only one of its column and
+                        // M: product of a marked column; S: otherwise the product is the only one of its column and
                         // matters only if its raw dot can still enter the top-k (NaN stays: the exact judge drops it)
-                        bool mem[4], sur[4];
-                        if (cnt == ITEM) {
+                        float x[4];
+                        u64 M[4], S[4];
+                        s2_core(c, v, segv, cut, x, M, S);
+                        if (cnt != ITEM) {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
-                                mem[j] = ((w[j] >> (c[j] & 31u)) & 1u) != 0u;
-                                sur[j] = !mem[j] & !(x[j] <= cut);
-                            }
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const bool ok = 4 * lane + j < cnt;
-                                mem[j] = ok & (((w[j] >> (c[j] & 31u)) & 1u) != 0u);
-                                sur[j] = ok & !mem[j] & !(x[j] <= cut);
+                                const u64 ok = __ballot(4 * lane + j < cnt);
+                                M[j] &= ok;
+                                S[j] &= ok;
                             }
                         }
-                        const u64 M0 = __ballot(mem[0]), M1 = __ballot(mem[1]), M2 = __ballot(mem[2]), M3 = __ballot(mem[3]);
-                        if ((M0 | M1) | (M2 | M3)) {
-                            const int n0 = __popcll(M0), n1 = __popcll(M1), n2 = __popcll(M2), n3 = __popcll(M3);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) S[j] &= ~M[j];
+                        if ((M[0] | M[1]) | (M[2] | M[3])) {
+                            const int n0 = __popcll(M[0]), n1 = __popcll(M[1]), n2 = __popcll(M[2]), n3 = __popcll(M[3]);
                             if (pool_reserve(wpm, n0 + n1 + n2 + n3, &sh[SH_MCTR], mpcap, &sh[SH_OVF])) {
                                 int pos = wpm.pos;
-                                if (mem[0]) mpool[pos + mbcnt64(M0)] = ((u64)(c[0] + 1u) << 32) | (u64)__float_as_uint(x[0]);
-                                pos += n0;
-                                if (mem[1]) mpool[pos + mbcnt64(M1)] = ((u64)(c[1] + 1u) << 32) | (u64)__float_as_uint(x[1]);
-                                pos += n1;
-                                if (mem[2]) mpool[pos + mbcnt64(M2)] = ((u64)(c[2] + 1u) << 32) | (u64)__float_as_uint(x[2]);
-                                pos += n2;
-                                if (mem[3]) mpool[pos + mbcnt64(M3)] = ((u64)(c[3] + 1u) << 32) | (u64)__float_as_uint(x[3]);
+                                lds_push64(M[0], __float_as_uint(x[0]), c[0] + 1u, pos, mpool_off); pos += n0;
+                                lds_push64(M[1], __float_as_uint(x[1]), c[1] + 1u, pos, mpool_off); pos += n1;
+                                lds_push64(M[2], __float_as_uint(x[2]), c[2] + 1u, pos, mpool_off); pos += n2;
+                                lds_push64(M[3], __float_as_uint(x[3]), c[3] + 1u, pos, mpool_off);
                                 wpm.pos = pos + n3;
                             }
                         }
-                        const u64 S0 = __ballot(sur[0]), S1 = __ballot(sur[1]), S2 = __ballot(sur[2]), S3 = __ballot(sur[3]);
-                        if ((S0 | S1) | (S2 | S3)) {
-                            const int n0 = __popcll(S0), n1 = __popcll(S1), n2 = __popcll(S2), n3 = __popcll(S3);
+                        if ((S[0] | S[1]) | (S[2] | S[3])) {
+                            const int n0 = __popcll(S[0]), n1 = __popcll(S[1]), n2 = __popcll(S[2]), n3 = __popcll(S[3]);
                             if constexpr (MONO) {
                                 // straight into the candidate buffer, keyed by the raw dot
                                 if (pool_reserve(wps, n0 + n1 + n2 + n3, &sh[SH_CNT], cap, &sh[SH_OVF])) {
                                     int pos = wps.pos;
-                                    if (sur[0]) U[pos + mbcnt64(S0)] = ((u64)fkey(x[0]) << 32) | (u64)c[0];
-                                    pos += n0;
-                                    if (sur[1]) U[pos + mbcnt64(S1)] = ((u64)fkey(x[1]) << 32) | (u64)c[1];
-                                    pos += n1;
-                                    if (sur[2]) U[pos + mbcnt64(S2)] = ((u64)fkey(x[2]) << 32) | (u64)c[2];
-                                    pos += n2;
-                                    if (sur[3]) U[pos + mbcnt64(S3)] = ((u64)fkey(x[3]) << 32) | (u64)c[3];
+                                    if constexpr (U_LDS) {
+                                        lds_push64(S[0], c[0], fkey(x[0]), pos, u_off); pos += n0;
+                                        lds_push64(S[1], c[1], fkey(x[1]), pos, u_off); pos += n1;
+                                        lds_push64(S[2], c[2], fkey(x[2]), pos, u_off); pos += n2;
+                                        lds_push64(S[3], c[3], fkey(x[3]), pos, u_off);
+                                    } else {
+                                        if ((S[0] >> lane) & 1ull) U[pos + mbcnt64(S[0])] = ((u64)fkey(x[0]) << 32) | (u64)c[0];
+                                        pos += n0;
+                                        if ((S[1] >> lane) & 1ull) U[pos + mbcnt64(S[1])] = ((u64)fkey(x[1]) << 32) | (u64)c[1];
+                                        pos += n1;
+                                        if ((S[2] >> lane) & 1ull) U[pos + mbcnt64(S[2])] = ((u64)fkey(x[2]) << 32) | (u64)c[2];
+                                        pos += n2;
+                                        if ((S[3] >> lane) & 1ull) U[pos + mbcnt64(S[3])] = ((u64)fkey(x[3]) << 32) | (u64)c[3];
+                                    }
                                     wps.pos = pos + n3;
                                 }
                             } else {
                                 if (pool_reserve(wps, n0 + n1 + n2 + n3, &sh[SH_PCTR], spcap, &sh[SH_OVF])) {
                                     int pos = wps.pos;
-                                    if (sur[0]) spool[pos + mbcnt64(S0)] = ((u64)(c[0] + 1u) << 32) | (u64)__float_as_uint(x[0]);
-                                    pos += n0;
-                                    if (sur[1]) spool[pos + mbcnt64(S1)] = ((u64)(c[1] + 1u) << 32) | (u64)__float_as_uint(x[1]);
-                                    pos += n1;
-                                    if (sur[2]) spool[pos + mbcnt64(S2)] = ((u64)(c[2] + 1u) << 32) | (u64)__float_as_uint(x[2]);
-                                    pos += n2;
-                                    if (sur[3]) spool[pos + mbcnt64(S3)] = ((u64)(c[3] + 1u) << 32) | (u64)__float_as_uint(x[3]);
+                                    lds_push64(S[0], __float_as_uint(x[0]), c[0] + 1u, pos, spool_off); pos += n0;
+                                    lds_push64(S[1], __float_as_uint(x[1]), c[1] + 1u, pos, spool_off); pos += n1;
+                                    lds_push64(S[2], __float_as_uint(x[2]), c[2] + 1u, pos, spool_off); pos += n2;
+                                    lds_push64(S[3], __float_as_uint(x[3]), c[3] + 1u, pos, spool_off);
                                     wps.pos = pos + n3;
                                 }
                             }
