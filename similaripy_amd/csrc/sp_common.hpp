@@ -541,6 +541,17 @@ __device__ __forceinline__ int wave_incl_scan_dpp(int v) {
     return v;
 }
 
+// wave64 maximum of an unsigned value on the DPP crossbar; the result is wave-uniform
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false));    // row_shr:1
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false));    // row_shr:2
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false));    // row_shr:4
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false));    // row_shr:8
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false));    // row_bcast:15
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false));    // row_bcast:31
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // Selection for candidate buffers of at most 2*NT entries: every thread keeps its (<= 2) entries in registers,
 // one LDS histogram per radix pass (hist4 = 4 x 256 counters, zero on entry and on exit), every wave scans the
 // histogram redundantly (no broadcast barrier), 1 barrier per pass.

@@ -150,41 +150,78 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         int nx_r0 = 0, nx_len = 0;
 
         if (tid == 0) { sh[SH_PCTR] = 0; sh[SH_MCTR] = 0; sh[SH_NITEMS] = 0; sh[SH_CNT] = 0; }
-        // Segments are visited in descending |m1 value| order: each segment scales its m2 row by its own m1 value,
-        // so the heavy segments first make the running k-th value rise early and the survivor rate fall
-        // monotonically.  First item and flat start of every segment come from one all-pairs pass spread over the
-        // whole workgroup (n1 <= 256): thread (seg, part) adds up the segments that precede `seg`.
-        int *keyS = (int *)items, *lenS = keyS + SORT_MAX, *ibS = lenS + SORT_MAX, *fsS = ibS + SORT_MAX;
-        if (tid < SORT_MAX) { ibS[tid] = 0; fsS[tid] = 0; }
-        if (tid < n1) { keyS[tid] = (int)(__float_as_uint(my_v) & 0x7FFFFFFFu); lenS[tid] = my_len; }
-        __syncthreads();
+        // Segment order.  The heaviest segments (largest |m1 value|: each segment scales its m2 row by its own m1 value)
+        // go first, so that the first stage of sweep 2 sees the large products and the running k-th value — the cutoff
+        // of everything after — starts high.
+        int my_ib = 0, my_fs = 0;       // first item / flat start of segment `tid`
+        int n_items = 0;
         int4 dNN, wNN;
-        if (!p.static_sched) q_nn = sh[SH_QA];
-        load_desc(q_nn, dNN, wNN);
-        if (p.static_sched) q_nn += (int)gridDim.x;
-        {
-            const int lg = (n1 <= 64) ? 6 : (n1 <= 128) ? 7 : 8;       // segments padded to a power of two >= 64
-            const int seg = tid & ((1 << lg) - 1), part = tid >> lg, parts = NT >> lg;
-            if (seg < n1) {
-                const int key = keyS[seg];
-                int ib = 0, fs = 0;
-                for (int j = part; j < n1; j += parts) {
-                    const int kj = keyS[j], lj = lenS[j];     // same address across the wave: broadcast reads
-                    const bool before = (kj > key) || (kj == key && j < seg);
-                    ib += before ? (lj + ITEM - 1) / ITEM : 0;
-                    fs += before ? lj : 0;
+        if (n1 <= 64) {
+            // One wave, one segment per lane, no barrier inside: the (up to) 8 largest |values| are found with 8 wave-max
+            // rounds; heavy segments first, the others behind, both in their original order (ballot + mbcnt); item and
+            // flat-start prefixes by one trip through LDS into position order and a DPP scan there.
+            if (tid < 64) {
+                const unsigned key = (tid < n1 && my_len > 0) ? ((__float_as_uint(my_v) & 0x7FFFFFFFu) | 1u) : 0u;   // 0 = no segment
+                unsigned rest = key, thr = 0u;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const unsigned mx = wave_max_u32(rest);
+                    if (mx != 0u) thr = mx;                    // uniform
+                    rest = (rest >= mx) ? 0u : rest;
                 }
-                if (ib) atomicAdd(&ibS[seg], ib);
-                if (fs) atomicAdd(&fsS[seg], fs);
+                const bool heavy = key != 0u && key >= thr;
+                const u64 H = __ballot(heavy), Lg = __ballot(key != 0u && !heavy);
+                const int pos = heavy ? mbcnt64(H) : __popcll(H) + mbcnt64(Lg);
+                const int nit = (my_len + ITEM - 1) / ITEM;
+                int *scr = (int *)items;                       // scratch (the items are written after it is read back)
+                scr[tid] = 0; scr[64 + tid] = 0;
+                if (key != 0u) { scr[pos] = nit; scr[64 + pos] = my_len; }
+                const int nit_p = scr[tid], len_p = scr[64 + tid];          // same wave: LDS accesses are in order
+                const int ib_incl = wave_incl_scan_dpp(nit_p), fs_incl = wave_incl_scan_dpp(len_p);
+                scr[128 + tid] = ib_incl - nit_p;
+                scr[192 + tid] = fs_incl - len_p;
+                if (key != 0u) { my_ib = scr[128 + pos]; my_fs = scr[192 + pos]; }
+                if (tid == 63) sh[SH_NITEMS] = ib_incl;
             }
-            if (tid < n1 && my_len > 0) atomicAdd(&sh[SH_NITEMS], (my_len + ITEM - 1) / ITEM);
+            __syncthreads();
+            if (!p.static_sched) q_nn = sh[SH_QA];
+            load_desc(q_nn, dNN, wNN);
+            if (p.static_sched) q_nn += (int)gridDim.x;
+            n_items = sh[SH_NITEMS];
+            __syncthreads();                    // scratch read before the items overwrite it
+        } else {
+            // up to SORT_MAX entries: full descending order from one all-pairs pass spread over the whole workgroup:
+            // thread (seg, part) adds up the segments that precede `seg`
+            int *keyS = (int *)items, *lenS = keyS + SORT_MAX, *ibS = lenS + SORT_MAX, *fsS = ibS + SORT_MAX;
+            if (tid < SORT_MAX) { ibS[tid] = 0; fsS[tid] = 0; }
+            if (tid < n1) { keyS[tid] = (int)(__float_as_uint(my_v) & 0x7FFFFFFFu); lenS[tid] = my_len; }
+            __syncthreads();
+            if (!p.static_sched) q_nn = sh[SH_QA];
+            load_desc(q_nn, dNN, wNN);
+            if (p.static_sched) q_nn += (int)gridDim.x;
+            {
+                const int lg = (n1 <= 128) ? 7 : 8;       // segments padded to a power of two
+                const int seg = tid & ((1 << lg) - 1), part = tid >> lg, parts = NT >> lg;
+                if (seg < n1) {
+                    const int key = keyS[seg];
+                    int ib = 0, fs = 0;
+                    for (int j = part; j < n1; j += parts) {
+                        const int kj = keyS[j], lj = lenS[j];     // same address across the wave: broadcast reads
+                        const bool before = (kj > key) || (kj == key && j < seg);
+                        ib += before ? (lj + ITEM - 1) / ITEM : 0;
+                        fs += before ? lj : 0;
+                    }
+                    if (ib) atomicAdd(&ibS[seg], ib);
+                    if (fs) atomicAdd(&fsS[seg], fs);
+                }
+                if (tid < n1 && my_len > 0) atomicAdd(&sh[SH_NITEMS], (my_len + ITEM - 1) / ITEM);
+            }
+            __syncthreads();
+            if (tid < n1) { my_ib = ibS[tid]; my_fs = fsS[tid]; }
+            n_items = sh[SH_NITEMS];
+            __syncthreads();                    // scratch read before the items overwrite it
         }
-        __syncthreads();
-        int my_ib = 0, my_fs = 0;
-        if (tid < n1) { my_ib = ibS[tid]; my_fs = fsS[tid]; }
-        const int n_items = sh[SH_NITEMS];
-        __syncthreads();                    // scratch read before the items overwrite it
-        bool failed = (n_items >= ITEM_CAP);
+        bool failed = (n_items >= ITEM_CAP) || (n_items > 63 * NW);      // (a wave keeps its <= 63 item descriptors in one register)
         PHASE_END(PH_SETUP);
 
         RowCtx rc;
@@ -241,10 +278,13 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 // of the buffer resource is per dword (scripts/buffer_oob_probe.hip), so an item at the very end of
                 // the array is safe, and a prefetch past the last item reads the sentinel: an all-out-of-range load
                 // (no memory traffic) instead of a branch, so the loads in flight are countable (s_waitcnt vmcnt(N)).
-                auto ld = [&](int it, unsigned (&c)[4], int &cnt) __attribute__((always_inline)) {
-                    const int4 d = items[min(it, n_items)];
-                    const int off = __builtin_amdgcn_readfirstlane(d.x);
-                    cnt = __builtin_amdgcn_readfirstlane(d.y);
+                // The wave's item descriptors are read ONCE, item wave + NW*i into lane i (beyond the end: the sentinel);
+                // a trip then gets its scalars with v_readlane instead of an LDS round trip.
+                const int4 myd = items[min(wave + NW * lane, n_items)];
+                auto ld = [&](int trip, unsigned (&c)[4], int &cnt) __attribute__((always_inline)) {
+                    const int tl = min(trip, 63);
+                    const int off = __builtin_amdgcn_readlane(myd.x, tl);
+                    cnt = __builtin_amdgcn_readlane(myd.y, tl);
                     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, lane * 16, off, 0);
                     c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
                 };
@@ -268,20 +308,21 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 };
                 unsigned cA[4], cB[4], cC[4];
                 int nA = 0, nB = 0, nC = 0;
-                int it = wave;
-                ld(it, cA, nA);
-                ld(it + NW, cB, nB);
-                while (it < n_items) {      // three items in flight per wave; bodies skip the sentinel
-                    ld(it + 2 * NW, cC, nC);
+                const int n_trips = (n_items - wave + NW - 1) / NW;      // items wave, wave+NW, ...
+                int trip = 0;
+                ld(0, cA, nA);
+                ld(1, cB, nB);
+                while (trip < n_trips) {      // three items in flight per wave; bodies skip the sentinel
+                    ld(trip + 2, cC, nC);
                     __builtin_amdgcn_sched_barrier(0);     // the prefetch is issued before the oldest item is waited for
                     body(cA, nA);
-                    ld(it + 3 * NW, cA, nA);
+                    ld(trip + 3, cA, nA);
                     __builtin_amdgcn_sched_barrier(0);
                     body(cB, nB);
-                    ld(it + 4 * NW, cB, nB);
+                    ld(trip + 4, cB, nB);
                     __builtin_amdgcn_sched_barrier(0);
                     body(cC, nC);
-                    it += 3 * NW;
+                    trip += 3;
                 }
             }
             __syncthreads();
@@ -352,11 +393,17 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 {
                     // ---- sweep 2 over items [i0, i1) ----
                     WavePool wps{0, -1};
-                    auto ld = [&](int it, unsigned (&c)[4], float (&v)[4], int &cnt, float &segv) __attribute__((always_inline)) {
-                        const int4 d = items[(it < i1) ? it : n_items];     // beyond this chunk: the sentinel item
-                        const int off = __builtin_amdgcn_readfirstlane(d.x);
-                        cnt = __builtin_amdgcn_readfirstlane(d.y);
-                        segv = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane(d.z));
+                    // item i0 + wave + NW*i of this stage in lane i (beyond the stage: the sentinel)
+                    int4 myd;
+                    {
+                        const int mine = i0 + wave + NW * lane;
+                        myd = items[(mine < i1) ? mine : n_items];
+                    }
+                    auto ld = [&](int trip, unsigned (&c)[4], float (&v)[4], int &cnt, float &segv) __attribute__((always_inline)) {
+                        const int tl = min(trip, 63);
+                        const int off = __builtin_amdgcn_readlane(myd.x, tl);
+                        cnt = __builtin_amdgcn_readlane(myd.y, tl);
+                        segv = __uint_as_float((unsigned)__builtin_amdgcn_readlane(myd.z, tl));
                         const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, lane * 16, off, 0);
                         const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs_val, lane * 16, off, 0);
                         c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w;
@@ -429,16 +476,17 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     float vA[4], vB[4];
                     int nA = 0, nB = 0;
                     float sA = 0.f, sB = 0.f;
-                    int it = i0 + wave;
-                    ld(it, cA, vA, nA, sA);
-                    while (it < i1) {      // two items (4 KiB) in flight per wave; bodies skip the sentinel
-                        ld(it + NW, cB, vB, nB, sB);
+                    const int n_trips = (i1 - i0 - wave + NW - 1) / NW;
+                    int trip = 0;
+                    ld(0, cA, vA, nA, sA);
+                    while (trip < n_trips) {      // two items (4 KiB) in flight per wave; bodies skip the sentinel
+                        ld(trip + 1, cB, vB, nB, sB);
                         __builtin_amdgcn_sched_barrier(0);     // the prefetch is issued before the current item is waited for
                         body(cA, vA, nA, sA);
-                        ld(it + 2 * NW, cA, vA, nA, sA);
+                        ld(trip + 2, cA, vA, nA, sA);
                         __builtin_amdgcn_sched_barrier(0);
                         body(cB, vB, nB, sB);
-                        it += 2 * NW;
+                        trip += 2;
                     }
                 }
                 i0 = i1;
