@@ -369,6 +369,7 @@ constexpr int PRE_BYTES = 4096;   // per-word exclusive popcount prefix of the c
 constexpr int POOL_BLK = 64;      // pool entries a wave reserves at a time (>= 64: one trip always fits a fresh block)
 constexpr int CS_MAXPROBE = 64;   // linear-probe budget in the collision set
 constexpr unsigned OOB_SOFFSET = 0xFFFFF000u;   // buffer-load scalar offset beyond any m2 extent: every lane out of range
+constexpr int SEL_E = 4;          // candidate-buffer entries per thread the register-resident selection handles
 constexpr int SORT_MAX = 256;     // m1 rows up to this many entries are visited in descending |value| order
 
 __device__ __forceinline__ int mbcnt64(u64 m) {
@@ -383,9 +384,10 @@ struct WavePool { int pos, end; };
 // Make room for `tot` (<= 256) more entries in the wave's window: nothing to do while the current block lasts, else
 // ONE returning atomic reserves a fresh block (a multiple of POOL_BLK entries).  Returns false when the pool is
 // exhausted (flag raised: the row is redone on the generic path).  Wave-uniform.
+template <int BLK = POOL_BLK>
 __device__ __forceinline__ bool pool_reserve(WavePool &wp, int tot, int *ctr, int cap, int *ovf) {
     if (wp.pos + tot <= wp.end) return true;
-    const int blk = (tot + POOL_BLK - 1) & ~(POOL_BLK - 1);
+    const int blk = (tot + BLK - 1) & ~(BLK - 1);
     int base = 0;
     if ((threadIdx.x & 63) == 0) base = atomicAdd(ctr, blk);
     base = __builtin_amdgcn_readfirstlane(base);
@@ -552,7 +554,7 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-// Selection for candidate buffers of at most 2*NT entries: every thread keeps its (<= 2) entries in registers,
+// Selection for candidate buffers of at most E*NT entries: every thread keeps its (<= E) entries in registers,
 // one LDS histogram per radix pass (hist4 = 4 x 256 counters, zero on entry and on exit), every wave scans the
 // histogram redundantly (no broadcast barrier), 1 barrier per pass.
 //   exact:  keeps exactly k entries; returns the key of the k-th largest.
@@ -562,18 +564,18 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
 // Must be entered by the whole workgroup.  Returns -1 when n <= k (nothing done).
 // ZERO_TAIL: the buffer is used with block-wise reservations (holes = zero entries): positions beyond the kept
 // entries are zeroed so that a later reservation never exposes stale entries.
-template <int NT, bool ZERO_TAIL = false>
+template <int NT, bool ZERO_TAIL = false, int E = 4>
 __device__ long long select_fast(u64 *U, int *hist4, int *sh, int k, bool exact) {
     const int tid = threadIdx.x, lane = tid & 63;
-    const int n = min(sh[SH_CNT], 2 * NT);
+    const int n = min(sh[SH_CNT], E * NT);
     if (tid == 0) { sh[SH_CNT2] = 0; sh[SH_EQ] = 0; }   // (the generic path's selection leaves them dirty)
     __syncthreads();
     if (n <= k) return -1;
-    u64 e[2];
-    unsigned key[2];
-    bool has[2];
+    u64 e[E];
+    unsigned key[E];
+    bool has[E];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < E; ++j) {
         const int i = tid + j * NT;
         has[j] = i < n;
         e[j] = has[j] ? U[i] : 0ull;
@@ -587,7 +589,7 @@ __device__ long long select_fast(u64 *U, int *hist4, int *sh, int k, bool exact)
         const unsigned hmask = (ps == 0) ? 0u : (0xFFFFFFFFu << (shift + 8));
         int *h = hist4 + ps * 256;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < E; ++j)
             if (has[j] && ((key[j] ^ prefix) & hmask) == 0u) atomicAdd(&h[(key[j] >> shift) & 255u], 1);
         __syncthreads();
         // ONE wave walks the histogram (the others would only repeat the same instructions) and publishes the digit
@@ -621,7 +623,7 @@ __device__ long long select_fast(u64 *U, int *hist4, int *sh, int k, bool exact)
     }
     const bool all_passes = (passes == 4);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < E; ++j) {
         bool keep = false;
         if (has[j]) {
             if (key[j] > prefix) keep = true;
@@ -640,7 +642,7 @@ __device__ long long select_fast(u64 *U, int *hist4, int *sh, int k, bool exact)
     if (ZERO_TAIL) {
         const int kept = sh[SH_CNT2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < E; ++j) {
             const int i = tid + j * NT;
             if (has[j] && i >= kept) U[i] = 0ull;
         }

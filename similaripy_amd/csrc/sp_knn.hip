@@ -106,10 +106,10 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
         cap = need_cap + 1024;
     }
     if (cap > 0x7FFFFFF0LL) return fail(SP_EINVAL, "k too large");
-    // sparse kernel's candidate buffer: the last quarter of region A when 2*NT entries (what its register-resident
+    // sparse kernel's candidate buffer: the last quarter of region A when SEL_E*NT entries (what its register-resident
     // selection handles) fit there and leave room above k; else global scratch
-    const bool u_lds_s = ((size_t)2 * NT * 8 <= (size_t)T * 2) && ((long long)a->k + 512 <= 2LL * NT);
-    const long long cap_s = u_lds_s ? 2LL * NT : ((need_cap + 1024) & ~1LL);
+    const bool u_lds_s = ((size_t)SEL_E * NT * 8 <= (size_t)T * 2) && ((long long)a->k + 512 <= (long long)SEL_E * NT);
+    const long long cap_s = u_lds_s ? (long long)SEL_E * NT : ((need_cap + 1024) & ~1LL);
     c->T = T; c->logT = logT; c->NT = NT; c->cap = (int)cap; c->u_lds = u_lds; c->cap_s = (int)cap_s; c->u_lds_s = u_lds_s;
     c->hash_fill = std::max(1, (int)((long long)T * load / 100));
     c->lds_sparse = lds_fixed_sparse(T);

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         }
         int nx_r0 = 0, nx_len = 0;
 
-        if (tid == 0) { sh[SH_PCTR] = 0; sh[SH_MCTR] = 0; sh[SH_NITEMS] = 0; sh[SH_CNT] = 0; }
+        if (tid == 0) { sh[SH_PCTR] = 0; sh[SH_MCTR] = 0; sh[SH_NITEMS] = 0; sh[SH_CNT] = 0; sh[SH_SEL] = -1; sh[SH_NEED] = 0; }
         // Segment order.  The heaviest segments (largest |m1 value|: each segment scales its m2 row by its own m1 value)
         // go first, so that the first stage of sweep 2 sees the large products and the running k-th value — the cutoff
         // of everything after — starts high.
@@ -388,7 +388,113 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             long long chunk = MONO ? room : min(room, spcap - 2 * ITEM);
             bool last_stage = false;
             WavePool wpm{0, -1};      // member-pool window: lives across the stages of the row
-            while (!last_stage) {
+
+            // ---- MONO, first stage without any selection.  One item per wave (the first NW items: the heaviest
+            // segments).  Every wave finds, among the per-lane maxima of its single products, the m-th largest
+            // (m*NW >= k, m wave-max rounds): at least m of its products reach that value.  The minimum over the
+            // waves is therefore a value that at least k products of the stage reach — a valid cutoff, known after
+            // ONE barrier, and only the products that reach it enter U (a second barrier checks that they fit; if
+            // not — heavily tied values — the stage falls back to "accept everything in fewer items + select"). ----
+            if constexpr (MONO) {
+                const int NA = min(n_items, NW);
+                const int mrounds = (p.k + NA - 1) / NA + 2;
+                if (NA == NW && mrounds <= 16) {
+                    unsigned c[4];
+                    float v[4], x[4];
+                    u64 M[4], S[4];
+                    unsigned lmax = 0u;
+                    const int4 d = items[wave];
+                    const int cntA = __builtin_amdgcn_readfirstlane(d.y);
+                    {
+                        const int off = __builtin_amdgcn_readfirstlane(d.x);
+                        const float segv = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane(d.z));
+                        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, lane * 16, off, 0);
+                        const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs_val, lane * 16, off, 0);
+                        c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w;
+                        v[0] = __uint_as_float(b.x); v[1] = __uint_as_float(b.y); v[2] = __uint_as_float(b.z); v[3] = __uint_as_float(b.w);
+                        s2_core(c, v, segv, cutx, x, M, S);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const u64 ok = (cntA == ITEM) ? ~0ull : __ballot(4 * lane + j < cntA);
+                        M[j] &= ok;
+                        S[j] &= ok & ~M[j];
+                        if ((S[j] >> lane) & 1ull) lmax = max(lmax, fkey(x[j]));
+                    }
+                    // m-th largest (distinct) lane maximum of this wave — fewer rounds for a wave with fewer candidate lanes
+                    // (a partial item), so that its looser statistics do not drag the common cutoff down; whether k
+                    // products reach the cutoff is counted exactly below
+                    const int cand_lanes = __popcll(__ballot(lmax != 0u));
+                    const int my_rounds = max(1, (mrounds * cand_lanes + 63) / 64);
+                    unsigned rest = lmax, tw = 0u;
+                    for (int r = 0; r < my_rounds; ++r) {
+                        const unsigned mx = wave_max_u32(rest);
+                        if (mx != 0u) tw = mx;
+                        rest = (rest >= mx) ? 0u : rest;
+                    }
+                    if (lane == 0 && tw != 0u) atomicMin((unsigned *)&sh[SH_SEL], tw);
+                    __syncthreads();
+                    const unsigned g = (unsigned)sh[SH_SEL];            // every product pushed below has key >= g
+                    u64 G[4];
+                    int cw = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        G[j] = S[j] & __ballot(fkey(x[j]) >= g);
+                        cw += __popcll(G[j]);
+                    }
+                    if (lane == 0 && cw) atomicAdd(&sh[SH_NEED], cw);
+                    __syncthreads();
+                    const int totalA = sh[SH_NEED];
+                    const bool fits = totalA <= room;                   // uniform
+                    const int nfull = max(1, room / ITEM);              // fallback: the first nfull items, everything accepted
+                    if (fits || wave < nfull) {
+                        if (!fits) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) G[j] = S[j];
+                        }
+                        const int m0 = __popcll(M[0]), m1 = __popcll(M[1]), m2 = __popcll(M[2]), m3 = __popcll(M[3]);
+                        if (m0 + m1 + m2 + m3) {
+                            if (pool_reserve(wpm, m0 + m1 + m2 + m3, &sh[SH_MCTR], mpcap, &sh[SH_OVF])) {
+                                int pos = wpm.pos;
+                                lds_push64(M[0], __float_as_uint(x[0]), c[0] + 1u, pos, mpool_off); pos += m0;
+                                lds_push64(M[1], __float_as_uint(x[1]), c[1] + 1u, pos, mpool_off); pos += m1;
+                                lds_push64(M[2], __float_as_uint(x[2]), c[2] + 1u, pos, mpool_off); pos += m2;
+                                lds_push64(M[3], __float_as_uint(x[3]), c[3] + 1u, pos, mpool_off);
+                                wpm.pos = pos + m3;
+                            }
+                        }
+                        const int n0 = __popcll(G[0]), n1 = __popcll(G[1]), n2 = __popcll(G[2]), n3 = __popcll(G[3]);
+                        if (n0 + n1 + n2 + n3) {
+                            int ubase = 0;
+                            if (lane == 0) ubase = atomicAdd(&sh[SH_CNT], n0 + n1 + n2 + n3);     // exact: no holes in this stage
+                            int pos = __builtin_amdgcn_readfirstlane(ubase);
+                            if ((G[0] >> lane) & 1ull) U[pos + mbcnt64(G[0])] = ((u64)fkey(x[0]) << 32) | (u64)c[0];
+                            pos += n0;
+                            if ((G[1] >> lane) & 1ull) U[pos + mbcnt64(G[1])] = ((u64)fkey(x[1]) << 32) | (u64)c[1];
+                            pos += n1;
+                            if ((G[2] >> lane) & 1ull) U[pos + mbcnt64(G[2])] = ((u64)fkey(x[2]) << 32) | (u64)c[2];
+                            pos += n2;
+                            if ((G[3] >> lane) & 1ull) U[pos + mbcnt64(G[3])] = ((u64)fkey(x[3]) << 32) | (u64)c[3];
+                        }
+                    }
+                    i0 = fits ? NW : nfull;
+                    if (fits && totalA >= p.k) {
+                        rc.have_thr = true;
+                        rc.thr_key = g;
+                        cutx = fmaxf(cutx0, funkey(g));
+                    }
+                    __syncthreads();
+                    if (sh[SH_OVF]) failed = true;
+                    // (not fitting: U now holds everything of the first nfull items; the next stage's selection trims it)
+                    chunk = fits ? max((long long)ITEM, (long long)items[min(i0, n_items)].w * (long long)(cap - min(sh[SH_CNT], cap)) / (2ll * (long long)p.k))
+                                 : (long long)ITEM;
+                    PHASE_END(PH_SWEEP2);
+                }
+            }
+            if (i0 >= n_items && !failed && i0 > 0) {
+                // (all items went through the first stage: let the loop run its last-stage part with an empty sweep)
+            }
+            while (!last_stage && !failed) {
                 const int i1 = (int)min((long long)n_items, (long long)i0 + max(1ll, chunk / ITEM));
                 {
                     // ---- sweep 2 over items [i0, i1) ----
@@ -442,7 +548,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                             const int n0 = __popcll(S[0]), n1 = __popcll(S[1]), n2 = __popcll(S[2]), n3 = __popcll(S[3]);
                             if constexpr (MONO) {
                                 // straight into the candidate buffer, keyed by the raw dot
-                                if (pool_reserve(wps, n0 + n1 + n2 + n3, &sh[SH_CNT], cap, &sh[SH_OVF])) {
+                                if (pool_reserve<16>(wps, n0 + n1 + n2 + n3, &sh[SH_CNT], cap, &sh[SH_OVF])) {     // small blocks: U is short of room
                                     int pos = wps.pos;
                                     if constexpr (U_LDS) {
                                         lds_push64(S[0], c[0], fkey(x[0]), pos, u_off); pos += n0;
@@ -622,7 +728,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     const bool want_sel = retry || (last_stage ? (n_eff > p.k) : (n_eff > p.k && (!rc.have_thr || 2 * n_eff > cap + p.k)));
                     if (want_sel) {
                         long long thr_new;
-                        if (cap <= 2 * NT) thr_new = select_fast<NT, MONO>(U, hist4, sh, p.k, last_stage && !retry);
+                        if (cap <= SEL_E * NT) thr_new = select_fast<NT, MONO, SEL_E>(U, hist4, sh, p.k, last_stage && !retry);
                         else {
                             thr_new = compact_topk<NT>(U, hist4, sh, p.k);
                             if constexpr (MONO) {     // block-wise reservations: nothing stale may stay behind the kept entries
