@@ -281,48 +281,52 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 // The wave's item descriptors are read ONCE, item wave + NW*i into lane i (beyond the end: the sentinel);
                 // a trip then gets its scalars with v_readlane instead of an LDS round trip.
                 const int4 myd = items[min(wave + NW * lane, n_items)];
-                auto ld = [&](int trip, unsigned (&c)[4], int &cnt) __attribute__((always_inline)) {
-                    const int tl = min(trip, 63);
-                    const int off = __builtin_amdgcn_readlane(myd.x, tl);
-                    cnt = __builtin_amdgcn_readlane(myd.y, tl);
-                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, lane * 16, off, 0);
-                    c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
+                // a trip = two items (eight columns per lane): twice the loads and twice the LDS atomics in flight per wait
+                auto ld = [&](int trip, unsigned (&c)[8], int &cnt0, int &cnt1) __attribute__((always_inline)) {
+                    const int t0 = min(2 * trip, 63), t1 = min(2 * trip + 1, 63);
+                    const int off0 = __builtin_amdgcn_readlane(myd.x, t0), off1 = __builtin_amdgcn_readlane(myd.x, t1);
+                    cnt0 = __builtin_amdgcn_readlane(myd.y, t0);
+                    cnt1 = __builtin_amdgcn_readlane(myd.y, t1);
+                    const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, lane * 16, off0, 0);
+                    const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, lane * 16, off1, 0);
+                    c[0] = v0.x; c[1] = v0.y; c[2] = v0.z; c[3] = v0.w;
+                    c[4] = v1.x; c[5] = v1.y; c[6] = v1.z; c[7] = v1.w;
                 };
-                auto body = [&](const unsigned (&c)[4], int cnt) __attribute__((always_inline)) {
-                    if (cnt == 0) return;                  // sentinel (wave-uniform)
-                    unsigned seen[4];
-                    if (cnt == ITEM) {
-                        s1_core<CBM_BYTES + PRE_BYTES, false>(c, c, amask, seen);
+                auto body = [&](const unsigned (&c)[8], int cnt0, int cnt1) __attribute__((always_inline)) {
+                    if (cnt0 == 0) return;                 // sentinel pair (wave-uniform; the second item of a pair may be the sentinel)
+                    unsigned seen[8];
+                    if (cnt0 == ITEM && cnt1 == ITEM) {
+                        s1_core8<CBM_BYTES + PRE_BYTES, false>(c, c, amask, seen);
                     } else {
-                        unsigned one[4];
+                        unsigned one[8];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) one[j] = (4 * lane + j < cnt) ? 1u : 0u;      // padding ORs nothing
-                        s1_core<CBM_BYTES + PRE_BYTES, true>(c, one, amask, seen);
+                        for (int j = 0; j < 4; ++j) {      // padding ORs nothing
+                            one[j] = (4 * lane + j < cnt0) ? 1u : 0u;
+                            one[4 + j] = (4 * lane + j < cnt1) ? 1u : 0u;
+                        }
+                        s1_core8<CBM_BYTES + PRE_BYTES, true>(c, one, amask, seen);
                     }
                     // ~2 % of the products find their column already there: mark it in the collision bitmap
-                    if (__ballot((seen[0] | seen[1] | seen[2] | seen[3]) != 0u)) {
+                    if (__ballot(((seen[0] | seen[1]) | (seen[2] | seen[3]) | (seen[4] | seen[5]) | (seen[6] | seen[7])) != 0u)) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
+                        for (int j = 0; j < 8; ++j)
                             if (seen[j]) atomicOr((unsigned *)(cbm + ((c[j] >> 3) & cmask)), 1u << (c[j] & 31u));
                     }
                 };
-                unsigned cA[4], cB[4], cC[4];
-                int nA = 0, nB = 0, nC = 0;
-                const int n_trips = (n_items - wave + NW - 1) / NW;      // items wave, wave+NW, ...
+                unsigned cA[8], cB[8];
+                int nA0 = 0, nA1 = 0, nB0 = 0, nB1 = 0;
+                const int n_mine = (n_items - wave + NW - 1) / NW;       // items wave, wave+NW, ...
+                const int n_trips = (n_mine + 1) / 2;
                 int trip = 0;
-                ld(0, cA, nA);
-                ld(1, cB, nB);
-                while (trip < n_trips) {      // three items in flight per wave; bodies skip the sentinel
-                    ld(trip + 2, cC, nC);
-                    __builtin_amdgcn_sched_barrier(0);     // the prefetch is issued before the oldest item is waited for
-                    body(cA, nA);
-                    ld(trip + 3, cA, nA);
+                ld(0, cA, nA0, nA1);
+                while (trip < n_trips) {      // two pairs in flight per wave; bodies skip the sentinel
+                    ld(trip + 1, cB, nB0, nB1);
+                    __builtin_amdgcn_sched_barrier(0);     // the prefetch is issued before the current pair is waited for
+                    body(cA, nA0, nA1);
+                    ld(trip + 2, cA, nA0, nA1);
                     __builtin_amdgcn_sched_barrier(0);
-                    body(cB, nB);
-                    ld(trip + 4, cB, nB);
-                    __builtin_amdgcn_sched_barrier(0);
-                    body(cC, nC);
-                    trip += 3;
+                    body(cB, nB0, nB1);
+                    trip += 2;
                 }
             }
             __syncthreads();
