@@ -280,7 +280,9 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 // (no memory traffic) instead of a branch, so the loads in flight are countable (s_waitcnt vmcnt(N)).
                 // The wave's item descriptors are read ONCE, item wave + NW*i into lane i (beyond the end: the sentinel);
                 // a trip then gets its scalars with v_readlane instead of an LDS round trip.
-                const int4 myd = items[min(wave + NW * lane, n_items)];
+                // visited back to front: what sweep 1 reads last is what sweep 2 reads first (L2 still holds it)
+                const int n_mine = (n_items - wave + NW - 1) / NW;       // items wave, wave+NW, ...
+                const int4 myd = items[(lane < n_mine) ? wave + NW * (n_mine - 1 - lane) : n_items];
                 // a trip = two items (eight columns per lane): twice the loads and twice the LDS atomics in flight per wait
                 auto ld = [&](int trip, unsigned (&c)[8], int &cnt0, int &cnt1) __attribute__((always_inline)) {
                     const int t0 = min(2 * trip, 63), t1 = min(2 * trip + 1, 63);
@@ -315,7 +317,6 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 };
                 unsigned cA[8], cB[8];
                 int nA0 = 0, nA1 = 0, nB0 = 0, nB1 = 0;
-                const int n_mine = (n_items - wave + NW - 1) / NW;       // items wave, wave+NW, ...
                 const int n_trips = (n_mine + 1) / 2;
                 int trip = 0;
                 ld(0, cA, nA0, nA1);
