@@ -635,20 +635,29 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                         unsigned h0 = (unsigned)pre16[wi0] + (unsigned)__popc(bw0 & ((1u << (c0m & 31u)) - 1u));
                         unsigned h1 = (unsigned)pre16[wi1] + (unsigned)__popc(bw1 & ((1u << (c1m & 31u)) - 1u));
                         bool a0 = (e0 != 0ull), a1 = (e1 != 0ull);
+                        u64 cur0 = 0ull, cur1 = 0ull, want0 = e0, want1 = e1;     // expected slot content -> new content
                         int rounds = 0;
                         while (__ballot(a0 | a1)) {
                             u64 r0 = 0ull, r1 = 0ull;
-                            if (a0) r0 = atomicCAS(&cs[h0], 0ull, e0);
-                            if (a1) r1 = atomicCAS(&cs[h1], 0ull, e1);
+                            if (a0) r0 = atomicCAS(&cs[h0], cur0, want0);
+                            if (a1) r1 = atomicCAS(&cs[h1], cur1, want1);
                             if (a0) {
-                                if (r0 == 0ull) a0 = false;                                                     // claimed, product deposited
-                                else if ((unsigned)(r0 >> 32) == k0) { atomicAdd((float *)&cs[h0], x0); a0 = false; }   // the column's slot: add
-                                else h0 = next_slot(h0, k0);                                                    // another column's slot
+                                if (r0 == cur0) a0 = false;                                  // claimed (cur = 0) or added (cur = the sum seen)
+                                else if ((unsigned)(r0 >> 32) == k0) {
+                                    if (cur0 == 0ull) {                                      // the column's slot: one compare-and-swap add
+                                        cur0 = r0;
+                                        want0 = (r0 & 0xFFFFFFFF00000000ull) | (u64)__float_as_uint(__uint_as_float((unsigned)r0) + x0);
+                                    } else { atomicAdd((float *)&cs[h0], x0); a0 = false; }  // contended (a column with many products): hardware add
+                                } else { h0 = next_slot(h0, k0); cur0 = 0ull; want0 = e0; }  // another column's slot
                             }
                             if (a1) {
-                                if (r1 == 0ull) a1 = false;
-                                else if ((unsigned)(r1 >> 32) == k1) { atomicAdd((float *)&cs[h1], x1); a1 = false; }
-                                else h1 = next_slot(h1, k1);
+                                if (r1 == cur1) a1 = false;
+                                else if ((unsigned)(r1 >> 32) == k1) {
+                                    if (cur1 == 0ull) {
+                                        cur1 = r1;
+                                        want1 = (r1 & 0xFFFFFFFF00000000ull) | (u64)__float_as_uint(__uint_as_float((unsigned)r1) + x1);
+                                    } else { atomicAdd((float *)&cs[h1], x1); a1 = false; }
+                                } else { h1 = next_slot(h1, k1); cur1 = 0ull; want1 = e1; }
                             }
                             if (++rounds > 4 * CS_MAXPROBE) { sh[SH_OVF] = 1; break; }     // set full
                         }
