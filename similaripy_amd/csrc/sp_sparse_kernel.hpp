@@ -398,8 +398,9 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             // segments).  Every wave finds, among the per-lane maxima of its single products, the m-th largest
             // (m*NW >= k, m wave-max rounds): at least m of its products reach that value.  The minimum over the
             // waves is therefore a value that at least k products of the stage reach — a valid cutoff, known after
-            // ONE barrier, and only the products that reach it enter U (a second barrier checks that they fit; if
-            // not — heavily tied values — the stage falls back to "accept everything in fewer items + select"). ----
+            // ONE barrier, and only the products that reach it enter U (a second barrier checks that at least k do and
+            // that they fit; if not — sparse items, heavily tied values — the stage falls back to "accept everything
+            // in fewer items, select afterwards"). ----
             if constexpr (MONO) {
                 const int NA = min(n_items, NW);
                 const int mrounds = (p.k + NA - 1) / NA + 2;
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     if (lane == 0 && cw) atomicAdd(&sh[SH_NEED], cw);
                     __syncthreads();
                     const int totalA = sh[SH_NEED];
-                    const bool fits = totalA <= room;                   // uniform
+                    const bool fits = totalA <= room && totalA >= p.k;   // uniform: k products reach g (so it is a valid cutoff) and they fit
                     const int nfull = max(1, room / ITEM);              // fallback: the first nfull items, everything accepted
                     if (fits || wave < nfull) {
                         if (!fits) {
@@ -483,7 +484,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                         }
                     }
                     i0 = fits ? NW : nfull;
-                    if (fits && totalA >= p.k) {
+                    if (fits) {
                         rc.have_thr = true;
                         rc.thr_key = g;
                         cutx = fmaxf(cutx0, funkey(g));
@@ -711,17 +712,34 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                             }
                         }
                     } else {
-                        for (int base = 0; base < n_ent; base += NT) {
-                            const int i = base + tid;
-                            u64 *src = (i < ext) ? &spool[i] : &cs[i - ext];
-                            const u64 e = (i < n_ent) ? *src : 0ull;
-                            int c[1] = {(int)((unsigned)(e >> 32) - 1u)};
-                            float xy[1] = {__uint_as_float((unsigned)e)};
-                            const unsigned occ = (e != 0ull && !(xy[0] <= rc.xy_cut)) ? 1u : 0u;
-                            const unsigned done = emit_candidates<1>(p, rc, c, xy, occ, U, sh, cap);
-                            if (e != 0ull && (!occ || done)) {
-                                *src = 0ull;
-                                if (i >= ext) atomicAnd((unsigned *)(cbm + (((unsigned)c[0] >> 3) & cmask)), ~(1u << ((unsigned)c[0] & 31u)));
+                        // two entries per thread and trip: the gathers of their column terms are in flight together
+                        constexpr int JN = 2;
+                        for (int base = 0; base < n_ent; base += JN * NT) {
+                            u64 e[JN];
+                            u64 *src[JN];
+                            int c[JN];
+                            float xy[JN];
+                            unsigned occ = 0;
+#pragma unroll
+                            for (int j = 0; j < JN; ++j) {
+                                const int i = base + j * NT + tid;
+                                src[j] = (i < ext) ? &spool[i] : &cs[i - ext];
+                                e[j] = (i < n_ent) ? *src[j] : 0ull;
+                            }
+#pragma unroll
+                            for (int j = 0; j < JN; ++j) {
+                                c[j] = (int)((unsigned)(e[j] >> 32) - 1u);
+                                xy[j] = __uint_as_float((unsigned)e[j]);
+                                if (e[j] != 0ull && !(xy[j] <= rc.xy_cut)) occ |= 1u << j;
+                            }
+                            const unsigned done = emit_candidates<JN>(p, rc, c, xy, occ, U, sh, cap);
+#pragma unroll
+                            for (int j = 0; j < JN; ++j) {
+                                if (e[j] != 0ull && (!(occ & (1u << j)) || (done & (1u << j)))) {
+                                    *src[j] = 0ull;
+                                    if (base + j * NT + tid >= ext)
+                                        atomicAnd((unsigned *)(cbm + (((unsigned)c[j] >> 3) & cmask)), ~(1u << ((unsigned)c[j] & 31u)));
+                                }
                             }
                         }
                     }

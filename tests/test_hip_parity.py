@@ -246,3 +246,76 @@ def test_library_refuses_bad_arguments():
     call.targets = np.array([0, 77], dtype=np.int32)   # out of range row id
     with pytest.raises(_abi.HipLibraryError):
         _host.run_hip(call)
+
+
+# ---------------------------------------------------------------------------------------------
+# sparse kernel (bitmap + two sweeps): shapes that take its different branches
+# ---------------------------------------------------------------------------------------------
+def _sparse_shape(n_rows=40000, n_cols=3000, density=0.004, seed=21):
+    """m2 = m.T has n_rows columns (> the default accumulator tile): rows go to the sparse kernel."""
+    return _rand((n_rows, n_cols), density, seed)
+
+
+def _info(call, **tuning):
+    return _host.run_hip(call, time_kernel=True, **tuning)[4]["phase_cycles"]
+
+
+@pytest.mark.parametrize("name,kw", [("dot", {}), ("cosine", dict(l2=1)), ("asym", dict(l2=1, c1=0.3, c2=0.7)),
+                                     ("rp3like", dict(l3=1, weight_depop_matrix2="sum", p2=0.6)),
+                                     ("tversky", dict(l1=1, t1=0.7, t2=0.3)), ("splus", dict(l1=0.5, l2=0.5, stabilized_shrink=5))],
+                         ids=["dot", "cosine", "asym", "rp3like", "tversky", "splus"])
+def test_sparse_kernel_monotone_and_general(name, kw):
+    """dot / cosine-type epilogues run the monotone variant (top-k on the raw dot), tversky / shrink the general one;
+    all rows must actually be served by the sparse kernel here."""
+    m = _sparse_shape()
+    call = _host.prepare(m, k=40, target_rows=np.arange(0, 40000, 13), **kw)
+    _check(call, "sparse " + name)
+    pc = _info(call)
+    assert pc[9] == call.n_targets and pc[10] == 0, (pc[9], pc[10])     # rows on the sparse kernel / given up
+
+
+def test_sparse_kernel_tied_values():
+    """Binary data: every product of a segment has the same value, whole stages tie at the cutoff (the first stage's
+    count check, the selection's tie counter and the strict cutoff all see it)."""
+    m = _sparse_shape(seed=22)
+    m.data[:] = 1.0
+    for kw in ({}, dict(l2=1)):
+        call = _host.prepare(m, k=30, target_rows=np.arange(5, 40000, 17), **kw)
+        _check(call, f"binary {kw}")
+    m.data[:] = np.random.default_rng(2).integers(1, 4, m.nnz).astype(np.float32)    # three levels
+    _check(_host.prepare(m, k=30, l2=1, target_rows=np.arange(1, 40000, 19)), "three levels")
+
+
+def test_sparse_kernel_long_rows_and_large_k():
+    """Rows with more than 64 entries take the all-pairs segment ordering; k too large for the selection-free first
+    stage (more than 16 wave-max rounds) takes the accept-everything first stage."""
+    rng = np.random.default_rng(23)
+    wide = sp.random_array((6000, 60000), density=0.002, format="csr", dtype=np.float32, random_state=rng)   # ~120 nnz/row
+    m2 = sp.random_array((60000, 50000), density=0.0005, format="csr", dtype=np.float32, random_state=rng)
+    call = _host.prepare(wide, m2, k=50, l2=1, target_rows=np.arange(0, 6000, 5))
+    _check(call, "n1 > 64")
+    m = _sparse_shape(seed=24)
+    call = _host.prepare(m, k=300, l2=1, target_rows=np.arange(0, 40000, 23))
+    _check(call, "k=300")
+    call = _host.prepare(m, k=1500, target_rows=np.arange(0, 40000, 97))      # candidate buffer in global memory
+    _check(call, "k=1500")
+
+
+def test_sparse_kernel_signed_values_and_thresholds():
+    m = _sparse_shape(seed=25)
+    m.data = (m.data - 0.4).astype(np.float32)
+    t = np.arange(3, 40000, 29)
+    _check(_host.prepare(m, k=25, l2=1, target_rows=t), "signed cosine")
+    _check(_host.prepare(m, k=25, threshold=0.05, target_rows=t), "signed dot, positive threshold")
+    _check(_host.prepare(m, k=25, l2=1, threshold=-0.05, target_rows=t), "signed cosine, negative threshold")
+    _check(_host.prepare(m, k=25, l1=1, t1=1, t2=1, threshold=0.001, target_rows=t), "signed jaccard-like")
+
+
+def test_sparse_kernel_small_pools_give_up_to_generic():
+    """With a small accumulator tile the sparse kernel's pools overflow for most rows: they must come back right
+    through the generic kernel's queue."""
+    m = _sparse_shape(seed=26)
+    call = _host.prepare(m, k=40, l2=1, target_rows=np.arange(0, 40000, 11))
+    _check(call, "T=2048", table_slots=2048)
+    pc = _info(call, table_slots=2048)
+    assert pc[9] + pc[10] >= 1
