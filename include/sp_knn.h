@@ -53,6 +53,7 @@ extern "C" {
 #define SP_FLAG_NO_SPARSE_PATH 8u /* never use the bitmap + collision-set path for sparse rows (A/B testing) */
 #define SP_FLAG_NO_FOLD       16u /* never divide the column term into the m2 stream (A/B testing) */
 #define SP_FLAG_NO_ROW_ORDER  32u /* queue rows in target order instead of descending work (A/B testing) */
+#define SP_FLAG_PHASE_TIMERS  64u /* with SP_FLAG_TIME_KERNEL: also run the in-kernel phase timers (s_memtime, ~1-2 % slower) */
 
 typedef struct sp_knn_args {
     uint32_t struct_size;      /* = sizeof(sp_knn_args); checked */
@@ -116,13 +117,18 @@ typedef struct sp_knn_args {
     /* results */
     float   kernel_ms;         /* OUT when SP_FLAG_TIME_KERNEL */
     int32_t passes_total;      /* OUT (debug, only with SP_FLAG_TIME_KERNEL): accumulate+drain passes summed over rows */
-    int64_t phase_cycles[12];  /* OUT with SP_FLAG_TIME_KERNEL: shader cycles summed over workgroups (lane 0) spent in
-                                  setup / segment search+scan / accumulate / drain / top-k select / output /
-                                  sparse sweep 1 / sparse sweep 2 / collision-set drain, then event counts:
-                                  rows on the sparse path / sparse rows that fell back / generic windows */
+    int64_t phase_cycles[12];  /* OUT with SP_FLAG_TIME_KERNEL | SP_FLAG_PHASE_TIMERS: shader cycles summed over workgroups (lane 0), both row kernels:
+                                  [0] row setup  [1] generic: segment scan | sparse: item list, bitmap clear + rank prefix
+                                  [2] generic: accumulate | sparse: member products into the collision set
+                                  [3] judge (column terms, epilogue, top-k buffer)  [4] selections  [5] write-out
+                                  [6] sparse sweep 1  [7] sparse sweep 2  [8] unused; then event counts:
+                                  [9] rows finished by the sparse kernel  [10] rows it handed to the generic kernel
+                                  [11] generic column windows */
     int32_t num_wgs_used;      /* OUT with SP_FLAG_TIME_KERNEL */
     int32_t _pad1;
-    int64_t reserved[4];
+    int64_t reserved[4];       /* [0] IN: kernel ablation bits, profiling only (0 in production)
+                                  [1], [2] OUT with SP_FLAG_TIME_KERNEL: duration of the sparse / generic row kernel of this
+                                  call in microseconds (hipEvents on `stream` around each launch) */
 } sp_knn_args;
 
 /* The hot path.  Replaces compute_similarities_parallel<int,float> (s_plus.h:265). */

@@ -408,7 +408,7 @@ def run_hip(call: KernelCall, device: Optional[int] = None, table_slots: int = 0
     counts = np.empty(n, dtype=np.int32)
 
     a = _abi.SpKnnArgs()
-    a.flags = ((_abi.SP_FLAG_TIME_KERNEL if time_kernel else 0) | (_abi.SP_FLAG_STATIC_SCHED if static_sched else 0)
+    a.flags = ((_abi.SP_FLAG_TIME_KERNEL | _abi.SP_FLAG_PHASE_TIMERS if time_kernel else 0) | (_abi.SP_FLAG_STATIC_SCHED if static_sched else 0)
                | (_abi.SP_FLAG_NO_SPARSE_PATH if no_sparse_path else 0) | (_abi.SP_FLAG_NO_FOLD if no_fold else 0))
     a.on_device = 0
     a.device = selected_device() if device is None else int(device)
@@ -442,7 +442,8 @@ def run_hip(call: KernelCall, device: Optional[int] = None, table_slots: int = 0
     if n > 0:
         _abi.call_knn(a)
     if time_kernel:
-        return rows, cols, values, counts, {"kernel_ms": float(a.kernel_ms), "passes_total": int(a.passes_total), "phase_cycles": [int(x) for x in a.phase_cycles], "num_wgs": int(a.num_wgs_used)}
+        return rows, cols, values, counts, {"kernel_ms": float(a.kernel_ms), "passes_total": int(a.passes_total), "phase_cycles": [int(x) for x in a.phase_cycles], "num_wgs": int(a.num_wgs_used),
+                                             "sparse_kernel_ms": int(a.reserved[1]) / 1e3, "generic_kernel_ms": int(a.reserved[2]) / 1e3}
     return rows, cols, values, counts
 
 

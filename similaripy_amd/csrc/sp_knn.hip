@@ -184,8 +184,9 @@ int device_cus(int device, int *n_cus) {
 }
 
 template <int NT>
-int launch_rows(const KParams &kp, const Config &c, hipStream_t stream) {
+int launch_rows(const KParams &kp, const Config &c, hipStream_t stream, hipEvent_t *ev /* [4] or NULL: around the two row kernels */) {
     // sparse rows first; what it cannot finish joins the generic queue, which the second launch drains
+    if (ev) HIP_TRY(hipEventRecord(ev[0], stream));
     if (kp.sparse_path) {
         auto ks = c.mono ? (c.u_lds_s ? sp_knn_sparse_kernel<NT, true, true> : sp_knn_sparse_kernel<NT, false, true>)
                          : (c.u_lds_s ? sp_knn_sparse_kernel<NT, true, false> : sp_knn_sparse_kernel<NT, false, false>);
@@ -193,10 +194,12 @@ int launch_rows(const KParams &kp, const Config &c, hipStream_t stream) {
         hipLaunchKernelGGL(ks, dim3(c.wgs_sparse), dim3(NT), c.lds_sparse, stream, kp);
         HIP_TRY(hipGetLastError());
     }
+    if (ev) { HIP_TRY(hipEventRecord(ev[1], stream)); HIP_TRY(hipEventRecord(ev[2], stream)); }
     auto kg = c.u_lds ? sp_knn_generic_kernel<NT, true> : sp_knn_generic_kernel<NT, false>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds_generic));
     hipLaunchKernelGGL(kg, dim3(c.wgs_generic), dim3(NT), c.lds_generic, stream, kp);
     HIP_TRY(hipGetLastError());
+    if (ev) HIP_TRY(hipEventRecord(ev[3], stream));
     return SP_OK;
 }
 
@@ -310,13 +313,15 @@ int run_device(sp_knn_args *a) {
     kp.bound_ok = bound_ok ? 1 : 0;
     kp.fold = c.fold ? 1 : 0;
     if (c.fold) kp.m2_data = folded;
-    kp.phase_cycles = timed ? (unsigned long long *)(ws + WS_PHASE_OFFSET) : nullptr;   // inside the zeroed header
+    kp.phase_cycles = (timed && (a->flags & SP_FLAG_PHASE_TIMERS)) ? (unsigned long long *)(ws + WS_PHASE_OFFSET) : nullptr;   // inside the zeroed header
     kp.dbg = (int)a->reserved[0];
 
-    if (c.NT == 256) rc = launch_rows<256>(kp, c, stream);
-    else if (c.NT == 512) rc = launch_rows<512>(kp, c, stream);
-    else if (c.NT == 768) rc = launch_rows<768>(kp, c, stream);
-    else rc = launch_rows<1024>(kp, c, stream);
+    hipEvent_t kev[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (timed) { for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&kev[i])); }
+    if (c.NT == 256) rc = launch_rows<256>(kp, c, stream, timed ? kev : nullptr);
+    else if (c.NT == 512) rc = launch_rows<512>(kp, c, stream, timed ? kev : nullptr);
+    else if (c.NT == 768) rc = launch_rows<768>(kp, c, stream, timed ? kev : nullptr);
+    else rc = launch_rows<1024>(kp, c, stream, timed ? kev : nullptr);
     if (rc) { if (own_ws) (void)hipFree(ws); return rc; }
 
     if (timed) {
@@ -332,6 +337,12 @@ int run_device(sp_knn_args *a) {
         for (int i = 0; i < PH_N; ++i) a->phase_cycles[i] = (int64_t)phc[i];
         a->passes_total = (int32_t)phc[CT_PASSES];
         a->num_wgs_used = c.wgs_sparse;
+        float ks_ms = 0.f, kg_ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ks_ms, kev[0], kev[1]));
+        HIP_TRY(hipEventElapsedTime(&kg_ms, kev[2], kev[3]));
+        a->reserved[1] = (int64_t)(ks_ms * 1000.0f);      // sparse row kernel, microseconds
+        a->reserved[2] = (int64_t)(kg_ms * 1000.0f);      // generic row kernel, microseconds
+        for (int i = 0; i < 4; ++i) (void)hipEventDestroy(kev[i]);
         (void)hipEventDestroy(ev0);
         (void)hipEventDestroy(ev1);
     }

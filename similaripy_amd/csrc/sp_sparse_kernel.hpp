@@ -289,6 +289,9 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     const int off0 = __builtin_amdgcn_readlane(myd.x, t0), off1 = __builtin_amdgcn_readlane(myd.x, t1);
                     cnt0 = __builtin_amdgcn_readlane(myd.y, t0);
                     cnt1 = __builtin_amdgcn_readlane(myd.y, t1);
+                    // lanes beyond a partial item's end get an out-of-range offset: they fetch nothing (instead of the next m2 row)
+                    // (lanes beyond a partial item's end read on into the next m2 row: in sweep 1 that over-fetch is cheaper than
+                    // the registers the out-of-range trick of sweep 2 would cost here)
                     const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, lane * 16, off0, 0);
                     const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, lane * 16, off1, 0);
                     c[0] = v0.x; c[1] = v0.y; c[2] = v0.z; c[3] = v0.w;
@@ -300,9 +303,10 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     if (cnt0 == ITEM && cnt1 == ITEM) {
                         s1_core8<CBM_BYTES + PRE_BYTES, false>(c, c, amask, seen);
                     } else {
+                        // padding ORs nothing (into whatever word the over-fetched column names: spread, no serialisation)
                         unsigned one[8];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {      // padding ORs nothing
+                        for (int j = 0; j < 4; ++j) {
                             one[j] = (4 * lane + j < cnt0) ? 1u : 0u;
                             one[4 + j] = (4 * lane + j < cnt1) ? 1u : 0u;
                         }
@@ -414,8 +418,9 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     {
                         const int off = __builtin_amdgcn_readfirstlane(d.x);
                         const float segv = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane(d.z));
-                        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, lane * 16, off, 0);
-                        const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs_val, lane * 16, off, 0);
+                        const int vo = (4 * lane < cntA) ? lane * 16 : (int)(OOB_SOFFSET - (unsigned)off);
+                        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, vo, off, 0);
+                        const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs_val, vo, off, 0);
                         c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w;
                         v[0] = __uint_as_float(b.x); v[1] = __uint_as_float(b.y); v[2] = __uint_as_float(b.z); v[3] = __uint_as_float(b.w);
                         s2_core(c, v, segv, cutx, x, M, S);
@@ -516,8 +521,10 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                         const int off = __builtin_amdgcn_readlane(myd.x, tl);
                         cnt = __builtin_amdgcn_readlane(myd.y, tl);
                         segv = __uint_as_float((unsigned)__builtin_amdgcn_readlane(myd.z, tl));
-                        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, lane * 16, off, 0);
-                        const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs_val, lane * 16, off, 0);
+                        // lanes beyond a partial item's end get an out-of-range offset: they fetch nothing
+                        const int vo = (4 * lane < cnt) ? lane * 16 : (int)(OOB_SOFFSET - (unsigned)off);
+                        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, vo, off, 0);
+                        const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs_val, vo, off, 0);
                         c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w;
                         v[0] = __uint_as_float(b.x); v[1] = __uint_as_float(b.y); v[2] = __uint_as_float(b.z); v[3] = __uint_as_float(b.w);
                     };

@@ -97,6 +97,8 @@ class DeviceProblem:
         if n == 0:
             return {"kernel_ms": 0.0, "passes_total": 0}
         flags = (_abi.SP_FLAG_TIME_KERNEL if time_kernel else 0) | (_abi.SP_FLAG_STATIC_SCHED if static_sched else 0)
+        if time_kernel and tuning.get("phase_timers", True):
+            flags |= _abi.SP_FLAG_PHASE_TIMERS
         if tuning.get("no_sparse_path"):
             flags |= _abi.SP_FLAG_NO_SPARSE_PATH
         if tuning.get("no_fold"):
@@ -111,4 +113,5 @@ class DeviceProblem:
                 self._ws = torch.empty(max(need, 4096), dtype=torch.uint8, device=self.device)
             a.workspace, a.workspace_bytes = self._ws.data_ptr(), self._ws.numel()
             _abi.call_knn(a)
-        return {"kernel_ms": float(a.kernel_ms), "passes_total": int(a.passes_total), "phase_cycles": [int(x) for x in a.phase_cycles], "num_wgs": int(a.num_wgs_used)}
+        return {"kernel_ms": float(a.kernel_ms), "passes_total": int(a.passes_total), "phase_cycles": [int(x) for x in a.phase_cycles], "num_wgs": int(a.num_wgs_used),
+                "sparse_kernel_ms": int(a.reserved[1]) / 1e3, "generic_kernel_ms": int(a.reserved[2]) / 1e3}
