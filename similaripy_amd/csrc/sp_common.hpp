@@ -469,44 +469,45 @@ __device__ __forceinline__ void s1_core(const unsigned (&c)[4], const unsigned (
     seen[0] = b0; seen[1] = b1; seen[2] = b2; seen[3] = b3;
 }
 
-// The same for eight columns (two items) per lane: twice the LDS atomics in flight per wait.
+// The same for eight columns (two items) per lane: twice the LDS atomics in flight per wait, address registers reused
+// as soon as their atomic is issued.  MASKED: element j of item i is real iff 4*lane + j < cnt_i (padding ORs nothing).
 template <int BM_OFF, bool MASKED>
-__device__ __forceinline__ void s1_core8(const unsigned (&c)[8], const unsigned (&one)[8], unsigned amask, unsigned (&seen)[8]) {
-    unsigned a0, a1, a2, a3, a4, a5, a6, a7, b0, b1, b2, b3, b4, b5, b6, b7;
+__device__ __forceinline__ void s1_core8(const unsigned (&c)[8], int lane4, int cnt0, int cnt1, unsigned amask, unsigned (&seen)[8]) {
+    unsigned a0, a1;
     if (!MASKED) {
         asm volatile(
-            "v_lshrrev_b32 %[a0], 3, %[c0]\n\t"
-            "v_lshrrev_b32 %[a1], 3, %[c1]\n\t"
-            "v_lshrrev_b32 %[a2], 3, %[c2]\n\t"
-            "v_lshrrev_b32 %[a3], 3, %[c3]\n\t"
-            "v_lshrrev_b32 %[a4], 3, %[c4]\n\t"
-            "v_lshrrev_b32 %[a5], 3, %[c5]\n\t"
-            "v_lshrrev_b32 %[a6], 3, %[c6]\n\t"
-            "v_lshrrev_b32 %[a7], 3, %[c7]\n\t"
             "v_lshlrev_b32_e64 %[b0], %[c0], 1\n\t"
-            "v_lshlrev_b32_e64 %[b1], %[c1], 1\n\t"
-            "v_lshlrev_b32_e64 %[b2], %[c2], 1\n\t"
-            "v_lshlrev_b32_e64 %[b3], %[c3], 1\n\t"
-            "v_lshlrev_b32_e64 %[b4], %[c4], 1\n\t"
-            "v_lshlrev_b32_e64 %[b5], %[c5], 1\n\t"
-            "v_lshlrev_b32_e64 %[b6], %[c6], 1\n\t"
-            "v_lshlrev_b32_e64 %[b7], %[c7], 1\n\t"
+            "v_lshrrev_b32 %[a0], 3, %[c0]\n\t"
             "v_and_b32 %[a0], %[am], %[a0]\n\t"
-            "v_and_b32 %[a1], %[am], %[a1]\n\t"
-            "v_and_b32 %[a2], %[am], %[a2]\n\t"
-            "v_and_b32 %[a3], %[am], %[a3]\n\t"
-            "v_and_b32 %[a4], %[am], %[a4]\n\t"
-            "v_and_b32 %[a5], %[am], %[a5]\n\t"
-            "v_and_b32 %[a6], %[am], %[a6]\n\t"
-            "v_and_b32 %[a7], %[am], %[a7]\n\t"
             "ds_or_rtn_b32 %[b0], %[a0], %[b0] offset:%[off]\n\t"
+            "v_lshlrev_b32_e64 %[b1], %[c1], 1\n\t"
+            "v_lshrrev_b32 %[a1], 3, %[c1]\n\t"
+            "v_and_b32 %[a1], %[am], %[a1]\n\t"
             "ds_or_rtn_b32 %[b1], %[a1], %[b1] offset:%[off]\n\t"
-            "ds_or_rtn_b32 %[b2], %[a2], %[b2] offset:%[off]\n\t"
-            "ds_or_rtn_b32 %[b3], %[a3], %[b3] offset:%[off]\n\t"
-            "ds_or_rtn_b32 %[b4], %[a4], %[b4] offset:%[off]\n\t"
-            "ds_or_rtn_b32 %[b5], %[a5], %[b5] offset:%[off]\n\t"
-            "ds_or_rtn_b32 %[b6], %[a6], %[b6] offset:%[off]\n\t"
-            "ds_or_rtn_b32 %[b7], %[a7], %[b7] offset:%[off]\n\t"
+            "v_lshlrev_b32_e64 %[b2], %[c2], 1\n\t"
+            "v_lshrrev_b32 %[a0], 3, %[c2]\n\t"
+            "v_and_b32 %[a0], %[am], %[a0]\n\t"
+            "ds_or_rtn_b32 %[b2], %[a0], %[b2] offset:%[off]\n\t"
+            "v_lshlrev_b32_e64 %[b3], %[c3], 1\n\t"
+            "v_lshrrev_b32 %[a1], 3, %[c3]\n\t"
+            "v_and_b32 %[a1], %[am], %[a1]\n\t"
+            "ds_or_rtn_b32 %[b3], %[a1], %[b3] offset:%[off]\n\t"
+            "v_lshlrev_b32_e64 %[b4], %[c4], 1\n\t"
+            "v_lshrrev_b32 %[a0], 3, %[c4]\n\t"
+            "v_and_b32 %[a0], %[am], %[a0]\n\t"
+            "ds_or_rtn_b32 %[b4], %[a0], %[b4] offset:%[off]\n\t"
+            "v_lshlrev_b32_e64 %[b5], %[c5], 1\n\t"
+            "v_lshrrev_b32 %[a1], 3, %[c5]\n\t"
+            "v_and_b32 %[a1], %[am], %[a1]\n\t"
+            "ds_or_rtn_b32 %[b5], %[a1], %[b5] offset:%[off]\n\t"
+            "v_lshlrev_b32_e64 %[b6], %[c6], 1\n\t"
+            "v_lshrrev_b32 %[a0], 3, %[c6]\n\t"
+            "v_and_b32 %[a0], %[am], %[a0]\n\t"
+            "ds_or_rtn_b32 %[b6], %[a0], %[b6] offset:%[off]\n\t"
+            "v_lshlrev_b32_e64 %[b7], %[c7], 1\n\t"
+            "v_lshrrev_b32 %[a1], 3, %[c7]\n\t"
+            "v_and_b32 %[a1], %[am], %[a1]\n\t"
+            "ds_or_rtn_b32 %[b7], %[a1], %[b7] offset:%[off]\n\t"
             "s_waitcnt lgkmcnt(0)\n\t"
             "v_bfe_u32 %[b0], %[b0], %[c0], 1\n\t"
             "v_bfe_u32 %[b1], %[b1], %[c1], 1\n\t"
@@ -516,65 +517,89 @@ __device__ __forceinline__ void s1_core8(const unsigned (&c)[8], const unsigned 
             "v_bfe_u32 %[b5], %[b5], %[c5], 1\n\t"
             "v_bfe_u32 %[b6], %[b6], %[c6], 1\n\t"
             "v_bfe_u32 %[b7], %[b7], %[c7], 1\n\t"
-            : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [a4] "=&v"(a4), [a5] "=&v"(a5), [a6] "=&v"(a6), [a7] "=&v"(a7), [b0] "=&v"(b0), [b1] "=&v"(b1), [b2] "=&v"(b2), [b3] "=&v"(b3), [b4] "=&v"(b4), [b5] "=&v"(b5), [b6] "=&v"(b6), [b7] "=&v"(b7)
+            : [a0] "=&v"(a0), [a1] "=&v"(a1), [b0] "=&v"(seen[0]), [b1] "=&v"(seen[1]), [b2] "=&v"(seen[2]), [b3] "=&v"(seen[3]), [b4] "=&v"(seen[4]), [b5] "=&v"(seen[5]), [b6] "=&v"(seen[6]), [b7] "=&v"(seen[7])
             : [c0] "v"(c[0]), [c1] "v"(c[1]), [c2] "v"(c[2]), [c3] "v"(c[3]), [c4] "v"(c[4]), [c5] "v"(c[5]), [c6] "v"(c[6]), [c7] "v"(c[7]), [am] "s"(amask), [off] "i"(BM_OFF)
             : "memory");
     } else {
+        const int d0 = cnt0 - lane4, d1 = cnt1 - lane4;      // element j is real iff j < d
         asm volatile(
+            "v_cmp_lt_i32 vcc, 0, %[d0]\n\t"
+            "v_cndmask_b32 %[b0], 0, 1, vcc\n\t"
+            "v_lshlrev_b32 %[b0], %[c0], %[b0]\n\t"
             "v_lshrrev_b32 %[a0], 3, %[c0]\n\t"
-            "v_lshrrev_b32 %[a1], 3, %[c1]\n\t"
-            "v_lshrrev_b32 %[a2], 3, %[c2]\n\t"
-            "v_lshrrev_b32 %[a3], 3, %[c3]\n\t"
-            "v_lshrrev_b32 %[a4], 3, %[c4]\n\t"
-            "v_lshrrev_b32 %[a5], 3, %[c5]\n\t"
-            "v_lshrrev_b32 %[a6], 3, %[c6]\n\t"
-            "v_lshrrev_b32 %[a7], 3, %[c7]\n\t"
-            "v_lshlrev_b32 %[b0], %[c0], %[o0]\n\t"
-            "v_lshlrev_b32 %[b1], %[c1], %[o1]\n\t"
-            "v_lshlrev_b32 %[b2], %[c2], %[o2]\n\t"
-            "v_lshlrev_b32 %[b3], %[c3], %[o3]\n\t"
-            "v_lshlrev_b32 %[b4], %[c4], %[o4]\n\t"
-            "v_lshlrev_b32 %[b5], %[c5], %[o5]\n\t"
-            "v_lshlrev_b32 %[b6], %[c6], %[o6]\n\t"
-            "v_lshlrev_b32 %[b7], %[c7], %[o7]\n\t"
             "v_and_b32 %[a0], %[am], %[a0]\n\t"
-            "v_and_b32 %[a1], %[am], %[a1]\n\t"
-            "v_and_b32 %[a2], %[am], %[a2]\n\t"
-            "v_and_b32 %[a3], %[am], %[a3]\n\t"
-            "v_and_b32 %[a4], %[am], %[a4]\n\t"
-            "v_and_b32 %[a5], %[am], %[a5]\n\t"
-            "v_and_b32 %[a6], %[am], %[a6]\n\t"
-            "v_and_b32 %[a7], %[am], %[a7]\n\t"
             "ds_or_rtn_b32 %[b0], %[a0], %[b0] offset:%[off]\n\t"
+            "v_cmp_lt_i32 vcc, 1, %[d0]\n\t"
+            "v_cndmask_b32 %[b1], 0, 1, vcc\n\t"
+            "v_lshlrev_b32 %[b1], %[c1], %[b1]\n\t"
+            "v_lshrrev_b32 %[a1], 3, %[c1]\n\t"
+            "v_and_b32 %[a1], %[am], %[a1]\n\t"
             "ds_or_rtn_b32 %[b1], %[a1], %[b1] offset:%[off]\n\t"
-            "ds_or_rtn_b32 %[b2], %[a2], %[b2] offset:%[off]\n\t"
-            "ds_or_rtn_b32 %[b3], %[a3], %[b3] offset:%[off]\n\t"
-            "ds_or_rtn_b32 %[b4], %[a4], %[b4] offset:%[off]\n\t"
-            "ds_or_rtn_b32 %[b5], %[a5], %[b5] offset:%[off]\n\t"
-            "ds_or_rtn_b32 %[b6], %[a6], %[b6] offset:%[off]\n\t"
-            "ds_or_rtn_b32 %[b7], %[a7], %[b7] offset:%[off]\n\t"
+            "v_cmp_lt_i32 vcc, 2, %[d0]\n\t"
+            "v_cndmask_b32 %[b2], 0, 1, vcc\n\t"
+            "v_lshlrev_b32 %[b2], %[c2], %[b2]\n\t"
+            "v_lshrrev_b32 %[a0], 3, %[c2]\n\t"
+            "v_and_b32 %[a0], %[am], %[a0]\n\t"
+            "ds_or_rtn_b32 %[b2], %[a0], %[b2] offset:%[off]\n\t"
+            "v_cmp_lt_i32 vcc, 3, %[d0]\n\t"
+            "v_cndmask_b32 %[b3], 0, 1, vcc\n\t"
+            "v_lshlrev_b32 %[b3], %[c3], %[b3]\n\t"
+            "v_lshrrev_b32 %[a1], 3, %[c3]\n\t"
+            "v_and_b32 %[a1], %[am], %[a1]\n\t"
+            "ds_or_rtn_b32 %[b3], %[a1], %[b3] offset:%[off]\n\t"
+            "v_cmp_lt_i32 vcc, 0, %[d1]\n\t"
+            "v_cndmask_b32 %[b4], 0, 1, vcc\n\t"
+            "v_lshlrev_b32 %[b4], %[c4], %[b4]\n\t"
+            "v_lshrrev_b32 %[a0], 3, %[c4]\n\t"
+            "v_and_b32 %[a0], %[am], %[a0]\n\t"
+            "ds_or_rtn_b32 %[b4], %[a0], %[b4] offset:%[off]\n\t"
+            "v_cmp_lt_i32 vcc, 1, %[d1]\n\t"
+            "v_cndmask_b32 %[b5], 0, 1, vcc\n\t"
+            "v_lshlrev_b32 %[b5], %[c5], %[b5]\n\t"
+            "v_lshrrev_b32 %[a1], 3, %[c5]\n\t"
+            "v_and_b32 %[a1], %[am], %[a1]\n\t"
+            "ds_or_rtn_b32 %[b5], %[a1], %[b5] offset:%[off]\n\t"
+            "v_cmp_lt_i32 vcc, 2, %[d1]\n\t"
+            "v_cndmask_b32 %[b6], 0, 1, vcc\n\t"
+            "v_lshlrev_b32 %[b6], %[c6], %[b6]\n\t"
+            "v_lshrrev_b32 %[a0], 3, %[c6]\n\t"
+            "v_and_b32 %[a0], %[am], %[a0]\n\t"
+            "ds_or_rtn_b32 %[b6], %[a0], %[b6] offset:%[off]\n\t"
+            "v_cmp_lt_i32 vcc, 3, %[d1]\n\t"
+            "v_cndmask_b32 %[b7], 0, 1, vcc\n\t"
+            "v_lshlrev_b32 %[b7], %[c7], %[b7]\n\t"
+            "v_lshrrev_b32 %[a1], 3, %[c7]\n\t"
+            "v_and_b32 %[a1], %[am], %[a1]\n\t"
+            "ds_or_rtn_b32 %[b7], %[a1], %[b7] offset:%[off]\n\t"
             "s_waitcnt lgkmcnt(0)\n\t"
             "v_bfe_u32 %[b0], %[b0], %[c0], 1\n\t"
+            "v_cmp_lt_i32 vcc, 0, %[d0]\n\t"
+            "v_cndmask_b32 %[b0], 0, %[b0], vcc\n\t"
             "v_bfe_u32 %[b1], %[b1], %[c1], 1\n\t"
+            "v_cmp_lt_i32 vcc, 1, %[d0]\n\t"
+            "v_cndmask_b32 %[b1], 0, %[b1], vcc\n\t"
             "v_bfe_u32 %[b2], %[b2], %[c2], 1\n\t"
+            "v_cmp_lt_i32 vcc, 2, %[d0]\n\t"
+            "v_cndmask_b32 %[b2], 0, %[b2], vcc\n\t"
             "v_bfe_u32 %[b3], %[b3], %[c3], 1\n\t"
+            "v_cmp_lt_i32 vcc, 3, %[d0]\n\t"
+            "v_cndmask_b32 %[b3], 0, %[b3], vcc\n\t"
             "v_bfe_u32 %[b4], %[b4], %[c4], 1\n\t"
+            "v_cmp_lt_i32 vcc, 0, %[d1]\n\t"
+            "v_cndmask_b32 %[b4], 0, %[b4], vcc\n\t"
             "v_bfe_u32 %[b5], %[b5], %[c5], 1\n\t"
+            "v_cmp_lt_i32 vcc, 1, %[d1]\n\t"
+            "v_cndmask_b32 %[b5], 0, %[b5], vcc\n\t"
             "v_bfe_u32 %[b6], %[b6], %[c6], 1\n\t"
+            "v_cmp_lt_i32 vcc, 2, %[d1]\n\t"
+            "v_cndmask_b32 %[b6], 0, %[b6], vcc\n\t"
             "v_bfe_u32 %[b7], %[b7], %[c7], 1\n\t"
-            "v_and_b32 %[b0], %[b0], %[o0]\n\t"
-            "v_and_b32 %[b1], %[b1], %[o1]\n\t"
-            "v_and_b32 %[b2], %[b2], %[o2]\n\t"
-            "v_and_b32 %[b3], %[b3], %[o3]\n\t"
-            "v_and_b32 %[b4], %[b4], %[o4]\n\t"
-            "v_and_b32 %[b5], %[b5], %[o5]\n\t"
-            "v_and_b32 %[b6], %[b6], %[o6]\n\t"
-            "v_and_b32 %[b7], %[b7], %[o7]\n\t"
-            : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [a4] "=&v"(a4), [a5] "=&v"(a5), [a6] "=&v"(a6), [a7] "=&v"(a7), [b0] "=&v"(b0), [b1] "=&v"(b1), [b2] "=&v"(b2), [b3] "=&v"(b3), [b4] "=&v"(b4), [b5] "=&v"(b5), [b6] "=&v"(b6), [b7] "=&v"(b7)
-            : [c0] "v"(c[0]), [c1] "v"(c[1]), [c2] "v"(c[2]), [c3] "v"(c[3]), [c4] "v"(c[4]), [c5] "v"(c[5]), [c6] "v"(c[6]), [c7] "v"(c[7]), [o0] "v"(one[0]), [o1] "v"(one[1]), [o2] "v"(one[2]), [o3] "v"(one[3]), [o4] "v"(one[4]), [o5] "v"(one[5]), [o6] "v"(one[6]), [o7] "v"(one[7]), [am] "s"(amask), [off] "i"(BM_OFF)
-            : "memory");
+            "v_cmp_lt_i32 vcc, 3, %[d1]\n\t"
+            "v_cndmask_b32 %[b7], 0, %[b7], vcc\n\t"
+            : [a0] "=&v"(a0), [a1] "=&v"(a1), [b0] "=&v"(seen[0]), [b1] "=&v"(seen[1]), [b2] "=&v"(seen[2]), [b3] "=&v"(seen[3]), [b4] "=&v"(seen[4]), [b5] "=&v"(seen[5]), [b6] "=&v"(seen[6]), [b7] "=&v"(seen[7])
+            : [c0] "v"(c[0]), [c1] "v"(c[1]), [c2] "v"(c[2]), [c3] "v"(c[3]), [c4] "v"(c[4]), [c5] "v"(c[5]), [c6] "v"(c[6]), [c7] "v"(c[7]), [d0] "v"(d0), [d1] "v"(d1), [am] "s"(amask), [off] "i"(BM_OFF)
+            : "memory", "vcc");
     }
-    seen[0] = b0; seen[1] = b1; seen[2] = b2; seen[3] = b3; seen[4] = b4; seen[5] = b5; seen[6] = b6; seen[7] = b7;
 }
 
 // Sweep 2, four products per lane: x = value * segv, M[j] = lanes whose column is marked in the collision bitmap

@@ -284,8 +284,8 @@ int run_device(sp_knn_args *a) {
         int4 *desc_s = (int4 *)(ws_rows + c.ws_desc_offset);            // [2n]
         int4 *desc_g = desc_s + 2 * (size_t)a->n_targets;               // [2n]
         HIP_TRY(hipMemsetAsync(ws_rows, 0, 512, stream));
-        const int waves_per_block = 256 / 64;
-        hipLaunchKernelGGL(sp_row_work_kernel, dim3((a->n_targets + waves_per_block - 1) / waves_per_block), dim3(256), 0, stream,
+        const int work_blocks = std::max(1, std::min((a->n_targets + 15) / 16, n_cus * 8));     // 16 rows (waves) per block and trip
+        hipLaunchKernelGGL(sp_row_work_kernel, dim3(work_blocks), dim3(1024), 0, stream,
                            a->n_targets, a->targets, a->m1_indices, a->m1_indptr, a->m2_indptr, work, bucket_count);
         if (c.ordered) {
             hipLaunchKernelGGL(sp_bucket_base_kernel, dim3(1), dim3(64), 0, stream, bucket_count, bucket_base);

@@ -300,18 +300,8 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 auto body = [&](const unsigned (&c)[8], int cnt0, int cnt1) __attribute__((always_inline)) {
                     if (cnt0 == 0) return;                 // sentinel pair (wave-uniform; the second item of a pair may be the sentinel)
                     unsigned seen[8];
-                    if (cnt0 == ITEM && cnt1 == ITEM) {
-                        s1_core8<CBM_BYTES + PRE_BYTES, false>(c, c, amask, seen);
-                    } else {
-                        // padding ORs nothing (into whatever word the over-fetched column names: spread, no serialisation)
-                        unsigned one[8];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            one[j] = (4 * lane + j < cnt0) ? 1u : 0u;
-                            one[4 + j] = (4 * lane + j < cnt1) ? 1u : 0u;
-                        }
-                        s1_core8<CBM_BYTES + PRE_BYTES, true>(c, one, amask, seen);
-                    }
+                    if (cnt0 == ITEM && cnt1 == ITEM) s1_core8<CBM_BYTES + PRE_BYTES, false>(c, 4 * lane, cnt0, cnt1, amask, seen);
+                    else s1_core8<CBM_BYTES + PRE_BYTES, true>(c, 4 * lane, cnt0, cnt1, amask, seen);      // padding ORs nothing
                     // ~2 % of the products find their column already there: mark it in the collision bitmap
                     if (__ballot(((seen[0] | seen[1]) | (seen[2] | seen[3]) | (seen[4] | seen[5]) | (seen[6] | seen[7])) != 0u)) {
 #pragma unroll
@@ -324,7 +314,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 const int n_trips = (n_mine + 1) / 2;
                 int trip = 0;
                 ld(0, cA, nA0, nA1);
-                while (trip < n_trips) {      // two pairs in flight per wave; bodies skip the sentinel
+                while (trip < n_trips) {      // two pairs (4 KiB) in flight per wave (a third measured slower); bodies skip the sentinel
                     ld(trip + 1, cB, nB0, nB1);
                     __builtin_amdgcn_sched_barrier(0);     // the prefetch is issued before the current pair is waited for
                     body(cA, nA0, nA1);
