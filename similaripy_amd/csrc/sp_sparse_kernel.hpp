@@ -360,7 +360,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                         ((u64 *)pre16)[i] = packed;
                     }
                     carry += all;
-                    __syncthreads();
+                    if (CBM_BYTES / 16 > NT) __syncthreads();     // (sh[SH_WSUM] is reused by the next trip)
                 }
                 if (carry > CSN / 2) failed = true;      // more marked columns than direct slots (uniform)
             }
@@ -757,7 +757,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     const bool want_sel = retry || (last_stage ? (n_eff > p.k) : (n_eff > p.k && (!rc.have_thr || 2 * n_eff > cap + p.k)));
                     if (want_sel) {
                         long long thr_new;
-                        if (cap <= SEL_E * NT) thr_new = select_fast<NT, MONO, SEL_E>(U, hist4, sh, p.k, last_stage && !retry);
+                        if (cap <= SEL_E * NT) thr_new = select_fast<NT, true, SEL_E>(U, hist4, sh, p.k, last_stage && !retry);
                         else {
                             thr_new = compact_topk<NT>(U, hist4, sh, p.k);
                             if constexpr (MONO) {     // block-wise reservations: nothing stale may stay behind the kept entries
@@ -842,8 +842,11 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             }
             if (tid == 0 && p.counts) p.counts[slot_i] = n_out;
             if (U_LDS || MONO) {
-                __syncthreads();     // U read before it is cleared: its storage is part of the next row's bitmap (LDS) / holes must read zero (MONO)
-                for (int i = tid; i < cap / 2; i += NT) ((int4 *)U)[i] = make_int4(0, 0, 0, 0);
+                // U's storage is part of the next row's bitmap (LDS) / holes must read zero (MONO).  Every selection zeroes
+                // what lies behind the entries it keeps, so only the first k entries can be non-zero here.
+                __syncthreads();     // U read before it is cleared
+                const int dirty = (cap <= SEL_E * NT) ? min(cap, p.k + 2) : cap;
+                for (int i = tid; i < (dirty + 1) / 2; i += NT) ((int4 *)U)[i] = make_int4(0, 0, 0, 0);
             }
             if (timing) ph[CT_ROWS_SPARSE] += 1;
         } else {
