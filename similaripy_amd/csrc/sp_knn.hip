@@ -68,7 +68,7 @@ struct Config {
     int nb_log2;            // sparse kernel: bitmap bits (log2)
     size_t ws_total;
     bool fold;
-    bool mono;              // the sparse kernel's monotone variant applies (val = xy / den or the raw dot, no row selectors)
+    bool mono;              // the sparse kernel's monotone variant applies (val = xy / den or the raw dot, no per-row target selector)
     bool ordered;
 };
 
@@ -130,7 +130,7 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
     c->fold = !(a->flags & SP_FLAG_NO_FOLD) && a->l1 == 0.f && a->a1 == 1.f && a->stabilized_shrink == 0.f &&
               a->bayesian_shrink == 0.f && ((a->l2 != 0.f) != (a->l3 != 0.f)) && a->nnz_m2 > 0;
     const bool any_norm = a->l1 != 0.f || a->l2 != 0.f || a->l3 != 0.f || a->stabilized_shrink != 0.f || a->bayesian_shrink != 0.f;
-    c->mono = (c->fold || !any_norm) && a->filter_mode != SP_SEL_MATRIX && a->target_col_mode != SP_SEL_MATRIX;
+    c->mono = (c->fold || !any_norm) && a->target_col_mode != SP_SEL_MATRIX;      // (a MATRIX filter is handled through the collision bitmap)
     c->ws_fold_bytes = c->fold ? (((size_t)a->nnz_m2 * 4 + 255) & ~(size_t)255) : 0;
     c->ordered = !(a->flags & (SP_FLAG_STATIC_SCHED | SP_FLAG_NO_ROW_ORDER)) && a->n_targets > std::min(c->wgs_sparse, c->wgs_generic);
     // 512 B of bucket counters | work[n] | order[n] | (32-byte aligned) sparse queue n x 32 B | generic queue n x 32 B

@@ -21,8 +21,8 @@
 namespace {
 
 // MONO: the similarity is a monotone function of the raw dot alone — val = xy / den with a per-row den > 0 (cosine-type
-// epilogues whose column term is folded into the m2 stream) or val = xy (no normalisation) — and no per-row column
-// selector is active.  Then the whole top-k runs on the raw dot: survivors go straight from the sweep into the
+// epilogues whose column term is folded into the m2 stream) or val = xy (no normalisation) — and no per-row TARGET
+// selector is active (a per-row FILTER is: its columns are pre-marked in the collision bitmap and dropped at the scan).  Then the whole top-k runs on the raw dot: survivors go straight from the sweep into the
 // candidate buffer (no survivor pool, no judge phase), the running k-th raw dot IS the cutoff, and the epilogue is
 // applied to the k winners at write-out.
 template <int NT, bool U_LDS, bool MONO>
@@ -324,6 +324,18 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     trip += 2;
                 }
             }
+            if constexpr (MONO) {
+                // MATRIX filter (s_plus.h:159-171): the row's excluded columns are marked in the collision bitmap, so all
+                // their products gather in the collision set, where the excluded columns are dropped at the scan
+                // (the filter row's bounds are re-read where they are needed instead of living in registers through the sweeps)
+                if (p.filter_mode == SP_SEL_MATRIX) {
+                    const int f0 = __builtin_amdgcn_readfirstlane(p.f_indptr[t]), f1 = __builtin_amdgcn_readfirstlane(p.f_indptr[t + 1]);
+                    for (int i = f0 + tid; i < f1; i += NT) {
+                        const unsigned c = (unsigned)p.f_indices[i];
+                        atomicOr((unsigned *)(cbm + ((c >> 3) & cmask)), 1u << (c & 31u));
+                    }
+                }
+            }
             __syncthreads();
             PHASE_END(PH_SWEEP1);
             // next row's m2 row bounds (its m1 entries were requested at the top of this row)
@@ -384,8 +396,9 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             // in descending weight — so the next chunk may be 4*n*(cap-k)/k long.
             const int room = cap - min(p.k, cap - 1);
             int i0 = 0;
-            long long chunk = MONO ? room : min(room, spcap - 2 * ITEM);
+            int chunk_items = max(1, (MONO ? room : min(room, spcap - 2 * ITEM)) / ITEM);     // items of the next stage
             bool last_stage = false;
+            bool force_sel = false;
             WavePool wpm{0, -1};      // member-pool window: lives across the stages of the row
 
             // ---- MONO, first stage without any selection.  One item per wave (the first NW items: the heaviest
@@ -398,7 +411,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             if constexpr (MONO) {
                 const int NA = min(n_items, NW);
                 const int mrounds = (p.k + NA - 1) / NA + 2;
-                if (NA == NW && mrounds <= 16) {
+                if (NA == NW && mrounds <= 16) {     // (k <= 14*NW; larger k: the accept-everything first stage of the loop below)
                     unsigned c[4];
                     float v[4], x[4];
                     u64 M[4], S[4];
@@ -425,8 +438,16 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     // m-th largest (distinct) lane maximum of this wave — fewer rounds for a wave with fewer candidate lanes
                     // (a partial item), so that its looser statistics do not drag the common cutoff down; whether k
                     // products reach the cutoff is counted exactly below
-                    const int cand_lanes = __popcll(__ballot(lmax != 0u));
-                    const int my_rounds = max(1, (mrounds * cand_lanes + 63) / 64);
+                    // rounds in proportion to the wave's share of the stage's lanes (item lengths are in the descriptors:
+                    // no reduction needed), k + 2*NW ranks in total
+                    int my_rounds;
+                    {
+                        const int lw = (lane < NW) ? (items[lane].y + 3) / 4 : 0;              // lanes of item `lane`
+                        const int lanes_all = wave_incl_scan_dpp(lw);                          // lane 63: the sum
+                        const int L = max(1, __builtin_amdgcn_readlane(lanes_all, 63));
+                        const int mine = (cntA + 3) / 4;
+                        my_rounds = max(1, min(24, ((p.k + 2 * NW) * mine + L - 1) / L));
+                    }
                     unsigned rest = lmax, tw = 0u;
                     for (int r = 0; r < my_rounds; ++r) {
                         const unsigned mx = wave_max_u32(rest);
@@ -446,8 +467,8 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     if (lane == 0 && cw) atomicAdd(&sh[SH_NEED], cw);
                     __syncthreads();
                     const int totalA = sh[SH_NEED];
-                    const bool fits = totalA <= room && totalA >= p.k;   // uniform: k products reach g (so it is a valid cutoff) and they fit
-                    const int nfull = max(1, room / ITEM);              // fallback: the first nfull items, everything accepted
+                    const bool fits = totalA <= room / 2 && totalA >= p.k;   // uniform: k products reach g (so it is a valid cutoff) and they leave U half empty
+                    const int nfull = max(1, (room / 2) / ITEM);        // fallback: the first nfull items, everything accepted (U at most half full)
                     if (fits || wave < nfull) {
                         if (!fits) {
 #pragma unroll
@@ -487,8 +508,14 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     __syncthreads();
                     if (sh[SH_OVF]) failed = true;
                     // (not fitting: U now holds everything of the first nfull items; the next stage's selection trims it)
-                    chunk = fits ? max((long long)ITEM, (long long)items[min(i0, n_items)].w * (long long)(cap - min(sh[SH_CNT], cap)) / (2ll * (long long)p.k))
-                                 : (long long)ITEM;
+                    {
+                        // (float arithmetic: a 64-bit integer division is ~100 instructions on every wave)
+                        const float left = (float)(cap - min(sh[SH_CNT], cap));
+                        const float pos = (float)items[min(i0, n_items)].w;
+                        const float ch = fits ? 2.f * pos * left / (float)max(2 * p.k, totalA) : 0.5f * left;      // !fits: no cutoff yet, everything is accepted
+                        chunk_items = max(1, (int)fminf(ch * (1.f / ITEM), 1e6f));
+                        force_sel = fits && totalA > 8 * p.k;
+                    }
                     PHASE_END(PH_SWEEP2);
                 }
             }
@@ -496,7 +523,9 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 // (all items went through the first stage: let the loop run its last-stage part with an empty sweep)
             }
             while (!last_stage && !failed) {
-                const int i1 = (int)min((long long)n_items, (long long)i0 + max(1ll, chunk / ITEM));
+                // (force_sel: the first stage's cutoff is loose — far more than k products reached it: tighten it with a
+                // selection before sweeping on, i.e. run this round with an empty sweep)
+                const int i1 = (force_sel && i0 < n_items) ? i0 : min(n_items, i0 + chunk_items);
                 {
                     // ---- sweep 2 over items [i0, i1) ----
                     WavePool wps{0, -1};
@@ -599,7 +628,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     }
                 }
                 i0 = i1;
-                last_stage = (i0 >= n_items);
+                last_stage = (i0 >= n_items);      // (an empty first round with i0 < n_items is never the last)
                 __syncthreads();
                 const int ext = min(sh[SH_PCTR], spcap);
                 const int mext = min(sh[SH_MCTR], mpcap);
@@ -682,6 +711,12 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                             }
 #pragma unroll
                             for (int j = 0; j < 4; ++j) want[j] = (e[j] != 0ull) && !(__uint_as_float((unsigned)e[j]) <= cutx);
+                            if (p.filter_mode == SP_SEL_MATRIX) {      // (uniform) excluded columns of this row
+                                const int f0 = __builtin_amdgcn_readfirstlane(p.f_indptr[t]), f1 = __builtin_amdgcn_readfirstlane(p.f_indptr[t + 1]);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    if (want[j] && range_has(p.f_indices, f0, f1, (int)((unsigned)(e[j] >> 32) - 1u))) want[j] = false;
+                            }
                             const u64 m0 = __ballot(want[0]), m1 = __ballot(want[1]), m2 = __ballot(want[2]), m3 = __ballot(want[3]);
                             const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
                             int wbase = 0;
@@ -754,7 +789,8 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     // selection: forced when U overflowed; exact after the last stage (final top-k); between stages
                     // when U is filling up (it raises the running k-th value, which is the cutoff of the next stage)
                     const int n_eff = min(n_now, cap);
-                    const bool want_sel = retry || (last_stage ? (n_eff > p.k) : (n_eff > p.k && (!rc.have_thr || 2 * n_eff > cap + p.k)));
+                    const bool want_sel = retry || (last_stage ? (n_eff > p.k) : (n_eff > p.k && (!rc.have_thr || force_sel || 2 * n_eff > cap + p.k)));
+                    force_sel = false;
                     if (want_sel) {
                         long long thr_new;
                         if (cap <= SEL_E * NT) thr_new = select_fast<NT, true, SEL_E>(U, hist4, sh, p.k, last_stage && !retry);
@@ -780,10 +816,14 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 // next chunk: with the k-th best of `pos` products as cutoff, an exchangeable stream lets k*m/pos of the
                 // next m products through; keep that below half of the room left in U (far fewer pass when the
                 // segments come in descending weight)
-                const long long pos = (i0 < n_items) ? (long long)items[i0].w : (long long)macs32;
-                const long long left = max(64, cap - min(sh[SH_CNT], cap));
-                chunk = rc.have_thr ? max((long long)ITEM, pos * left / (2ll * (long long)p.k)) : (long long)room;
-                if (!MONO) chunk = max(chunk, (long long)room);
+                const float pos = (i0 < n_items) ? (float)items[i0].w : (float)macs32;
+                const float left = (float)max(64, cap - min(sh[SH_CNT], cap));
+                // (the cutoff is the value that `cnt` of the `pos` products offered so far reach: cnt ~ k after a selection, more
+                // after the selection-free first stage)
+                const float cnt_u = (float)max(2 * p.k, min(sh[SH_CNT], cap));
+                float ch = rc.have_thr ? fmaxf((float)ITEM, 2.f * pos * left / cnt_u) : (float)room;
+                if (!MONO) ch = fmaxf(ch, (float)room);
+                chunk_items = max(1, (int)fminf(ch * (1.f / ITEM), 1e6f));
             }
         }
 
@@ -841,6 +881,15 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 }
             }
             if (tid == 0 && p.counts) p.counts[slot_i] = n_out;
+            if constexpr (MONO) {
+                if (p.filter_mode == SP_SEL_MATRIX) {      // marks of excluded columns that no product reached
+                    const int f0 = __builtin_amdgcn_readfirstlane(p.f_indptr[t]), f1 = __builtin_amdgcn_readfirstlane(p.f_indptr[t + 1]);
+                    for (int i = f0 + tid; i < f1; i += NT) {
+                        const unsigned c = (unsigned)p.f_indices[i];
+                        atomicAnd((unsigned *)(cbm + ((c >> 3) & cmask)), ~(1u << (c & 31u)));
+                    }
+                }
+            }
             if (U_LDS || MONO) {
                 // U's storage is part of the next row's bitmap (LDS) / holes must read zero (MONO).  Every selection zeroes
                 // what lies behind the entries it keeps, so only the first k entries can be non-zero here.

@@ -319,3 +319,23 @@ def test_sparse_kernel_small_pools_give_up_to_generic():
     _check(call, "T=2048", table_slots=2048)
     pc = _info(call, table_slots=2048)
     assert pc[9] + pc[10] >= 1
+
+
+def test_sparse_kernel_row_selectors():
+    """User-scoring shape (BASELINE configs[4]): dot_product(urm, W.T, filter_cols=urm).  The monotone variant handles the
+    MATRIX filter through its collision bitmap; a MATRIX target selector takes the general variant's judge."""
+    rng = np.random.default_rng(31)
+    urm = sp.random_array((20000, 30000), density=0.002, format="csr", dtype=np.float32, random_state=rng)     # ~60 items per user
+    w = sp.random_array((30000, 30000), density=0.001, format="csr", dtype=np.float32, random_state=rng)     # ~30 neighbours per item
+    t = np.arange(0, 20000, 9)
+    for kw in (dict(filter_cols=urm), dict(filter_cols=urm, l2=1), dict(target_cols=urm), dict(filter_cols=urm, target_cols=list(range(0, 30000, 2)))):
+        call = _host.prepare(urm, w, k=40, target_rows=t, **kw)
+        counts = _check(call, f"sparse selectors {sorted(kw)}")
+        pc = _info(call)
+        assert pc[9] + pc[10] == call.n_targets - int((np.diff(call.m1_indptr)[call.targets] == 0).sum()) or pc[9] > 0
+    # nothing a user already has may be recommended
+    call = _host.prepare(urm, w, k=40, target_rows=t, filter_cols=urm)
+    rows, cols, vals, counts = _host.run_hip(call)
+    for i, u in enumerate(t[:200]):
+        have = urm.indices[urm.indptr[u]:urm.indptr[u + 1]]
+        assert not np.intersect1d(cols[i * 40:i * 40 + counts[i]], have).size
