@@ -60,7 +60,7 @@ struct KParams {
     int sparse_path;       // 1 = rows with few expected collisions take the bitmap path
     int fold;              // 1 = the single active column term (Ycos or Ydep) is already divided into m2_data: treat it as 1
     unsigned long long *phase_cycles;  // optional [PH_N]
-    int dbg;               // ablation bits for profiling only (results are WRONG when non-zero):
+    int dbg;               // ablation bits for profiling only (results are WRONG when non-zero; 8 / 16: sweep 1 / sweep 2 of the sparse kernel load but do not process):
                            // 1 = generic accumulate: no LDS inserts, 4 = no Y gathers
 };
 
@@ -648,9 +648,12 @@ __device__ __forceinline__ void s2_core(const unsigned (&c)[4], const float (&v)
 
 // Append the 8-byte entries {lo, hi} of the lanes in `m` to an LDS list at byte offset `base_off` (wave-uniform),
 // starting at entry `pos` (wave-uniform): lane rank by v_mbcnt, exec narrowed to `m` around the two stores.
-__device__ __forceinline__ void lds_push64(u64 m, unsigned lo, unsigned hi, int pos, unsigned base_off) {
+__device__ __forceinline__ void lds_push64(u64 m_in, unsigned lo, unsigned hi, int pos, unsigned base_off) {
     unsigned t;
     u64 sv;
+    // (the mask is wave-uniform, but under register pressure the compiler may keep it in vector registers, which an "s"
+    // operand cannot take: readfirstlane pins it to scalar registers and folds away when it is there already)
+    const u64 m = ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(m_in >> 32)) << 32) | (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)m_in);
     asm volatile(
         "v_mbcnt_lo_u32_b32 %[t], %[mlo], 0\n\t"
         "v_mbcnt_hi_u32_b32 %[t], %[mhi], %[t]\n\t"

@@ -291,7 +291,13 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     cnt1 = __builtin_amdgcn_readlane(myd.y, t1);
                     // lanes beyond a partial item's end get an out-of-range offset: they fetch nothing (instead of the next m2 row)
                     // (lanes beyond a partial item's end read on into the next m2 row: in sweep 1 that over-fetch is cheaper than
-                    // the registers the out-of-range trick of sweep 2 would cost here)
+                    // the instructions the out-of-range trick of sweep 2 costs here — measured 14.5k -> 15.6k cycles per row at C2.
+                    // Also measured and dropped, C2 cycles per row for sweep 1 / sweep 2 against 14.5k / 30.0k: requesting all the
+                    // row's lines up front with one-dword "touch" loads 20.8k / -; 768 threads with 3 pairs / 4 items in flight
+                    // 16.2k / 35.8k (two in flight there: 15.5k / 33.6k); pairs handed out by an LDS counter instead of the
+                    // static share 15.4k / 31.3k (it halves the 3.5k cycles the waves wait at the closing barrier, and spends
+                    // more than that on the counter and descriptor round trips).  With the sweep bodies removed (dbg bits 8 | 16)
+                    // the loads alone take 10.4k / 24.4k: the bodies do not overlap with the loads of the other waves.)
                     const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, lane * 16, off0, 0);
                     const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, lane * 16, off1, 0);
                     c[0] = v0.x; c[1] = v0.y; c[2] = v0.z; c[3] = v0.w;
@@ -299,6 +305,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 };
                 auto body = [&](const unsigned (&c)[8], int cnt0, int cnt1) __attribute__((always_inline)) {
                     if (cnt0 == 0) return;                 // sentinel pair (wave-uniform; the second item of a pair may be the sentinel)
+                    if (p.dbg & 8) { asm volatile("" ::"v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7])); return; }   // ablation: loads only
                     unsigned seen[8];
                     if (cnt0 == ITEM && cnt1 == ITEM) s1_core8<CBM_BYTES + PRE_BYTES, false>(c, 4 * lane, cnt0, cnt1, amask, seen);
                     else s1_core8<CBM_BYTES + PRE_BYTES, true>(c, 4 * lane, cnt0, cnt1, amask, seen);      // padding ORs nothing
@@ -550,6 +557,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     const float cut = MONO ? cutx : rc.xy_cut;
                     auto body = [&](const unsigned (&c)[4], const float (&v)[4], int cnt, float segv) __attribute__((always_inline)) {
                         if (cnt == 0) return;                  // sentinel (wave-uniform)
+                        if (p.dbg & 16) { asm volatile("" ::"v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); return; }   // ablation: loads only
                         // M: product of a marked column; S: otherwise the product is the only one of its column and
                         // matters only if its raw dot can still enter the top-k (NaN stays: the exact judge drops it)
                         float x[4];
