@@ -55,6 +55,7 @@ struct KParams {
     int nb_log2;           // log2 of the sparse path's column bitmap size in bits (<= log2(T*64))
     int hash_fill;         // slots' worth of MACs one hash window may receive (= T * load_pct / 100)
     int static_sched;
+    const float4 *Ypack;   // optional: {Ytv, Ycos, Ydep, 0} per column when two or more column terms are in use (one gather instead of several)
     const float *ymin;     // [3] minima of Ytv / Ycos / Ydep over all columns (valid iff bound_ok)
     int bound_ok;          // weights/shrinks are all >= 0: the epilogue upper bound is sound
     int sparse_path;       // 1 = rows with few expected collisions take the bitmap path
@@ -328,17 +329,26 @@ __device__ __forceinline__ unsigned emit_candidates(const KParams &p, const RowC
         gc[j] = ((live & (1u << j)) && !(p.dbg & 4)) ? c[j] : 0;
         ytv[j] = 0.f; ycos[j] = 0.f; ydep[j] = 0.f;
     }
-    if (p.l1 != 0.f) {
+    if (p.Ypack) {
+        // two or more column terms: one 16-byte gather per candidate
 #pragma unroll
-        for (int j = 0; j < N; ++j) ytv[j] = p.Ytv[gc[j]];
-    }
-    if (p.l2 != 0.f) {
+        for (int j = 0; j < N; ++j) {
+            const float4 y = p.Ypack[gc[j]];
+            ytv[j] = y.x; ycos[j] = y.y; ydep[j] = y.z;
+        }
+    } else {
+        if (p.l1 != 0.f) {
 #pragma unroll
-        for (int j = 0; j < N; ++j) ycos[j] = p.fold ? 1.f : p.Ycos[gc[j]];
-    }
-    if (p.l3 != 0.f) {
+            for (int j = 0; j < N; ++j) ytv[j] = p.Ytv[gc[j]];
+        }
+        if (p.l2 != 0.f) {
 #pragma unroll
-        for (int j = 0; j < N; ++j) ydep[j] = p.fold ? 1.f : p.Ydep[gc[j]];
+            for (int j = 0; j < N; ++j) ycos[j] = p.fold ? 1.f : p.Ycos[gc[j]];
+        }
+        if (p.l3 != 0.f) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) ydep[j] = p.fold ? 1.f : p.Ydep[gc[j]];
+        }
     }
     unsigned want = 0;
     unsigned key[N];

@@ -8,7 +8,7 @@
 //   keep the k largest val[c] >= threshold that pass the column selectors (s_plus.h:192-215, 39-64)
 //
 // Launch sequence of one call (all on the caller's stream):
-//   sp_fold_colterm_kernel | sp_colterm_min_kernel   column term folded into the m2 stream / its minima
+//   sp_fold_colterm_kernel | sp_pack_colterms_kernel, sp_colterm_min_kernel   column term folded into the m2 stream | column terms interleaved, their minima
 //   sp_row_work_kernel, sp_bucket_base_kernel, sp_row_order_kernel   MACs per row, descending-work queue
 //   sp_row_desc_kernel       classified 32-byte row descriptors: sparse queue / generic queue
 //   sp_knn_sparse_kernel     (sp_sparse_kernel.hpp)  bitmap + two sweeps, the headline shape; persistent
@@ -62,7 +62,8 @@ struct Config {
     size_t lds_sparse, lds_generic;
     size_t ws_gu_bytes;     // candidate buffers in global memory for both kernels (0 when they live in LDS)
     size_t ws_gu_s_bytes;   // the sparse kernel's part of it (first)
-    size_t ws_fold_bytes;   // scaled copy of m2_data when the column term is folded in (0 otherwise)
+    size_t ws_fold_bytes;   // scaled copy of m2_data when the column term is folded in, or the packed column terms (0 otherwise)
+    bool pack;              // two or more column terms gathered per candidate: interleaved copy, one gather
     size_t ws_rows_bytes;   // bucket counters + work[n] + order[n] + the two descriptor queues
     size_t ws_desc_offset;  // of the sparse queue inside that block (the generic queue follows it)
     int nb_log2;            // sparse kernel: bitmap bits (log2)
@@ -131,7 +132,8 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
               a->bayesian_shrink == 0.f && ((a->l2 != 0.f) != (a->l3 != 0.f)) && a->nnz_m2 > 0;
     const bool any_norm = a->l1 != 0.f || a->l2 != 0.f || a->l3 != 0.f || a->stabilized_shrink != 0.f || a->bayesian_shrink != 0.f;
     c->mono = (c->fold || !any_norm) && a->target_col_mode != SP_SEL_MATRIX;      // (a MATRIX filter is handled through the collision bitmap)
-    c->ws_fold_bytes = c->fold ? (((size_t)a->nnz_m2 * 4 + 255) & ~(size_t)255) : 0;
+    c->pack = !c->fold && ((a->l1 != 0.f) + (a->l2 != 0.f) + (a->l3 != 0.f) >= 2) && a->n_output_cols > 0;
+    c->ws_fold_bytes = c->fold ? (((size_t)a->nnz_m2 * 4 + 255) & ~(size_t)255) : c->pack ? (((size_t)a->n_output_cols * 16 + 255) & ~(size_t)255) : 0;
     c->ordered = !(a->flags & (SP_FLAG_STATIC_SCHED | SP_FLAG_NO_ROW_ORDER)) && a->n_targets > std::min(c->wgs_sparse, c->wgs_generic);
     // 512 B of bucket counters | work[n] | order[n] | (32-byte aligned) sparse queue n x 32 B | generic queue n x 32 B
     c->ws_desc_offset = (512 + (size_t)a->n_targets * 8 + 31) & ~(size_t)31;
@@ -243,12 +245,20 @@ int run_device(sp_knn_args *a) {
                           (a->stabilized_shrink >= 0.f) && (a->bayesian_shrink >= 0.f);
     float *ymin_dev = (float *)(ws + WS_YMIN_OFFSET);
     float *folded = nullptr;
+    float4 *ypack = nullptr;
     if (c.fold) {
         folded = (float *)ws_fold;
         hipLaunchKernelGGL(sp_fold_colterm_kernel, dim3(256 * 8), dim3(256), 0, stream, (long long)a->nnz_m2, a->m2_indices,
                            a->m2_data, a->l2 != 0.f ? a->Ycosine : a->Ydepop, folded);
         HIP_TRY(hipGetLastError());
-    } else if (bound_ok && (a->l1 != 0.f || a->l2 != 0.f || a->l3 != 0.f)) {
+    } else if (c.pack) {
+        ypack = (float4 *)ws_fold;
+        hipLaunchKernelGGL(sp_pack_colterms_kernel, dim3(std::min(2048, (a->n_output_cols + 255) / 256)), dim3(256), 0, stream, a->n_output_cols,
+                           a->l1 != 0.f ? a->Ytversky : nullptr, a->l2 != 0.f ? a->Ycosine : nullptr,
+                           a->l3 != 0.f ? a->Ydepop : nullptr, ypack);
+        HIP_TRY(hipGetLastError());
+    }
+    if (!c.fold && bound_ok && (a->l1 != 0.f || a->l2 != 0.f || a->l3 != 0.f)) {
         hipLaunchKernelGGL(sp_colterm_min_kernel, dim3(1), dim3(1024), 0, stream, a->n_output_cols,
                            a->l1 != 0.f ? a->Ytversky : nullptr, a->l2 != 0.f ? a->Ycosine : nullptr,
                            a->l3 != 0.f ? a->Ydepop : nullptr, ymin_dev);
@@ -310,6 +320,7 @@ int run_device(sp_knn_args *a) {
     kp.hash_fill = c.hash_fill;
     kp.static_sched = (a->flags & SP_FLAG_STATIC_SCHED) ? 1 : 0;
     kp.ymin = ymin_dev;
+    kp.Ypack = ypack;
     kp.bound_ok = bound_ok ? 1 : 0;
     kp.fold = c.fold ? 1 : 0;
     if (c.fold) kp.m2_data = folded;

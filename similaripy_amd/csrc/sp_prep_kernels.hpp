@@ -164,6 +164,14 @@ __global__ __launch_bounds__(1024) void sp_colterm_min_kernel(int n_cols, const 
     }
 }
 
+// Interleave the column terms in use into one {Ytv, Ycos, Ydep, 0} record per column (0 for a term whose weight is 0:
+// the epilogue never looks at it), so that judging a candidate costs one gather.
+__global__ __launch_bounds__(256) void sp_pack_colterms_kernel(int n_cols, const float *__restrict__ Ytv, const float *__restrict__ Ycos,
+                                                                const float *__restrict__ Ydep, float4 *__restrict__ out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_cols; i += gridDim.x * blockDim.x)
+        out[i] = make_float4(Ytv ? Ytv[i] : 0.f, Ycos ? Ycos[i] : 0.f, Ydep ? Ydep[i] : 0.f, 0.f);
+}
+
 // Fold the column term of a product-form epilogue into the m2 stream:  out[i] = data[i] / Y[indices[i]]
 // (0 where Y is 0: the reference returns 0 for a zero denominator, s_plus.h:147-150).  One streaming pass.
 __global__ __launch_bounds__(256) void sp_fold_colterm_kernel(long long nnz, const int *__restrict__ indices,

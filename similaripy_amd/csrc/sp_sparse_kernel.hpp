@@ -752,7 +752,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                             }
                         }
                     } else {
-                        // two entries per thread and trip: the gathers of their column terms are in flight together
+                        // four entries per thread and trip: the gathers of their column terms (one each: packed) are in flight together
                         constexpr int JN = 2;
                         for (int base = 0; base < n_ent; base += JN * NT) {
                             u64 e[JN];
