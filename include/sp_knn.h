@@ -53,6 +53,9 @@ extern "C" {
 #define SP_FLAG_NO_SPARSE_PATH 8u /* never use the bitmap + collision-set path for sparse rows (A/B testing) */
 #define SP_FLAG_NO_FOLD       16u /* never divide the column term into the m2 stream (A/B testing) */
 #define SP_FLAG_NO_ROW_ORDER  32u /* queue rows in target order instead of descending work (A/B testing) */
+#define SP_FLAG_M2_IS_M1_T    128u /* m2 = m1^T (the `matrix2=None` call, s_plus.pyx:169-170): built on the device from m1 by the callee;
+                                     the m2_* pointers and nnz_m2 are ignored (may be NULL / 0), n_rows_m2 = columns of m1,
+                                     n_output_cols must equal n_rows_m1.  See sp_prep.h. */
 #define SP_FLAG_PHASE_TIMERS  64u /* with SP_FLAG_TIME_KERNEL: also run the in-kernel phase timers (s_memtime, ~1-2 % slower) */
 
 typedef struct sp_knn_args {
@@ -128,7 +131,9 @@ typedef struct sp_knn_args {
     int32_t _pad1;
     int64_t reserved[4];       /* [0] IN: kernel ablation bits, profiling only (0 in production)
                                   [1], [2] OUT with SP_FLAG_TIME_KERNEL: duration of the sparse / generic row kernel of this
-                                  call in microseconds (hipEvents on `stream` around each launch) */
+                                  call in microseconds (hipEvents on `stream` around each launch)
+                                  [3] OUT with SP_FLAG_TIME_KERNEL | SP_FLAG_M2_IS_M1_T: duration of the transpose, microseconds
+                                  (kernel_ms includes it) */
 } sp_knn_args;
 
 /* The hot path.  Replaces compute_similarities_parallel<int,float> (s_plus.h:265). */

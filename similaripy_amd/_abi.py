@@ -1,4 +1,4 @@
-"""ctypes binding of include/sp_knn.h (libsimilaripy_hip.so).
+"""ctypes binding of include/sp_knn.h and include/sp_prep.h (libsimilaripy_hip.so).
 
 This is the only way the Python layer reaches compute.  There is no CPU fallback:
 if the library is missing, cannot be loaded, or sees no HIP device, the call raises.
@@ -21,6 +21,7 @@ SP_FLAG_NO_SPARSE_PATH = 8
 SP_FLAG_NO_FOLD = 16
 SP_FLAG_NO_ROW_ORDER = 32
 SP_FLAG_PHASE_TIMERS = 64
+SP_FLAG_M2_IS_M1_T = 128
 
 _c_f32p = C.POINTER(C.c_float)
 _c_i32p = C.POINTER(C.c_int32)
@@ -93,6 +94,52 @@ class SpKnnArgs(C.Structure):
 
 
 # every symbol include/sp_knn.h declares; tests check the library exports all of them
+class SpCsrTransposeArgs(C.Structure):
+    """Mirror of ``struct sp_csr_transpose_args`` (include/sp_prep.h) — keep field order identical."""
+
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("flags", C.c_uint32),
+        ("on_device", C.c_int32),
+        ("device", C.c_int32),
+        ("n_rows", C.c_int32),
+        ("n_cols", C.c_int32),
+        ("nnz", C.c_int64),
+        ("data", C.c_void_p),
+        ("indices", C.c_void_p),
+        ("indptr", C.c_void_p),
+        ("out_data", C.c_void_p),
+        ("out_indices", C.c_void_p),
+        ("out_indptr", C.c_void_p),
+        ("stream", C.c_void_p),
+        ("workspace", C.c_void_p),
+        ("workspace_bytes", C.c_int64),
+        ("kernel_ms", C.c_float),
+        ("_pad0", C.c_int32),
+    ]
+
+
+class SpCsrSqsumsArgs(C.Structure):
+    """Mirror of ``struct sp_csr_sqsums_args`` (include/sp_prep.h) — keep field order identical."""
+
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("flags", C.c_uint32),
+        ("on_device", C.c_int32),
+        ("device", C.c_int32),
+        ("n_rows", C.c_int32),
+        ("_pad0", C.c_int32),
+        ("nnz", C.c_int64),
+        ("data", C.c_void_p),
+        ("indptr", C.c_void_p),
+        ("out_rows", C.c_void_p),
+        ("out_cols_of_t", C.c_void_p),
+        ("stream", C.c_void_p),
+        ("kernel_ms", C.c_float),
+        ("_pad1", C.c_int32),
+    ]
+
+
 EXPORTED_SYMBOLS = (
     "sp_knn_f32_i32",
     "sp_knn_workspace_bytes",
@@ -100,6 +147,9 @@ EXPORTED_SYMBOLS = (
     "sp_backend_info",
     "sp_last_error",
     "sp_abi_version",
+    "sp_csr_transpose_f32_i32",
+    "sp_csr_transpose_workspace_bytes",
+    "sp_csr_row_sqsums_f32",
 )
 
 
@@ -150,6 +200,12 @@ def load(build_if_missing: bool = True):
     lib.sp_last_error.restype = C.c_char_p
     lib.sp_abi_version.argtypes = []
     lib.sp_abi_version.restype = C.c_int
+    lib.sp_csr_transpose_f32_i32.argtypes = [C.POINTER(SpCsrTransposeArgs)]
+    lib.sp_csr_transpose_f32_i32.restype = C.c_int
+    lib.sp_csr_transpose_workspace_bytes.argtypes = [C.POINTER(SpCsrTransposeArgs)]
+    lib.sp_csr_transpose_workspace_bytes.restype = C.c_int64
+    lib.sp_csr_row_sqsums_f32.argtypes = [C.POINTER(SpCsrSqsumsArgs)]
+    lib.sp_csr_row_sqsums_f32.restype = C.c_int
     _lib = lib
     return lib
 
@@ -192,6 +248,31 @@ def call_knn(args: SpKnnArgs) -> None:
     rc = lib.sp_knn_f32_i32(C.byref(args))
     if rc != 0:
         raise HipLibraryError(f"sp_knn_f32_i32 failed ({rc}): {last_error()}")
+
+
+def call_transpose(args: SpCsrTransposeArgs) -> None:
+    lib = load()
+    args.struct_size = C.sizeof(SpCsrTransposeArgs)
+    rc = lib.sp_csr_transpose_f32_i32(C.byref(args))
+    if rc != 0:
+        raise HipLibraryError(f"sp_csr_transpose_f32_i32 failed ({rc}): {last_error()}")
+
+
+def call_row_sqsums(args: SpCsrSqsumsArgs) -> None:
+    lib = load()
+    args.struct_size = C.sizeof(SpCsrSqsumsArgs)
+    rc = lib.sp_csr_row_sqsums_f32(C.byref(args))
+    if rc != 0:
+        raise HipLibraryError(f"sp_csr_row_sqsums_f32 failed ({rc}): {last_error()}")
+
+
+def transpose_workspace_bytes(args: SpCsrTransposeArgs) -> int:
+    lib = load()
+    args.struct_size = C.sizeof(SpCsrTransposeArgs)
+    n = lib.sp_csr_transpose_workspace_bytes(C.byref(args))
+    if n < 0:
+        raise HipLibraryError(f"sp_csr_transpose_workspace_bytes failed ({n}): {last_error()}")
+    return int(n)
 
 
 def workspace_bytes(args: SpKnnArgs) -> int:

@@ -77,6 +77,7 @@ class KernelCall:
     target_col_mode: int = MODE_NONE
     target_col_m_indptr: np.ndarray = field(default_factory=lambda: _EMPTY_I32)
     target_col_m_indices: np.ndarray = field(default_factory=lambda: _EMPTY_I32)
+    m2_is_m1t: bool = False    # m2 = m1^T is built on the device (SP_FLAG_M2_IS_M1_T): the m2_* arrays are empty
 
     @property
     def n_targets(self) -> int:
@@ -159,6 +160,39 @@ def build_squared_norms(m1_data, m1_indices, m1_indptr, n_cols_m1, m2_data, m2_i
     sq2 = np.square(m2_data, dtype=np.float32)
     return (csr_sum(sq1, m1_indices, m1_indptr, n_cols_m1, axis=1),
             csr_sum(sq2, m2_indices, m2_indptr, n_cols_m2, axis=0))
+
+
+def squared_norms_m1t_hip(m1_data, m1_indptr, device: Optional[int] = None):
+    """build_squared_norms_m1t on the GPU (sp_csr_row_sqsums_f32, include/sp_prep.h): the same two float32 vectors,
+    bit for bit (NumPy's pairwise order for the row sums, float64 storage order for the column sums of m1^T).
+    No CPU fallback: raises without a device."""
+    _abi.require_device()
+    n_rows = int(m1_indptr.shape[0]) - 1
+    sq1 = np.empty(n_rows, dtype=np.float32)
+    sq2 = np.empty(n_rows, dtype=np.float32)
+    a = _abi.SpCsrSqsumsArgs()
+    a.on_device = 0
+    a.device = selected_device() if device is None else int(device)
+    a.n_rows, a.nnz = n_rows, int(m1_data.shape[0])
+    data, indptr = _abi.as_f32(m1_data), _abi.as_i32(m1_indptr)
+    a.data = data.ctypes.data if data.size else None
+    a.indptr = indptr.ctypes.data
+    a.out_rows, a.out_cols_of_t = sq1.ctypes.data, sq2.ctypes.data
+    if n_rows:
+        _abi.call_row_sqsums(a)
+    return sq1, sq2
+
+
+def build_squared_norms_m1t(m1_data, m1_indptr):
+    """build_squared_norms for m2 = m1^T without m2: the column sums of m2^2 are the row sums of m1^2, added up
+    the way the reference adds the columns of m2 (np.bincount: float64, storage order — s_plus_utils.pyx:160-164;
+    the storage order of a column of m1^T is the order of the row of m1)."""
+    sq = np.square(m1_data, dtype=np.float32)
+    n_rows = m1_indptr.shape[0] - 1
+    sq1 = csr_sum(sq, None, m1_indptr, 0, axis=1)
+    row_of = np.repeat(np.arange(n_rows, dtype=np.int32), np.diff(m1_indptr))
+    sq2 = np.bincount(row_of, weights=sq, minlength=n_rows).astype(np.float32, copy=False)
+    return sq1, sq2
 
 
 def build_cosine_normalization(m1_sq, m2_sq, c1, c2, additive_shrink):
@@ -309,8 +343,14 @@ def prepare(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_mat
             p1=0.0, p2=0.0, a1=1.0, l1=0.0, l2=0.0, l3=0.0, t1=1.0, t2=1.0, c1=0.5, c2=0.5, k=100,
             stabilized_shrink=0.0, bayesian_shrink=0.0, additive_shrink=0.0, threshold=0.0,
             binary=False, target_rows=None, filter_cols=None, target_cols=None,
-            verbose=False, format_output='csr') -> KernelCall:
-    """Everything s_plus.pyx does before the `with nogil:` block (:168-353)."""
+            verbose=False, format_output='csr', m2_on_device=False) -> KernelCall:
+    """Everything s_plus.pyx does before the `with nogil:` block (:168-353).
+
+    m2_on_device: for the `matrix2=None` call, leave the transpose (s_plus.pyx:169-170, 205-206) to the device
+    (SP_FLAG_M2_IS_M1_T, include/sp_prep.h): m2 is never built on the host, its column norms are taken from the
+    rows of m1 with the arithmetic the reference applies to the columns of m2.  Falls back to the host
+    transpose when the call needs m2 on the host (ARRAY column selectors, depopularisation weights)."""
+    m2_from_m1 = matrix2 is None
     if matrix2 is None:
         matrix2 = matrix1.T
     k = int(k)
@@ -328,9 +368,17 @@ def prepare(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_mat
             raise ValueError("target_rows contains row ids outside matrix1")
 
     m1, m1_data, m1_indices, m1_indptr = _csr_f32_i32(matrix1, binary)
-    m2, m2_data, m2_indices, m2_indptr = _csr_f32_i32(matrix2, binary)
-    n_rows_m1, n_rows_m2 = m1.shape
-    n_output_cols = m2.shape[1]
+    sel_f = build_column_selector(filter_cols)
+    sel_t = build_column_selector(target_cols)
+    on_dev = bool(m2_on_device) and m2_from_m1 and l3 == 0 and sel_f[0] != MODE_ARRAY and sel_t[0] != MODE_ARRAY
+    if on_dev:
+        m2_data, m2_indices, m2_indptr = _EMPTY_F32, _EMPTY_I32, _EMPTY_I32
+        n_rows_m1, n_rows_m2 = m1.shape
+        n_output_cols = n_rows_m1
+    else:
+        m2, m2_data, m2_indices, m2_indptr = _csr_f32_i32(matrix2, binary)
+        n_rows_m1, n_rows_m2 = m1.shape
+        n_output_cols = m2.shape[1]
 
     # all scalar parameters are C floats in the reference (s_plus.pyx:100-113)
     f32 = lambda x: float(np.float32(x))  # noqa: E731
@@ -342,11 +390,14 @@ def prepare(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_mat
         m2_data=m2_data, m2_indices=m2_indices, m2_indptr=m2_indptr,
         n_rows_m1=n_rows_m1, n_rows_m2=n_rows_m2, n_output_cols=n_output_cols, k=k,
         a1=a1, l1=l1, l2=l2, l3=l3, t1=t1, t2=t2,
-        stabilized_shrink=stabilized_shrink, bayesian_shrink=bayesian_shrink, threshold=threshold)
+        stabilized_shrink=stabilized_shrink, bayesian_shrink=bayesian_shrink, threshold=threshold, m2_is_m1t=on_dev)
 
     if l1 != 0 or l2 != 0:
-        sq1, sq2 = build_squared_norms(m1_data, m1_indices, m1_indptr, n_rows_m2,
-                                       m2_data, m2_indices, m2_indptr, n_output_cols)
+        if on_dev:
+            sq1, sq2 = squared_norms_m1t_hip(m1_data, m1_indptr)
+        else:
+            sq1, sq2 = build_squared_norms(m1_data, m1_indices, m1_indptr, n_rows_m2,
+                                           m2_data, m2_indices, m2_indptr, n_output_cols)
         if l1 != 0:
             call.Xtversky, call.Ytversky = sq1, sq2
         if l2 != 0:
@@ -358,8 +409,10 @@ def prepare(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_mat
         call.Xdepop = np.ascontiguousarray(call.Xdepop, dtype=np.float32)
         call.Ydepop = np.ascontiguousarray(call.Ydepop, dtype=np.float32)
 
-    call.filter_mode, call.filter_m_indptr, call.filter_m_indices = build_column_selector(filter_cols)
-    call.target_col_mode, call.target_col_m_indptr, call.target_col_m_indices = build_column_selector(target_cols)
+    call.filter_mode, call.filter_m_indptr, call.filter_m_indices = sel_f
+    call.target_col_mode, call.target_col_m_indptr, call.target_col_m_indices = sel_t
+    if on_dev:
+        return call        # (the device builds m2 with ascending column ids)
     if call.filter_mode == MODE_ARRAY or call.target_col_mode == MODE_ARRAY:
         keep = compute_target_columns(filter_cols, target_cols, n_output_cols)
         call.m2_data, call.m2_indices, call.m2_indptr = filter_matrix_columns(
@@ -414,6 +467,8 @@ def run_hip(call: KernelCall, device: Optional[int] = None, table_slots: int = 0
     a.device = selected_device() if device is None else int(device)
     a.n_targets, a.n_rows_m1, a.n_rows_m2, a.n_output_cols = n, call.n_rows_m1, call.n_rows_m2, call.n_output_cols
     a.nnz_m1, a.nnz_m2 = int(call.m1_data.shape[0]), int(call.m2_data.shape[0])
+    if call.m2_is_m1t:
+        a.flags |= _abi.SP_FLAG_M2_IS_M1_T
     keep = []  # keep converted arrays alive across the call
 
     def f32(x):
@@ -443,7 +498,7 @@ def run_hip(call: KernelCall, device: Optional[int] = None, table_slots: int = 0
         _abi.call_knn(a)
     if time_kernel:
         return rows, cols, values, counts, {"kernel_ms": float(a.kernel_ms), "passes_total": int(a.passes_total), "phase_cycles": [int(x) for x in a.phase_cycles], "num_wgs": int(a.num_wgs_used),
-                                             "sparse_kernel_ms": int(a.reserved[1]) / 1e3, "generic_kernel_ms": int(a.reserved[2]) / 1e3}
+                                             "sparse_kernel_ms": int(a.reserved[1]) / 1e3, "generic_kernel_ms": int(a.reserved[2]) / 1e3, "transpose_ms": int(a.reserved[3]) / 1e3}
     return rows, cols, values, counts
 
 
@@ -468,7 +523,7 @@ def s_plus(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_matr
     _say(verbose if isinstance(verbose, bool) else False, "Preprocessing")
     call = prepare(matrix1, matrix2, weight_depop_matrix1, weight_depop_matrix2, p1, p2, a1, l1, l2, l3,
                    t1, t2, c1, c2, k, stabilized_shrink, bayesian_shrink, additive_shrink, threshold,
-                   binary, target_rows, filter_cols, target_cols, verbose, format_output)
+                   binary, target_rows, filter_cols, target_cols, verbose, format_output, m2_on_device=True)
     _say(verbose, "Computing")
     rows, cols, values, counts = run_hip(call)
     _say(verbose, f"Building {format_output} matrix")

@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "../../include/sp_knn.h"
+#include "../../include/sp_prep.h"
 #include "sp_common.hpp"
 #include "sp_prep_kernels.hpp"
 #include "sp_sparse_kernel.hpp"
@@ -36,6 +37,8 @@
 // host side: C ABI
 // ---------------------------------------------------------------------------------------------
 namespace {
+
+#define TRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
 thread_local char g_err[512] = "";
 
@@ -155,16 +158,19 @@ int validate(const sp_knn_args *a) {
     if (a->k < 1) return fail(SP_EINVAL, "k must be >= 1, got %d", a->k);
     if (a->nnz_m1 < 0 || a->nnz_m2 < 0 || a->nnz_m1 > 0x7FFFFFFFLL || a->nnz_m2 > 0x7FFFFFFFLL)
         return fail(SP_EINVAL, "nnz must fit int32 indptr (reference limit, s_plus.pyx:241-244)");
-    if (a->nnz_m2 >= (1LL << 30) - 1024)
+    const bool m2t = (a->flags & SP_FLAG_M2_IS_M1_T) != 0;     // m2 = m1^T, built on the device: the m2_* pointers and nnz_m2 are ignored
+    if ((m2t ? a->nnz_m1 : a->nnz_m2) >= (1LL << 30) - 1024)
         return fail(SP_EINVAL, "nnz(m2) = %lld: this build addresses m2 with 32-bit byte offsets and needs nnz(m2) < 2^30",
-                    (long long)a->nnz_m2);
+                    (long long)(m2t ? a->nnz_m1 : a->nnz_m2));
+    if (m2t && a->n_output_cols != a->n_rows_m1)
+        return fail(SP_EINVAL, "SP_FLAG_M2_IS_M1_T: n_output_cols (%d) must equal n_rows_m1 (%d)", a->n_output_cols, a->n_rows_m1);
     if (a->n_targets > 0) {
-        if (!a->targets || !a->m1_indptr || !a->m2_indptr || !a->cols || !a->values)
+        if (!a->targets || !a->m1_indptr || (!m2t && !a->m2_indptr) || !a->cols || !a->values)
             return fail(SP_EINVAL, "NULL input/output pointer");
         if (!a->rows && !(a->on_device && (a->flags & SP_FLAG_NO_ROWS_OUT)))
             return fail(SP_EINVAL, "rows is NULL");
         if (a->nnz_m1 > 0 && (!a->m1_data || !a->m1_indices)) return fail(SP_EINVAL, "m1 arrays NULL");
-        if (a->nnz_m2 > 0 && (!a->m2_data || !a->m2_indices)) return fail(SP_EINVAL, "m2 arrays NULL");
+        if (!m2t && a->nnz_m2 > 0 && (!a->m2_data || !a->m2_indices)) return fail(SP_EINVAL, "m2 arrays NULL");
         if (a->l1 != 0.f && (!a->Xtversky || !a->Ytversky)) return fail(SP_EINVAL, "l1 != 0 needs Xtversky/Ytversky");
         if (a->l2 != 0.f && (!a->Xcosine || !a->Ycosine)) return fail(SP_EINVAL, "l2 != 0 needs Xcosine/Ycosine");
         if (a->l3 != 0.f && (!a->Xdepop || !a->Ydepop)) return fail(SP_EINVAL, "l3 != 0 needs Xdepop/Ydepop");
@@ -206,7 +212,7 @@ int launch_rows(const KParams &kp, const Config &c, hipStream_t stream, hipEvent
 }
 
 // all pointers in `a` are device pointers here
-int run_device(sp_knn_args *a) {
+int run_device_impl(sp_knn_args *a) {
     HIP_TRY(hipSetDevice(a->device));
     if (a->n_targets == 0) { a->kernel_ms = 0.f; return SP_OK; }
     int n_cus = 256;
@@ -364,6 +370,87 @@ int run_device(sp_knn_args *a) {
     return SP_OK;
 }
 
+}  // namespace
+#include "sp_transpose.hpp"
+namespace {
+
+// Layout of the extra scratch a SP_FLAG_M2_IS_M1_T call needs behind the kernel's own workspace: the three arrays of
+// m2 = m1^T, then the transpose's scratch.
+struct M2tLayout { size_t knn, data, indices, indptr, tr, total; };
+int m2t_layout(const sp_knn_args *a, int n_cus, sp_knn_args *plain, M2tLayout *L) {
+    *plain = *a;
+    plain->flags &= ~SP_FLAG_M2_IS_M1_T;
+    plain->nnz_m2 = a->nnz_m1;
+    Config c;
+    TRY(make_config(plain, n_cus, &c));
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    L->knn = al(c.ws_total);
+    L->data = L->knn;
+    L->indices = L->data + al((size_t)a->nnz_m1 * 4);
+    L->indptr = L->indices + al((size_t)a->nnz_m1 * 4);
+    L->tr = L->indptr + al(((size_t)a->n_rows_m2 + 1) * 4);
+    L->total = L->tr + transpose_ws_bytes(a->nnz_m1, a->n_rows_m2);
+    return SP_OK;
+}
+
+// device pointers in, device pointers out; with SP_FLAG_M2_IS_M1_T the transpose (s_plus.pyx:169-170, 205-206) is built
+// first, on the same stream, into scratch behind the kernel's workspace
+int run_device(sp_knn_args *a) {
+    if (!(a->flags & SP_FLAG_M2_IS_M1_T)) return run_device_impl(a);
+    HIP_TRY(hipSetDevice(a->device));
+    if (a->n_targets == 0) { a->kernel_ms = 0.f; return SP_OK; }
+    int n_cus = 256;
+    TRY(device_cus(a->device, &n_cus));
+    sp_knn_args b;
+    M2tLayout L;
+    TRY(m2t_layout(a, n_cus, &b, &L));
+    hipStream_t stream = (hipStream_t)a->stream;
+    unsigned char *ws = (unsigned char *)a->workspace;
+    bool own_ws = false;
+    if (!ws) {
+        HIP_TRY(hipMalloc((void **)&ws, L.total));
+        own_ws = true;
+    } else if (a->workspace_bytes < (int64_t)L.total) {
+        return fail(SP_EWORKSPACE, "workspace too small: need %zu bytes, got %lld", L.total, (long long)a->workspace_bytes);
+    }
+    const bool timed = (a->flags & SP_FLAG_TIME_KERNEL) != 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (timed) {
+        HIP_TRY(hipEventCreate(&ev0));
+        HIP_TRY(hipEventCreate(&ev1));
+        HIP_TRY(hipEventRecord(ev0, stream));
+    }
+    float *m2_data = (float *)(ws + L.data);
+    int *m2_indices = (int *)(ws + L.indices), *m2_indptr = (int *)(ws + L.indptr);
+    int rc = transpose_device(a->n_rows_m1, a->n_rows_m2, a->nnz_m1, a->m1_data, a->m1_indices, a->m1_indptr,
+                              m2_data, m2_indices, m2_indptr, ws + L.tr, L.total - L.tr, stream);
+    float tr_ms = 0.f;
+    if (!rc && timed) {
+        HIP_TRY(hipEventRecord(ev1, stream));
+        HIP_TRY(hipEventSynchronize(ev1));
+        HIP_TRY(hipEventElapsedTime(&tr_ms, ev0, ev1));
+    }
+    if (timed) { (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); }
+    if (!rc) {
+        b.m2_data = m2_data; b.m2_indices = m2_indices; b.m2_indptr = m2_indptr;
+        b.workspace = ws;
+        b.workspace_bytes = (int64_t)L.knn;
+        rc = run_device_impl(&b);
+        a->kernel_ms = b.kernel_ms + tr_ms;
+        a->passes_total = b.passes_total;
+        a->num_wgs_used = b.num_wgs_used;
+        memcpy(a->phase_cycles, b.phase_cycles, sizeof(a->phase_cycles));
+        a->reserved[1] = b.reserved[1];
+        a->reserved[2] = b.reserved[2];
+        a->reserved[3] = (int64_t)(tr_ms * 1000.f);
+    }
+    if (own_ws) {
+        (void)hipStreamSynchronize(stream);
+        (void)hipFree(ws);
+    }
+    return rc;
+}
+
 // RAII device allocation list for the host-pointer entry
 struct DevPool {
     std::vector<void *> ptrs;
@@ -396,7 +483,6 @@ struct DevPool {
     }
 };
 
-#define TRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
 // host pointers in, host pointers out: the drop-in for s_plus.pyx:359-384
 int run_host(sp_knn_args *a) {
@@ -418,9 +504,13 @@ int run_host(sp_knn_args *a) {
     TRY(pool.up(a->m1_data, (size_t)a->nnz_m1, &d.m1_data));
     TRY(pool.up(a->m1_indices, (size_t)a->nnz_m1, &d.m1_indices));
     TRY(pool.up(a->m1_indptr, (size_t)a->n_rows_m1 + 1, &d.m1_indptr));
-    TRY(pool.up(a->m2_data, (size_t)a->nnz_m2, &d.m2_data));
-    TRY(pool.up(a->m2_indices, (size_t)a->nnz_m2, &d.m2_indices));
-    TRY(pool.up(a->m2_indptr, (size_t)a->n_rows_m2 + 1, &d.m2_indptr));
+    if (a->flags & SP_FLAG_M2_IS_M1_T) {       // m2 never exists on the host: built on the device from m1
+        d.m2_data = nullptr; d.m2_indices = nullptr; d.m2_indptr = nullptr;
+    } else {
+        TRY(pool.up(a->m2_data, (size_t)a->nnz_m2, &d.m2_data));
+        TRY(pool.up(a->m2_indices, (size_t)a->nnz_m2, &d.m2_indices));
+        TRY(pool.up(a->m2_indptr, (size_t)a->n_rows_m2 + 1, &d.m2_indptr));
+    }
     TRY(pool.up(a->l1 != 0.f ? a->Xtversky : nullptr, (size_t)a->n_rows_m1, &d.Xtversky));
     TRY(pool.up(a->l1 != 0.f ? a->Ytversky : nullptr, (size_t)a->n_output_cols, &d.Ytversky));
     TRY(pool.up(a->l2 != 0.f ? a->Xcosine : nullptr, (size_t)a->n_rows_m1, &d.Xcosine));
@@ -449,6 +539,7 @@ int run_host(sp_knn_args *a) {
     a->passes_total = d.passes_total;
     a->num_wgs_used = d.num_wgs_used;
     memcpy(a->phase_cycles, d.phase_cycles, sizeof(a->phase_cycles));
+    a->reserved[1] = d.reserved[1]; a->reserved[2] = d.reserved[2]; a->reserved[3] = d.reserved[3];
     return SP_OK;
 }
 
@@ -485,10 +576,123 @@ int64_t sp_knn_workspace_bytes(const sp_knn_args *a) {
         rc = device_cus(a->device, &n_cus);
         if (rc) return rc;
     }
+    if (a->flags & SP_FLAG_M2_IS_M1_T) {
+        sp_knn_args plain;
+        M2tLayout L;
+        rc = m2t_layout(a, n_cus, &plain, &L);
+        if (rc) return rc;
+        return (int64_t)L.total;
+    }
     Config c;
     rc = make_config(a, n_cus, &c);
     if (rc) return rc;
     return (int64_t)c.ws_total;
+}
+
+int64_t sp_csr_transpose_workspace_bytes(const sp_csr_transpose_args *a) {
+    if (!a || a->struct_size != sizeof(sp_csr_transpose_args)) return fail(SP_EINVAL, "sp_csr_transpose_args size mismatch");
+    if (a->nnz < 0 || a->n_cols < 0) return fail(SP_EINVAL, "negative size");
+    return (int64_t)transpose_ws_bytes(a->nnz, a->n_cols);
+}
+
+int sp_csr_transpose_f32_i32(sp_csr_transpose_args *a) {
+    g_err[0] = 0;
+    if (!a || a->struct_size != sizeof(sp_csr_transpose_args)) return fail(SP_EINVAL, "sp_csr_transpose_args size mismatch");
+    if (a->n_rows < 0 || a->n_cols < 0 || a->nnz < 0 || a->nnz > 0x7FFFFFFFLL) return fail(SP_EINVAL, "bad shape / nnz");
+    if (!a->indptr || !a->out_indptr || (a->nnz > 0 && (!a->data || !a->indices || !a->out_data || !a->out_indices)))
+        return fail(SP_EINVAL, "NULL input/output pointer");
+    const int ndev = sp_device_count();
+    if (ndev <= 0) return fail(SP_ENODEVICE, "no HIP device visible: similaripy_amd has no CPU fallback");
+    if (a->device < 0 || a->device >= ndev) return fail(SP_EINVAL, "device %d out of range (have %d)", a->device, ndev);
+    HIP_TRY(hipSetDevice(a->device));
+    const size_t need = transpose_ws_bytes(a->nnz, a->n_cols);
+    const bool timed = (a->flags & SP_FLAG_TIME_KERNEL) != 0;
+    a->kernel_ms = 0.f;
+    if (a->on_device) {
+        hipStream_t stream = (hipStream_t)a->stream;
+        unsigned char *ws = (unsigned char *)a->workspace;
+        bool own = false;
+        if (!ws) { HIP_TRY(hipMalloc((void **)&ws, need)); own = true; }
+        else if (a->workspace_bytes < (int64_t)need) return fail(SP_EWORKSPACE, "workspace too small: need %zu bytes, got %lld", need, (long long)a->workspace_bytes);
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        if (timed) { HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1)); HIP_TRY(hipEventRecord(ev0, stream)); }
+        int rc = transpose_device(a->n_rows, a->n_cols, a->nnz, a->data, a->indices, a->indptr, a->out_data, a->out_indices, a->out_indptr, ws, need, stream);
+        if (timed) {
+            if (!rc) { HIP_TRY(hipEventRecord(ev1, stream)); HIP_TRY(hipEventSynchronize(ev1)); HIP_TRY(hipEventElapsedTime(&a->kernel_ms, ev0, ev1)); }
+            (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
+        }
+        if (own) { (void)hipStreamSynchronize(stream); (void)hipFree(ws); }
+        return rc;
+    }
+    // host buffers in, host buffers out
+    for (int64_t i = 0; i < a->nnz; ++i)
+        if (a->indices[i] < 0 || a->indices[i] >= a->n_cols) return fail(SP_EINVAL, "indices[%lld]=%d out of range [0,%d)", (long long)i, a->indices[i], a->n_cols);
+    DevPool pool;
+    const float *d_data; const int32_t *d_indices, *d_indptr;
+    float *o_data; int32_t *o_indices, *o_indptr;
+    unsigned char *ws;
+    TRY(pool.up(a->data, (size_t)a->nnz, &d_data));
+    TRY(pool.up(a->indices, (size_t)a->nnz, &d_indices));
+    TRY(pool.up(a->indptr, (size_t)a->n_rows + 1, &d_indptr));
+    TRY(pool.alloc((size_t)a->nnz, &o_data));
+    TRY(pool.alloc((size_t)a->nnz, &o_indices));
+    TRY(pool.alloc((size_t)a->n_cols + 1, &o_indptr));
+    TRY(pool.alloc(need, &ws));
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (timed) { HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1)); HIP_TRY(hipEventRecord(ev0, nullptr)); }
+    int rc = transpose_device(a->n_rows, a->n_cols, a->nnz, d_data, d_indices, d_indptr, o_data, o_indices, o_indptr, ws, need, nullptr);
+    if (timed) {
+        if (!rc) { HIP_TRY(hipEventRecord(ev1, nullptr)); HIP_TRY(hipEventSynchronize(ev1)); HIP_TRY(hipEventElapsedTime(&a->kernel_ms, ev0, ev1)); }
+        (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
+    }
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    if (a->nnz > 0) {
+        HIP_TRY(hipMemcpy(a->out_data, o_data, (size_t)a->nnz * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(a->out_indices, o_indices, (size_t)a->nnz * 4, hipMemcpyDeviceToHost));
+    }
+    HIP_TRY(hipMemcpy(a->out_indptr, o_indptr, ((size_t)a->n_cols + 1) * 4, hipMemcpyDeviceToHost));
+    return SP_OK;
+}
+
+int sp_csr_row_sqsums_f32(sp_csr_sqsums_args *a) {
+    g_err[0] = 0;
+    if (!a || a->struct_size != sizeof(sp_csr_sqsums_args)) return fail(SP_EINVAL, "sp_csr_sqsums_args size mismatch");
+    if (a->n_rows < 0 || a->nnz < 0 || a->nnz > 0x7FFFFFFFLL) return fail(SP_EINVAL, "bad shape / nnz");
+    if (!a->indptr || (a->nnz > 0 && !a->data)) return fail(SP_EINVAL, "NULL input pointer");
+    const int ndev = sp_device_count();
+    if (ndev <= 0) return fail(SP_ENODEVICE, "no HIP device visible: similaripy_amd has no CPU fallback");
+    if (a->device < 0 || a->device >= ndev) return fail(SP_EINVAL, "device %d out of range (have %d)", a->device, ndev);
+    HIP_TRY(hipSetDevice(a->device));
+    a->kernel_ms = 0.f;
+    if (a->n_rows == 0 || (!a->out_rows && !a->out_cols_of_t)) return SP_OK;
+    const bool timed = (a->flags & SP_FLAG_TIME_KERNEL) != 0;
+    const int blocks = std::min(256 * 16, (a->n_rows + 255) / 256);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    DevPool pool;
+    const float *d_data = a->data;
+    const int32_t *d_indptr = a->indptr;
+    float *o_rows = a->out_rows, *o_cols = a->out_cols_of_t;
+    hipStream_t stream = a->on_device ? (hipStream_t)a->stream : nullptr;
+    if (!a->on_device) {
+        TRY(pool.up(a->data, (size_t)a->nnz, &d_data));
+        TRY(pool.up(a->indptr, (size_t)a->n_rows + 1, &d_indptr));
+        if (a->out_rows) TRY(pool.alloc((size_t)a->n_rows, &o_rows));
+        if (a->out_cols_of_t) TRY(pool.alloc((size_t)a->n_rows, &o_cols));
+    }
+    if (timed) { HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1)); HIP_TRY(hipEventRecord(ev0, stream)); }
+    hipLaunchKernelGGL(sp_row_sqsums_kernel, dim3(blocks), dim3(256), 0, stream, a->n_rows, d_data, d_indptr, o_rows, o_cols);
+    HIP_TRY(hipGetLastError());
+    if (timed) {
+        HIP_TRY(hipEventRecord(ev1, stream)); HIP_TRY(hipEventSynchronize(ev1)); HIP_TRY(hipEventElapsedTime(&a->kernel_ms, ev0, ev1));
+        (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
+    }
+    if (!a->on_device) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (a->out_rows) HIP_TRY(hipMemcpy(a->out_rows, o_rows, (size_t)a->n_rows * 4, hipMemcpyDeviceToHost));
+        if (a->out_cols_of_t) HIP_TRY(hipMemcpy(a->out_cols_of_t, o_cols, (size_t)a->n_rows * 4, hipMemcpyDeviceToHost));
+    }
+    return SP_OK;
 }
 
 int sp_knn_f32_i32(sp_knn_args *a) {

@@ -48,7 +48,7 @@ class DeviceProblem:
     def _args(self, targets_t, n_targets, cols_t, vals_t, counts_t, rows_t, stream, flags, tuning):
         c = self.call
         a = _abi.SpKnnArgs()
-        a.flags = flags | (0 if rows_t is not None else _abi.SP_FLAG_NO_ROWS_OUT)
+        a.flags = flags | (0 if rows_t is not None else _abi.SP_FLAG_NO_ROWS_OUT) | (_abi.SP_FLAG_M2_IS_M1_T if c.m2_is_m1t else 0)
         a.on_device = 1
         a.device = self.device.index or 0
         a.n_targets, a.n_rows_m1, a.n_rows_m2, a.n_output_cols = n_targets, c.n_rows_m1, c.n_rows_m2, c.n_output_cols
@@ -114,4 +114,4 @@ class DeviceProblem:
             a.workspace, a.workspace_bytes = self._ws.data_ptr(), self._ws.numel()
             _abi.call_knn(a)
         return {"kernel_ms": float(a.kernel_ms), "passes_total": int(a.passes_total), "phase_cycles": [int(x) for x in a.phase_cycles], "num_wgs": int(a.num_wgs_used),
-                "sparse_kernel_ms": int(a.reserved[1]) / 1e3, "generic_kernel_ms": int(a.reserved[2]) / 1e3}
+                "sparse_kernel_ms": int(a.reserved[1]) / 1e3, "generic_kernel_ms": int(a.reserved[2]) / 1e3, "transpose_ms": int(a.reserved[3]) / 1e3}

@@ -91,9 +91,20 @@ def oracle_backend(monkeypatch):
     from similaripy_amd import _host
 
     def run(call, *a, **kw):
+        if call.m2_is_m1t:
+            # the product leaves m1^T to the device (SP_FLAG_M2_IS_M1_T); the oracle gets it from scipy, as the reference does
+            import dataclasses
+            import scipy.sparse as sp
+            m2 = sp.csr_array((call.m1_data, call.m1_indices, call.m1_indptr), shape=(call.n_rows_m1, call.n_rows_m2)).T.tocsr()
+            m2.sort_indices()
+            call = dataclasses.replace(call, m2_data=np.ascontiguousarray(m2.data, dtype=np.float32),
+                                       m2_indices=np.ascontiguousarray(m2.indices, dtype=np.int32),
+                                       m2_indptr=np.ascontiguousarray(m2.indptr, dtype=np.int32), m2_is_m1t=False)
         rows, cols, values = so.run_kernel(call, "port")
         counts, _ = so.slot_counts(rows, cols, values, call.targets, call.k) if call.n_targets else (np.zeros(0, np.int32), None)
         return rows, cols, values, counts
 
     monkeypatch.setattr(_host, "run_hip", run)
+    # (same for the device-side norms of the `matrix2=None` call: their NumPy statement stands in)
+    monkeypatch.setattr(_host, "squared_norms_m1t_hip", lambda data, indptr, device=None: _host.build_squared_norms_m1t(data, indptr))
     return run

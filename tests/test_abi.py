@@ -1,4 +1,4 @@
-"""CPU tier: the C-ABI shared library loads and exports every symbol include/sp_knn.h declares.
+"""CPU tier: the C-ABI shared library loads and exports every symbol include/*.h declares.
 No compute calls (no GPU here); argument validation and the 'no device' refusal are exercised."""
 from __future__ import annotations
 
@@ -14,6 +14,7 @@ from similaripy_amd import _abi, _host
 
 ROOT = Path(__file__).resolve().parent.parent
 HEADER = (ROOT / "include" / "sp_knn.h").read_text()
+PREP_HEADER = (ROOT / "include" / "sp_prep.h").read_text()
 
 
 def test_library_builds_and_loads():
@@ -23,7 +24,7 @@ def test_library_builds_and_loads():
 
 def test_every_declared_symbol_is_exported():
     # function declarations of the header: `<ret> name(args);` at top level
-    declared = set(re.findall(r"^\s*(?:const\s+char\s*\*\s*|int64_t\s+|int\s+)(sp_[a-z0-9_]+)\s*\(", HEADER, flags=re.M))
+    declared = set(re.findall(r"^\s*(?:const\s+char\s*\*\s*|int64_t\s+|int\s+)(sp_[a-z0-9_]+)\s*\(", HEADER + PREP_HEADER, flags=re.M))
     assert declared, "no declarations parsed"
     assert declared == set(_abi.EXPORTED_SYMBOLS), (declared, _abi.EXPORTED_SYMBOLS)
     lib = _abi.load()
@@ -46,6 +47,45 @@ def test_struct_layout_matches_header_field_order():
         names += [re.sub(r"\[.*\]", "", r.strip().lstrip("*")) for r in rest]
     mirror = [f[0] for f in _abi.SpKnnArgs._fields_]
     assert names == mirror
+
+
+def test_transpose_struct_layout_and_refusals():
+    body = PREP_HEADER[PREP_HEADER.index("typedef struct sp_csr_transpose_args {") + len("typedef struct sp_csr_transpose_args {"):PREP_HEADER.index("} sp_csr_transpose_args;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = [re.sub(r"\[.*\]", "", stmt.strip().split()[-1].lstrip("*")) for stmt in body.split(";") if stmt.strip()]
+    assert names == [f[0] for f in _abi.SpCsrTransposeArgs._fields_]
+    lib = _abi.load()
+    a = _abi.SpCsrTransposeArgs()
+    a.struct_size = 4
+    assert lib.sp_csr_transpose_f32_i32(C.byref(a)) == -1             # SP_EINVAL
+    a.struct_size = C.sizeof(_abi.SpCsrTransposeArgs)
+    a.n_rows, a.n_cols, a.nnz = 3, 4, 10
+    assert lib.sp_csr_transpose_workspace_bytes(C.byref(a)) >= 10 * 8 + 5 * 8
+    indptr = np.zeros(4, dtype=np.int32)
+    out = np.zeros(5, dtype=np.int32)
+    a.nnz = 0
+    a.indptr, a.out_indptr = indptr.ctypes.data, out.ctypes.data
+    if lib.sp_device_count() == 0:
+        assert lib.sp_csr_transpose_f32_i32(C.byref(a)) == -2         # SP_ENODEVICE: no CPU fallback
+        assert b"no HIP device" in lib.sp_last_error()
+
+
+def test_sqsums_struct_layout_and_refusals():
+    body = PREP_HEADER[PREP_HEADER.index("typedef struct sp_csr_sqsums_args {") + len("typedef struct sp_csr_sqsums_args {"):PREP_HEADER.index("} sp_csr_sqsums_args;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = [re.sub(r"\[.*\]", "", stmt.strip().split()[-1].lstrip("*")) for stmt in body.split(";") if stmt.strip()]
+    assert names == [f[0] for f in _abi.SpCsrSqsumsArgs._fields_]
+    lib = _abi.load()
+    a = _abi.SpCsrSqsumsArgs()
+    a.struct_size = 4
+    assert lib.sp_csr_row_sqsums_f32(C.byref(a)) == -1                # SP_EINVAL
+    a.struct_size = C.sizeof(_abi.SpCsrSqsumsArgs)
+    indptr = np.zeros(4, dtype=np.int32)
+    a.n_rows, a.nnz, a.indptr = 3, 0, indptr.ctypes.data
+    if lib.sp_device_count() == 0:
+        assert lib.sp_csr_row_sqsums_f32(C.byref(a)) == -2            # SP_ENODEVICE: no CPU fallback
+        with pytest.raises(_abi.HipLibraryError):
+            _host.squared_norms_m1t_hip(np.ones(3, np.float32), np.array([0, 1, 3], np.int32))
 
 
 def test_struct_size_is_checked():

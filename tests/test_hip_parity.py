@@ -339,3 +339,104 @@ def test_sparse_kernel_row_selectors():
     for i, u in enumerate(t[:200]):
         have = urm.indices[urm.indptr[u]:urm.indptr[u + 1]]
         assert not np.intersect1d(cols[i * 40:i * 40 + counts[i]], have).size
+
+
+# --------------------------------------------------------------------------------------------
+# device-side preprocessing (include/sp_prep.h): the transpose of the `matrix2=None` call
+# --------------------------------------------------------------------------------------------
+def _transpose_hip(m):
+    """sp_csr_transpose_f32_i32 with host buffers (the binding of INTEGRATION.md)."""
+    from similaripy_amd import _abi
+    m = m.tocsr()
+    data = np.ascontiguousarray(m.data, dtype=np.float32)
+    indices = np.ascontiguousarray(m.indices, dtype=np.int32)
+    indptr = np.ascontiguousarray(m.indptr, dtype=np.int32)
+    out_data = np.empty(data.shape[0], dtype=np.float32)
+    out_indices = np.empty(data.shape[0], dtype=np.int32)
+    out_indptr = np.empty(m.shape[1] + 1, dtype=np.int32)
+    a = _abi.SpCsrTransposeArgs()
+    a.on_device, a.device = 0, 0
+    a.n_rows, a.n_cols, a.nnz = m.shape[0], m.shape[1], data.shape[0]
+    a.data, a.indices, a.indptr = data.ctypes.data, indices.ctypes.data, indptr.ctypes.data
+    a.out_data, a.out_indices, a.out_indptr = out_data.ctypes.data, out_indices.ctypes.data, out_indptr.ctypes.data
+    _abi.call_transpose(a)
+    return out_data, out_indices, out_indptr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,density,seed", [((300, 200), 0.05, 1), ((60, 4000), 0.2, 2), ((5000, 7), 0.6, 3),
+                                                ((1, 50), 0.5, 4), ((50, 1), 0.5, 5), ((40, 40), 0.0, 6)])
+def test_device_transpose_matches_scipy(shape, density, seed):
+    """m.T.tocsr() (s_plus.pyx:169-170, 205-206), bit for bit: row pointers, ascending column ids, values."""
+    m = sp.random_array(shape, density=density, format="csr", dtype=np.float32, random_state=np.random.default_rng(seed))
+    m.sort_indices()
+    d, i, p = _transpose_hip(m)
+    ref = m.T.tocsr()
+    ref.sort_indices()
+    assert np.array_equal(p, ref.indptr.astype(np.int32))
+    assert np.array_equal(i, ref.indices.astype(np.int32))
+    assert np.array_equal(d.view(np.uint32), ref.data.astype(np.float32).view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_device_transpose_long_and_skewed_rows():
+    """Output rows in all three sort classes (<= 1024 records in LDS, <= 16384 in LDS, beyond: global memory), empty
+    output rows, and a column every input row hits."""
+    rng = np.random.default_rng(11)
+    n_rows, n_cols = 40_000, 600
+    cols = [np.array([0], dtype=np.int64)] * n_rows                                       # column 0: 40 000 records
+    extra = [np.unique(np.concatenate(([1] if r % 3 == 0 else [], 2 + rng.integers(0, 400, size=rng.integers(0, 6))))).astype(np.int64) for r in range(n_rows)]
+    indptr = np.zeros(n_rows + 1, dtype=np.int64)
+    idx = []
+    for r in range(n_rows):
+        row = np.concatenate((cols[r], extra[r]))
+        idx.append(row)
+        indptr[r + 1] = indptr[r] + row.shape[0]
+    indices = np.concatenate(idx).astype(np.int32)
+    data = rng.standard_normal(indices.shape[0]).astype(np.float32)
+    m = sp.csr_array((data, indices, indptr.astype(np.int32)), shape=(n_rows, n_cols))     # columns 402.. stay empty
+    d, i, p = _transpose_hip(m)
+    ref = m.T.tocsr()
+    ref.sort_indices()
+    lens = np.diff(ref.indptr)
+    assert lens.max() > 16384 and ((lens > 1024) & (lens <= 16384)).any() and (lens == 0).any()
+    assert np.array_equal(p, ref.indptr.astype(np.int32))
+    assert np.array_equal(i, ref.indices.astype(np.int32))
+    assert np.array_equal(d.view(np.uint32), ref.data.view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,kw", [("cosine", {}), ("jaccard", {}), ("dice", {"shrink": 3}), ("asymmetric_cosine", {"alpha": 0.3}),
+                                     ("tversky", {"alpha": 0.7, "beta": 0.2}), ("dot_product", {}),
+                                     ("s_plus", {"l1": 0.4, "l2": 0.6, "t1": 0.8, "t2": 0.5, "c1": 0.4, "c2": 0.6, "shrink": 2.0})])
+def test_public_call_with_device_transpose_matches_host_transpose(name, kw):
+    """`sim.f(m)` builds m.T on the device (SP_FLAG_M2_IS_M1_T); `sim.f(m, m.T)` takes the host-built transpose through
+    the same kernel.  Same top-k sets, values within 1e-6 relative (the column norms are summed as the reference sums
+    them in both paths)."""
+    import similaripy_amd as sim
+    m = sp.random_array((700, 500), density=0.04, format="csr", dtype=np.float32, random_state=np.random.default_rng(21))
+    f = getattr(sim, name)
+    a = f(m, k=12, verbose=False, format_output="csr", **kw).tocsr()
+    b = f(m, m.T.tocsr(), k=12, verbose=False, format_output="csr", **kw).tocsr()
+    a.sort_indices(); b.sort_indices()
+    assert a.shape == b.shape
+    da, db = a.toarray(), b.toarray()
+    close = np.isclose(da, db, rtol=1e-6, atol=0)
+    # entries present on one side only may differ where the k-th value is tied
+    assert close.mean() > 0.9999
+    assert np.allclose(np.sort(da, axis=1)[:, -12:], np.sort(db, axis=1)[:, -12:], rtol=1e-6, atol=0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lens", [[0, 1, 2, 7, 8, 9, 15, 16, 17, 0, 64, 127, 128, 129, 130, 137, 0], [255, 256, 257, 300, 513, 1025, 4097, 10000, 70001],
+                                  [64] * 3000])
+def test_device_squared_norms_bit_identical_to_numpy(lens):
+    """sp_csr_row_sqsums_f32 against the host statement of s_plus_utils.pyx:128-201 (np.add.reduceat / np.bincount):
+    every float32, bit for bit — NumPy's pairwise blocks included."""
+    rng = np.random.default_rng(5)
+    indptr = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
+    data = (rng.standard_normal(int(indptr[-1])) * rng.choice([1e-3, 1.0, 30.0], size=int(indptr[-1]))).astype(np.float32)
+    want1, want2 = _host.build_squared_norms_m1t(data, indptr)
+    got1, got2 = _host.squared_norms_m1t_hip(data, indptr)
+    assert np.array_equal(got1.view(np.uint32), want1.view(np.uint32))
+    assert np.array_equal(got2.view(np.uint32), want2.view(np.uint32))
