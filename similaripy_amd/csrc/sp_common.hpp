@@ -1,6 +1,9 @@
 // sp_common.hpp — device-side vocabulary shared by the kernels of libsimilaripy_hip.so (gfx950 only).
 // Epilogue, candidate filter, top-k buffer primitives, selections.  Reference: similaripy/cython_code/s_plus.h.
 #pragma once
+#ifndef SP_ABLATION
+#define SP_ABLATION 0
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
@@ -61,7 +64,8 @@ struct KParams {
     int sparse_path;       // 1 = rows with few expected collisions take the bitmap path
     int fold;              // 1 = the single active column term (Ycos or Ydep) is already divided into m2_data: treat it as 1
     unsigned long long *phase_cycles;  // optional [PH_N]
-    int dbg;               // ablation bits for profiling only (results are WRONG when non-zero; 8 / 16: sweep 1 / sweep 2 of the sparse kernel load but do not process):
+    int dbg;               // ablation bits for profiling only (results are WRONG when non-zero; 8 / 16: sweep 1 / sweep 2 of the sparse kernel
+                           // load but do not process — compiled in only with -DSP_ABLATION=1: the test costs the sweeps 1 %):
                            // 1 = generic accumulate: no LDS inserts, 4 = no Y gathers
 };
 

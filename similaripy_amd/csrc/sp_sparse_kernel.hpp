@@ -305,7 +305,9 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 };
                 auto body = [&](const unsigned (&c)[8], int cnt0, int cnt1) __attribute__((always_inline)) {
                     if (cnt0 == 0) return;                 // sentinel pair (wave-uniform; the second item of a pair may be the sentinel)
+#if SP_ABLATION
                     if (p.dbg & 8) { asm volatile("" ::"v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7])); return; }   // ablation: loads only
+#endif
                     unsigned seen[8];
                     if (cnt0 == ITEM && cnt1 == ITEM) s1_core8<CBM_BYTES + PRE_BYTES, false>(c, 4 * lane, cnt0, cnt1, amask, seen);
                     else s1_core8<CBM_BYTES + PRE_BYTES, true>(c, 4 * lane, cnt0, cnt1, amask, seen);      // padding ORs nothing
@@ -557,7 +559,9 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     const float cut = MONO ? cutx : rc.xy_cut;
                     auto body = [&](const unsigned (&c)[4], const float (&v)[4], int cnt, float segv) __attribute__((always_inline)) {
                         if (cnt == 0) return;                  // sentinel (wave-uniform)
+#if SP_ABLATION
                         if (p.dbg & 16) { asm volatile("" ::"v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); return; }   // ablation: loads only
+#endif
                         // M: product of a marked column; S: otherwise the product is the only one of its column and
                         // matters only if its raw dot can still enter the top-k (NaN stays: the exact judge drops it)
                         float x[4];
