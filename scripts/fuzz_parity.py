@@ -1,0 +1,147 @@
+"""Randomised parity sweep on the GPU: HIP kernels (through the C ABI) against the oracle port on seeded random cases —
+shapes that hit both row kernels, every epilogue family, shrinks, thresholds, signed values, ties (binary / quantised
+data), target rows, ARRAY / MATRIX selectors, explicit and implicit m2, small tiles (forces windows / give-ups).
+Tie-aware comparison as in tests/test_hip_parity.py (identical sets where untied, values within 1e-5 relative).
+    python scripts/fuzz_parity.py --cases 300 --seed 1
+Test infrastructure: the oracle is only the checker here."""
+import argparse, sys, time, traceback
+from pathlib import Path
+import numpy as np, scipy.sparse as sp
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+from oracle import splus_oracle as so
+from similaripy_amd import _host
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--cases", type=int, default=200)
+ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--only", type=int, default=-1, help="run only this case of the seed's sequence (the others are generated and skipped)")
+ap.add_argument("--dump-slot", type=int, default=-1, help="with --only: print both sides of this slot")
+ap.add_argument("--tuning", default="", help="with --only: override the case's tuning, e.g. table_slots=2048,no_sparse_path=1")
+ap.add_argument("--max-macs", type=float, default=4e8, help="skip cases whose oracle run would take too long")
+a = ap.parse_args()
+rng = np.random.default_rng(a.seed)
+
+
+def rand_matrix(n_rows, n_cols, density, kind):
+    m = sp.random_array((n_rows, n_cols), density=density, format="csr", dtype=np.float32, random_state=rng)
+    if kind == "binary":
+        m.data[:] = 1.0
+    elif kind == "quant":
+        m.data[:] = np.round(m.data * 4 + 1) / 4           # heavy ties
+    elif kind == "signed":
+        m.data[:] = (m.data - 0.5) * 2
+    elif kind == "skewed":                                   # popular columns / long rows
+        cols = (rng.pareto(1.2, size=m.nnz) * n_cols / 50).astype(np.int64) % n_cols
+        m = sp.csr_array((m.data, cols.astype(np.int32), m.indptr), shape=m.shape)
+        m.sum_duplicates()
+    return m
+
+
+def one_case(i):
+    shape_kind = rng.choice(["small", "wide_out", "tall", "dense_rows"])
+    if shape_kind == "small":
+        n_rows, n_cols, dens = int(rng.integers(1, 400)), int(rng.integers(1, 300)), float(rng.choice([0.02, 0.1, 0.4]))
+    elif shape_kind == "wide_out":          # m2 = m.T has many columns: the sparse kernel
+        n_rows, n_cols, dens = int(rng.integers(20000, 60000)), int(rng.integers(500, 4000)), float(rng.choice([0.002, 0.005, 0.01]))
+    elif shape_kind == "tall":
+        n_rows, n_cols, dens = int(rng.integers(3000, 9000)), int(rng.integers(50, 400)), float(rng.choice([0.02, 0.08]))
+    else:
+        n_rows, n_cols, dens = int(rng.integers(200, 1500)), int(rng.integers(2000, 8000)), float(rng.choice([0.02, 0.05]))
+    kind = str(rng.choice(["plain", "plain", "binary", "quant", "signed", "skewed"]))
+    m = rand_matrix(n_rows, n_cols, dens, kind)
+    explicit_m2 = rng.random() < 0.3
+    m2 = None
+    if explicit_m2:
+        nc2 = int(rng.integers(1, 5000)) if shape_kind != "wide_out" else int(rng.integers(20000, 50000))
+        m2 = rand_matrix(n_cols, nc2, float(rng.choice([0.002, 0.01, 0.05])) if nc2 > 1000 else 0.1, str(rng.choice(["plain", "signed", "quant"])))
+    n_out = m.shape[0] if m2 is None else m2.shape[1]
+    fam = str(rng.choice(["dot", "cosine", "asym", "tversky", "jaccard", "dice", "splus", "depop", "rp3like"]))
+    kw = {}
+    if fam == "cosine": kw.update(l2=1.0)
+    elif fam == "asym": kw.update(l2=1.0, c1=float(rng.random()), c2=float(rng.random()))
+    elif fam == "tversky": kw.update(l1=1.0, t1=float(rng.random()), t2=float(rng.random()))
+    elif fam == "jaccard": kw.update(l1=1.0, t1=1.0, t2=1.0)
+    elif fam == "dice": kw.update(l1=1.0, t1=0.5, t2=0.5)
+    elif fam == "splus": kw.update(l1=float(rng.random()), l2=float(rng.random()), t1=float(rng.random()), t2=float(rng.random()), c1=float(rng.random()), c2=float(rng.random()))
+    elif fam == "depop": kw.update(l1=0.3, l2=0.3, l3=0.4, weight_depop_matrix1="sum", weight_depop_matrix2="sum", p1=float(rng.random()), p2=float(rng.random()))
+    elif fam == "rp3like": kw.update(l3=1.0, weight_depop_matrix2="sum", p2=float(rng.random()))
+    if fam != "dot" and rng.random() < 0.4:
+        kw[str(rng.choice(["stabilized_shrink", "bayesian_shrink", "additive_shrink"]))] = float(rng.choice([0.5, 3.0, 20.0]))
+    thr_draw, thr_val = rng.random(), float(rng.choice([0.0, 1e-3, 0.05, 0.3, -0.1]))
+    if thr_draw < 0.25 and kind not in ("quant", "binary") and not kw.get("binary"):     # (quantised values sit ON round thresholds: which side a value falls is rounding)
+        kw["threshold"] = thr_val
+    if rng.random() < 0.15: kw["a1"] = float(rng.choice([0.5, 2.0]))
+    if rng.random() < 0.2: kw["binary"] = True
+    k = int(rng.choice([1, 5, 10, 50, 100, 200, 1000]))
+    n_t = int(min(m.shape[0], rng.choice([m.shape[0], 50, 300, 1500])))
+    targets = None if n_t == m.shape[0] and rng.random() < 0.5 else np.sort(rng.choice(m.shape[0], size=n_t, replace=False)).astype(np.int32)
+    sel = rng.random()
+    if sel < 0.12: kw["filter_cols"] = rng.choice(n_out, size=max(1, n_out // 7), replace=False).tolist()
+    elif sel < 0.2: kw["target_cols"] = rng.choice(n_out, size=max(1, n_out // 3), replace=False).tolist()
+    elif sel < 0.32: kw["filter_cols"] = sp.random_array((m.shape[0], n_out), density=min(0.5, 30.0 / max(n_out, 1)), format="csr", dtype=np.float32, random_state=rng)
+    elif sel < 0.4: kw["target_cols"] = sp.random_array((m.shape[0], n_out), density=min(0.9, 200.0 / max(n_out, 1)), format="csr", dtype=np.float32, random_state=rng)
+    tuning = {}
+    if rng.random() < 0.2: tuning["table_slots"] = int(rng.choice([1024, 2048, 4096]))
+    if rng.random() < 0.15: tuning["threads_per_wg"] = int(rng.choice([256, 512, 768]))
+    on_dev = (m2 is None) and rng.random() < 0.6
+    desc = f"#{i} {shape_kind} {m.shape} kind={kind} m2={'explicit ' + str(m2.shape) if m2 is not None else 'm1.T' + ('(device)' if on_dev else '')} fam={fam} k={k} targets={'all' if targets is None else len(targets)} kw={ {x: (v if not hasattr(v, 'shape') and not isinstance(v, list) else type(v).__name__) for x, v in kw.items()} } tuning={tuning}"
+    if a.only >= 0 and i != a.only:
+        return "skipped", desc
+    if a.tuning:
+        tuning = {x.split("=")[0]: int(x.split("=")[1]) for x in a.tuning.split(",")}
+    call = _host.prepare(m, m2, k=k, target_rows=targets, m2_on_device=on_dev, **kw)
+    # bound the oracle's work
+    ref_call = call
+    if call.m2_is_m1t:
+        import dataclasses
+        t = sp.csr_array((call.m1_data, call.m1_indices, call.m1_indptr), shape=(call.n_rows_m1, call.n_rows_m2)).T.tocsr(); t.sort_indices()
+        ref_call = dataclasses.replace(call, m2_data=np.ascontiguousarray(t.data, np.float32), m2_indices=np.ascontiguousarray(t.indices, np.int32), m2_indptr=np.ascontiguousarray(t.indptr, np.int32), m2_is_m1t=False)
+    colnnz = np.diff(ref_call.m2_indptr)
+    macs = float(colnnz[ref_call.m1_indices].sum()) * (len(ref_call.targets) / max(1, ref_call.n_rows_m1))
+    if macs > a.max_macs:
+        return "skipped", desc
+    rows, cols, vals, counts = _host.run_hip(call, **tuning)
+    got = so.canonical(rows, cols, vals, call.targets, call.k)
+    want = so.canonical(*so.run_kernel(ref_call, "port"), call.targets, call.k)
+    if a.dump_slot >= 0:
+        gc, gv = got[a.dump_slot]; wc, wv = want[a.dump_slot]
+        print(desc); print("got ", dict(zip(gc.tolist(), gv.tolist()))); print("want", dict(zip(wc.tolist(), wv.tolist())))
+        miss = sorted(set(wc.tolist()) - set(gc.tolist())); print("missing", miss, "target row", call.targets[a.dump_slot])
+        t = int(call.targets[a.dump_slot])
+        us = call.m1_indices[call.m1_indptr[t]:call.m1_indptr[t + 1]]
+        allc = np.concatenate([ref_call.m2_indices[ref_call.m2_indptr[u]:ref_call.m2_indptr[u + 1]] for u in us]) if len(us) else np.zeros(0, np.int32)
+        uq, cn = np.unique(allc, return_counts=True)
+        print("row has", len(us), "m1 entries,", allc.shape[0], "products,", uq.shape[0], "distinct columns; products per missing column:", {int(c): int(cn[uq == c][0]) for c in miss},
+              "; multi-product columns:", int((cn > 1).sum()), "segment lengths", [int(ref_call.m2_indptr[u + 1] - ref_call.m2_indptr[u]) for u in us])
+        import dataclasses
+        one = dataclasses.replace(call, targets=np.array([t], dtype=np.int32))
+        r1, c1, v1, n1 = _host.run_hip(one, **tuning)
+        print("alone: kept", int(n1[0]), "missing", sorted(set(wc.tolist()) - set(c1[:n1[0]].tolist())))
+        info = _host.run_hip(one, time_kernel=True, **tuning)[4]
+        print("alone: rows sparse / given up:", info["phase_cycles"][9], info["phase_cycles"][10])
+    # signed data: sums cancel, and a different (equally valid) summation order moves a value by more than 1e-5 of itself
+    signed = kind == "signed" or (m2 is not None and bool((m2.data < 0).any()))
+    # ... and with a Bayesian shrink b the value has a pole at raw dot = -b: near it no tolerance is meaningful
+    pole = signed and kw.get("bayesian_shrink", 0.0) != 0.0      # (values there may differ by any factor: 1e9 = sets only)
+    so.compare_topk(got, want, call.k, rtol=(1e9 if pole else 1e-4) if signed else 1e-5, atol=1e-6 if signed else 1e-7, what=desc)
+    n, kk = call.n_targets, call.k
+    pad = np.arange(kk)[None, :] >= counts[:, None]
+    assert not rows.reshape(n, kk)[pad].any() and not cols.reshape(n, kk)[pad].any() and not vals.reshape(n, kk)[pad].any(), "padding not zero: " + desc
+    return "ok", desc
+
+
+t0 = time.time()
+stats = {"ok": 0, "skipped": 0, "failed": 0}
+for i in range(a.cases):
+    state = rng.bit_generator.state
+    try:
+        r, desc = one_case(i)
+        stats[r] += 1
+    except Exception as exc:      # keep going: report every failing case with what it takes to reproduce it
+        stats["failed"] += 1
+        print(f"FAILED case {i} (seed {a.seed}): {type(exc).__name__}: {str(exc)[:600]}", flush=True)
+        if not isinstance(exc, AssertionError):
+            traceback.print_exc()
+print(f"fuzz: {stats} in {time.time() - t0:.0f}s (seed {a.seed})")
+sys.exit(1 if stats["failed"] else 0)

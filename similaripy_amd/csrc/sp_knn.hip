@@ -81,7 +81,7 @@ struct Config {
 constexpr size_t WS_QUEUE_BYTES = 256;
 constexpr size_t WS_PHASE_OFFSET = 64;
 constexpr size_t WS_YMIN_OFFSET = 176;
-static_assert(WS_PHASE_OFFSET + PH_N * 8 <= WS_YMIN_OFFSET && WS_YMIN_OFFSET + 12 <= WS_QUEUE_BYTES, "workspace header layout");
+static_assert(WS_PHASE_OFFSET + PH_N * 8 <= WS_YMIN_OFFSET && WS_YMIN_OFFSET + 16 <= WS_QUEUE_BYTES, "workspace header layout");
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
 // LDS of the two kernels without the candidate buffer (see their carve-ups)
@@ -271,6 +271,13 @@ int run_device_impl(sp_knn_args *a) {
         HIP_TRY(hipGetLastError());
     }
 
+    int *neg_flag = (int *)(ws + WS_YMIN_OFFSET + 12);      // (inside the zeroed header)
+    if (a->bayesian_shrink != 0.f) {
+        if (a->nnz_m1 > 0) hipLaunchKernelGGL(sp_any_negative_kernel, dim3(1024), dim3(256), 0, stream, (long long)a->nnz_m1, a->m1_data, neg_flag);
+        if (a->nnz_m2 > 0) hipLaunchKernelGGL(sp_any_negative_kernel, dim3(1024), dim3(256), 0, stream, (long long)a->nnz_m2, a->m2_data, neg_flag);
+        HIP_TRY(hipGetLastError());
+    }
+
     KParams kp;
     memset(&kp, 0, sizeof(kp));
     kp.n_targets = a->n_targets; kp.targets = a->targets;
@@ -328,6 +335,7 @@ int run_device_impl(sp_knn_args *a) {
     kp.ymin = ymin_dev;
     kp.Ypack = ypack;
     kp.bound_ok = bound_ok ? 1 : 0;
+    kp.neg_flag = (a->bayesian_shrink != 0.f) ? neg_flag : nullptr;
     kp.fold = c.fold ? 1 : 0;
     if (c.fold) kp.m2_data = folded;
     kp.phase_cycles = (timed && (a->flags & SP_FLAG_PHASE_TIMERS)) ? (unsigned long long *)(ws + WS_PHASE_OFFSET) : nullptr;   // inside the zeroed header

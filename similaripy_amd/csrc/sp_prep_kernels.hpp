@@ -172,6 +172,13 @@ __global__ __launch_bounds__(256) void sp_pack_colterms_kernel(int n_cols, const
         out[i] = make_float4(Ytv ? Ytv[i] : 0.f, Ycos ? Ycos[i] : 0.f, Ydep ? Ydep[i] : 0.f, 0.f);
 }
 
+// *flag |= 1 iff any value is negative (the Bayesian-shrink epilogue is not monotone in a negative raw dot)
+__global__ __launch_bounds__(256) void sp_any_negative_kernel(long long nnz, const float *__restrict__ data, int *__restrict__ flag) {
+    bool neg = false;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nnz; i += (long long)gridDim.x * blockDim.x) neg |= data[i] < 0.f;
+    if (__ballot(neg) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
 // Fold the column term of a product-form epilogue into the m2 stream:  out[i] = data[i] / Y[indices[i]]
 // (0 where Y is 0: the reference returns 0 for a zero denominator, s_plus.h:147-150).  One streaming pass.
 __global__ __launch_bounds__(256) void sp_fold_colterm_kernel(long long nnz, const int *__restrict__ indices,

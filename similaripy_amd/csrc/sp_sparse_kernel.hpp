@@ -173,13 +173,21 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 const u64 H = __ballot(heavy), Lg = __ballot(key != 0u && !heavy);
                 const int pos = heavy ? mbcnt64(H) : __popcll(H) + mbcnt64(Lg);
                 const int nit = (my_len + ITEM - 1) / ITEM;
-                int *scr = (int *)items;                       // scratch (the items are written after it is read back)
+                // Scratch (the items are written after it is read back).  The lanes of this wave talk to each other through
+                // it without a barrier: LDS executes a wave's accesses in order.  To the compiler that is one thread reading
+                // back its own store — for a lane without a segment it folded the read to the 0 just written there and lost
+                // the segment another lane had scattered to that position (rows whose m1 entries point at EMPTY m2 rows;
+                // found by scripts/fuzz_parity.py).  The wavefront-scope fences emit no instruction; they keep the
+                // compiler from forwarding a lane's own store across them.
+                int *scr = (int *)items;
                 scr[tid] = 0; scr[64 + tid] = 0;
                 if (key != 0u) { scr[pos] = nit; scr[64 + pos] = my_len; }
-                const int nit_p = scr[tid], len_p = scr[64 + tid];          // same wave: LDS accesses are in order
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                const int nit_p = scr[tid], len_p = scr[64 + tid];
                 const int ib_incl = wave_incl_scan_dpp(nit_p), fs_incl = wave_incl_scan_dpp(len_p);
                 scr[128 + tid] = ib_incl - nit_p;
                 scr[192 + tid] = fs_incl - len_p;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 if (key != 0u) { my_ib = scr[128 + pos]; my_fs = scr[192 + pos]; }
                 if (tid == 63) sh[SH_NITEMS] = ib_incl;
             }
@@ -251,6 +259,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             // den = l1*(t1*(X-xy) + t2*(Y-xy) + xy) + l2*Xc*Yc + l3*Xd*Yd + stab  >=  bA + bB*xy  when the
             // column terms are replaced by their minima and their multipliers are non-negative
             epi.bound = p.bound_ok && !(epi.xcos < 0.f) && !(epi.xdep < 0.f);
+            epi.cut_ok = !(p.bayes != 0.f && p.neg_flag != nullptr && *p.neg_flag != 0);
             epi.bA = p.l1 * (p.t1 * epi.xtv + p.t2 * ymin_tv) + p.l2 * epi.xcos * ymin_cos + p.l3 * epi.xdep * ymin_dep + p.stab;
             epi.bB = p.l1 * (1.f - p.t1 - p.t2);
             rc.set_cut(p.threshold);
@@ -269,7 +278,6 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             }
             __syncthreads();
             PHASE_END(PH_SEGMENTS);
-
             // ---- sweep 1: column ids only.  Branch-free: every product ORs its bit into the bitmap; the returned
             // word tells whether the column was there already, in which case (only then a non-zero operand) the
             // column's bit is ORed into the collision bitmap as well. ----

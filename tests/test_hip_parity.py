@@ -311,6 +311,39 @@ def test_sparse_kernel_signed_values_and_thresholds():
     _check(_host.prepare(m, k=25, l1=1, t1=1, t2=1, threshold=0.001, target_rows=t), "signed jaccard-like")
 
 
+@pytest.mark.parametrize("shape,density", [((40000, 2000), 0.005), ((1500, 2500), 0.04)], ids=["sparse_kernel", "generic_kernel"])
+def test_bayesian_shrink_with_negative_values(shape, density):
+    """xy/(xy+b) is not monotone for a negative raw dot: xy in (-b, 0) gives large POSITIVE values, so no raw-dot cutoff may
+    drop negative dots (found by scripts/fuzz_parity.py)."""
+    m = _rand(shape, density, 77)
+    m.data[:] = (m.data - 0.5) * 2
+    for kw in (dict(l2=1, c1=0.55, c2=0.4, bayesian_shrink=0.5), dict(l1=1, t1=0.6, t2=0.4, bayesian_shrink=2.0), dict(l2=1, bayesian_shrink=0.5, stabilized_shrink=1.0)):
+        call = _host.prepare(m, k=100, target_rows=np.arange(0, shape[0], 23), **kw)
+        rows, cols, vals, counts = _host.run_hip(call)
+        got = so.canonical(rows, cols, vals, call.targets, call.k)
+        want = so.canonical(*so.run_kernel(call, "port"), call.targets, call.k)
+        # cancelling sums, and a pole of the value at xy = -b: the index sets must agree, the values only roughly
+        so.compare_topk(got, want, call.k, rtol=2e-2, atol=1e-6, what=f"bayes+negatives {kw}")
+
+
+def test_sparse_kernel_rows_pointing_at_empty_m2_rows():
+    """An explicit m2 with EMPTY rows (an item without neighbours in the scoring shape, BASELINE configs[4]): the segment
+    order of a target row then has lanes without a segment between lanes with one.  (A compiler-folded read in that
+    ordering lost whole segments; found by scripts/fuzz_parity.py.)"""
+    rng = np.random.default_rng(41)
+    m1 = sp.random_array((6000, 400), density=0.03, format="csr", dtype=np.float32, random_state=rng)           # ~12 entries per row
+    m2 = sp.random_array((400, 30000), density=0.0001, format="csr", dtype=np.float32, random_state=rng)      # ~3 per row: ~5 % of the rows empty
+    assert (np.diff(m2.indptr) == 0).sum() > 5
+    for kw in ({}, dict(l2=1), dict(l1=1, t1=0.7, t2=0.9)):
+        call = _host.prepare(m1, m2, k=50, **kw)
+        _check(call, f"empty m2 rows {kw}")
+        pc = _info(call)
+        assert pc[9] > 0.9 * call.n_targets          # served by the sparse kernel
+    # the same through a small tile (every pool tiny)
+    call = _host.prepare(m1, m2, k=50)
+    _check(call, "empty m2 rows, small tile", table_slots=2048)
+
+
 def test_sparse_kernel_small_pools_give_up_to_generic():
     """With a small accumulator tile the sparse kernel's pools overflow for most rows: they must come back right
     through the generic kernel's queue."""
