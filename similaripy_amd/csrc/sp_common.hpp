@@ -26,7 +26,7 @@ constexpr int U_SLACK = 1024;    // candidate-buffer entries beyond k (room betw
 #define DRAIN_UNROLL (NT >= 1024 ? 2 : NT >= 768 ? 4 : 8)
 
 // scalar slots in LDS
-enum { SH_CNT = 0, SH_OVF, SH_SEL, SH_NEED, SH_EQ, SH_CNT2, SH_RETRY, SH_QA, SH_QB, SH_PCTR, SH_MCTR, SH_NITEMS, SH_STOP, SH_WSUM, SH_N = SH_WSUM + 16 };   // SH_CNT2/SEL/NEED/EQ belong to the selections
+enum { SH_CNT = 0, SH_OVF, SH_SEL, SH_NEED, SH_EQ, SH_CNT2, SH_RETRY, SH_QA, SH_QB, SH_PCTR, SH_MCTR, SH_NITEMS, SH_STOP, SH_WSUM, SH_NHI = SH_WSUM + 16, SH_N };   // SH_CNT2/SEL/NEED/EQ belong to the selections
 
 // phases timed by lane 0 of every workgroup when KParams::phase_cycles != NULL, then event counters
 enum { PH_SETUP = 0, PH_SEGMENTS, PH_ACCUM, PH_DRAIN, PH_SELECT, PH_OUTPUT, PH_SWEEP1, PH_SWEEP2, PH_CSDRAIN,
@@ -718,11 +718,15 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
 // Must be entered by the whole workgroup.  Returns -1 when n <= k (nothing done).
 // ZERO_TAIL: the buffer is used with block-wise reservations (holes = zero entries): positions beyond the kept
 // entries are zeroed so that a later reservation never exposes stale entries.
+// hint: a key every live entry is known to reach (the running cutoff; 0 = none).  An exact selection then starts at the
+// second digit: the entries whose first byte exceeds the hint's are only counted, the others of its byte go straight
+// into the second histogram — one radix pass (fill, two barriers, walk) less whenever the k-th largest shares the
+// hint's first byte, which is the rule (else: the regular four passes).
 template <int NT, bool ZERO_TAIL = false, int E = 4>
-__device__ long long select_fast(u64 *U, int *hist4, int *sh, int k, bool exact) {
+__device__ long long select_fast(u64 *U, int *hist4, int *sh, int k, bool exact, unsigned hint = 0u) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int n = min(sh[SH_CNT], E * NT);
-    if (tid == 0) { sh[SH_CNT2] = 0; sh[SH_EQ] = 0; }   // (the generic path's selection leaves them dirty)
+    if (tid == 0) { sh[SH_CNT2] = 0; sh[SH_EQ] = 0; sh[SH_NHI] = 0; }   // (the generic path's selection leaves them dirty)
     __syncthreads();
     if (n <= k) return -1;
     u64 e[E];
@@ -738,14 +742,46 @@ __device__ long long select_fast(u64 *U, int *hist4, int *sh, int k, bool exact)
     unsigned prefix = 0;
     int need = k;
     int passes = 0;
-    for (int ps = 0; ps < 4; ++ps) {
+    int first_ps = 0;
+    bool prefilled = false;
+    if (exact && hint != 0u) {       // (uniform; intermediate selections measured slower with it: their cutoff is often a byte below)
+        const unsigned top = hint >> 24;
+        int *h1 = hist4 + 256;
+        int mine = 0;                // entries above the hint's first byte | entries of that byte << 16
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            if (has[j]) {
+                const unsigned kb = key[j] >> 24;
+                if (kb == top) { atomicAdd(&h1[(key[j] >> 16) & 255u], 1); mine += 1 << 16; }
+                else if (kb > top) mine += 1;
+            }
+        }
+        const int tot = wave_incl_scan_dpp(mine);
+        if (lane == 63 && tot) atomicAdd(&sh[SH_NHI], tot);
+        __syncthreads();
+        const int both = sh[SH_NHI];
+        const int n_hi = both & 0xFFFF, n_top = both >> 16;
+        if (n_hi < k && k - n_hi <= n_top) {
+            prefix = top << 24;
+            need = k - n_hi;
+            first_ps = 1;
+            prefilled = true;
+            passes = 1;
+        } else {                     // the k-th largest is not in the hint's byte: regular passes
+            for (int i = tid; i < 256; i += NT) h1[i] = 0;
+            __syncthreads();
+        }
+    }
+    for (int ps = first_ps; ps < 4; ++ps) {
         const int shift = 24 - 8 * ps;
         const unsigned hmask = (ps == 0) ? 0u : (0xFFFFFFFFu << (shift + 8));
         int *h = hist4 + ps * 256;
+        if (!(prefilled && ps == 1)) {
 #pragma unroll
-        for (int j = 0; j < E; ++j)
-            if (has[j] && ((key[j] ^ prefix) & hmask) == 0u) atomicAdd(&h[(key[j] >> shift) & 255u], 1);
-        __syncthreads();
+            for (int j = 0; j < E; ++j)
+                if (has[j] && ((key[j] ^ prefix) & hmask) == 0u) atomicAdd(&h[(key[j] >> shift) & 255u], 1);
+            __syncthreads();
+        }
         // ONE wave walks the histogram (the others would only repeat the same instructions) and publishes the digit
         if (tid < 64) {
             // lane L owns bins 255-4L .. 252-4L (lanes ascend as digits descend)
