@@ -293,9 +293,12 @@ def build_csr(targets, cols, values, counts, k: int, n_rows: int, n_cols: int) -
     counts = counts.astype(np.int64, copy=False)
     if n_targets == 0:
         return sp.csr_array((n_rows, n_cols), dtype=np.float32)
-    valid = (np.arange(k, dtype=np.int64)[None, :] < counts[:, None]).ravel()
-    v = values[valid]
-    c = cols[valid]
+    if bool((counts == k).all()):
+        v, c = values, cols                      # every slot full (the usual case at scale): nothing to strip, no copies
+    else:
+        valid = (np.arange(k, dtype=np.int64)[None, :] < counts[:, None]).ravel()
+        v = values[valid]
+        c = cols[valid]
     row_nnz = np.zeros(n_rows, dtype=np.int64)
     strictly_increasing = n_targets == 1 or bool(np.all(targets[1:] > targets[:-1]))
     if strictly_increasing:
@@ -309,7 +312,8 @@ def build_csr(targets, cols, values, counts, k: int, n_rows: int, n_cols: int) -
     indptr = np.zeros(n_rows + 1, dtype=idx_dtype)
     np.cumsum(row_nnz, out=indptr[1:])
     res = sp.csr_array((v, c.astype(idx_dtype, copy=False), indptr), shape=(n_rows, n_cols), dtype=np.float32)
-    res.eliminate_zeros()
+    if np.count_nonzero(res.data) != res.data.shape[0]:      # (the in-place pass of eliminate_zeros costs more than the check)
+        res.eliminate_zeros()
     return res
 
 
