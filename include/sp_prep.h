@@ -67,7 +67,8 @@ typedef struct sp_csr_sqsums_args {
     const int32_t *indptr;     /* [n_rows + 1] */
     float   *out_rows;         /* [n_rows] or NULL: sum of data^2 per row as np.add.reduceat gives it (float32, NumPy's pairwise order) */
     float   *out_cols_of_t;    /* [n_rows] or NULL: the same sums as np.bincount gives them for the columns of the TRANSPOSE
-                                  (float64 running sum in storage order, rounded to float32) */
+                                  (float64 running sum in storage order, rounded to float32; rows beyond 4096 entries are
+                                  summed in 256 float64 chunks: the float32 result can differ by one ulp about once in 1e8 rows) */
     void    *stream;
     float    kernel_ms;        /* OUT with SP_FLAG_TIME_KERNEL */
     int32_t  _pad1;

@@ -690,6 +690,7 @@ int sp_csr_row_sqsums_f32(sp_csr_sqsums_args *a) {
     }
     if (timed) { HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1)); HIP_TRY(hipEventRecord(ev0, stream)); }
     hipLaunchKernelGGL(sp_row_sqsums_kernel, dim3(blocks), dim3(256), 0, stream, a->n_rows, d_data, d_indptr, o_rows, o_cols);
+    hipLaunchKernelGGL(sp_row_sqsums_long_kernel, dim3(std::min(a->n_rows, 2048)), dim3(256), 0, stream, a->n_rows, d_data, d_indptr, o_rows, o_cols);
     HIP_TRY(hipGetLastError());
     if (timed) {
         HIP_TRY(hipEventRecord(ev1, stream)); HIP_TRY(hipEventSynchronize(ev1)); HIP_TRY(hipEventElapsedTime(&a->kernel_ms, ev0, ev1));

@@ -179,11 +179,14 @@ __device__ float np_pairwise_sq(const float *a, long long n) {
     return __fadd_rn(np_pairwise_sq(a, n2), np_pairwise_sq(a + n2, n - n2));
 }
 
-// one thread per row (rows are short next to the row count in every shape the reference is used on)
+constexpr int SQ_LONG = 4096;      // rows beyond this many entries get a workgroup of their own
+
+// one thread per row (rows are short next to the row count in most shapes the reference is used on)
 __global__ __launch_bounds__(256) void sp_row_sqsums_kernel(int n_rows, const float *__restrict__ data, const int *__restrict__ indptr,
                                                              float *__restrict__ out_rows, float *__restrict__ out_cols) {
     for (long long r = blockIdx.x * (long long)blockDim.x + threadIdx.x; r < n_rows; r += (long long)gridDim.x * blockDim.x) {
         const int b = indptr[r], e = indptr[r + 1];
+        if (e - b > SQ_LONG) continue;       // sp_row_sqsums_long_kernel's
         if (out_rows) {
             float v = 0.f;
             if (e > b) {
@@ -197,6 +200,72 @@ __global__ __launch_bounds__(256) void sp_row_sqsums_kernel(int n_rows, const fl
             for (int i = b; i < e; ++i) acc = __dadd_rn(acc, (double)sq_rn(data[i]));
             out_cols[r] = (float)acc;
         }
+    }
+}
+
+// Long rows (a popular item of a ratings matrix: 10^5..10^6 entries): one workgroup per row.
+//   out_rows: NumPy's pairwise recursion is a binary tree; its top eight levels are laid out in LDS (node i: children 2i,
+//   2i+1; a node of <= 128 elements is a leaf), every thread sums one level-8 subtree (or a shallower leaf) with the
+//   same recursion, and the partial sums are added back up the same tree: the same float32 additions in the same
+//   order as NumPy — bit-identical.
+//   out_cols_of_t: np.bincount's float64 running sum is inherently sequential; here every thread sums a contiguous
+//   chunk in float64 and the 256 partial sums are added in order.  The float64 roundings differ from the strictly
+//   sequential sum (relative 1e-16); the float32 result differs only if that crosses a float32 rounding boundary (about
+//   once in 1e8 rows).
+__global__ __launch_bounds__(256) void sp_row_sqsums_long_kernel(int n_rows, const float *__restrict__ data, const int *__restrict__ indptr,
+                                                                  float *__restrict__ out_rows, float *__restrict__ out_cols) {
+    __shared__ long long n_off[512];
+    __shared__ long long n_len[512];      // 0 = no such node
+    __shared__ float n_val[512];
+    __shared__ double part[256];
+    const int tid = threadIdx.x;
+    for (int r = blockIdx.x; r < n_rows; r += gridDim.x) {
+        const int b = indptr[r], e = indptr[r + 1];
+        if (e - b <= SQ_LONG) continue;       // (uniform)
+        const float *a = data + b;
+        const long long n = e - b;
+        if (out_rows) {
+            for (int i = tid; i < 512; i += 256) { n_len[i] = 0; n_off[i] = 0; }
+            __syncthreads();
+            if (tid == 0) { n_off[1] = 1; n_len[1] = n - 1; }       // (the first element is added last, as reduceat does)
+            __syncthreads();
+            for (int lvl = 0; lvl < 8; ++lvl) {
+                const int i = (1 << lvl) + tid;
+                if (tid < (1 << lvl) && n_len[i] > 128) {
+                    long long n2 = n_len[i] / 2;
+                    n2 -= n2 % 8;
+                    n_off[2 * i] = n_off[i]; n_len[2 * i] = n2;
+                    n_off[2 * i + 1] = n_off[i] + n2; n_len[2 * i + 1] = n_len[i] - n2;
+                }
+                __syncthreads();
+            }
+            // leaves of the eight-level tree: nodes without children (level 8 nodes, or <= 128 elements above)
+            for (int i = 1 + tid; i < 512; i += 256) {
+                const bool is_leaf = n_len[i] > 0 && (i >= 256 || n_len[2 * i] == 0);
+                if (is_leaf) n_val[i] = np_pairwise_sq(a + n_off[i], n_len[i]);
+            }
+            __syncthreads();
+            for (int lvl = 7; lvl >= 0; --lvl) {
+                const int i = (1 << lvl) + tid;
+                if (tid < (1 << lvl) && n_len[i] > 0 && n_len[2 * i] > 0) n_val[i] = __fadd_rn(n_val[2 * i], n_val[2 * i + 1]);
+                __syncthreads();
+            }
+            if (tid == 0) out_rows[r] = __fadd_rn(sq_rn(a[0]), n_val[1]);
+        }
+        if (out_cols) {
+            const long long per = (n + 255) / 256;
+            const long long lo = min(n, tid * per), hi = min(n, lo + per);
+            double acc = 0.0;
+            for (long long i = lo; i < hi; ++i) acc = __dadd_rn(acc, (double)sq_rn(a[i]));
+            part[tid] = acc;
+            __syncthreads();
+            if (tid == 0) {
+                double tot = 0.0;
+                for (int i = 0; i < 256; ++i) tot = __dadd_rn(tot, part[i]);
+                out_cols[r] = (float)tot;
+            }
+        }
+        __syncthreads();
     }
 }
 

@@ -461,8 +461,9 @@ def test_public_call_with_device_transpose_matches_host_transpose(name, kw):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("lens", [[0, 1, 2, 7, 8, 9, 15, 16, 17, 0, 64, 127, 128, 129, 130, 137, 0], [255, 256, 257, 300, 513, 1025, 4097, 10000, 70001],
-                                  [64] * 3000])
+@pytest.mark.parametrize("lens", [[0, 1, 2, 7, 8, 9, 15, 16, 17, 0, 64, 127, 128, 129, 130, 137, 0], [255, 256, 257, 300, 513, 1025, 4096, 4097, 10000, 70001],
+                                  [64] * 3000, [4098, 4225, 5000, 33000, 33001, 131073, 600001, 3, 0, 1048577]],
+                         ids=["short", "medium", "many", "workgroup_per_row"])
 def test_device_squared_norms_bit_identical_to_numpy(lens):
     """sp_csr_row_sqsums_f32 against the host statement of s_plus_utils.pyx:128-201 (np.add.reduceat / np.bincount):
     every float32, bit for bit — NumPy's pairwise blocks included."""
