@@ -12,6 +12,8 @@ from oracle import splus_oracle as so
 from bench import fixed_degree_csr
 
 n_users = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+# optional tuning sweep: "threads_per_wg=512,table_slots=8192;threads_per_wg=512,table_slots=4096"
+sweeps = [dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in grp.split(",")) for grp in sys.argv[2].split(";")] if len(sys.argv) > 2 else []
 n_items, k = 100_000, 100
 urm = fixed_degree_csr(n_users, n_items, 64, 12345)
 t0 = time.perf_counter()
@@ -46,6 +48,11 @@ ties = so.compare_topk(got, want, k, rtol=1e-5, atol=1e-7, what="c5")
 for t in sample[:50]:
     assert not np.intersect1d(hc[t*k:t*k+hn[t]], urm.indices[urm.indptr[t]:urm.indptr[t+1]]).size
 print(f"   parity OK on {len(sample)} rows (boundary ties {ties}); filter respected", flush=True)
+for tun in sweeps:
+    prob.run(cols, vals, counts, **tun); torch.cuda.synchronize()
+    i1 = prob.run(cols, vals, counts, time_kernel=True, phase_timers=False, **tun)
+    i2 = prob.run(cols, vals, counts, time_kernel=True, **tun)
+    print(f"   tuning {tun}: {i1['kernel_ms']:.1f} ms, workgroups {i1['num_wgs']}, rows sparse / given up {i2['phase_cycles'][9]} / {i2['phase_cycles'][10]}", flush=True)
 names = ("setup", "segments", "accumulate", "drain", "select", "output", "sweep1", "sweep2", "csdrain")
 tot = float(sum(ph[:9])); per_row = tot / call.n_targets
 print("   cycles/row %.0f: " % per_row + "  ".join(f"{n}={c / call.n_targets:.0f}" for n, c in zip(names, ph[:9])), flush=True)

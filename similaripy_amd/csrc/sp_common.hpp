@@ -381,7 +381,10 @@ __device__ __forceinline__ unsigned emit_candidates(const KParams &p, const RowC
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int ITEM = 256;         // m2 elements per work item: one 16-byte load per lane
-constexpr int ITEM_CAP = 1008;    // work items per row (LDS: 16 B each)
+constexpr int ITEM_CAP = 1008;    // work items per row (LDS: 16 B each) of a 1024-thread workgroup
+// ... and of a smaller one: a wave keeps at most 63 item descriptors, so NW*64 entries are all a row can use (the area
+// doubles as 4 KiB of scratch for the segment order: never below 256 entries)
+__host__ __device__ constexpr int item_cap(int NT) { return NT >= 1024 ? ITEM_CAP : (NT / 64) * 64; }
 constexpr int CBM_BYTES = 8192;   // collision bitmap of the sparse kernel (64k bits = 2048 words)
 constexpr int PRE_BYTES = 4096;   // per-word exclusive popcount prefix of the collision bitmap (u16 each)
 constexpr int POOL_BLK = 64;      // pool entries a wave reserves at a time (>= 64: one trip always fits a fresh block)

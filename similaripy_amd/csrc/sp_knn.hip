@@ -58,7 +58,8 @@ int fail(int code, const char *fmt, ...) {
     } while (0)
 
 struct Config {
-    int T, logT, NT, cap, hash_fill;
+    int T, logT, NT, cap, hash_fill;   // generic kernel (and, unless auto-tuned apart, the sparse kernel)
+    int T_s, logT_s, NT_s;             // sparse kernel: tile (region A = 8*T_s bytes) and workgroup size
     int cap_s;                     // sparse kernel's candidate buffer capacity
     int wgs_sparse, wgs_generic;   // persistent workgroups of the two row kernels
     bool u_lds, u_lds_s;           // candidate buffer in LDS: generic / sparse kernel
@@ -85,7 +86,7 @@ static_assert(WS_PHASE_OFFSET + PH_N * 8 <= WS_YMIN_OFFSET && WS_YMIN_OFFSET + 1
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
 // LDS of the two kernels without the candidate buffer (see their carve-ups)
-size_t lds_fixed_sparse(int T) { return (size_t)T * 8 + (size_t)ITEM_CAP * 16 + 4096 + CBM_BYTES + PRE_BYTES + 32 * 4 + 16 * 8; }   // (its candidate buffer lives inside region A)
+size_t lds_fixed_sparse(int T, int NT) { return (size_t)T * 8 + (size_t)item_cap(NT) * 16 + 4096 + CBM_BYTES + PRE_BYTES + 32 * 4 + 16 * 8; }   // (its candidate buffer lives inside region A)
 size_t lds_fixed_generic(int T, int NT) { return (size_t)T * 8 + (size_t)16 * NT + 256 + 256 * 4 + 64 * 4 + 32 * 4 + 16 * 8; }
 
 int make_config(const sp_knn_args *a, int n_cus, Config *c) {
@@ -99,7 +100,7 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
 
     const long long need_cap = (long long)a->k + U_SLACK;
     const size_t fixed = lds_fixed_generic(T, NT);
-    if (std::max(fixed + 8 * 1024, lds_fixed_sparse(T)) > LDS_LIMIT) return fail(SP_EINVAL, "table_slots=%d does not fit the 160 KiB LDS", T);
+    if (std::max(fixed + 8 * 1024, lds_fixed_sparse(T, NT)) > LDS_LIMIT) return fail(SP_EINVAL, "table_slots=%d does not fit the 160 KiB LDS", T);
     // generic kernel's candidate buffer: LDS if k + slack entries fit beside the table, else global scratch
     long long cap_lds = (long long)((LDS_LIMIT - fixed) / 8);
     bool u_lds = need_cap <= cap_lds;
@@ -112,21 +113,30 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
     if (cap > 0x7FFFFFF0LL) return fail(SP_EINVAL, "k too large");
     // sparse kernel's candidate buffer: the last quarter of region A when SEL_E*NT entries (what its register-resident
     // selection handles) fit there and leave room above k; else global scratch
-    const bool u_lds_s = ((size_t)SEL_E * NT * 8 <= (size_t)T * 2) && ((long long)a->k + 512 <= (long long)SEL_E * NT);
-    const long long cap_s = u_lds_s ? (long long)SEL_E * NT : ((need_cap + 1024) & ~1LL);
+    // The sparse kernel's own shape.  Its column bitmap needs one bit per output column: up to 2^18 columns fit a
+    // 32 KiB region A, and then THREE 256-thread workgroups share a CU (53.5 KB of LDS each) instead of one of 1024
+    // threads — the dense phases of one overlap with the sweeps of the others, and a 4-wave barrier is cheap
+    // (user-scoring slice, 100k items: 97 -> 50 ms).  Needs k + 512 <= 1024 for the candidate buffer to stay in LDS.
+    int NT_s = NT, T_s = T, logT_s = logT;
+    if (!a->threads_per_wg && !a->table_slots && a->n_output_cols <= (1 << 18) && (long long)a->k + 512 <= (long long)SEL_E * 256) {
+        NT_s = 256; T_s = 4096; logT_s = 12;
+    }
+    const bool u_lds_s = ((size_t)SEL_E * NT_s * 8 <= (size_t)T_s * 2) && ((long long)a->k + 512 <= (long long)SEL_E * NT_s);
+    const long long cap_s = u_lds_s ? (long long)SEL_E * NT_s : ((need_cap + 1024) & ~1LL);
     c->T = T; c->logT = logT; c->NT = NT; c->cap = (int)cap; c->u_lds = u_lds; c->cap_s = (int)cap_s; c->u_lds_s = u_lds_s;
+    c->T_s = T_s; c->logT_s = logT_s; c->NT_s = NT_s;
     c->hash_fill = std::max(1, (int)((long long)T * load / 100));
-    c->lds_sparse = lds_fixed_sparse(T);
+    c->lds_sparse = lds_fixed_sparse(T_s, NT_s);
     c->lds_generic = lds_fixed_generic(T, NT) + (u_lds ? (size_t)cap * 8 : 0);
-    auto wgs_for = [&](size_t lds) {
+    auto wgs_for = [&](size_t lds, int nt) {
         int per_cu = (int)std::max<size_t>(1, LDS_LIMIT / lds);
-        per_cu = std::min(per_cu, 2048 / NT);
+        per_cu = std::min(per_cu, 2048 / nt);
         per_cu = std::max(1, std::min(per_cu, 8));
         int n = a->num_wgs > 0 ? a->num_wgs : n_cus * per_cu;
         return std::max(1, std::min(n, std::max(1, a->n_targets)));
     };
-    c->wgs_sparse = wgs_for(c->lds_sparse);
-    c->wgs_generic = wgs_for(c->lds_generic);
+    c->wgs_sparse = wgs_for(c->lds_sparse, NT_s);
+    c->wgs_generic = wgs_for(c->lds_generic, NT);
     c->ws_gu_s_bytes = u_lds_s ? 0 : (((size_t)c->wgs_sparse * (size_t)cap_s * 8 + 255) & ~(size_t)255);
     c->ws_gu_bytes = c->ws_gu_s_bytes + (u_lds ? 0 : (((size_t)c->wgs_generic * (size_t)cap * 8 + 255) & ~(size_t)255));
     // product-form epilogue  val = xy / (l * X[t] * Y[c])  (cosine, asymmetric cosine, rp3beta without shrink):
@@ -143,7 +153,7 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
     c->ws_rows_bytes = (c->ws_desc_offset + (size_t)a->n_targets * 64 + 255) & ~(size_t)255;
     // sparse kernel: one bit per column while the columns fit region A, else columns alias modulo the bitmap size
     int nb = 10;
-    while (nb < logT + 6 && (1LL << nb) < (long long)a->n_output_cols) ++nb;
+    while (nb < c->logT_s + 6 && (1LL << nb) < (long long)a->n_output_cols) ++nb;
     c->nb_log2 = nb;
     c->ws_total = WS_QUEUE_BYTES + c->ws_gu_bytes + c->ws_fold_bytes + c->ws_rows_bytes;
     return SP_OK;
@@ -192,21 +202,43 @@ int device_cus(int device, int *n_cus) {
 }
 
 template <int NT>
-int launch_rows(const KParams &kp, const Config &c, hipStream_t stream, hipEvent_t *ev /* [4] or NULL: around the two row kernels */) {
-    // sparse rows first; what it cannot finish joins the generic queue, which the second launch drains
-    if (ev) HIP_TRY(hipEventRecord(ev[0], stream));
-    if (kp.sparse_path) {
-        auto ks = c.mono ? (c.u_lds_s ? sp_knn_sparse_kernel<NT, true, true> : sp_knn_sparse_kernel<NT, false, true>)
-                         : (c.u_lds_s ? sp_knn_sparse_kernel<NT, true, false> : sp_knn_sparse_kernel<NT, false, false>);
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds_sparse));
-        hipLaunchKernelGGL(ks, dim3(c.wgs_sparse), dim3(NT), c.lds_sparse, stream, kp);
-        HIP_TRY(hipGetLastError());
-    }
-    if (ev) { HIP_TRY(hipEventRecord(ev[1], stream)); HIP_TRY(hipEventRecord(ev[2], stream)); }
+int launch_sparse(const KParams &kp, const Config &c, hipStream_t stream) {
+    auto ks = c.mono ? (c.u_lds_s ? sp_knn_sparse_kernel<NT, true, true> : sp_knn_sparse_kernel<NT, false, true>)
+                     : (c.u_lds_s ? sp_knn_sparse_kernel<NT, true, false> : sp_knn_sparse_kernel<NT, false, false>);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds_sparse));
+    hipLaunchKernelGGL(ks, dim3(c.wgs_sparse), dim3(NT), c.lds_sparse, stream, kp);
+    HIP_TRY(hipGetLastError());
+    return SP_OK;
+}
+
+template <int NT>
+int launch_generic(const KParams &kp, const Config &c, hipStream_t stream) {
     auto kg = c.u_lds ? sp_knn_generic_kernel<NT, true> : sp_knn_generic_kernel<NT, false>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds_generic));
     hipLaunchKernelGGL(kg, dim3(c.wgs_generic), dim3(NT), c.lds_generic, stream, kp);
     HIP_TRY(hipGetLastError());
+    return SP_OK;
+}
+
+// kp_s: the sparse kernel's parameters (its own tile), kp: the generic kernel's
+int launch_rows(const KParams &kp_s, const KParams &kp, const Config &c, hipStream_t stream, hipEvent_t *ev /* [4] or NULL: around the two row kernels */) {
+    // sparse rows first; what it cannot finish joins the generic queue, which the second launch drains
+    if (ev) HIP_TRY(hipEventRecord(ev[0], stream));
+    if (kp.sparse_path) {
+        int rc;
+        if (c.NT_s == 256) rc = launch_sparse<256>(kp_s, c, stream);
+        else if (c.NT_s == 512) rc = launch_sparse<512>(kp_s, c, stream);
+        else if (c.NT_s == 768) rc = launch_sparse<768>(kp_s, c, stream);
+        else rc = launch_sparse<1024>(kp_s, c, stream);
+        if (rc) return rc;
+    }
+    if (ev) { HIP_TRY(hipEventRecord(ev[1], stream)); HIP_TRY(hipEventRecord(ev[2], stream)); }
+    int rc;
+    if (c.NT == 256) rc = launch_generic<256>(kp, c, stream);
+    else if (c.NT == 512) rc = launch_generic<512>(kp, c, stream);
+    else if (c.NT == 768) rc = launch_generic<768>(kp, c, stream);
+    else rc = launch_generic<1024>(kp, c, stream);
+    if (rc) return rc;
     if (ev) HIP_TRY(hipEventRecord(ev[3], stream));
     return SP_OK;
 }
@@ -317,7 +349,7 @@ int run_device_impl(sp_knn_args *a) {
         ClassifyParams cp;
         cp.sparse_path = kp.sparse_path;
         cp.n_cols = a->n_output_cols; cp.T = c.T; cp.nb_log2 = c.nb_log2;
-        cp.cs_slots = c.T / 4;
+        cp.cs_slots = c.T_s / 4;
         cp.mono = c.mono ? 1 : 0;
         cp.any_norm = (a->l1 != 0.f || a->l2 != 0.f || a->l3 != 0.f || a->stabilized_shrink != 0.f || a->bayesian_shrink != 0.f) ? 1 : 0;
         cp.l2 = a->l2; cp.l3 = a->l3;
@@ -343,10 +375,9 @@ int run_device_impl(sp_knn_args *a) {
 
     hipEvent_t kev[4] = {nullptr, nullptr, nullptr, nullptr};
     if (timed) { for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&kev[i])); }
-    if (c.NT == 256) rc = launch_rows<256>(kp, c, stream, timed ? kev : nullptr);
-    else if (c.NT == 512) rc = launch_rows<512>(kp, c, stream, timed ? kev : nullptr);
-    else if (c.NT == 768) rc = launch_rows<768>(kp, c, stream, timed ? kev : nullptr);
-    else rc = launch_rows<1024>(kp, c, stream, timed ? kev : nullptr);
+    KParams kp_s = kp;
+    kp_s.T = c.T_s; kp_s.logT = c.logT_s;
+    rc = launch_rows(kp_s, kp, c, stream, timed ? kev : nullptr);
     if (rc) { if (own_ws) (void)hipFree(ws); return rc; }
 
     if (timed) {

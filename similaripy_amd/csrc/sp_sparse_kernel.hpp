@@ -39,13 +39,14 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
     //                     that its reads need no base add;  pre16[]: its per-word popcount prefix (rank of a marked column)
     // region A [.., +T*8) sweep 1: column bitmap (nb bits, from the start);
     //                     afterwards: [0,A/4) collision set, [A/4,A/2) survivor pool, [A/2,3A/4) member pool, [3A/4,A) candidate buffer U
-    // items[ITEM_CAP]     {m2 byte offset, count, m1 value bits, flat start};  hist4[4][256] radix histograms
+    // items[item_cap(NT)] {m2 byte offset, count, m1 value bits, flat start};  hist4[4][256] radix histograms
     // sh[32], ph[16]      scalars, phase timers
     unsigned char *cbm = smem;
     unsigned short *pre16 = (unsigned short *)(smem + CBM_BYTES);      // [CBM_BYTES/4] marked columns below each bitmap word
     unsigned char *rA = smem + CBM_BYTES + PRE_BYTES;
     int4 *items = (int4 *)(rA + A_bytes);
-    int *hist4 = (int *)(items + ITEM_CAP);
+    constexpr int ICAP = item_cap(NT);
+    int *hist4 = (int *)(items + ICAP);
     int *sh = hist4 + 1024;
     u64 *ph = (u64 *)(sh + 32);
     u64 *U = U_LDS ? (u64 *)(rA + (A_bytes / 4) * 3) : (p.gU + (size_t)blockIdx.x * (size_t)p.cap_s);
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             n_items = sh[SH_NITEMS];
             __syncthreads();                    // scratch read before the items overwrite it
         }
-        bool failed = (n_items >= ITEM_CAP) || (n_items > 63 * NW);      // (a wave keeps its <= 63 item descriptors in one register)
+        bool failed = (n_items >= ICAP) || (n_items > 63 * NW);      // (a wave keeps its <= 63 item descriptors in one register)
         PHASE_END(PH_SETUP);
 
         RowCtx rc;

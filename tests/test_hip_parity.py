@@ -271,7 +271,13 @@ def test_sparse_kernel_monotone_and_general(name, kw):
     call = _host.prepare(m, k=40, target_rows=np.arange(0, 40000, 13), **kw)
     _check(call, "sparse " + name)
     pc = _info(call)
-    assert pc[9] == call.n_targets and pc[10] == 0, (pc[9], pc[10])     # rows on the sparse kernel / given up
+    # rows finished by the sparse kernel / handed to the generic one (the auto-tuned small workgroups have small pools: a
+    # few rows may overflow them and be re-queued — their results are checked above like all others)
+    assert pc[9] + pc[10] == call.n_targets and pc[10] <= 0.01 * call.n_targets, (pc[9], pc[10])
+    # the large-workgroup shape serves them all
+    pc = _info(call, threads_per_wg=1024, table_slots=16384)
+    assert pc[9] == call.n_targets and pc[10] == 0, (pc[9], pc[10])
+    _check(call, "sparse " + name + " (1024 threads)", threads_per_wg=1024, table_slots=16384)
 
 
 def test_sparse_kernel_tied_values():
