@@ -118,7 +118,11 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
     // threads — the dense phases of one overlap with the sweeps of the others, and a 4-wave barrier is cheap
     // (user-scoring slice, 100k items: 97 -> 50 ms).  Needs k + 512 <= 1024 for the candidate buffer to stay in LDS.
     int NT_s = NT, T_s = T, logT_s = logT;
-    if (!a->threads_per_wg && !a->table_slots && a->n_output_cols <= (1 << 18) && (long long)a->k + 512 <= (long long)SEL_E * 256) {
+    // ... and for the typical row to stay on this kernel with the smaller collision set (rows are classified one by one
+    // on the device: expected colliding products MACs^2 / (2 n_cols) <= 0.3 * slots; here the average row, from sizes alone)
+    const double avg_macs = (a->n_rows_m1 > 0 && a->n_rows_m2 > 0) ? ((double)a->nnz_m1 / a->n_rows_m1) * ((double)a->nnz_m2 / a->n_rows_m2) : 0.0;
+    const bool small_rows = avg_macs * avg_macs / (2.0 * std::max(1, a->n_output_cols)) <= 0.25 * 1024.0;
+    if (!a->threads_per_wg && !a->table_slots && a->n_output_cols <= (1 << 18) && (long long)a->k + 512 <= (long long)SEL_E * 256 && small_rows) {
         NT_s = 256; T_s = 4096; logT_s = 12;
     }
     const bool u_lds_s = ((size_t)SEL_E * NT_s * 8 <= (size_t)T_s * 2) && ((long long)a->k + 512 <= (long long)SEL_E * NT_s);
