@@ -18,9 +18,19 @@ ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--only", type=int, default=-1, help="run only this case of the seed's sequence (the others are generated and skipped)")
 ap.add_argument("--dump-slot", type=int, default=-1, help="with --only: print both sides of this slot")
 ap.add_argument("--tuning", default="", help="with --only: override the case's tuning, e.g. table_slots=2048,no_sparse_path=1")
+ap.add_argument("--dbg", type=int, default=0)
 ap.add_argument("--max-macs", type=float, default=4e8, help="skip cases whose oracle run would take too long")
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
+
+
+def _run_dbg(call, tuning, dbg):
+    from similaripy_amd.device import DeviceProblem
+    prob = DeviceProblem(call)
+    c, v, n, r = prob.alloc_outputs(with_rows=True)
+    prob.run(c, v, n, rows=r, dbg=dbg, **tuning)
+    import torch; torch.cuda.synchronize()
+    return r.cpu().numpy(), c.cpu().numpy(), v.cpu().numpy(), n.cpu().numpy()
 
 
 def rand_matrix(n_rows, n_cols, density, kind):
@@ -103,7 +113,7 @@ def one_case(i):
     macs = float(colnnz[ref_call.m1_indices].sum()) * (len(ref_call.targets) / max(1, ref_call.n_rows_m1))
     if macs > a.max_macs:
         return "skipped", desc
-    rows, cols, vals, counts = _host.run_hip(call, **tuning)
+    rows, cols, vals, counts = _host.run_hip(call, **tuning) if not a.dbg else _run_dbg(call, tuning, a.dbg)
     got = so.canonical(rows, cols, vals, call.targets, call.k)
     want = so.canonical(*so.run_kernel(ref_call, "port"), call.targets, call.k)
     # Reference quirk (s_plus.h:112-116): `add()` takes "running sum == 0" for "first touch", so a column whose partial
@@ -137,7 +147,8 @@ def one_case(i):
     # signed data: sums cancel, and a different (equally valid) summation order moves a value by more than 1e-5 of itself
     signed = kind == "signed" or (m2 is not None and bool((m2.data < 0).any()))
     # ... and with a Bayesian shrink b the value has a pole at raw dot = -b: near it no tolerance is meaningful
-    pole = signed and kw.get("bayesian_shrink", 0.0) != 0.0      # (values there may differ by any factor: 1e9 = sets only)
+    pole = signed and (kw.get("bayesian_shrink", 0.0) != 0.0 or kw.get("l1", 0.0) != 0.0)      # (a Tversky denominator has one too)
+    pole_ = pole      # (values there may differ by any factor: 1e9 = sets only)
     so.compare_topk(got, want, call.k, rtol=(1e9 if pole else 1e-3) if signed else 1e-5, atol=1e-5 if signed else 1e-7, what=desc)
     n, kk = call.n_targets, call.k
     pad = np.arange(kk)[None, :] >= counts[:, None]

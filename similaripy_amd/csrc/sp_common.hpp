@@ -61,7 +61,7 @@ struct KParams {
     const float4 *Ypack;   // optional: {Ytv, Ycos, Ydep, 0} per column when two or more column terms are in use (one gather instead of several)
     const float *ymin;     // [3] minima of Ytv / Ycos / Ydep over all columns (valid iff bound_ok)
     int bound_ok;          // weights/shrinks are all >= 0: the epilogue upper bound is sound
-    const int *neg_flag;   // Bayesian shrink only: *neg_flag != 0 iff m1 or m2 holds a negative value (see RowCtx::set_cut)
+    const int *neg_flag;   // Bayesian shrink / Tversky with t1+t2 < 1 only: *neg_flag != 0 iff m1 or m2 holds a negative value (see RowCtx::set_cut)
     int sparse_path;       // 1 = rows with few expected collisions take the bitmap path
     int fold;              // 1 = the single active column term (Ycos or Ydep) is already divided into m2_data: treat it as 1
     unsigned long long *phase_cycles;  // optional [PH_N]
@@ -110,7 +110,7 @@ struct Epi {
     bool any;
     // upper bound without column terms: den >= bA + bB*xy for every column (valid iff bound)
     bool bound;
-    bool cut_ok;   // the raw-dot cutoff may be used (false: Bayesian shrink with negative data, see RowCtx::set_cut)
+    bool cut_ok;   // the raw-dot cutoff may be used (false: negative data under a Bayesian shrink or a Tversky term with t1+t2 < 1, see RowCtx::set_cut)
     float bA, bB;
 
     // ytv / ycos / ydep: the column terms Ytv[col] / Ycos[col] / Ydep[col], gathered by the caller so
@@ -246,8 +246,11 @@ struct RowCtx {
         if (have_thr) t = fmaxf(t, funkey(thr_key));
         xy_cut = ninf;
         if (!epi.any) { xy_cut = t; return; }                        // value == raw dot, exact
-        // Bayesian factor xy/(xy+b): a NEGATIVE raw dot in (-b, 0) gives a positive value that grows without bound as
-        // xy -> -b, so "raw dot <= cutoff => out" holds only when no product can be negative (flag set per call)
+        // "raw dot <= cutoff => out" needs the value to grow with the raw dot below the cutoff too.  With NEGATIVE raw
+        // dots it does not in two cases: the Bayesian factor xy/(xy+b) turns xy in (-b, 0) into a positive value that
+        // grows without bound as xy -> -b; and a Tversky denominator bA + bB*xy with bB > 0 changes sign at
+        // xy = -bA/bB, beyond which negative over negative is large and positive.  Both only when a product can be
+        // negative at all (flag set per call).
         if (!epi.bound || !epi.cut_ok || epi.a1 != 1.f || !(t >= 0.f) || !(epi.bA > 0.f)) return;
         // ub(xy) = s*xy / (bA + bB*xy) > t   <=>   xy * (s - t*bB) > t*bA      (denominator > 0 region, s = 1.00002)
         const float s = 1.00002f;

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
         // den = l1*(t1*(X-xy) + t2*(Y-xy) + xy) + l2*Xc*Yc + l3*Xd*Yd + stab  >=  bA + bB*xy  when the
         // column terms are replaced by their minima and their multipliers are non-negative
         epi.bound = p.bound_ok && !(epi.xcos < 0.f) && !(epi.xdep < 0.f);
-            epi.cut_ok = !(p.bayes != 0.f && p.neg_flag != nullptr && *p.neg_flag != 0);
+            epi.cut_ok = !((p.bayes != 0.f || p.l1 * (1.f - p.t1 - p.t2) > 0.f) && p.neg_flag != nullptr && *p.neg_flag != 0);
         epi.bA = p.l1 * (p.t1 * epi.xtv + p.t2 * ymin_tv) + p.l2 * epi.xcos * ymin_cos + p.l3 * epi.xdep * ymin_dep + p.stab;
         epi.bB = p.l1 * (1.f - p.t1 - p.t2);
 

@@ -308,7 +308,8 @@ int run_device_impl(sp_knn_args *a) {
     }
 
     int *neg_flag = (int *)(ws + WS_YMIN_OFFSET + 12);      // (inside the zeroed header)
-    if (a->bayesian_shrink != 0.f) {
+    const bool sign_matters = a->bayesian_shrink != 0.f || a->l1 * (1.f - a->t1 - a->t2) > 0.f;      // (see RowCtx::set_cut)
+    if (sign_matters) {
         if (a->nnz_m1 > 0) hipLaunchKernelGGL(sp_any_negative_kernel, dim3(1024), dim3(256), 0, stream, (long long)a->nnz_m1, a->m1_data, neg_flag);
         if (a->nnz_m2 > 0) hipLaunchKernelGGL(sp_any_negative_kernel, dim3(1024), dim3(256), 0, stream, (long long)a->nnz_m2, a->m2_data, neg_flag);
         HIP_TRY(hipGetLastError());
@@ -371,7 +372,7 @@ int run_device_impl(sp_knn_args *a) {
     kp.ymin = ymin_dev;
     kp.Ypack = ypack;
     kp.bound_ok = bound_ok ? 1 : 0;
-    kp.neg_flag = (a->bayesian_shrink != 0.f) ? neg_flag : nullptr;
+    kp.neg_flag = sign_matters ? neg_flag : nullptr;
     kp.fold = c.fold ? 1 : 0;
     if (c.fold) kp.m2_data = folded;
     kp.phase_cycles = (timed && (a->flags & SP_FLAG_PHASE_TIMERS)) ? (unsigned long long *)(ws + WS_PHASE_OFFSET) : nullptr;   // inside the zeroed header

@@ -323,8 +323,15 @@ def test_bayesian_shrink_with_negative_values(shape, density):
     drop negative dots (found by scripts/fuzz_parity.py)."""
     m = _rand(shape, density, 77)
     m.data[:] = (m.data - 0.5) * 2
-    for kw in (dict(l2=1, c1=0.55, c2=0.4, bayesian_shrink=0.5), dict(l1=1, t1=0.6, t2=0.4, bayesian_shrink=2.0), dict(l2=1, bayesian_shrink=0.5, stabilized_shrink=1.0)):
+    # ... and so is a Tversky value with t1 + t2 < 1: its denominator changes sign at a negative raw dot (second bug of
+    # the same kind, seen only once the candidate buffer was small enough for a selection to happen mid-row)
+    for kw in (dict(l2=1, c1=0.55, c2=0.4, bayesian_shrink=0.5), dict(l1=1, t1=0.6, t2=0.4, bayesian_shrink=2.0), dict(l2=1, bayesian_shrink=0.5, stabilized_shrink=1.0),
+               dict(l1=1, t1=0.03, t2=0.37), dict(l1=1, t1=0.27, t2=0.14, additive_shrink=3.0)):
         call = _host.prepare(m, k=100, target_rows=np.arange(0, shape[0], 23), **kw)
+        rows, cols, vals, counts = _host.run_hip(call, threads_per_wg=256)      # (small candidate buffer: selections mid-row)
+        got = so.canonical(rows, cols, vals, call.targets, call.k)
+        want = so.canonical(*so.run_kernel(call, "port"), call.targets, call.k)
+        so.compare_topk(got, want, call.k, rtol=2e-2, atol=1e-6, what=f"negatives, 256 threads {kw}")
         rows, cols, vals, counts = _host.run_hip(call)
         got = so.canonical(rows, cols, vals, call.targets, call.k)
         want = so.canonical(*so.run_kernel(call, "port"), call.targets, call.k)
