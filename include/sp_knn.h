@@ -48,7 +48,7 @@ extern "C" {
 
 /* flags */
 #define SP_FLAG_TIME_KERNEL   1u  /* bracket device work with hipEvents on `stream`, sync, fill kernel_ms */
-#define SP_FLAG_NO_ROWS_OUT   2u  /* device mode: `rows` may be NULL and is not written */
+#define SP_FLAG_NO_ROWS_OUT   2u  /* `rows` may be NULL and is not written (it is targets[i] repeated over slot i: a CSR consumer does not need it) */
 #define SP_FLAG_STATIC_SCHED  4u  /* round-robin rows over workgroups instead of the atomic row queue */
 #define SP_FLAG_NO_SPARSE_PATH 8u /* never use the bitmap + collision-set path for sparse rows (A/B testing) */
 #define SP_FLAG_NO_FOLD       16u /* never divide the column term into the m2 stream (A/B testing) */

@@ -454,18 +454,18 @@ def selected_device() -> int:
 
 def run_hip(call: KernelCall, device: Optional[int] = None, table_slots: int = 0, threads_per_wg: int = 0,
             num_wgs: int = 0, load_pct: int = 0, time_kernel: bool = False, static_sched: bool = False,
-            no_sparse_path: bool = False, no_fold: bool = False):
+            no_sparse_path: bool = False, no_fold: bool = False, want_rows: bool = True):
     """The `with nogil:` block of s_plus.pyx:359-384, on the GPU: host buffers in, host buffers out
     through the C ABI (include/sp_knn.h).  Returns rows, cols, values, counts[, info]."""
     _abi.require_device()
     n, k = call.n_targets, call.k
-    rows = np.empty(n * k, dtype=np.int32)
+    rows = np.empty(n * k, dtype=np.int32) if want_rows else None      # (slot i's rows are all targets[i]: CSR assembly does not read them)
     cols = np.empty(n * k, dtype=np.int32)
     values = np.empty(n * k, dtype=np.float32)
     counts = np.empty(n, dtype=np.int32)
 
     a = _abi.SpKnnArgs()
-    a.flags = ((_abi.SP_FLAG_TIME_KERNEL | _abi.SP_FLAG_PHASE_TIMERS if time_kernel else 0) | (_abi.SP_FLAG_STATIC_SCHED if static_sched else 0)
+    a.flags = ((0 if want_rows else _abi.SP_FLAG_NO_ROWS_OUT) | (_abi.SP_FLAG_TIME_KERNEL | _abi.SP_FLAG_PHASE_TIMERS if time_kernel else 0) | (_abi.SP_FLAG_STATIC_SCHED if static_sched else 0)
                | (_abi.SP_FLAG_NO_SPARSE_PATH if no_sparse_path else 0) | (_abi.SP_FLAG_NO_FOLD if no_fold else 0))
     a.on_device = 0
     a.device = selected_device() if device is None else int(device)
@@ -496,7 +496,7 @@ def run_hip(call: KernelCall, device: Optional[int] = None, table_slots: int = 0
     a.target_col_mode = call.target_col_mode
     a.target_col_m_indptr, a.target_col_m_indices = i32(call.target_col_m_indptr), i32(call.target_col_m_indices)
     a.target_col_nnz = int(call.target_col_m_indices.shape[0])
-    a.rows, a.cols, a.values, a.out_counts = rows.ctypes.data, cols.ctypes.data, values.ctypes.data, counts.ctypes.data
+    a.rows, a.cols, a.values, a.out_counts = (rows.ctypes.data if want_rows else None), cols.ctypes.data, values.ctypes.data, counts.ctypes.data
     a.table_slots, a.threads_per_wg, a.num_wgs, a.load_pct = table_slots, threads_per_wg, num_wgs, load_pct
     if n > 0:
         _abi.call_knn(a)
@@ -529,7 +529,7 @@ def s_plus(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_matr
                    t1, t2, c1, c2, k, stabilized_shrink, bayesian_shrink, additive_shrink, threshold,
                    binary, target_rows, filter_cols, target_cols, verbose, format_output, m2_on_device=True)
     _say(verbose, "Computing")
-    rows, cols, values, counts = run_hip(call)
+    rows, cols, values, counts = run_hip(call, want_rows=(format_output != 'csr'))
     _say(verbose, f"Building {format_output} matrix")
     res = finish(call, rows, cols, values, counts, format_output)
     _say(verbose, "Done")

@@ -181,7 +181,7 @@ int validate(const sp_knn_args *a) {
     if (a->n_targets > 0) {
         if (!a->targets || !a->m1_indptr || (!m2t && !a->m2_indptr) || !a->cols || !a->values)
             return fail(SP_EINVAL, "NULL input/output pointer");
-        if (!a->rows && !(a->on_device && (a->flags & SP_FLAG_NO_ROWS_OUT)))
+        if (!a->rows && !(a->flags & SP_FLAG_NO_ROWS_OUT))
             return fail(SP_EINVAL, "rows is NULL");
         if (a->nnz_m1 > 0 && (!a->m1_data || !a->m1_indices)) return fail(SP_EINVAL, "m1 arrays NULL");
         if (!m2t && a->nnz_m2 > 0 && (!a->m2_data || !a->m2_indices)) return fail(SP_EINVAL, "m2 arrays NULL");
@@ -566,7 +566,9 @@ int run_host(sp_knn_args *a) {
     TRY(pool.up(fm ? a->filter_m_indices : nullptr, (size_t)a->filter_nnz, &d.filter_m_indices));
     TRY(pool.up(tm ? a->target_col_m_indptr : nullptr, (size_t)a->n_rows_m1 + 1, &d.target_col_m_indptr));
     TRY(pool.up(tm ? a->target_col_m_indices : nullptr, (size_t)a->target_col_nnz, &d.target_col_m_indices));
-    TRY(pool.alloc(nt * k, &d.rows));
+    const bool want_rows = !(a->flags & SP_FLAG_NO_ROWS_OUT);
+    d.rows = nullptr;
+    if (want_rows) TRY(pool.alloc(nt * k, &d.rows));
     TRY(pool.alloc(nt * k, &d.cols));
     TRY(pool.alloc(nt * k, &d.values));
     d.out_counts = nullptr;
@@ -575,7 +577,7 @@ int run_host(sp_knn_args *a) {
     int rc = run_device(&d);
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(a->rows, d.rows, nt * k * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (want_rows) HIP_TRY(hipMemcpy(a->rows, d.rows, nt * k * sizeof(int32_t), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(a->cols, d.cols, nt * k * sizeof(int32_t), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(a->values, d.values, nt * k * sizeof(float), hipMemcpyDeviceToHost));
     if (a->out_counts) HIP_TRY(hipMemcpy(a->out_counts, d.out_counts, nt * sizeof(int32_t), hipMemcpyDeviceToHost));
