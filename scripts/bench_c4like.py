@@ -26,6 +26,8 @@ if len(sys.argv) > 2 and sys.argv[2] == 'shuffle':      # real catalogues are no
     perm = np.random.default_rng(5).permutation(n_items)
     urm = urm[:, perm].tocsr()
 NO_ORDER = len(sys.argv) > 3 and sys.argv[3] == 'noorder'
+# optional tuning sweep (kernel time only): "threads_per_wg=512,table_slots=4096;threads_per_wg=256,table_slots=4096"
+sweeps = [dict((kv.split('=')[0], int(kv.split('=')[1])) for kv in grp.split(',')) for grp in sys.argv[4].split(';')] if len(sys.argv) > 4 else []
 m1 = urm.T.tocsr()
 print(f"URM {urm.shape} nnz {urm.nnz}; item-item on m1 {m1.shape}", flush=True)
 k = 200
@@ -52,6 +54,12 @@ for name, prep in (("cosine", lambda: _host.prepare(m1, k=k, l2=1)),
     print(json.dumps({"workload": name, "rows": call.n_targets, "macs_total": int(macs.sum()), "macs_max_row": int(macs.max()),
                       "kernel_ms": ms, "rows_per_s": call.n_targets / ms * 1e3, "algorithmic_GBps": nbytes / ms / 1e6,
                       "rows_sparse": ph[9], "generic_windows": ph[11]}), flush=True)
+    for tun in sweeps:
+        prob.run(cols, vals, counts, no_row_order=NO_ORDER, **tun); torch.cuda.synchronize()
+        i1 = prob.run(cols, vals, counts, time_kernel=True, phase_timers=False, no_row_order=NO_ORDER, **tun)
+        print(f"   tuning {tun}: {i1['kernel_ms']:.2f} ms, workgroups {i1['num_wgs']}", flush=True)
+    if sweeps:
+        prob.run(cols, vals, counts, no_row_order=NO_ORDER); torch.cuda.synchronize()
     # parity on a sample of rows (heaviest + random)
     order = np.argsort(-macs); sample = np.unique(np.concatenate([order[:3], np.random.default_rng(1).choice(call.n_targets, 40, replace=False)])).astype(np.int32)
     import copy
