@@ -113,7 +113,7 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
     if (cap > 0x7FFFFFF0LL) return fail(SP_EINVAL, "k too large");
     // sparse kernel's candidate buffer: the last quarter of region A when SEL_E*NT entries (what its register-resident
     // selection handles) fit there and leave room above k; else global scratch
-    // The sparse kernel's own shape.  Its column bitmap needs one bit per output column: up to 2^18 columns fit a
+    // The sparse kernel's own shape.  Its column bitmap wants one bit per output column: up to 2^18 columns fit a
     // 32 KiB region A, and then THREE 256-thread workgroups share a CU (53.5 KB of LDS each) instead of one of 1024
     // threads — the dense phases of one overlap with the sweeps of the others, and a 4-wave barrier is cheap
     // (user-scoring slice, 100k items: 97 -> 50 ms).  Needs k + 512 <= 1024 for the candidate buffer to stay in LDS.
@@ -121,8 +121,9 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
     // ... and for the typical row to stay on this kernel with the smaller collision set (rows are classified one by one
     // on the device: expected colliding products MACs^2 / (2 n_cols) <= 0.3 * slots; here the average row, from sizes alone)
     const double avg_macs = (a->n_rows_m1 > 0 && a->n_rows_m2 > 0) ? ((double)a->nnz_m1 / a->n_rows_m1) * ((double)a->nnz_m2 / a->n_rows_m2) : 0.0;
-    const bool small_rows = avg_macs * avg_macs / (2.0 * std::max(1, a->n_output_cols)) <= 0.25 * 1024.0;
-    if (!a->threads_per_wg && !a->table_slots && a->n_output_cols <= (1 << 18) && (long long)a->k + 512 <= (long long)SEL_E * 256 && small_rows) {
+    // (beyond 2^18 columns the bitmap aliases — columns modulo its size — which only adds expected collisions)
+    const bool small_rows = avg_macs * avg_macs / (2.0 * std::max(1, std::min(a->n_output_cols, 1 << 18))) <= 0.25 * 1024.0;
+    if (!a->threads_per_wg && !a->table_slots && (long long)a->k + 512 <= (long long)SEL_E * 256 && small_rows) {
         NT_s = 256; T_s = 4096; logT_s = 12;
     }
     const bool u_lds_s = ((size_t)SEL_E * NT_s * 8 <= (size_t)T_s * 2) && ((long long)a->k + 512 <= (long long)SEL_E * NT_s);

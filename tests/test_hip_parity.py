@@ -357,6 +357,19 @@ def test_sparse_kernel_rows_pointing_at_empty_m2_rows():
     _check(call, "empty m2 rows, small tile", table_slots=2048)
 
 
+def test_sparse_kernel_small_shape_with_aliasing_bitmap():
+    """Light rows over MORE than 2^18 output columns: the auto-tuned 256-thread shape is used with a bitmap in which
+    columns alias modulo 2^18 (aliasing only adds collisions, which the collision set tells apart by key)."""
+    rng = np.random.default_rng(43)
+    m1 = sp.random_array((8000, 500), density=0.03, format="csr", dtype=np.float32, random_state=rng)            # ~15 entries per row
+    m2 = sp.random_array((500, 700_000), density=0.0002, format="csr", dtype=np.float32, random_state=rng)     # ~140 per row: ~2k products per target row
+    for kw in ({}, dict(l2=1), dict(l1=1, t1=0.6, t2=0.6, stabilized_shrink=1.0)):
+        call = _host.prepare(m1, m2, k=60, target_rows=np.arange(0, 8000, 3), **kw)
+        _check(call, f"aliasing bitmap {kw}")
+        info = _host.run_hip(call, time_kernel=True)[4]
+        assert info["num_wgs"] > 256 and info["phase_cycles"][9] > 0.9 * call.n_targets      # three workgroups per CU, rows on the sparse kernel
+
+
 def test_sparse_kernel_small_pools_give_up_to_generic():
     """With a small accumulator tile the sparse kernel's pools overflow for most rows: they must come back right
     through the generic kernel's queue."""
