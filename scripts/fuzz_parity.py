@@ -19,6 +19,7 @@ ap.add_argument("--only", type=int, default=-1, help="run only this case of the 
 ap.add_argument("--dump-slot", type=int, default=-1, help="with --only: print both sides of this slot")
 ap.add_argument("--tuning", default="", help="with --only: override the case's tuning, e.g. table_slots=2048,no_sparse_path=1")
 ap.add_argument("--dbg", type=int, default=0)
+ap.add_argument("--huge", action="store_true", help="add shapes with more than 2^18 output columns (changes the case sequence of a seed)")
 ap.add_argument("--max-macs", type=float, default=4e8, help="skip cases whose oracle run would take too long")
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
@@ -49,22 +50,26 @@ def rand_matrix(n_rows, n_cols, density, kind):
 
 
 def one_case(i):
-    shape_kind = rng.choice(["small", "wide_out", "tall", "dense_rows"])
+    shape_kind = rng.choice(["small", "wide_out", "tall", "dense_rows", "huge_out"] if a.huge else ["small", "wide_out", "tall", "dense_rows"])
     if shape_kind == "small":
         n_rows, n_cols, dens = int(rng.integers(1, 400)), int(rng.integers(1, 300)), float(rng.choice([0.02, 0.1, 0.4]))
     elif shape_kind == "wide_out":          # m2 = m.T has many columns: the sparse kernel
         n_rows, n_cols, dens = int(rng.integers(20000, 60000)), int(rng.integers(500, 4000)), float(rng.choice([0.002, 0.005, 0.01]))
+    elif shape_kind == "huge_out":          # explicit m2 with more than 2^18 columns: the aliasing bitmap of the small shape
+        n_rows, n_cols, dens = int(rng.integers(3000, 8000)), int(rng.integers(300, 800)), float(rng.choice([0.01, 0.03]))
     elif shape_kind == "tall":
         n_rows, n_cols, dens = int(rng.integers(3000, 9000)), int(rng.integers(50, 400)), float(rng.choice([0.02, 0.08]))
     else:
         n_rows, n_cols, dens = int(rng.integers(200, 1500)), int(rng.integers(2000, 8000)), float(rng.choice([0.02, 0.05]))
     kind = str(rng.choice(["plain", "plain", "binary", "quant", "signed", "skewed"]))
     m = rand_matrix(n_rows, n_cols, dens, kind)
-    explicit_m2 = rng.random() < 0.3
+    explicit_m2 = rng.random() < 0.3 or shape_kind == "huge_out"
     m2 = None
     if explicit_m2:
         nc2 = int(rng.integers(1, 5000)) if shape_kind != "wide_out" else int(rng.integers(20000, 50000))
-        m2 = rand_matrix(n_cols, nc2, float(rng.choice([0.002, 0.01, 0.05])) if nc2 > 1000 else 0.1, str(rng.choice(["plain", "signed", "quant"])))
+        if shape_kind == "huge_out":
+            nc2 = int(rng.integers(300_000, 900_000))
+        m2 = rand_matrix(n_cols, nc2, (float(rng.choice([0.00005, 0.0002, 0.0005])) if nc2 > 100_000 else float(rng.choice([0.002, 0.01, 0.05]))) if nc2 > 1000 else 0.1, str(rng.choice(["plain", "signed", "quant"])))
     n_out = m.shape[0] if m2 is None else m2.shape[1]
     fam = str(rng.choice(["dot", "cosine", "asym", "tversky", "jaccard", "dice", "splus", "depop", "rp3like"]))
     kw = {}
@@ -89,6 +94,8 @@ def one_case(i):
     n_t = int(min(m.shape[0], rng.choice([m.shape[0], 50, 300, 1500])))
     targets = None if n_t == m.shape[0] and rng.random() < 0.5 else np.sort(rng.choice(m.shape[0], size=n_t, replace=False)).astype(np.int32)
     sel = rng.random()
+    if shape_kind == "huge_out" and sel >= 0.2:
+        sel = 1.0            # (no MATRIX selectors over ~1e6 columns x ~1e4 rows here)
     if sel < 0.12: kw["filter_cols"] = rng.choice(n_out, size=max(1, n_out // 7), replace=False).tolist()
     elif sel < 0.2: kw["target_cols"] = rng.choice(n_out, size=max(1, n_out // 3), replace=False).tolist()
     elif sel < 0.32: kw["filter_cols"] = sp.random_array((m.shape[0], n_out), density=min(0.5, 30.0 / max(n_out, 1)), format="csr", dtype=np.float32, random_state=rng)
