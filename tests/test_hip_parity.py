@@ -500,3 +500,33 @@ def test_device_squared_norms_bit_identical_to_numpy(lens):
     got1, got2 = _host.squared_norms_m1t_hip(data, indptr)
     assert np.array_equal(got1.view(np.uint32), want1.view(np.uint32))
     assert np.array_equal(got2.view(np.uint32), want2.view(np.uint32))
+
+
+def test_public_call_device_transpose_edge_shapes():
+    """`matrix2=None` through the device-built transpose on degenerate inputs: empty matrix, one row, one column, empty
+    rows, k beyond the column count, target rows, CSC / float64 / integer input, binary.  Tie-aware: the sorted values
+    of every output row must equal those of the host-transposed call."""
+    rng = np.random.default_rng(0)
+
+    def rowvals(s, k):
+        d = s.toarray()
+        return -np.sort(-d, axis=1)[:, :min(k, d.shape[1])]
+
+    def chk(m, k, **kw):
+        for fmt in ("csr", "coo"):
+            a = sim.cosine(m, k=k, verbose=False, format_output=fmt, **kw).tocsr()
+            b = sim.cosine(m, m.T.tocsr(), k=k, verbose=False, format_output=fmt, **kw).tocsr()
+            a.sum_duplicates(); b.sum_duplicates()
+            assert a.shape == b.shape
+            assert np.allclose(rowvals(a, k), rowvals(b, k), rtol=1e-6, atol=1e-7), (m.shape, kw, fmt)
+
+    chk(sp.csr_array((50, 30), dtype=np.float32), 5)
+    chk(sp.random_array((1, 40), density=0.5, format="csr", dtype=np.float32, random_state=rng), 5)
+    chk(sp.random_array((40, 1), density=0.5, format="csr", dtype=np.float32, random_state=rng), 5)
+    m = sp.random_array((200, 100), density=0.05, format="csr", dtype=np.float32, random_state=rng).tolil()
+    m[10:60] = 0
+    m = m.tocsr()
+    chk(m, 7); chk(m, 500); chk(m, 3, target_rows=[0, 5, 199, 20])
+    m64 = sp.random_array((300, 80), density=0.1, format="csc", dtype=np.float64, random_state=rng)
+    chk(m64, 9, binary=True); chk(m64, 9, shrink=2.0)
+    chk(sp.csr_array(rng.integers(0, 3, (60, 40)).astype(np.int64)), 4)
