@@ -10,17 +10,26 @@ Workload at N=1 = BASELINE.json configs[1] ("C2"): cosine, m1 = 1M x 100k fixed-
 (SURVEY §8d canonical generator, seed 12345), m2 = m1.T, k = 100.  A "step" is one pass of the kernel
 over all target rows with every operand already resident in HBM.
 
-N > 1 ("weak"): every rank owns 1M target rows of its own (m1 shard seeded 12345+rank), m2 / Y* are the
-replicated operands (rank 0's matrix transposed), no collective during compute, and the step ends
-with the single RCCL gather of the (cols, values) slabs on rank 0 — inside the timed region.
+N > 1 goes through the shipped multi-GPU driver, `similaripy_amd.distributed.ShardedDeviceProblem`: every rank builds
+the same problem, `partition_targets` cuts the target list into N contiguous work-balanced slices, each rank's slice is
+resident on its own GPU (m2 / Y* replicated), no collective during compute, and the step ends with the single RCCL
+gather of the (cols, values, counts) slabs on rank 0 — inside the timed region.
+  --scaling weak (default): m1 = the 1M x 100k matrix of C2 stacked N times (N*1M rows), m2 = the transpose of ONE copy:
+      N*1M output rows, exactly 1M per rank, every rank does the work of the N=1 run (at N=1 it IS the N=1 run).
+  --scaling strong: the 1M rows of C2, cut N ways.
 
 Extra objects on the JSON line:
   roofline     — algorithmic bytes per launch (16*nnz1 + 8*MACs + 8*k per row) over the average
                  duration of the dominant kernel (sp_knn_sparse_kernel), measured with HIP events recorded on the
                  launch stream around that launch in K extra passes of the same step right after the timed region
                  (the timed steps themselves stay asynchronous).
-  cpu_baseline — the reference kernel itself (oracle/_ref, kind "reference"; or the C port) timed on the
-                 host cores of this box on a bounded sample of the same workload (rank 0, N=1 only).
+  cpu_baseline — the reference kernel itself (oracle/_ref, kind "reference"; or the C port) timed on the physical
+                 host cores of this box (OMP_PROC_BIND=spread, OMP_PLACES=cores, in a child process so that the OpenMP
+                 runtime sees them) on a bounded sample of the same workload: warm-up + 3 rounds, mean +- std, for the
+                 reference's default column blocking (block_size=0 -> 262144: the headline `value`) and for blocking off
+                 (rank 0, N=1 only).
+  end_to_end_s — wall clock of the public call `similaripy_amd.cosine(m, k=100, format_output="csr")` (the reference
+                 harness's definition, benchmark.py:168-189), host preprocessing and output assembly included.
 """
 from __future__ import annotations
 
@@ -44,17 +53,7 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def fixed_degree_csr(n_rows: int, n_cols: int, nnz_row: int, seed: int) -> sp.csr_array:
-    """SURVEY §8d canonical generator for C2/C3."""
-    rng = np.random.default_rng(seed)
-    cols = rng.integers(0, n_cols, (n_rows, nnz_row), dtype=np.int32)
-    cols.sort(axis=1)
-    data = rng.random(n_rows * nnz_row, dtype=np.float32)
-    indptr = np.arange(0, n_rows * nnz_row + 1, nnz_row, dtype=np.int32)   # int32 like the reference's kernel
-    m = sp.csr_array((data, cols.ravel(), indptr), shape=(n_rows, n_cols))
-    m.sum_duplicates()
-    m.data[m.data == 0] = np.float32(0.5)   # rng.random can return exactly 0; keep nnz structural
-    return m
+from similaripy_amd.workloads import c1_matrix, fixed_degree_csr      # noqa: E402  (SURVEY §8d canonical generators)
 
 
 def algorithmic_bytes(call) -> tuple[int, int]:
@@ -70,12 +69,22 @@ def algorithmic_bytes(call) -> tuple[int, int]:
     return nbytes, macs
 
 
+def lib_source_sha() -> str:
+    """Short hash of the kernel sources: profiles/hbm_traffic.json entries are valid for one build only."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted((ROOT / "similaripy_amd" / "csrc").glob("*")):
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c1"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--rows", type=int, default=0)
     ap.add_argument("--cols", type=int, default=0)
     ap.add_argument("--nnz-row", type=int, default=0)
@@ -89,7 +98,8 @@ def main():
     ap.add_argument("--no-fold", action="store_true", help="do not fold the column term into the m2 stream (A/B)")
     ap.add_argument("--dbg", type=int, default=0, help="kernel ablation bits (profiling only; results invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=3.0, help="target wall time of ONE cpu_baseline round")
     args = ap.parse_args()
 
     import torch
@@ -107,7 +117,7 @@ def main():
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from similaripy_amd import _abi, _host
-    from similaripy_amd.device import DeviceProblem
+    from similaripy_amd.distributed import ShardedDeviceProblem
 
     _abi.require_device()
 
@@ -124,39 +134,38 @@ def main():
     sim_name = "cosine" if args.workload != "c3" else "s_plus(l1=.5,l2=.5,shrink=10)"
 
     t0 = time.perf_counter()
-    m0 = fixed_degree_csr(n_rows, n_cols, nnz_row, 12345)
-    if rank == 0:
-        m1, m2 = m0, None                     # m2 = m1.T
+    if args.workload == "c1" and not (args.rows or args.cols or args.nnz_row):
+        m1 = c1_matrix()                                     # configs[0] exactly: sps.random
+        gen = "sps.random d=0.01"
     else:
-        m1, m2 = fixed_degree_csr(n_rows, n_cols, nnz_row, 12345 + rank), m0.T
-    call = _host.prepare(m1, m2, k=k, **kern_kw)
+        m1 = fixed_degree_csr(n_rows, n_cols, nnz_row, 12345)
+        gen = f"fixed-degree CSR nnz/row={nnz_row}"
+    # the same problem on every rank (seeded); weak scaling: the matrix stacked `world` times over one copy's transpose
+    reps = world if args.scaling == "weak" else 1
+    m2 = m1.T.tocsr()
+    m1_job = sp.vstack([m1] * reps, format="csr") if reps > 1 else m1
+    call = _host.prepare(m1_job, m2, k=k, **kern_kw)
     t_prep = time.perf_counter() - t0
-    nbytes, macs = algorithmic_bytes(call)
-    log(f"rank {rank}: {sim_name} {n_rows}x{n_cols} nnz/row~{m1.nnz / n_rows:.2f} k={k}: "
-        f"MACs/row={macs / n_rows:.0f}, algorithmic {nbytes / 1e9:.1f} GB/launch, host prep {t_prep:.1f}s")
+    nbytes, macs = algorithmic_bytes(call)                   # over ALL target slots of the job
+    total_rows = call.n_targets
+    log(f"rank {rank}: {sim_name} {n_rows}x{n_cols} nnz/row~{m1.nnz / n_rows:.2f} k={k}, {total_rows} target slots: "
+        f"MACs/row={macs / total_rows:.0f}, algorithmic {nbytes / 1e9:.1f} GB/step, host prep {t_prep:.1f}s")
 
-    prob = DeviceProblem(call, dev)
-    cols, vals, counts, _ = prob.alloc_outputs()
+    shard = ShardedDeviceProblem(call, device=dev)           # partition_targets + DeviceProblem of this rank's slice
     tuning = dict(table_slots=args.table_slots, threads_per_wg=args.threads, num_wgs=args.num_wgs, load_pct=args.load_pct, dbg=args.dbg,
                   no_sparse_path=args.no_sparse_path, no_fold=args.no_fold)
-
-    gathered = None
-    if world > 1 and rank == 0:
-        gathered = ([torch.empty_like(cols) for _ in range(world)], [torch.empty_like(vals) for _ in range(world)])
-
     ev_pairs = []
 
     def step(timed: bool):
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()                                    # torch's current stream == the launch stream
-        prob.run(cols, vals, counts, static_sched=args.static_sched, **tuning)
+        shard.run(gather=False, static_sched=args.static_sched, **tuning)
         e1.record()
         if timed:
             ev_pairs.append((e0, e1))
         if world > 1:                                  # the one collective of the path: slabs -> rank 0
-            dist.gather(cols, gathered[0] if rank == 0 else None, dst=0)
-            dist.gather(vals, gathered[1] if rank == 0 else None, dst=0)
+            shard.gather()
 
     def fence():
         torch.cuda.synchronize()
@@ -179,28 +188,32 @@ def main():
 
     step_ms = [a.elapsed_time(b) for a, b in ev_pairs]       # whole step on the launch stream: prep launches + row kernels
     # dominant kernel: hipEvents around its launch inside the library, K more passes of the same step (untimed region)
-    infos = [prob.run(cols, vals, counts, time_kernel=True, static_sched=args.static_sched, phase_timers=False, **tuning) for _ in range(max(1, args.steps))]
-    info = prob.run(cols, vals, counts, time_kernel=True, static_sched=args.static_sched, **tuning)     # one pass with the in-kernel phase timers
+    infos = [shard.run(gather=False, time_kernel=True, static_sched=args.static_sched, phase_timers=False, **tuning) for _ in range(max(1, args.steps))]
+    info = shard.run(gather=False, time_kernel=True, static_sched=args.static_sched, **tuning)     # one pass with the in-kernel phase timers
     sparse_ms = float(np.mean([i["sparse_kernel_ms"] for i in infos]))
     generic_ms = float(np.mean([i["generic_kernel_ms"] for i in infos]))
     dominant = "sp_knn_sparse_kernel" if sparse_ms >= generic_ms else "sp_knn_generic_kernel"
     kern_avg_s = max(sparse_ms, generic_ms) / 1e3
-    n_kept = int(counts.sum().item())
+    n_kept = int(shard.pad_cnt.sum().item())
+    # this rank's launch processes its slice: algorithmic bytes of that slice
+    local_bytes, _ = algorithmic_bytes(shard.prob.call)
 
     if rank != 0:
         dist.destroy_process_group()
         return
 
-    total_rows = n_rows * world
     value = total_rows * args.steps / elapsed
-    achieved = nbytes / kern_avg_s / 1e9
+    achieved = local_bytes / kern_avg_s / 1e9
     traffic = None
     tfile = ROOT / "profiles" / "hbm_traffic.json"
-    if tfile.exists():
+    if tfile.exists():       # PMC passes cannot run inside this process: taken from the committed profile of THIS build only
         try:
-            traffic = json.loads(tfile.read_text()).get(f"{args.workload}:{n_rows}x{n_cols}x{nnz_row}:k{k}", {}).get("bytes_per_launch")
+            ent = json.loads(tfile.read_text()).get(f"{args.workload}:{n_rows}x{n_cols}x{nnz_row}:k{k}", {})
+            if ent.get("lib_source_sha") == lib_source_sha() and world == 1:
+                traffic = ent.get("bytes_per_launch")
         except Exception:
             traffic = None
+    par = f"row-sharded x{world} (distributed.partition_targets, contiguous work-balanced slices)" + (", one gather to rank 0 in the step" if world > 1 else "")
     out = {
         "metric": "similarity rows/sec, cosine k=100 on CSR" if args.workload == "c2" else f"similarity rows/sec, {sim_name} k={k} on CSR",
         "value": value,
@@ -210,27 +223,40 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"{sim_name} on fixed-degree CSR {n_rows}x{n_cols}, nnz/row={nnz_row}, k={k}, m2=m1.T "
-                        f"(BASELINE configs[1]{' x ' + str(world) + ' ranks, own 1M-row m1 shard each, m2 replicated' if world > 1 else ''})",
-            "rows_per_gpu": n_rows, "cols": n_cols, "nnz_per_row": nnz_row, "k": k,
-            "macs_per_row": macs / n_rows,
-            "parallelism": f"row-sharded x{world}" + (", gather to rank 0 in the step" if world > 1 else ""),
-            "kept_entries": n_kept, "generic_windows_per_row": info["passes_total"] / n_rows,
+            "workload": f"{sim_name} on {gen} {n_rows}x{n_cols}, k={k}, m2=m1.T (BASELINE configs[{ {'c1': 0, 'c2': 1, 'c3': 2}[args.workload] }])"
+                        + (f"; weak scaling: m1 = that matrix stacked {reps} times ({total_rows} rows, {n_rows} per rank), m2 = one copy's transpose" if reps > 1 else ""),
+            "target_slots": total_rows, "rows_per_gpu": total_rows // world, "cols": n_cols, "nnz_per_row": nnz_row, "k": k,
+            "macs_per_row": macs / total_rows,
+            "parallelism": par,
+            "kept_entries_rank0": n_kept, "generic_windows_per_row": info["passes_total"] / max(1, shard.n_loc),
             "phase_share": phase_share(info),
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-            "kernel": dominant, "kernel_ms_avg": kern_avg_s * 1e3, "algorithmic_bytes_per_launch": nbytes,
+            "kernel": dominant, "kernel_ms_avg": kern_avg_s * 1e3, "algorithmic_bytes_per_launch": local_bytes,
             "step_ms_avg_on_stream": float(np.mean(step_ms)), "sparse_kernel_ms": sparse_ms, "generic_kernel_ms": generic_ms,
         },
     }
-
+    if world == 1 and not args.no_end_to_end:
+        import similaripy_amd as sim
+        sim.cosine(m1[:2000], k=10, verbose=False)          # (library / allocator warm-up)
+        fn = (lambda: sim.cosine(m1, k=k, verbose=False, format_output="csr")) if args.workload != "c3" else \
+             (lambda: sim.s_plus(m1, l1=0.5, l2=0.5, shrink=10, k=k, verbose=False, format_output="csr"))
+        ts = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            res = fn()
+            ts.append(time.perf_counter() - t0)
+        out["end_to_end_s"] = min(ts)
+        out["end_to_end"] = {"call": f"similaripy_amd.{'cosine' if args.workload != 'c3' else 's_plus'}(m, k={k}, format_output='csr')",
+                             "seconds": ts, "rows_per_s": n_rows / min(ts), "out_nnz": int(res.nnz)}
+        del res
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(call, args.cpu_seconds)
     print(json.dumps(out), flush=True)
@@ -251,38 +277,77 @@ def phase_share(info) -> dict:
     return d
 
 
-def cpu_baseline(call, budget_s: float) -> dict:
-    """Time the CPU kernel on a bounded sample (first S target rows) of the same workload."""
-    from oracle import splus_oracle as so
-    import copy
+def physical_cores() -> int:
+    """Distinct (package, core) pairs of the host; falls back to os.cpu_count()."""
+    seen = set()
+    try:
+        for d in Path("/sys/devices/system/cpu").glob("cpu[0-9]*"):
+            t = d / "topology"
+            seen.add(((t / "physical_package_id").read_text().strip(), (t / "core_id").read_text().strip()))
+    except Exception:
+        seen = set()
+    return len(seen) or (os.cpu_count() or 1)
 
-    kind = "reference" if so.available("reference") else "port"
-    cores = so.max_threads(kind)
 
-    def run(n, block_size):
-        c = copy.copy(call)
-        c.targets = np.ascontiguousarray(call.targets[:n])
-        t0 = time.perf_counter()
-        so.run_kernel(c, kind, num_threads=0, block_size=block_size)
-        return time.perf_counter() - t0
-
-    n_total = call.targets.shape[0]
+_CPU_CHILD = r"""
+import json, sys, time, types
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from oracle import splus_oracle as so
+d = np.load(sys.argv[2], mmap_mode=None)
+meta = json.loads(str(d["meta"]))
+call = types.SimpleNamespace(**{k: d[k] for k in d.files if k != "meta"}, **meta["scalars"])
+kind = "reference" if so.available("reference") else "port"
+budget = float(sys.argv[3])
+n_total = call.targets.shape[0]
+def run(n, bs):
+    c = types.SimpleNamespace(**vars(call)); c.targets = np.ascontiguousarray(call.targets[:n])
+    t0 = time.perf_counter(); so.run_kernel(c, kind, num_threads=0, block_size=bs); return time.perf_counter() - t0
+out = {"kind": kind, "threads": so.max_threads(kind)}
+for name, bs in (("blocked_262144", 262144), ("unblocked", 0)):
     probe = min(n_total, 4000)
-    run(min(n_total, 500), 0)                               # warm the thread team / page in
-    rate = probe / run(probe, 0)
-    sample = int(max(probe, min(n_total, rate * budget_s)))
-    t = run(sample, 0)
-    val = sample / t
-    # the reference's default column blocking (block_size=0 -> 262144, s_plus.pyx:218-225); without its
-    # popularity reorder, which only changes slot order — reported for completeness on a smaller sample
-    s2 = max(probe, sample // 4)
-    val_blocked = s2 / run(s2, 262144)
-    log(f"cpu_baseline[{kind}] {cores} threads: unblocked {val:.0f} rows/s on {sample} rows; blocked(262144) {val_blocked:.0f} rows/s")
+    run(min(n_total, 500), bs)                                  # thread team up, pages in
+    rate = probe / run(probe, bs)
+    sample = int(max(probe, min(n_total, rate * budget)))
+    run(sample, bs)                                              # warm-up round at full sample size
+    ts = [run(sample, bs) for _ in range(3)]
+    r = [sample / t for t in ts]
+    out[name] = {"rows_per_s": float(np.mean(r)), "std": float(np.std(r)), "rounds": r, "sample_rows": sample, "seconds": ts}
+print(json.dumps(out))
+"""
+
+
+def cpu_baseline(call, round_s: float) -> dict:
+    """The CPU kernel (oracle/_ref = the reference header compiled in place, else the C port) on a bounded prefix of the
+    same target rows, in a child process whose OpenMP runtime is pinned to the physical cores."""
+    import subprocess
+    import tempfile
+
+    cores = physical_cores()
+    names = ("targets", "m1_data", "m1_indices", "m1_indptr", "m2_data", "m2_indices", "m2_indptr",
+             "Xtversky", "Ytversky", "Xcosine", "Ycosine", "Xdepop", "Ydepop",
+             "filter_m_indptr", "filter_m_indices", "target_col_m_indptr", "target_col_m_indices")
+    scal = {n: getattr(call, n) for n in ("a1", "l1", "l2", "l3", "t1", "t2", "stabilized_shrink", "bayesian_shrink", "threshold",
+                                          "k", "n_output_cols", "filter_mode", "target_col_mode")}
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    with tempfile.TemporaryDirectory(dir=shm) as td:
+        f = os.path.join(td, "call.npz")
+        np.savez(f, meta=json.dumps({"scalars": scal}), **{n: getattr(call, n) for n in names})
+        env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_PROC_BIND="spread", OMP_PLACES="cores")
+        proc = subprocess.run([sys.executable, "-c", _CPU_CHILD, str(ROOT), f, str(round_s)], env=env, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError("cpu_baseline child failed:\n" + proc.stderr[-2000:])
+    r = json.loads(proc.stdout.strip().splitlines()[-1])
+    b, u = r["blocked_262144"], r["unblocked"]
+    log(f"cpu_baseline[{r['kind']}] {r['threads']} threads on {cores} physical cores: blocked(262144, the reference default) "
+        f"{b['rows_per_s']:.0f} +- {b['std']:.0f} rows/s; unblocked {u['rows_per_s']:.0f} +- {u['std']:.0f} rows/s")
     return {
-        "value": val, "unit": "rows/s", "cores": cores, "kind": kind,
-        "sample": f"first {sample} of {n_total} target rows of the same workload, block_size off (the faster CPU variant), "
-                  f"{t:.1f}s wall, all {cores} host threads (OpenMP dynamic schedule)",
-        "blocked_262144_rows_per_s": val_blocked,
+        "value": b["rows_per_s"], "std": b["std"], "unit": "rows/s", "cores": r["threads"], "kind": r["kind"],
+        "sample": f"first {b['sample_rows']} of {call.targets.shape[0]} target rows of the same workload, the reference's default column "
+                  f"blocking (block_size=0 -> 262144, s_plus.pyx:218-225; without its popularity reorder, which only permutes slot order), "
+                  f"1 warm-up + 3 rounds of {np.mean(b['seconds']):.1f}s, {r['threads']} OpenMP threads = physical cores, "
+                  f"OMP_PROC_BIND=spread OMP_PLACES=cores, dynamic schedule",
+        "blocked_262144": b, "unblocked": u,
     }
 
 

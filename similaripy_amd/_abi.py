@@ -180,8 +180,13 @@ def load(build_if_missing: bool = True):
     if not path.exists():
         raise HipLibraryError(f"{path} not found: run `python -c 'import __graft_entry__ as g; g.build()'`")
     # torch ships its own libamdhip64.so.7; importing it first makes the HIP runtime a single
-    # shared instance, so torch device pointers / streams are valid inside this library.
-    import torch  # noqa: F401
+    # shared instance, so torch device pointers / streams are valid inside this library.  The plain
+    # drop-in path (host buffers in and out) does not need torch: without it the system's HIP runtime is used;
+    # device.py / distributed.py import torch themselves.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
 
     try:
         lib = C.CDLL(str(path), mode=C.RTLD_GLOBAL)

@@ -57,6 +57,27 @@ int fail(int code, const char *fmt, ...) {
             return fail(SP_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
     } while (0)
 
+// Owned scratch of one call: a workspace the library allocated itself and the timing events.  Every early return of
+// the functions below (HIP_TRY) releases them.
+struct CallGuard {
+    void *ws = nullptr;                  // non-null only when owned
+    hipStream_t stream = nullptr;
+    std::vector<hipEvent_t> events;
+    int event(hipEvent_t *e) {
+        *e = nullptr;
+        HIP_TRY(hipEventCreate(e));
+        events.push_back(*e);
+        return SP_OK;
+    }
+    ~CallGuard() {
+        for (hipEvent_t e : events) (void)hipEventDestroy(e);
+        if (ws) {
+            (void)hipStreamSynchronize(stream);
+            (void)hipFree(ws);
+        }
+    }
+};
+
 struct Config {
     int T, logT, NT, cap, hash_fill;   // generic kernel (and, unless auto-tuned apart, the sparse kernel)
     int T_s, logT_s, NT_s;             // sparse kernel: tile (region A = 8*T_s bytes) and workgroup size
@@ -261,10 +282,11 @@ int run_device_impl(sp_knn_args *a) {
 
     hipStream_t stream = (hipStream_t)a->stream;
     unsigned char *ws = (unsigned char *)a->workspace;
-    bool own_ws = false;
+    CallGuard guard;
+    guard.stream = stream;
     if (!ws) {
         HIP_TRY(hipMalloc((void **)&ws, c.ws_total));
-        own_ws = true;
+        guard.ws = ws;
     } else if (a->workspace_bytes < (int64_t)c.ws_total) {
         return fail(SP_EWORKSPACE, "workspace too small: need %zu bytes, got %lld", c.ws_total, (long long)a->workspace_bytes);
     }
@@ -272,8 +294,8 @@ int run_device_impl(sp_knn_args *a) {
     const bool timed = (a->flags & SP_FLAG_TIME_KERNEL) != 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (timed) {
-        HIP_TRY(hipEventCreate(&ev0));
-        HIP_TRY(hipEventCreate(&ev1));
+        TRY(guard.event(&ev0));
+        TRY(guard.event(&ev1));
         HIP_TRY(hipEventRecord(ev0, stream));
     }
 
@@ -380,11 +402,11 @@ int run_device_impl(sp_knn_args *a) {
     kp.dbg = (int)a->reserved[0];
 
     hipEvent_t kev[4] = {nullptr, nullptr, nullptr, nullptr};
-    if (timed) { for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&kev[i])); }
+    if (timed) { for (int i = 0; i < 4; ++i) TRY(guard.event(&kev[i])); }
     KParams kp_s = kp;
     kp_s.T = c.T_s; kp_s.logT = c.logT_s;
     rc = launch_rows(kp_s, kp, c, stream, timed ? kev : nullptr);
-    if (rc) { if (own_ws) (void)hipFree(ws); return rc; }
+    if (rc) return rc;
 
     if (timed) {
         HIP_TRY(hipEventRecord(ev1, stream));
@@ -404,15 +426,8 @@ int run_device_impl(sp_knn_args *a) {
         HIP_TRY(hipEventElapsedTime(&kg_ms, kev[2], kev[3]));
         a->reserved[1] = (int64_t)(ks_ms * 1000.0f);      // sparse row kernel, microseconds
         a->reserved[2] = (int64_t)(kg_ms * 1000.0f);      // generic row kernel, microseconds
-        for (int i = 0; i < 4; ++i) (void)hipEventDestroy(kev[i]);
-        (void)hipEventDestroy(ev0);
-        (void)hipEventDestroy(ev1);
     }
-    if (own_ws) {
-        HIP_TRY(hipStreamSynchronize(stream));
-        HIP_TRY(hipFree(ws));
-    }
-    return SP_OK;
+    return SP_OK;      // (the guard waits for the stream before it frees an owned workspace)
 }
 
 }  // namespace
@@ -451,18 +466,19 @@ int run_device(sp_knn_args *a) {
     TRY(m2t_layout(a, n_cus, &b, &L));
     hipStream_t stream = (hipStream_t)a->stream;
     unsigned char *ws = (unsigned char *)a->workspace;
-    bool own_ws = false;
+    CallGuard guard;
+    guard.stream = stream;
     if (!ws) {
         HIP_TRY(hipMalloc((void **)&ws, L.total));
-        own_ws = true;
+        guard.ws = ws;
     } else if (a->workspace_bytes < (int64_t)L.total) {
         return fail(SP_EWORKSPACE, "workspace too small: need %zu bytes, got %lld", L.total, (long long)a->workspace_bytes);
     }
     const bool timed = (a->flags & SP_FLAG_TIME_KERNEL) != 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (timed) {
-        HIP_TRY(hipEventCreate(&ev0));
-        HIP_TRY(hipEventCreate(&ev1));
+        TRY(guard.event(&ev0));
+        TRY(guard.event(&ev1));
         HIP_TRY(hipEventRecord(ev0, stream));
     }
     float *m2_data = (float *)(ws + L.data);
@@ -475,7 +491,6 @@ int run_device(sp_knn_args *a) {
         HIP_TRY(hipEventSynchronize(ev1));
         HIP_TRY(hipEventElapsedTime(&tr_ms, ev0, ev1));
     }
-    if (timed) { (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); }
     if (!rc) {
         b.m2_data = m2_data; b.m2_indices = m2_indices; b.m2_indptr = m2_indptr;
         b.workspace = ws;
@@ -488,10 +503,6 @@ int run_device(sp_knn_args *a) {
         a->reserved[1] = b.reserved[1];
         a->reserved[2] = b.reserved[2];
         a->reserved[3] = (int64_t)(tr_ms * 1000.f);
-    }
-    if (own_ws) {
-        (void)hipStreamSynchronize(stream);
-        (void)hipFree(ws);
     }
     return rc;
 }
@@ -529,6 +540,19 @@ struct DevPool {
 };
 
 
+// structure of a host CSR: indptr[0] = 0, monotone, indptr[n] = nnz, every index in [0, n_cols)
+int check_csr(const char *what, const int32_t *indptr, const int32_t *indices, int n_rows, int64_t nnz, int n_cols) {
+    if (n_rows > 0 && !indptr) return fail(SP_EINVAL, "%s: indptr is NULL", what);
+    if (n_rows > 0 && indptr[0] != 0) return fail(SP_EINVAL, "%s: indptr[0] = %d, expected 0", what, indptr[0]);
+    for (int r = 0; r < n_rows; ++r)
+        if (indptr[r + 1] < indptr[r]) return fail(SP_EINVAL, "%s: indptr decreases at row %d", what, r);
+    if (n_rows > 0 && (int64_t)indptr[n_rows] != nnz) return fail(SP_EINVAL, "%s: indptr[%d] = %d but nnz = %lld", what, n_rows, indptr[n_rows], (long long)nnz);
+    int32_t lo = 0, hi = -1;
+    for (int64_t i = 0; i < nnz; ++i) { lo = std::min(lo, indices[i]); hi = std::max(hi, indices[i]); }
+    if (lo < 0 || hi >= n_cols) return fail(SP_EINVAL, "%s: column index out of range [0,%d) (min %d, max %d)", what, n_cols, lo, hi);
+    return SP_OK;
+}
+
 // host pointers in, host pointers out: the drop-in for s_plus.pyx:359-384
 int run_host(sp_knn_args *a) {
     HIP_TRY(hipSetDevice(a->device));
@@ -538,6 +562,12 @@ int run_host(sp_knn_args *a) {
     for (size_t i = 0; i < nt; ++i)
         if (a->targets[i] < 0 || a->targets[i] >= a->n_rows_m1)
             return fail(SP_EINVAL, "targets[%zu]=%d out of range [0,%d)", i, a->targets[i], a->n_rows_m1);
+
+    // ... nor a hand-built CSR: out-of-range indices or a non-monotone indptr would become out-of-bounds device reads and atomics
+    TRY(check_csr("m1", a->m1_indptr, a->m1_indices, a->n_rows_m1, a->nnz_m1, a->n_rows_m2));
+    if (!(a->flags & SP_FLAG_M2_IS_M1_T)) TRY(check_csr("m2", a->m2_indptr, a->m2_indices, a->n_rows_m2, a->nnz_m2, a->n_output_cols));
+    if (a->filter_mode == SP_SEL_MATRIX) TRY(check_csr("filter_cols", a->filter_m_indptr, a->filter_m_indices, a->n_rows_m1, a->filter_nnz, a->n_output_cols));
+    if (a->target_col_mode == SP_SEL_MATRIX) TRY(check_csr("target_cols", a->target_col_m_indptr, a->target_col_m_indices, a->n_rows_m1, a->target_col_nnz, a->n_output_cols));
 
     DevPool pool;
     sp_knn_args d = *a;

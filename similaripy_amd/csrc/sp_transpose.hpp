@@ -294,11 +294,8 @@ int transpose_device(int n_rows, int n_cols, long long nnz, const float *data, c
         hipLaunchKernelGGL(sp_tr_scatter_kernel, dim3(blocks), dim3(256), 0, stream, n_rows, data, indices, indptr, cursor, rec);
         const int sb = std::min(n_cols, 256 * 32);
         hipLaunchKernelGGL(sp_tr_sort_lds_kernel<TR_SHORT>, dim3(sb), dim3(256), TR_SHORT * 8, stream, n_cols, 0, out_indptr, rec, out_indices, out_data);
-        static bool attr_set = false;
-        if (!attr_set) {
-            HIP_TRY(hipFuncSetAttribute((const void *)sp_tr_sort_lds_kernel<TR_MEDIUM>, hipFuncAttributeMaxDynamicSharedMemorySize, TR_MEDIUM * 8));
-            attr_set = true;
-        }
+        // (per device, and cheap: set on every call like the row kernels' launchers do)
+        HIP_TRY(hipFuncSetAttribute((const void *)sp_tr_sort_lds_kernel<TR_MEDIUM>, hipFuncAttributeMaxDynamicSharedMemorySize, TR_MEDIUM * 8));
         hipLaunchKernelGGL(sp_tr_sort_lds_kernel<TR_MEDIUM>, dim3(std::min(n_cols, 256 * 4)), dim3(256), TR_MEDIUM * 8, stream, n_cols, TR_SHORT, out_indptr, rec, out_indices, out_data);
         hipLaunchKernelGGL(sp_tr_sort_global_kernel, dim3(std::min(n_cols, 256 * 2)), dim3(1024), 0, stream, n_cols, TR_MEDIUM, out_indptr, rec, out_indices, out_data);
     }

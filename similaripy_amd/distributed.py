@@ -12,12 +12,19 @@ The path shards exactly like the reference's only parallel loop — output rows 
     (RCCL over xGMI when the backend is "nccl", gloo on CPU for tests).  Slabs are padded to the
     largest slice so a plain `gather` works; `rows` is implied by the slot and rebuilt on the root.
 
-`compute` is injected (a callable `(call_slice) -> rows, cols, values, counts`) so the CPU test tier can
-drive this module over gloo with the oracle kernel; the product passes the HIP path.
+Two drivers share the partition, the slab layout and the gather:
+
+  ShardedDeviceProblem   the product path: the rank's slice as a `DeviceProblem` resident in HBM (operands uploaded
+                         once), launches through the C ABI on torch's current stream, slabs gathered device to device
+                         (no host bounce).  `bench.py --gpus N`, `similaripy_amd.multi_gpu` and the `-m gpu` tests
+                         all run this class.
+  sharded_knn            host-array form with an injected `compute` callable — the CPU test tier drives it over gloo
+                         with the oracle kernel; with `hip_compute()` it runs the HIP library on the rank's own GPU.
 """
 from __future__ import annotations
 
 import copy
+import os
 from typing import Callable, Optional, Tuple
 
 import numpy as np
@@ -27,7 +34,11 @@ from ._host import KernelCall
 
 def row_work(call: KernelCall) -> np.ndarray:
     """MACs per target slot: sum over the row's m1 entries of the length of the m2 row they select."""
-    nnz2 = np.diff(call.m2_indptr).astype(np.int64)
+    if call.m2_is_m1t:
+        # m2 = m1^T is built on the device: the length of m2 row u is the number of m1 entries in column u
+        nnz2 = np.bincount(call.m1_indices, minlength=call.n_rows_m2).astype(np.int64)
+    else:
+        nnz2 = np.diff(call.m2_indptr).astype(np.int64)
     per_entry = nnz2[call.m1_indices]
     csum = np.concatenate(([0], np.cumsum(per_entry)))
     macs_row = csum[call.m1_indptr[1:]] - csum[call.m1_indptr[:-1]]
@@ -41,16 +52,90 @@ def partition_targets(work: np.ndarray, world_size: int) -> np.ndarray:
     total = float(csum[-1]) if n else 0.0
     bounds = np.zeros(world_size + 1, dtype=np.int64)
     for r in range(1, world_size):
-        bounds[r] = int(np.searchsorted(csum, total * r / world_size, side="left")) if n else 0
+        # slice r starts behind the first row at which the running work reaches r/world of the total
+        bounds[r] = min(n, int(np.searchsorted(csum, total * r / world_size, side="left")) + 1) if n else 0
     bounds[world_size] = n
     return np.maximum.accumulate(bounds)
 
 
-def slice_call(call: KernelCall, lo: int, hi: int) -> KernelCall:
-    """The same problem restricted to target slots [lo, hi)."""
+def slice_call(call: KernelCall, lo: int, hi: int, compact: bool = False) -> KernelCall:
+    """The same problem restricted to target slots [lo, hi).
+
+    compact: also cut m1, the X* vectors and the MATRIX selectors down to the rows [min target, max target] of the slice
+    and shift the targets accordingly — what a rank uploads when the whole m1 is large (10M users).  The `rows` output of a
+    compact call holds SHIFTED row ids; the sharded drivers never read it (rows are rebuilt from `call.targets`)."""
     c = copy.copy(call)
     c.targets = np.ascontiguousarray(call.targets[lo:hi])
+    if not compact or c.targets.size == 0 or call.m2_is_m1t:
+        return c
+    r0, r1 = int(c.targets.min()), int(c.targets.max()) + 1
+    if r0 == 0 and r1 == call.n_rows_m1:
+        return c
+    p0, p1 = int(call.m1_indptr[r0]), int(call.m1_indptr[r1])
+    c.targets = (c.targets - r0).astype(np.int32)
+    c.m1_data = np.ascontiguousarray(call.m1_data[p0:p1])
+    c.m1_indices = np.ascontiguousarray(call.m1_indices[p0:p1])
+    c.m1_indptr = (call.m1_indptr[r0:r1 + 1] - p0).astype(np.int32)
+    c.n_rows_m1 = r1 - r0
+    for name in ("Xtversky", "Xcosine", "Xdepop"):
+        a = getattr(call, name)
+        if a.size:
+            setattr(c, name, np.ascontiguousarray(a[r0:r1]))
+    for ptr, idx in (("filter_m_indptr", "filter_m_indices"), ("target_col_m_indptr", "target_col_m_indices")):
+        ip = getattr(call, ptr)
+        if ip.size:
+            q0, q1 = int(ip[r0]), int(ip[r1])
+            setattr(c, ptr, (ip[r0:r1 + 1] - q0).astype(np.int32))
+            setattr(c, idx, np.ascontiguousarray(getattr(call, idx)[q0:q1]))
     return c
+
+
+def local_device() -> int:
+    """The GPU of this rank in the one-process-per-GPU layout: LOCAL_RANK (torchrun / multi_gpu.spawn), else torch's
+    current device, else SIMILARIPY_AMD_DEVICE / 0."""
+    if "LOCAL_RANK" in os.environ:
+        return int(os.environ["LOCAL_RANK"])
+    try:
+        import torch
+        if torch.cuda.is_available():
+            return int(torch.cuda.current_device())
+    except Exception:
+        pass
+    return int(os.environ.get("SIMILARIPY_AMD_DEVICE", "0"))
+
+
+def _gather_slabs(pad_cols, pad_vals, pad_cnt, dst, group):
+    """THE collective of the path: every rank's padded (cols, values, counts) slab to rank `dst`."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    gc = [torch.empty_like(pad_cols) for _ in range(world)] if rank == dst else None
+    gv = [torch.empty_like(pad_vals) for _ in range(world)] if rank == dst else None
+    gn = [torch.empty_like(pad_cnt) for _ in range(world)] if rank == dst else None
+    dist.gather(pad_cols, gc, dst=dst, group=group)
+    dist.gather(pad_vals, gv, dst=dst, group=group)
+    dist.gather(pad_cnt, gn, dst=dst, group=group)
+    return gc, gv, gn
+
+
+def _assemble(call: KernelCall, bounds, gc, gv, gn):
+    """Root: slabs -> flat (rows, cols, values, counts) in the slot order of `call.targets`."""
+    n, k = call.n_targets, call.k
+    out_cols = np.zeros(n * k, dtype=np.int32)
+    out_vals = np.zeros(n * k, dtype=np.float32)
+    out_cnt = np.zeros(n, dtype=np.int32)
+    for r in range(len(gc)):
+        a, b = int(bounds[r]), int(bounds[r + 1])
+        if b > a:
+            out_cols[a * k: b * k] = gc[r][: (b - a) * k].cpu().numpy()
+            out_vals[a * k: b * k] = gv[r][: (b - a) * k].cpu().numpy()
+            out_cnt[a:b] = gn[r][: b - a].cpu().numpy()
+    # rows: slot i holds targets[i] in its first counts[i] entries, 0 in the padding (SURVEY A.3 #2)
+    real = (np.arange(k, dtype=np.int32)[None, :] < out_cnt[:, None])
+    out_rows = np.where(real, call.targets[:, None], 0).astype(np.int32).ravel()
+    return out_rows, out_cols, out_vals, out_cnt
 
 
 def sharded_knn(call: KernelCall, compute: Callable[[KernelCall], Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]],
@@ -59,6 +144,7 @@ def sharded_knn(call: KernelCall, compute: Callable[[KernelCall], Tuple[np.ndarr
 
     Every rank passes the same `call` (same targets, replicated operands).  Returns
     (rows, cols, values, counts) for ALL targets on rank `dst`, None elsewhere.
+    `device`: where the gather tensors live; default: the rank's GPU under the nccl backend, the CPU otherwise.
     """
     import torch
     import torch.distributed as dist
@@ -73,43 +159,93 @@ def sharded_knn(call: KernelCall, compute: Callable[[KernelCall], Tuple[np.ndarr
     rows, cols, vals, counts = compute(slice_call(call, lo, hi))
     n_loc = hi - lo
 
-    dev = torch.device("cpu") if device is None else torch.device(device)
+    if device is None:
+        dev = torch.device("cuda", local_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    else:
+        dev = torch.device(device)
     pad_cols = torch.zeros(n_max * k, dtype=torch.int32, device=dev)
     pad_vals = torch.zeros(n_max * k, dtype=torch.float32, device=dev)
     pad_cnt = torch.zeros(n_max, dtype=torch.int32, device=dev)
     pad_cols[: n_loc * k] = torch.as_tensor(np.ascontiguousarray(cols), device=dev)
     pad_vals[: n_loc * k] = torch.as_tensor(np.ascontiguousarray(vals), device=dev)
     pad_cnt[:n_loc] = torch.as_tensor(np.ascontiguousarray(counts), device=dev)
-
-    gather_c = [torch.empty_like(pad_cols) for _ in range(world)] if rank == dst else None
-    gather_v = [torch.empty_like(pad_vals) for _ in range(world)] if rank == dst else None
-    gather_n = [torch.empty_like(pad_cnt) for _ in range(world)] if rank == dst else None
-    dist.gather(pad_cols, gather_c, dst=dst, group=group)
-    dist.gather(pad_vals, gather_v, dst=dst, group=group)
-    dist.gather(pad_cnt, gather_n, dst=dst, group=group)
+    gc, gv, gn = _gather_slabs(pad_cols, pad_vals, pad_cnt, dst, group)
     if rank != dst:
         return None
-
-    n = call.n_targets
-    out_cols = np.zeros(n * k, dtype=np.int32)
-    out_vals = np.zeros(n * k, dtype=np.float32)
-    out_cnt = np.zeros(n, dtype=np.int32)
-    for r in range(world):
-        a, b = int(bounds[r]), int(bounds[r + 1])
-        out_cols[a * k: b * k] = gather_c[r][: (b - a) * k].cpu().numpy()
-        out_vals[a * k: b * k] = gather_v[r][: (b - a) * k].cpu().numpy()
-        out_cnt[a:b] = gather_n[r][: b - a].cpu().numpy()
-    # rows: slot i holds targets[i] in its first counts[i] entries, 0 in the padding
-    real = (np.arange(k, dtype=np.int32)[None, :] < out_cnt[:, None])
-    out_rows = np.where(real, call.targets[:, None], 0).astype(np.int32).ravel()
-    return out_rows, out_cols, out_vals, out_cnt
+    return _assemble(call, bounds, gc, gv, gn)
 
 
 def hip_compute(device: Optional[int] = None, **tuning):
-    """`compute` callable for sharded_knn backed by the HIP library (the product path)."""
+    """`compute` callable for sharded_knn backed by the HIP library, on this rank's own GPU by default."""
     from . import _host
 
     def run(call_slice: KernelCall):
-        return _host.run_hip(call_slice, device=device, **tuning)
+        return _host.run_hip(call_slice, device=local_device() if device is None else int(device), **tuning)
 
     return run
+
+
+class ShardedDeviceProblem:
+    """This rank's slice of a row-sharded problem, resident on its GPU.
+
+    Every rank constructs it with the same `call`; the constructor partitions `call.targets` by work, uploads the
+    operands once (`DeviceProblem`: m2 / Y* replicated, m1 / X* / selectors whole) and allocates the padded output slabs
+    — on the root also the receive buffers.  `run()` = one step: the kernel over the rank's slice on torch's current
+    stream, then the one gather (device to device; RCCL over xGMI under the nccl backend).  `result()` on the root copies
+    the gathered slabs to the host in the slot order of `call.targets`.
+    """
+
+    def __init__(self, call: KernelCall, group=None, device=None, dst: int = 0, compact: bool = True):
+        import torch
+        import torch.distributed as dist
+
+        from .device import DeviceProblem
+
+        self.call, self.group, self.dst = call, group, dst
+        self.distributed = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.distributed else 1
+        self.rank = dist.get_rank(group) if self.distributed else 0
+        self.device = torch.device("cuda", local_device()) if device is None else torch.device(device)
+        self.bounds = partition_targets(row_work(call), self.world)
+        self.lo, self.hi = int(self.bounds[self.rank]), int(self.bounds[self.rank + 1])
+        self.n_loc = self.hi - self.lo
+        self.n_max = int(np.max(np.diff(self.bounds)))
+        k = call.k
+        self.prob = DeviceProblem(slice_call(call, self.lo, self.hi, compact=compact), self.device)
+        z = lambda n, dt: torch.zeros(n, dtype=dt, device=self.device)  # noqa: E731
+        self.pad_cols, self.pad_vals, self.pad_cnt = z(self.n_max * k, torch.int32), z(self.n_max * k, torch.float32), z(self.n_max, torch.int32)
+        self.recv = None
+        if self.rank == dst and self.world > 1:
+            self.recv = tuple([torch.empty_like(t) for _ in range(self.world)] for t in (self.pad_cols, self.pad_vals, self.pad_cnt))
+
+    def run(self, gather: bool = True, **kw):
+        """One step.  Returns the kernel's info dict (see DeviceProblem.run)."""
+        k = self.call.k
+        info = {"kernel_ms": 0.0, "passes_total": 0}
+        if self.n_loc:
+            info = self.prob.run(self.pad_cols[: self.n_loc * k], self.pad_vals[: self.n_loc * k], self.pad_cnt[: self.n_loc], **kw)
+        if gather:
+            self.gather()
+        return info
+
+    def gather(self):
+        """THE collective of the path: the padded slabs of every rank to the root (device to device)."""
+        import torch.distributed as dist
+
+        if self.world == 1:
+            return
+        root = self.rank == self.dst
+        dist.gather(self.pad_cols, self.recv[0] if root else None, dst=self.dst, group=self.group)
+        dist.gather(self.pad_vals, self.recv[1] if root else None, dst=self.dst, group=self.group)
+        dist.gather(self.pad_cnt, self.recv[2] if root else None, dst=self.dst, group=self.group)
+
+    def result(self):
+        """Root: (rows, cols, values, counts) of ALL targets as host arrays; None elsewhere."""
+        import torch
+
+        torch.cuda.synchronize(self.device)
+        if self.rank != self.dst:
+            return None
+        if self.world == 1:
+            return _assemble(self.call, self.bounds, [self.pad_cols], [self.pad_vals], [self.pad_cnt])
+        return _assemble(self.call, self.bounds, *self.recv)

@@ -91,3 +91,76 @@ def test_sharded_equals_single_process_gloo():
     # rows array follows the slot convention
     r = rows.reshape(-1, k)
     assert np.all((r == call.targets[:, None]) | (r == 0))
+
+
+def test_compact_slice_is_the_same_problem():
+    """slice_call(compact=True) — what a rank uploads — gives the oracle the same answers as the plain slice, MATRIX
+    selectors and X* vectors included."""
+    from oracle import splus_oracle as so
+    rng = np.random.default_rng(3)
+    m = sp.random_array((300, 90), density=0.1, format="csr", dtype=np.float32, random_state=rng)
+    m2 = sp.random_array((90, 150), density=0.1, format="csr", dtype=np.float32, random_state=rng)
+    filt = sp.random_array((300, 150), density=0.05, format="csr", dtype=np.float32, random_state=rng)
+    call = _host.prepare(m, m2, k=9, l1=0.4, l2=0.6, stabilized_shrink=2.0, filter_cols=filt,
+                         target_rows=np.arange(20, 290, dtype=np.int32))
+    assert call.filter_mode == _host.MODE_MATRIX
+    for lo, hi in ((0, 100), (100, 270), (37, 38)):
+        a = D.slice_call(call, lo, hi)
+        b = D.slice_call(call, lo, hi, compact=True)
+        assert b.n_rows_m1 == hi - lo and b.m1_indptr[0] == 0 and b.targets.min() == 0
+        ra, ca, va = so.run_kernel(a, "port", num_threads=1)
+        rb, cb, vb = so.run_kernel(b, "port", num_threads=1)
+        np.testing.assert_array_equal(ca, cb)
+        np.testing.assert_array_equal(va, vb)
+        # rows of the compact call are shifted by the slice's first row
+        real = (ra != 0) | (ca != 0) | (va != 0)
+        np.testing.assert_array_equal(ra[real], rb[real] + int(a.targets.min()))
+
+
+def test_row_work_of_a_device_transposed_call():
+    """A KernelCall of the public wrappers (m2 = m1^T left to the device) has no m2 arrays: the work vector comes from
+    the column counts of m1 and equals the one of the host-transposed call."""
+    rng = np.random.default_rng(5)
+    m = sp.random_array((200, 70), density=0.1, format="csr", dtype=np.float32, random_state=rng)
+    host = _host.prepare(m, k=5)
+    dev = _host.prepare(m, k=5, m2_on_device=True)
+    assert dev.m2_is_m1t and dev.m2_indptr.size == 0
+    np.testing.assert_array_equal(D.row_work(host), D.row_work(dev))
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_sharded_device_problem_nccl_world1_equals_single_call():
+    """The shipped multi-GPU driver (ShardedDeviceProblem: partition -> resident slice -> kernel -> gather) under the
+    nccl (= RCCL) backend with one rank equals the plain single call."""
+    import torch
+    import torch.distributed as dist
+    from oracle import splus_oracle as so
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        rng = np.random.default_rng(7)
+        m = sp.random_array((3000, 2500), density=0.01, format="csr", dtype=np.float32, random_state=rng)
+        call = _host.prepare(m, k=20, l2=1, target_rows=np.arange(100, 2900, dtype=np.int32))
+        sh = D.ShardedDeviceProblem(call)
+        assert sh.world == 1 and sh.n_loc == call.n_targets
+        sh.run()
+        rows, cols, vals, counts = sh.result()
+        r1, c1, v1, n1 = _host.run_hip(call)
+        k = call.k
+        so.compare_topk(so.canonical(rows, cols, vals, call.targets, k), so.canonical(r1, c1, v1, call.targets, k), k, rtol=1e-6, atol=0, what="sharded vs single")
+        np.testing.assert_array_equal(counts, n1)
+        want = so.canonical(*so.run_kernel(call, "port"), call.targets, k)
+        so.compare_topk(so.canonical(rows, cols, vals, call.targets, k), want, k, rtol=1e-5, atol=1e-7, what="sharded vs oracle")
+        # hip_compute() defaults to the rank's own device (ADVICE r1), and sharded_knn puts its gather tensors there
+        out = D.sharded_knn(call, D.hip_compute())
+        np.testing.assert_array_equal(out[3], n1)
+    finally:
+        dist.destroy_process_group()

@@ -1,8 +1,15 @@
-"""GPU tier, BASELINE.json configs[1] at FULL size (cosine, 1M x 100k, 64 nnz/row, k=100).
+"""GPU tier: every BASELINE.json config at its defining shape.
 
-The oracle cannot finish 1M rows in seconds, so the full result is checked through size-independent
-properties of cosine similarity, and a random sample of rows is compared with the oracle exactly
-(tie-aware, 1e-5 relative)."""
+  configs[0]  sim.cosine on sps.random 10k x 20k d=0.01 k=50            every row vs the oracle
+  configs[1]  cosine 1M x 100k, 64 nnz/row, k=100                        properties over all rows + 300 rows vs the oracle
+  configs[2]  s_plus(l1=.5, l2=.5, shrink=10) on the same matrix         300 rows vs the oracle, all rows on the sparse kernel
+  configs[3]  p3alpha + rp3beta, MovieLens-32M-shaped URM.T, k=200       through the public wrappers; 320 rows (the 20 heaviest
+                                                                         included) vs the oracle
+  configs[4]  dot_product(urm, W.T, filter_cols=urm), 1M users, k=100    300 rows vs the oracle + "nothing seen is recommended"
+                                                                         over all rows (one GPU's slice of the 10M-user job)
+
+The oracle cannot finish these sizes in seconds, so full results are checked through size-independent properties and a
+sample of rows is compared with the oracle exactly (tie-aware, 1e-5 relative; long float32 sums: see `_rtol_for`)."""
 from __future__ import annotations
 
 import copy
@@ -11,27 +18,95 @@ from pathlib import Path
 
 import numpy as np
 import pytest
+import scipy.sparse as sp
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
-from bench import fixed_degree_csr                     # noqa: E402  (the canonical C2 generator)
+import similaripy_amd as sim                            # noqa: E402
 from oracle import splus_oracle as so                  # noqa: E402
-from similaripy_amd import _host                       # noqa: E402
+from similaripy_amd import _host, workloads            # noqa: E402
+from similaripy_amd.normalization import normalize     # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
+RTOL, ATOL = 1e-5, 1e-7       # north_star: float32 values within 1e-5 relative
+
+
+def _rtol_for(n_terms: int) -> float:
+    """Tolerance of a value that is a float32 sum of `n_terms` products added in a DIFFERENT order than the oracle's
+    (LDS atomics vs a sequential loop): 1e-5 plus the random-walk rounding of both sums, 2 * sqrt(n) * 2^-24.
+    Rows of a few thousand products stay at 1e-5; an item with 10^5 ratings gets ~5e-5."""
+    return RTOL + 2.0 * np.sqrt(float(n_terms)) * 2.0 ** -24
+
+
+def _slots_from_csr(res: sp.csr_array, rows):
+    out = []
+    for t in rows:
+        c = res.indices[res.indptr[t]:res.indptr[t + 1]]
+        v = res.data[res.indptr[t]:res.indptr[t + 1]]
+        o = np.argsort(c, kind="stable")
+        out.append((c[o].astype(np.int32), v[o].astype(np.float32)))
+    return out
+
+
+def _slots_from_flat(cols, vals, counts, k, rows):
+    out = []
+    for t in rows:
+        n = int(counts[t])
+        c, v = cols[t * k: t * k + n], vals[t * k: t * k + n]
+        o = np.argsort(c, kind="stable")
+        out.append((c[o], v[o]))
+    return out
+
+
+def _oracle_slots(call, sample, drop_zeros=False):
+    sub = copy.copy(call)
+    sub.targets = np.ascontiguousarray(sample, dtype=np.int32)
+    want = so.canonical(*so.run_kernel(sub, "port"), sub.targets, call.k)
+    if drop_zeros:      # CSR output: genuine zeros are removed (s_plus.pyx:424)
+        want = [(c[v != 0], v[v != 0]) for c, v in want]
+    return want
+
+
+# ------------------------------------------------------------------------------------------------------------
+# configs[0]
+# ------------------------------------------------------------------------------------------------------------
+def test_config0_cosine_sps_random_all_rows():
+    m = workloads.c1_matrix()
+    assert m.shape == (10_000, 20_000)
+    call = _host.prepare(m, k=50, l2=1, c1=0.5, c2=0.5)
+    rows, cols, vals, counts = _host.run_hip(call)
+    got = so.canonical(rows, cols, vals, call.targets, 50)
+    want = so.canonical(*so.run_kernel(call, "port"), call.targets, 50)
+    so.compare_topk(got, want, 50, rtol=RTOL, atol=ATOL, what="C1")
+    # ... and through the public wrapper, the reference tests' comparator (check_sum, tests/test_similarity.py:8-14)
+    res = sim.cosine(m, k=50, verbose=False, format_output="csr")
+    assert res.shape == (10_000, 10_000) and res.dtype == np.float32
+    ref = sp.csr_array((np.concatenate([v for _, v in want]), np.concatenate([c for c, _ in want]),
+                        np.concatenate(([0], np.cumsum([c.shape[0] for c, _ in want])))), shape=res.shape)
+    cs = lambda x: float(np.sum(np.asarray(x.sum(axis=1), dtype=np.float64).ravel() ** 2))  # noqa: E731
+    np.testing.assert_allclose(cs(res), cs(ref), rtol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# configs[1] and configs[2]: one matrix
+# ------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def c2_matrix():
+    return workloads.fixed_degree_csr(1_000_000, 100_000, 64, 12345)
+
 
 @pytest.fixture(scope="module")
-def c2():
-    m = fixed_degree_csr(1_000_000, 100_000, 64, 12345)
+def c2(c2_matrix):
+    m = c2_matrix
     call = _host.prepare(m, k=100, l2=1, c1=0.5, c2=0.5)
-    rows, cols, vals, counts = _host.run_hip(call)
-    return m, call, rows.reshape(-1, 100), cols.reshape(-1, 100), vals.reshape(-1, 100), counts
+    rows, cols, vals, counts, info = _host.run_hip(call, time_kernel=True)
+    return m, call, rows.reshape(-1, 100), cols.reshape(-1, 100), vals.reshape(-1, 100), counts, info
 
 
-def test_full_size_properties(c2):
-    m, call, rows, cols, vals, counts = c2
+def test_config1_full_size_properties(c2):
+    m, call, rows, cols, vals, counts, info = c2
     n, k = 1_000_000, 100
     # every row has far more than k candidates (~40k): all slots are used, no padding
     assert counts.min() == k and counts.max() == k
@@ -49,23 +124,125 @@ def test_full_size_properties(c2):
     srt = np.sort(cols[pick], axis=1)
     assert np.all(srt[:, 1:] != srt[:, :-1])
     # symmetry of cosine on m @ m.T: if j is in i's list with value v and i is in j's list, the values agree
-    i_idx = pick[:2000]
-    for i in i_idx[:200]:
+    for i in pick[:200]:
         for j, v in zip(cols[i, :5], vals[i, :5]):
             hit = np.flatnonzero(cols[j] == i)
             if hit.size:
                 assert abs(vals[j, hit[0]] - v) <= 1e-5 * max(abs(v), 1e-12)
+    # the headline shape runs on the sparse (bitmap) kernel, nothing handed to the generic one
+    ph = info["phase_cycles"]
+    assert ph[9] == n and ph[10] == 0, (ph[9], ph[10])
 
 
-def test_full_size_sample_vs_oracle(c2):
-    m, call, rows, cols, vals, counts = c2
+def test_config1_sample_vs_oracle(c2):
+    m, call, rows, cols, vals, counts, info = c2
     k = 100
     sample = np.sort(np.random.default_rng(1).choice(1_000_000, 300, replace=False)).astype(np.int32)
-    sub = copy.copy(call)
-    sub.targets = sample
-    want = so.canonical(*so.run_kernel(sub, "port"), sample, k)
-    got = []
-    for t in sample:
-        o = np.argsort(cols[t], kind="stable")
-        got.append((cols[t][o], vals[t][o]))
-    so.compare_topk(got, want, k, rtol=1e-5, atol=1e-7, what="C2 sample")
+    want = _oracle_slots(call, sample)
+    got = _slots_from_flat(cols.ravel(), vals.ravel(), counts, k, sample)
+    so.compare_topk(got, want, k, rtol=RTOL, atol=ATOL, what="C2 sample")
+
+
+def test_config2_splus_hybrid_full_size(c2_matrix):
+    """s_plus (tversky + cosine hybrid, stabilized shrink 10) on the 1M x 100k matrix: the GENERAL variant of the sparse
+    kernel (survivor pool + judge) at its defining shape."""
+    m = c2_matrix
+    n, k = 1_000_000, 100
+    call = _host.prepare(m, k=k, l1=0.5, l2=0.5, stabilized_shrink=10.0)
+    rows, cols, vals, counts, info = _host.run_hip(call, time_kernel=True)
+    ph = info["phase_cycles"]
+    assert ph[9] == n and ph[10] == 0, f"rows on the sparse kernel {ph[9]}, handed to the generic kernel {ph[10]}"
+    assert counts.min() == k and counts.max() == k
+    c2d, v2d = cols.reshape(n, k), vals.reshape(n, k)
+    assert c2d.min() >= 0 and c2d.max() < n and np.isfinite(v2d).all() and v2d.min() > 0
+    # hybrid of non-negative data with shrink: every value is below the unshrunk cosine's maximum of 1
+    assert v2d.max() < 1.0
+    # the row itself: xy = |x|^2, den = .5*|x|^2 + .5*|x|^2 + 10  ->  |x|^2 / (|x|^2 + 10), and it is the row's maximum
+    sq = np.add.reduceat(np.square(m.data, dtype=np.float32), m.indptr[:-1])
+    self_pos = (c2d == np.arange(n, dtype=np.int32)[:, None])
+    assert self_pos.sum(axis=1).min() == 1
+    np.testing.assert_allclose(v2d[self_pos], sq / (sq + np.float32(10.0)), rtol=2e-5)
+    sample = np.sort(np.random.default_rng(2).choice(n, 300, replace=False)).astype(np.int32)
+    want = _oracle_slots(call, sample)
+    got = _slots_from_flat(cols, vals, counts, k, sample)
+    so.compare_topk(got, want, k, rtol=RTOL, atol=ATOL, what="C3 sample")
+
+
+# ------------------------------------------------------------------------------------------------------------
+# configs[3]: p3alpha + rp3beta on the MovieLens-32M-shaped URM, item-item, k=200, public wrappers
+# ------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def c4():
+    urm = workloads.movielens_like_urm()
+    assert urm.shape == (200_948, 84_432) and urm.nnz == 32_000_204
+    m1 = urm.T.tocsr()
+    m1.sort_indices()
+    # the oracle's operands: the reference's own preprocessing (similarity.py:410-415, 477-483) in NumPy
+    m2 = m1.T.tocsr()
+    pop_m2 = np.asarray(m2.sum(axis=0)).ravel()
+    a = normalize(m1, norm="l1", axis=1)
+    a.data = np.power(a.data, 0.8)
+    b = normalize(m2, norm="l1", axis=1)
+    b.data = np.power(b.data, 0.8)
+    # sample: the 20 heaviest rows (most MACs: popular items, they reach nearly every column) + 300 random ones
+    nnz2 = np.diff(b.indptr).astype(np.int64)
+    per = nnz2[a.indices]
+    csum = np.concatenate(([0], np.cumsum(per)))
+    macs = csum[a.indptr[1:]] - csum[a.indptr[:-1]]
+    heavy = np.argsort(-macs)[:20]
+    rnd = np.random.default_rng(4).choice(m1.shape[0], 300, replace=False)
+    sample = np.unique(np.concatenate((heavy, rnd))).astype(np.int32)
+    return m1, a, b, pop_m2, sample, macs
+
+
+@pytest.mark.parametrize("name", ["p3alpha", "rp3beta"])
+def test_config3_p3_item_item_public_wrappers(c4, name):
+    m1, a, b, pop_m2, sample, macs = c4
+    k = 200
+    if name == "p3alpha":
+        res = sim.p3alpha(m1, alpha=0.8, k=k, verbose=False, format_output="csr")
+        call = _host.prepare(a, b, k=k, target_rows=sample)
+    else:
+        res = sim.rp3beta(m1, alpha=0.8, beta=0.4, k=k, verbose=False, format_output="csr")
+        call = _host.prepare(a, b, k=k, weight_depop_matrix2=pop_m2, p2=0.4, l3=1, target_rows=sample)
+    n = m1.shape[0]
+    assert res.shape == (n, n) and res.dtype == np.float32 and isinstance(res, sp.csr_array)
+    row_nnz = np.diff(res.indptr)
+    assert row_nnz.max() <= k and res.indices.min() >= 0 and res.indices.max() < n
+    assert np.isfinite(res.data).all() and res.data.min() > 0
+    # items nobody rated have no neighbours; every rated item reaches at least itself
+    rated = np.diff(m1.indptr) > 0
+    assert not row_nnz[~rated].any() and row_nnz[rated].min() >= 1
+    want = _oracle_slots(call, sample, drop_zeros=True)
+    got = _slots_from_csr(res, sample)
+    # per-row tolerance: a popular item's value is a sum of up to 10^5 float32 products in another order
+    n1 = np.diff(m1.indptr)
+    for g, w, t in zip(got, want, sample):
+        so.compare_topk([g], [w], k, rtol=_rtol_for(int(n1[t])), atol=1e-12, what=f"C4 {name} row {t} ({n1[t]} ratings, {macs[t]} MACs)")
+
+
+# ------------------------------------------------------------------------------------------------------------
+# configs[4]: user scoring with filter_cols=urm, one GPU's 1M-user slice of the 10M-user job
+# ------------------------------------------------------------------------------------------------------------
+def test_config4_user_scoring_with_seen_filter():
+    n_users, n_items, k = 1_000_000, 100_000, 100
+    urm = workloads.fixed_degree_csr(n_users, n_items, 64, 12345)
+    W = sim.cosine(urm[:200_000].T.tocsr(), k=100, verbose=False, format_output="csr")      # item-item model from a user subsample
+    assert W.shape == (n_items, n_items)
+    Wt = W.T.tocsr()
+    res = sim.dot_product(urm, Wt, k=k, filter_cols=urm, verbose=False, format_output="csr")
+    assert res.shape == (n_users, n_items) and res.dtype == np.float32
+    row_nnz = np.diff(res.indptr)
+    assert row_nnz.max() <= k and row_nnz.min() > 0
+    # nothing seen is recommended — over ALL rows (pattern product in chunks of 100k users)
+    pat = sp.csr_array((np.ones(urm.nnz, dtype=np.float32), urm.indices, urm.indptr), shape=urm.shape)
+    for lo in range(0, n_users, 100_000):
+        hi = lo + 100_000
+        assert res[lo:hi].multiply(pat[lo:hi]).nnz == 0, f"users {lo}..{hi}: a seen item was recommended"
+    # scores of non-negative data are positive and sorted sets are duplicate-free (spot check)
+    assert res.data.min() > 0
+    call = _host.prepare(urm, Wt, k=k, filter_cols=urm)
+    sample = np.sort(np.random.default_rng(5).choice(n_users, 300, replace=False)).astype(np.int32)
+    want = _oracle_slots(call, sample, drop_zeros=True)
+    got = _slots_from_csr(res, sample)
+    so.compare_topk(got, want, k, rtol=RTOL, atol=ATOL, what="C5 sample")

@@ -246,6 +246,18 @@ def test_library_refuses_bad_arguments():
     call.targets = np.array([0, 77], dtype=np.int32)   # out of range row id
     with pytest.raises(_abi.HipLibraryError):
         _host.run_hip(call)
+    # a hand-built CSR with a column id beyond the matrix / a decreasing indptr never reaches the device
+    import copy
+    bad = copy.copy(_host.prepare(m, k=5))
+    bad.m2_indices = bad.m2_indices.copy()
+    bad.m2_indices[3] = 10_000
+    with pytest.raises(_abi.HipLibraryError, match="out of range"):
+        _host.run_hip(bad)
+    bad = copy.copy(_host.prepare(m, k=5))
+    bad.m1_indptr = bad.m1_indptr.copy()
+    bad.m1_indptr[5] = bad.m1_indptr[6] + 1
+    with pytest.raises(_abi.HipLibraryError, match="indptr"):
+        _host.run_hip(bad)
 
 
 # ---------------------------------------------------------------------------------------------
