@@ -25,10 +25,19 @@ namespace {
 // selector is active (a per-row FILTER is: its columns are pre-marked in the collision bitmap and dropped at the scan).  Then the whole top-k runs on the raw dot: survivors go straight from the sweep into the
 // candidate buffer (no survivor pool, no judge phase), the running k-th raw dot IS the cutoff, and the epilogue is
 // applied to the k winners at write-out.
-template <int NT, bool U_LDS, bool MONO>
-__global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
+// CBMB: bytes of the collision bitmap (8192, or 4096 in the two-workgroups-per-CU shape); WIN: the columns may be cut into
+// two WINDOWS of `1 << nb_log2` columns each that are processed one after the other with an exact bitmap (instead of
+// one aliasing bitmap over all columns): per window sweep 1 / clear / sweep 2 stages / accumulate / drain, the candidate
+// buffer and the running cutoff carried from window to window (the buffer waits in the histogram area while the next
+// window's sweep 1 owns region A).  With a 2^19-bit bitmap (64 KiB) and 512 threads TWO workgroups share a CU, so the
+// dense phases of one row hide under the sweeps of another (BASELINE configs[1]: 1M columns = 2 windows).
+// (second launch bound = waves per SIMD: the two-workgroups-per-CU shape needs 2 x 8 waves on 4 SIMDs, i.e. <= 128 VGPRs)
+template <int NT, bool U_LDS, bool MONO, int CBMB = 8192, bool WIN = false>
+__global__ __launch_bounds__(NT, (WIN ? 4 : 1)) void sp_knn_sparse_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NW = NT / 64;
+    constexpr int CBM_BYTES = CBMB, PRE_BYTES = CBMB / 2;
+    static_assert(!WIN || U_LDS, "windows need the candidate buffer in LDS");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -39,7 +48,8 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
     //                     that its reads need no base add;  pre16[]: its per-word popcount prefix (rank of a marked column)
     // region A [.., +T*8) sweep 1: column bitmap (nb bits, from the start);
     //                     afterwards: [0,A/4) collision set, [A/4,A/2) survivor pool, [A/2,3A/4) member pool, [3A/4,A) candidate buffer U
-    // items[item_cap(NT)] {m2 byte offset, count, m1 value bits, flat start};  hist4[4][256] radix histograms
+    // items[item_cap(NT)] {m2 byte offset, count, m1 value bits, flat start};  hist4[4][256] radix histograms (between
+    //                     two windows of a row: the stash of the candidate buffer, <= STASH_CAP entries)
     // sh[32], ph[16]      scalars, phase timers
     unsigned char *cbm = smem;
     unsigned short *pre16 = (unsigned short *)(smem + CBM_BYTES);      // [CBM_BYTES/4] marked columns below each bitmap word
@@ -51,6 +61,8 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
     u64 *ph = (u64 *)(sh + 32);
     u64 *U = U_LDS ? (u64 *)(rA + (A_bytes / 4) * 3) : (p.gU + (size_t)blockIdx.x * (size_t)p.cap_s);
     const int cap = p.cap_s;
+    const int n_win = WIN ? p.n_win : 1;
+    constexpr int STASH_CAP = 512;
 
     const unsigned amask = (unsigned)((1u << (p.nb_log2 - 3)) - 1u) & ~3u;      // column -> byte of its bitmap word
     const int nb_bytes = 1 << (p.nb_log2 - 3);
@@ -121,12 +133,14 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
     }
     // m1 entry / m2 row bounds of segment `tid` of the current row (rows of this kernel have <= SORT_MAX <= NT entries)
     int my_r0 = 0, my_len = 0;
+    int my_sp = 0;         // WIN: position of the segment's first element of the second window
     float my_v = 0.f;
     if (dC.x >= 0 && tid < dC.w) {
         const int u = p.m1_indices[dC.z + tid];
         my_v = p.m1_data[dC.z + tid];
         my_r0 = p.m2_indptr[u];
         my_len = p.m2_indptr[u + 1] - my_r0;
+        if (WIN && n_win > 1) my_sp = p.m2_split[u];
     }
 
     for (;;) {
@@ -148,90 +162,34 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             nx_u = p.m1_indices[dN.z + tid];
             nx_v = p.m1_data[dN.z + tid];
         }
-        int nx_r0 = 0, nx_len = 0;
+        int nx_r0 = 0, nx_len = 0, nx_sp = 0;
 
-        if (tid == 0) { sh[SH_PCTR] = 0; sh[SH_MCTR] = 0; sh[SH_NITEMS] = 0; sh[SH_CNT] = 0; sh[SH_SEL] = -1; sh[SH_NEED] = 0; }
+        if (tid == 0) { sh[SH_PCTR] = 0; sh[SH_MCTR] = 0; sh[SH_NITEMS] = 0; sh[SH_CNT] = 0; sh[SH_SEL] = -1; sh[SH_NEED] = 0; sh[SH_WMACS] = 0; }
         // Segment order.  The heaviest segments (largest |m1 value|: each segment scales its m2 row by its own m1 value)
         // go first, so that the first stage of sweep 2 sees the large products and the running k-th value — the cutoff
         // of everything after — starts high.
-        int my_ib = 0, my_fs = 0;       // first item / flat start of segment `tid`
-        int n_items = 0;
         int4 dNN, wNN;
-        if (n1 <= 64) {
-            // One wave, one segment per lane, no barrier inside: the (up to) 8 largest |values| are found with 8 wave-max
-            // rounds; heavy segments first, the others behind, both in their original order (ballot + mbcnt); item and
-            // flat-start prefixes by one trip through LDS into position order and a DPP scan there.
-            if (tid < 64) {
-                const unsigned key = (tid < n1 && my_len > 0) ? ((__float_as_uint(my_v) & 0x7FFFFFFFu) | 1u) : 0u;   // 0 = no segment
-                unsigned rest = key, thr = 0u;
+        // n1 <= 64: one wave, one segment per lane: the (up to) 8 largest |values| are found with 8 wave-max rounds; heavy
+        // segments first, the others behind, both in their original order (ballot + mbcnt).  The order is the same for
+        // every window of the row.
+        unsigned seg_key = 0u;
+        int seg_pos = 0;
+        if (n1 <= 64 && tid < 64) {
+            seg_key = (tid < n1 && my_len > 0) ? ((__float_as_uint(my_v) & 0x7FFFFFFFu) | 1u) : 0u;   // 0 = no segment
+            unsigned rest = seg_key, thr = 0u;
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const unsigned mx = wave_max_u32(rest);
-                    if (mx != 0u) thr = mx;                    // uniform
-                    rest = (rest >= mx) ? 0u : rest;
-                }
-                const bool heavy = key != 0u && key >= thr;
-                const u64 H = __ballot(heavy), Lg = __ballot(key != 0u && !heavy);
-                const int pos = heavy ? mbcnt64(H) : __popcll(H) + mbcnt64(Lg);
-                const int nit = (my_len + ITEM - 1) / ITEM;
-                // Scratch (the items are written after it is read back).  The lanes of this wave talk to each other through
-                // it without a barrier: LDS executes a wave's accesses in order.  To the compiler that is one thread reading
-                // back its own store — for a lane without a segment it folded the read to the 0 just written there and lost
-                // the segment another lane had scattered to that position (rows whose m1 entries point at EMPTY m2 rows;
-                // found by scripts/fuzz_parity.py).  The wavefront-scope fences emit no instruction; they keep the
-                // compiler from forwarding a lane's own store across them.
-                int *scr = (int *)items;
-                scr[tid] = 0; scr[64 + tid] = 0;
-                if (key != 0u) { scr[pos] = nit; scr[64 + pos] = my_len; }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                const int nit_p = scr[tid], len_p = scr[64 + tid];
-                const int ib_incl = wave_incl_scan_dpp(nit_p), fs_incl = wave_incl_scan_dpp(len_p);
-                scr[128 + tid] = ib_incl - nit_p;
-                scr[192 + tid] = fs_incl - len_p;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                if (key != 0u) { my_ib = scr[128 + pos]; my_fs = scr[192 + pos]; }
-                if (tid == 63) sh[SH_NITEMS] = ib_incl;
+            for (int r = 0; r < 8; ++r) {
+                const unsigned mx = wave_max_u32(rest);
+                if (mx != 0u) thr = mx;                    // uniform
+                rest = (rest >= mx) ? 0u : rest;
             }
-            __syncthreads();
-            if (!p.static_sched) q_nn = sh[SH_QA];
-            load_desc(q_nn, dNN, wNN);
-            if (p.static_sched) q_nn += (int)gridDim.x;
-            n_items = sh[SH_NITEMS];
-            __syncthreads();                    // scratch read before the items overwrite it
-        } else {
-            // up to SORT_MAX entries: full descending order from one all-pairs pass spread over the whole workgroup:
-            // thread (seg, part) adds up the segments that precede `seg`
-            int *keyS = (int *)items, *lenS = keyS + SORT_MAX, *ibS = lenS + SORT_MAX, *fsS = ibS + SORT_MAX;
-            if (tid < SORT_MAX) { ibS[tid] = 0; fsS[tid] = 0; }
-            if (tid < n1) { keyS[tid] = (int)(__float_as_uint(my_v) & 0x7FFFFFFFu); lenS[tid] = my_len; }
-            __syncthreads();
-            if (!p.static_sched) q_nn = sh[SH_QA];
-            load_desc(q_nn, dNN, wNN);
-            if (p.static_sched) q_nn += (int)gridDim.x;
-            {
-                const int lg = (n1 <= 128) ? 7 : 8;       // segments padded to a power of two
-                const int seg = tid & ((1 << lg) - 1), part = tid >> lg, parts = NT >> lg;
-                if (seg < n1) {
-                    const int key = keyS[seg];
-                    int ib = 0, fs = 0;
-                    for (int j = part; j < n1; j += parts) {
-                        const int kj = keyS[j], lj = lenS[j];     // same address across the wave: broadcast reads
-                        const bool before = (kj > key) || (kj == key && j < seg);
-                        ib += before ? (lj + ITEM - 1) / ITEM : 0;
-                        fs += before ? lj : 0;
-                    }
-                    if (ib) atomicAdd(&ibS[seg], ib);
-                    if (fs) atomicAdd(&fsS[seg], fs);
-                }
-                if (tid < n1 && my_len > 0) atomicAdd(&sh[SH_NITEMS], (my_len + ITEM - 1) / ITEM);
-            }
-            __syncthreads();
-            if (tid < n1) { my_ib = ibS[tid]; my_fs = fsS[tid]; }
-            n_items = sh[SH_NITEMS];
-            __syncthreads();                    // scratch read before the items overwrite it
+            const bool heavy = seg_key != 0u && seg_key >= thr;
+            const u64 H = __ballot(heavy), Lg = __ballot(seg_key != 0u && !heavy);
+            seg_pos = heavy ? mbcnt64(H) : __popcll(H) + mbcnt64(Lg);
         }
-        bool failed = (n_items >= ICAP) || (n_items > 63 * NW);      // (a wave keeps its <= 63 item descriptors in one register)
-        PHASE_END(PH_SETUP);
+        bool failed = false;
+        float seen_before = 0.f;      // products of the windows already done
+        int n_stash = 0;              // candidate-buffer entries waiting in the histogram area between two windows
 
         RowCtx rc;
         rc.have_thr = false;
@@ -269,13 +227,96 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             if (p.target_mode == SP_SEL_MATRIX) { rc.g0 = __builtin_amdgcn_readfirstlane(p.t_indptr[t]); rc.g1 = __builtin_amdgcn_readfirstlane(p.t_indptr[t + 1]); }
         }
 
+
+        for (int win = 0; win < n_win && !failed; ++win) {
+        // ---- this window's piece of segment `tid` (one window: the whole m2 row) ----
+        int pr0 = my_r0, plen = my_len;
+        if (WIN && n_win > 1) {
+            if (win == 0) plen = my_sp - my_r0;
+            else { pr0 = my_sp; plen = my_r0 + my_len - my_sp; }
+        }
+        // columns of this window: [wlo, wlo + wspan)
+        const unsigned wlo = (WIN && win > 0) ? (1u << p.nb_log2) : 0u;
+        const unsigned wspan = (WIN && n_win > 1 && win == 0) ? (1u << p.nb_log2) : 0xFFFFFFFFu;
+        int my_ib = 0, my_fs = 0;       // first item / flat start of segment `tid`
+        int n_items = 0;
+        int win_macs = 0;               // products of this window
+        if (n1 <= 64) {
+            // item and flat-start prefixes by one trip through LDS into position order and a DPP scan there, no barrier inside
+            if (tid < 64) {
+                const int nit = (plen + ITEM - 1) / ITEM;
+                // Scratch (the items are written after it is read back).  The lanes of this wave talk to each other through
+                // it without a barrier: LDS executes a wave's accesses in order.  To the compiler that is one thread reading
+                // back its own store — for a lane without a segment it folded the read to the 0 just written there and lost
+                // the segment another lane had scattered to that position (rows whose m1 entries point at EMPTY m2 rows;
+                // found by scripts/fuzz_parity.py).  The wavefront-scope fences emit no instruction; they keep the
+                // compiler from forwarding a lane's own store across them.
+                int *scr = (int *)items;
+                scr[tid] = 0; scr[64 + tid] = 0;
+                if (seg_key != 0u) { scr[seg_pos] = nit; scr[64 + seg_pos] = plen; }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                const int nit_p = scr[tid], len_p = scr[64 + tid];
+                const int ib_incl = wave_incl_scan_dpp(nit_p), fs_incl = wave_incl_scan_dpp(len_p);
+                scr[128 + tid] = ib_incl - nit_p;
+                scr[192 + tid] = fs_incl - len_p;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if (seg_key != 0u) { my_ib = scr[128 + seg_pos]; my_fs = scr[192 + seg_pos]; }
+                if (tid == 63) { sh[SH_NITEMS] = ib_incl; sh[SH_WMACS] = fs_incl; }
+            }
+            __syncthreads();
+            if (win == 0) {
+                if (!p.static_sched) q_nn = sh[SH_QA];
+                load_desc(q_nn, dNN, wNN);
+                if (p.static_sched) q_nn += (int)gridDim.x;
+            }
+            n_items = sh[SH_NITEMS];
+            win_macs = sh[SH_WMACS];
+            __syncthreads();                    // scratch read before the items overwrite it
+        } else {
+            // up to SORT_MAX entries: full descending order from one all-pairs pass spread over the whole workgroup:
+            // thread (seg, part) adds up the segments that precede `seg`
+            int *keyS = (int *)items, *lenS = keyS + SORT_MAX, *ibS = lenS + SORT_MAX, *fsS = ibS + SORT_MAX;
+            if (tid < SORT_MAX) { ibS[tid] = 0; fsS[tid] = 0; }
+            if (tid < n1) { keyS[tid] = (int)(__float_as_uint(my_v) & 0x7FFFFFFFu); lenS[tid] = plen; }
+            __syncthreads();
+            if (win == 0) {
+                if (!p.static_sched) q_nn = sh[SH_QA];
+                load_desc(q_nn, dNN, wNN);
+                if (p.static_sched) q_nn += (int)gridDim.x;
+            }
+            {
+                const int lg = (n1 <= 128) ? 7 : 8;       // segments padded to a power of two
+                const int seg = tid & ((1 << lg) - 1), part = tid >> lg, parts = NT >> lg;
+                if (seg < n1) {
+                    const int key = keyS[seg];
+                    int ib = 0, fs = 0;
+                    for (int j = part; j < n1; j += parts) {
+                        const int kj = keyS[j], lj = lenS[j];     // same address across the wave: broadcast reads
+                        const bool before = (kj > key) || (kj == key && j < seg);
+                        ib += before ? (lj + ITEM - 1) / ITEM : 0;
+                        fs += before ? lj : 0;
+                    }
+                    if (ib) atomicAdd(&ibS[seg], ib);
+                    if (fs) atomicAdd(&fsS[seg], fs);
+                }
+                if (tid < n1 && plen > 0) { atomicAdd(&sh[SH_NITEMS], (plen + ITEM - 1) / ITEM); atomicAdd(&sh[SH_WMACS], plen); }
+            }
+            __syncthreads();
+            if (tid < n1) { my_ib = ibS[tid]; my_fs = fsS[tid]; }
+            n_items = sh[SH_NITEMS];
+            win_macs = sh[SH_WMACS];
+            __syncthreads();                    // scratch read before the items overwrite it
+        }
+        failed = failed || (n_items >= ICAP) || (n_items > 63 * NW);      // (a wave keeps its <= 63 item descriptors in one register)
+        PHASE_END(PH_SETUP);
+
         if (!failed) {
             // sentinel item behind the last one: a prefetch past the end loads nothing (every lane out of range)
-            if (tid == NT - 1) items[n_items] = make_int4((int)OOB_SOFFSET, 0, 0, (int)macs32);
+            if (tid == NT - 1) items[n_items] = make_int4((int)OOB_SOFFSET, 0, 0, win_macs);
             if (tid < n1) {
                 int q = 0;
-                for (int o = 0; o < my_len; o += ITEM, ++q)
-                    items[my_ib + q] = make_int4((my_r0 + o) * 4, min(ITEM, my_len - o), (int)__float_as_uint(my_v), my_fs + o);
+                for (int o = 0; o < plen; o += ITEM, ++q)
+                    items[my_ib + q] = make_int4((pr0 + o) * 4, min(ITEM, plen - o), (int)__float_as_uint(my_v), my_fs + o);
             }
             __syncthreads();
             PHASE_END(PH_SEGMENTS);
@@ -355,16 +396,17 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     const int f0 = __builtin_amdgcn_readfirstlane(p.f_indptr[t]), f1 = __builtin_amdgcn_readfirstlane(p.f_indptr[t + 1]);
                     for (int i = f0 + tid; i < f1; i += NT) {
                         const unsigned c = (unsigned)p.f_indices[i];
-                        atomicOr((unsigned *)(cbm + ((c >> 3) & cmask)), 1u << (c & 31u));
+                        if (c - wlo < wspan) atomicOr((unsigned *)(cbm + ((c >> 3) & cmask)), 1u << (c & 31u));     // (this window's columns)
                     }
                 }
             }
             __syncthreads();
             PHASE_END(PH_SWEEP1);
             // next row's m2 row bounds (its m1 entries were requested at the top of this row)
-            if (dN.x >= 0 && tid < dN.w) {
+            if (win == 0 && dN.x >= 0 && tid < dN.w) {
                 nx_r0 = p.m2_indptr[nx_u];
                 nx_len = p.m2_indptr[nx_u + 1] - nx_r0;
+                if (WIN && n_win > 1) nx_sp = p.m2_split[nx_u];
             }
             // the bitmap has done its job: back to zero (16-byte stores); its storage now serves sweep 2
             for (int i = tid; i < (nb_bytes >> 4); i += NT) ((int4 *)rA)[i] = make_int4(0, 0, 0, 0);
@@ -399,11 +441,19 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 }
                 if (carry > CSN / 2) failed = true;      // more marked columns than direct slots (uniform)
             }
+            if (WIN && win > 0) {
+                // the candidate buffer comes back from the histogram area (which goes back to zero)
+                u64 *stash = (u64 *)hist4;
+                for (int i = tid; i < n_stash; i += NT) { U[i] = stash[i]; stash[i] = 0ull; }
+                if (tid == 0) sh[SH_CNT] = n_stash;
+                __syncthreads();
+            }
             PHASE_END(PH_SEGMENTS);  // (bitmap clear)
-        } else {
+        } else if (win == 0) {
             if (dN.x >= 0 && tid < dN.w) {
                 nx_r0 = p.m2_indptr[nx_u];
                 nx_len = p.m2_indptr[nx_u + 1] - nx_r0;
+                if (WIN && n_win > 1) nx_sp = p.m2_split[nx_u];
             }
         }
 
@@ -418,11 +468,20 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             // k*m/n of the next m would survive in an exchangeable stream — far fewer here, because segments come
             // in descending weight — so the next chunk may be 4*n*(cap-k)/k long.
             const int room = cap - min(p.k, cap - 1);
+            const bool final_win = (win == n_win - 1);
             int i0 = 0;
             int chunk_items = max(1, (MONO ? room : min(room, spcap - 2 * ITEM)) / ITEM);     // items of the next stage
+            if (WIN && win > 0 && rc.have_thr) {
+                // a later window starts with the cutoff of the earlier ones: sized like any later stage (see the end of the loop)
+                const float left = (float)max(64, cap - min(n_stash, cap));
+                const float cnt_u = (float)max(2 * p.k, min(n_stash, cap));
+                float ch = fmaxf((float)ITEM, 2.f * seen_before * left / cnt_u);
+                if (!MONO) ch = fmaxf(ch, (float)room);
+                chunk_items = max(1, (int)fminf(ch * (1.f / ITEM), 1e6f));
+            }
             bool last_stage = false;
             bool force_sel = false;
-            WavePool wpm{0, -1};      // member-pool window: lives across the stages of the row
+            WavePool wpm{0, -1};      // member-pool window: lives across the stages of the window
 
             // ---- MONO, first stage without any selection.  One item per wave (the first NW items: the heaviest
             // segments).  Every wave finds, among the per-lane maxima of its single products, the m-th largest
@@ -433,8 +492,8 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             // in fewer items, select afterwards"). ----
             if constexpr (MONO) {
                 const int NA = min(n_items, NW);
-                const int mrounds = (p.k + NA - 1) / NA + 2;
-                if (NA == NW && mrounds <= 16) {     // (k <= 14*NW; larger k: the accept-everything first stage of the loop below)
+                const int mrounds = (p.k + NW - 1) / NW + 2;
+                if (win == 0 && NA == NW && mrounds <= 16) {     // (k <= 14*NW; larger k: the accept-everything first stage of the loop below)
                     unsigned c[4];
                     float v[4], x[4];
                     u64 M[4], S[4];
@@ -449,7 +508,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                         const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs_val, vo, off, 0);
                         c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w;
                         v[0] = __uint_as_float(b.x); v[1] = __uint_as_float(b.y); v[2] = __uint_as_float(b.z); v[3] = __uint_as_float(b.w);
-                        s2_core(c, v, segv, cutx, x, M, S);
+                        s2_core<CBMB>(c, v, segv, cutx, x, M, S);
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -581,7 +640,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                         __builtin_amdgcn_s_setprio(3);
                         float x[4];
                         u64 M[4], S[4];
-                        s2_core(c, v, segv, cut, x, M, S);
+                        s2_core<CBMB>(c, v, segv, cut, x, M, S);
                         if (cnt != ITEM) {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
@@ -817,7 +876,9 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     // selection: forced when U overflowed; exact after the last stage (final top-k); between stages
                     // when U is filling up (it raises the running k-th value, which is the cutoff of the next stage)
                     const int n_eff = min(n_now, cap);
-                    const bool want_sel = retry || (last_stage ? (n_eff > p.k) : (n_eff > p.k && (!rc.have_thr || force_sel || 2 * n_eff > cap + p.k)));
+                    // (the last stage of a window that is not the row's last: the buffer must fit the stash and carry a cutoff)
+                    const bool want_sel = retry || ((last_stage && final_win) ? (n_eff > p.k)
+                                                   : (n_eff > p.k && (!rc.have_thr || force_sel || 2 * n_eff > cap + p.k || (last_stage && n_eff > STASH_CAP))));
                     force_sel = false;
                     if (want_sel) {
                         long long thr_new;
@@ -844,7 +905,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 // next chunk: with the k-th best of `pos` products as cutoff, an exchangeable stream lets k*m/pos of the
                 // next m products through; keep that below half of the room left in U (far fewer pass when the
                 // segments come in descending weight)
-                const float pos = (i0 < n_items) ? (float)items[i0].w : (float)macs32;
+                const float pos = seen_before + (float)items[min(i0, n_items)].w;      // (the sentinel holds the window's total)
                 const float left = (float)max(64, cap - min(sh[SH_CNT], cap));
                 // (the cutoff is the value that `cnt` of the `pos` products offered so far reach: cnt ~ k after a selection, more
                 // after the selection-free first stage)
@@ -854,6 +915,32 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 chunk_items = max(1, (int)fminf(ch * (1.f / ITEM), 1e6f));
             }
         }
+
+        if constexpr (MONO) {
+            if (!failed && p.filter_mode == SP_SEL_MATRIX) {      // marks of this window's excluded columns that no product reached
+                const int f0 = __builtin_amdgcn_readfirstlane(p.f_indptr[t]), f1 = __builtin_amdgcn_readfirstlane(p.f_indptr[t + 1]);
+                for (int i = f0 + tid; i < f1; i += NT) {
+                    const unsigned c = (unsigned)p.f_indices[i];
+                    if (c - wlo < wspan) atomicAnd((unsigned *)(cbm + ((c >> 3) & cmask)), ~(1u << (c & 31u)));
+                }
+            }
+        }
+        if (WIN && win < n_win - 1) {
+            // between two windows: region A becomes the next window's bitmap, the candidates wait in the histogram area
+            __syncthreads();
+            if (!failed) {
+                n_stash = min(sh[SH_CNT], cap);
+                if (n_stash > STASH_CAP) failed = true;      // (cannot happen: the window's last stage selects down to k <= STASH_CAP)
+                else {
+                    u64 *stash = (u64 *)hist4;
+                    for (int i = tid; i < n_stash; i += NT) { stash[i] = U[i]; U[i] = 0ull; }
+                }
+                seen_before += (float)win_macs;
+            }
+            if (tid == 0) { sh[SH_PCTR] = 0; sh[SH_MCTR] = 0; sh[SH_NITEMS] = 0; sh[SH_WMACS] = 0; sh[SH_CNT] = 0; }
+            __syncthreads();
+        }
+        }      // windows
 
         if (!failed) {
             // ================= write-out =================
@@ -909,15 +996,6 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 }
             }
             if (tid == 0 && p.counts) p.counts[slot_i] = n_out;
-            if constexpr (MONO) {
-                if (p.filter_mode == SP_SEL_MATRIX) {      // marks of excluded columns that no product reached
-                    const int f0 = __builtin_amdgcn_readfirstlane(p.f_indptr[t]), f1 = __builtin_amdgcn_readfirstlane(p.f_indptr[t + 1]);
-                    for (int i = f0 + tid; i < f1; i += NT) {
-                        const unsigned c = (unsigned)p.f_indices[i];
-                        atomicAnd((unsigned *)(cbm + ((c >> 3) & cmask)), ~(1u << (c & 31u)));
-                    }
-                }
-            }
             if (U_LDS || MONO) {
                 // U's storage is part of the next row's bitmap (LDS) / holes must read zero (MONO).  Every selection zeroes
                 // what lies behind the entries it keeps, so only the first k entries can be non-zero here.
@@ -947,7 +1025,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                        __builtin_amdgcn_readfirstlane(dNN.z), __builtin_amdgcn_readfirstlane(dNN.w));
         wN = make_int4(__builtin_amdgcn_readfirstlane(wNN.x), __builtin_amdgcn_readfirstlane(wNN.y),
                        __builtin_amdgcn_readfirstlane(wNN.z), __builtin_amdgcn_readfirstlane(wNN.w));
-        my_r0 = nx_r0; my_len = nx_len; my_v = nx_v;
+        my_r0 = nx_r0; my_len = nx_len; my_v = nx_v; my_sp = nx_sp;
         __syncthreads();
         PHASE_END(PH_OUTPUT);
     }
