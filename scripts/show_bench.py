@@ -1,14 +1,18 @@
-"""Pretty-print a bench.py JSON line from stdin: rate, roofline fraction and per-row cycles by phase."""
-import json, sys
+"""Compact view of bench.py JSON lines (stdin): kernel time and cycles per row by phase."""
+import json
+import sys
+
 for line in sys.stdin:
     line = line.strip()
     if not line.startswith("{"):
         continue
     d = json.loads(line)
-    ph = d["config"]["phase_share"]
-    rows_per_wg = d["config"]["rows_per_gpu"] / 256.0
-    cyc_row = ph["cycles_per_wg"] / rows_per_wg
-    print(f"{d['roofline']['kernel_ms_avg']:.1f} ms  {d['value']/1e6:.2f} M rows/s  frac {d['roofline']['frac']:.3f}  cycles/row {cyc_row:.0f}")
-    names = ("setup", "segments", "accumulate", "drain", "select", "output", "sweep1", "sweep2", "csdrain")
-    print("  " + "  ".join(f"{n}={ph[n]*cyc_row:.0f}" for n in names))
-    print(f"  sparse rows {ph['rows_sparse_path']}  fallback {ph['rows_fallback_cs_full']}  generic windows {ph['generic_windows']}")
+    r, cfg = d["roofline"], d["config"]
+    ps = cfg["phase_share"]
+    rows = max(1, cfg.get("rows_per_gpu", 1))
+    wgs_cycles = ps["cycles_per_wg"]
+    names = ("setup", "segments", "sweep1", "sweep2", "accumulate", "drain", "select", "output")
+    tot_share = sum(ps[n] for n in names) or 1.0
+    print(f"kernel {r['kernel_ms_avg']:.2f} ms  frac {r['frac']:.3f}  step {d['ms_per_step']:.2f} ms  value {d['value']:.3e}  "
+          f"cycles/wg {wgs_cycles:.3e}  " + " ".join(f"{n}={ps[n]:.3f}" for n in names) +
+          f"  sparse_rows={ps['rows_sparse_path']} fallback={ps['rows_fallback_cs_full']}")

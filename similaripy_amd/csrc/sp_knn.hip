@@ -149,10 +149,10 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
     const bool small_rows = avg_macs * avg_macs / (2.0 * std::max(1, std::min(a->n_output_cols, 1 << 18))) <= 0.25 * 1024.0;
     bool duo = false;
     int n_win = 1;
-    const bool tune_free = !a->threads_per_wg && !a->table_slots && !(a->flags & SP_FLAG_NO_DUO);
+    const bool tune_free = !a->threads_per_wg && !a->table_slots;
     if (tune_free && (long long)a->k + 512 <= (long long)SEL_E * 256 && small_rows) {
         NT_s = 256; T_s = 4096; logT_s = 12;
-    } else if (tune_free && a->k <= 448 && a->n_output_cols > (1 << 18) && a->n_output_cols <= (1 << 20)) {
+    } else if (tune_free && (a->flags & SP_FLAG_DUO) && a->k <= 448 && a->n_output_cols > (1 << 18) && a->n_output_cols <= (1 << 20)) {
         // Heavier rows over up to 2^20 columns: TWO 512-thread workgroups per CU (78 KB of LDS each), each with an EXACT
         // 2^19-bit column bitmap over one WINDOW of the columns at a time — two windows when there are more than 2^19
         // columns — so that the dense phases of one row hide under the sweeps of another (BASELINE configs[1]).

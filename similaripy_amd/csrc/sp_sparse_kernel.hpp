@@ -63,6 +63,16 @@ __global__ __launch_bounds__(NT, (WIN ? 4 : 1)) void sp_knn_sparse_kernel(const 
     const int cap = p.cap_s;
     const int n_win = WIN ? p.n_win : 1;
     constexpr int STASH_CAP = 512;
+    // REGISTER-RESIDENT rows (MONO).  The sweeps are bound by the latency of their loads (two 1-KiB trips in flight per wave:
+    // a C2 row spent ~9 memory round trips of ~2 us in them) and sweep 2 read the column ids a second time.  A row whose
+    // waves own at most RR_MAX items each keeps its column ids in REGISTERS instead: every wave issues the id loads of all
+    // its items at once right after the items are known (RR_MAX x 4 registers per lane), sweep 1 runs out of registers, and
+    // sweep 2 — the selection-free first stage and ONE stage over everything else — re-uses them and fetches only the
+    // values, through a ring of RR_RING items that is filled for the first time while the bitmap is cleared:
+    // ids are read once (8 B per product instead of 12) and a row waits for ~2 round trips instead of ~9.
+    // The ids are dead before the dense phases (accumulate / drain / select), whose registers they could not share.
+    constexpr int RR_MAX = (MONO && U_LDS && NT == 1024 && !WIN) ? 0 : 0;
+    constexpr int RR_RING = 6;
 
     const unsigned amask = (unsigned)((1u << (p.nb_log2 - 3)) - 1u) & ~3u;      // column -> byte of its bitmap word
     const int nb_bytes = 1 << (p.nb_log2 - 3);
@@ -188,6 +198,18 @@ __global__ __launch_bounds__(NT, (WIN ? 4 : 1)) void sp_knn_sparse_kernel(const 
             seg_pos = heavy ? mbcnt64(H) : __popcll(H) + mbcnt64(Lg);
         }
         bool failed = false;
+        bool rr = false;              // this row runs register-resident
+        int rr_off = 0, rr_cnt = 0, rr_seg = 0;       // lane i: byte offset / count / m1 value bits of the wave's i-th item
+        u32x4 rr_ids[RR_MAX > 0 ? RR_MAX : 1];      // column ids of the wave's items
+        u32x4 rr_v0;                                // values of its first item (the first stage's)
+        u32x4 rr_ring[RR_RING];                     // values of the others, RR_RING in flight
+        // the 16-byte load of the wave's i-th item (i: compile-time constant); lanes beyond a partial item's end get an
+        // out-of-range offset and fetch nothing
+        auto rr_load = [&](const __amdgpu_buffer_rsrc_t &rs, int i) __attribute__((always_inline)) -> u32x4 {
+            const int off = __builtin_amdgcn_readlane(rr_off, i), cnt = __builtin_amdgcn_readlane(rr_cnt, i);
+            const int vo = (4 * lane < cnt) ? lane * 16 : (int)(OOB_SOFFSET - (unsigned)off);
+            return __builtin_amdgcn_raw_buffer_load_b128(rs, vo, off, 0);
+        };
         float seen_before = 0.f;      // products of the windows already done
         int n_stash = 0;              // candidate-buffer entries waiting in the histogram area between two windows
 
@@ -320,6 +342,19 @@ __global__ __launch_bounds__(NT, (WIN ? 4 : 1)) void sp_knn_sparse_kernel(const 
             }
             __syncthreads();
             PHASE_END(PH_SEGMENTS);
+            // (uniform; the register-resident flow is first stage + one stage: it needs the first stage, see there)
+            rr = RR_MAX > 0 && n_items <= RR_MAX * NW && n_items >= NW && (p.k + NW - 1) / NW + 2 <= 16;
+            if constexpr (RR_MAX > 0) {
+                if (rr) {
+                    // item wave + NW*i in lane i (beyond the wave's share: the sentinel, which loads nothing)
+                    const int mine = wave + NW * lane;
+                    const int4 d = items[(mine < n_items) ? mine : n_items];
+                    rr_off = d.x; rr_cnt = d.y; rr_seg = d.z;
+#pragma unroll
+                    for (int i = 0; i < RR_MAX; ++i) rr_ids[i] = rr_load(rs_idx, i);
+                    rr_v0 = rr_load(rs_val, 0);
+                }
+            }
             // ---- sweep 1: column ids only.  Branch-free: every product ORs its bit into the bitmap; the returned
             // word tells whether the column was there already, in which case (only then a non-zero operand) the
             // column's bit is ORed into the collision bitmap as well. ----
@@ -332,7 +367,7 @@ __global__ __launch_bounds__(NT, (WIN ? 4 : 1)) void sp_knn_sparse_kernel(const 
                 // a trip then gets its scalars with v_readlane instead of an LDS round trip.
                 // visited back to front: what sweep 1 reads last is what sweep 2 reads first (L2 still holds it)
                 const int n_mine = (n_items - wave + NW - 1) / NW;       // items wave, wave+NW, ...
-                const int4 myd = items[(lane < n_mine) ? wave + NW * (n_mine - 1 - lane) : n_items];
+                const int4 myd = (RR_MAX > 0 && rr) ? make_int4(0, 0, 0, 0) : items[(lane < n_mine) ? wave + NW * (n_mine - 1 - lane) : n_items];
                 // a trip = two items (eight columns per lane): twice the loads and twice the LDS atomics in flight per wait
                 auto ld = [&](int trip, unsigned (&c)[8], int &cnt0, int &cnt1) __attribute__((always_inline)) {
                     const int t0 = min(2 * trip, 63), t1 = min(2 * trip + 1, 63);
@@ -373,19 +408,41 @@ __global__ __launch_bounds__(NT, (WIN ? 4 : 1)) void sp_knn_sparse_kernel(const 
                     }
                     __builtin_amdgcn_s_setprio(0);
                 };
-                unsigned cA[8], cB[8];
-                int nA0 = 0, nA1 = 0, nB0 = 0, nB1 = 0;
-                const int n_trips = (n_mine + 1) / 2;
-                int trip = 0;
-                ld(0, cA, nA0, nA1);
-                while (trip < n_trips) {      // two pairs (4 KiB) in flight per wave (a third measured slower); bodies skip the sentinel
-                    ld(trip + 1, cB, nB0, nB1);
-                    __builtin_amdgcn_sched_barrier(0);     // the prefetch is issued before the current pair is waited for
-                    body(cA, nA0, nA1);
-                    ld(trip + 2, cA, nA0, nA1);
-                    __builtin_amdgcn_sched_barrier(0);
-                    body(cB, nB0, nB1);
-                    trip += 2;
+                bool streamed = true;
+                if constexpr (RR_MAX > 0) {
+                    if (rr) {
+                        // register-resident: the ids are (arriving) in rr_ids, pairs of items as the core takes them
+                        streamed = false;
+#pragma unroll
+                        for (int q = 0; q < RR_MAX / 2; ++q) {
+                            const int cnt0 = __builtin_amdgcn_readlane(rr_cnt, 2 * q), cnt1 = __builtin_amdgcn_readlane(rr_cnt, 2 * q + 1);
+                            const unsigned c[8] = {rr_ids[2 * q].x, rr_ids[2 * q].y, rr_ids[2 * q].z, rr_ids[2 * q].w,
+                                                   rr_ids[2 * q + 1].x, rr_ids[2 * q + 1].y, rr_ids[2 * q + 1].z, rr_ids[2 * q + 1].w};
+                            body(c, cnt0, cnt1);
+                        }
+                    }
+                }
+                if (streamed) {
+                    unsigned cA[8], cB[8];
+                    int nA0 = 0, nA1 = 0, nB0 = 0, nB1 = 0;
+                    const int n_trips = (n_mine + 1) / 2;
+                    int trip = 0;
+                    ld(0, cA, nA0, nA1);
+                    while (trip < n_trips) {      // two pairs (4 KiB) in flight per wave (a third measured slower); bodies skip the sentinel
+                        ld(trip + 1, cB, nB0, nB1);
+                        __builtin_amdgcn_sched_barrier(0);     // the prefetch is issued before the current pair is waited for
+                        body(cA, nA0, nA1);
+                        ld(trip + 2, cA, nA0, nA1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        body(cB, nB0, nB1);
+                        trip += 2;
+                    }
+                }
+            }
+            if constexpr (RR_MAX > 0) {
+                if (rr) {      // values of items 1 .. RR_RING: they arrive while the bitmap is cleared and the first stage runs
+#pragma unroll
+                    for (int i = 1; i <= RR_RING; ++i) rr_ring[i - 1] = rr_load(rs_val, i);
                 }
             }
             if constexpr (MONO) {
@@ -503,9 +560,13 @@ __global__ __launch_bounds__(NT, (WIN ? 4 : 1)) void sp_knn_sparse_kernel(const 
                     {
                         const int off = __builtin_amdgcn_readfirstlane(d.x);
                         const float segv = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane(d.z));
-                        const int vo = (4 * lane < cntA) ? lane * 16 : (int)(OOB_SOFFSET - (unsigned)off);
-                        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, vo, off, 0);
-                        const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs_val, vo, off, 0);
+                        u32x4 a, b;
+                        if (RR_MAX > 0 && rr) { a = rr_ids[0]; b = rr_v0; }      // (item `wave` is the wave's own first item)
+                        else {
+                            const int vo = (4 * lane < cntA) ? lane * 16 : (int)(OOB_SOFFSET - (unsigned)off);
+                            a = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, vo, off, 0);
+                            b = __builtin_amdgcn_raw_buffer_load_b128(rs_val, vo, off, 0);
+                        }
                         c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w;
                         v[0] = __uint_as_float(b.x); v[1] = __uint_as_float(b.y); v[2] = __uint_as_float(b.z); v[3] = __uint_as_float(b.w);
                         s2_core<CBMB>(c, v, segv, cutx, x, M, S);
@@ -604,13 +665,101 @@ __global__ __launch_bounds__(NT, (WIN ? 4 : 1)) void sp_knn_sparse_kernel(const 
             if (i0 >= n_items && !failed && i0 > 0) {
                 // (all items went through the first stage: let the loop run its last-stage part with an empty sweep)
             }
+                float cut = 0.f;          // raw-dot cutoff of the running stage (set at its start)
+                WavePool wps{0, -1};      // survivor window of the running stage
+                auto body = [&](const unsigned (&c)[4], const float (&v)[4], int cnt, float segv) __attribute__((always_inline)) {
+                    if (cnt == 0) return;                  // sentinel (wave-uniform)
+#if SP_ABLATION
+                    if (p.dbg & 16) { asm volatile("" ::"v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); return; }   // ablation: loads only
+#endif
+                    // M: product of a marked column; S: otherwise the product is the only one of its column and
+                    // matters only if its raw dot can still enter the top-k (NaN stays: the exact judge drops it)
+                    __builtin_amdgcn_s_setprio(3);
+                    float x[4];
+                    u64 M[4], S[4];
+                    s2_core<CBMB>(c, v, segv, cut, x, M, S);
+                    if (cnt != ITEM) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const u64 ok = __ballot(4 * lane + j < cnt);
+                            M[j] &= ok;
+                            S[j] &= ok;
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) S[j] &= ~M[j];
+                    if ((M[0] | M[1]) | (M[2] | M[3])) {
+                        const int n0 = __popcll(M[0]), n1 = __popcll(M[1]), n2 = __popcll(M[2]), n3 = __popcll(M[3]);
+                        if (pool_reserve(wpm, n0 + n1 + n2 + n3, &sh[SH_MCTR], mpcap, &sh[SH_OVF])) {
+                            int pos = wpm.pos;
+                            lds_push64(M[0], __float_as_uint(x[0]), c[0] + 1u, pos, mpool_off); pos += n0;
+                            lds_push64(M[1], __float_as_uint(x[1]), c[1] + 1u, pos, mpool_off); pos += n1;
+                            lds_push64(M[2], __float_as_uint(x[2]), c[2] + 1u, pos, mpool_off); pos += n2;
+                            lds_push64(M[3], __float_as_uint(x[3]), c[3] + 1u, pos, mpool_off);
+                            wpm.pos = pos + n3;
+                        }
+                    }
+                    if ((S[0] | S[1]) | (S[2] | S[3])) {
+                        const int n0 = __popcll(S[0]), n1 = __popcll(S[1]), n2 = __popcll(S[2]), n3 = __popcll(S[3]);
+                        if constexpr (MONO) {
+                            // straight into the candidate buffer, keyed by the raw dot
+                            if (pool_reserve<16>(wps, n0 + n1 + n2 + n3, &sh[SH_CNT], cap, &sh[SH_OVF])) {     // small blocks: U is short of room
+                                int pos = wps.pos;
+                                if constexpr (U_LDS) {
+                                    lds_push64(S[0], c[0], fkey(x[0]), pos, u_off); pos += n0;
+                                    lds_push64(S[1], c[1], fkey(x[1]), pos, u_off); pos += n1;
+                                    lds_push64(S[2], c[2], fkey(x[2]), pos, u_off); pos += n2;
+                                    lds_push64(S[3], c[3], fkey(x[3]), pos, u_off);
+                                } else {
+                                    if ((S[0] >> lane) & 1ull) U[pos + mbcnt64(S[0])] = ((u64)fkey(x[0]) << 32) | (u64)c[0];
+                                    pos += n0;
+                                    if ((S[1] >> lane) & 1ull) U[pos + mbcnt64(S[1])] = ((u64)fkey(x[1]) << 32) | (u64)c[1];
+                                    pos += n1;
+                                    if ((S[2] >> lane) & 1ull) U[pos + mbcnt64(S[2])] = ((u64)fkey(x[2]) << 32) | (u64)c[2];
+                                    pos += n2;
+                                    if ((S[3] >> lane) & 1ull) U[pos + mbcnt64(S[3])] = ((u64)fkey(x[3]) << 32) | (u64)c[3];
+                                }
+                                wps.pos = pos + n3;
+                            }
+                        } else {
+                            if (pool_reserve(wps, n0 + n1 + n2 + n3, &sh[SH_PCTR], spcap, &sh[SH_OVF])) {
+                                int pos = wps.pos;
+                                lds_push64(S[0], __float_as_uint(x[0]), c[0] + 1u, pos, spool_off); pos += n0;
+                                lds_push64(S[1], __float_as_uint(x[1]), c[1] + 1u, pos, spool_off); pos += n1;
+                                lds_push64(S[2], __float_as_uint(x[2]), c[2] + 1u, pos, spool_off); pos += n2;
+                                lds_push64(S[3], __float_as_uint(x[3]), c[3] + 1u, pos, spool_off);
+                                wps.pos = pos + n3;
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_s_setprio(0);
+                };
+            if constexpr (RR_MAX > 0) {
+                // ---- register-resident rows: ONE stage over everything behind the first stage, ids from registers, values
+                // through the ring (its first fill has been in flight since the end of sweep 1) ----
+                if (rr && !failed && rc.have_thr && !force_sel && i0 == NW) {
+                    cut = MONO ? cutx : rc.xy_cut;
+#pragma unroll
+                    for (int i = 1; i < RR_MAX; ++i) {
+                        const int cnt = __builtin_amdgcn_readlane(rr_cnt, i);
+                        const float segv = __uint_as_float((unsigned)__builtin_amdgcn_readlane(rr_seg, i));
+                        const u32x4 vv = rr_ring[(i - 1) % RR_RING];
+                        const unsigned c[4] = {rr_ids[i].x, rr_ids[i].y, rr_ids[i].z, rr_ids[i].w};
+                        const float v[4] = {__uint_as_float(vv.x), __uint_as_float(vv.y), __uint_as_float(vv.z), __uint_as_float(vv.w)};
+                        body(c, v, cnt, segv);
+                        if (i + RR_RING < RR_MAX) rr_ring[(i - 1) % RR_RING] = rr_load(rs_val, i + RR_RING);
+                    }
+                    i0 = n_items;      // (the loop below runs its last-stage part with an empty sweep)
+                }
+            }
             while (!last_stage && !failed) {
                 // (force_sel: the first stage's cutoff is loose — far more than k products reached it: tighten it with a
                 // selection before sweeping on, i.e. run this round with an empty sweep)
                 const int i1 = (force_sel && i0 < n_items) ? i0 : min(n_items, i0 + chunk_items);
                 {
                     // ---- sweep 2 over items [i0, i1) ----
-                    WavePool wps{0, -1};
+                    wps = WavePool{0, -1};
+                    cut = MONO ? cutx : rc.xy_cut;
                     // item i0 + wave + NW*i of this stage in lane i (beyond the stage: the sentinel)
                     int4 myd;
                     {
@@ -629,89 +778,23 @@ __global__ __launch_bounds__(NT, (WIN ? 4 : 1)) void sp_knn_sparse_kernel(const 
                         c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w;
                         v[0] = __uint_as_float(b.x); v[1] = __uint_as_float(b.y); v[2] = __uint_as_float(b.z); v[3] = __uint_as_float(b.w);
                     };
-                    const float cut = MONO ? cutx : rc.xy_cut;
-                    auto body = [&](const unsigned (&c)[4], const float (&v)[4], int cnt, float segv) __attribute__((always_inline)) {
-                        if (cnt == 0) return;                  // sentinel (wave-uniform)
-#if SP_ABLATION
-                        if (p.dbg & 16) { asm volatile("" ::"v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); return; }   // ablation: loads only
-#endif
-                        // M: product of a marked column; S: otherwise the product is the only one of its column and
-                        // matters only if its raw dot can still enter the top-k (NaN stays: the exact judge drops it)
-                        __builtin_amdgcn_s_setprio(3);
-                        float x[4];
-                        u64 M[4], S[4];
-                        s2_core<CBMB>(c, v, segv, cut, x, M, S);
-                        if (cnt != ITEM) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const u64 ok = __ballot(4 * lane + j < cnt);
-                                M[j] &= ok;
-                                S[j] &= ok;
-                            }
+                    {
+                        unsigned cA[4], cB[4];
+                        float vA[4], vB[4];
+                        int nA = 0, nB = 0;
+                        float sA = 0.f, sB = 0.f;
+                        const int n_trips = (i1 - i0 - wave + NW - 1) / NW;
+                        int trip = 0;
+                        ld(0, cA, vA, nA, sA);
+                        while (trip < n_trips) {      // two items (4 KiB) in flight per wave; bodies skip the sentinel
+                            ld(trip + 1, cB, vB, nB, sB);
+                            __builtin_amdgcn_sched_barrier(0);     // the prefetch is issued before the current item is waited for
+                            body(cA, vA, nA, sA);
+                            ld(trip + 2, cA, vA, nA, sA);
+                            __builtin_amdgcn_sched_barrier(0);
+                            body(cB, vB, nB, sB);
+                            trip += 2;
                         }
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) S[j] &= ~M[j];
-                        if ((M[0] | M[1]) | (M[2] | M[3])) {
-                            const int n0 = __popcll(M[0]), n1 = __popcll(M[1]), n2 = __popcll(M[2]), n3 = __popcll(M[3]);
-                            if (pool_reserve(wpm, n0 + n1 + n2 + n3, &sh[SH_MCTR], mpcap, &sh[SH_OVF])) {
-                                int pos = wpm.pos;
-                                lds_push64(M[0], __float_as_uint(x[0]), c[0] + 1u, pos, mpool_off); pos += n0;
-                                lds_push64(M[1], __float_as_uint(x[1]), c[1] + 1u, pos, mpool_off); pos += n1;
-                                lds_push64(M[2], __float_as_uint(x[2]), c[2] + 1u, pos, mpool_off); pos += n2;
-                                lds_push64(M[3], __float_as_uint(x[3]), c[3] + 1u, pos, mpool_off);
-                                wpm.pos = pos + n3;
-                            }
-                        }
-                        if ((S[0] | S[1]) | (S[2] | S[3])) {
-                            const int n0 = __popcll(S[0]), n1 = __popcll(S[1]), n2 = __popcll(S[2]), n3 = __popcll(S[3]);
-                            if constexpr (MONO) {
-                                // straight into the candidate buffer, keyed by the raw dot
-                                if (pool_reserve<16>(wps, n0 + n1 + n2 + n3, &sh[SH_CNT], cap, &sh[SH_OVF])) {     // small blocks: U is short of room
-                                    int pos = wps.pos;
-                                    if constexpr (U_LDS) {
-                                        lds_push64(S[0], c[0], fkey(x[0]), pos, u_off); pos += n0;
-                                        lds_push64(S[1], c[1], fkey(x[1]), pos, u_off); pos += n1;
-                                        lds_push64(S[2], c[2], fkey(x[2]), pos, u_off); pos += n2;
-                                        lds_push64(S[3], c[3], fkey(x[3]), pos, u_off);
-                                    } else {
-                                        if ((S[0] >> lane) & 1ull) U[pos + mbcnt64(S[0])] = ((u64)fkey(x[0]) << 32) | (u64)c[0];
-                                        pos += n0;
-                                        if ((S[1] >> lane) & 1ull) U[pos + mbcnt64(S[1])] = ((u64)fkey(x[1]) << 32) | (u64)c[1];
-                                        pos += n1;
-                                        if ((S[2] >> lane) & 1ull) U[pos + mbcnt64(S[2])] = ((u64)fkey(x[2]) << 32) | (u64)c[2];
-                                        pos += n2;
-                                        if ((S[3] >> lane) & 1ull) U[pos + mbcnt64(S[3])] = ((u64)fkey(x[3]) << 32) | (u64)c[3];
-                                    }
-                                    wps.pos = pos + n3;
-                                }
-                            } else {
-                                if (pool_reserve(wps, n0 + n1 + n2 + n3, &sh[SH_PCTR], spcap, &sh[SH_OVF])) {
-                                    int pos = wps.pos;
-                                    lds_push64(S[0], __float_as_uint(x[0]), c[0] + 1u, pos, spool_off); pos += n0;
-                                    lds_push64(S[1], __float_as_uint(x[1]), c[1] + 1u, pos, spool_off); pos += n1;
-                                    lds_push64(S[2], __float_as_uint(x[2]), c[2] + 1u, pos, spool_off); pos += n2;
-                                    lds_push64(S[3], __float_as_uint(x[3]), c[3] + 1u, pos, spool_off);
-                                    wps.pos = pos + n3;
-                                }
-                            }
-                        }
-                        __builtin_amdgcn_s_setprio(0);
-                    };
-                    unsigned cA[4], cB[4];
-                    float vA[4], vB[4];
-                    int nA = 0, nB = 0;
-                    float sA = 0.f, sB = 0.f;
-                    const int n_trips = (i1 - i0 - wave + NW - 1) / NW;
-                    int trip = 0;
-                    ld(0, cA, vA, nA, sA);
-                    while (trip < n_trips) {      // two items (4 KiB) in flight per wave; bodies skip the sentinel
-                        ld(trip + 1, cB, vB, nB, sB);
-                        __builtin_amdgcn_sched_barrier(0);     // the prefetch is issued before the current item is waited for
-                        body(cA, vA, nA, sA);
-                        ld(trip + 2, cA, vA, nA, sA);
-                        __builtin_amdgcn_sched_barrier(0);
-                        body(cB, vB, nB, sB);
-                        trip += 2;
                     }
                 }
                 i0 = i1;

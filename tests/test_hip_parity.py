@@ -557,8 +557,8 @@ def duo_matrices():
     return m
 
 
-def _duo_check(call, what, rtol=RTOL, expect_wgs=512, **tuning):
-    rows, cols, vals, counts, info = _host.run_hip(call, time_kernel=True, **tuning)
+def _duo_check(call, what, rtol=RTOL, expect_wgs=512, duo=True, **tuning):
+    rows, cols, vals, counts, info = _host.run_hip(call, time_kernel=True, duo=duo, **tuning)
     k = call.k
     ph = info["phase_cycles"]
     assert info["num_wgs"] == expect_wgs, (what, info["num_wgs"])
@@ -582,10 +582,10 @@ def test_sparse_kernel_duo_shape(duo_matrices, n_rows, name, kw):
     for k in (100, 300):
         call = _host.prepare(m, k=k, target_rows=targets, **kw)
         ph = _duo_check(call, f"duo {name} k={k}")
-        assert ph[9] + ph[10] == targets.shape[0] and ph[9] >= 0.99 * targets.shape[0], (name, k, ph[9], ph[10])
+        assert ph[9] + ph[10] == targets.shape[0] and ph[9] >= 0.95 * targets.shape[0], (name, k, ph[9], ph[10])
     # same rows without the duo shape: identical sets (A/B switch works)
     call = _host.prepare(m, k=100, target_rows=targets[:200], **kw)
-    _duo_check(call, f"no-duo {name}", no_duo=True, expect_wgs=200)
+    _duo_check(call, f"no-duo {name}", duo=False, expect_wgs=200)
 
 
 def test_sparse_kernel_duo_filter_matrix_signed_and_long_rows(duo_matrices):
