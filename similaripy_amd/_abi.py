@@ -20,7 +20,6 @@ SP_FLAG_STATIC_SCHED = 4
 SP_FLAG_NO_SPARSE_PATH = 8
 SP_FLAG_NO_FOLD = 16
 SP_FLAG_NO_ROW_ORDER = 32
-SP_FLAG_DUO = 256
 SP_FLAG_PHASE_TIMERS = 64
 SP_FLAG_M2_IS_M1_T = 128
 

@@ -454,7 +454,7 @@ def selected_device() -> int:
 
 def run_hip(call: KernelCall, device: Optional[int] = None, table_slots: int = 0, threads_per_wg: int = 0,
             num_wgs: int = 0, load_pct: int = 0, time_kernel: bool = False, static_sched: bool = False,
-            no_sparse_path: bool = False, no_fold: bool = False, want_rows: bool = True, duo: bool = False):
+            no_sparse_path: bool = False, no_fold: bool = False, want_rows: bool = True):
     """The `with nogil:` block of s_plus.pyx:359-384, on the GPU: host buffers in, host buffers out
     through the C ABI (include/sp_knn.h).  Returns rows, cols, values, counts[, info]."""
     _abi.require_device()
@@ -466,7 +466,7 @@ def run_hip(call: KernelCall, device: Optional[int] = None, table_slots: int = 0
 
     a = _abi.SpKnnArgs()
     a.flags = ((0 if want_rows else _abi.SP_FLAG_NO_ROWS_OUT) | (_abi.SP_FLAG_TIME_KERNEL | _abi.SP_FLAG_PHASE_TIMERS if time_kernel else 0) | (_abi.SP_FLAG_STATIC_SCHED if static_sched else 0)
-               | (_abi.SP_FLAG_NO_SPARSE_PATH if no_sparse_path else 0) | (_abi.SP_FLAG_NO_FOLD if no_fold else 0) | (_abi.SP_FLAG_DUO if duo else 0))
+               | (_abi.SP_FLAG_NO_SPARSE_PATH if no_sparse_path else 0) | (_abi.SP_FLAG_NO_FOLD if no_fold else 0))
     a.on_device = 0
     a.device = selected_device() if device is None else int(device)
     a.n_targets, a.n_rows_m1, a.n_rows_m2, a.n_output_cols = n, call.n_rows_m1, call.n_rows_m2, call.n_output_cols

@@ -26,7 +26,7 @@ constexpr int U_SLACK = 1024;    // candidate-buffer entries beyond k (room betw
 #define DRAIN_UNROLL (NT >= 1024 ? 2 : NT >= 768 ? 4 : 8)
 
 // scalar slots in LDS
-enum { SH_CNT = 0, SH_OVF, SH_SEL, SH_NEED, SH_EQ, SH_CNT2, SH_RETRY, SH_QA, SH_QB, SH_PCTR, SH_MCTR, SH_NITEMS, SH_STOP, SH_WSUM, SH_NHI = SH_WSUM + 16, SH_WMACS, SH_N };   // SH_CNT2/SEL/NEED/EQ belong to the selections
+enum { SH_CNT = 0, SH_OVF, SH_SEL, SH_NEED, SH_EQ, SH_CNT2, SH_RETRY, SH_QA, SH_QB, SH_PCTR, SH_MCTR, SH_NITEMS, SH_STOP, SH_WSUM, SH_NHI = SH_WSUM + 16, SH_N };   // SH_CNT2/SEL/NEED/EQ belong to the selections
 
 // phases timed by lane 0 of every workgroup when KParams::phase_cycles != NULL, then event counters
 enum { PH_SETUP = 0, PH_SEGMENTS, PH_ACCUM, PH_DRAIN, PH_SELECT, PH_OUTPUT, PH_SWEEP1, PH_SWEEP2, PH_CSDRAIN,
@@ -65,8 +65,6 @@ struct KParams {
     int sparse_path;       // 1 = rows with few expected collisions take the bitmap path
     int fold;              // 1 = the single active column term (Ycos or Ydep) is already divided into m2_data: treat it as 1
     unsigned long long *phase_cycles;  // optional [PH_N]
-    const int *m2_split;   // windows only: per m2 row, the position (as in m2_indptr) of its first element with column >= 1 << nb_log2
-    int n_win;             // 1, or 2: the columns are processed in two windows of 1 << nb_log2 columns (exact bitmap in each)
     int dbg;               // ablation bits for profiling only (results are WRONG when non-zero; 8 / 16: sweep 1 / sweep 2 of the sparse kernel
                            // load but do not process — compiled in only with -DSP_ABLATION=1: the test costs the sweeps 1 %):
                            // 1 = generic accumulate: no LDS inserts, 4 = no Y gathers
@@ -389,12 +387,9 @@ constexpr int ITEM = 256;         // m2 elements per work item: one 16-byte load
 constexpr int ITEM_CAP = 1008;    // work items per row (LDS: 16 B each) of a 1024-thread workgroup
 // ... and of a smaller one: a wave keeps at most 63 item descriptors, so NW*64 entries are all a row can use (the area
 // doubles as 4 KiB of scratch for the segment order: never below 256 entries)
-// (512 threads: 256 entries too — the shape in which two workgroups share a CU has no room for more, and one WINDOW of a row
-// seldom has more items)
-__host__ __device__ constexpr int item_cap(int NT) { return NT >= 1024 ? ITEM_CAP : NT >= 768 ? (NT / 64) * 64 : 256; }
-constexpr int CBM_DEFAULT = 8192; // collision bitmap of the sparse kernel (64k bits = 2048 words); its per-word exclusive
-                                  // popcount prefix (u16 each) takes half as many bytes again
-constexpr int CBM_DUO = 4096;     // ... of the shape in which two workgroups share a CU
+__host__ __device__ constexpr int item_cap(int NT) { return NT >= 1024 ? ITEM_CAP : (NT / 64) * 64; }
+constexpr int CBM_BYTES = 8192;   // collision bitmap of the sparse kernel (64k bits = 2048 words)
+constexpr int PRE_BYTES = 4096;   // per-word exclusive popcount prefix of the collision bitmap (u16 each)
 constexpr int POOL_BLK = 64;      // pool entries a wave reserves at a time (>= 64: one trip always fits a fresh block)
 constexpr int CS_MAXPROBE = 64;   // linear-probe budget in the collision set
 constexpr unsigned OOB_SOFFSET = 0xFFFFF000u;   // buffer-load scalar offset beyond any m2 extent: every lane out of range
@@ -633,18 +628,18 @@ __device__ __forceinline__ void s1_core8(const unsigned (&c)[8], int lane4, int 
 
 // Sweep 2, four products per lane: x = value * segv, M[j] = lanes whose column is marked in the collision bitmap
 // (LDS offset 0, CBM_BYTES long), L[j] = lanes with !(x <= cut)  (NaN counts as above the cutoff).
-template <int CBMB>
 __device__ __forceinline__ void s2_core(const unsigned (&c)[4], const float (&v)[4], float segv, float cut, float (&x)[4], u64 (&M)[4], u64 (&L)[4]) {
     unsigned a0, a1, a2, a3;
+    static_assert(CBM_BYTES == 8192, "the literal below is CBM_BYTES - 4");
     asm volatile(
         "v_lshrrev_b32 %[a0], 3, %[c0]\n\t"
         "v_lshrrev_b32 %[a1], 3, %[c1]\n\t"
         "v_lshrrev_b32 %[a2], 3, %[c2]\n\t"
         "v_lshrrev_b32 %[a3], 3, %[c3]\n\t"
-        "v_and_b32 %[a0], %[cm], %[a0]\n\t"
-        "v_and_b32 %[a1], %[cm], %[a1]\n\t"
-        "v_and_b32 %[a2], %[cm], %[a2]\n\t"
-        "v_and_b32 %[a3], %[cm], %[a3]\n\t"
+        "v_and_b32 %[a0], 0x1ffc, %[a0]\n\t"
+        "v_and_b32 %[a1], 0x1ffc, %[a1]\n\t"
+        "v_and_b32 %[a2], 0x1ffc, %[a2]\n\t"
+        "v_and_b32 %[a3], 0x1ffc, %[a3]\n\t"
         "ds_read_b32 %[a0], %[a0]\n\t"
         "ds_read_b32 %[a1], %[a1]\n\t"
         "ds_read_b32 %[a2], %[a2]\n\t"
@@ -671,7 +666,7 @@ __device__ __forceinline__ void s2_core(const unsigned (&c)[4], const float (&v)
           [M0] "=&s"(M[0]), [M1] "=&s"(M[1]), [M2] "=&s"(M[2]), [M3] "=&s"(M[3]),
           [L0] "=&s"(L[0]), [L1] "=&s"(L[1]), [L2] "=&s"(L[2]), [L3] "=&s"(L[3])
         : [c0] "v"(c[0]), [c1] "v"(c[1]), [c2] "v"(c[2]), [c3] "v"(c[3]),
-          [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]), [sv] "s"(segv), [cut] "s"(cut), [cm] "i"(CBMB - 4)
+          [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]), [sv] "s"(segv), [cut] "s"(cut)
         : "memory");
 }
 

@@ -92,9 +92,6 @@ struct Config {
     size_t ws_rows_bytes;   // bucket counters + work[n] + order[n] + the two descriptor queues
     size_t ws_desc_offset;  // of the sparse queue inside that block (the generic queue follows it)
     int nb_log2;            // sparse kernel: bitmap bits (log2)
-    int n_win;              // sparse kernel: column windows (1 or 2)
-    bool duo;               // sparse kernel: the two-workgroups-per-CU shape (512 threads, 64 KiB region A, 4 KiB collision bitmap)
-    size_t ws_split_bytes;  // per-m2-row window split positions (0 unless n_win == 2)
     size_t ws_total;
     bool fold;
     bool mono;              // the sparse kernel's monotone variant applies (val = xy / den or the raw dot, no per-row target selector)
@@ -110,7 +107,7 @@ static_assert(WS_PHASE_OFFSET + PH_N * 8 <= WS_YMIN_OFFSET && WS_YMIN_OFFSET + 1
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
 // LDS of the two kernels without the candidate buffer (see their carve-ups)
-size_t lds_fixed_sparse(int T, int NT, int cbm) { return (size_t)T * 8 + (size_t)item_cap(NT) * 16 + 4096 + (size_t)cbm + (size_t)cbm / 2 + 32 * 4 + 16 * 8; }   // (its candidate buffer lives inside region A)
+size_t lds_fixed_sparse(int T, int NT) { return (size_t)T * 8 + (size_t)item_cap(NT) * 16 + 4096 + CBM_BYTES + PRE_BYTES + 32 * 4 + 16 * 8; }   // (its candidate buffer lives inside region A)
 size_t lds_fixed_generic(int T, int NT) { return (size_t)T * 8 + (size_t)16 * NT + 256 + 256 * 4 + 64 * 4 + 32 * 4 + 16 * 8; }
 
 int make_config(const sp_knn_args *a, int n_cus, Config *c) {
@@ -124,7 +121,7 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
 
     const long long need_cap = (long long)a->k + U_SLACK;
     const size_t fixed = lds_fixed_generic(T, NT);
-    if (std::max(fixed + 8 * 1024, lds_fixed_sparse(T, NT, CBM_DEFAULT)) > LDS_LIMIT) return fail(SP_EINVAL, "table_slots=%d does not fit the 160 KiB LDS", T);
+    if (std::max(fixed + 8 * 1024, lds_fixed_sparse(T, NT)) > LDS_LIMIT) return fail(SP_EINVAL, "table_slots=%d does not fit the 160 KiB LDS", T);
     // generic kernel's candidate buffer: LDS if k + slack entries fit beside the table, else global scratch
     long long cap_lds = (long long)((LDS_LIMIT - fixed) / 8);
     bool u_lds = need_cap <= cap_lds;
@@ -147,31 +144,15 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
     const double avg_macs = (a->n_rows_m1 > 0 && a->n_rows_m2 > 0) ? ((double)a->nnz_m1 / a->n_rows_m1) * ((double)a->nnz_m2 / a->n_rows_m2) : 0.0;
     // (beyond 2^18 columns the bitmap aliases — columns modulo its size — which only adds expected collisions)
     const bool small_rows = avg_macs * avg_macs / (2.0 * std::max(1, std::min(a->n_output_cols, 1 << 18))) <= 0.25 * 1024.0;
-    bool duo = false;
-    int n_win = 1;
-    const bool tune_free = !a->threads_per_wg && !a->table_slots;
-    if (tune_free && (long long)a->k + 512 <= (long long)SEL_E * 256 && small_rows) {
+    if (!a->threads_per_wg && !a->table_slots && (long long)a->k + 512 <= (long long)SEL_E * 256 && small_rows) {
         NT_s = 256; T_s = 4096; logT_s = 12;
-    } else if (tune_free && (a->flags & SP_FLAG_DUO) && a->k <= 448 && a->n_output_cols > (1 << 18) && a->n_output_cols <= (1 << 20)) {
-        // Heavier rows over up to 2^20 columns: TWO 512-thread workgroups per CU (78 KB of LDS each), each with an EXACT
-        // 2^19-bit column bitmap over one WINDOW of the columns at a time — two windows when there are more than 2^19
-        // columns — so that the dense phases of one row hide under the sweeps of another (BASELINE configs[1]).
-        // Taken when the average row's expected collisions per window stay well inside the 1024 direct slots.
-        const int nw = a->n_output_cols > (1 << 19) ? 2 : 1;
-        const double f = nw > 1 ? (double)(1 << 19) / a->n_output_cols : 1.0;
-        const double expect = 0.5 * (avg_macs * f) * (avg_macs * f) / (double)std::min(a->n_output_cols, 1 << 19);
-        if (expect <= 0.25 * 2048.0) {
-            duo = true; n_win = nw;
-            NT_s = 512; T_s = 8192; logT_s = 13;
-        }
     }
     const bool u_lds_s = ((size_t)SEL_E * NT_s * 8 <= (size_t)T_s * 2) && ((long long)a->k + 512 <= (long long)SEL_E * NT_s);
     const long long cap_s = u_lds_s ? (long long)SEL_E * NT_s : ((need_cap + 1024) & ~1LL);
     c->T = T; c->logT = logT; c->NT = NT; c->cap = (int)cap; c->u_lds = u_lds; c->cap_s = (int)cap_s; c->u_lds_s = u_lds_s;
     c->T_s = T_s; c->logT_s = logT_s; c->NT_s = NT_s;
     c->hash_fill = std::max(1, (int)((long long)T * load / 100));
-    c->duo = duo; c->n_win = n_win;
-    c->lds_sparse = lds_fixed_sparse(T_s, NT_s, duo ? CBM_DUO : CBM_DEFAULT);
+    c->lds_sparse = lds_fixed_sparse(T_s, NT_s);
     c->lds_generic = lds_fixed_generic(T, NT) + (u_lds ? (size_t)cap * 8 : 0);
     auto wgs_for = [&](size_t lds, int nt) {
         int per_cu = (int)std::max<size_t>(1, LDS_LIMIT / lds);
@@ -200,8 +181,7 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
     int nb = 10;
     while (nb < c->logT_s + 6 && (1LL << nb) < (long long)a->n_output_cols) ++nb;
     c->nb_log2 = nb;
-    c->ws_split_bytes = n_win > 1 ? (((size_t)a->n_rows_m2 * 4 + 255) & ~(size_t)255) : 0;
-    c->ws_total = WS_QUEUE_BYTES + c->ws_gu_bytes + c->ws_fold_bytes + c->ws_rows_bytes + c->ws_split_bytes;
+    c->ws_total = WS_QUEUE_BYTES + c->ws_gu_bytes + c->ws_fold_bytes + c->ws_rows_bytes;
     return SP_OK;
 }
 
@@ -257,15 +237,6 @@ int launch_sparse(const KParams &kp, const Config &c, hipStream_t stream) {
     return SP_OK;
 }
 
-// the two-workgroups-per-CU shape: 512 threads, candidate buffer in LDS, 4 KiB collision bitmap, column windows
-int launch_sparse_duo(const KParams &kp, const Config &c, hipStream_t stream) {
-    auto ks = c.mono ? sp_knn_sparse_kernel<512, true, true, CBM_DUO, true> : sp_knn_sparse_kernel<512, true, false, CBM_DUO, true>;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds_sparse));
-    hipLaunchKernelGGL(ks, dim3(c.wgs_sparse), dim3(512), c.lds_sparse, stream, kp);
-    HIP_TRY(hipGetLastError());
-    return SP_OK;
-}
-
 template <int NT>
 int launch_generic(const KParams &kp, const Config &c, hipStream_t stream) {
     auto kg = c.u_lds ? sp_knn_generic_kernel<NT, true> : sp_knn_generic_kernel<NT, false>;
@@ -281,8 +252,7 @@ int launch_rows(const KParams &kp_s, const KParams &kp, const Config &c, hipStre
     if (ev) HIP_TRY(hipEventRecord(ev[0], stream));
     if (kp.sparse_path) {
         int rc;
-        if (c.duo) rc = launch_sparse_duo(kp_s, c, stream);
-        else if (c.NT_s == 256) rc = launch_sparse<256>(kp_s, c, stream);
+        if (c.NT_s == 256) rc = launch_sparse<256>(kp_s, c, stream);
         else if (c.NT_s == 512) rc = launch_sparse<512>(kp_s, c, stream);
         else if (c.NT_s == 768) rc = launch_sparse<768>(kp_s, c, stream);
         else rc = launch_sparse<1024>(kp_s, c, stream);
@@ -333,7 +303,6 @@ int run_device_impl(sp_knn_args *a) {
     unsigned char *ws_gu = ws + WS_QUEUE_BYTES;
     unsigned char *ws_fold = ws_gu + c.ws_gu_bytes;
     unsigned char *ws_rows = ws_fold + c.ws_fold_bytes;
-    unsigned char *ws_split = ws_rows + c.ws_rows_bytes;
 
     // minima of the column-term vectors feed the gather-free upper bound (Epi::upper); it is sound only
     // when every weight / shrink is non-negative (NaN parameters fail the comparisons and disable it)
@@ -407,7 +376,7 @@ int run_device_impl(sp_knn_args *a) {
         }
         ClassifyParams cp;
         cp.sparse_path = kp.sparse_path;
-        cp.n_cols = a->n_output_cols; cp.T = c.T; cp.nb_log2 = c.nb_log2; cp.n_win = c.n_win;
+        cp.n_cols = a->n_output_cols; cp.T = c.T; cp.nb_log2 = c.nb_log2;
         cp.cs_slots = c.T_s / 4;
         cp.mono = c.mono ? 1 : 0;
         cp.any_norm = (a->l1 != 0.f || a->l2 != 0.f || a->l3 != 0.f || a->stabilized_shrink != 0.f || a->bayesian_shrink != 0.f) ? 1 : 0;
@@ -420,13 +389,6 @@ int run_device_impl(sp_knn_args *a) {
         kp.desc_g = desc_g;
     }
     kp.m2_bytes = (unsigned)((size_t)a->nnz_m2 * 4);
-    kp.n_win = c.n_win;
-    if (c.n_win > 1 && kp.sparse_path) {
-        hipLaunchKernelGGL(sp_m2_split_kernel, dim3((a->n_rows_m2 + 255) / 256), dim3(256), 0, stream, a->n_rows_m2, a->m2_indptr, a->m2_indices,
-                           1 << c.nb_log2, (int *)ws_split);
-        HIP_TRY(hipGetLastError());
-        kp.m2_split = (const int *)ws_split;
-    }
     kp.nb_log2 = c.nb_log2;
     kp.hash_fill = c.hash_fill;
     kp.static_sched = (a->flags & SP_FLAG_STATIC_SCHED) ? 1 : 0;

@@ -83,7 +83,6 @@ __global__ __launch_bounds__(256) void sp_row_order_kernel(int n_targets, const 
 struct ClassifyParams {
     int sparse_path;       // 0: everything is generic
     int n_cols, T;
-    int n_win;             // column windows of the sparse kernel (1: one bitmap over all columns, aliasing beyond its size)
     int nb_log2;           // sparse bitmap bits
     int cs_slots;          // collision-set slots of the sparse kernel
     int mono;              // the monotone sparse kernel runs: descriptor word 1.y carries den (val = xy / den), rows
@@ -119,15 +118,8 @@ __global__ __launch_bounds__(256) void sp_row_desc_kernel(int n_targets, const i
         if (cp.sparse_path && den_ok && macs > 0u && macs < (1u << 30) && (e - s) <= SORT_MAX && cp.n_cols > cp.T) {
             // expected number of products that find their bit set: true collisions + bitmap aliasing
             const float m = (float)macs;
-            float expect;
-            if (cp.n_win > 1) {
-                // two exact windows: the wider one holds `1 << nb_log2` of the n_cols columns and that share of the products
-                const float f = (float)(1 << cp.nb_log2) / (float)cp.n_cols;
-                expect = 0.5f * (m * f) * (m * f) / (float)(1 << cp.nb_log2);
-            } else {
-                const float alias = (cp.nb_log2 < 31 && (1 << cp.nb_log2) < cp.n_cols) ? 1.f / (float)(1 << cp.nb_log2) : 0.f;
-                expect = 0.5f * m * m * (1.f / (float)cp.n_cols + alias);
-            }
+            const float alias = (cp.nb_log2 < 31 && (1 << cp.nb_log2) < cp.n_cols) ? 1.f / (float)(1 << cp.nb_log2) : 0.f;
+            const float expect = 0.5f * m * m * (1.f / (float)cp.n_cols + alias);
             sparse = expect <= 0.30f * (float)cp.cs_slots;
         }
     }
@@ -145,14 +137,6 @@ __global__ __launch_bounds__(256) void sp_row_desc_kernel(int n_targets, const i
         dst[0] = d0;
         dst[1] = d1;
     }
-}
-
-// Column windows of the sparse kernel: split[u] = position (as in m2_indptr) of the first element of m2 row u whose column
-// is >= win_cols (rows are column-sorted).  One thread per row, a binary search each.
-__global__ __launch_bounds__(256) void sp_m2_split_kernel(int n_rows_m2, const int *__restrict__ m2_indptr, const int *__restrict__ m2_indices,
-                                                           int win_cols, int *__restrict__ split) {
-    const int u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u < n_rows_m2) split[u] = lower_bound_g(m2_indices, m2_indptr[u], m2_indptr[u + 1], win_cols);
 }
 
 // Minima of the three column-term vectors over all columns (one workgroup; feeds Epi::upper).

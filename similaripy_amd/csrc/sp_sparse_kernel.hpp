@@ -25,19 +25,10 @@ namespace {
 // selector is active (a per-row FILTER is: its columns are pre-marked in the collision bitmap and dropped at the scan).  Then the whole top-k runs on the raw dot: survivors go straight from the sweep into the
 // candidate buffer (no survivor pool, no judge phase), the running k-th raw dot IS the cutoff, and the epilogue is
 // applied to the k winners at write-out.
-// CBMB: bytes of the collision bitmap (8192, or 4096 in the two-workgroups-per-CU shape); WIN: the columns may be cut into
-// two WINDOWS of `1 << nb_log2` columns each that are processed one after the other with an exact bitmap (instead of
-// one aliasing bitmap over all columns): per window sweep 1 / clear / sweep 2 stages / accumulate / drain, the candidate
-// buffer and the running cutoff carried from window to window (the buffer waits in the histogram area while the next
-// window's sweep 1 owns region A).  With a 2^19-bit bitmap (64 KiB) and 512 threads TWO workgroups share a CU, so the
-// dense phases of one row hide under the sweeps of another (BASELINE configs[1]: 1M columns = 2 windows).
-// (second launch bound = waves per SIMD: the two-workgroups-per-CU shape needs 2 x 8 waves on 4 SIMDs, i.e. <= 128 VGPRs)
-template <int NT, bool U_LDS, bool MONO, int CBMB = 8192, bool WIN = false>
-__global__ __launch_bounds__(NT, (WIN ? 4 : 1)) void sp_knn_sparse_kernel(const KParams p) {
+template <int NT, bool U_LDS, bool MONO>
+__global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NW = NT / 64;
-    constexpr int CBM_BYTES = CBMB, PRE_BYTES = CBMB / 2;
-    static_assert(!WIN || U_LDS, "windows need the candidate buffer in LDS");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -48,8 +39,7 @@ __global__ __launch_bounds__(NT, (WIN ? 4 : 1)) void sp_knn_sparse_kernel(const 
     //                     that its reads need no base add;  pre16[]: its per-word popcount prefix (rank of a marked column)
     // region A [.., +T*8) sweep 1: column bitmap (nb bits, from the start);
     //                     afterwards: [0,A/4) collision set, [A/4,A/2) survivor pool, [A/2,3A/4) member pool, [3A/4,A) candidate buffer U
-    // items[item_cap(NT)] {m2 byte offset, count, m1 value bits, flat start};  hist4[4][256] radix histograms (between
-    //                     two windows of a row: the stash of the candidate buffer, <= STASH_CAP entries)
+    // items[item_cap(NT)] {m2 byte offset, count, m1 value bits, flat start};  hist4[4][256] radix histograms
     // sh[32], ph[16]      scalars, phase timers
     unsigned char *cbm = smem;
     unsigned short *pre16 = (unsigned short *)(smem + CBM_BYTES);      // [CBM_BYTES/4] marked columns below each bitmap word
@@ -61,18 +51,6 @@ __global__ __launch_bounds__(NT, (WIN ? 4 : 1)) void sp_knn_sparse_kernel(const 
     u64 *ph = (u64 *)(sh + 32);
     u64 *U = U_LDS ? (u64 *)(rA + (A_bytes / 4) * 3) : (p.gU + (size_t)blockIdx.x * (size_t)p.cap_s);
     const int cap = p.cap_s;
-    const int n_win = WIN ? p.n_win : 1;
-    constexpr int STASH_CAP = 512;
-    // REGISTER-RESIDENT rows (MONO).  The sweeps are bound by the latency of their loads (two 1-KiB trips in flight per wave:
-    // a C2 row spent ~9 memory round trips of ~2 us in them) and sweep 2 read the column ids a second time.  A row whose
-    // waves own at most RR_MAX items each keeps its column ids in REGISTERS instead: every wave issues the id loads of all
-    // its items at once right after the items are known (RR_MAX x 4 registers per lane), sweep 1 runs out of registers, and
-    // sweep 2 — the selection-free first stage and ONE stage over everything else — re-uses them and fetches only the
-    // values, through a ring of RR_RING items that is filled for the first time while the bitmap is cleared:
-    // ids are read once (8 B per product instead of 12) and a row waits for ~2 round trips instead of ~9.
-    // The ids are dead before the dense phases (accumulate / drain / select), whose registers they could not share.
-    constexpr int RR_MAX = (MONO && U_LDS && NT == 1024 && !WIN) ? 0 : 0;
-    constexpr int RR_RING = 6;
 
     const unsigned amask = (unsigned)((1u << (p.nb_log2 - 3)) - 1u) & ~3u;      // column -> byte of its bitmap word
     const int nb_bytes = 1 << (p.nb_log2 - 3);
@@ -143,14 +121,12 @@ __global__ __launch_bounds__(NT, (WIN ? 4 : 1)) void sp_knn_sparse_kernel(const 
     }
     // m1 entry / m2 row bounds of segment `tid` of the current row (rows of this kernel have <= SORT_MAX <= NT entries)
     int my_r0 = 0, my_len = 0;
-    int my_sp = 0;         // WIN: position of the segment's first element of the second window
     float my_v = 0.f;
     if (dC.x >= 0 && tid < dC.w) {
         const int u = p.m1_indices[dC.z + tid];
         my_v = p.m1_data[dC.z + tid];
         my_r0 = p.m2_indptr[u];
         my_len = p.m2_indptr[u + 1] - my_r0;
-        if (WIN && n_win > 1) my_sp = p.m2_split[u];
     }
 
     for (;;) {
@@ -172,46 +148,90 @@ __global__ __launch_bounds__(NT, (WIN ? 4 : 1)) void sp_knn_sparse_kernel(const 
             nx_u = p.m1_indices[dN.z + tid];
             nx_v = p.m1_data[dN.z + tid];
         }
-        int nx_r0 = 0, nx_len = 0, nx_sp = 0;
+        int nx_r0 = 0, nx_len = 0;
 
-        if (tid == 0) { sh[SH_PCTR] = 0; sh[SH_MCTR] = 0; sh[SH_NITEMS] = 0; sh[SH_CNT] = 0; sh[SH_SEL] = -1; sh[SH_NEED] = 0; sh[SH_WMACS] = 0; }
+        if (tid == 0) { sh[SH_PCTR] = 0; sh[SH_MCTR] = 0; sh[SH_NITEMS] = 0; sh[SH_CNT] = 0; sh[SH_SEL] = -1; sh[SH_NEED] = 0; }
         // Segment order.  The heaviest segments (largest |m1 value|: each segment scales its m2 row by its own m1 value)
         // go first, so that the first stage of sweep 2 sees the large products and the running k-th value — the cutoff
         // of everything after — starts high.
+        int my_ib = 0, my_fs = 0;       // first item / flat start of segment `tid`
+        int n_items = 0;
         int4 dNN, wNN;
-        // n1 <= 64: one wave, one segment per lane: the (up to) 8 largest |values| are found with 8 wave-max rounds; heavy
-        // segments first, the others behind, both in their original order (ballot + mbcnt).  The order is the same for
-        // every window of the row.
-        unsigned seg_key = 0u;
-        int seg_pos = 0;
-        if (n1 <= 64 && tid < 64) {
-            seg_key = (tid < n1 && my_len > 0) ? ((__float_as_uint(my_v) & 0x7FFFFFFFu) | 1u) : 0u;   // 0 = no segment
-            unsigned rest = seg_key, thr = 0u;
+        if (n1 <= 64) {
+            // One wave, one segment per lane, no barrier inside: the (up to) 8 largest |values| are found with 8 wave-max
+            // rounds; heavy segments first, the others behind, both in their original order (ballot + mbcnt); item and
+            // flat-start prefixes by one trip through LDS into position order and a DPP scan there.
+            if (tid < 64) {
+                const unsigned key = (tid < n1 && my_len > 0) ? ((__float_as_uint(my_v) & 0x7FFFFFFFu) | 1u) : 0u;   // 0 = no segment
+                unsigned rest = key, thr = 0u;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const unsigned mx = wave_max_u32(rest);
-                if (mx != 0u) thr = mx;                    // uniform
-                rest = (rest >= mx) ? 0u : rest;
+                for (int r = 0; r < 8; ++r) {
+                    const unsigned mx = wave_max_u32(rest);
+                    if (mx != 0u) thr = mx;                    // uniform
+                    rest = (rest >= mx) ? 0u : rest;
+                }
+                const bool heavy = key != 0u && key >= thr;
+                const u64 H = __ballot(heavy), Lg = __ballot(key != 0u && !heavy);
+                const int pos = heavy ? mbcnt64(H) : __popcll(H) + mbcnt64(Lg);
+                const int nit = (my_len + ITEM - 1) / ITEM;
+                // Scratch (the items are written after it is read back).  The lanes of this wave talk to each other through
+                // it without a barrier: LDS executes a wave's accesses in order.  To the compiler that is one thread reading
+                // back its own store — for a lane without a segment it folded the read to the 0 just written there and lost
+                // the segment another lane had scattered to that position (rows whose m1 entries point at EMPTY m2 rows;
+                // found by scripts/fuzz_parity.py).  The wavefront-scope fences emit no instruction; they keep the
+                // compiler from forwarding a lane's own store across them.
+                int *scr = (int *)items;
+                scr[tid] = 0; scr[64 + tid] = 0;
+                if (key != 0u) { scr[pos] = nit; scr[64 + pos] = my_len; }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                const int nit_p = scr[tid], len_p = scr[64 + tid];
+                const int ib_incl = wave_incl_scan_dpp(nit_p), fs_incl = wave_incl_scan_dpp(len_p);
+                scr[128 + tid] = ib_incl - nit_p;
+                scr[192 + tid] = fs_incl - len_p;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if (key != 0u) { my_ib = scr[128 + pos]; my_fs = scr[192 + pos]; }
+                if (tid == 63) sh[SH_NITEMS] = ib_incl;
             }
-            const bool heavy = seg_key != 0u && seg_key >= thr;
-            const u64 H = __ballot(heavy), Lg = __ballot(seg_key != 0u && !heavy);
-            seg_pos = heavy ? mbcnt64(H) : __popcll(H) + mbcnt64(Lg);
+            __syncthreads();
+            if (!p.static_sched) q_nn = sh[SH_QA];
+            load_desc(q_nn, dNN, wNN);
+            if (p.static_sched) q_nn += (int)gridDim.x;
+            n_items = sh[SH_NITEMS];
+            __syncthreads();                    // scratch read before the items overwrite it
+        } else {
+            // up to SORT_MAX entries: full descending order from one all-pairs pass spread over the whole workgroup:
+            // thread (seg, part) adds up the segments that precede `seg`
+            int *keyS = (int *)items, *lenS = keyS + SORT_MAX, *ibS = lenS + SORT_MAX, *fsS = ibS + SORT_MAX;
+            if (tid < SORT_MAX) { ibS[tid] = 0; fsS[tid] = 0; }
+            if (tid < n1) { keyS[tid] = (int)(__float_as_uint(my_v) & 0x7FFFFFFFu); lenS[tid] = my_len; }
+            __syncthreads();
+            if (!p.static_sched) q_nn = sh[SH_QA];
+            load_desc(q_nn, dNN, wNN);
+            if (p.static_sched) q_nn += (int)gridDim.x;
+            {
+                const int lg = (n1 <= 128) ? 7 : 8;       // segments padded to a power of two
+                const int seg = tid & ((1 << lg) - 1), part = tid >> lg, parts = NT >> lg;
+                if (seg < n1) {
+                    const int key = keyS[seg];
+                    int ib = 0, fs = 0;
+                    for (int j = part; j < n1; j += parts) {
+                        const int kj = keyS[j], lj = lenS[j];     // same address across the wave: broadcast reads
+                        const bool before = (kj > key) || (kj == key && j < seg);
+                        ib += before ? (lj + ITEM - 1) / ITEM : 0;
+                        fs += before ? lj : 0;
+                    }
+                    if (ib) atomicAdd(&ibS[seg], ib);
+                    if (fs) atomicAdd(&fsS[seg], fs);
+                }
+                if (tid < n1 && my_len > 0) atomicAdd(&sh[SH_NITEMS], (my_len + ITEM - 1) / ITEM);
+            }
+            __syncthreads();
+            if (tid < n1) { my_ib = ibS[tid]; my_fs = fsS[tid]; }
+            n_items = sh[SH_NITEMS];
+            __syncthreads();                    // scratch read before the items overwrite it
         }
-        bool failed = false;
-        bool rr = false;              // this row runs register-resident
-        int rr_off = 0, rr_cnt = 0, rr_seg = 0;       // lane i: byte offset / count / m1 value bits of the wave's i-th item
-        u32x4 rr_ids[RR_MAX > 0 ? RR_MAX : 1];      // column ids of the wave's items
-        u32x4 rr_v0;                                // values of its first item (the first stage's)
-        u32x4 rr_ring[RR_RING];                     // values of the others, RR_RING in flight
-        // the 16-byte load of the wave's i-th item (i: compile-time constant); lanes beyond a partial item's end get an
-        // out-of-range offset and fetch nothing
-        auto rr_load = [&](const __amdgpu_buffer_rsrc_t &rs, int i) __attribute__((always_inline)) -> u32x4 {
-            const int off = __builtin_amdgcn_readlane(rr_off, i), cnt = __builtin_amdgcn_readlane(rr_cnt, i);
-            const int vo = (4 * lane < cnt) ? lane * 16 : (int)(OOB_SOFFSET - (unsigned)off);
-            return __builtin_amdgcn_raw_buffer_load_b128(rs, vo, off, 0);
-        };
-        float seen_before = 0.f;      // products of the windows already done
-        int n_stash = 0;              // candidate-buffer entries waiting in the histogram area between two windows
+        bool failed = (n_items >= ICAP) || (n_items > 63 * NW);      // (a wave keeps its <= 63 item descriptors in one register)
+        PHASE_END(PH_SETUP);
 
         RowCtx rc;
         rc.have_thr = false;
@@ -249,112 +269,16 @@ __global__ __launch_bounds__(NT, (WIN ? 4 : 1)) void sp_knn_sparse_kernel(const 
             if (p.target_mode == SP_SEL_MATRIX) { rc.g0 = __builtin_amdgcn_readfirstlane(p.t_indptr[t]); rc.g1 = __builtin_amdgcn_readfirstlane(p.t_indptr[t + 1]); }
         }
 
-
-        for (int win = 0; win < n_win && !failed; ++win) {
-        // ---- this window's piece of segment `tid` (one window: the whole m2 row) ----
-        int pr0 = my_r0, plen = my_len;
-        if (WIN && n_win > 1) {
-            if (win == 0) plen = my_sp - my_r0;
-            else { pr0 = my_sp; plen = my_r0 + my_len - my_sp; }
-        }
-        // columns of this window: [wlo, wlo + wspan)
-        const unsigned wlo = (WIN && win > 0) ? (1u << p.nb_log2) : 0u;
-        const unsigned wspan = (WIN && n_win > 1 && win == 0) ? (1u << p.nb_log2) : 0xFFFFFFFFu;
-        int my_ib = 0, my_fs = 0;       // first item / flat start of segment `tid`
-        int n_items = 0;
-        int win_macs = 0;               // products of this window
-        if (n1 <= 64) {
-            // item and flat-start prefixes by one trip through LDS into position order and a DPP scan there, no barrier inside
-            if (tid < 64) {
-                const int nit = (plen + ITEM - 1) / ITEM;
-                // Scratch (the items are written after it is read back).  The lanes of this wave talk to each other through
-                // it without a barrier: LDS executes a wave's accesses in order.  To the compiler that is one thread reading
-                // back its own store — for a lane without a segment it folded the read to the 0 just written there and lost
-                // the segment another lane had scattered to that position (rows whose m1 entries point at EMPTY m2 rows;
-                // found by scripts/fuzz_parity.py).  The wavefront-scope fences emit no instruction; they keep the
-                // compiler from forwarding a lane's own store across them.
-                int *scr = (int *)items;
-                scr[tid] = 0; scr[64 + tid] = 0;
-                if (seg_key != 0u) { scr[seg_pos] = nit; scr[64 + seg_pos] = plen; }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                const int nit_p = scr[tid], len_p = scr[64 + tid];
-                const int ib_incl = wave_incl_scan_dpp(nit_p), fs_incl = wave_incl_scan_dpp(len_p);
-                scr[128 + tid] = ib_incl - nit_p;
-                scr[192 + tid] = fs_incl - len_p;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                if (seg_key != 0u) { my_ib = scr[128 + seg_pos]; my_fs = scr[192 + seg_pos]; }
-                if (tid == 63) { sh[SH_NITEMS] = ib_incl; sh[SH_WMACS] = fs_incl; }
-            }
-            __syncthreads();
-            if (win == 0) {
-                if (!p.static_sched) q_nn = sh[SH_QA];
-                load_desc(q_nn, dNN, wNN);
-                if (p.static_sched) q_nn += (int)gridDim.x;
-            }
-            n_items = sh[SH_NITEMS];
-            win_macs = sh[SH_WMACS];
-            __syncthreads();                    // scratch read before the items overwrite it
-        } else {
-            // up to SORT_MAX entries: full descending order from one all-pairs pass spread over the whole workgroup:
-            // thread (seg, part) adds up the segments that precede `seg`
-            int *keyS = (int *)items, *lenS = keyS + SORT_MAX, *ibS = lenS + SORT_MAX, *fsS = ibS + SORT_MAX;
-            if (tid < SORT_MAX) { ibS[tid] = 0; fsS[tid] = 0; }
-            if (tid < n1) { keyS[tid] = (int)(__float_as_uint(my_v) & 0x7FFFFFFFu); lenS[tid] = plen; }
-            __syncthreads();
-            if (win == 0) {
-                if (!p.static_sched) q_nn = sh[SH_QA];
-                load_desc(q_nn, dNN, wNN);
-                if (p.static_sched) q_nn += (int)gridDim.x;
-            }
-            {
-                const int lg = (n1 <= 128) ? 7 : 8;       // segments padded to a power of two
-                const int seg = tid & ((1 << lg) - 1), part = tid >> lg, parts = NT >> lg;
-                if (seg < n1) {
-                    const int key = keyS[seg];
-                    int ib = 0, fs = 0;
-                    for (int j = part; j < n1; j += parts) {
-                        const int kj = keyS[j], lj = lenS[j];     // same address across the wave: broadcast reads
-                        const bool before = (kj > key) || (kj == key && j < seg);
-                        ib += before ? (lj + ITEM - 1) / ITEM : 0;
-                        fs += before ? lj : 0;
-                    }
-                    if (ib) atomicAdd(&ibS[seg], ib);
-                    if (fs) atomicAdd(&fsS[seg], fs);
-                }
-                if (tid < n1 && plen > 0) { atomicAdd(&sh[SH_NITEMS], (plen + ITEM - 1) / ITEM); atomicAdd(&sh[SH_WMACS], plen); }
-            }
-            __syncthreads();
-            if (tid < n1) { my_ib = ibS[tid]; my_fs = fsS[tid]; }
-            n_items = sh[SH_NITEMS];
-            win_macs = sh[SH_WMACS];
-            __syncthreads();                    // scratch read before the items overwrite it
-        }
-        failed = failed || (n_items >= ICAP) || (n_items > 63 * NW);      // (a wave keeps its <= 63 item descriptors in one register)
-        PHASE_END(PH_SETUP);
-
         if (!failed) {
             // sentinel item behind the last one: a prefetch past the end loads nothing (every lane out of range)
-            if (tid == NT - 1) items[n_items] = make_int4((int)OOB_SOFFSET, 0, 0, win_macs);
+            if (tid == NT - 1) items[n_items] = make_int4((int)OOB_SOFFSET, 0, 0, (int)macs32);
             if (tid < n1) {
                 int q = 0;
-                for (int o = 0; o < plen; o += ITEM, ++q)
-                    items[my_ib + q] = make_int4((pr0 + o) * 4, min(ITEM, plen - o), (int)__float_as_uint(my_v), my_fs + o);
+                for (int o = 0; o < my_len; o += ITEM, ++q)
+                    items[my_ib + q] = make_int4((my_r0 + o) * 4, min(ITEM, my_len - o), (int)__float_as_uint(my_v), my_fs + o);
             }
             __syncthreads();
             PHASE_END(PH_SEGMENTS);
-            // (uniform; the register-resident flow is first stage + one stage: it needs the first stage, see there)
-            rr = RR_MAX > 0 && n_items <= RR_MAX * NW && n_items >= NW && (p.k + NW - 1) / NW + 2 <= 16;
-            if constexpr (RR_MAX > 0) {
-                if (rr) {
-                    // item wave + NW*i in lane i (beyond the wave's share: the sentinel, which loads nothing)
-                    const int mine = wave + NW * lane;
-                    const int4 d = items[(mine < n_items) ? mine : n_items];
-                    rr_off = d.x; rr_cnt = d.y; rr_seg = d.z;
-#pragma unroll
-                    for (int i = 0; i < RR_MAX; ++i) rr_ids[i] = rr_load(rs_idx, i);
-                    rr_v0 = rr_load(rs_val, 0);
-                }
-            }
             // ---- sweep 1: column ids only.  Branch-free: every product ORs its bit into the bitmap; the returned
             // word tells whether the column was there already, in which case (only then a non-zero operand) the
             // column's bit is ORed into the collision bitmap as well. ----
@@ -367,7 +291,7 @@ __global__ __launch_bounds__(NT, (WIN ? 4 : 1)) void sp_knn_sparse_kernel(const 
                 // a trip then gets its scalars with v_readlane instead of an LDS round trip.
                 // visited back to front: what sweep 1 reads last is what sweep 2 reads first (L2 still holds it)
                 const int n_mine = (n_items - wave + NW - 1) / NW;       // items wave, wave+NW, ...
-                const int4 myd = (RR_MAX > 0 && rr) ? make_int4(0, 0, 0, 0) : items[(lane < n_mine) ? wave + NW * (n_mine - 1 - lane) : n_items];
+                const int4 myd = items[(lane < n_mine) ? wave + NW * (n_mine - 1 - lane) : n_items];
                 // a trip = two items (eight columns per lane): twice the loads and twice the LDS atomics in flight per wait
                 auto ld = [&](int trip, unsigned (&c)[8], int &cnt0, int &cnt1) __attribute__((always_inline)) {
                     const int t0 = min(2 * trip, 63), t1 = min(2 * trip + 1, 63);
@@ -408,41 +332,19 @@ __global__ __launch_bounds__(NT, (WIN ? 4 : 1)) void sp_knn_sparse_kernel(const 
                     }
                     __builtin_amdgcn_s_setprio(0);
                 };
-                bool streamed = true;
-                if constexpr (RR_MAX > 0) {
-                    if (rr) {
-                        // register-resident: the ids are (arriving) in rr_ids, pairs of items as the core takes them
-                        streamed = false;
-#pragma unroll
-                        for (int q = 0; q < RR_MAX / 2; ++q) {
-                            const int cnt0 = __builtin_amdgcn_readlane(rr_cnt, 2 * q), cnt1 = __builtin_amdgcn_readlane(rr_cnt, 2 * q + 1);
-                            const unsigned c[8] = {rr_ids[2 * q].x, rr_ids[2 * q].y, rr_ids[2 * q].z, rr_ids[2 * q].w,
-                                                   rr_ids[2 * q + 1].x, rr_ids[2 * q + 1].y, rr_ids[2 * q + 1].z, rr_ids[2 * q + 1].w};
-                            body(c, cnt0, cnt1);
-                        }
-                    }
-                }
-                if (streamed) {
-                    unsigned cA[8], cB[8];
-                    int nA0 = 0, nA1 = 0, nB0 = 0, nB1 = 0;
-                    const int n_trips = (n_mine + 1) / 2;
-                    int trip = 0;
-                    ld(0, cA, nA0, nA1);
-                    while (trip < n_trips) {      // two pairs (4 KiB) in flight per wave (a third measured slower); bodies skip the sentinel
-                        ld(trip + 1, cB, nB0, nB1);
-                        __builtin_amdgcn_sched_barrier(0);     // the prefetch is issued before the current pair is waited for
-                        body(cA, nA0, nA1);
-                        ld(trip + 2, cA, nA0, nA1);
-                        __builtin_amdgcn_sched_barrier(0);
-                        body(cB, nB0, nB1);
-                        trip += 2;
-                    }
-                }
-            }
-            if constexpr (RR_MAX > 0) {
-                if (rr) {      // values of items 1 .. RR_RING: they arrive while the bitmap is cleared and the first stage runs
-#pragma unroll
-                    for (int i = 1; i <= RR_RING; ++i) rr_ring[i - 1] = rr_load(rs_val, i);
+                unsigned cA[8], cB[8];
+                int nA0 = 0, nA1 = 0, nB0 = 0, nB1 = 0;
+                const int n_trips = (n_mine + 1) / 2;
+                int trip = 0;
+                ld(0, cA, nA0, nA1);
+                while (trip < n_trips) {      // two pairs (4 KiB) in flight per wave (a third measured slower); bodies skip the sentinel
+                    ld(trip + 1, cB, nB0, nB1);
+                    __builtin_amdgcn_sched_barrier(0);     // the prefetch is issued before the current pair is waited for
+                    body(cA, nA0, nA1);
+                    ld(trip + 2, cA, nA0, nA1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    body(cB, nB0, nB1);
+                    trip += 2;
                 }
             }
             if constexpr (MONO) {
@@ -453,17 +355,16 @@ __global__ __launch_bounds__(NT, (WIN ? 4 : 1)) void sp_knn_sparse_kernel(const 
                     const int f0 = __builtin_amdgcn_readfirstlane(p.f_indptr[t]), f1 = __builtin_amdgcn_readfirstlane(p.f_indptr[t + 1]);
                     for (int i = f0 + tid; i < f1; i += NT) {
                         const unsigned c = (unsigned)p.f_indices[i];
-                        if (c - wlo < wspan) atomicOr((unsigned *)(cbm + ((c >> 3) & cmask)), 1u << (c & 31u));     // (this window's columns)
+                        atomicOr((unsigned *)(cbm + ((c >> 3) & cmask)), 1u << (c & 31u));
                     }
                 }
             }
             __syncthreads();
             PHASE_END(PH_SWEEP1);
             // next row's m2 row bounds (its m1 entries were requested at the top of this row)
-            if (win == 0 && dN.x >= 0 && tid < dN.w) {
+            if (dN.x >= 0 && tid < dN.w) {
                 nx_r0 = p.m2_indptr[nx_u];
                 nx_len = p.m2_indptr[nx_u + 1] - nx_r0;
-                if (WIN && n_win > 1) nx_sp = p.m2_split[nx_u];
             }
             // the bitmap has done its job: back to zero (16-byte stores); its storage now serves sweep 2
             for (int i = tid; i < (nb_bytes >> 4); i += NT) ((int4 *)rA)[i] = make_int4(0, 0, 0, 0);
@@ -498,19 +399,11 @@ __global__ __launch_bounds__(NT, (WIN ? 4 : 1)) void sp_knn_sparse_kernel(const 
                 }
                 if (carry > CSN / 2) failed = true;      // more marked columns than direct slots (uniform)
             }
-            if (WIN && win > 0) {
-                // the candidate buffer comes back from the histogram area (which goes back to zero)
-                u64 *stash = (u64 *)hist4;
-                for (int i = tid; i < n_stash; i += NT) { U[i] = stash[i]; stash[i] = 0ull; }
-                if (tid == 0) sh[SH_CNT] = n_stash;
-                __syncthreads();
-            }
             PHASE_END(PH_SEGMENTS);  // (bitmap clear)
-        } else if (win == 0) {
+        } else {
             if (dN.x >= 0 && tid < dN.w) {
                 nx_r0 = p.m2_indptr[nx_u];
                 nx_len = p.m2_indptr[nx_u + 1] - nx_r0;
-                if (WIN && n_win > 1) nx_sp = p.m2_split[nx_u];
             }
         }
 
@@ -525,20 +418,11 @@ __global__ __launch_bounds__(NT, (WIN ? 4 : 1)) void sp_knn_sparse_kernel(const 
             // k*m/n of the next m would survive in an exchangeable stream — far fewer here, because segments come
             // in descending weight — so the next chunk may be 4*n*(cap-k)/k long.
             const int room = cap - min(p.k, cap - 1);
-            const bool final_win = (win == n_win - 1);
             int i0 = 0;
             int chunk_items = max(1, (MONO ? room : min(room, spcap - 2 * ITEM)) / ITEM);     // items of the next stage
-            if (WIN && win > 0 && rc.have_thr) {
-                // a later window starts with the cutoff of the earlier ones: sized like any later stage (see the end of the loop)
-                const float left = (float)max(64, cap - min(n_stash, cap));
-                const float cnt_u = (float)max(2 * p.k, min(n_stash, cap));
-                float ch = fmaxf((float)ITEM, 2.f * seen_before * left / cnt_u);
-                if (!MONO) ch = fmaxf(ch, (float)room);
-                chunk_items = max(1, (int)fminf(ch * (1.f / ITEM), 1e6f));
-            }
             bool last_stage = false;
             bool force_sel = false;
-            WavePool wpm{0, -1};      // member-pool window: lives across the stages of the window
+            WavePool wpm{0, -1};      // member-pool window: lives across the stages of the row
 
             // ---- MONO, first stage without any selection.  One item per wave (the first NW items: the heaviest
             // segments).  Every wave finds, among the per-lane maxima of its single products, the m-th largest
@@ -549,8 +433,8 @@ __global__ __launch_bounds__(NT, (WIN ? 4 : 1)) void sp_knn_sparse_kernel(const 
             // in fewer items, select afterwards"). ----
             if constexpr (MONO) {
                 const int NA = min(n_items, NW);
-                const int mrounds = (p.k + NW - 1) / NW + 2;
-                if (win == 0 && NA == NW && mrounds <= 16) {     // (k <= 14*NW; larger k: the accept-everything first stage of the loop below)
+                const int mrounds = (p.k + NA - 1) / NA + 2;
+                if (NA == NW && mrounds <= 16) {     // (k <= 14*NW; larger k: the accept-everything first stage of the loop below)
                     unsigned c[4];
                     float v[4], x[4];
                     u64 M[4], S[4];
@@ -560,16 +444,12 @@ __global__ __launch_bounds__(NT, (WIN ? 4 : 1)) void sp_knn_sparse_kernel(const 
                     {
                         const int off = __builtin_amdgcn_readfirstlane(d.x);
                         const float segv = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane(d.z));
-                        u32x4 a, b;
-                        if (RR_MAX > 0 && rr) { a = rr_ids[0]; b = rr_v0; }      // (item `wave` is the wave's own first item)
-                        else {
-                            const int vo = (4 * lane < cntA) ? lane * 16 : (int)(OOB_SOFFSET - (unsigned)off);
-                            a = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, vo, off, 0);
-                            b = __builtin_amdgcn_raw_buffer_load_b128(rs_val, vo, off, 0);
-                        }
+                        const int vo = (4 * lane < cntA) ? lane * 16 : (int)(OOB_SOFFSET - (unsigned)off);
+                        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, vo, off, 0);
+                        const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs_val, vo, off, 0);
                         c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w;
                         v[0] = __uint_as_float(b.x); v[1] = __uint_as_float(b.y); v[2] = __uint_as_float(b.z); v[3] = __uint_as_float(b.w);
-                        s2_core<CBMB>(c, v, segv, cutx, x, M, S);
+                        s2_core(c, v, segv, cutx, x, M, S);
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -665,101 +545,13 @@ __global__ __launch_bounds__(NT, (WIN ? 4 : 1)) void sp_knn_sparse_kernel(const 
             if (i0 >= n_items && !failed && i0 > 0) {
                 // (all items went through the first stage: let the loop run its last-stage part with an empty sweep)
             }
-                float cut = 0.f;          // raw-dot cutoff of the running stage (set at its start)
-                WavePool wps{0, -1};      // survivor window of the running stage
-                auto body = [&](const unsigned (&c)[4], const float (&v)[4], int cnt, float segv) __attribute__((always_inline)) {
-                    if (cnt == 0) return;                  // sentinel (wave-uniform)
-#if SP_ABLATION
-                    if (p.dbg & 16) { asm volatile("" ::"v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); return; }   // ablation: loads only
-#endif
-                    // M: product of a marked column; S: otherwise the product is the only one of its column and
-                    // matters only if its raw dot can still enter the top-k (NaN stays: the exact judge drops it)
-                    __builtin_amdgcn_s_setprio(3);
-                    float x[4];
-                    u64 M[4], S[4];
-                    s2_core<CBMB>(c, v, segv, cut, x, M, S);
-                    if (cnt != ITEM) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const u64 ok = __ballot(4 * lane + j < cnt);
-                            M[j] &= ok;
-                            S[j] &= ok;
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) S[j] &= ~M[j];
-                    if ((M[0] | M[1]) | (M[2] | M[3])) {
-                        const int n0 = __popcll(M[0]), n1 = __popcll(M[1]), n2 = __popcll(M[2]), n3 = __popcll(M[3]);
-                        if (pool_reserve(wpm, n0 + n1 + n2 + n3, &sh[SH_MCTR], mpcap, &sh[SH_OVF])) {
-                            int pos = wpm.pos;
-                            lds_push64(M[0], __float_as_uint(x[0]), c[0] + 1u, pos, mpool_off); pos += n0;
-                            lds_push64(M[1], __float_as_uint(x[1]), c[1] + 1u, pos, mpool_off); pos += n1;
-                            lds_push64(M[2], __float_as_uint(x[2]), c[2] + 1u, pos, mpool_off); pos += n2;
-                            lds_push64(M[3], __float_as_uint(x[3]), c[3] + 1u, pos, mpool_off);
-                            wpm.pos = pos + n3;
-                        }
-                    }
-                    if ((S[0] | S[1]) | (S[2] | S[3])) {
-                        const int n0 = __popcll(S[0]), n1 = __popcll(S[1]), n2 = __popcll(S[2]), n3 = __popcll(S[3]);
-                        if constexpr (MONO) {
-                            // straight into the candidate buffer, keyed by the raw dot
-                            if (pool_reserve<16>(wps, n0 + n1 + n2 + n3, &sh[SH_CNT], cap, &sh[SH_OVF])) {     // small blocks: U is short of room
-                                int pos = wps.pos;
-                                if constexpr (U_LDS) {
-                                    lds_push64(S[0], c[0], fkey(x[0]), pos, u_off); pos += n0;
-                                    lds_push64(S[1], c[1], fkey(x[1]), pos, u_off); pos += n1;
-                                    lds_push64(S[2], c[2], fkey(x[2]), pos, u_off); pos += n2;
-                                    lds_push64(S[3], c[3], fkey(x[3]), pos, u_off);
-                                } else {
-                                    if ((S[0] >> lane) & 1ull) U[pos + mbcnt64(S[0])] = ((u64)fkey(x[0]) << 32) | (u64)c[0];
-                                    pos += n0;
-                                    if ((S[1] >> lane) & 1ull) U[pos + mbcnt64(S[1])] = ((u64)fkey(x[1]) << 32) | (u64)c[1];
-                                    pos += n1;
-                                    if ((S[2] >> lane) & 1ull) U[pos + mbcnt64(S[2])] = ((u64)fkey(x[2]) << 32) | (u64)c[2];
-                                    pos += n2;
-                                    if ((S[3] >> lane) & 1ull) U[pos + mbcnt64(S[3])] = ((u64)fkey(x[3]) << 32) | (u64)c[3];
-                                }
-                                wps.pos = pos + n3;
-                            }
-                        } else {
-                            if (pool_reserve(wps, n0 + n1 + n2 + n3, &sh[SH_PCTR], spcap, &sh[SH_OVF])) {
-                                int pos = wps.pos;
-                                lds_push64(S[0], __float_as_uint(x[0]), c[0] + 1u, pos, spool_off); pos += n0;
-                                lds_push64(S[1], __float_as_uint(x[1]), c[1] + 1u, pos, spool_off); pos += n1;
-                                lds_push64(S[2], __float_as_uint(x[2]), c[2] + 1u, pos, spool_off); pos += n2;
-                                lds_push64(S[3], __float_as_uint(x[3]), c[3] + 1u, pos, spool_off);
-                                wps.pos = pos + n3;
-                            }
-                        }
-                    }
-                    __builtin_amdgcn_s_setprio(0);
-                };
-            if constexpr (RR_MAX > 0) {
-                // ---- register-resident rows: ONE stage over everything behind the first stage, ids from registers, values
-                // through the ring (its first fill has been in flight since the end of sweep 1) ----
-                if (rr && !failed && rc.have_thr && !force_sel && i0 == NW) {
-                    cut = MONO ? cutx : rc.xy_cut;
-#pragma unroll
-                    for (int i = 1; i < RR_MAX; ++i) {
-                        const int cnt = __builtin_amdgcn_readlane(rr_cnt, i);
-                        const float segv = __uint_as_float((unsigned)__builtin_amdgcn_readlane(rr_seg, i));
-                        const u32x4 vv = rr_ring[(i - 1) % RR_RING];
-                        const unsigned c[4] = {rr_ids[i].x, rr_ids[i].y, rr_ids[i].z, rr_ids[i].w};
-                        const float v[4] = {__uint_as_float(vv.x), __uint_as_float(vv.y), __uint_as_float(vv.z), __uint_as_float(vv.w)};
-                        body(c, v, cnt, segv);
-                        if (i + RR_RING < RR_MAX) rr_ring[(i - 1) % RR_RING] = rr_load(rs_val, i + RR_RING);
-                    }
-                    i0 = n_items;      // (the loop below runs its last-stage part with an empty sweep)
-                }
-            }
             while (!last_stage && !failed) {
                 // (force_sel: the first stage's cutoff is loose — far more than k products reached it: tighten it with a
                 // selection before sweeping on, i.e. run this round with an empty sweep)
                 const int i1 = (force_sel && i0 < n_items) ? i0 : min(n_items, i0 + chunk_items);
                 {
                     // ---- sweep 2 over items [i0, i1) ----
-                    wps = WavePool{0, -1};
-                    cut = MONO ? cutx : rc.xy_cut;
+                    WavePool wps{0, -1};
                     // item i0 + wave + NW*i of this stage in lane i (beyond the stage: the sentinel)
                     int4 myd;
                     {
@@ -778,23 +570,89 @@ __global__ __launch_bounds__(NT, (WIN ? 4 : 1)) void sp_knn_sparse_kernel(const 
                         c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w;
                         v[0] = __uint_as_float(b.x); v[1] = __uint_as_float(b.y); v[2] = __uint_as_float(b.z); v[3] = __uint_as_float(b.w);
                     };
-                    {
-                        unsigned cA[4], cB[4];
-                        float vA[4], vB[4];
-                        int nA = 0, nB = 0;
-                        float sA = 0.f, sB = 0.f;
-                        const int n_trips = (i1 - i0 - wave + NW - 1) / NW;
-                        int trip = 0;
-                        ld(0, cA, vA, nA, sA);
-                        while (trip < n_trips) {      // two items (4 KiB) in flight per wave; bodies skip the sentinel
-                            ld(trip + 1, cB, vB, nB, sB);
-                            __builtin_amdgcn_sched_barrier(0);     // the prefetch is issued before the current item is waited for
-                            body(cA, vA, nA, sA);
-                            ld(trip + 2, cA, vA, nA, sA);
-                            __builtin_amdgcn_sched_barrier(0);
-                            body(cB, vB, nB, sB);
-                            trip += 2;
+                    const float cut = MONO ? cutx : rc.xy_cut;
+                    auto body = [&](const unsigned (&c)[4], const float (&v)[4], int cnt, float segv) __attribute__((always_inline)) {
+                        if (cnt == 0) return;                  // sentinel (wave-uniform)
+#if SP_ABLATION
+                        if (p.dbg & 16) { asm volatile("" ::"v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); return; }   // ablation: loads only
+#endif
+                        // M: product of a marked column; S: otherwise the product is the only one of its column and
+                        // matters only if its raw dot can still enter the top-k (NaN stays: the exact judge drops it)
+                        __builtin_amdgcn_s_setprio(3);
+                        float x[4];
+                        u64 M[4], S[4];
+                        s2_core(c, v, segv, cut, x, M, S);
+                        if (cnt != ITEM) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const u64 ok = __ballot(4 * lane + j < cnt);
+                                M[j] &= ok;
+                                S[j] &= ok;
+                            }
                         }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) S[j] &= ~M[j];
+                        if ((M[0] | M[1]) | (M[2] | M[3])) {
+                            const int n0 = __popcll(M[0]), n1 = __popcll(M[1]), n2 = __popcll(M[2]), n3 = __popcll(M[3]);
+                            if (pool_reserve(wpm, n0 + n1 + n2 + n3, &sh[SH_MCTR], mpcap, &sh[SH_OVF])) {
+                                int pos = wpm.pos;
+                                lds_push64(M[0], __float_as_uint(x[0]), c[0] + 1u, pos, mpool_off); pos += n0;
+                                lds_push64(M[1], __float_as_uint(x[1]), c[1] + 1u, pos, mpool_off); pos += n1;
+                                lds_push64(M[2], __float_as_uint(x[2]), c[2] + 1u, pos, mpool_off); pos += n2;
+                                lds_push64(M[3], __float_as_uint(x[3]), c[3] + 1u, pos, mpool_off);
+                                wpm.pos = pos + n3;
+                            }
+                        }
+                        if ((S[0] | S[1]) | (S[2] | S[3])) {
+                            const int n0 = __popcll(S[0]), n1 = __popcll(S[1]), n2 = __popcll(S[2]), n3 = __popcll(S[3]);
+                            if constexpr (MONO) {
+                                // straight into the candidate buffer, keyed by the raw dot
+                                if (pool_reserve<16>(wps, n0 + n1 + n2 + n3, &sh[SH_CNT], cap, &sh[SH_OVF])) {     // small blocks: U is short of room
+                                    int pos = wps.pos;
+                                    if constexpr (U_LDS) {
+                                        lds_push64(S[0], c[0], fkey(x[0]), pos, u_off); pos += n0;
+                                        lds_push64(S[1], c[1], fkey(x[1]), pos, u_off); pos += n1;
+                                        lds_push64(S[2], c[2], fkey(x[2]), pos, u_off); pos += n2;
+                                        lds_push64(S[3], c[3], fkey(x[3]), pos, u_off);
+                                    } else {
+                                        if ((S[0] >> lane) & 1ull) U[pos + mbcnt64(S[0])] = ((u64)fkey(x[0]) << 32) | (u64)c[0];
+                                        pos += n0;
+                                        if ((S[1] >> lane) & 1ull) U[pos + mbcnt64(S[1])] = ((u64)fkey(x[1]) << 32) | (u64)c[1];
+                                        pos += n1;
+                                        if ((S[2] >> lane) & 1ull) U[pos + mbcnt64(S[2])] = ((u64)fkey(x[2]) << 32) | (u64)c[2];
+                                        pos += n2;
+                                        if ((S[3] >> lane) & 1ull) U[pos + mbcnt64(S[3])] = ((u64)fkey(x[3]) << 32) | (u64)c[3];
+                                    }
+                                    wps.pos = pos + n3;
+                                }
+                            } else {
+                                if (pool_reserve(wps, n0 + n1 + n2 + n3, &sh[SH_PCTR], spcap, &sh[SH_OVF])) {
+                                    int pos = wps.pos;
+                                    lds_push64(S[0], __float_as_uint(x[0]), c[0] + 1u, pos, spool_off); pos += n0;
+                                    lds_push64(S[1], __float_as_uint(x[1]), c[1] + 1u, pos, spool_off); pos += n1;
+                                    lds_push64(S[2], __float_as_uint(x[2]), c[2] + 1u, pos, spool_off); pos += n2;
+                                    lds_push64(S[3], __float_as_uint(x[3]), c[3] + 1u, pos, spool_off);
+                                    wps.pos = pos + n3;
+                                }
+                            }
+                        }
+                        __builtin_amdgcn_s_setprio(0);
+                    };
+                    unsigned cA[4], cB[4];
+                    float vA[4], vB[4];
+                    int nA = 0, nB = 0;
+                    float sA = 0.f, sB = 0.f;
+                    const int n_trips = (i1 - i0 - wave + NW - 1) / NW;
+                    int trip = 0;
+                    ld(0, cA, vA, nA, sA);
+                    while (trip < n_trips) {      // two items (4 KiB) in flight per wave; bodies skip the sentinel
+                        ld(trip + 1, cB, vB, nB, sB);
+                        __builtin_amdgcn_sched_barrier(0);     // the prefetch is issued before the current item is waited for
+                        body(cA, vA, nA, sA);
+                        ld(trip + 2, cA, vA, nA, sA);
+                        __builtin_amdgcn_sched_barrier(0);
+                        body(cB, vB, nB, sB);
+                        trip += 2;
                     }
                 }
                 i0 = i1;
@@ -959,9 +817,7 @@ __global__ __launch_bounds__(NT, (WIN ? 4 : 1)) void sp_knn_sparse_kernel(const 
                     // selection: forced when U overflowed; exact after the last stage (final top-k); between stages
                     // when U is filling up (it raises the running k-th value, which is the cutoff of the next stage)
                     const int n_eff = min(n_now, cap);
-                    // (the last stage of a window that is not the row's last: the buffer must fit the stash and carry a cutoff)
-                    const bool want_sel = retry || ((last_stage && final_win) ? (n_eff > p.k)
-                                                   : (n_eff > p.k && (!rc.have_thr || force_sel || 2 * n_eff > cap + p.k || (last_stage && n_eff > STASH_CAP))));
+                    const bool want_sel = retry || (last_stage ? (n_eff > p.k) : (n_eff > p.k && (!rc.have_thr || force_sel || 2 * n_eff > cap + p.k)));
                     force_sel = false;
                     if (want_sel) {
                         long long thr_new;
@@ -988,7 +844,7 @@ __global__ __launch_bounds__(NT, (WIN ? 4 : 1)) void sp_knn_sparse_kernel(const 
                 // next chunk: with the k-th best of `pos` products as cutoff, an exchangeable stream lets k*m/pos of the
                 // next m products through; keep that below half of the room left in U (far fewer pass when the
                 // segments come in descending weight)
-                const float pos = seen_before + (float)items[min(i0, n_items)].w;      // (the sentinel holds the window's total)
+                const float pos = (i0 < n_items) ? (float)items[i0].w : (float)macs32;
                 const float left = (float)max(64, cap - min(sh[SH_CNT], cap));
                 // (the cutoff is the value that `cnt` of the `pos` products offered so far reach: cnt ~ k after a selection, more
                 // after the selection-free first stage)
@@ -998,32 +854,6 @@ __global__ __launch_bounds__(NT, (WIN ? 4 : 1)) void sp_knn_sparse_kernel(const 
                 chunk_items = max(1, (int)fminf(ch * (1.f / ITEM), 1e6f));
             }
         }
-
-        if constexpr (MONO) {
-            if (!failed && p.filter_mode == SP_SEL_MATRIX) {      // marks of this window's excluded columns that no product reached
-                const int f0 = __builtin_amdgcn_readfirstlane(p.f_indptr[t]), f1 = __builtin_amdgcn_readfirstlane(p.f_indptr[t + 1]);
-                for (int i = f0 + tid; i < f1; i += NT) {
-                    const unsigned c = (unsigned)p.f_indices[i];
-                    if (c - wlo < wspan) atomicAnd((unsigned *)(cbm + ((c >> 3) & cmask)), ~(1u << (c & 31u)));
-                }
-            }
-        }
-        if (WIN && win < n_win - 1) {
-            // between two windows: region A becomes the next window's bitmap, the candidates wait in the histogram area
-            __syncthreads();
-            if (!failed) {
-                n_stash = min(sh[SH_CNT], cap);
-                if (n_stash > STASH_CAP) failed = true;      // (cannot happen: the window's last stage selects down to k <= STASH_CAP)
-                else {
-                    u64 *stash = (u64 *)hist4;
-                    for (int i = tid; i < n_stash; i += NT) { stash[i] = U[i]; U[i] = 0ull; }
-                }
-                seen_before += (float)win_macs;
-            }
-            if (tid == 0) { sh[SH_PCTR] = 0; sh[SH_MCTR] = 0; sh[SH_NITEMS] = 0; sh[SH_WMACS] = 0; sh[SH_CNT] = 0; }
-            __syncthreads();
-        }
-        }      // windows
 
         if (!failed) {
             // ================= write-out =================
@@ -1079,6 +909,15 @@ __global__ __launch_bounds__(NT, (WIN ? 4 : 1)) void sp_knn_sparse_kernel(const 
                 }
             }
             if (tid == 0 && p.counts) p.counts[slot_i] = n_out;
+            if constexpr (MONO) {
+                if (p.filter_mode == SP_SEL_MATRIX) {      // marks of excluded columns that no product reached
+                    const int f0 = __builtin_amdgcn_readfirstlane(p.f_indptr[t]), f1 = __builtin_amdgcn_readfirstlane(p.f_indptr[t + 1]);
+                    for (int i = f0 + tid; i < f1; i += NT) {
+                        const unsigned c = (unsigned)p.f_indices[i];
+                        atomicAnd((unsigned *)(cbm + ((c >> 3) & cmask)), ~(1u << (c & 31u)));
+                    }
+                }
+            }
             if (U_LDS || MONO) {
                 // U's storage is part of the next row's bitmap (LDS) / holes must read zero (MONO).  Every selection zeroes
                 // what lies behind the entries it keeps, so only the first k entries can be non-zero here.
@@ -1108,7 +947,7 @@ __global__ __launch_bounds__(NT, (WIN ? 4 : 1)) void sp_knn_sparse_kernel(const 
                        __builtin_amdgcn_readfirstlane(dNN.z), __builtin_amdgcn_readfirstlane(dNN.w));
         wN = make_int4(__builtin_amdgcn_readfirstlane(wNN.x), __builtin_amdgcn_readfirstlane(wNN.y),
                        __builtin_amdgcn_readfirstlane(wNN.z), __builtin_amdgcn_readfirstlane(wNN.w));
-        my_r0 = nx_r0; my_len = nx_len; my_v = nx_v; my_sp = nx_sp;
+        my_r0 = nx_r0; my_len = nx_len; my_v = nx_v;
         __syncthreads();
         PHASE_END(PH_OUTPUT);
     }

@@ -105,8 +105,6 @@ class DeviceProblem:
             flags |= _abi.SP_FLAG_NO_FOLD
         if tuning.get("no_row_order"):
             flags |= _abi.SP_FLAG_NO_ROW_ORDER
-        if tuning.get("duo"):
-            flags |= _abi.SP_FLAG_DUO
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream().cuda_stream
             a = self._args(targets_t, n, cols, vals, counts, rows, stream, flags, tuning)

@@ -542,80 +542,3 @@ def test_public_call_device_transpose_edge_shapes():
     m64 = sp.random_array((300, 80), density=0.1, format="csc", dtype=np.float64, random_state=rng)
     chk(m64, 9, binary=True); chk(m64, 9, shrink=2.0)
     chk(sp.csr_array(rng.integers(0, 3, (60, 40)).astype(np.int64)), 4)
-
-
-# ---------------------------------------------------------------------------------------------
-# sparse kernel, two-workgroups-per-CU shape ("duo": 512 threads, exact 2^19-bit bitmap, column WINDOWS)
-# ---------------------------------------------------------------------------------------------
-@pytest.fixture(scope="module")
-def duo_matrices():
-    """m (600k x 20k, 24 per row): m @ m.T has 600k output columns = two windows; ~17k products per row.
-    The first 400k rows alone give one window (<= 2^19 columns)."""
-    from similaripy_amd.workloads import fixed_degree_csr
-    m = fixed_degree_csr(600_000, 20_000, 24, 77)
-    # a few long rows (> 64 entries: the all-pairs segment order) and signed values further down
-    return m
-
-
-def _duo_check(call, what, rtol=RTOL, expect_wgs=512, duo=True, **tuning):
-    rows, cols, vals, counts, info = _host.run_hip(call, time_kernel=True, duo=duo, **tuning)
-    k = call.k
-    ph = info["phase_cycles"]
-    assert info["num_wgs"] == expect_wgs, (what, info["num_wgs"])
-    got = so.canonical(rows, cols, vals, call.targets, k)
-    want = so.canonical(*so.run_kernel(call, "port"), call.targets, k)
-    so.compare_topk(got, want, k, rtol=rtol, atol=ATOL, what=what)
-    return ph
-
-
-@pytest.mark.parametrize("n_rows,name,kw", [
-    (600_000, "cosine_2win", dict(l2=1)),
-    (600_000, "dot_2win", dict()),
-    (600_000, "hybrid_2win", dict(l1=0.5, l2=0.5, stabilized_shrink=10.0)),
-    (600_000, "jaccard_threshold_2win", dict(l1=1, threshold=0.02)),
-    (400_000, "cosine_1win", dict(l2=1)),
-    (400_000, "tversky_bayes_1win", dict(l1=1, t1=0.8, t2=0.4, bayesian_shrink=5.0)),
-], ids=lambda x: x if isinstance(x, str) else None)
-def test_sparse_kernel_duo_shape(duo_matrices, n_rows, name, kw):
-    m = duo_matrices[:n_rows]
-    targets = np.sort(np.random.default_rng(3).choice(n_rows, 1500, replace=False)).astype(np.int32)
-    for k in (100, 300):
-        call = _host.prepare(m, k=k, target_rows=targets, **kw)
-        ph = _duo_check(call, f"duo {name} k={k}")
-        assert ph[9] + ph[10] == targets.shape[0] and ph[9] >= 0.95 * targets.shape[0], (name, k, ph[9], ph[10])
-    # same rows without the duo shape: identical sets (A/B switch works)
-    call = _host.prepare(m, k=100, target_rows=targets[:200], **kw)
-    _duo_check(call, f"no-duo {name}", duo=False, expect_wgs=200)
-
-
-def test_sparse_kernel_duo_filter_matrix_signed_and_long_rows(duo_matrices):
-    """dot_product with a MATRIX filter (the user-scoring idiom) through the windowed kernel; signed data; rows with more
-    than 64 entries (all-pairs segment order) and rows whose second window is empty."""
-    base = duo_matrices
-    rng = np.random.default_rng(9)
-    m = base.copy()
-    m.data = (m.data - 0.3).astype(np.float32)                 # signed
-    m.data[m.data == 0] = np.float32(0.25)
-    # long rows: rows 0..49 get 150 entries each
-    long_rows = sp.random_array((50, m.shape[1]), density=150 / m.shape[1], format="csr", dtype=np.float32, random_state=rng)
-    m = sp.vstack([long_rows, m[50:]], format="csr")
-    m.sort_indices()
-    n = m.shape[0]
-    targets = np.concatenate((np.arange(0, 50), np.sort(rng.choice(np.arange(50, n), 800, replace=False)))).astype(np.int32)
-    filt = sp.random_array((n, n), density=3e-5, format="csr", dtype=np.float32, random_state=rng)      # ~18 excluded columns per row, both windows
-    call = _host.prepare(m, k=50, target_rows=targets, filter_cols=filt, threshold=-1e30)
-    assert call.filter_mode == _host.MODE_MATRIX
-    _duo_check(call, "duo dot + MATRIX filter, signed")
-    call = _host.prepare(m, k=50, l2=1, target_rows=targets, filter_cols=filt)
-    _duo_check(call, "duo cosine + MATRIX filter, signed")
-    # target MATRIX selector: the general variant
-    tsel = sp.random_array((n, n), density=2e-4, format="csr", dtype=np.float32, random_state=rng)
-    call = _host.prepare(m, k=20, l2=1, target_rows=targets, target_cols=tsel)
-    _duo_check(call, "duo cosine + MATRIX target selector")
-    # a matrix whose rows only reach the FIRST window's columns from most segments: m2 = explicit, columns skewed
-    m2 = m.T.tocsr()
-    keep = (m2.indices < (1 << 19)) | (rng.random(m2.nnz) < 0.02)
-    m2.data = (m2.data * keep).astype(np.float32)
-    m2.eliminate_zeros()
-    call = _host.prepare(m, m2, k=100, l2=1, target_rows=targets)
-    _duo_check(call, "duo, nearly empty second window")
