@@ -45,6 +45,7 @@ extern "C" {
 #define SP_EHIP         -3   /* a HIP runtime call failed (see sp_last_error) */
 #define SP_ENOMEM       -4
 #define SP_EWORKSPACE   -5   /* caller workspace too small */
+#define SP_EZEROS       -6   /* SP_FLAG_CHECK_ZEROS: the matrices hold explicit zeros (see explicit_zeros); nothing was computed */
 
 /* flags */
 #define SP_FLAG_TIME_KERNEL   1u  /* bracket device work with hipEvents on `stream`, sync, fill kernel_ms */
@@ -57,6 +58,20 @@ extern "C" {
                                      the m2_* pointers and nnz_m2 are ignored (may be NULL / 0), n_rows_m2 = columns of m1,
                                      n_output_cols must equal n_rows_m1.  See sp_prep.h. */
 #define SP_FLAG_PHASE_TIMERS  64u /* with SP_FLAG_TIME_KERNEL: also run the in-kernel phase timers (s_memtime, ~1-2 % slower) */
+/* host mode (on_device = 0) only: the stages of s_plus.pyx that the reference runs on the host around its kernel */
+#define SP_FLAG_CHECK_ZEROS   256u /* count the stored entries of m1 (and of an explicit m2) that are 0 on the device, after the upload
+                                     (the reference calls eliminate_zeros() first, s_plus.pyx:210-211); if there are any, nothing is
+                                     computed, explicit_zeros holds the count and SP_EZEROS is returned: the caller drops them and calls again */
+#define SP_FLAG_CSR_OUT       512u /* assemble the CSR result on the device (build_csr_matrix utils.pyx:141-173 -> coo_to_csr.h:28-71 ->
+                                     eliminate_zeros s_plus.pyx:424): `targets` must be strictly increasing; csr_indptr receives the
+                                     n_rows_m1 + 1 row pointers, the first csr_nnz entries of `cols` / `values` the column ids and values of
+                                     the non-zero entries in row order (slot order inside a row); rows / out_counts are not written */
+#define SP_FLAG_P3_PREP      1024u /* with SP_FLAG_M2_IS_M1_T: the preprocessing of p3alpha / rp3beta (similarity.py:410-415, 477-483;
+                                     normalization.pyx:131-161) on the device: the rows of m1 and the rows of m2 = m1^T are divided by
+                                     their L1 norms, then every entry is raised to p3_alpha.  The caller's m1 is not modified. */
+#define SP_FLAG_DEPOP_ROWSUM 2048u /* with SP_FLAG_P3_PREP and l3 != 0: Ydepop[c] = (sum of the RAW row c of m1)^depop_p2, i.e. the column
+                                     popularity of the raw m2 = m1^T (similarity.py:479; np.power in float32, s_plus_utils.pyx:257-276),
+                                     built on the device; the Ydepop pointer is ignored */
 
 typedef struct sp_knn_args {
     uint32_t struct_size;      /* = sizeof(sp_knn_args); checked */
@@ -134,6 +149,13 @@ typedef struct sp_knn_args {
                                   call in microseconds (hipEvents on `stream` around each launch)
                                   [3] OUT with SP_FLAG_TIME_KERNEL | SP_FLAG_M2_IS_M1_T: duration of the transpose, microseconds
                                   (kernel_ms includes it) */
+
+    /* ABI 2: host-side stages of s_plus.pyx on the device */
+    float    p3_alpha;         /* SP_FLAG_P3_PREP */
+    float    depop_p2;         /* SP_FLAG_DEPOP_ROWSUM */
+    int32_t *csr_indptr;       /* SP_FLAG_CSR_OUT: OUT [n_rows_m1 + 1], caller-allocated */
+    int64_t  csr_nnz;          /* SP_FLAG_CSR_OUT: OUT */
+    int64_t  explicit_zeros;   /* SP_FLAG_CHECK_ZEROS: OUT */
 } sp_knn_args;
 
 /* The hot path.  Replaces compute_similarities_parallel<int,float> (s_plus.h:265). */
@@ -152,8 +174,13 @@ int sp_backend_info(int device, char *buf, int buflen);
 /* Last error message of the calling thread ("" if none). */
 const char *sp_last_error(void);
 
+/* The library keeps the device buffers of host-mode calls (operands, outputs, workspace) in a size-bucketed cache instead of
+   returning them to the driver after every call (hipMalloc / hipFree of GB-sized buffers cost milliseconds each).  This
+   releases the cache of the calling thread's current device; returns the bytes released. */
+int64_t sp_device_cache_trim(void);
+
 /* ABI version of this header. */
-#define SP_KNN_ABI_VERSION 1
+#define SP_KNN_ABI_VERSION 2
 int sp_abi_version(void);
 
 #ifdef __cplusplus

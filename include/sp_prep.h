@@ -78,6 +78,55 @@ typedef struct sp_csr_sqsums_args {
    = csr_sum(m1^2, axis=1) and csr_sum((m1^T)^2, axis=0) (:128-166), both from the rows of m1, bit-identical to NumPy. */
 int sp_csr_row_sqsums_f32(sp_csr_sqsums_args *args);
 
+/* ---- row normalisers ------------------------------------------------------------------------------
+ * In-place weighting of the rows of a CSR, the device counterpart of
+ *   inplace_normalize_csr_l1 / _l2 / _max      similaripy/cython_code/normalization.pyx:97-197
+ *   inplace_normalize_csr_tfidf                similaripy/cython_code/normalization.pyx:200-262
+ *   inplace_normalize_csr_bm25plus             similaripy/cython_code/normalization.pyx:265-334   (BM25 = delta 0)
+ * float32 or float64 data (the reference keeps either, normalization.py:23-40), int32 indices.  Sums are formed in the
+ * data type like the reference's, in a different order (wave reductions): results agree to a few ulp. */
+#define SP_NORM_L1       0
+#define SP_NORM_L2       1
+#define SP_NORM_MAX      2
+#define SP_NORM_TFIDF    3
+#define SP_NORM_BM25PLUS 4
+/* tf / idf modes in the order of the reference's enums (normalization.pyx:12-24) */
+#define SP_TF_BINARY 0
+#define SP_TF_RAW    1
+#define SP_TF_SQRT   2
+#define SP_TF_FREQ   3
+#define SP_TF_LOG    4
+#define SP_IDF_UNARY  0
+#define SP_IDF_BASE   1
+#define SP_IDF_SMOOTH 2
+#define SP_IDF_PROB   3
+#define SP_IDF_BM25   4
+
+typedef struct sp_csr_normalize_args {
+    uint32_t struct_size;      /* = sizeof(sp_csr_normalize_args); checked */
+    uint32_t flags;            /* SP_FLAG_TIME_KERNEL or 0 */
+    int32_t  on_device;        /* 0: host pointers (H2D, kernels, D2H of data); 1: device pointers, asynchronous on `stream` */
+    int32_t  device;
+    int32_t  n_rows;           /* documents */
+    int32_t  n_cols;           /* terms */
+    int64_t  nnz;
+    int32_t  dtype;            /* 0 = float32, 1 = float64 */
+    int32_t  mode;             /* SP_NORM_* */
+    void          *data;       /* [nnz] IN / OUT */
+    const int32_t *indices;    /* [nnz]; read by TFIDF / BM25PLUS only (may be NULL otherwise) */
+    const int32_t *indptr;     /* [n_rows + 1] */
+    int32_t  tf_mode;          /* SP_TF_*  (TFIDF / BM25PLUS) */
+    int32_t  idf_mode;         /* SP_IDF_* (TFIDF / BM25PLUS) */
+    double   k1, b, delta;     /* BM25PLUS (BM25: delta = 0) */
+    double   logbase;          /* TFIDF / BM25PLUS */
+    double   pow_alpha;        /* L1 / L2 / MAX: entries are raised to this power afterwards when != 1 (similarity.py:411, 413) */
+    void    *stream;           /* device mode */
+    float    kernel_ms;        /* OUT with SP_FLAG_TIME_KERNEL */
+    int32_t  _pad0;
+} sp_csr_normalize_args;
+
+int sp_csr_normalize(sp_csr_normalize_args *args);
+
 #ifdef __cplusplus
 }
 #endif

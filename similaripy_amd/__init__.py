@@ -1,10 +1,10 @@
 """similaripy_amd — MI355X-native top-k sparse similarity, drop-in for similaripy's hot path.
 
-Public surface mirrors similaripy/__init__.py:8-19 for what is on the hot path.
+Public surface mirrors similaripy/__init__.py:8-36.
 Compute happens only in libsimilaripy_hip.so (hand-written HIP for gfx950); importing the
 package needs no GPU, calling a similarity function does.
 """
-from .normalization import normalize
+from .normalization import bm25, bm25plus, normalize, tfidf
 from .similarity import (
     asymmetric_cosine,
     cosine,
@@ -22,6 +22,9 @@ __version__ = "0.1.0"
 __all__ = [
     "__version__",
     "normalize",
+    "bm25",
+    "bm25plus",
+    "tfidf",
     "dot_product",
     "cosine",
     "asymmetric_cosine",

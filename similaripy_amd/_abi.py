@@ -22,6 +22,14 @@ SP_FLAG_NO_FOLD = 16
 SP_FLAG_NO_ROW_ORDER = 32
 SP_FLAG_PHASE_TIMERS = 64
 SP_FLAG_M2_IS_M1_T = 128
+SP_FLAG_CHECK_ZEROS = 256
+SP_FLAG_CSR_OUT = 512
+SP_FLAG_P3_PREP = 1024
+SP_FLAG_DEPOP_ROWSUM = 2048
+SP_EZEROS = -6
+SP_NORM_L1, SP_NORM_L2, SP_NORM_MAX, SP_NORM_TFIDF, SP_NORM_BM25PLUS = range(5)
+SP_TF_MODES = {'binary': 0, 'raw': 1, 'sqrt': 2, 'freq': 3, 'log': 4}       # normalization.pyx:12-17
+SP_IDF_MODES = {'unary': 0, 'base': 1, 'smooth': 2, 'prob': 3, 'bm25': 4}   # normalization.pyx:19-24
 
 _c_f32p = C.POINTER(C.c_float)
 _c_i32p = C.POINTER(C.c_int32)
@@ -90,6 +98,11 @@ class SpKnnArgs(C.Structure):
         ("num_wgs_used", C.c_int32),
         ("_pad1", C.c_int32),
         ("reserved", C.c_int64 * 4),
+        ("p3_alpha", C.c_float),
+        ("depop_p2", C.c_float),
+        ("csr_indptr", C.c_void_p),
+        ("csr_nnz", C.c_int64),
+        ("explicit_zeros", C.c_int64),
     ]
 
 
@@ -140,6 +153,35 @@ class SpCsrSqsumsArgs(C.Structure):
     ]
 
 
+class SpCsrNormalizeArgs(C.Structure):
+    """Mirror of ``struct sp_csr_normalize_args`` (include/sp_prep.h) — keep field order identical."""
+
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("flags", C.c_uint32),
+        ("on_device", C.c_int32),
+        ("device", C.c_int32),
+        ("n_rows", C.c_int32),
+        ("n_cols", C.c_int32),
+        ("nnz", C.c_int64),
+        ("dtype", C.c_int32),
+        ("mode", C.c_int32),
+        ("data", C.c_void_p),
+        ("indices", C.c_void_p),
+        ("indptr", C.c_void_p),
+        ("tf_mode", C.c_int32),
+        ("idf_mode", C.c_int32),
+        ("k1", C.c_double),
+        ("b", C.c_double),
+        ("delta", C.c_double),
+        ("logbase", C.c_double),
+        ("pow_alpha", C.c_double),
+        ("stream", C.c_void_p),
+        ("kernel_ms", C.c_float),
+        ("_pad0", C.c_int32),
+    ]
+
+
 EXPORTED_SYMBOLS = (
     "sp_knn_f32_i32",
     "sp_knn_workspace_bytes",
@@ -150,11 +192,17 @@ EXPORTED_SYMBOLS = (
     "sp_csr_transpose_f32_i32",
     "sp_csr_transpose_workspace_bytes",
     "sp_csr_row_sqsums_f32",
+    "sp_csr_normalize",
+    "sp_device_cache_trim",
 )
 
 
 class HipLibraryError(RuntimeError):
     pass
+
+
+class ExplicitZerosError(HipLibraryError):
+    """SP_FLAG_CHECK_ZEROS found stored zeros: the caller eliminates them (s_plus.pyx:210-211) and calls again."""
 
 
 _lib = None
@@ -211,6 +259,10 @@ def load(build_if_missing: bool = True):
     lib.sp_csr_transpose_workspace_bytes.restype = C.c_int64
     lib.sp_csr_row_sqsums_f32.argtypes = [C.POINTER(SpCsrSqsumsArgs)]
     lib.sp_csr_row_sqsums_f32.restype = C.c_int
+    lib.sp_csr_normalize.argtypes = [C.POINTER(SpCsrNormalizeArgs)]
+    lib.sp_csr_normalize.restype = C.c_int
+    lib.sp_device_cache_trim.argtypes = []
+    lib.sp_device_cache_trim.restype = C.c_int64
     _lib = lib
     return lib
 
@@ -251,6 +303,8 @@ def call_knn(args: SpKnnArgs) -> None:
     lib = load()
     args.struct_size = C.sizeof(SpKnnArgs)
     rc = lib.sp_knn_f32_i32(C.byref(args))
+    if rc == SP_EZEROS:
+        raise ExplicitZerosError(last_error())
     if rc != 0:
         raise HipLibraryError(f"sp_knn_f32_i32 failed ({rc}): {last_error()}")
 
@@ -269,6 +323,19 @@ def call_row_sqsums(args: SpCsrSqsumsArgs) -> None:
     rc = lib.sp_csr_row_sqsums_f32(C.byref(args))
     if rc != 0:
         raise HipLibraryError(f"sp_csr_row_sqsums_f32 failed ({rc}): {last_error()}")
+
+
+def call_normalize(args: SpCsrNormalizeArgs) -> None:
+    lib = load()
+    args.struct_size = C.sizeof(SpCsrNormalizeArgs)
+    rc = lib.sp_csr_normalize(C.byref(args))
+    if rc != 0:
+        raise HipLibraryError(f"sp_csr_normalize failed ({rc}): {last_error()}")
+
+
+def device_cache_trim() -> int:
+    """Give the cached device buffers of host-mode calls back to the driver; returns the bytes released."""
+    return int(load().sp_device_cache_trim())
 
 
 def transpose_workspace_bytes(args: SpCsrTransposeArgs) -> int:

@@ -78,6 +78,8 @@ class KernelCall:
     target_col_m_indptr: np.ndarray = field(default_factory=lambda: _EMPTY_I32)
     target_col_m_indices: np.ndarray = field(default_factory=lambda: _EMPTY_I32)
     m2_is_m1t: bool = False    # m2 = m1^T is built on the device (SP_FLAG_M2_IS_M1_T): the m2_* arrays are empty
+    p3_alpha: Optional[float] = None         # SP_FLAG_P3_PREP: m1 / m2 = m1^T rows are L1-normalised and raised to this power on the device
+    depop_rowsum_p2: Optional[float] = None  # SP_FLAG_DEPOP_ROWSUM: Ydepop = (row sums of the raw m1)^p2, built on the device
 
     @property
     def n_targets(self) -> int:
@@ -327,11 +329,12 @@ def _say(verbose: bool, msg: str) -> None:
         print(f"[similaripy_amd] {msg}", file=sys.stderr, flush=True)
 
 
-def _csr_f32_i32(m, binary: bool):
+def _csr_f32_i32(m, binary: bool, check_zeros: bool = True):
     """CSR view with zeros eliminated, float32 data (ones if `binary`), int32 indices/indptr.
-    Unlike the reference (s_plus.pyx:210-211) the caller's matrix is never modified."""
+    Unlike the reference (s_plus.pyx:210-211) the caller's matrix is never modified.
+    check_zeros=False: the caller leaves the search for stored zeros to the device (SP_FLAG_CHECK_ZEROS)."""
     m = m.tocsr()
-    if m.data.shape[0] and np.count_nonzero(m.data) != m.data.shape[0]:
+    if check_zeros and m.data.shape[0] and np.count_nonzero(m.data) != m.data.shape[0]:
         m = m.copy()
         m.eliminate_zeros()
     if m.nnz > np.iinfo(np.int32).max:
@@ -347,8 +350,13 @@ def prepare(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_mat
             p1=0.0, p2=0.0, a1=1.0, l1=0.0, l2=0.0, l3=0.0, t1=1.0, t2=1.0, c1=0.5, c2=0.5, k=100,
             stabilized_shrink=0.0, bayesian_shrink=0.0, additive_shrink=0.0, threshold=0.0,
             binary=False, target_rows=None, filter_cols=None, target_cols=None,
-            verbose=False, format_output='csr', m2_on_device=False) -> KernelCall:
+            verbose=False, format_output='csr', m2_on_device=False, check_zeros=True,
+            p3_alpha=None, p3_depop_beta=None) -> KernelCall:
     """Everything s_plus.pyx does before the `with nogil:` block (:168-353).
+
+    check_zeros=False: stored zeros are looked for on the device (run_hip(check_zeros=True)) instead of here.
+    p3_alpha / p3_depop_beta: the call is p3alpha / rp3beta on the RAW matrix1 (matrix2=None): normalisation, power and
+    the column popularity are left to the device (SP_FLAG_P3_PREP / SP_FLAG_DEPOP_ROWSUM); needs m2_on_device.
 
     m2_on_device: for the `matrix2=None` call, leave the transpose (s_plus.pyx:169-170, 205-206) to the device
     (SP_FLAG_M2_IS_M1_T, include/sp_prep.h): m2 is never built on the host, its column norms are taken from the
@@ -371,16 +379,19 @@ def prepare(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_mat
             # the reference does not check (s_plus.pyx:191-196: out-of-range is UB there)
             raise ValueError("target_rows contains row ids outside matrix1")
 
-    m1, m1_data, m1_indices, m1_indptr = _csr_f32_i32(matrix1, binary)
+    m1, m1_data, m1_indices, m1_indptr = _csr_f32_i32(matrix1, binary, check_zeros)
     sel_f = build_column_selector(filter_cols)
     sel_t = build_column_selector(target_cols)
-    on_dev = bool(m2_on_device) and m2_from_m1 and l3 == 0 and sel_f[0] != MODE_ARRAY and sel_t[0] != MODE_ARRAY
+    p3 = p3_alpha is not None
+    on_dev = bool(m2_on_device) and m2_from_m1 and (l3 == 0 or (p3 and p3_depop_beta is not None)) and sel_f[0] != MODE_ARRAY and sel_t[0] != MODE_ARRAY
+    if p3 and not on_dev:
+        raise ValueError("p3_alpha needs the device-side transpose (matrix2=None, no array selectors)")
     if on_dev:
         m2_data, m2_indices, m2_indptr = _EMPTY_F32, _EMPTY_I32, _EMPTY_I32
         n_rows_m1, n_rows_m2 = m1.shape
         n_output_cols = n_rows_m1
     else:
-        m2, m2_data, m2_indices, m2_indptr = _csr_f32_i32(matrix2, binary)
+        m2, m2_data, m2_indices, m2_indptr = _csr_f32_i32(matrix2, binary, check_zeros)
         n_rows_m1, n_rows_m2 = m1.shape
         n_output_cols = m2.shape[1]
 
@@ -395,6 +406,8 @@ def prepare(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_mat
         n_rows_m1=n_rows_m1, n_rows_m2=n_rows_m2, n_output_cols=n_output_cols, k=k,
         a1=a1, l1=l1, l2=l2, l3=l3, t1=t1, t2=t2,
         stabilized_shrink=stabilized_shrink, bayesian_shrink=bayesian_shrink, threshold=threshold, m2_is_m1t=on_dev)
+    if p3:
+        call.p3_alpha = f32(p3_alpha)
 
     if l1 != 0 or l2 != 0:
         if on_dev:
@@ -406,7 +419,11 @@ def prepare(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_mat
             call.Xtversky, call.Ytversky = sq1, sq2
         if l2 != 0:
             call.Xcosine, call.Ycosine = build_cosine_normalization(sq1, sq2, c1, c2, additive_shrink)
-    if l3 != 0:
+    if l3 != 0 and p3 and p3_depop_beta is not None:
+        # rp3beta: Xdepop = ones ('none'), Ydepop = popularity^beta from the raw rows of m1 on the device (s_plus_utils.pyx:257-276)
+        call.Xdepop = np.ones(n_rows_m1, dtype=np.float32)
+        call.depop_rowsum_p2 = f32(p3_depop_beta)
+    elif l3 != 0:
         call.Xdepop, call.Ydepop = build_depop_normalization(
             (m1_data, m1_indices, m1_indptr, n_rows_m2), (m2_data, m2_indices, m2_indptr, n_output_cols),
             n_rows_m1, n_output_cols, weight_depop_matrix1, weight_depop_matrix2, p1, p2)
@@ -454,19 +471,33 @@ def selected_device() -> int:
 
 def run_hip(call: KernelCall, device: Optional[int] = None, table_slots: int = 0, threads_per_wg: int = 0,
             num_wgs: int = 0, load_pct: int = 0, time_kernel: bool = False, static_sched: bool = False,
-            no_sparse_path: bool = False, no_fold: bool = False, want_rows: bool = True):
+            no_sparse_path: bool = False, no_fold: bool = False, want_rows: bool = True,
+            check_zeros: bool = False, csr_out: bool = False):
     """The `with nogil:` block of s_plus.pyx:359-384, on the GPU: host buffers in, host buffers out
-    through the C ABI (include/sp_knn.h).  Returns rows, cols, values, counts[, info]."""
+    through the C ABI (include/sp_knn.h).  Returns rows, cols, values, counts[, info].
+
+    check_zeros: SP_FLAG_CHECK_ZEROS — raises _abi.ExplicitZerosError when m1 / m2 hold stored zeros.
+    csr_out: SP_FLAG_CSR_OUT — the CSR result is assembled on the device (strictly increasing targets only); returns
+    (indptr, indices, data) of the final matrix instead (views of the buffers the library filled)."""
     _abi.require_device()
     n, k = call.n_targets, call.k
+    want_rows = want_rows and not csr_out
     rows = np.empty(n * k, dtype=np.int32) if want_rows else None      # (slot i's rows are all targets[i]: CSR assembly does not read them)
     cols = np.empty(n * k, dtype=np.int32)
     values = np.empty(n * k, dtype=np.float32)
-    counts = np.empty(n, dtype=np.int32)
+    counts = np.empty(n, dtype=np.int32) if not csr_out else None
+    csr_indptr = np.zeros(call.n_rows_m1 + 1, dtype=np.int32) if csr_out else None
 
     a = _abi.SpKnnArgs()
     a.flags = ((0 if want_rows else _abi.SP_FLAG_NO_ROWS_OUT) | (_abi.SP_FLAG_TIME_KERNEL | _abi.SP_FLAG_PHASE_TIMERS if time_kernel else 0) | (_abi.SP_FLAG_STATIC_SCHED if static_sched else 0)
-               | (_abi.SP_FLAG_NO_SPARSE_PATH if no_sparse_path else 0) | (_abi.SP_FLAG_NO_FOLD if no_fold else 0))
+               | (_abi.SP_FLAG_NO_SPARSE_PATH if no_sparse_path else 0) | (_abi.SP_FLAG_NO_FOLD if no_fold else 0)
+               | (_abi.SP_FLAG_CHECK_ZEROS if check_zeros else 0) | (_abi.SP_FLAG_CSR_OUT if csr_out else 0))
+    if call.p3_alpha is not None:
+        a.flags |= _abi.SP_FLAG_P3_PREP
+        a.p3_alpha = call.p3_alpha
+    if call.depop_rowsum_p2 is not None:
+        a.flags |= _abi.SP_FLAG_DEPOP_ROWSUM
+        a.depop_p2 = call.depop_rowsum_p2
     a.on_device = 0
     a.device = selected_device() if device is None else int(device)
     a.n_targets, a.n_rows_m1, a.n_rows_m2, a.n_output_cols = n, call.n_rows_m1, call.n_rows_m2, call.n_output_cols
@@ -496,10 +527,15 @@ def run_hip(call: KernelCall, device: Optional[int] = None, table_slots: int = 0
     a.target_col_mode = call.target_col_mode
     a.target_col_m_indptr, a.target_col_m_indices = i32(call.target_col_m_indptr), i32(call.target_col_m_indices)
     a.target_col_nnz = int(call.target_col_m_indices.shape[0])
-    a.rows, a.cols, a.values, a.out_counts = (rows.ctypes.data if want_rows else None), cols.ctypes.data, values.ctypes.data, counts.ctypes.data
+    a.rows, a.cols, a.values = (rows.ctypes.data if want_rows else None), cols.ctypes.data, values.ctypes.data
+    a.out_counts = counts.ctypes.data if counts is not None else None
+    a.csr_indptr = csr_indptr.ctypes.data if csr_out else None
     a.table_slots, a.threads_per_wg, a.num_wgs, a.load_pct = table_slots, threads_per_wg, num_wgs, load_pct
     if n > 0:
         _abi.call_knn(a)
+    if csr_out:
+        nnz = int(a.csr_nnz) if n > 0 else 0
+        return csr_indptr, cols[:nnz], values[:nnz]
     if time_kernel:
         return rows, cols, values, counts, {"kernel_ms": float(a.kernel_ms), "passes_total": int(a.passes_total), "phase_cycles": [int(x) for x in a.phase_cycles], "num_wgs": int(a.num_wgs_used),
                                              "sparse_kernel_ms": int(a.reserved[1]) / 1e3, "generic_kernel_ms": int(a.reserved[2]) / 1e3, "transpose_ms": int(a.reserved[3]) / 1e3}
@@ -524,13 +560,41 @@ def s_plus(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_matr
     ``num_threads`` and ``block_size`` are CPU tuning knobs of the reference; they are accepted
     and ignored (they never change the result).
     """
+    return _s_plus_impl(matrix1, matrix2, weight_depop_matrix1, weight_depop_matrix2, p1, p2, a1, l1, l2, l3,
+                        t1, t2, c1, c2, k, stabilized_shrink, bayesian_shrink, additive_shrink, threshold,
+                        binary, target_rows, filter_cols, target_cols, verbose, format_output)
+
+
+def _s_plus_impl(matrix1, matrix2, weight_depop_matrix1, weight_depop_matrix2, p1, p2, a1, l1, l2, l3,
+                 t1, t2, c1, c2, k, stabilized_shrink, bayesian_shrink, additive_shrink, threshold,
+                 binary, target_rows, filter_cols, target_cols, verbose, format_output,
+                 p3_alpha=None, p3_depop_beta=None):
+    """prepare -> kernel -> assembly.  The stages the reference runs on the host around its kernel are left to the device
+    where the call allows it: the transpose and the norms of the `matrix2=None` call, the search for stored zeros, the
+    preprocessing of p3alpha / rp3beta (p3_alpha / p3_depop_beta: matrix1 is the RAW matrix then) and the CSR assembly."""
     _say(verbose if isinstance(verbose, bool) else False, "Preprocessing")
-    call = prepare(matrix1, matrix2, weight_depop_matrix1, weight_depop_matrix2, p1, p2, a1, l1, l2, l3,
-                   t1, t2, c1, c2, k, stabilized_shrink, bayesian_shrink, additive_shrink, threshold,
-                   binary, target_rows, filter_cols, target_cols, verbose, format_output, m2_on_device=True)
+    args = (matrix1, matrix2, weight_depop_matrix1, weight_depop_matrix2, p1, p2, a1, l1, l2, l3,
+            t1, t2, c1, c2, k, stabilized_shrink, bayesian_shrink, additive_shrink, threshold,
+            binary, target_rows, filter_cols, target_cols, verbose, format_output)
+    p3kw = dict(p3_alpha=p3_alpha, p3_depop_beta=p3_depop_beta)
+    # stored zeros: looked for on the device, where the data goes anyway (under `binary` the uploaded data are ones: host check)
+    device_zero_check = not binary
+    call = prepare(*args, m2_on_device=True, check_zeros=not device_zero_check, **p3kw)
+    t = call.targets
+    csr_out = (format_output == 'csr' and call.n_targets > 0 and call.n_targets * call.k <= np.iinfo(np.int32).max
+               and (call.n_targets == 1 or bool(np.all(t[1:] > t[:-1]))))
     _say(verbose, "Computing")
-    rows, cols, values, counts = run_hip(call, want_rows=(format_output != 'csr'))
+    try:
+        out = run_hip(call, want_rows=(format_output != 'csr'), check_zeros=device_zero_check, csr_out=csr_out)
+    except _abi.ExplicitZerosError:
+        call = prepare(*args, m2_on_device=True, check_zeros=True, **p3kw)      # eliminate_zeros on the host (s_plus.pyx:210-211)
+        out = run_hip(call, want_rows=(format_output != 'csr'), csr_out=csr_out)
     _say(verbose, f"Building {format_output} matrix")
-    res = finish(call, rows, cols, values, counts, format_output)
+    if csr_out:
+        indptr, indices, data = out
+        res = sp.csr_array((data, indices, indptr), shape=(call.n_rows_m1, call.n_output_cols), dtype=np.float32)
+    else:
+        rows, cols, values, counts = out
+        res = finish(call, rows, cols, values, counts, format_output)
     _say(verbose, "Done")
     return res

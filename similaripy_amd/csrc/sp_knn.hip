@@ -23,6 +23,8 @@
 #include <string.h>
 #include <stdarg.h>
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <type_traits>
 #include <vector>
 
@@ -30,12 +32,15 @@
 #include "../../include/sp_prep.h"
 #include "sp_common.hpp"
 #include "sp_prep_kernels.hpp"
+#include "sp_rowops.hpp"
 #include "sp_sparse_kernel.hpp"
 #include "sp_generic_kernel.hpp"
 
 // ---------------------------------------------------------------------------------------------
 // host side: C ABI
 // ---------------------------------------------------------------------------------------------
+extern "C" int64_t sp_knn_workspace_bytes(const sp_knn_args *a);
+
 namespace {
 
 #define TRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
@@ -198,18 +203,25 @@ int validate(const sp_knn_args *a) {
     if ((m2t ? a->nnz_m1 : a->nnz_m2) >= (1LL << 30) - 1024)
         return fail(SP_EINVAL, "nnz(m2) = %lld: this build addresses m2 with 32-bit byte offsets and needs nnz(m2) < 2^30",
                     (long long)(m2t ? a->nnz_m1 : a->nnz_m2));
+    if ((a->flags & (SP_FLAG_P3_PREP | SP_FLAG_DEPOP_ROWSUM)) && !m2t)
+        return fail(SP_EINVAL, "SP_FLAG_P3_PREP / SP_FLAG_DEPOP_ROWSUM need SP_FLAG_M2_IS_M1_T");
+    if ((a->flags & SP_FLAG_DEPOP_ROWSUM) && !(a->flags & SP_FLAG_P3_PREP))
+        return fail(SP_EINVAL, "SP_FLAG_DEPOP_ROWSUM needs SP_FLAG_P3_PREP");
+    if ((a->flags & (SP_FLAG_CSR_OUT | SP_FLAG_CHECK_ZEROS)) && a->on_device)
+        return fail(SP_EINVAL, "SP_FLAG_CSR_OUT / SP_FLAG_CHECK_ZEROS are host-mode flags (on_device = 0)");
+    if ((a->flags & SP_FLAG_CSR_OUT) && a->n_targets > 0 && !a->csr_indptr) return fail(SP_EINVAL, "SP_FLAG_CSR_OUT needs csr_indptr");
     if (m2t && a->n_output_cols != a->n_rows_m1)
         return fail(SP_EINVAL, "SP_FLAG_M2_IS_M1_T: n_output_cols (%d) must equal n_rows_m1 (%d)", a->n_output_cols, a->n_rows_m1);
     if (a->n_targets > 0) {
         if (!a->targets || !a->m1_indptr || (!m2t && !a->m2_indptr) || !a->cols || !a->values)
             return fail(SP_EINVAL, "NULL input/output pointer");
-        if (!a->rows && !(a->flags & SP_FLAG_NO_ROWS_OUT))
+        if (!a->rows && !(a->flags & (SP_FLAG_NO_ROWS_OUT | SP_FLAG_CSR_OUT)))
             return fail(SP_EINVAL, "rows is NULL");
         if (a->nnz_m1 > 0 && (!a->m1_data || !a->m1_indices)) return fail(SP_EINVAL, "m1 arrays NULL");
         if (!m2t && a->nnz_m2 > 0 && (!a->m2_data || !a->m2_indices)) return fail(SP_EINVAL, "m2 arrays NULL");
         if (a->l1 != 0.f && (!a->Xtversky || !a->Ytversky)) return fail(SP_EINVAL, "l1 != 0 needs Xtversky/Ytversky");
         if (a->l2 != 0.f && (!a->Xcosine || !a->Ycosine)) return fail(SP_EINVAL, "l2 != 0 needs Xcosine/Ycosine");
-        if (a->l3 != 0.f && (!a->Xdepop || !a->Ydepop)) return fail(SP_EINVAL, "l3 != 0 needs Xdepop/Ydepop");
+        if (a->l3 != 0.f && (!a->Xdepop || (!a->Ydepop && !(a->flags & SP_FLAG_DEPOP_ROWSUM)))) return fail(SP_EINVAL, "l3 != 0 needs Xdepop/Ydepop");
         if (a->filter_mode == SP_SEL_MATRIX && (!a->filter_m_indptr || (a->filter_nnz > 0 && !a->filter_m_indices)))
             return fail(SP_EINVAL, "filter MATRIX mode needs indptr/indices");
         if (a->target_col_mode == SP_SEL_MATRIX && (!a->target_col_m_indptr || (a->target_col_nnz > 0 && !a->target_col_m_indices)))
@@ -436,10 +448,10 @@ namespace {
 
 // Layout of the extra scratch a SP_FLAG_M2_IS_M1_T call needs behind the kernel's own workspace: the three arrays of
 // m2 = m1^T, then the transpose's scratch.
-struct M2tLayout { size_t knn, data, indices, indptr, tr, total; };
+struct M2tLayout { size_t knn, data, indices, indptr, m1copy, ydepop, tr, total; };
 int m2t_layout(const sp_knn_args *a, int n_cus, sp_knn_args *plain, M2tLayout *L) {
     *plain = *a;
-    plain->flags &= ~SP_FLAG_M2_IS_M1_T;
+    plain->flags &= ~(SP_FLAG_M2_IS_M1_T | SP_FLAG_P3_PREP | SP_FLAG_DEPOP_ROWSUM);
     plain->nnz_m2 = a->nnz_m1;
     Config c;
     TRY(make_config(plain, n_cus, &c));
@@ -448,7 +460,10 @@ int m2t_layout(const sp_knn_args *a, int n_cus, sp_knn_args *plain, M2tLayout *L
     L->data = L->knn;
     L->indices = L->data + al((size_t)a->nnz_m1 * 4);
     L->indptr = L->indices + al((size_t)a->nnz_m1 * 4);
-    L->tr = L->indptr + al(((size_t)a->n_rows_m2 + 1) * 4);
+    // SP_FLAG_P3_PREP: a normalised copy of m1's values (the caller's stay as they are) and, for rp3beta, the column term
+    L->m1copy = L->indptr + al(((size_t)a->n_rows_m2 + 1) * 4);
+    L->ydepop = L->m1copy + ((a->flags & SP_FLAG_P3_PREP) ? al((size_t)a->nnz_m1 * 4) : 0);
+    L->tr = L->ydepop + ((a->flags & SP_FLAG_DEPOP_ROWSUM) ? al((size_t)a->n_rows_m1 * 4) : 0);
     L->total = L->tr + transpose_ws_bytes(a->nnz_m1, a->n_rows_m2);
     return SP_OK;
 }
@@ -491,6 +506,23 @@ int run_device(sp_knn_args *a) {
         HIP_TRY(hipEventSynchronize(ev1));
         HIP_TRY(hipEventElapsedTime(&tr_ms, ev0, ev1));
     }
+    if (!rc && (a->flags & SP_FLAG_P3_PREP) && a->nnz_m1 > 0) {
+        // p3alpha / rp3beta (similarity.py:410-415, 477-483): the column popularity comes from the RAW matrix, then the rows of
+        // m1 and of m2 = m1^T are divided by their L1 norms and every entry is raised to alpha
+        const int wave_blocks = [](int n) { return std::max(1, std::min(256 * 16, (n + 3) / 4)); }(std::max(a->n_rows_m1, a->n_rows_m2));
+        if (a->flags & SP_FLAG_DEPOP_ROWSUM) {
+            float *yd = (float *)(ws + L.ydepop);
+            hipLaunchKernelGGL(sp_row_sums_kernel, dim3(wave_blocks), dim3(256), 0, stream, a->n_rows_m1, a->m1_data, a->m1_indptr, yd);
+            hipLaunchKernelGGL(sp_pow_f32_kernel, dim3((a->n_rows_m1 + 255) / 256), dim3(256), 0, stream, a->n_rows_m1, yd, yd, (double)a->depop_p2);
+            b.Ydepop = yd;
+        }
+        float *m1n = (float *)(ws + L.m1copy);
+        HIP_TRY(hipMemcpyAsync(m1n, a->m1_data, (size_t)a->nnz_m1 * 4, hipMemcpyDeviceToDevice, stream));
+        hipLaunchKernelGGL((sp_row_normalize_kernel<float, RO_L1>), dim3(wave_blocks), dim3(256), 0, stream, a->n_rows_m1, m1n, a->m1_indptr, (double)a->p3_alpha);
+        hipLaunchKernelGGL((sp_row_normalize_kernel<float, RO_L1>), dim3(wave_blocks), dim3(256), 0, stream, a->n_rows_m2, m2_data, m2_indptr, (double)a->p3_alpha);
+        HIP_TRY(hipGetLastError());
+        b.m1_data = m1n;
+    }
     if (!rc) {
         b.m2_data = m2_data; b.m2_indices = m2_indices; b.m2_indptr = m2_indptr;
         b.workspace = ws;
@@ -507,33 +539,99 @@ int run_device(sp_knn_args *a) {
     return rc;
 }
 
-// RAII device allocation list for the host-pointer entry
+// Device buffers of host-mode calls are cached per device in size buckets (next multiple of 1/8 of a power of two) and
+// reused by later calls: hipMalloc / hipFree of GB-sized buffers cost milliseconds each, and a similarity pipeline
+// (normalise -> similarity -> scoring) makes many such calls.  sp_device_cache_trim() gives the memory back.
+struct DeviceCache {
+    std::mutex mu;
+    std::map<std::pair<int, size_t>, std::vector<void *>> free_blocks;      // (device, bucket bytes) -> idle blocks
+    static size_t bucket(size_t n) {
+        n = std::max<size_t>(n, 256);
+        size_t p = 256;
+        while (p < n) p <<= 1;
+        const size_t step = p >> 3;                   // 8 buckets per octave: at most 12.5 % over-allocation
+        return step ? ((n + step - 1) / step) * step : p;
+    }
+    int get(int device, size_t bytes, void **out, size_t *got) {
+        const size_t b = bucket(bytes);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto it = free_blocks.find({device, b});
+            if (it != free_blocks.end() && !it->second.empty()) {
+                *out = it->second.back();
+                it->second.pop_back();
+                *got = b;
+                return SP_OK;
+            }
+        }
+        void *d = nullptr;
+        hipError_t e = hipMalloc(&d, b);
+        if (e != hipSuccess) {          // out of memory: drop the cache and try once more
+            (void)hipGetLastError();
+            trim(device);
+            e = hipMalloc(&d, b);
+        }
+        if (e != hipSuccess) return fail(SP_ENOMEM, "hipMalloc(%zu bytes) failed: %s", b, hipGetErrorString(e));
+        *out = d;
+        *got = b;
+        return SP_OK;
+    }
+    void put(int device, size_t b, void *p) {
+        std::lock_guard<std::mutex> lk(mu);
+        free_blocks[{device, b}].push_back(p);
+    }
+    long long trim(int device) {
+        std::vector<std::pair<size_t, void *>> victims;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (auto &kv : free_blocks)
+                if (kv.first.first == device || device < 0) {
+                    for (void *p : kv.second) victims.push_back({kv.first.second, p});
+                    kv.second.clear();
+                }
+        }
+        long long n = 0;
+        for (auto &v : victims) { (void)hipFree(v.second); n += (long long)v.first; }
+        return n;
+    }
+};
+DeviceCache g_cache;
+const bool g_cache_on = getenv("SIMILARIPY_AMD_NO_DEVICE_CACHE") == nullptr;
+
+// RAII device allocation list for the host-pointer entries; blocks go back to the cache (after a device sync: a block is
+// never handed out again while a kernel of the call that used it may still run)
 struct DevPool {
-    std::vector<void *> ptrs;
-    ~DevPool() { for (void *p : ptrs) (void)hipFree(p); }
+    int device = 0;
+    std::vector<std::pair<void *, size_t>> blocks;
+    ~DevPool() {
+        if (blocks.empty()) return;
+        (void)hipDeviceSynchronize();
+        for (auto &b : blocks) {
+            if (g_cache_on) g_cache.put(device, b.second, b.first);
+            else (void)hipFree(b.first);
+        }
+    }
+    int raw(size_t bytes, void **d) {
+        size_t got = 0;
+        if (g_cache_on) TRY(g_cache.get(device, bytes, d, &got));
+        else { HIP_TRY(hipMalloc(d, std::max<size_t>(bytes, 256))); got = bytes; }
+        blocks.push_back({*d, got});
+        return SP_OK;
+    }
     template <typename Tp>
     int up(const Tp *host, size_t n, const Tp **dev) {
         *dev = nullptr;
-        if (!host || n == 0) {
-            // keep a valid (1-element) device pointer so kernels never see host addresses
-            void *d = nullptr;
-            HIP_TRY(hipMalloc(&d, sizeof(Tp)));
-            ptrs.push_back(d);
-            *dev = (const Tp *)d;
-            return SP_OK;
-        }
         void *d = nullptr;
-        HIP_TRY(hipMalloc(&d, n * sizeof(Tp)));
-        ptrs.push_back(d);
-        HIP_TRY(hipMemcpy(d, host, n * sizeof(Tp), hipMemcpyHostToDevice));
+        // (an empty operand still gets a valid device pointer so that kernels never see host addresses)
+        TRY(raw(std::max<size_t>(n, 1) * sizeof(Tp), &d));
+        if (host && n) HIP_TRY(hipMemcpy(d, host, n * sizeof(Tp), hipMemcpyHostToDevice));
         *dev = (const Tp *)d;
         return SP_OK;
     }
     template <typename Tp>
     int alloc(size_t n, Tp **dev) {
         void *d = nullptr;
-        HIP_TRY(hipMalloc(&d, std::max<size_t>(n, 1) * sizeof(Tp)));
-        ptrs.push_back(d);
+        TRY(raw(std::max<size_t>(n, 1) * sizeof(Tp), &d));
         *dev = (Tp *)d;
         return SP_OK;
     }
@@ -570,6 +668,7 @@ int run_host(sp_knn_args *a) {
     if (a->target_col_mode == SP_SEL_MATRIX) TRY(check_csr("target_cols", a->target_col_m_indptr, a->target_col_m_indices, a->n_rows_m1, a->target_col_nnz, a->n_output_cols));
 
     DevPool pool;
+    pool.device = a->device;
     sp_knn_args d = *a;
     d.on_device = 1;
     d.stream = nullptr;
@@ -597,21 +696,83 @@ int run_host(sp_knn_args *a) {
     TRY(pool.up(fm ? a->filter_m_indices : nullptr, (size_t)a->filter_nnz, &d.filter_m_indices));
     TRY(pool.up(tm ? a->target_col_m_indptr : nullptr, (size_t)a->n_rows_m1 + 1, &d.target_col_m_indptr));
     TRY(pool.up(tm ? a->target_col_m_indices : nullptr, (size_t)a->target_col_nnz, &d.target_col_m_indices));
-    const bool want_rows = !(a->flags & SP_FLAG_NO_ROWS_OUT);
+
+    if (a->flags & SP_FLAG_CHECK_ZEROS) {
+        // explicit zeros are structural for the kernel (a candidate with value 0, a 1 under `binary`): the reference removes them
+        // first (s_plus.pyx:210-211).  Counted here, where the data already is; the rare matrix that has some goes back to the caller.
+        unsigned long long *cnt = nullptr;
+        TRY(pool.alloc(1, &cnt));
+        HIP_TRY(hipMemset(cnt, 0, sizeof(*cnt)));
+        if (a->nnz_m1 > 0) hipLaunchKernelGGL(sp_zero_count_kernel, dim3(1024), dim3(256), 0, nullptr, (long long)a->nnz_m1, d.m1_data, cnt);
+        if (!(a->flags & SP_FLAG_M2_IS_M1_T) && a->nnz_m2 > 0)
+            hipLaunchKernelGGL(sp_zero_count_kernel, dim3(1024), dim3(256), 0, nullptr, (long long)a->nnz_m2, d.m2_data, cnt);
+        HIP_TRY(hipGetLastError());
+        unsigned long long h = 0;
+        HIP_TRY(hipMemcpy(&h, cnt, sizeof(h), hipMemcpyDeviceToHost));
+        a->explicit_zeros = (int64_t)h;
+        if (h) return fail(SP_EZEROS, "%llu stored entries are zero: eliminate them first (s_plus.pyx:210-211)", h);
+    }
+
+    const bool csr_out = (a->flags & SP_FLAG_CSR_OUT) != 0;
+    if (csr_out) {
+        for (size_t i = 1; i < nt; ++i)
+            if (a->targets[i] <= a->targets[i - 1]) return fail(SP_EINVAL, "SP_FLAG_CSR_OUT needs strictly increasing targets (targets[%zu]=%d after %d)", i, a->targets[i], a->targets[i - 1]);
+        if (nt * k > 0x7FFFFFFFull) return fail(SP_EINVAL, "SP_FLAG_CSR_OUT: n_targets * k = %zu does not fit int32 row pointers", nt * k);
+        d.flags |= SP_FLAG_NO_ROWS_OUT;
+    }
+    d.flags &= ~(SP_FLAG_CSR_OUT | SP_FLAG_CHECK_ZEROS);
+    const bool want_rows = !(d.flags & SP_FLAG_NO_ROWS_OUT);
     d.rows = nullptr;
     if (want_rows) TRY(pool.alloc(nt * k, &d.rows));
     TRY(pool.alloc(nt * k, &d.cols));
     TRY(pool.alloc(nt * k, &d.values));
     d.out_counts = nullptr;
-    if (a->out_counts) TRY(pool.alloc(nt, &d.out_counts));
+    if (a->out_counts || csr_out) TRY(pool.alloc(nt, &d.out_counts));
+    {
+        // the kernel's workspace comes from the cache as well
+        const int64_t need = sp_knn_workspace_bytes(&d);
+        if (need < 0) return (int)need;
+        unsigned char *w = nullptr;
+        TRY(pool.alloc((size_t)need, &w));
+        d.workspace = w;
+        d.workspace_bytes = need;
+    }
 
     int rc = run_device(&d);
     if (rc) return rc;
-    HIP_TRY(hipDeviceSynchronize());
-    if (want_rows) HIP_TRY(hipMemcpy(a->rows, d.rows, nt * k * sizeof(int32_t), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(a->cols, d.cols, nt * k * sizeof(int32_t), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(a->values, d.values, nt * k * sizeof(float), hipMemcpyDeviceToHost));
-    if (a->out_counts) HIP_TRY(hipMemcpy(a->out_counts, d.out_counts, nt * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (csr_out) {
+        // counting sort of the slots by row (coo_to_csr.h:28-71) with the zeros left out (s_plus.pyx:424): targets ascend, so
+        // the slots already are in row order — per-slot non-zero counts, a scan, one compaction pass, and only the CSR travels
+        const int n_rows = a->n_rows_m1;
+        int *indptr = nullptr, *o_idx = nullptr;
+        float *o_val = nullptr;
+        long long *total = nullptr;
+        TRY(pool.alloc((size_t)n_rows + 1, &indptr));
+        TRY(pool.alloc(nt * k, &o_idx));
+        TRY(pool.alloc(nt * k, &o_val));
+        TRY(pool.alloc(1, &total));
+        HIP_TRY(hipMemsetAsync(indptr, 0, ((size_t)n_rows + 1) * 4, nullptr));
+        const int wb = (int)std::max<size_t>(1, std::min<size_t>(256 * 16, (nt + 3) / 4));
+        hipLaunchKernelGGL(sp_slot_nnz_kernel, dim3(wb), dim3(256), 0, nullptr, (int)nt, (int)k, d.targets, d.out_counts, d.values, indptr);
+        hipLaunchKernelGGL(sp_inclusive_scan_kernel, dim3(1), dim3(1024), 0, nullptr, n_rows + 1, indptr, total);
+        hipLaunchKernelGGL(sp_csr_compact_kernel, dim3(wb), dim3(256), 0, nullptr, (int)nt, (int)k, d.targets, d.out_counts, d.cols, d.values, indptr, o_idx, o_val);
+        HIP_TRY(hipGetLastError());
+        long long nnz = 0;
+        HIP_TRY(hipMemcpy(&nnz, total, sizeof(nnz), hipMemcpyDeviceToHost));
+        a->csr_nnz = nnz;
+        HIP_TRY(hipMemcpy(a->csr_indptr, indptr, ((size_t)n_rows + 1) * 4, hipMemcpyDeviceToHost));
+        if (nnz > 0) {
+            HIP_TRY(hipMemcpy(a->cols, o_idx, (size_t)nnz * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(a->values, o_val, (size_t)nnz * 4, hipMemcpyDeviceToHost));
+        }
+        if (a->out_counts) HIP_TRY(hipMemcpy(a->out_counts, d.out_counts, nt * sizeof(int32_t), hipMemcpyDeviceToHost));
+    } else {
+        HIP_TRY(hipDeviceSynchronize());
+        if (want_rows) HIP_TRY(hipMemcpy(a->rows, d.rows, nt * k * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(a->cols, d.cols, nt * k * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(a->values, d.values, nt * k * sizeof(float), hipMemcpyDeviceToHost));
+        if (a->out_counts) HIP_TRY(hipMemcpy(a->out_counts, d.out_counts, nt * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
     a->kernel_ms = d.kernel_ms;
     a->passes_total = d.passes_total;
     a->num_wgs_used = d.num_wgs_used;
@@ -705,6 +866,7 @@ int sp_csr_transpose_f32_i32(sp_csr_transpose_args *a) {
     for (int64_t i = 0; i < a->nnz; ++i)
         if (a->indices[i] < 0 || a->indices[i] >= a->n_cols) return fail(SP_EINVAL, "indices[%lld]=%d out of range [0,%d)", (long long)i, a->indices[i], a->n_cols);
     DevPool pool;
+    pool.device = a->device;
     const float *d_data; const int32_t *d_indices, *d_indptr;
     float *o_data; int32_t *o_indices, *o_indptr;
     unsigned char *ws;
@@ -747,6 +909,7 @@ int sp_csr_row_sqsums_f32(sp_csr_sqsums_args *a) {
     const int blocks = std::min(256 * 16, (a->n_rows + 255) / 256);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     DevPool pool;
+    pool.device = a->device;
     const float *d_data = a->data;
     const int32_t *d_indptr = a->indptr;
     float *o_rows = a->out_rows, *o_cols = a->out_cols_of_t;
@@ -769,6 +932,88 @@ int sp_csr_row_sqsums_f32(sp_csr_sqsums_args *a) {
         HIP_TRY(hipDeviceSynchronize());
         if (a->out_rows) HIP_TRY(hipMemcpy(a->out_rows, o_rows, (size_t)a->n_rows * 4, hipMemcpyDeviceToHost));
         if (a->out_cols_of_t) HIP_TRY(hipMemcpy(a->out_cols_of_t, o_cols, (size_t)a->n_rows * 4, hipMemcpyDeviceToHost));
+    }
+    return SP_OK;
+}
+
+int64_t sp_device_cache_trim(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    (void)hipDeviceSynchronize();
+    return (int64_t)g_cache.trim(dev);
+}
+
+int sp_csr_normalize(sp_csr_normalize_args *a) {
+    g_err[0] = 0;
+    if (!a || a->struct_size != sizeof(sp_csr_normalize_args)) return fail(SP_EINVAL, "sp_csr_normalize_args size mismatch");
+    if (a->n_rows < 0 || a->n_cols < 0 || a->nnz < 0 || a->nnz > 0x7FFFFFFFLL) return fail(SP_EINVAL, "bad shape / nnz");
+    if (a->dtype != 0 && a->dtype != 1) return fail(SP_EINVAL, "dtype must be 0 (float32) or 1 (float64)");
+    if (a->mode < SP_NORM_L1 || a->mode > SP_NORM_BM25PLUS) return fail(SP_EINVAL, "bad mode %d", a->mode);
+    const bool weighted = a->mode == SP_NORM_TFIDF || a->mode == SP_NORM_BM25PLUS;
+    if (weighted && (a->tf_mode < 0 || a->tf_mode > 4 || a->idf_mode < 0 || a->idf_mode > 4)) return fail(SP_EINVAL, "bad tf / idf mode");
+    if (!a->indptr || (a->nnz > 0 && (!a->data || (weighted && !a->indices)))) return fail(SP_EINVAL, "NULL input pointer");
+    const int ndev = sp_device_count();
+    if (ndev <= 0) return fail(SP_ENODEVICE, "no HIP device visible: similaripy_amd has no CPU fallback");
+    if (a->device < 0 || a->device >= ndev) return fail(SP_EINVAL, "device %d out of range (have %d)", a->device, ndev);
+    HIP_TRY(hipSetDevice(a->device));
+    a->kernel_ms = 0.f;
+    if (a->n_rows == 0 || a->nnz == 0) return SP_OK;
+    const size_t esz = a->dtype ? 8 : 4;
+    DevPool pool;
+    pool.device = a->device;
+    void *d_data = a->data;
+    const int32_t *d_indices = a->indices, *d_indptr = a->indptr;
+    hipStream_t stream = a->on_device ? (hipStream_t)a->stream : nullptr;
+    if (!a->on_device) {
+        if (a->indptr[0] != 0 || (int64_t)a->indptr[a->n_rows] != a->nnz) return fail(SP_EINVAL, "indptr does not span [0, nnz]");
+        for (int r = 0; r < a->n_rows; ++r) if (a->indptr[r + 1] < a->indptr[r]) return fail(SP_EINVAL, "indptr decreases at row %d", r);
+        if (weighted) for (int64_t i = 0; i < a->nnz; ++i) if (a->indices[i] < 0 || a->indices[i] >= a->n_cols) return fail(SP_EINVAL, "indices[%lld] out of range", (long long)i);
+        TRY(pool.raw((size_t)a->nnz * esz, &d_data));
+        HIP_TRY(hipMemcpy(d_data, a->data, (size_t)a->nnz * esz, hipMemcpyHostToDevice));
+        if (weighted) TRY(pool.up(a->indices, (size_t)a->nnz, &d_indices));
+        TRY(pool.up(a->indptr, (size_t)a->n_rows + 1, &d_indptr));
+    }
+    // scratch of the weighted modes: document lengths, document frequencies, idf, average length
+    void *doc_len = nullptr, *idf = nullptr, *avg = nullptr;
+    int *df = nullptr;
+    if (weighted) {
+        TRY(pool.raw((size_t)a->n_rows * esz, &doc_len));
+        TRY(pool.raw(std::max<size_t>(1, (size_t)a->n_cols) * esz, &idf));
+        TRY(pool.raw(64, &avg));
+        TRY(pool.alloc(std::max<size_t>(1, (size_t)a->n_cols), &df));
+        HIP_TRY(hipMemsetAsync(df, 0, std::max<size_t>(1, (size_t)a->n_cols) * 4, stream));
+    }
+    const bool timed = (a->flags & SP_FLAG_TIME_KERNEL) != 0;
+    CallGuard guard;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (timed) { TRY(guard.event(&ev0)); TRY(guard.event(&ev1)); HIP_TRY(hipEventRecord(ev0, stream)); }
+    const int wb = std::max(1, std::min(256 * 16, (a->n_rows + 3) / 4));
+    auto run = [&](auto tag) {
+        using T = decltype(tag);
+        T *data = (T *)d_data;
+        if (a->mode == SP_NORM_L1) hipLaunchKernelGGL((sp_row_normalize_kernel<T, RO_L1>), dim3(wb), dim3(256), 0, stream, a->n_rows, data, d_indptr, a->pow_alpha);
+        else if (a->mode == SP_NORM_L2) hipLaunchKernelGGL((sp_row_normalize_kernel<T, RO_L2>), dim3(wb), dim3(256), 0, stream, a->n_rows, data, d_indptr, a->pow_alpha);
+        else if (a->mode == SP_NORM_MAX) hipLaunchKernelGGL((sp_row_normalize_kernel<T, RO_MAX>), dim3(wb), dim3(256), 0, stream, a->n_rows, data, d_indptr, a->pow_alpha);
+        else {
+            // log_logbase = log(logbase) held in the data type (normalization.pyx:223, 296)
+            const T llb = (T)log(a->logbase);
+            hipLaunchKernelGGL((sp_doc_stats_kernel<T>), dim3(wb), dim3(256), 0, stream, a->n_rows, (const T *)data, d_indices, d_indptr, (T *)doc_len, df);
+            hipLaunchKernelGGL((sp_idf_kernel<T>), dim3((a->n_cols + 255) / 256), dim3(256), 0, stream, a->n_cols, (const int *)df, (T *)idf, a->n_rows, a->idf_mode, llb);
+            hipLaunchKernelGGL((sp_avg_doc_len_kernel<T>), dim3(1), dim3(1024), 0, stream, a->n_rows, (const T *)doc_len, (T *)avg);
+            if (a->mode == SP_NORM_TFIDF)
+                hipLaunchKernelGGL((sp_tf_weight_kernel<T, RO_TFIDF>), dim3(wb), dim3(256), 0, stream, a->n_rows, data, d_indices, d_indptr, (const T *)doc_len,
+                                   (const T *)idf, (const T *)avg, a->tf_mode, llb, (T)0, (T)0, (T)0);
+            else
+                hipLaunchKernelGGL((sp_tf_weight_kernel<T, RO_BM25PLUS>), dim3(wb), dim3(256), 0, stream, a->n_rows, data, d_indices, d_indptr, (const T *)doc_len,
+                                   (const T *)idf, (const T *)avg, a->tf_mode, llb, (T)a->k1, (T)a->b, (T)a->delta);
+        }
+    };
+    if (a->dtype) run(double()); else run(float());
+    HIP_TRY(hipGetLastError());
+    if (timed) { HIP_TRY(hipEventRecord(ev1, stream)); HIP_TRY(hipEventSynchronize(ev1)); HIP_TRY(hipEventElapsedTime(&a->kernel_ms, ev0, ev1)); }
+    if (!a->on_device) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(a->data, d_data, (size_t)a->nnz * esz, hipMemcpyDeviceToHost));
     }
     return SP_OK;
 }

@@ -128,12 +128,35 @@ def _p3_inputs(matrix1, matrix2, alpha):
     return matrix1, matrix2, raw_m2
 
 
+def _p3_on_device(matrix1, matrix2, binary, filter_cols, target_cols) -> bool:
+    """Can the whole preprocessing of p3alpha / rp3beta run inside the kernel call (SP_FLAG_P3_PREP, include/sp_knn.h)?
+    Only for the plain call: matrix2 = matrix1.T, float32 data (float64 input is normalised in float64 by the reference),
+    no `binary` (which throws the normalised values away), no array-style column selectors (they edit m2 on the host)."""
+    from scipy.sparse import issparse
+    if matrix2 is not None or binary or not issparse(matrix1) or matrix1.data.dtype != np.float32:
+        return False
+    for sel in (filter_cols, target_cols):
+        if isinstance(sel, (list, np.ndarray)) and len(sel) != 0:
+            return False
+    return True
+
+
+def _run_p3(matrix1, alpha, beta, k, shrink, shrink_type, threshold, target_rows, target_cols, filter_cols, verbose, format_output):
+    stab, bayes, add = __get_shrink_values__(shrink, shrink_type)
+    return _host._s_plus_impl(
+        matrix1, None, 'none', 'none', 0.0, 0.0 if beta is None else beta, 1.0, 0.0, 0.0, 0.0 if beta is None else 1.0,
+        1.0, 1.0, 0.5, 0.5, k, stab, bayes, add, threshold, False, target_rows, filter_cols, target_cols, verbose, format_output,
+        p3_alpha=alpha, p3_depop_beta=beta)
+
+
 def p3alpha(matrix1: sparray, matrix2: Optional[sparray] = None, alpha: float = 1.0, k: int = 100,
             shrink: float = 0.0, shrink_type: _Shrink = 'stabilized', threshold: float = 0.0,
             binary: bool = False, target_rows: _Rows = None, target_cols: _Cols = None,
             filter_cols: _Cols = None, verbose: bool = True, format_output: _Fmt = 'coo',
             num_threads: int = 0, block_size: Optional[int] = 0) -> sparray:
     """Top-k P3alpha: product of the two row-stochastic transition matrices, entries ^alpha."""
+    if _p3_on_device(matrix1, matrix2, binary, filter_cols, target_cols):
+        return _run_p3(matrix1, alpha, None, k, shrink, shrink_type, threshold, target_rows, target_cols, filter_cols, verbose, format_output)
     matrix1, matrix2, _ = _p3_inputs(matrix1, matrix2, alpha)
     return _run(matrix1, matrix2, {}, k, shrink, shrink_type, threshold, binary, target_rows, target_cols,
                 filter_cols, verbose, format_output, num_threads, block_size)
@@ -145,6 +168,8 @@ def rp3beta(matrix1: sparray, matrix2: Optional[sparray] = None, alpha: float = 
             filter_cols: _Cols = None, verbose: bool = True, format_output: _Fmt = 'coo',
             num_threads: int = 0, block_size: Optional[int] = 0) -> sparray:
     """Top-k RP3beta: P3alpha divided by (column popularity of the raw matrix2)^beta."""
+    if _p3_on_device(matrix1, matrix2, binary, filter_cols, target_cols):
+        return _run_p3(matrix1, alpha, beta, k, shrink, shrink_type, threshold, target_rows, target_cols, filter_cols, verbose, format_output)
     if matrix2 is None:
         matrix2 = matrix1.T
     pop_m2 = np.asarray(matrix2.sum(axis=0)).ravel()          # similarity.py:479 — BEFORE normalisation

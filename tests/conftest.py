@@ -88,13 +88,32 @@ def oracle_backend(monkeypatch):
     HOST logic (wrappers, preprocessing, output assembly) against the reference's golden vectors.
     The product never does this."""
     from oracle import splus_oracle as so
-    from similaripy_amd import _host
+    from similaripy_amd import _abi, _host
 
     def run(call, *a, **kw):
+        import dataclasses
+        import scipy.sparse as sp
+        from oracle import norm_oracle
+        if kw.get("check_zeros") and (np.count_nonzero(call.m1_data) != call.m1_data.shape[0] or np.count_nonzero(call.m2_data) != call.m2_data.shape[0]):
+            raise _abi.ExplicitZerosError("stored zeros")            # what SP_FLAG_CHECK_ZEROS reports
+        if call.p3_alpha is not None:
+            # SP_FLAG_P3_PREP / SP_FLAG_DEPOP_ROWSUM, as the reference does it on the host (similarity.py:410-415, 477-483)
+            m1 = sp.csr_array((call.m1_data, call.m1_indices, call.m1_indptr), shape=(call.n_rows_m1, call.n_rows_m2))
+            m2 = m1.T.tocsr()
+            m2.sort_indices()
+            rep = {}
+            if call.depop_rowsum_p2 is not None:
+                pop = np.asarray(m2.sum(axis=0)).ravel()
+                rep["Ydepop"] = np.power(pop, np.float32(call.depop_rowsum_p2), dtype=np.float32)
+            a1 = norm_oracle.normalize(m1, norm="l1")
+            a1.data = np.power(a1.data, np.float32(call.p3_alpha))
+            b1 = norm_oracle.normalize(m2, norm="l1")
+            b1.data = np.power(b1.data, np.float32(call.p3_alpha))
+            call = dataclasses.replace(call, m1_data=np.ascontiguousarray(a1.data, dtype=np.float32), m2_data=np.ascontiguousarray(b1.data, dtype=np.float32),
+                                       m2_indices=np.ascontiguousarray(b1.indices, dtype=np.int32), m2_indptr=np.ascontiguousarray(b1.indptr, dtype=np.int32),
+                                       m2_is_m1t=False, p3_alpha=None, depop_rowsum_p2=None, **rep)
         if call.m2_is_m1t:
             # the product leaves m1^T to the device (SP_FLAG_M2_IS_M1_T); the oracle gets it from scipy, as the reference does
-            import dataclasses
-            import scipy.sparse as sp
             m2 = sp.csr_array((call.m1_data, call.m1_indices, call.m1_indptr), shape=(call.n_rows_m1, call.n_rows_m2)).T.tocsr()
             m2.sort_indices()
             call = dataclasses.replace(call, m2_data=np.ascontiguousarray(m2.data, dtype=np.float32),
@@ -102,9 +121,17 @@ def oracle_backend(monkeypatch):
                                        m2_indptr=np.ascontiguousarray(m2.indptr, dtype=np.int32), m2_is_m1t=False)
         rows, cols, values = so.run_kernel(call, "port")
         counts, _ = so.slot_counts(rows, cols, values, call.targets, call.k) if call.n_targets else (np.zeros(0, np.int32), None)
+        if kw.get("csr_out"):
+            # SP_FLAG_CSR_OUT: what the device assembles is what build_csr assembles on the host
+            res = _host.build_csr(call.targets, cols, values, counts, call.k, call.n_rows_m1, call.n_output_cols)
+            return res.indptr.astype(np.int32), res.indices.astype(np.int32), res.data.astype(np.float32)
         return rows, cols, values, counts
 
     monkeypatch.setattr(_host, "run_hip", run)
+    # (the product's row normalisers run on the device: their NumPy restatement stands in)
+    from oracle import norm_oracle
+    from similaripy_amd import normalization
+    monkeypatch.setattr(normalization, "_run", norm_oracle.inplace_run)
     # (same for the device-side norms of the `matrix2=None` call: their NumPy statement stands in)
     monkeypatch.setattr(_host, "squared_norms_m1t_hip", lambda data, indptr, device=None: _host.build_squared_norms_m1t(data, indptr))
     return run

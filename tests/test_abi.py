@@ -19,7 +19,7 @@ PREP_HEADER = (ROOT / "include" / "sp_prep.h").read_text()
 
 def test_library_builds_and_loads():
     lib = _abi.load()
-    assert lib.sp_abi_version() == 1
+    assert lib.sp_abi_version() == 2
 
 
 def test_every_declared_symbol_is_exported():
@@ -86,6 +86,35 @@ def test_sqsums_struct_layout_and_refusals():
         assert lib.sp_csr_row_sqsums_f32(C.byref(a)) == -2            # SP_ENODEVICE: no CPU fallback
         with pytest.raises(_abi.HipLibraryError):
             _host.squared_norms_m1t_hip(np.ones(3, np.float32), np.array([0, 1, 3], np.int32))
+
+
+def test_normalize_struct_layout_and_refusals():
+    body = PREP_HEADER[PREP_HEADER.index("typedef struct sp_csr_normalize_args {") + len("typedef struct sp_csr_normalize_args {"):PREP_HEADER.index("} sp_csr_normalize_args;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for stmt in body.split(";"):
+        stmt = stmt.strip()
+        if not stmt:
+            continue
+        first, *rest = stmt.split(",")
+        names.append(first.split()[-1].lstrip("*"))
+        names += [r.strip().lstrip("*") for r in rest]
+    assert names == [f[0] for f in _abi.SpCsrNormalizeArgs._fields_]
+    lib = _abi.load()
+    a = _abi.SpCsrNormalizeArgs()
+    a.struct_size = 4
+    assert lib.sp_csr_normalize(C.byref(a)) == -1                     # SP_EINVAL
+    a.struct_size = C.sizeof(_abi.SpCsrNormalizeArgs)
+    a.mode = 9
+    assert lib.sp_csr_normalize(C.byref(a)) == -1 and b"bad mode" in lib.sp_last_error()
+    indptr = np.zeros(4, dtype=np.int32)
+    a.mode, a.n_rows, a.nnz, a.indptr = _abi.SP_NORM_L1, 3, 0, indptr.ctypes.data
+    if lib.sp_device_count() == 0:
+        assert lib.sp_csr_normalize(C.byref(a)) == -2                 # SP_ENODEVICE: no CPU fallback
+        from similaripy_amd.normalization import normalize
+        with pytest.raises(_abi.HipLibraryError):
+            normalize(sp.random_array((5, 4), density=0.5, format="csr", dtype=np.float32, random_state=np.random.default_rng(0)), norm="l1")
+    assert lib.sp_device_cache_trim() >= 0
 
 
 def test_struct_size_is_checked():

@@ -26,7 +26,7 @@ sys.path.insert(0, str(ROOT))
 import similaripy_amd as sim                            # noqa: E402
 from oracle import splus_oracle as so                  # noqa: E402
 from similaripy_amd import _host, workloads            # noqa: E402
-from similaripy_amd.normalization import normalize     # noqa: E402
+from oracle.norm_oracle import normalize               # noqa: E402  (NumPy statement of the reference's L1 normaliser)
 
 pytestmark = pytest.mark.gpu
 

@@ -542,3 +542,114 @@ def test_public_call_device_transpose_edge_shapes():
     m64 = sp.random_array((300, 80), density=0.1, format="csc", dtype=np.float64, random_state=rng)
     chk(m64, 9, binary=True); chk(m64, 9, shrink=2.0)
     chk(sp.csr_array(rng.integers(0, 3, (60, 40)).astype(np.int64)), 4)
+
+
+# ---------------------------------------------------------------------------------------------
+# host-side stages of s_plus.pyx on the device (ABI 2): stored zeros, CSR assembly, p3 preprocessing
+# ---------------------------------------------------------------------------------------------
+def _csr_equal(a: sp.csr_array, b: sp.csr_array):
+    a, b = a.copy(), b.copy()
+    a.sort_indices()
+    b.sort_indices()
+    np.testing.assert_array_equal(a.indptr, b.indptr)
+    np.testing.assert_array_equal(a.indices, b.indices)
+    np.testing.assert_array_equal(a.data, b.data)
+
+
+@pytest.mark.parametrize("shape,density,k", [((500, 300), 0.05, 20), ((64, 4000), 0.01, 7), ((3000, 40), 0.3, 3000)], ids=["ragged", "wide", "k_clamped"])
+def test_device_csr_assembly_equals_host_assembly(shape, density, k):
+    """SP_FLAG_CSR_OUT (counts -> scan -> compaction -> zeros dropped, coo_to_csr.h:28-71 + s_plus.pyx:424) gives the
+    matrix build_csr assembles on the host from the same slots: empty rows, short slots, sorted target subsets."""
+    m = _rand(shape, density, 31).tolil()
+    m[5, :] = 0
+    m[17, :] = 0
+    m = sp.csr_array(m.tocsr())
+    for target_rows in (None, np.array([2, 3, 5, 40, 41, 63], dtype=np.int32)):
+        for kw in (dict(l2=1), dict(threshold=0.0), dict(l1=1, threshold=0.3)):
+            call = _host.prepare(m, k=k, target_rows=target_rows, **kw)
+            rows, cols, vals, counts = _host.run_hip(call)
+            want = _host.build_csr(call.targets, cols, vals, counts, call.k, call.n_rows_m1, call.n_output_cols)
+            indptr, indices, data = _host.run_hip(call, csr_out=True)
+            got = sp.csr_array((data, indices, indptr), shape=want.shape)
+            assert indptr.dtype == np.int32 and indptr[-1] == data.shape[0] == indices.shape[0]
+            _csr_equal(got, want)
+    # genuine zero values among the winners are dropped like padding: signed data whose dot products cancel exactly
+    z = sp.csr_array(np.array([[1, -1, 0, 0], [1, 1, 0, 0], [0, 0, 2, 0], [1, 0, 0, 0]], dtype=np.float32))
+    call = _host.prepare(z, k=4, threshold=-10.0)
+    rows, cols, vals, counts = _host.run_hip(call)
+    assert (vals.reshape(4, 4)[0][:counts[0]] == 0).any()                     # row 0 . row 1 = 0, kept in COO (SURVEY A.3 #5)
+    want = _host.build_csr(call.targets, cols, vals, counts, 4, 4, 4)
+    indptr, indices, data = _host.run_hip(call, csr_out=True)
+    _csr_equal(sp.csr_array((data, indices, indptr), shape=(4, 4)), want)
+    # unsorted / repeated targets are refused by the device path (the wrappers then assemble on the host)
+    bad = _host.prepare(m, k=3, target_rows=[7, 2])
+    with pytest.raises(_abi.HipLibraryError, match="strictly increasing"):
+        _host.run_hip(bad, csr_out=True)
+    res = sim.cosine(m, k=3, target_rows=[7, 2, 7], verbose=False, format_output="csr")      # host assembly, rows added up slot after slot
+    assert res[[7], :].nnz == 6 and res[[2], :].nnz == 3
+
+
+def test_stored_zeros_found_on_device_and_eliminated():
+    """s_plus.pyx:210-211: explicit zeros are dropped before anything else.  The public call looks for them on the device
+    (SP_FLAG_CHECK_ZEROS) and only then pays for the host pass."""
+    m = _rand((300, 200), 0.06, 8)
+    mz = m.copy()
+    mz.data[::9] = 0.0                                     # stored zeros
+    clean = mz.copy()
+    clean.eliminate_zeros()
+    call = _host.prepare(mz, k=10, l2=1, check_zeros=False)
+    with pytest.raises(_abi.ExplicitZerosError):
+        _host.run_hip(call, check_zeros=True)
+    _host.run_hip(_host.prepare(clean, k=10, l2=1, check_zeros=False), check_zeros=True)      # nothing to report
+    for fn, kw in ((sim.cosine, {}), (sim.jaccard, {}), (sim.dot_product, dict(binary=True)), (sim.p3alpha, dict(alpha=0.7)),
+                   (sim.rp3beta, dict(alpha=0.7, beta=0.3))):
+        a = fn(mz, k=10, verbose=False, format_output="csr", **kw)
+        b = fn(clean, k=10, verbose=False, format_output="csr", **kw)
+        _csr_equal(a, b)
+    assert mz.nnz == m.nnz                                  # the caller's matrix keeps its stored zeros
+    # explicit matrix2 with zeros
+    m2 = _rand((200, 150), 0.1, 9)
+    m2z = m2.copy()
+    m2z.data[::5] = 0.0
+    c2 = m2z.copy()
+    c2.eliminate_zeros()
+    _csr_equal(sim.cosine(m, m2z, k=8, verbose=False, format_output="csr"), sim.cosine(m, c2, k=8, verbose=False, format_output="csr"))
+
+
+@pytest.mark.parametrize("fn,kw", [("p3alpha", dict(alpha=0.8)), ("p3alpha", dict(alpha=1.0)), ("rp3beta", dict(alpha=0.8, beta=0.4)),
+                                   ("rp3beta", dict(alpha=1.7, beta=1.0, shrink=2.0))], ids=["p3alpha", "p3alpha_a1", "rp3beta", "rp3beta_shrink"])
+def test_p3_preprocessing_on_device_matches_host_statement(fn, kw):
+    """SP_FLAG_P3_PREP / SP_FLAG_DEPOP_ROWSUM: the public p3alpha / rp3beta leave L1 normalisation, ^alpha and the column
+    popularity to the device.  Checked against the oracle kernel fed with the reference's host preprocessing in NumPy
+    (similarity.py:410-415, 477-483).  Tolerance: normalised values differ by an ulp (reordered float32 sums), the rest is
+    the kernel's 1e-5."""
+    from oracle import norm_oracle
+    m = _rand((700, 500), 0.03, 12).tolil()
+    m[3, :] = 0                                            # an empty row and an empty column
+    m[:, 9] = 0
+    m = sp.csr_array(m.tocsr())
+    k = 15
+    res = getattr(sim, fn)(m, k=k, verbose=False, format_output="csr", **kw)
+    m2 = m.T.tocsr()
+    a = norm_oracle.normalize(m, norm="l1")
+    a.data = np.power(a.data, np.float32(kw["alpha"]))
+    b = norm_oracle.normalize(m2, norm="l1")
+    b.data = np.power(b.data, np.float32(kw["alpha"]))
+    extra = dict(stabilized_shrink=kw.get("shrink", 0.0))
+    if fn == "rp3beta":
+        extra.update(weight_depop_matrix2=np.asarray(m2.sum(axis=0)).ravel(), p2=kw["beta"], l3=1)
+    call = _host.prepare(a, b, k=k, **extra)
+    want = so.canonical(*so.run_kernel(call, "port"), call.targets, k)
+    want = [(c[v != 0], v[v != 0]) for c, v in want]
+    got = []
+    for t in range(m.shape[0]):
+        c, v = res.indices[res.indptr[t]:res.indptr[t + 1]], res.data[res.indptr[t]:res.indptr[t + 1]]
+        o = np.argsort(c)
+        got.append((c[o].astype(np.int32), v[o].astype(np.float32)))
+    so.compare_topk(got, want, k, rtol=2e-5, atol=1e-9, what=fn)
+    # the call did not touch the caller's matrix, and float64 / explicit matrix2 / binary calls (host preprocessing) agree with it
+    res64 = getattr(sim, fn)(m.astype(np.float64), k=k, verbose=False, format_output="csr", **kw)
+    res_m2 = getattr(sim, fn)(m, m.T.tocsr(), k=k, verbose=False, format_output="csr", **kw)
+    for other in (res64, res_m2):
+        assert abs(other.sum() - res.sum()) <= 2e-5 * abs(res.sum())
+        assert other.nnz == res.nnz

@@ -9,7 +9,7 @@ import scipy.sparse as sp
 import similaripy_amd as sim
 from oracle import splus_oracle as so
 from similaripy_amd import _host
-from similaripy_amd.normalization import normalize
+from oracle.norm_oracle import normalize      # (the NumPy restatement; the product's runs on the device: tests/test_normalization.py)
 
 
 def _csr(m):
