@@ -548,12 +548,14 @@ def test_public_call_device_transpose_edge_shapes():
 # host-side stages of s_plus.pyx on the device (ABI 2): stored zeros, CSR assembly, p3 preprocessing
 # ---------------------------------------------------------------------------------------------
 def _csr_equal(a: sp.csr_array, b: sp.csr_array):
+    """Same structure; values to 1e-6: the two matrices come from two kernel runs, whose float32 sums are formed by LDS
+    atomics in an order that differs from run to run (an ulp)."""
     a, b = a.copy(), b.copy()
     a.sort_indices()
     b.sort_indices()
     np.testing.assert_array_equal(a.indptr, b.indptr)
     np.testing.assert_array_equal(a.indices, b.indices)
-    np.testing.assert_array_equal(a.data, b.data)
+    np.testing.assert_allclose(a.data, b.data, rtol=1e-6, atol=0)
 
 
 @pytest.mark.parametrize("shape,density,k", [((500, 300), 0.05, 20), ((64, 4000), 0.01, 7), ((3000, 40), 0.3, 3000)], ids=["ragged", "wide", "k_clamped"])
@@ -605,7 +607,15 @@ def test_stored_zeros_found_on_device_and_eliminated():
                    (sim.rp3beta, dict(alpha=0.7, beta=0.3))):
         a = fn(mz, k=10, verbose=False, format_output="csr", **kw)
         b = fn(clean, k=10, verbose=False, format_output="csr", **kw)
-        _csr_equal(a, b)
+        if kw.get("binary"):
+            # integer dot products tie at the k-th place: the kept VALUES are determined, the columns among the tied are not
+            np.testing.assert_array_equal(a.indptr, b.indptr)
+            va = np.sort(a.data.reshape(-1, 10), axis=1) if a.nnz == 3000 else None
+            vb = np.sort(b.data.reshape(-1, 10), axis=1) if b.nnz == 3000 else None
+            assert va is not None and vb is not None
+            np.testing.assert_array_equal(va, vb)
+        else:
+            _csr_equal(a, b)
     assert mz.nnz == m.nnz                                  # the caller's matrix keeps its stored zeros
     # explicit matrix2 with zeros
     m2 = _rand((200, 150), 0.1, 9)
