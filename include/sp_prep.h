@@ -78,6 +78,30 @@ typedef struct sp_csr_sqsums_args {
    = csr_sum(m1^2, axis=1) and csr_sum((m1^T)^2, axis=0) (:128-166), both from the rows of m1, bit-identical to NumPy. */
 int sp_csr_row_sqsums_f32(sp_csr_sqsums_args *args);
 
+/* Column sums of a CSR as np.bincount forms them (float64 accumulator, rounded to float32 at the end):
+ *   csr_sum(axis=0)                       similaripy/cython_code/s_plus_utils.pyx:160-164
+ * used by _build_squared_norms (:169-201) for the columns of an explicit matrix2 (square = 1: sums of data^2, the square
+ * formed in float32 as np.square does) and by _build_depop_normalization (:231-278) for weight 'sum' (square = 0).
+ * The float64 additions happen in whatever order the atomics arrive: the float32 result is np.bincount's except for
+ * the rare sum whose float64 rounding error straddles a float32 rounding boundary (one ulp). */
+typedef struct sp_csr_colsums_args {
+    uint32_t struct_size;      /* = sizeof(sp_csr_colsums_args); checked */
+    uint32_t flags;            /* SP_FLAG_TIME_KERNEL or 0 */
+    int32_t  on_device;        /* 0: host pointers; 1: device pointers, asynchronous on `stream` (scratch from the library's cache) */
+    int32_t  device;
+    int32_t  n_cols;
+    int32_t  square;           /* 1: sum of data^2, 0: sum of data */
+    int64_t  nnz;
+    const float   *data;       /* [nnz] */
+    const int32_t *indices;    /* [nnz], each in [0, n_cols) */
+    float   *out;              /* [n_cols] */
+    void    *stream;
+    float    kernel_ms;        /* OUT with SP_FLAG_TIME_KERNEL */
+    int32_t  _pad0;
+} sp_csr_colsums_args;
+
+int sp_csr_col_sums_f32(sp_csr_colsums_args *args);
+
 /* ---- row normalisers ------------------------------------------------------------------------------
  * In-place weighting of the rows of a CSR, the device counterpart of
  *   inplace_normalize_csr_l1 / _l2 / _max      similaripy/cython_code/normalization.pyx:97-197

@@ -153,6 +153,26 @@ class SpCsrSqsumsArgs(C.Structure):
     ]
 
 
+class SpCsrColsumsArgs(C.Structure):
+    """Mirror of ``struct sp_csr_colsums_args`` (include/sp_prep.h) — keep field order identical."""
+
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("flags", C.c_uint32),
+        ("on_device", C.c_int32),
+        ("device", C.c_int32),
+        ("n_cols", C.c_int32),
+        ("square", C.c_int32),
+        ("nnz", C.c_int64),
+        ("data", C.c_void_p),
+        ("indices", C.c_void_p),
+        ("out", C.c_void_p),
+        ("stream", C.c_void_p),
+        ("kernel_ms", C.c_float),
+        ("_pad0", C.c_int32),
+    ]
+
+
 class SpCsrNormalizeArgs(C.Structure):
     """Mirror of ``struct sp_csr_normalize_args`` (include/sp_prep.h) — keep field order identical."""
 
@@ -193,6 +213,7 @@ EXPORTED_SYMBOLS = (
     "sp_csr_transpose_workspace_bytes",
     "sp_csr_row_sqsums_f32",
     "sp_csr_normalize",
+    "sp_csr_col_sums_f32",
     "sp_device_cache_trim",
 )
 
@@ -261,6 +282,8 @@ def load(build_if_missing: bool = True):
     lib.sp_csr_row_sqsums_f32.restype = C.c_int
     lib.sp_csr_normalize.argtypes = [C.POINTER(SpCsrNormalizeArgs)]
     lib.sp_csr_normalize.restype = C.c_int
+    lib.sp_csr_col_sums_f32.argtypes = [C.POINTER(SpCsrColsumsArgs)]
+    lib.sp_csr_col_sums_f32.restype = C.c_int
     lib.sp_device_cache_trim.argtypes = []
     lib.sp_device_cache_trim.restype = C.c_int64
     _lib = lib
@@ -331,6 +354,14 @@ def call_normalize(args: SpCsrNormalizeArgs) -> None:
     rc = lib.sp_csr_normalize(C.byref(args))
     if rc != 0:
         raise HipLibraryError(f"sp_csr_normalize failed ({rc}): {last_error()}")
+
+
+def call_col_sums(args: SpCsrColsumsArgs) -> None:
+    lib = load()
+    args.struct_size = C.sizeof(SpCsrColsumsArgs)
+    rc = lib.sp_csr_col_sums_f32(C.byref(args))
+    if rc != 0:
+        raise HipLibraryError(f"sp_csr_col_sums_f32 failed ({rc}): {last_error()}")
 
 
 def device_cache_trim() -> int:

@@ -185,6 +185,42 @@ def squared_norms_m1t_hip(m1_data, m1_indptr, device: Optional[int] = None):
     return sq1, sq2
 
 
+def col_sums_hip(data, indices, n_cols: int, square: bool, device: Optional[int] = None) -> np.ndarray:
+    """csr_sum(axis=0) of a float32 CSR on the GPU (sp_csr_col_sums_f32, include/sp_prep.h): np.bincount's float64
+    accumulation, rounded to float32 (s_plus_utils.pyx:160-164); square: of data^2 (np.square in float32 first).  No CPU fallback."""
+    _abi.require_device()
+    out = np.zeros(n_cols, dtype=np.float32)
+    a = _abi.SpCsrColsumsArgs()
+    a.on_device = 0
+    a.device = selected_device() if device is None else int(device)
+    a.n_cols, a.square, a.nnz = int(n_cols), 1 if square else 0, int(data.shape[0])
+    d, i = _abi.as_f32(data), _abi.as_i32(indices)
+    a.data = d.ctypes.data if d.size else None
+    a.indices = i.ctypes.data if i.size else None
+    a.out = out.ctypes.data if n_cols else None
+    if n_cols:
+        _abi.call_col_sums(a)
+    return out
+
+
+def squared_norms_hip(m1_data, m1_indptr, m2_data, m2_indices, n_cols_m2: int):
+    """build_squared_norms for an EXPLICIT matrix2 on the GPU: the row sums of m1^2 (sp_csr_row_sqsums_f32: NumPy's pairwise
+    order, bit for bit) and the column sums of m2^2 (sp_csr_col_sums_f32: np.bincount's float64 accumulator)."""
+    _abi.require_device()
+    n_rows = int(m1_indptr.shape[0]) - 1
+    sq1 = np.zeros(n_rows, dtype=np.float32)
+    if n_rows and m1_data.shape[0]:
+        a = _abi.SpCsrSqsumsArgs()
+        a.on_device = 0
+        a.device = selected_device()
+        a.n_rows, a.nnz = n_rows, int(m1_data.shape[0])
+        data, indptr = _abi.as_f32(m1_data), _abi.as_i32(m1_indptr)
+        a.data, a.indptr = data.ctypes.data, indptr.ctypes.data
+        a.out_rows, a.out_cols_of_t = sq1.ctypes.data, None
+        _abi.call_row_sqsums(a)
+    return sq1, col_sums_hip(m2_data, m2_indices, n_cols_m2, square=True)
+
+
 def build_squared_norms_m1t(m1_data, m1_indptr):
     """build_squared_norms for m2 = m1^T without m2: the column sums of m2^2 are the row sums of m1^2, added up
     the way the reference adds the columns of m2 (np.bincount: float64, storage order — s_plus_utils.pyx:160-164;
@@ -204,7 +240,7 @@ def build_cosine_normalization(m1_sq, m2_sq, c1, c2, additive_shrink):
             np.power(m2_sq + add, c2, dtype=np.float32))
 
 
-def build_depop_normalization(m1, m2, n_rows_m1, n_cols_m2, weight_spec1, weight_spec2, p1, p2):
+def build_depop_normalization(m1, m2, n_rows_m1, n_cols_m2, weight_spec1, weight_spec2, p1, p2, sums_on_device: bool = False):
     """w^p, 'none' -> ones, 'sum' -> csr_sum^p — s_plus_utils.pyx:231-278.
     m1/m2 are (data, indices, indptr, n_cols) tuples of the float32 (or binarised) matrices."""
     p1, p2 = float(np.float32(p1)), float(np.float32(p2))
@@ -216,6 +252,8 @@ def build_depop_normalization(m1, m2, n_rows_m1, n_cols_m2, weight_spec1, weight
             return np.ones(n_rows_m1 if which == 1 else n_cols_m2, dtype=np.float32)
         if spec == 'sum':
             d, i, ptr, nc = m1 if which == 1 else m2
+            if which == 2 and sums_on_device:      # column sums of m2: the device's np.bincount (sp_csr_col_sums_f32)
+                return np.power(col_sums_hip(d, i, nc, square=False), p, dtype=np.float32)
             return np.power(csr_sum(d, i, ptr, nc, axis=1 if which == 1 else 0), p, dtype=np.float32)
         raise ValueError(f"Invalid weight_spec{which}: {spec}")
 
@@ -412,6 +450,8 @@ def prepare(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_mat
     if l1 != 0 or l2 != 0:
         if on_dev:
             sq1, sq2 = squared_norms_m1t_hip(m1_data, m1_indptr)
+        elif m2_on_device:      # (the public call with an explicit matrix2: both norm vectors from the device)
+            sq1, sq2 = squared_norms_hip(m1_data, m1_indptr, m2_data, m2_indices, n_output_cols)
         else:
             sq1, sq2 = build_squared_norms(m1_data, m1_indices, m1_indptr, n_rows_m2,
                                            m2_data, m2_indices, m2_indptr, n_output_cols)
@@ -426,7 +466,7 @@ def prepare(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_mat
     elif l3 != 0:
         call.Xdepop, call.Ydepop = build_depop_normalization(
             (m1_data, m1_indices, m1_indptr, n_rows_m2), (m2_data, m2_indices, m2_indptr, n_output_cols),
-            n_rows_m1, n_output_cols, weight_depop_matrix1, weight_depop_matrix2, p1, p2)
+            n_rows_m1, n_output_cols, weight_depop_matrix1, weight_depop_matrix2, p1, p2, sums_on_device=bool(m2_on_device))
         call.Xdepop = np.ascontiguousarray(call.Xdepop, dtype=np.float32)
         call.Ydepop = np.ascontiguousarray(call.Ydepop, dtype=np.float32)
 

@@ -943,6 +943,51 @@ int64_t sp_device_cache_trim(void) {
     return (int64_t)g_cache.trim(dev);
 }
 
+int sp_csr_col_sums_f32(sp_csr_colsums_args *a) {
+    g_err[0] = 0;
+    if (!a || a->struct_size != sizeof(sp_csr_colsums_args)) return fail(SP_EINVAL, "sp_csr_colsums_args size mismatch");
+    if (a->n_cols < 0 || a->nnz < 0 || a->nnz > 0x7FFFFFFFLL) return fail(SP_EINVAL, "bad shape / nnz");
+    if ((a->n_cols > 0 && !a->out) || (a->nnz > 0 && (!a->data || !a->indices))) return fail(SP_EINVAL, "NULL pointer");
+    const int ndev = sp_device_count();
+    if (ndev <= 0) return fail(SP_ENODEVICE, "no HIP device visible: similaripy_amd has no CPU fallback");
+    if (a->device < 0 || a->device >= ndev) return fail(SP_EINVAL, "device %d out of range (have %d)", a->device, ndev);
+    HIP_TRY(hipSetDevice(a->device));
+    a->kernel_ms = 0.f;
+    if (a->n_cols == 0) return SP_OK;
+    DevPool pool;
+    pool.device = a->device;
+    const float *d_data = a->data;
+    const int32_t *d_idx = a->indices;
+    float *d_out = a->out;
+    hipStream_t stream = a->on_device ? (hipStream_t)a->stream : nullptr;
+    if (!a->on_device) {
+        for (int64_t i = 0; i < a->nnz; ++i)
+            if (a->indices[i] < 0 || a->indices[i] >= a->n_cols) return fail(SP_EINVAL, "indices[%lld]=%d out of range [0,%d)", (long long)i, a->indices[i], a->n_cols);
+        TRY(pool.up(a->data, (size_t)a->nnz, &d_data));
+        TRY(pool.up(a->indices, (size_t)a->nnz, &d_idx));
+        TRY(pool.alloc((size_t)a->n_cols, &d_out));
+    }
+    double *acc = nullptr;
+    TRY(pool.alloc((size_t)a->n_cols, &acc));
+    const bool timed = (a->flags & SP_FLAG_TIME_KERNEL) != 0;
+    CallGuard guard;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (timed) { TRY(guard.event(&ev0)); TRY(guard.event(&ev1)); HIP_TRY(hipEventRecord(ev0, stream)); }
+    HIP_TRY(hipMemsetAsync(acc, 0, (size_t)a->n_cols * 8, stream));
+    if (a->nnz > 0) {
+        if (a->square) hipLaunchKernelGGL((sp_col_sums_f64_kernel<true>), dim3(256 * 8), dim3(256), 0, stream, (long long)a->nnz, d_data, d_idx, acc);
+        else hipLaunchKernelGGL((sp_col_sums_f64_kernel<false>), dim3(256 * 8), dim3(256), 0, stream, (long long)a->nnz, d_data, d_idx, acc);
+    }
+    hipLaunchKernelGGL(sp_f64_to_f32_kernel, dim3((a->n_cols + 255) / 256), dim3(256), 0, stream, a->n_cols, (const double *)acc, d_out);
+    HIP_TRY(hipGetLastError());
+    if (timed) { HIP_TRY(hipEventRecord(ev1, stream)); HIP_TRY(hipEventSynchronize(ev1)); HIP_TRY(hipEventElapsedTime(&a->kernel_ms, ev0, ev1)); }
+    if (!a->on_device) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(a->out, d_out, (size_t)a->n_cols * 4, hipMemcpyDeviceToHost));
+    }
+    return SP_OK;
+}
+
 int sp_csr_normalize(sp_csr_normalize_args *a) {
     g_err[0] = 0;
     if (!a || a->struct_size != sizeof(sp_csr_normalize_args)) return fail(SP_EINVAL, "sp_csr_normalize_args size mismatch");

@@ -128,6 +128,9 @@ def oracle_backend(monkeypatch):
         return rows, cols, values, counts
 
     monkeypatch.setattr(_host, "run_hip", run)
+    monkeypatch.setattr(_host, "squared_norms_hip", lambda d1, p1, d2, i2, nc: (
+        _host.csr_sum(np.square(d1, dtype=np.float32), None, p1, 0, axis=1), _host.csr_sum(np.square(d2, dtype=np.float32), i2, None, nc, axis=0)))
+    monkeypatch.setattr(_host, "col_sums_hip", lambda d, i, nc, square, device=None: _host.csr_sum(np.square(d, dtype=np.float32) if square else d, i, None, nc, axis=0))
     # (the product's row normalisers run on the device: their NumPy restatement stands in)
     from oracle import norm_oracle
     from similaripy_amd import normalization

@@ -117,6 +117,22 @@ def test_normalize_struct_layout_and_refusals():
     assert lib.sp_device_cache_trim() >= 0
 
 
+def test_colsums_struct_layout_and_refusals():
+    body = PREP_HEADER[PREP_HEADER.index("typedef struct sp_csr_colsums_args {") + len("typedef struct sp_csr_colsums_args {"):PREP_HEADER.index("} sp_csr_colsums_args;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = [stmt.strip().split()[-1].lstrip("*") for stmt in body.split(";") if stmt.strip()]
+    assert names == [f[0] for f in _abi.SpCsrColsumsArgs._fields_]
+    lib = _abi.load()
+    a = _abi.SpCsrColsumsArgs()
+    a.struct_size = 4
+    assert lib.sp_csr_col_sums_f32(C.byref(a)) == -1                  # SP_EINVAL
+    a.struct_size = C.sizeof(_abi.SpCsrColsumsArgs)
+    out = np.zeros(3, dtype=np.float32)
+    a.n_cols, a.nnz, a.out = 3, 0, out.ctypes.data
+    if lib.sp_device_count() == 0:
+        assert lib.sp_csr_col_sums_f32(C.byref(a)) == -2              # SP_ENODEVICE: no CPU fallback
+
+
 def test_struct_size_is_checked():
     lib = _abi.load()
     a = _abi.SpKnnArgs()

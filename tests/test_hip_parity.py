@@ -663,3 +663,29 @@ def test_p3_preprocessing_on_device_matches_host_statement(fn, kw):
     for other in (res64, res_m2):
         assert abs(other.sum() - res.sum()) <= 2e-5 * abs(res.sum())
         assert other.nnz == res.nnz
+
+
+def test_device_norms_of_an_explicit_matrix2():
+    """_build_squared_norms / csr_sum(axis=0) for an explicit matrix2 on the device (sp_csr_col_sums_f32): np.bincount's
+    float64 accumulator, so the float32 result is NumPy's (an ulp where the float64 rounding straddles a boundary)."""
+    m1 = _rand((900, 400), 0.05, 41)
+    m2 = _rand((400, 1300), 0.04, 42)
+    m2.data[::3] *= -1
+    want1, want2 = _host.build_squared_norms(m1.data, m1.indices, m1.indptr, 400, m2.data, m2.indices, m2.indptr, 1300)
+    got1, got2 = _host.squared_norms_hip(m1.data, m1.indptr, m2.data, m2.indices, 1300)
+    np.testing.assert_array_equal(got1, want1)
+    np.testing.assert_allclose(got2, want2, rtol=1.2e-7, atol=0)
+    assert (got2 == want2).mean() > 0.999
+    np.testing.assert_allclose(_host.col_sums_hip(m2.data, m2.indices, 1300, square=False), _host.csr_sum(m2.data, m2.indices, m2.indptr, 1300, axis=0), rtol=1e-6, atol=1e-7)
+    # through the public calls: cosine with an explicit matrix2 and s_plus with pop2='sum' equal the host-prepared kernel call
+    for fn, kw, prep in ((sim.cosine, {}, dict(l2=1)), (sim.s_plus, dict(l1=0.0, l2=0.0, l3=1.0, pop2="sum", beta2=0.5), dict(l3=1, weight_depop_matrix2="sum", p2=0.5))):
+        res = fn(m1, m2, k=12, verbose=False, format_output="csr", **kw)
+        call = _host.prepare(m1, m2, k=12, **prep)
+        want = so.canonical(*so.run_kernel(call, "port"), call.targets, 12)
+        want = [(c[v != 0], v[v != 0]) for c, v in want]
+        got = []
+        for t in range(m1.shape[0]):
+            c, v = res.indices[res.indptr[t]:res.indptr[t + 1]], res.data[res.indptr[t]:res.indptr[t + 1]]
+            o = np.argsort(c)
+            got.append((c[o].astype(np.int32), v[o].astype(np.float32)))
+        so.compare_topk(got, want, 12, rtol=RTOL, atol=ATOL, what=fn.__name__)
