@@ -4,6 +4,7 @@ Public surface mirrors similaripy/__init__.py:8-36.
 Compute happens only in libsimilaripy_hip.so (hand-written HIP for gfx950); importing the
 package needs no GPU, calling a similarity function does.
 """
+from . import multi_gpu  # noqa: F401  (one process -> one worker per GPU)
 from .normalization import bm25, bm25plus, normalize, tfidf
 from .similarity import (
     asymmetric_cosine,

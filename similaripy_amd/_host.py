@@ -605,6 +605,23 @@ def s_plus(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_matr
                         binary, target_rows, filter_cols, target_cols, verbose, format_output)
 
 
+_MULTI_GPU_ROUTE: list = []      # set by multi_gpu.similarity() around a wrapper call
+
+
+def multi_gpu_route():
+    """(devices, chunk_rows) when the kernel stage is to be sharded over several GPUs (similaripy_amd.multi_gpu), else None:
+    an explicit multi_gpu.similarity(...) call, or SIMILARIPY_AMD_DEVICES=0,1,... in the environment."""
+    if _MULTI_GPU_ROUTE:
+        r = _MULTI_GPU_ROUTE[-1]
+        return r.devices, r.chunk_rows
+    from .multi_gpu import devices_from_env
+    d = devices_from_env()
+    if d:
+        c = os.environ.get("SIMILARIPY_AMD_CHUNK_ROWS", "")
+        return d, (int(c) if c else None)
+    return None
+
+
 def _s_plus_impl(matrix1, matrix2, weight_depop_matrix1, weight_depop_matrix2, p1, p2, a1, l1, l2, l3,
                  t1, t2, c1, c2, k, stabilized_shrink, bayesian_shrink, additive_shrink, threshold,
                  binary, target_rows, filter_cols, target_cols, verbose, format_output,
@@ -617,6 +634,17 @@ def _s_plus_impl(matrix1, matrix2, weight_depop_matrix1, weight_depop_matrix2, p
             t1, t2, c1, c2, k, stabilized_shrink, bayesian_shrink, additive_shrink, threshold,
             binary, target_rows, filter_cols, target_cols, verbose, format_output)
     p3kw = dict(p3_alpha=p3_alpha, p3_depop_beta=p3_depop_beta)
+    route = multi_gpu_route()
+    if route is not None:
+        # several GPUs: the host stages once, here; the kernel stage in one worker process per GPU (multi_gpu.run_call)
+        if p3_alpha is not None:
+            raise ValueError("the multi-GPU route takes preprocessed matrices (similarity.p3alpha / rp3beta do that)")
+        from . import multi_gpu
+        call = prepare(*args, m2_on_device=False, check_zeros=True)
+        _say(verbose, f"Computing on devices {route[0]}")
+        res = multi_gpu.run_call(call, route[0], format_output, chunk_rows=route[1])
+        _say(verbose, "Done")
+        return res
     # stored zeros: looked for on the device, where the data goes anyway (under `binary` the uploaded data are ones: host check)
     device_zero_check = not binary
     call = prepare(*args, m2_on_device=True, check_zeros=not device_zero_check, **p3kw)

@@ -195,7 +195,7 @@ class ShardedDeviceProblem:
     the gathered slabs to the host in the slot order of `call.targets`.
     """
 
-    def __init__(self, call: KernelCall, group=None, device=None, dst: int = 0, compact: bool = True):
+    def __init__(self, call: KernelCall, group=None, device=None, dst: int = 0, compact: bool = True, chunk_rows: Optional[int] = None):
         import torch
         import torch.distributed as dist
 
@@ -206,12 +206,28 @@ class ShardedDeviceProblem:
         self.world = dist.get_world_size(group) if self.distributed else 1
         self.rank = dist.get_rank(group) if self.distributed else 0
         self.device = torch.device("cuda", local_device()) if device is None else torch.device(device)
-        self.bounds = partition_targets(row_work(call), self.world)
-        self.lo, self.hi = int(self.bounds[self.rank]), int(self.bounds[self.rank + 1])
-        self.n_loc = self.hi - self.lo
-        self.n_max = int(np.max(np.diff(self.bounds)))
+        self.work = row_work(call)
         k = call.k
-        self.prob = DeviceProblem(slice_call(call, self.lo, self.hi, compact=compact), self.device)
+        self.chunk_rows = None if not chunk_rows or chunk_rows >= call.n_targets else int(chunk_rows)
+        if self.chunk_rows is None:
+            self.bounds = partition_targets(self.work, self.world)
+            self.lo, self.hi = int(self.bounds[self.rank]), int(self.bounds[self.rank + 1])
+            self.n_loc = self.hi - self.lo
+            self.n_max = int(np.max(np.diff(self.bounds)))
+            self.prob = DeviceProblem(slice_call(call, self.lo, self.hi, compact=compact), self.device)
+        else:
+            # streaming: the target list is taken in chunks, every chunk cut `world` ways by work; the operands stay
+            # resident whole (a rank's rows of different chunks do not form one range), only the slabs are chunk-sized
+            self._chunk_bounds = {}
+            n_max = 0
+            for c0 in range(0, call.n_targets, self.chunk_rows):
+                c1 = min(call.n_targets, c0 + self.chunk_rows)
+                b = partition_targets(self.work[c0:c1], self.world) + c0
+                self._chunk_bounds[(c0, c1)] = b
+                n_max = max(n_max, int(np.max(np.diff(b))))
+            self.bounds = None
+            self.lo, self.hi, self.n_loc, self.n_max = 0, 0, 0, n_max
+            self.prob = DeviceProblem(call, self.device)
         z = lambda n, dt: torch.zeros(n, dtype=dt, device=self.device)  # noqa: E731
         self.pad_cols, self.pad_vals, self.pad_cnt = z(self.n_max * k, torch.int32), z(self.n_max * k, torch.float32), z(self.n_max, torch.int32)
         self.recv = None
@@ -238,6 +254,43 @@ class ShardedDeviceProblem:
         dist.gather(self.pad_cols, self.recv[0] if root else None, dst=self.dst, group=self.group)
         dist.gather(self.pad_vals, self.recv[1] if root else None, dst=self.dst, group=self.group)
         dist.gather(self.pad_cnt, self.recv[2] if root else None, dst=self.dst, group=self.group)
+
+    # ---- streaming form: one resident problem, the target list in chunks (10M users x k do not fit host arrays at once) ----
+    def chunks(self):
+        """The chunks [lo, hi) of the target list, in order (one chunk = everything when chunk_rows is not set)."""
+        if self.chunk_rows is None:
+            return [(0, self.call.n_targets)]
+        return sorted(self._chunk_bounds)
+
+    def run_chunk(self, lo: int, hi: int, **kw):
+        """Kernel over this rank's share of target slots [lo, hi), then the gather of that chunk's slabs."""
+        if self.chunk_rows is None:
+            return self.run(**kw)
+        b = self._chunk_bounds[(lo, hi)]
+        a0, a1 = int(b[self.rank]), int(b[self.rank + 1])
+        k = self.call.k
+        info = {"kernel_ms": 0.0, "passes_total": 0}
+        if a1 > a0:
+            info = self.prob.run(self.pad_cols[: (a1 - a0) * k], self.pad_vals[: (a1 - a0) * k], self.pad_cnt[: a1 - a0],
+                                 targets=self.prob.t["targets"][a0:a1], **kw)
+        self.gather()
+        return info
+
+    def chunk_result(self, lo: int, hi: int):
+        """Root: (cols, values, counts) of target slots [lo, hi) as host arrays; None elsewhere."""
+        import torch
+
+        torch.cuda.synchronize(self.device)
+        if self.rank != self.dst:
+            return None
+        if self.chunk_rows is None:
+            _, cols, vals, cnt = self.result()
+            return cols, vals, cnt
+        b = self._chunk_bounds[(lo, hi)] - lo
+        sub = slice_call(self.call, lo, hi)
+        slabs = ([self.pad_cols], [self.pad_vals], [self.pad_cnt]) if self.world == 1 else self.recv
+        _, cols, vals, cnt = _assemble(sub, b, *slabs)
+        return cols, vals, cnt
 
     def result(self):
         """Root: (rows, cols, values, counts) of ALL targets as host arrays; None elsewhere."""

@@ -135,6 +135,8 @@ def _p3_on_device(matrix1, matrix2, binary, filter_cols, target_cols) -> bool:
     from scipy.sparse import issparse
     if matrix2 is not None or binary or not issparse(matrix1) or matrix1.data.dtype != np.float32:
         return False
+    if _host.multi_gpu_route() is not None:      # (the workers of the multi-GPU route get preprocessed matrices)
+        return False
     for sel in (filter_cols, target_cols):
         if isinstance(sel, (list, np.ndarray)) and len(sel) != 0:
             return False

@@ -1,0 +1,23 @@
+"""CPU-tier stand-in for multi_gpu._hip_runner: the same generator protocol (chunks of the target list, every chunk cut
+`world` ways by work, one gather per chunk) over gloo with the oracle kernel as the compute.  Test infrastructure only."""
+from __future__ import annotations
+
+import numpy as np
+
+
+def oracle_runner(call, group, device, chunk_rows):
+    import torch.distributed as dist
+    from oracle import splus_oracle as so
+    from similaripy_amd import distributed as D
+
+    def compute(c):
+        rows, cols, vals = so.run_kernel(c, "port", num_threads=1)
+        counts = so.slot_counts(rows, cols, vals, c.targets, c.k)[0] if c.n_targets else np.zeros(0, np.int32)
+        return rows, cols, vals, counts
+
+    n = call.n_targets
+    chunk = n if not chunk_rows else int(chunk_rows)
+    for lo in range(0, n, chunk):
+        hi = min(n, lo + chunk)
+        out = D.sharded_knn(D.slice_call(call, lo, hi), compute, dst=0, group=group)
+        yield (lo, hi, out[1], out[2], out[3]) if dist.get_rank(group) == 0 else None

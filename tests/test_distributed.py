@@ -8,6 +8,7 @@ import sys
 from pathlib import Path
 
 import numpy as np
+import pytest
 import scipy.sparse as sp
 import torch.multiprocessing as mp
 
@@ -128,8 +129,6 @@ def test_row_work_of_a_device_transposed_call():
     np.testing.assert_array_equal(D.row_work(host), D.row_work(dev))
 
 
-import pytest  # noqa: E402
-
 
 @pytest.mark.gpu
 def test_sharded_device_problem_nccl_world1_equals_single_call():
@@ -164,3 +163,49 @@ def test_sharded_device_problem_nccl_world1_equals_single_call():
         np.testing.assert_array_equal(out[3], n1)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fmt,chunk", [("csr", None), ("csr", 100), ("coo", 64)])
+def test_multi_gpu_entry_spawns_ranks_and_assembles_gloo(fmt, chunk):
+    """similaripy_amd.multi_gpu.run_call — the one-process entry that spawns a worker per device — over gloo with the
+    oracle kernel (tests/mgpu_oracle_runner.py): shm hand-over, chunked streaming, CSR / COO assembly equal the
+    single-process result."""
+    from oracle import splus_oracle as so
+    from similaripy_amd import multi_gpu
+    call = _problem()
+    res = multi_gpu.run_call(call, devices=2, format_output=fmt, chunk_rows=chunk, backend="gloo", runner="tests.mgpu_oracle_runner:oracle_runner")
+    rows, cols, vals = so.run_kernel(call, "port", num_threads=1)
+    counts = so.slot_counts(rows, cols, vals, call.targets, call.k)[0]
+    want = _host.finish(call, rows, cols, vals, counts, fmt)
+    assert type(res) is type(want) and res.shape == want.shape and res.nnz == want.nnz
+    a, b = res.tocsr(), want.tocsr()
+    a.sort_indices()
+    b.sort_indices()
+    np.testing.assert_array_equal(a.indptr, b.indptr)
+    np.testing.assert_array_equal(a.indices, b.indices)
+    np.testing.assert_array_equal(a.data, b.data)
+
+
+@pytest.mark.gpu
+def test_multi_gpu_entry_one_device_nccl():
+    """The spawned route on the real thing: one worker on device 0 under nccl (ShardedDeviceProblem, resident operands,
+    chunked), through the public wrappers — explicit `multi_gpu.similarity(...)` and the SIMILARIPY_AMD_DEVICES route."""
+    import similaripy_amd as sim
+    from oracle import splus_oracle as so
+    rng = np.random.default_rng(13)
+    m = sp.random_array((6000, 900), density=0.01, format="csr", dtype=np.float32, random_state=rng)
+    want = sim.cosine(m, k=15, verbose=False, format_output="csr")
+    for chunk in (None, 2500):
+        got = sim.multi_gpu.similarity("cosine", m, k=15, verbose=False, format_output="csr", devices=[0], chunk_rows=chunk)
+        assert got.shape == want.shape and abs(got.nnz - want.nnz) == 0
+        g, w = got.copy(), want.copy()
+        g.sort_indices()
+        w.sort_indices()
+        np.testing.assert_array_equal(g.indptr, w.indptr)
+        assert (g.indices == w.indices).mean() > 0.999          # (k-th place ties may resolve differently between two runs)
+        np.testing.assert_allclose(g.sum(), w.sum(), rtol=1e-5)
+    # rp3beta: preprocessing on the host side of the route, user scoring with a seen-items filter in chunks
+    r1 = sim.multi_gpu.similarity("rp3beta", m, alpha=0.8, beta=0.4, k=10, verbose=False, format_output="csr", devices=[0])
+    r0 = sim.rp3beta(m, alpha=0.8, beta=0.4, k=10, verbose=False, format_output="csr")
+    np.testing.assert_allclose(r1.sum(), r0.sum(), rtol=2e-5)
+    assert r1.nnz == r0.nnz
