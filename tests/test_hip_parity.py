@@ -317,6 +317,13 @@ def test_sparse_kernel_long_rows_and_large_k():
     _check(call, "k=300")
     call = _host.prepare(m, k=1500, target_rows=np.arange(0, 40000, 97))      # candidate buffer in global memory
     _check(call, "k=1500")
+    # candidate buffer of the SPARSE kernel in global memory (k + 512 > 4 * 1024 entries), at scale: denser rows, all targets
+    big = _rand((40000, 3000), 0.012, 26)
+    for kw in (dict(l2=1), dict(l1=0.5, l2=0.5, stabilized_shrink=3.0)):
+        call = _host.prepare(big, k=3800, target_rows=np.arange(0, 40000, 41), **kw)
+        ph = _info(call)
+        assert ph[9] > 0, "the global-memory candidate buffer variant of the sparse kernel did not run"
+        _check(call, f"sparse kernel, k=3800 {kw}")
 
 
 def test_sparse_kernel_signed_values_and_thresholds():

@@ -190,3 +190,17 @@ def test_csr_and_coo_assembly():
     coo = _host.build_coo(rows, cols, vals, 6, 10)
     assert isinstance(coo, sp.coo_array) and coo.nnz == 9     # padding kept
     np.testing.assert_array_equal(coo.toarray(), dense)
+
+
+def test_csr_assembly_with_64_bit_indices():
+    """build_csr_matrix picks 64-bit indices when n_targets * k or the column count exceed int32 (utils.pyx:141-173,
+    coo_to_csr<long>): exercised with a column count beyond 2^31 on a tiny result."""
+    targets = np.array([0, 2], dtype=np.int32)
+    cols = np.array([5, 1, 0, 7, 0, 0], np.int32)
+    vals = np.array([1.0, 2.0, 0.0, 3.0, 0.0, 0.0], np.float32)
+    counts = np.array([2, 1], np.int32)
+    n_cols = 2 ** 31 + 5
+    csr = _host.build_csr(targets, cols, vals, counts, 3, 3, n_cols)
+    assert csr.indices.dtype == np.int64 and csr.indptr.dtype == np.int64 and csr.shape == (3, n_cols)
+    assert csr.nnz == 3 and csr.indptr.tolist() == [0, 2, 2, 3]
+    assert sorted(zip(csr.indices[:2].tolist(), csr.data[:2].tolist())) == [(1, 2.0), (5, 1.0)] and csr.indices[2] == 7
