@@ -96,7 +96,6 @@ def main():
     ap.add_argument("--static-sched", action="store_true")
     ap.add_argument("--no-sparse-path", action="store_true", help="force the generic windowed path (A/B)")
     ap.add_argument("--no-fold", action="store_true", help="do not fold the column term into the m2 stream (A/B)")
-    ap.add_argument("--no-defer", action="store_true", help="finish rows inside the row kernel (A/B)")
     ap.add_argument("--dbg", type=int, default=0, help="kernel ablation bits (profiling only; results invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
@@ -154,7 +153,7 @@ def main():
 
     shard = ShardedDeviceProblem(call, device=dev)           # partition_targets + DeviceProblem of this rank's slice
     tuning = dict(table_slots=args.table_slots, threads_per_wg=args.threads, num_wgs=args.num_wgs, load_pct=args.load_pct, dbg=args.dbg,
-                  no_sparse_path=args.no_sparse_path, no_fold=args.no_fold, no_defer=args.no_defer)
+                  no_sparse_path=args.no_sparse_path, no_fold=args.no_fold)
     ev_pairs = []
 
     def step(timed: bool):

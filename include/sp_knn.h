@@ -53,7 +53,6 @@ extern "C" {
 #define SP_FLAG_STATIC_SCHED  4u  /* round-robin rows over workgroups instead of the atomic row queue */
 #define SP_FLAG_NO_SPARSE_PATH 8u /* never use the bitmap + collision-set path for sparse rows (A/B testing) */
 #define SP_FLAG_NO_FOLD       16u /* never divide the column term into the m2 stream (A/B testing) */
-#define SP_FLAG_NO_DEFER      4096u /* finish every sparse-kernel row inside the row kernel instead of the wave-per-row finishing kernel (A/B testing) */
 #define SP_FLAG_NO_ROW_ORDER  32u /* queue rows in target order instead of descending work (A/B testing) */
 #define SP_FLAG_M2_IS_M1_T    128u /* m2 = m1^T (the `matrix2=None` call, s_plus.pyx:169-170): built on the device from m1 by the callee;
                                      the m2_* pointers and nnz_m2 are ignored (may be NULL / 0), n_rows_m2 = columns of m1,

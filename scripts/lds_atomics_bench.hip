@@ -7,10 +7,11 @@
 
 constexpr int T = 16384;
 
-enum Kind { ADD_F32_1LANE = -3, CAS64_1LANE = -2, ADD_F32_4LANE = -1, ADD_F32 = 0, CAS_RTN_B32, CAS_RTN_B64, ADD_RTN_U32, WRITE_B32, READ_B32, READ_B64, ADD_F32_SEQ, CAS_THEN_ADD, KINDS };
+enum Kind { ADD_F32_1LANE = -3, CAS64_1LANE = -2, ADD_F32_4LANE = -1, ADD_F32 = 0, CAS_RTN_B32, CAS_RTN_B64, ADD_RTN_U32, WRITE_B32, READ_B32, READ_B64, ADD_F32_SEQ, CAS_THEN_ADD, ADD_U64, CAS32_THEN_ADD_U64, KINDS };
 static const char *names[KINDS] = {"ds_add_f32 (random)", "ds_cmpst_rtn_b32 (random)", "ds_cmpst_rtn_b64 (random)",
                                    "ds_add_rtn_u32 (random)", "ds_write_b32 (random)", "ds_read_b32 (random)",
-                                   "ds_read_b64 (random)", "ds_add_f32 (lane-linear)", "cas_b32 + add_f32 (dependent)"};
+                                   "ds_read_b64 (random)", "ds_add_f32 (lane-linear)", "cas_b32 + add_f32 (dependent)", "ds_add_u64 (random, no return)",
+                                   "cas_b32 + add_u64 (dependent)"};
 
 template <int KIND>
 __global__ void k(int iters, unsigned long long *out, unsigned long long *cyc) {
@@ -39,6 +40,11 @@ __global__ void k(int iters, unsigned long long *out, unsigned long long *cyc) {
             else if (KIND == READ_B32) acc += (unsigned)((volatile int *)iv)[slot];
             else if (KIND == READ_B64) acc += ((volatile unsigned long long *)tab)[slot];
             else if (KIND == ADD_F32_SEQ) atomicAdd(&fv[(threadIdx.x + it * 64 + j * 1024) & (T - 1)], 1.0f);
+            else if (KIND == ADD_U64) atomicAdd(&tab[slot], (unsigned long long)s);
+            else if (KIND == CAS32_THEN_ADD_U64) {
+                int prev = atomicCAS(&iv[2 * (slot >> 1)], -1, (int)slot);
+                if (prev == -1 || prev == (int)slot) atomicAdd(&tab[(T / 2) + (slot >> 1)], (unsigned long long)s);
+            }
             else if (KIND == CAS_THEN_ADD) {
                 int prev = atomicCAS(&iv[slot], -1, (int)slot);
                 if (prev == -1 || prev == (int)slot) atomicAdd(&fv[T + slot], 1.0f);
@@ -80,7 +86,7 @@ int main() {
     for (int threads : {256, 512, 1024}) {
         run<ADD_F32_1LANE>(threads); run<ADD_F32_4LANE>(threads); run<CAS64_1LANE>(threads);
         run<ADD_F32>(threads); run<CAS_RTN_B32>(threads); run<CAS_RTN_B64>(threads); run<ADD_RTN_U32>(threads);
-        run<WRITE_B32>(threads); run<READ_B32>(threads); run<READ_B64>(threads); run<ADD_F32_SEQ>(threads); run<CAS_THEN_ADD>(threads);
+        run<WRITE_B32>(threads); run<READ_B32>(threads); run<READ_B64>(threads); run<ADD_F32_SEQ>(threads); run<CAS_THEN_ADD>(threads); run<ADD_U64>(threads); run<CAS32_THEN_ADD_U64>(threads);
         printf("\n");
     }
     return 0;

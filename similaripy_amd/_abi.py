@@ -26,7 +26,6 @@ SP_FLAG_CHECK_ZEROS = 256
 SP_FLAG_CSR_OUT = 512
 SP_FLAG_P3_PREP = 1024
 SP_FLAG_DEPOP_ROWSUM = 2048
-SP_FLAG_NO_DEFER = 4096
 SP_EZEROS = -6
 SP_NORM_L1, SP_NORM_L2, SP_NORM_MAX, SP_NORM_TFIDF, SP_NORM_BM25PLUS = range(5)
 SP_TF_MODES = {'binary': 0, 'raw': 1, 'sqrt': 2, 'freq': 3, 'log': 4}       # normalization.pyx:12-17

@@ -35,8 +35,6 @@ enum { SH_CNT = 0, SH_OVF, SH_SEL, SH_NEED, SH_EQ, SH_CNT2, SH_RETRY, SH_QA, SH_
 enum { PH_SETUP = 0, PH_SEGMENTS, PH_ACCUM, PH_DRAIN, PH_SELECT, PH_OUTPUT, PH_SWEEP1, PH_SWEEP2, PH_CSDRAIN,
        CT_ROWS_SPARSE, CT_ROWS_FALLBACK, CT_PASSES, PH_N };
 
-struct FinRec;
-
 struct KParams {
     int n_targets;
     const int *targets;
@@ -70,26 +68,10 @@ struct KParams {
     int sparse_path;       // 1 = rows with few expected collisions take the bitmap path
     int fold;              // 1 = the single active column term (Ycos or Ydep) is already divided into m2_data: treat it as 1
     unsigned long long *phase_cycles;  // optional [PH_N]
-    // deferred finishing of sparse-kernel rows (MONO variant, sp_finish_kernel.hpp)
-    int defer;             // 1 = at its last stage a row's member pool and candidate buffer go to `dlog`, the dense phases are left to sp_knn_finish_kernel
-    int q_begin, q_end;    // the launch takes the queue positions [q_begin, min(q_end, qcount[0])) (a batch); the queue head starts at q_begin
-    int dslice, dmem_cap;  // log entries per row (members first, dmem_cap of them, then the candidates)
-    unsigned long long *dlog;
-    FinRec *drec;          // [q_end - q_begin]
     int dbg;               // ablation bits for profiling only (results are WRONG when non-zero; 8 / 16: sweep 1 / sweep 2 of the sparse kernel
                            // load but do not process — compiled in only with -DSP_ABLATION=1: the test costs the sweeps 1 %):
                            // 1 = generic accumulate: no LDS inserts, 4 = no Y gathers
 };
-
-// Deferred finishing (sp_finish_kernel.hpp): one record per queue position of the batch, written by the sparse row kernel for
-// every row it took
-struct FinRec {
-    int4 d0, d1;           // the row's descriptor (slot, m1 row, m1 start, m1 length | MACs, den, -, -): to hand it on to the generic queue
-    int n_mem, n_cand;     // entries of the two log slices in use (holes = zero entries included)
-    unsigned cut_bits;     // the row's final raw-dot cutoff
-    int state;             // 0 = not a deferred row (failed / not reached), 1 = to be finished, 2 = finished
-};
-static_assert(sizeof(FinRec) == 48, "FinRec layout");
 
 // order-preserving float <-> uint map (so radix-select works for negative thresholds too)
 __device__ __forceinline__ unsigned fkey(float f) {

@@ -34,7 +34,6 @@
 #include "sp_prep_kernels.hpp"
 #include "sp_rowops.hpp"
 #include "sp_sparse_kernel.hpp"
-#include "sp_finish_kernel.hpp"
 #include "sp_generic_kernel.hpp"
 
 // ---------------------------------------------------------------------------------------------
@@ -98,10 +97,6 @@ struct Config {
     size_t ws_rows_bytes;   // bucket counters + work[n] + order[n] + the two descriptor queues
     size_t ws_desc_offset;  // of the sparse queue inside that block (the generic queue follows it)
     int nb_log2;            // sparse kernel: bitmap bits (log2)
-    bool defer;             // sparse kernel: the dense end of a row is left to sp_knn_finish_kernel (batches of defer_rows queue positions)
-    int defer_rows;         // queue positions per batch
-    int dslice, dmem_cap;   // log entries per row / of them for members
-    size_t ws_defer_bytes;  // records + counters + log of one batch
     size_t ws_total;
     bool fold;
     bool mono;              // the sparse kernel's monotone variant applies (val = xy / den or the raw dot, no per-row target selector)
@@ -191,21 +186,7 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
     int nb = 10;
     while (nb < c->logT_s + 6 && (1LL << nb) < (long long)a->n_output_cols) ++nb;
     c->nb_log2 = nb;
-    // Deferred finishing (sp_finish_kernel.hpp): the monotone sparse kernel in its 1024-thread shape spends 30 % of a row in
-    // dense phases that leave most of the CU idle; one wave per row does them afterwards.  Worth it from a few thousand rows.
-    c->defer = c->mono && u_lds_s && NT_s == 1024 && T_s == 16384 && !a->threads_per_wg && !a->table_slots && !(a->flags & SP_FLAG_NO_DEFER) &&
-               a->n_targets >= 4096 && a->k <= 2048;
-    c->dmem_cap = T_s / 4;                       // = the member pool's capacity
-    c->dslice = c->dmem_cap + (int)cap_s;
-    c->defer_rows = 0;
-    c->ws_defer_bytes = 0;
-    if (c->defer) {
-        const size_t per_row = (size_t)c->dslice * 8 + sizeof(FinRec);
-        const size_t budget = (size_t)4 << 30;                                     // 4 GiB of log per batch
-        c->defer_rows = (int)std::max<size_t>(8192, std::min<size_t>((size_t)a->n_targets, budget / per_row));
-        c->ws_defer_bytes = (((size_t)c->defer_rows * per_row + 256) + 255) & ~(size_t)255;
-    }
-    c->ws_total = WS_QUEUE_BYTES + c->ws_gu_bytes + c->ws_fold_bytes + c->ws_rows_bytes + c->ws_defer_bytes;
+    c->ws_total = WS_QUEUE_BYTES + c->ws_gu_bytes + c->ws_fold_bytes + c->ws_rows_bytes;
     return SP_OK;
 }
 
@@ -277,44 +258,17 @@ int launch_generic(const KParams &kp, const Config &c, hipStream_t stream) {
     return SP_OK;
 }
 
-// kp_s: the sparse kernel's parameters (its own tile), kp: the generic kernel's; ws_defer: scratch of the deferred finishing
-int launch_rows(const KParams &kp_s, const KParams &kp, const Config &c, int n_targets, int n_cus, unsigned char *ws_defer, hipStream_t stream,
-                hipEvent_t *ev /* [4] or NULL: around the two row kernels */) {
+// kp_s: the sparse kernel's parameters (its own tile), kp: the generic kernel's
+int launch_rows(const KParams &kp_s, const KParams &kp, const Config &c, hipStream_t stream, hipEvent_t *ev /* [4] or NULL: around the two row kernels */) {
     // sparse rows first; what it cannot finish joins the generic queue, which the second launch drains
     if (ev) HIP_TRY(hipEventRecord(ev[0], stream));
     if (kp.sparse_path) {
-        auto launch = [&](const KParams &k) -> int {
-            if (c.NT_s == 256) return launch_sparse<256>(k, c, stream);
-            if (c.NT_s == 512) return launch_sparse<512>(k, c, stream);
-            if (c.NT_s == 768) return launch_sparse<768>(k, c, stream);
-            return launch_sparse<1024>(k, c, stream);
-        };
-        if (!c.defer) {
-            TRY(launch(kp_s));
-        } else {
-            // batches of queue positions: row kernel (sweeps; the rows' pools go to the log) -> finishing kernel (one wave per row)
-            FinRec *recs = (FinRec *)ws_defer;
-            unsigned *counters = (unsigned *)(ws_defer + (size_t)c.defer_rows * sizeof(FinRec));      // [0], [1]: the two finishing launches
-            u64 *dlog = (u64 *)(ws_defer + (((size_t)c.defer_rows * sizeof(FinRec) + 256 + 255) & ~(size_t)255));
-            const size_t lds_a = (size_t)4 * 4096 * 8 + 4 * 1024, lds_b = (size_t)2 * 8192 * 8 + 2 * 1024;
-            auto fa = sp_knn_finish_kernel<4096, 4>;
-            auto fb = sp_knn_finish_kernel<8192, 2>;
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fa), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
-            for (int q0 = 0; q0 < n_targets; q0 += c.defer_rows) {
-                const int q1 = std::min(n_targets, q0 + c.defer_rows);
-                KParams k = kp_s;
-                k.defer = 1; k.q_begin = q0; k.q_end = q1;
-                k.dslice = c.dslice; k.dmem_cap = c.dmem_cap; k.dlog = dlog; k.drec = recs;
-                HIP_TRY(hipMemsetAsync(recs, 0, (size_t)(q1 - q0) * sizeof(FinRec) + 256, stream));      // (records and both counters)
-                HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)k.queue, q0, 1, stream));                            // the queue head starts at the batch
-                TRY(launch(k));
-                const int fin_wgs = std::max(1, std::min(n_cus, (q1 - q0 + 3) / 4));
-                hipLaunchKernelGGL(fa, dim3(fin_wgs), dim3(256), lds_a, stream, k, recs, (const u64 *)dlog, q0, q1, counters);
-                hipLaunchKernelGGL(fb, dim3(fin_wgs), dim3(128), lds_b, stream, k, recs, (const u64 *)dlog, q0, q1, counters + 1);
-                HIP_TRY(hipGetLastError());
-            }
-        }
+        int rc;
+        if (c.NT_s == 256) rc = launch_sparse<256>(kp_s, c, stream);
+        else if (c.NT_s == 512) rc = launch_sparse<512>(kp_s, c, stream);
+        else if (c.NT_s == 768) rc = launch_sparse<768>(kp_s, c, stream);
+        else rc = launch_sparse<1024>(kp_s, c, stream);
+        if (rc) return rc;
     }
     if (ev) { HIP_TRY(hipEventRecord(ev[1], stream)); HIP_TRY(hipEventRecord(ev[2], stream)); }
     int rc;
@@ -361,7 +315,6 @@ int run_device_impl(sp_knn_args *a) {
     unsigned char *ws_gu = ws + WS_QUEUE_BYTES;
     unsigned char *ws_fold = ws_gu + c.ws_gu_bytes;
     unsigned char *ws_rows = ws_fold + c.ws_fold_bytes;
-    unsigned char *ws_defer = ws_rows + c.ws_rows_bytes;
 
     // minima of the column-term vectors feed the gather-free upper bound (Epi::upper); it is sound only
     // when every weight / shrink is non-negative (NaN parameters fail the comparisons and disable it)
@@ -464,7 +417,7 @@ int run_device_impl(sp_knn_args *a) {
     if (timed) { for (int i = 0; i < 4; ++i) TRY(guard.event(&kev[i])); }
     KParams kp_s = kp;
     kp_s.T = c.T_s; kp_s.logT = c.logT_s;
-    rc = launch_rows(kp_s, kp, c, a->n_targets, n_cus, ws_defer, stream, timed ? kev : nullptr);
+    rc = launch_rows(kp_s, kp, c, stream, timed ? kev : nullptr);
     if (rc) return rc;
 
     if (timed) {

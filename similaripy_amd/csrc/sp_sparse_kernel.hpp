@@ -94,7 +94,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
     // is four dependent global loads (~1 us each under load).  It is software-pipelined across rows: while row r is
     // processed, the queue slot of row r+3 is claimed, the descriptor of row r+2 is loaded, the m1 entries of
     // row r+1 are loaded (top of the row) and its m2 row bounds fetched (middle of the row).
-    const int n_rows = (p.q_end > 0) ? min(p.q_end, (int)p.qcount[0]) : (int)p.qcount[0];      // (a batch of the queue, or all of it)
+    const int n_rows = (int)p.qcount[0];
     const int4 *desc = p.desc;
     auto load_desc = [&](int q, int4 &d0, int4 &d1) {
         d0 = make_int4(-1, 0, 0, 0);
@@ -103,14 +103,11 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
     };
     int q_nn = 0;      // queue index two rows ahead (static schedule: computed; dynamic: through LDS)
     int pend_q = 0;    // (tid 0) claimed queue index three rows ahead
-    int qC = 0, qN = 0;    // queue positions of the current and the next row (deferred finishing: the row's record / log slice)
     int4 dC, dN, wC, wN;   // descriptors (both halves) of the current and the next row
     if (p.static_sched) {
-        qC = p.q_begin + (int)blockIdx.x;
-        qN = qC + (int)gridDim.x;
-        load_desc(qC, dC, wC);
-        load_desc(qN, dN, wN);
-        q_nn = qN + (int)gridDim.x;
+        load_desc((int)blockIdx.x, dC, wC);
+        load_desc((int)(blockIdx.x + gridDim.x), dN, wN);
+        q_nn = (int)(blockIdx.x + 2 * gridDim.x);
     } else {
         if (tid == 0) {
             sh[SH_QA] = (int)atomicAdd(&p.queue[0], 1u);
@@ -118,10 +115,8 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             pend_q = (int)atomicAdd(&p.queue[0], 1u);
         }
         __syncthreads();
-        qC = sh[SH_QA];
-        qN = sh[SH_QB];
-        load_desc(qC, dC, wC);
-        load_desc(qN, dN, wN);
+        load_desc(sh[SH_QA], dC, wC);
+        load_desc(sh[SH_QB], dN, wN);
         __syncthreads();
     }
     // m1 entry / m2 row bounds of segment `tid` of the current row (rows of this kernel have <= SORT_MAX <= NT entries)
@@ -162,7 +157,6 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         int my_ib = 0, my_fs = 0;       // first item / flat start of segment `tid`
         int n_items = 0;
         int4 dNN, wNN;
-        int qNN = 0;
         if (n1 <= 64) {
             // One wave, one segment per lane, no barrier inside: the (up to) 8 largest |values| are found with 8 wave-max
             // rounds; heavy segments first, the others behind, both in their original order (ballot + mbcnt); item and
@@ -201,7 +195,6 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             __syncthreads();
             if (!p.static_sched) q_nn = sh[SH_QA];
             load_desc(q_nn, dNN, wNN);
-            qNN = q_nn;
             if (p.static_sched) q_nn += (int)gridDim.x;
             n_items = sh[SH_NITEMS];
             __syncthreads();                    // scratch read before the items overwrite it
@@ -214,7 +207,6 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             __syncthreads();
             if (!p.static_sched) q_nn = sh[SH_QA];
             load_desc(q_nn, dNN, wNN);
-            qNN = q_nn;
             if (p.static_sched) q_nn += (int)gridDim.x;
             {
                 const int lg = (n1 <= 128) ? 7 : 8;       // segments padded to a power of two
@@ -239,7 +231,6 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             __syncthreads();                    // scratch read before the items overwrite it
         }
         bool failed = (n_items >= ICAP) || (n_items > 63 * NW);      // (a wave keeps its <= 63 item descriptors in one register)
-        bool deferred = false;       // the row's dense phases are left to sp_knn_finish_kernel
         PHASE_END(PH_SETUP);
 
         RowCtx rc;
@@ -683,33 +674,6 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 const int mext = min(sh[SH_MCTR], mpcap);
                 if (sh[SH_OVF]) { failed = true; break; }     // a pool overflowed
                 PHASE_END(PH_SWEEP2);
-                if constexpr (MONO && U_LDS) {
-                    if (p.defer && last_stage) {
-                        // ---- deferred finishing: the row's member pool and candidate buffer go to the log (coalesced 8-byte stores; holes —
-                        // abandoned tails of the waves' reservation blocks — travel as zeros), the pools and the collision bitmap
-                        // go back to zero, and sp_knn_finish_kernel does the rest: accumulate, scan, select, write-out ----
-                        const int n_u = min(sh[SH_CNT], cap);
-                        const int ri = qC - p.q_begin;
-                        u64 *lm = p.dlog + (size_t)ri * (size_t)p.dslice;
-                        u64 *lc = lm + p.dmem_cap;
-                        for (int i = tid; i < mext; i += NT) { lm[i] = mpool[i]; mpool[i] = 0ull; }
-                        for (int i = tid; i < n_u; i += NT) { lc[i] = U[i]; U[i] = 0ull; }
-                        for (int i = tid; i < CBM_BYTES / 16; i += NT) ((int4 *)cbm)[i] = make_int4(0, 0, 0, 0);
-                        if (tid == 0) {
-                            FinRec r;
-                            r.d0 = dC; r.d1 = wC;
-                            r.n_mem = mext; r.n_cand = n_u;
-                            r.cut_bits = __float_as_uint(cutx);
-                            r.state = 1;
-                            p.drec[ri] = r;
-                            sh[SH_PCTR] = 0; sh[SH_MCTR] = 0; sh[SH_CNT] = 0;
-                        }
-                        __syncthreads();
-                        deferred = true;
-                        PHASE_END(PH_ACCUM);
-                        break;
-                    }
-                }
                 if (last_stage) {
                     // ---- products of marked columns: find-or-insert in the collision set.  {column+1 : sum} slots,
                     // 0 = free; see below. ----
@@ -903,7 +867,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             }
         }
 
-        if (!failed && !deferred) {
+        if (!failed) {
             // ================= write-out =================
             __syncthreads();
             const int n_sel = min(sh[SH_CNT], p.k);
@@ -974,7 +938,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 for (int i = tid; i < (dirty + 1) / 2; i += NT) ((int4 *)U)[i] = make_int4(0, 0, 0, 0);
             }
             if (timing) ph[CT_ROWS_SPARSE] += 1;
-        } else if (failed) {
+        } else {
             // a pool or the collision set overflowed (or the row has too many items): hand the row to the generic
             // kernel's queue and put the LDS state back to clean
             __syncthreads();
@@ -996,7 +960,6 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         wN = make_int4(__builtin_amdgcn_readfirstlane(wNN.x), __builtin_amdgcn_readfirstlane(wNN.y),
                        __builtin_amdgcn_readfirstlane(wNN.z), __builtin_amdgcn_readfirstlane(wNN.w));
         my_r0 = nx_r0; my_len = nx_len; my_v = nx_v;
-        qC = qN; qN = __builtin_amdgcn_readfirstlane(qNN);
         __syncthreads();
         PHASE_END(PH_OUTPUT);
     }

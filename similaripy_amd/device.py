@@ -103,8 +103,6 @@ class DeviceProblem:
             flags |= _abi.SP_FLAG_NO_SPARSE_PATH
         if tuning.get("no_fold"):
             flags |= _abi.SP_FLAG_NO_FOLD
-        if tuning.get("no_defer"):
-            flags |= _abi.SP_FLAG_NO_DEFER
         if tuning.get("no_row_order"):
             flags |= _abi.SP_FLAG_NO_ROW_ORDER
         with torch.cuda.device(self.device):

@@ -753,76 +753,3 @@ def test_device_norms_of_an_explicit_matrix2():
             o = np.argsort(c)
             got.append((c[o].astype(np.int32), v[o].astype(np.float32)))
         so.compare_topk(got, want, 12, rtol=RTOL, atol=ATOL, what=fn.__name__)
-
-
-# ---------------------------------------------------------------------------------------------
-# deferred finishing: the monotone sparse kernel leaves accumulate / scan / select / write-out to sp_knn_finish_kernel
-# ---------------------------------------------------------------------------------------------
-@pytest.fixture(scope="module")
-def defer_matrix():
-    """200k x 4000, 16 per row: 200k output columns, ~12.8k products per row — the 1024-thread shape of the sparse kernel,
-    enough target rows for the deferred path (>= 4096)."""
-    from similaripy_amd.workloads import fixed_degree_csr
-    return fixed_degree_csr(200_000, 4_000, 16, 91)
-
-
-@pytest.mark.parametrize("name,kw", [("cosine", dict(l2=1)), ("dot", dict()), ("asym_threshold", dict(l2=1, c1=0.3, c2=0.7, threshold=0.05)),
-                                     ("dot_k300", dict(k=300)), ("cosine_k2", dict(l2=1, k=2))], ids=lambda x: x if isinstance(x, str) else None)
-def test_deferred_finishing_matches_oracle_and_in_kernel_finish(defer_matrix, name, kw):
-    m = defer_matrix
-    kw = dict(kw)
-    k = kw.pop("k", 50)
-    call = _host.prepare(m, k=k, **kw)
-    rows, cols, vals, counts, info = _host.run_hip(call, time_kernel=True)
-    ph = info["phase_cycles"]
-    assert ph[9] + ph[10] == call.n_targets and ph[9] > 0.99 * call.n_targets, (ph[9], ph[10])
-    r0, c0, v0, n0 = _host.run_hip(call, no_defer=True)
-    np.testing.assert_array_equal(counts, n0)
-    n = call.n_targets
-    # the same kept VALUES in every slot (ties at the k-th place may pick other columns), to an ulp (two runs)
-    np.testing.assert_allclose(np.sort(vals.reshape(n, k), axis=1), np.sort(v0.reshape(n, k), axis=1), rtol=1e-6, atol=0)
-    assert (np.sort(cols.reshape(n, k), axis=1) == np.sort(c0.reshape(n, k), axis=1)).mean() > 0.9999
-    pad = np.arange(k)[None, :] >= counts[:, None]
-    assert not rows.reshape(n, k)[pad].any() and not cols.reshape(n, k)[pad].any() and not vals.reshape(n, k)[pad].any()
-    assert np.all(rows.reshape(n, k)[~pad] == np.broadcast_to(call.targets[:, None], (n, k))[~pad])
-    sample = np.sort(np.random.default_rng(2).choice(n, 400, replace=False)).astype(np.int32)
-    import copy
-    sub = copy.copy(call)
-    sub.targets = sample
-    want = so.canonical(*so.run_kernel(sub, "port"), sample, k)
-    got = []
-    for t in sample:
-        c, v = cols[t * k: t * k + counts[t]], vals[t * k: t * k + counts[t]]
-        o = np.argsort(c, kind="stable")
-        got.append((c[o], v[o]))
-    so.compare_topk(got, want, k, rtol=RTOL, atol=ATOL, what=f"deferred {name}")
-
-
-def test_deferred_finishing_with_matrix_filter_signed_data_and_target_subset(defer_matrix):
-    """The user-scoring idiom (MATRIX filter: excluded columns are dropped at the finishing scan), signed values (sums that
-    cancel, negative cutoffs), a target subset in arbitrary order, and batches (rows >> one batch is not reachable in a
-    test, but the queue-position bookkeeping is the same)."""
-    m = defer_matrix.copy()
-    m.data = (m.data - 0.35).astype(np.float32)
-    m.data[m.data == 0] = np.float32(0.1)
-    n = m.shape[0]
-    rng = np.random.default_rng(8)
-    targets = rng.permutation(n)[:50_000].astype(np.int32)
-    filt = sp.random_array((n, n), density=2e-5, format="csr", dtype=np.float32, random_state=rng)
-    call = _host.prepare(m, k=40, target_rows=targets, filter_cols=filt, threshold=-1e30)
-    rows, cols, vals, counts, info = _host.run_hip(call, time_kernel=True)
-    assert info["phase_cycles"][9] > 0.99 * call.n_targets
-    sel = np.arange(0, call.n_targets, 125)
-    import copy
-    sub = copy.copy(call)
-    sub.targets = np.ascontiguousarray(call.targets[sel])
-    want = so.canonical(*so.run_kernel(sub, "port"), sub.targets, 40)
-    got = []
-    for i in sel:
-        c, v = cols[i * 40: i * 40 + counts[i]], vals[i * 40: i * 40 + counts[i]]
-        o = np.argsort(c, kind="stable")
-        got.append((c[o], v[o]))
-    so.compare_topk(got, want, 40, rtol=2e-4, atol=1e-6, what="deferred, MATRIX filter, signed")      # cancelling sums (see _f64_value_bounds)
-    for i in sel[:100]:
-        t = call.targets[i]
-        assert not np.intersect1d(cols[i * 40: i * 40 + counts[i]], filt.indices[filt.indptr[t]:filt.indptr[t + 1]]).size
