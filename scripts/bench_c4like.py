@@ -9,22 +9,10 @@ from similaripy_amd.device import DeviceProblem
 from similaripy_amd.normalization import normalize
 from oracle import splus_oracle as so
 
-def make_urm(n_users, n_items, nnz, seed=0):
-    rng = np.random.default_rng(seed)
-    act = rng.lognormal(mean=0.0, sigma=1.0, size=n_users); act = act / act.sum()
-    pop = 1.0 / np.arange(1, n_items + 1) ** 0.9; pop = pop / pop.sum()
-    u = rng.choice(n_users, size=nnz, p=act).astype(np.int32)
-    i = rng.choice(n_items, size=nnz, p=pop).astype(np.int32)
-    r = (rng.integers(1, 11, size=nnz) * 0.5).astype(np.float32)
-    m = sp.csr_array((r, (u, i)), shape=(n_users, n_items)); m.sum_duplicates()
-    return m
+from similaripy_amd.workloads import movielens_like_urm, ML32M_USERS, ML32M_ITEMS, ML32M_NNZ
 
-scale = float(sys.argv[1]) if len(sys.argv) > 1 else 0.25
-n_users, n_items, nnz = int(200948 * scale), int(84432 * scale), int(32_000_204 * scale)
-urm = make_urm(n_users, n_items, nnz)
-if len(sys.argv) > 2 and sys.argv[2] == 'shuffle':      # real catalogues are not sorted by popularity
-    perm = np.random.default_rng(5).permutation(n_items)
-    urm = urm[:, perm].tocsr()
+scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+urm = movielens_like_urm(int(ML32M_USERS * scale), int(ML32M_ITEMS * scale), int(ML32M_NNZ * scale), shuffle_items=not (len(sys.argv) > 2 and sys.argv[2] == 'sorted'))
 NO_ORDER = len(sys.argv) > 3 and sys.argv[3] == 'noorder'
 # optional tuning sweep (kernel time only): "threads_per_wg=512,table_slots=4096;threads_per_wg=256,table_slots=4096"
 sweeps = [dict((kv.split('=')[0], int(kv.split('=')[1])) for kv in grp.split(',')) for grp in sys.argv[4].split(';')] if len(sys.argv) > 4 else []
