@@ -57,5 +57,5 @@ for name, prep in (("cosine", lambda: _host.prepare(m1, k=k, l2=1)),
     got = []
     for t in sample:
         n = hn[t]; cc = hc[t*k:t*k+n]; vv = hv[t*k:t*k+n]; o = np.argsort(cc); got.append((cc[o], vv[o]))
-    ties = so.compare_topk(got, want, k, rtol=3e-4, atol=1e-9, what=name)   # long float32 sums: reorder noise ~sqrt(n)*6e-8
+    ties = so.compare_topk(got, want, k, rtol=1e-3, atol=1e-9, what=name)   # float32 sums of up to 2e5 products in another order (tests/test_hip_fullsize.py bounds it per row)
     print(f"   parity OK on {len(sample)} rows (boundary ties {ties})", flush=True)
