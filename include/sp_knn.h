@@ -46,6 +46,7 @@ extern "C" {
 #define SP_ENOMEM       -4
 #define SP_EWORKSPACE   -5   /* caller workspace too small */
 #define SP_EZEROS       -6   /* SP_FLAG_CHECK_ZEROS: the matrices hold explicit zeros (see explicit_zeros); nothing was computed */
+#define SP_EUNSORTED    -7   /* SP_FLAG_M1_IS_M2_T (host mode): a row of m2 does not have ascending column ids; nothing was computed */
 
 /* flags */
 #define SP_FLAG_TIME_KERNEL   1u  /* bracket device work with hipEvents on `stream`, sync, fill kernel_ms */
@@ -66,12 +67,22 @@ extern "C" {
                                      eliminate_zeros s_plus.pyx:424): `targets` must be strictly increasing; csr_indptr receives the
                                      n_rows_m1 + 1 row pointers, the first csr_nnz entries of `cols` / `values` the column ids and values of
                                      the non-zero entries in row order (slot order inside a row); rows / out_counts are not written */
-#define SP_FLAG_P3_PREP      1024u /* with SP_FLAG_M2_IS_M1_T: the preprocessing of p3alpha / rp3beta (similarity.py:410-415, 477-483;
+#define SP_FLAG_P3_PREP      1024u /* with SP_FLAG_M2_IS_M1_T or SP_FLAG_M1_IS_M2_T: the preprocessing of p3alpha / rp3beta (similarity.py:410-415, 477-483;
                                      normalization.pyx:131-161) on the device: the rows of m1 and the rows of m2 = m1^T are divided by
-                                     their L1 norms, then every entry is raised to p3_alpha.  The caller's m1 is not modified. */
+                                     their L1 norms, then every entry is raised to p3_alpha.  The caller's matrix is not modified. */
 #define SP_FLAG_DEPOP_ROWSUM 2048u /* with SP_FLAG_P3_PREP and l3 != 0: Ydepop[c] = (sum of the RAW row c of m1)^depop_p2, i.e. the column
                                      popularity of the raw m2 = m1^T (similarity.py:479; np.power in float32, s_plus_utils.pyx:257-276),
                                      built on the device; the Ydepop pointer is ignored */
+/* ABI 3 */
+#define SP_FLAG_M1_IS_M2_T   4096u /* m1 = m2^T, built on the device from m2: the call whose matrix1 arrives as CSC (`sim.cosine(URM.T)`, the
+                                     documented item-item usage; the reference converts it with matrix1.tocsr() on the host,
+                                     s_plus.pyx:205-206, while matrix2 = matrix1.T already is the CSR the caller holds).  The m1_*
+                                     pointers and nnz_m1 are ignored, n_rows_m1 must equal n_output_cols, the rows of m2 must have
+                                     ascending column ids (host mode checks: SP_EUNSORTED).  Excludes SP_FLAG_M2_IS_M1_T. */
+#define SP_FLAG_NORMS_ON_DEVICE 8192u /* with SP_FLAG_M2_IS_M1_T or SP_FLAG_M1_IS_M2_T: the Xtversky / Ytversky (l1 != 0) and Xcosine /
+                                     Ycosine (l2 != 0) pointers are ignored; the vectors are built on the device from the rows of m1
+                                     (_build_squared_norms s_plus_utils.pyx:169-201 as sp_csr_row_sqsums_f32 does, sp_prep.h;
+                                     _build_cosine_normalization :204-228 with norm_c1 / norm_c2 / norm_add) */
 
 typedef struct sp_knn_args {
     uint32_t struct_size;      /* = sizeof(sp_knn_args); checked */
@@ -156,6 +167,11 @@ typedef struct sp_knn_args {
     int32_t *csr_indptr;       /* SP_FLAG_CSR_OUT: OUT [n_rows_m1 + 1], caller-allocated */
     int64_t  csr_nnz;          /* SP_FLAG_CSR_OUT: OUT */
     int64_t  explicit_zeros;   /* SP_FLAG_CHECK_ZEROS: OUT */
+
+    /* ABI 3 */
+    float    norm_c1, norm_c2; /* SP_FLAG_NORMS_ON_DEVICE: Xcosine = (sum x^2 + norm_add)^norm_c1, Ycosine = (sum y^2 + norm_add)^norm_c2 */
+    float    norm_add;         /* additive_shrink */
+    int32_t  _pad2;
 } sp_knn_args;
 
 /* The hot path.  Replaces compute_similarities_parallel<int,float> (s_plus.h:265). */
@@ -180,7 +196,7 @@ const char *sp_last_error(void);
 int64_t sp_device_cache_trim(void);
 
 /* ABI version of this header. */
-#define SP_KNN_ABI_VERSION 2
+#define SP_KNN_ABI_VERSION 3
 int sp_abi_version(void);
 
 #ifdef __cplusplus

@@ -26,7 +26,10 @@ SP_FLAG_CHECK_ZEROS = 256
 SP_FLAG_CSR_OUT = 512
 SP_FLAG_P3_PREP = 1024
 SP_FLAG_DEPOP_ROWSUM = 2048
+SP_FLAG_M1_IS_M2_T = 4096
+SP_FLAG_NORMS_ON_DEVICE = 8192
 SP_EZEROS = -6
+SP_EUNSORTED = -7
 SP_NORM_L1, SP_NORM_L2, SP_NORM_MAX, SP_NORM_TFIDF, SP_NORM_BM25PLUS = range(5)
 SP_TF_MODES = {'binary': 0, 'raw': 1, 'sqrt': 2, 'freq': 3, 'log': 4}       # normalization.pyx:12-17
 SP_IDF_MODES = {'unary': 0, 'base': 1, 'smooth': 2, 'prob': 3, 'bm25': 4}   # normalization.pyx:19-24
@@ -103,6 +106,7 @@ class SpKnnArgs(C.Structure):
         ("csr_indptr", C.c_void_p),
         ("csr_nnz", C.c_int64),
         ("explicit_zeros", C.c_int64),
+        ("norm_c1", C.c_float), ("norm_c2", C.c_float), ("norm_add", C.c_float), ("_pad2", C.c_int32),
     ]
 
 
@@ -226,6 +230,10 @@ class ExplicitZerosError(HipLibraryError):
     """SP_FLAG_CHECK_ZEROS found stored zeros: the caller eliminates them (s_plus.pyx:210-211) and calls again."""
 
 
+class UnsortedRowsError(HipLibraryError):
+    """SP_FLAG_M1_IS_M2_T found a row of m2 whose column ids do not ascend: the caller converts on the host and calls again."""
+
+
 _lib = None
 
 
@@ -328,6 +336,8 @@ def call_knn(args: SpKnnArgs) -> None:
     rc = lib.sp_knn_f32_i32(C.byref(args))
     if rc == SP_EZEROS:
         raise ExplicitZerosError(last_error())
+    if rc == SP_EUNSORTED:
+        raise UnsortedRowsError(last_error())
     if rc != 0:
         raise HipLibraryError(f"sp_knn_f32_i32 failed ({rc}): {last_error()}")
 

@@ -80,6 +80,8 @@ class KernelCall:
     m2_is_m1t: bool = False    # m2 = m1^T is built on the device (SP_FLAG_M2_IS_M1_T): the m2_* arrays are empty
     p3_alpha: Optional[float] = None         # SP_FLAG_P3_PREP: m1 / m2 = m1^T rows are L1-normalised and raised to this power on the device
     depop_rowsum_p2: Optional[float] = None  # SP_FLAG_DEPOP_ROWSUM: Ydepop = (row sums of the raw m1)^p2, built on the device
+    m1_is_m2t: bool = False    # m1 = m2^T is built on the device (SP_FLAG_M1_IS_M2_T, matrix1 came as CSC): the m1_* arrays are empty
+    norms_on_device: Optional[tuple] = None  # SP_FLAG_NORMS_ON_DEVICE: (c1, c2, additive_shrink); X/Y tversky / cosine vectors are empty
 
     @property
     def n_targets(self) -> int:
@@ -389,7 +391,7 @@ def prepare(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_mat
             stabilized_shrink=0.0, bayesian_shrink=0.0, additive_shrink=0.0, threshold=0.0,
             binary=False, target_rows=None, filter_cols=None, target_cols=None,
             verbose=False, format_output='csr', m2_on_device=False, check_zeros=True,
-            p3_alpha=None, p3_depop_beta=None) -> KernelCall:
+            p3_alpha=None, p3_depop_beta=None, norms_on_device=False, csc_direct=False) -> KernelCall:
     """Everything s_plus.pyx does before the `with nogil:` block (:168-353).
 
     check_zeros=False: stored zeros are looked for on the device (run_hip(check_zeros=True)) instead of here.
@@ -399,7 +401,13 @@ def prepare(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_mat
     m2_on_device: for the `matrix2=None` call, leave the transpose (s_plus.pyx:169-170, 205-206) to the device
     (SP_FLAG_M2_IS_M1_T, include/sp_prep.h): m2 is never built on the host, its column norms are taken from the
     rows of m1 with the arithmetic the reference applies to the columns of m2.  Falls back to the host
-    transpose when the call needs m2 on the host (ARRAY column selectors, depopularisation weights)."""
+    transpose when the call needs m2 on the host (ARRAY column selectors, depopularisation weights).
+
+    norms_on_device: with the device-side transpose, leave _build_squared_norms / _build_cosine_normalization to the same
+    library call (SP_FLAG_NORMS_ON_DEVICE): the call carries (c1, c2, additive_shrink) instead of the vectors.
+    csc_direct: a CSC matrix1 (`URM.T` of a CSR URM: the documented item-item call) is not converted on the host
+    (matrix1.tocsr(), s_plus.pyx:205-206): its arrays ARE the CSR of matrix2 = matrix1.T, and m1 is built from them on
+    the device (SP_FLAG_M1_IS_M2_T).  Needs norms_on_device (there is no m1 on the host to take norms from)."""
     m2_from_m1 = matrix2 is None
     if matrix2 is None:
         matrix2 = matrix1.T
@@ -417,21 +425,33 @@ def prepare(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_mat
             # the reference does not check (s_plus.pyx:191-196: out-of-range is UB there)
             raise ValueError("target_rows contains row ids outside matrix1")
 
-    m1, m1_data, m1_indices, m1_indptr = _csr_f32_i32(matrix1, binary, check_zeros)
     sel_f = build_column_selector(filter_cols)
     sel_t = build_column_selector(target_cols)
     p3 = p3_alpha is not None
     on_dev = bool(m2_on_device) and m2_from_m1 and (l3 == 0 or (p3 and p3_depop_beta is not None)) and sel_f[0] != MODE_ARRAY and sel_t[0] != MODE_ARRAY
     if p3 and not on_dev:
         raise ValueError("p3_alpha needs the device-side transpose (matrix2=None, no array selectors)")
-    if on_dev:
-        m2_data, m2_indices, m2_indptr = _EMPTY_F32, _EMPTY_I32, _EMPTY_I32
-        n_rows_m1, n_rows_m2 = m1.shape
+    dev_norms = on_dev and bool(norms_on_device) and (l1 != 0 or l2 != 0)
+    csc = (on_dev and bool(csc_direct) and getattr(matrix1, "format", None) == "csc" and (dev_norms or (l1 == 0 and l2 == 0))
+           and matrix1.nnz <= np.iinfo(np.int32).max
+           and not (check_zeros and matrix1.data.shape[0] and np.count_nonzero(matrix1.data) != matrix1.data.shape[0]))
+    if csc:
+        # (data, indices, indptr) of the CSC matrix1 are the CSR arrays of matrix2 = matrix1.T (s_plus.pyx:169-170)
+        n_rows_m1, n_rows_m2 = matrix1.shape
         n_output_cols = n_rows_m1
+        m1_data, m1_indices, m1_indptr = _EMPTY_F32, _EMPTY_I32, _EMPTY_I32
+        m2_data = np.ones(matrix1.data.shape[0], dtype=np.float32) if binary else np.ascontiguousarray(matrix1.data, dtype=np.float32)
+        m2_indices = np.ascontiguousarray(matrix1.indices, dtype=np.int32)
+        m2_indptr = np.ascontiguousarray(matrix1.indptr, dtype=np.int32)
     else:
-        m2, m2_data, m2_indices, m2_indptr = _csr_f32_i32(matrix2, binary, check_zeros)
+        m1, m1_data, m1_indices, m1_indptr = _csr_f32_i32(matrix1, binary, check_zeros)
         n_rows_m1, n_rows_m2 = m1.shape
-        n_output_cols = m2.shape[1]
+        if on_dev:
+            m2_data, m2_indices, m2_indptr = _EMPTY_F32, _EMPTY_I32, _EMPTY_I32
+            n_output_cols = n_rows_m1
+        else:
+            m2, m2_data, m2_indices, m2_indptr = _csr_f32_i32(matrix2, binary, check_zeros)
+            n_output_cols = m2.shape[1]
 
     # all scalar parameters are C floats in the reference (s_plus.pyx:100-113)
     f32 = lambda x: float(np.float32(x))  # noqa: E731
@@ -443,11 +463,14 @@ def prepare(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_mat
         m2_data=m2_data, m2_indices=m2_indices, m2_indptr=m2_indptr,
         n_rows_m1=n_rows_m1, n_rows_m2=n_rows_m2, n_output_cols=n_output_cols, k=k,
         a1=a1, l1=l1, l2=l2, l3=l3, t1=t1, t2=t2,
-        stabilized_shrink=stabilized_shrink, bayesian_shrink=bayesian_shrink, threshold=threshold, m2_is_m1t=on_dev)
+        stabilized_shrink=stabilized_shrink, bayesian_shrink=bayesian_shrink, threshold=threshold,
+        m2_is_m1t=on_dev and not csc, m1_is_m2t=csc)
     if p3:
         call.p3_alpha = f32(p3_alpha)
 
-    if l1 != 0 or l2 != 0:
+    if dev_norms:
+        call.norms_on_device = (f32(c1), f32(c2), f32(additive_shrink))
+    elif l1 != 0 or l2 != 0:
         if on_dev:
             sq1, sq2 = squared_norms_m1t_hip(m1_data, m1_indptr)
         elif m2_on_device:      # (the public call with an explicit matrix2: both norm vectors from the device)
@@ -473,7 +496,7 @@ def prepare(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_mat
     call.filter_mode, call.filter_m_indptr, call.filter_m_indices = sel_f
     call.target_col_mode, call.target_col_m_indptr, call.target_col_m_indices = sel_t
     if on_dev:
-        return call        # (the device builds m2 with ascending column ids)
+        return call        # (the device builds m2 with ascending column ids; SP_FLAG_M1_IS_M2_T checks those of the caller's)
     if call.filter_mode == MODE_ARRAY or call.target_col_mode == MODE_ARRAY:
         keep = compute_target_columns(filter_cols, target_cols, n_output_cols)
         call.m2_data, call.m2_indices, call.m2_indptr = filter_matrix_columns(
@@ -544,6 +567,11 @@ def run_hip(call: KernelCall, device: Optional[int] = None, table_slots: int = 0
     a.nnz_m1, a.nnz_m2 = int(call.m1_data.shape[0]), int(call.m2_data.shape[0])
     if call.m2_is_m1t:
         a.flags |= _abi.SP_FLAG_M2_IS_M1_T
+    if call.m1_is_m2t:
+        a.flags |= _abi.SP_FLAG_M1_IS_M2_T
+    if call.norms_on_device is not None:
+        a.flags |= _abi.SP_FLAG_NORMS_ON_DEVICE
+        a.norm_c1, a.norm_c2, a.norm_add = call.norms_on_device
     keep = []  # keep converted arrays alive across the call
 
     def f32(x):
@@ -647,16 +675,24 @@ def _s_plus_impl(matrix1, matrix2, weight_depop_matrix1, weight_depop_matrix2, p
         return res
     # stored zeros: looked for on the device, where the data goes anyway (under `binary` the uploaded data are ones: host check)
     device_zero_check = not binary
-    call = prepare(*args, m2_on_device=True, check_zeros=not device_zero_check, **p3kw)
-    t = call.targets
-    csr_out = (format_output == 'csr' and call.n_targets > 0 and call.n_targets * call.k <= np.iinfo(np.int32).max
-               and (call.n_targets == 1 or bool(np.all(t[1:] > t[:-1]))))
-    _say(verbose, "Computing")
-    try:
-        out = run_hip(call, want_rows=(format_output != 'csr'), check_zeros=device_zero_check, csr_out=csr_out)
-    except _abi.ExplicitZerosError:
-        call = prepare(*args, m2_on_device=True, check_zeros=True, **p3kw)      # eliminate_zeros on the host (s_plus.pyx:210-211)
-        out = run_hip(call, want_rows=(format_output != 'csr'), csr_out=csr_out)
+    opts = dict(check_zeros=not device_zero_check, csc_direct=True)
+    while True:
+        call = prepare(*args, m2_on_device=True, norms_on_device=True, **opts, **p3kw)
+        t = call.targets
+        csr_out = (format_output == 'csr' and call.n_targets > 0 and call.n_targets * call.k <= np.iinfo(np.int32).max
+                   and (call.n_targets == 1 or bool(np.all(t[1:] > t[:-1]))))
+        _say(verbose, "Computing")
+        try:
+            out = run_hip(call, want_rows=(format_output != 'csr'), check_zeros=not opts["check_zeros"], csr_out=csr_out)
+            break
+        except _abi.ExplicitZerosError:
+            if opts["check_zeros"]:
+                raise
+            opts["check_zeros"] = True          # eliminate_zeros on the host (s_plus.pyx:210-211), then again
+        except _abi.UnsortedRowsError:
+            if not opts["csc_direct"]:
+                raise
+            opts["csc_direct"] = False          # matrix1.tocsr() on the host (s_plus.pyx:205-206), then again
     _say(verbose, f"Building {format_output} matrix")
     if csr_out:
         indptr, indices, data = out

@@ -200,27 +200,30 @@ int validate(const sp_knn_args *a) {
     if (a->nnz_m1 < 0 || a->nnz_m2 < 0 || a->nnz_m1 > 0x7FFFFFFFLL || a->nnz_m2 > 0x7FFFFFFFLL)
         return fail(SP_EINVAL, "nnz must fit int32 indptr (reference limit, s_plus.pyx:241-244)");
     const bool m2t = (a->flags & SP_FLAG_M2_IS_M1_T) != 0;     // m2 = m1^T, built on the device: the m2_* pointers and nnz_m2 are ignored
+    const bool m1t = (a->flags & SP_FLAG_M1_IS_M2_T) != 0;     // m1 = m2^T, built on the device: the m1_* pointers and nnz_m1 are ignored
+    const bool dev_norms = (a->flags & SP_FLAG_NORMS_ON_DEVICE) != 0;
+    if (m2t && m1t) return fail(SP_EINVAL, "SP_FLAG_M2_IS_M1_T and SP_FLAG_M1_IS_M2_T exclude each other");
     if ((m2t ? a->nnz_m1 : a->nnz_m2) >= (1LL << 30) - 1024)
         return fail(SP_EINVAL, "nnz(m2) = %lld: this build addresses m2 with 32-bit byte offsets and needs nnz(m2) < 2^30",
                     (long long)(m2t ? a->nnz_m1 : a->nnz_m2));
-    if ((a->flags & (SP_FLAG_P3_PREP | SP_FLAG_DEPOP_ROWSUM)) && !m2t)
-        return fail(SP_EINVAL, "SP_FLAG_P3_PREP / SP_FLAG_DEPOP_ROWSUM need SP_FLAG_M2_IS_M1_T");
+    if ((a->flags & (SP_FLAG_P3_PREP | SP_FLAG_DEPOP_ROWSUM | SP_FLAG_NORMS_ON_DEVICE)) && !m2t && !m1t)
+        return fail(SP_EINVAL, "SP_FLAG_P3_PREP / SP_FLAG_DEPOP_ROWSUM / SP_FLAG_NORMS_ON_DEVICE need SP_FLAG_M2_IS_M1_T or SP_FLAG_M1_IS_M2_T");
     if ((a->flags & SP_FLAG_DEPOP_ROWSUM) && !(a->flags & SP_FLAG_P3_PREP))
         return fail(SP_EINVAL, "SP_FLAG_DEPOP_ROWSUM needs SP_FLAG_P3_PREP");
     if ((a->flags & (SP_FLAG_CSR_OUT | SP_FLAG_CHECK_ZEROS)) && a->on_device)
         return fail(SP_EINVAL, "SP_FLAG_CSR_OUT / SP_FLAG_CHECK_ZEROS are host-mode flags (on_device = 0)");
     if ((a->flags & SP_FLAG_CSR_OUT) && a->n_targets > 0 && !a->csr_indptr) return fail(SP_EINVAL, "SP_FLAG_CSR_OUT needs csr_indptr");
-    if (m2t && a->n_output_cols != a->n_rows_m1)
-        return fail(SP_EINVAL, "SP_FLAG_M2_IS_M1_T: n_output_cols (%d) must equal n_rows_m1 (%d)", a->n_output_cols, a->n_rows_m1);
+    if ((m2t || m1t) && a->n_output_cols != a->n_rows_m1)
+        return fail(SP_EINVAL, "SP_FLAG_M2_IS_M1_T / SP_FLAG_M1_IS_M2_T: n_output_cols (%d) must equal n_rows_m1 (%d)", a->n_output_cols, a->n_rows_m1);
     if (a->n_targets > 0) {
-        if (!a->targets || !a->m1_indptr || (!m2t && !a->m2_indptr) || !a->cols || !a->values)
+        if (!a->targets || (!m1t && !a->m1_indptr) || (!m2t && !a->m2_indptr) || !a->cols || !a->values)
             return fail(SP_EINVAL, "NULL input/output pointer");
         if (!a->rows && !(a->flags & (SP_FLAG_NO_ROWS_OUT | SP_FLAG_CSR_OUT)))
             return fail(SP_EINVAL, "rows is NULL");
-        if (a->nnz_m1 > 0 && (!a->m1_data || !a->m1_indices)) return fail(SP_EINVAL, "m1 arrays NULL");
+        if (!m1t && a->nnz_m1 > 0 && (!a->m1_data || !a->m1_indices)) return fail(SP_EINVAL, "m1 arrays NULL");
         if (!m2t && a->nnz_m2 > 0 && (!a->m2_data || !a->m2_indices)) return fail(SP_EINVAL, "m2 arrays NULL");
-        if (a->l1 != 0.f && (!a->Xtversky || !a->Ytversky)) return fail(SP_EINVAL, "l1 != 0 needs Xtversky/Ytversky");
-        if (a->l2 != 0.f && (!a->Xcosine || !a->Ycosine)) return fail(SP_EINVAL, "l2 != 0 needs Xcosine/Ycosine");
+        if (!dev_norms && a->l1 != 0.f && (!a->Xtversky || !a->Ytversky)) return fail(SP_EINVAL, "l1 != 0 needs Xtversky/Ytversky");
+        if (!dev_norms && a->l2 != 0.f && (!a->Xcosine || !a->Ycosine)) return fail(SP_EINVAL, "l2 != 0 needs Xcosine/Ycosine");
         if (a->l3 != 0.f && (!a->Xdepop || (!a->Ydepop && !(a->flags & SP_FLAG_DEPOP_ROWSUM)))) return fail(SP_EINVAL, "l3 != 0 needs Xdepop/Ydepop");
         if (a->filter_mode == SP_SEL_MATRIX && (!a->filter_m_indptr || (a->filter_nnz > 0 && !a->filter_m_indices)))
             return fail(SP_EINVAL, "filter MATRIX mode needs indptr/indices");
@@ -446,32 +449,43 @@ int run_device_impl(sp_knn_args *a) {
 #include "sp_transpose.hpp"
 namespace {
 
-// Layout of the extra scratch a SP_FLAG_M2_IS_M1_T call needs behind the kernel's own workspace: the three arrays of
-// m2 = m1^T, then the transpose's scratch.
-struct M2tLayout { size_t knn, data, indices, indptr, m1copy, ydepop, tr, total; };
+// Layout of the extra scratch a SP_FLAG_M2_IS_M1_T / SP_FLAG_M1_IS_M2_T call needs behind the kernel's own workspace: the
+// three arrays of the matrix built here (m2 = m1^T or m1 = m2^T), the optional vectors, then the transpose's scratch.
+struct M2tLayout { size_t knn, data, indices, indptr, p3copy, ydepop, norms, tr, total; };
 int m2t_layout(const sp_knn_args *a, int n_cus, sp_knn_args *plain, M2tLayout *L) {
+    const bool m1t = (a->flags & SP_FLAG_M1_IS_M2_T) != 0;
+    const int64_t nnz = m1t ? a->nnz_m2 : a->nnz_m1;
+    const int built_rows = m1t ? a->n_rows_m1 : a->n_rows_m2;      // rows of the matrix built here = columns of the one given
     *plain = *a;
-    plain->flags &= ~(SP_FLAG_M2_IS_M1_T | SP_FLAG_P3_PREP | SP_FLAG_DEPOP_ROWSUM);
-    plain->nnz_m2 = a->nnz_m1;
+    plain->flags &= ~(SP_FLAG_M2_IS_M1_T | SP_FLAG_M1_IS_M2_T | SP_FLAG_P3_PREP | SP_FLAG_DEPOP_ROWSUM | SP_FLAG_NORMS_ON_DEVICE);
+    plain->nnz_m1 = plain->nnz_m2 = nnz;
     Config c;
     TRY(make_config(plain, n_cus, &c));
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     L->knn = al(c.ws_total);
     L->data = L->knn;
-    L->indices = L->data + al((size_t)a->nnz_m1 * 4);
-    L->indptr = L->indices + al((size_t)a->nnz_m1 * 4);
-    // SP_FLAG_P3_PREP: a normalised copy of m1's values (the caller's stay as they are) and, for rp3beta, the column term
-    L->m1copy = L->indptr + al(((size_t)a->n_rows_m2 + 1) * 4);
-    L->ydepop = L->m1copy + ((a->flags & SP_FLAG_P3_PREP) ? al((size_t)a->nnz_m1 * 4) : 0);
-    L->tr = L->ydepop + ((a->flags & SP_FLAG_DEPOP_ROWSUM) ? al((size_t)a->n_rows_m1 * 4) : 0);
-    L->total = L->tr + transpose_ws_bytes(a->nnz_m1, a->n_rows_m2);
+    L->indices = L->data + al((size_t)nnz * 4);
+    L->indptr = L->indices + al((size_t)nnz * 4);
+    // SP_FLAG_P3_PREP: a normalised copy of the caller's values (they stay as they are) and, for rp3beta, the column term
+    L->p3copy = L->indptr + al(((size_t)built_rows + 1) * 4);
+    L->ydepop = L->p3copy + ((a->flags & SP_FLAG_P3_PREP) ? al((size_t)nnz * 4) : 0);
+    L->norms = L->ydepop + ((a->flags & SP_FLAG_DEPOP_ROWSUM) ? al((size_t)a->n_rows_m1 * 4) : 0);
+    L->tr = L->norms + ((a->flags & SP_FLAG_NORMS_ON_DEVICE) ? 4 * al((size_t)a->n_rows_m1 * 4) : 0);
+    L->total = L->tr + transpose_ws_bytes(nnz, built_rows);
     return SP_OK;
 }
 
-// device pointers in, device pointers out; with SP_FLAG_M2_IS_M1_T the transpose (s_plus.pyx:169-170, 205-206) is built
-// first, on the same stream, into scratch behind the kernel's workspace
+// out[i] = (in[i] + add)^p in float32: _build_cosine_normalization (s_plus_utils.pyx:204-228: the sum in float32, np.power in float32)
+__global__ __launch_bounds__(256) void sp_add_pow_f32_kernel(int n, const float *__restrict__ in, float *__restrict__ out, float add, double p) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)pow((double)__fadd_rn(in[i], add), p);
+}
+
+// device pointers in, device pointers out; with SP_FLAG_M2_IS_M1_T / SP_FLAG_M1_IS_M2_T the transpose (s_plus.pyx:169-170,
+// 205-206) is built first, on the same stream, into scratch behind the kernel's workspace
 int run_device(sp_knn_args *a) {
-    if (!(a->flags & SP_FLAG_M2_IS_M1_T)) return run_device_impl(a);
+    const bool m2t = (a->flags & SP_FLAG_M2_IS_M1_T) != 0, m1t = (a->flags & SP_FLAG_M1_IS_M2_T) != 0;
+    if (!m2t && !m1t) return run_device_impl(a);
     HIP_TRY(hipSetDevice(a->device));
     if (a->n_targets == 0) { a->kernel_ms = 0.f; return SP_OK; }
     int n_cus = 256;
@@ -496,46 +510,74 @@ int run_device(sp_knn_args *a) {
         TRY(guard.event(&ev1));
         HIP_TRY(hipEventRecord(ev0, stream));
     }
-    float *m2_data = (float *)(ws + L.data);
-    int *m2_indices = (int *)(ws + L.indices), *m2_indptr = (int *)(ws + L.indptr);
-    int rc = transpose_device(a->n_rows_m1, a->n_rows_m2, a->nnz_m1, a->m1_data, a->m1_indices, a->m1_indptr,
-                              m2_data, m2_indices, m2_indptr, ws + L.tr, L.total - L.tr, stream);
+    const int64_t nnz = b.nnz_m1;
+    float *t_data = (float *)(ws + L.data);
+    int *t_indices = (int *)(ws + L.indices), *t_indptr = (int *)(ws + L.indptr);
+    int rc = m2t ? transpose_device(a->n_rows_m1, a->n_rows_m2, nnz, a->m1_data, a->m1_indices, a->m1_indptr,
+                                    t_data, t_indices, t_indptr, ws + L.tr, L.total - L.tr, stream)
+                 : transpose_device(a->n_rows_m2, a->n_rows_m1, nnz, a->m2_data, a->m2_indices, a->m2_indptr,
+                                    t_data, t_indices, t_indptr, ws + L.tr, L.total - L.tr, stream);
     float tr_ms = 0.f;
     if (!rc && timed) {
         HIP_TRY(hipEventRecord(ev1, stream));
         HIP_TRY(hipEventSynchronize(ev1));
         HIP_TRY(hipEventElapsedTime(&tr_ms, ev0, ev1));
     }
-    if (!rc && (a->flags & SP_FLAG_P3_PREP) && a->nnz_m1 > 0) {
+    if (rc) return rc;
+    // both matrices now exist; `own` marks the one built here (writable), the other one is the caller's
+    const float *m1_data = m2t ? a->m1_data : t_data;
+    const int *m1_indptr = m2t ? a->m1_indptr : t_indptr;
+    const float *m2_data = m2t ? t_data : a->m2_data;
+    const int *m2_indptr = m2t ? t_indptr : a->m2_indptr;
+    if (m2t) { b.m2_data = t_data; b.m2_indices = t_indices; b.m2_indptr = t_indptr; }
+    else     { b.m1_data = t_data; b.m1_indices = t_indices; b.m1_indptr = t_indptr; }
+    const int wave_blocks = [](int n) { return std::max(1, std::min(256 * 16, (n + 3) / 4)); }(std::max(a->n_rows_m1, a->n_rows_m2));
+    const int vec_blocks = (a->n_rows_m1 + 255) / 256;
+    if ((a->flags & SP_FLAG_NORMS_ON_DEVICE) && (a->l1 != 0.f || a->l2 != 0.f) && a->n_rows_m1 > 0) {
+        // _build_squared_norms for m2 = m1^T, from the rows of m1 (sp_csr_row_sqsums_f32's two kernels), then
+        // _build_cosine_normalization (s_plus_utils.pyx:204-228)
+        const size_t stride = ((size_t)a->n_rows_m1 * 4 + 255) & ~(size_t)255;
+        float *sq1 = (float *)(ws + L.norms), *sq2 = (float *)(ws + L.norms + stride);
+        float *xc = (float *)(ws + L.norms + 2 * stride), *yc = (float *)(ws + L.norms + 3 * stride);
+        hipLaunchKernelGGL(sp_row_sqsums_kernel, dim3(std::min(256 * 16, vec_blocks)), dim3(256), 0, stream, a->n_rows_m1, m1_data, m1_indptr, sq1, sq2);
+        hipLaunchKernelGGL(sp_row_sqsums_long_kernel, dim3(std::min(a->n_rows_m1, 2048)), dim3(256), 0, stream, a->n_rows_m1, m1_data, m1_indptr, sq1, sq2);
+        if (a->l1 != 0.f) { b.Xtversky = sq1; b.Ytversky = sq2; }
+        if (a->l2 != 0.f) {
+            hipLaunchKernelGGL(sp_add_pow_f32_kernel, dim3(vec_blocks), dim3(256), 0, stream, a->n_rows_m1, sq1, xc, a->norm_add, (double)a->norm_c1);
+            hipLaunchKernelGGL(sp_add_pow_f32_kernel, dim3(vec_blocks), dim3(256), 0, stream, a->n_rows_m1, sq2, yc, a->norm_add, (double)a->norm_c2);
+            b.Xcosine = xc; b.Ycosine = yc;
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    if ((a->flags & SP_FLAG_P3_PREP) && nnz > 0) {
         // p3alpha / rp3beta (similarity.py:410-415, 477-483): the column popularity comes from the RAW matrix, then the rows of
         // m1 and of m2 = m1^T are divided by their L1 norms and every entry is raised to alpha
-        const int wave_blocks = [](int n) { return std::max(1, std::min(256 * 16, (n + 3) / 4)); }(std::max(a->n_rows_m1, a->n_rows_m2));
         if (a->flags & SP_FLAG_DEPOP_ROWSUM) {
             float *yd = (float *)(ws + L.ydepop);
-            hipLaunchKernelGGL(sp_row_sums_kernel, dim3(wave_blocks), dim3(256), 0, stream, a->n_rows_m1, a->m1_data, a->m1_indptr, yd);
-            hipLaunchKernelGGL(sp_pow_f32_kernel, dim3((a->n_rows_m1 + 255) / 256), dim3(256), 0, stream, a->n_rows_m1, yd, yd, (double)a->depop_p2);
+            hipLaunchKernelGGL(sp_row_sums_kernel, dim3(wave_blocks), dim3(256), 0, stream, a->n_rows_m1, m1_data, m1_indptr, yd);
+            hipLaunchKernelGGL(sp_pow_f32_kernel, dim3(vec_blocks), dim3(256), 0, stream, a->n_rows_m1, yd, yd, (double)a->depop_p2);
             b.Ydepop = yd;
         }
-        float *m1n = (float *)(ws + L.m1copy);
-        HIP_TRY(hipMemcpyAsync(m1n, a->m1_data, (size_t)a->nnz_m1 * 4, hipMemcpyDeviceToDevice, stream));
-        hipLaunchKernelGGL((sp_row_normalize_kernel<float, RO_L1>), dim3(wave_blocks), dim3(256), 0, stream, a->n_rows_m1, m1n, a->m1_indptr, (double)a->p3_alpha);
-        hipLaunchKernelGGL((sp_row_normalize_kernel<float, RO_L1>), dim3(wave_blocks), dim3(256), 0, stream, a->n_rows_m2, m2_data, m2_indptr, (double)a->p3_alpha);
+        // the caller's values stay as they are: a normalised copy of them, the matrix built here in place
+        float *cp = (float *)(ws + L.p3copy);
+        HIP_TRY(hipMemcpyAsync(cp, m2t ? m1_data : m2_data, (size_t)nnz * 4, hipMemcpyDeviceToDevice, stream));
+        float *m1n = m2t ? cp : t_data, *m2n = m2t ? t_data : cp;
+        hipLaunchKernelGGL((sp_row_normalize_kernel<float, RO_L1>), dim3(wave_blocks), dim3(256), 0, stream, a->n_rows_m1, m1n, m1_indptr, (double)a->p3_alpha);
+        hipLaunchKernelGGL((sp_row_normalize_kernel<float, RO_L1>), dim3(wave_blocks), dim3(256), 0, stream, a->n_rows_m2, m2n, m2_indptr, (double)a->p3_alpha);
         HIP_TRY(hipGetLastError());
         b.m1_data = m1n;
+        b.m2_data = m2n;
     }
-    if (!rc) {
-        b.m2_data = m2_data; b.m2_indices = m2_indices; b.m2_indptr = m2_indptr;
-        b.workspace = ws;
-        b.workspace_bytes = (int64_t)L.knn;
-        rc = run_device_impl(&b);
-        a->kernel_ms = b.kernel_ms + tr_ms;
-        a->passes_total = b.passes_total;
-        a->num_wgs_used = b.num_wgs_used;
-        memcpy(a->phase_cycles, b.phase_cycles, sizeof(a->phase_cycles));
-        a->reserved[1] = b.reserved[1];
-        a->reserved[2] = b.reserved[2];
-        a->reserved[3] = (int64_t)(tr_ms * 1000.f);
-    }
+    b.workspace = ws;
+    b.workspace_bytes = (int64_t)L.knn;
+    rc = run_device_impl(&b);
+    a->kernel_ms = b.kernel_ms + tr_ms;
+    a->passes_total = b.passes_total;
+    a->num_wgs_used = b.num_wgs_used;
+    memcpy(a->phase_cycles, b.phase_cycles, sizeof(a->phase_cycles));
+    a->reserved[1] = b.reserved[1];
+    a->reserved[2] = b.reserved[2];
+    a->reserved[3] = (int64_t)(tr_ms * 1000.f);
     return rc;
 }
 
@@ -662,8 +704,9 @@ int run_host(sp_knn_args *a) {
             return fail(SP_EINVAL, "targets[%zu]=%d out of range [0,%d)", i, a->targets[i], a->n_rows_m1);
 
     // ... nor a hand-built CSR: out-of-range indices or a non-monotone indptr would become out-of-bounds device reads and atomics
-    TRY(check_csr("m1", a->m1_indptr, a->m1_indices, a->n_rows_m1, a->nnz_m1, a->n_rows_m2));
-    if (!(a->flags & SP_FLAG_M2_IS_M1_T)) TRY(check_csr("m2", a->m2_indptr, a->m2_indices, a->n_rows_m2, a->nnz_m2, a->n_output_cols));
+    const bool m2t = (a->flags & SP_FLAG_M2_IS_M1_T) != 0, m1t = (a->flags & SP_FLAG_M1_IS_M2_T) != 0;
+    if (!m1t) TRY(check_csr("m1", a->m1_indptr, a->m1_indices, a->n_rows_m1, a->nnz_m1, a->n_rows_m2));
+    if (!m2t) TRY(check_csr("m2", a->m2_indptr, a->m2_indices, a->n_rows_m2, a->nnz_m2, a->n_output_cols));
     if (a->filter_mode == SP_SEL_MATRIX) TRY(check_csr("filter_cols", a->filter_m_indptr, a->filter_m_indices, a->n_rows_m1, a->filter_nnz, a->n_output_cols));
     if (a->target_col_mode == SP_SEL_MATRIX) TRY(check_csr("target_cols", a->target_col_m_indptr, a->target_col_m_indices, a->n_rows_m1, a->target_col_nnz, a->n_output_cols));
 
@@ -675,20 +718,26 @@ int run_host(sp_knn_args *a) {
     d.workspace = nullptr;
     d.workspace_bytes = 0;
     TRY(pool.up(a->targets, nt, &d.targets));
-    TRY(pool.up(a->m1_data, (size_t)a->nnz_m1, &d.m1_data));
-    TRY(pool.up(a->m1_indices, (size_t)a->nnz_m1, &d.m1_indices));
-    TRY(pool.up(a->m1_indptr, (size_t)a->n_rows_m1 + 1, &d.m1_indptr));
-    if (a->flags & SP_FLAG_M2_IS_M1_T) {       // m2 never exists on the host: built on the device from m1
+    if (m1t) {                                 // m1 never exists on the host: built on the device from m2
+        d.m1_data = nullptr; d.m1_indices = nullptr; d.m1_indptr = nullptr;
+        d.nnz_m1 = a->nnz_m2;
+    } else {
+        TRY(pool.up(a->m1_data, (size_t)a->nnz_m1, &d.m1_data));
+        TRY(pool.up(a->m1_indices, (size_t)a->nnz_m1, &d.m1_indices));
+        TRY(pool.up(a->m1_indptr, (size_t)a->n_rows_m1 + 1, &d.m1_indptr));
+    }
+    if (m2t) {                                 // m2 never exists on the host: built on the device from m1
         d.m2_data = nullptr; d.m2_indices = nullptr; d.m2_indptr = nullptr;
     } else {
         TRY(pool.up(a->m2_data, (size_t)a->nnz_m2, &d.m2_data));
         TRY(pool.up(a->m2_indices, (size_t)a->nnz_m2, &d.m2_indices));
         TRY(pool.up(a->m2_indptr, (size_t)a->n_rows_m2 + 1, &d.m2_indptr));
     }
-    TRY(pool.up(a->l1 != 0.f ? a->Xtversky : nullptr, (size_t)a->n_rows_m1, &d.Xtversky));
-    TRY(pool.up(a->l1 != 0.f ? a->Ytversky : nullptr, (size_t)a->n_output_cols, &d.Ytversky));
-    TRY(pool.up(a->l2 != 0.f ? a->Xcosine : nullptr, (size_t)a->n_rows_m1, &d.Xcosine));
-    TRY(pool.up(a->l2 != 0.f ? a->Ycosine : nullptr, (size_t)a->n_output_cols, &d.Ycosine));
+    const bool host_norms = !(a->flags & SP_FLAG_NORMS_ON_DEVICE);
+    TRY(pool.up(host_norms && a->l1 != 0.f ? a->Xtversky : nullptr, (size_t)a->n_rows_m1, &d.Xtversky));
+    TRY(pool.up(host_norms && a->l1 != 0.f ? a->Ytversky : nullptr, (size_t)a->n_output_cols, &d.Ytversky));
+    TRY(pool.up(host_norms && a->l2 != 0.f ? a->Xcosine : nullptr, (size_t)a->n_rows_m1, &d.Xcosine));
+    TRY(pool.up(host_norms && a->l2 != 0.f ? a->Ycosine : nullptr, (size_t)a->n_output_cols, &d.Ycosine));
     TRY(pool.up(a->l3 != 0.f ? a->Xdepop : nullptr, (size_t)a->n_rows_m1, &d.Xdepop));
     TRY(pool.up(a->l3 != 0.f ? a->Ydepop : nullptr, (size_t)a->n_output_cols, &d.Ydepop));
     const bool fm = a->filter_mode == SP_SEL_MATRIX, tm = a->target_col_mode == SP_SEL_MATRIX;
@@ -703,14 +752,27 @@ int run_host(sp_knn_args *a) {
         unsigned long long *cnt = nullptr;
         TRY(pool.alloc(1, &cnt));
         HIP_TRY(hipMemset(cnt, 0, sizeof(*cnt)));
-        if (a->nnz_m1 > 0) hipLaunchKernelGGL(sp_zero_count_kernel, dim3(1024), dim3(256), 0, nullptr, (long long)a->nnz_m1, d.m1_data, cnt);
-        if (!(a->flags & SP_FLAG_M2_IS_M1_T) && a->nnz_m2 > 0)
+        if (!m1t && a->nnz_m1 > 0) hipLaunchKernelGGL(sp_zero_count_kernel, dim3(1024), dim3(256), 0, nullptr, (long long)a->nnz_m1, d.m1_data, cnt);
+        if (!m2t && a->nnz_m2 > 0)
             hipLaunchKernelGGL(sp_zero_count_kernel, dim3(1024), dim3(256), 0, nullptr, (long long)a->nnz_m2, d.m2_data, cnt);
         HIP_TRY(hipGetLastError());
         unsigned long long h = 0;
         HIP_TRY(hipMemcpy(&h, cnt, sizeof(h), hipMemcpyDeviceToHost));
         a->explicit_zeros = (int64_t)h;
         if (h) return fail(SP_EZEROS, "%llu stored entries are zero: eliminate them first (s_plus.pyx:210-211)", h);
+    }
+
+    if (m1t && a->nnz_m2 > 1) {
+        // the column windows of the row kernels need ascending column ids inside each m2 row (sp_knn.h); a CSC that came
+        // from a canonical CSR has them, anything else goes back to the caller
+        unsigned int *bad = nullptr;
+        TRY(pool.alloc(1, &bad));
+        HIP_TRY(hipMemset(bad, 0, sizeof(*bad)));
+        hipLaunchKernelGGL(sp_rows_sorted_kernel, dim3(std::max(1, std::min(256 * 16, (a->n_rows_m2 + 3) / 4))), dim3(256), 0, nullptr, a->n_rows_m2, d.m2_indptr, d.m2_indices, bad);
+        HIP_TRY(hipGetLastError());
+        unsigned int h = 0;
+        HIP_TRY(hipMemcpy(&h, bad, sizeof(h), hipMemcpyDeviceToHost));
+        if (h) return fail(SP_EUNSORTED, "SP_FLAG_M1_IS_M2_T: %u rows of m2 do not have ascending column ids", h);
     }
 
     const bool csr_out = (a->flags & SP_FLAG_CSR_OUT) != 0;
@@ -814,7 +876,7 @@ int64_t sp_knn_workspace_bytes(const sp_knn_args *a) {
         rc = device_cus(a->device, &n_cus);
         if (rc) return rc;
     }
-    if (a->flags & SP_FLAG_M2_IS_M1_T) {
+    if (a->flags & (SP_FLAG_M2_IS_M1_T | SP_FLAG_M1_IS_M2_T)) {
         sp_knn_args plain;
         M2tLayout L;
         rc = m2t_layout(a, n_cus, &plain, &L);

@@ -47,6 +47,18 @@ __global__ __launch_bounds__(256) void sp_zero_count_kernel(long long nnz, const
     if ((threadIdx.x & 63) == 0 && n) atomicAdd(counter, (unsigned long long)n);
 }
 
+// number of rows whose column ids descend somewhere (one wave per row)
+__global__ __launch_bounds__(256) void sp_rows_sorted_kernel(int n_rows, const int *__restrict__ indptr, const int *__restrict__ indices, unsigned int *__restrict__ bad_rows) {
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6, n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long r = wave0; r < n_rows; r += n_waves) {
+        const int b = indptr[r], e = indptr[r + 1];
+        int bad = 0;
+        for (int i = b + 1 + lane; i < e; i += 64) bad |= (indices[i] < indices[i - 1]) ? 1 : 0;
+        if (__any(bad) && lane == 0) atomicAdd(bad_rows, 1u);
+    }
+}
+
 // ---- l1 / l2 / max (normalization.pyx:97-197), optionally followed by ^alpha (similarity.py:411, 413) ----
 // One wave per row.  Rows whose norm is 0 (max: <= 0, or empty) are left alone.
 template <typename T, int MODE>

@@ -549,17 +549,86 @@ def test_public_call_with_device_transpose_matches_host_transpose(name, kw):
     f = getattr(sim, name)
     a = f(m, k=12, verbose=False, format_output="csr", **kw).tocsr()
     b = f(m, m.T.tocsr(), k=12, verbose=False, format_output="csr", **kw).tocsr()
+    _assert_same_topk(a, b, 12)
+
+
+def _assert_same_topk(a, b, k, rtol=1e-6, tied=False):
+    """Two results of the same call through two paths: same kept values per row; positions may differ only on a k-th place tie
+    (tied: the data are binary, whole groups of candidates share a value — only the kept values are compared)."""
+    a, b = a.tocsr(), b.tocsr()
     a.sort_indices(); b.sort_indices()
     assert a.shape == b.shape
     da, db = a.toarray(), b.toarray()
     # the kept VALUES of every row agree (the real assertion); positions may differ only where the k-th place is tied
-    assert np.allclose(np.sort(da, axis=1)[:, -12:], np.sort(db, axis=1)[:, -12:], rtol=1e-6, atol=0)
-    mism = ~np.isclose(da, db, rtol=1e-6, atol=0)
-    assert mism.sum() <= 8, f"{mism.sum()} entries differ between the two paths (a tie swap costs 2)"
+    assert np.allclose(np.sort(da, axis=1)[:, -k:], np.sort(db, axis=1)[:, -k:], rtol=rtol, atol=0)
+    mism = ~np.isclose(da, db, rtol=rtol, atol=0)
+    assert tied or mism.sum() <= 8, f"{mism.sum()} entries differ between the two paths (a tie swap costs 2)"
     for r in np.flatnonzero(mism.any(axis=1)):
         kth = min(da[r][da[r] != 0].min(), db[r][db[r] != 0].min())
         vals = np.concatenate((da[r][mism[r]], db[r][mism[r]]))
-        assert np.allclose(vals[vals != 0], kth, rtol=1e-6), "a differing entry that is not on the k-th place tie"
+        assert np.allclose(vals[vals != 0], kth, rtol=rtol), "a differing entry that is not on the k-th place tie"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,kw", [("cosine", {}), ("cosine", {"binary": True}), ("jaccard", {}), ("dice", {"shrink": 3}), ("asymmetric_cosine", {"alpha": 0.3}),
+                                     ("tversky", {"alpha": 0.7, "beta": 0.2}), ("dot_product", {}), ("p3alpha", {"alpha": 0.8}), ("rp3beta", {"alpha": 0.8, "beta": 0.4}),
+                                     ("s_plus", {"l1": 0.4, "l2": 0.6, "t1": 0.8, "t2": 0.5, "c1": 0.4, "c2": 0.6, "shrink": 2.0, "shrink_type": "additive"})],
+                         ids=lambda x: x if isinstance(x, str) else "-".join(f"{a}{b}" for a, b in x.items()) or "default")
+def test_csc_matrix1_is_converted_on_the_device(name, kw):
+    """`sim.f(URM.T)` — the documented item-item call: URM.T is a CSC whose arrays are the CSR of matrix2 = matrix1.T.  The
+    reference converts matrix1 with scipy (matrix1.tocsr(), s_plus.pyx:205-206); here m1 is built on the device from m2
+    (SP_FLAG_M1_IS_M2_T) and the norms come from its rows (SP_FLAG_NORMS_ON_DEVICE).  Same result as the call on the
+    host-converted CSR."""
+    urm = sp.random_array((500, 700), density=0.04, format="csr", dtype=np.float32, random_state=np.random.default_rng(33))
+    item = urm.T
+    assert item.format == "csc"
+    call = _host.prepare(item, k=12, l2=1.0, m2_on_device=True, norms_on_device=True, csc_direct=True)
+    assert call.m1_is_m2t and not call.m2_is_m1t and call.m1_data.size == 0 and call.norms_on_device is not None
+    f = getattr(sim, name)
+    a = f(item, k=12, verbose=False, format_output="csr", **kw)
+    b = f(item.tocsr(), k=12, verbose=False, format_output="csr", **kw)
+    _assert_same_topk(a, b, 12, rtol=2e-6, tied=bool(kw.get("binary")))
+    c = f(item, k=12, verbose=False, format_output="coo", **kw)
+    assert abs(c.sum() - a.sum()) <= 1e-5 * abs(a.sum()) and c.nnz >= a.nnz
+
+
+@pytest.mark.gpu
+def test_csc_matrix1_edge_cases():
+    """Selectors, float64 / int64 CSC arrays, stored zeros and unsorted columns (both fall back to the host conversion)."""
+    rng = np.random.default_rng(5)
+    urm = sp.random_array((300, 420), density=0.05, format="csr", dtype=np.float32, random_state=rng)
+    item = urm.T
+    ref = sim.cosine(item.tocsr(), k=9, verbose=False, format_output="csr")
+    # target rows, a row-filter matrix
+    rows = np.array([5, 17, 100, 419], dtype=np.int32)
+    filt = sp.random_array((420, 420), density=0.02, format="csr", dtype=np.float32, random_state=rng)
+    _assert_same_topk(sim.cosine(item, k=9, target_rows=rows, filter_cols=filt, verbose=False, format_output="csr"),
+                      sim.cosine(item.tocsr(), k=9, target_rows=rows, filter_cols=filt, verbose=False, format_output="csr"), 9)
+    # float64 data and int64 index arrays
+    i64 = sp.csc_array((item.data.astype(np.float64), item.indices.astype(np.int64), item.indptr.astype(np.int64)), shape=item.shape)
+    _assert_same_topk(sim.cosine(i64, k=9, verbose=False, format_output="csr"), ref, 9)
+    # stored zeros: found on the device, eliminated on the host, same result as without them
+    z = item.copy()
+    z.data[::7] = 0
+    zc = z.tocsr().copy(); zc.eliminate_zeros()
+    _assert_same_topk(sim.cosine(z, k=9, verbose=False, format_output="csr"), sim.cosine(zc, k=9, verbose=False, format_output="csr"), 9)
+    assert np.count_nonzero(z.data == 0) > 0, "the caller's matrix is not modified"
+    # columns whose row ids do not ascend: the library reports it (SP_EUNSORTED) and the host conversion takes over
+    perm = item.copy()
+    for c in range(perm.shape[1]):
+        b, e = perm.indptr[c], perm.indptr[c + 1]
+        if e - b > 1:
+            perm.indices[b:e] = perm.indices[b:e][::-1].copy()
+            perm.data[b:e] = perm.data[b:e][::-1].copy()
+    call = _host.prepare(perm, k=9, l2=1.0, m2_on_device=True, norms_on_device=True, csc_direct=True)
+    with pytest.raises(_abi.UnsortedRowsError):
+        _host.run_hip(call)
+    _assert_same_topk(sim.cosine(perm, k=9, verbose=False, format_output="csr"), ref, 9)
+    # an empty matrix and a single column
+    e = sim.cosine(sp.csc_array((40, 30), dtype=np.float32), k=5, verbose=False, format_output="csr")
+    assert e.shape == (40, 40) and e.nnz == 0
+    one = sp.csc_array(np.arange(1, 7, dtype=np.float32).reshape(6, 1))
+    _assert_same_topk(sim.dot_product(one, k=3, verbose=False, format_output="csr"), sim.dot_product(one.tocsr(), k=3, verbose=False, format_output="csr"), 3)
 
 
 @pytest.mark.gpu

@@ -174,6 +174,33 @@ def test_trailing_empty_rows_do_not_raise(oracle_backend):
     so.compare_topk(got, so.dense_topk(S, mask, 5), 5, rtol=3e-5)
 
 
+@pytest.mark.parametrize("fn,kw", [("cosine", {}), ("jaccard", {"binary": True}), ("tversky", {"alpha": 0.6, "beta": 0.3}), ("dot_product", {}),
+                                   ("p3alpha", {"alpha": 0.7}), ("rp3beta", {"alpha": 0.7, "beta": 0.5}), ("s_plus", {"l2": 1.0, "shrink": 2.0, "shrink_type": "additive", "c1": 0.3, "c2": 0.7})])
+def test_csc_matrix1_takes_the_direct_route(fn, kw, oracle_backend):
+    """A CSC matrix1 (`URM.T`) is handed over as the CSR of matrix2 (SP_FLAG_M1_IS_M2_T) with the norms left to the callee
+    (SP_FLAG_NORMS_ON_DEVICE); the result is the one of the host-converted CSR call (s_plus.pyx:205-206)."""
+    urm = sp.random_array((40, 55), density=0.15, format="csr", dtype=np.float32, random_state=np.random.default_rng(8))
+    item = urm.T
+    call = _host.prepare(item, k=6, l1=0.5, l2=0.5, m2_on_device=True, norms_on_device=True, csc_direct=True, c1=0.3, additive_shrink=1.0)
+    assert call.m1_is_m2t and not call.m2_is_m1t and call.m1_indptr.size == 0 and call.Xcosine.size == 0
+    assert call.norms_on_device == (float(np.float32(0.3)), 0.5, 1.0)
+    np.testing.assert_array_equal(call.m2_indptr, urm.indptr)
+    # without norms_on_device there is no way to take norms: the host conversion is used
+    assert not _host.prepare(item, k=6, l2=1.0, m2_on_device=True, csc_direct=True).m1_is_m2t
+    assert _host.prepare(item, k=6, m2_on_device=True, csc_direct=True).m1_is_m2t          # (dot product: no norms needed)
+    a = getattr(sim, fn)(item, k=6, verbose=False, format_output="csr", **kw)
+    b = getattr(sim, fn)(item.tocsr(), k=6, verbose=False, format_output="csr", **kw)
+    assert a.shape == b.shape == (55, 55)
+    np.testing.assert_allclose(a.toarray(), b.toarray(), rtol=1e-6, atol=0)
+    # columns with descending row ids: reported by the callee, converted on the host
+    perm = item.copy()
+    for c in range(perm.shape[1]):
+        lo, hi = perm.indptr[c], perm.indptr[c + 1]
+        perm.indices[lo:hi] = perm.indices[lo:hi][::-1].copy()
+        perm.data[lo:hi] = perm.data[lo:hi][::-1].copy()
+    np.testing.assert_allclose(getattr(sim, fn)(perm, k=6, verbose=False, format_output="csr", **kw).toarray(), b.toarray(), rtol=1e-6, atol=0)
+
+
 def test_csr_and_coo_assembly():
     targets = np.array([4, 1, 1], dtype=np.int32)           # unsorted, repeated
     k = 3
