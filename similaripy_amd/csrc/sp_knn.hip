@@ -23,14 +23,17 @@
 #include <string.h>
 #include <stdarg.h>
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
 #include "../../include/sp_knn.h"
 #include "../../include/sp_prep.h"
 #include "sp_common.hpp"
+#include "sp_scan.hpp"
 #include "sp_prep_kernels.hpp"
 #include "sp_rowops.hpp"
 #include "sp_sparse_kernel.hpp"
@@ -694,8 +697,49 @@ int check_csr(const char *what, const int32_t *indptr, const int32_t *indices, i
 }
 
 // host pointers in, host pointers out: the drop-in for s_plus.pyx:359-384
+// SIMILARIPY_AMD_TRACE=1: wall clock of the stages of a host-mode call on stderr (the device is synchronised at every mark)
+struct StageTrace {
+    bool on = false;
+    std::chrono::steady_clock::time_point t0;
+    StageTrace() { const char *e = getenv("SIMILARIPY_AMD_TRACE"); on = e && *e && *e != '0'; t0 = std::chrono::steady_clock::now(); }
+    void mark(const char *what) {
+        if (!on) return;
+        (void)hipDeviceSynchronize();
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[similaripy_hip] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
+// Touches one byte per page of host ranges on helper threads (see run_host).
+struct HostPrefault {
+    std::vector<std::pair<unsigned char *, size_t>> ranges;
+    std::vector<std::thread> threads;
+    void add(void *p, size_t bytes) { if (p && bytes) ranges.push_back({(unsigned char *)p, bytes}); }
+    void start() {
+        const unsigned hw = std::thread::hardware_concurrency();
+        const size_t per_range = std::max<size_t>(1, std::min<size_t>(4, hw ? hw / 2 : 1) );
+        for (auto &r : ranges) {
+            const size_t chunk = ((r.second + per_range - 1) / per_range + 4095) & ~(size_t)4095;
+            for (size_t off = 0; off < r.second; off += chunk) {
+                unsigned char *b = r.first + off;
+                const size_t n = std::min(chunk, r.second - off);
+                try {
+                    threads.emplace_back([b, n]() {
+                        for (size_t i = 0; i < n; i += 4096) ((volatile unsigned char *)b)[i] = 0;
+                        ((volatile unsigned char *)b)[n - 1] = 0;
+                    });
+                } catch (...) { /* no thread: the copy pays for these pages itself */ }
+            }
+        }
+    }
+    void join() { for (auto &t : threads) if (t.joinable()) t.join(); threads.clear(); }
+    ~HostPrefault() { join(); }
+};
+
 int run_host(sp_knn_args *a) {
     HIP_TRY(hipSetDevice(a->device));
+    StageTrace trace;
     const size_t nt = (size_t)a->n_targets, k = (size_t)a->k;
     if (nt == 0) return SP_OK;
     // the reference trusts `targets` (s_plus.pyx:191-196, no bounds check); a device kernel must not
@@ -703,13 +747,8 @@ int run_host(sp_knn_args *a) {
         if (a->targets[i] < 0 || a->targets[i] >= a->n_rows_m1)
             return fail(SP_EINVAL, "targets[%zu]=%d out of range [0,%d)", i, a->targets[i], a->n_rows_m1);
 
-    // ... nor a hand-built CSR: out-of-range indices or a non-monotone indptr would become out-of-bounds device reads and atomics
     const bool m2t = (a->flags & SP_FLAG_M2_IS_M1_T) != 0, m1t = (a->flags & SP_FLAG_M1_IS_M2_T) != 0;
-    if (!m1t) TRY(check_csr("m1", a->m1_indptr, a->m1_indices, a->n_rows_m1, a->nnz_m1, a->n_rows_m2));
-    if (!m2t) TRY(check_csr("m2", a->m2_indptr, a->m2_indices, a->n_rows_m2, a->nnz_m2, a->n_output_cols));
-    if (a->filter_mode == SP_SEL_MATRIX) TRY(check_csr("filter_cols", a->filter_m_indptr, a->filter_m_indices, a->n_rows_m1, a->filter_nnz, a->n_output_cols));
-    if (a->target_col_mode == SP_SEL_MATRIX) TRY(check_csr("target_cols", a->target_col_m_indptr, a->target_col_m_indices, a->n_rows_m1, a->target_col_nnz, a->n_output_cols));
-
+    trace.mark("argument checks (host)");
     DevPool pool;
     pool.device = a->device;
     sp_knn_args d = *a;
@@ -746,33 +785,58 @@ int run_host(sp_knn_args *a) {
     TRY(pool.up(tm ? a->target_col_m_indptr : nullptr, (size_t)a->n_rows_m1 + 1, &d.target_col_m_indptr));
     TRY(pool.up(tm ? a->target_col_m_indices : nullptr, (size_t)a->target_col_nnz, &d.target_col_m_indices));
 
-    if (a->flags & SP_FLAG_CHECK_ZEROS) {
-        // explicit zeros are structural for the kernel (a candidate with value 0, a 1 under `binary`): the reference removes them
-        // first (s_plus.pyx:210-211).  Counted here, where the data already is; the rare matrix that has some goes back to the caller.
-        unsigned long long *cnt = nullptr;
-        TRY(pool.alloc(1, &cnt));
-        HIP_TRY(hipMemset(cnt, 0, sizeof(*cnt)));
-        if (!m1t && a->nnz_m1 > 0) hipLaunchKernelGGL(sp_zero_count_kernel, dim3(1024), dim3(256), 0, nullptr, (long long)a->nnz_m1, d.m1_data, cnt);
-        if (!m2t && a->nnz_m2 > 0)
-            hipLaunchKernelGGL(sp_zero_count_kernel, dim3(1024), dim3(256), 0, nullptr, (long long)a->nnz_m2, d.m2_data, cnt);
+    trace.mark("operands to the device");
+    {
+        // ... nor a hand-built CSR: out-of-range indices or a non-monotone indptr would become out-of-bounds device reads and
+        // atomics.  Checked here, where the arrays already are (one launch per matrix), together with the two content checks:
+        //   SP_FLAG_CHECK_ZEROS  explicit zeros are structural for the kernel (a candidate with value 0, a 1 under `binary`): the
+        //                        reference removes them first (s_plus.pyx:210-211); the rare matrix that has some goes back to the caller
+        //   SP_FLAG_M1_IS_M2_T   the column windows of the row kernels need ascending column ids inside each m2 row (sp_knn.h)
+        struct Mat { const char *what; const int32_t *indptr, *indices; int n_rows; int64_t nnz; int n_cols; };
+        const Mat mats[4] = {
+            {"m1", m1t ? nullptr : d.m1_indptr, d.m1_indices, a->n_rows_m1, a->nnz_m1, a->n_rows_m2},
+            {"m2", m2t ? nullptr : d.m2_indptr, d.m2_indices, a->n_rows_m2, a->nnz_m2, a->n_output_cols},
+            {"filter_cols", fm ? d.filter_m_indptr : nullptr, d.filter_m_indices, a->n_rows_m1, a->filter_nnz, a->n_output_cols},
+            {"target_cols", tm ? d.target_col_m_indptr : nullptr, d.target_col_m_indices, a->n_rows_m1, a->target_col_nnz, a->n_output_cols}};
+        int32_t h[20];
+        for (int i = 0; i < 4; ++i) { h[4 * i] = 0; h[4 * i + 1] = 0x7FFFFFFF; h[4 * i + 2] = 0; h[4 * i + 3] = -1; }
+        h[16] = h[17] = h[18] = h[19] = 0;       // [16..17] zero count (64 bit), [18] rows with descending ids
+        const int32_t *st_c = nullptr;
+        TRY(pool.up(h, 20, &st_c));
+        int32_t *st = const_cast<int32_t *>(st_c);
+        for (int i = 0; i < 4; ++i) {
+            if (!mats[i].indptr) continue;
+            const long long work = std::max<long long>(mats[i].nnz, mats[i].n_rows);
+            hipLaunchKernelGGL(sp_check_csr_kernel, dim3((unsigned)std::max<long long>(1, std::min<long long>(256 * 16, (work + 255) / 256))), dim3(256), 0, nullptr,
+                               mats[i].n_rows, (long long)mats[i].nnz, mats[i].indptr, mats[i].indices, st + 4 * i);
+        }
+        if (a->flags & SP_FLAG_CHECK_ZEROS) {
+            if (!m1t && a->nnz_m1 > 0) hipLaunchKernelGGL(sp_zero_count_kernel, dim3(1024), dim3(256), 0, nullptr, (long long)a->nnz_m1, d.m1_data, (unsigned long long *)(st + 16));
+            if (!m2t && a->nnz_m2 > 0) hipLaunchKernelGGL(sp_zero_count_kernel, dim3(1024), dim3(256), 0, nullptr, (long long)a->nnz_m2, d.m2_data, (unsigned long long *)(st + 16));
+        }
         HIP_TRY(hipGetLastError());
-        unsigned long long h = 0;
-        HIP_TRY(hipMemcpy(&h, cnt, sizeof(h), hipMemcpyDeviceToHost));
-        a->explicit_zeros = (int64_t)h;
-        if (h) return fail(SP_EZEROS, "%llu stored entries are zero: eliminate them first (s_plus.pyx:210-211)", h);
-    }
-
-    if (m1t && a->nnz_m2 > 1) {
-        // the column windows of the row kernels need ascending column ids inside each m2 row (sp_knn.h); a CSC that came
-        // from a canonical CSR has them, anything else goes back to the caller
-        unsigned int *bad = nullptr;
-        TRY(pool.alloc(1, &bad));
-        HIP_TRY(hipMemset(bad, 0, sizeof(*bad)));
-        hipLaunchKernelGGL(sp_rows_sorted_kernel, dim3(std::max(1, std::min(256 * 16, (a->n_rows_m2 + 3) / 4))), dim3(256), 0, nullptr, a->n_rows_m2, d.m2_indptr, d.m2_indices, bad);
-        HIP_TRY(hipGetLastError());
-        unsigned int h = 0;
-        HIP_TRY(hipMemcpy(&h, bad, sizeof(h), hipMemcpyDeviceToHost));
-        if (h) return fail(SP_EUNSORTED, "SP_FLAG_M1_IS_M2_T: %u rows of m2 do not have ascending column ids", h);
+        HIP_TRY(hipMemcpy(h, st, sizeof(h), hipMemcpyDeviceToHost));
+        for (int i = 0; i < 4; ++i) {
+            if (!mats[i].indptr) continue;
+            const int32_t *e = h + 4 * i;
+            if (e[0] & 1) return fail(SP_EINVAL, "%s: indptr[0] is not 0", mats[i].what);
+            if (e[0] & 2) return fail(SP_EINVAL, "%s: indptr decreases at row %d", mats[i].what, e[1]);
+            if (e[0] & 4) return fail(SP_EINVAL, "%s: indptr[%d] differs from nnz = %lld", mats[i].what, mats[i].n_rows, (long long)mats[i].nnz);
+            if (e[2] < 0 || e[3] >= mats[i].n_cols) return fail(SP_EINVAL, "%s: column index out of range [0,%d) (min %d, max %d)", mats[i].what, mats[i].n_cols, e[2], e[3]);
+        }
+        if (m1t && a->nnz_m2 > 1) {
+            // (only now: this kernel walks the rows of m2, whose row pointers have just been validated)
+            hipLaunchKernelGGL(sp_rows_sorted_kernel, dim3(std::max(1, std::min(256 * 16, (a->n_rows_m2 + 3) / 4))), dim3(256), 0, nullptr, a->n_rows_m2, d.m2_indptr, d.m2_indices, (unsigned int *)(st + 18));
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpy(h + 18, st + 18, sizeof(int32_t), hipMemcpyDeviceToHost));
+        }
+        unsigned long long zeros = 0;
+        memcpy(&zeros, h + 16, sizeof(zeros));
+        if (a->flags & SP_FLAG_CHECK_ZEROS) {
+            a->explicit_zeros = (int64_t)zeros;
+            if (zeros) return fail(SP_EZEROS, "%llu stored entries are zero: eliminate them first (s_plus.pyx:210-211)", zeros);
+        }
+        if (h[18]) return fail(SP_EUNSORTED, "SP_FLAG_M1_IS_M2_T: %d rows of m2 do not have ascending column ids", h[18]);
     }
 
     const bool csr_out = (a->flags & SP_FLAG_CSR_OUT) != 0;
@@ -800,8 +864,21 @@ int run_host(sp_knn_args *a) {
         d.workspace_bytes = need;
     }
 
+    trace.mark("checks, output buffers");
+    // While the device works the host is idle: helper threads touch the pages of the caller's (typically fresh, never touched)
+    // output arrays so that the copies back do not pay for the page faults.  Output-only memory: writing zeros is harmless.
+    HostPrefault prefault;
+    if (nt * k >= (size_t)1 << 22) {
+        if (want_rows && a->rows) prefault.add(a->rows, nt * k * sizeof(int32_t));
+        prefault.add(a->cols, nt * k * sizeof(int32_t));
+        prefault.add(a->values, nt * k * sizeof(float));
+        prefault.start();
+    }
     int rc = run_device(&d);
     if (rc) return rc;
+    trace.mark("transpose, norms, row kernels");
+    prefault.join();
+    trace.mark("output pages touched (host)");
     if (csr_out) {
         // counting sort of the slots by row (coo_to_csr.h:28-71) with the zeros left out (s_plus.pyx:424): targets ascend, so
         // the slots already are in row order — per-slot non-zero counts, a scan, one compaction pass, and only the CSR travels
@@ -812,11 +889,13 @@ int run_host(sp_knn_args *a) {
         TRY(pool.alloc((size_t)n_rows + 1, &indptr));
         TRY(pool.alloc(nt * k, &o_idx));
         TRY(pool.alloc(nt * k, &o_val));
+        long long *scan_part = nullptr;
         TRY(pool.alloc(1, &total));
+        TRY(pool.alloc((size_t)SCAN_CHUNKS, &scan_part));
         HIP_TRY(hipMemsetAsync(indptr, 0, ((size_t)n_rows + 1) * 4, nullptr));
         const int wb = (int)std::max<size_t>(1, std::min<size_t>(256 * 16, (nt + 3) / 4));
         hipLaunchKernelGGL(sp_slot_nnz_kernel, dim3(wb), dim3(256), 0, nullptr, (int)nt, (int)k, d.targets, d.out_counts, d.values, indptr);
-        hipLaunchKernelGGL(sp_inclusive_scan_kernel, dim3(1), dim3(1024), 0, nullptr, n_rows + 1, indptr, total);
+        scan_i32<true>((long long)n_rows + 1, indptr, indptr, nullptr, total, scan_part, nullptr);      // (indptr[0] = 0: in place it becomes the row pointers)
         hipLaunchKernelGGL(sp_csr_compact_kernel, dim3(wb), dim3(256), 0, nullptr, (int)nt, (int)k, d.targets, d.out_counts, d.cols, d.values, indptr, o_idx, o_val);
         HIP_TRY(hipGetLastError());
         long long nnz = 0;
@@ -835,6 +914,7 @@ int run_host(sp_knn_args *a) {
         HIP_TRY(hipMemcpy(a->values, d.values, nt * k * sizeof(float), hipMemcpyDeviceToHost));
         if (a->out_counts) HIP_TRY(hipMemcpy(a->out_counts, d.out_counts, nt * sizeof(int32_t), hipMemcpyDeviceToHost));
     }
+    trace.mark("assembly, result to the host");
     a->kernel_ms = d.kernel_ms;
     a->passes_total = d.passes_total;
     a->num_wgs_used = d.num_wgs_used;

@@ -47,6 +47,32 @@ __global__ __launch_bounds__(256) void sp_zero_count_kernel(long long nnz, const
     if ((threadIdx.x & 63) == 0 && n) atomicAdd(counter, (unsigned long long)n);
 }
 
+// Structure check of an uploaded CSR (what scipy's check_format does on the host): st[0] |= 1 indptr[0] != 0, |= 2 indptr decreases
+// (st[1] = first such row), |= 4 indptr[n_rows] != nnz; st[2] / st[3] = min / max column id.  st comes in as {0, INT_MAX, 0, -1}.
+// Reads indptr[0..n_rows] and indices[0..nnz) only, whatever they hold.
+__global__ __launch_bounds__(256) void sp_check_csr_kernel(int n_rows, long long nnz, const int *__restrict__ indptr, const int *__restrict__ indices, int *__restrict__ st) {
+    const long long t0 = blockIdx.x * (long long)blockDim.x + threadIdx.x, nthr = (long long)gridDim.x * blockDim.x;
+    int flags = 0, bad_row = 0x7FFFFFFF;
+    if (t0 == 0 && n_rows > 0) flags |= (indptr[0] != 0 ? 1 : 0) | ((long long)indptr[n_rows] != nnz ? 4 : 0);
+    for (long long r = t0; r < n_rows; r += nthr)
+        if (indptr[r + 1] < indptr[r]) { flags |= 2; bad_row = min(bad_row, (int)r); }
+    int lo = 0, hi = -1;
+    for (long long i = t0; i < nnz; i += nthr) { const int c = indices[i]; lo = min(lo, c); hi = max(hi, c); }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        flags |= __shfl_xor(flags, d, 64);
+        bad_row = min(bad_row, __shfl_xor(bad_row, d, 64));
+        lo = min(lo, __shfl_xor(lo, d, 64));
+        hi = max(hi, __shfl_xor(hi, d, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (flags) atomicOr(&st[0], flags);
+        if (flags & 2) atomicMin(&st[1], bad_row);
+        if (lo < 0) atomicMin(&st[2], lo);
+        if (hi >= 0) atomicMax(&st[3], hi);
+    }
+}
+
 // number of rows whose column ids descend somewhere (one wave per row)
 __global__ __launch_bounds__(256) void sp_rows_sorted_kernel(int n_rows, const int *__restrict__ indptr, const int *__restrict__ indices, unsigned int *__restrict__ bad_rows) {
     const int lane = threadIdx.x & 63;
@@ -228,27 +254,6 @@ __global__ __launch_bounds__(256) void sp_slot_nnz_kernel(int n_targets, int k, 
         c = ro_wave_sum(c);
         if (lane == 0) row_nnz_shifted[targets[s] + 1] = c;
     }
-}
-
-// in-place inclusive scan of a[0..n) by one workgroup (a[0] = 0 on entry: a becomes the row pointer array)
-__global__ __launch_bounds__(1024) void sp_inclusive_scan_kernel(int n, int *__restrict__ a, long long *__restrict__ total) {
-    __shared__ long long part[1024];
-    const int tid = threadIdx.x;
-    const int per = (n + 1023) / 1024;
-    const int b = min(n, tid * per), e = min(n, b + per);
-    long long s = 0;
-    for (int i = b; i < e; ++i) s += a[i];
-    part[tid] = s;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        const long long v = (tid >= d) ? part[tid - d] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    long long run = part[tid] - s;
-    for (int i = b; i < e; ++i) { run += a[i]; a[i] = (int)run; }
-    if (tid == 1023) total[0] = part[1023];
 }
 
 // non-zero entries of slot i, in slot order, to [indptr[targets[i]], ...)

@@ -25,31 +25,6 @@ __global__ __launch_bounds__(256) void sp_tr_count_kernel(long long nnz, const i
         atomicAdd(&cnt[indices[i]], 1);
 }
 
-// one workgroup: out[i] = sum of cnt[0..i), out[n] = total; cursor = a second copy of out[0..n)
-__global__ __launch_bounds__(1024) void sp_tr_scan_kernel(int n, const int *__restrict__ cnt, int *__restrict__ out, int *__restrict__ cursor) {
-    __shared__ long long part[1024];
-    const int tid = threadIdx.x;
-    const int per = (n + 1023) / 1024;
-    const int b = min(n, tid * per), e = min(n, b + per);
-    long long s = 0;
-    for (int i = b; i < e; ++i) s += cnt[i];
-    part[tid] = s;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {        // Hillis-Steele over the 1024 partial sums
-        const long long v = (tid >= d) ? part[tid - d] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    long long run = part[tid] - s;
-    for (int i = b; i < e; ++i) {
-        out[i] = (int)run;
-        cursor[i] = (int)run;
-        run += cnt[i];
-    }
-    if (tid == 1023) out[n] = (int)part[1023];
-}
-
 // one wave per input row
 __global__ __launch_bounds__(256) void sp_tr_scatter_kernel(int n_rows, const float *__restrict__ data, const int *__restrict__ indices,
                                                              const int *__restrict__ indptr, int *__restrict__ cursor, tr_u64 *__restrict__ rec) {
@@ -271,9 +246,9 @@ __global__ __launch_bounds__(256) void sp_row_sqsums_long_kernel(int n_rows, con
 
 constexpr int TR_SHORT = 1024, TR_MEDIUM = 16384;
 
-// bytes of scratch the transpose needs: counters/cursors (n_cols+1 ints each) and the 64-bit records
+// bytes of scratch the transpose needs: counters/cursors (n_cols+1 ints each), the 64-bit records, the scan's chunk sums
 size_t transpose_ws_bytes(long long nnz, int n_cols) {
-    return (((size_t)n_cols + 1) * 4 * 2 + 255 & ~(size_t)255) + (((size_t)nnz * 8 + 255) & ~(size_t)255);
+    return (((size_t)n_cols + 1) * 4 * 2 + 255 & ~(size_t)255) + (((size_t)nnz * 8 + 255) & ~(size_t)255) + SCAN_SCRATCH_BYTES;
 }
 
 // all pointers on the device; asynchronous on `stream`
@@ -288,7 +263,8 @@ int transpose_device(int n_rows, int n_cols, long long nnz, const float *data, c
         const int blocks = (int)std::min<long long>(256 * 16, (nnz + 255) / 256);
         hipLaunchKernelGGL(sp_tr_count_kernel, dim3(blocks), dim3(256), 0, stream, nnz, indices, cnt);
     }
-    hipLaunchKernelGGL(sp_tr_scan_kernel, dim3(1), dim3(1024), 0, stream, n_cols, cnt, out_indptr, cursor);
+    // out_indptr[i] = entries before output row i (out_indptr[n_cols] = nnz); cursor = a second copy the scatter advances
+    scan_i32<false>(n_cols, cnt, out_indptr, cursor, nullptr, (unsigned char *)rec + (((size_t)nnz * 8 + 255) & ~(size_t)255), stream);
     if (nnz > 0 && n_rows > 0) {
         const int blocks = (int)std::min<long long>(256 * 32, ((long long)n_rows + 3) / 4);
         hipLaunchKernelGGL(sp_tr_scatter_kernel, dim3(blocks), dim3(256), 0, stream, n_rows, data, indices, indptr, cursor, rec);
