@@ -29,6 +29,13 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
     u64 *ph = (u64 *)(sh + 32);                 // [16] phase timers / event counters (lane 0 only)
     u64 *U = U_LDS ? (u64 *)(ph + 16) : (p.gU_g + (size_t)blockIdx.x * (size_t)p.cap);
 
+    // Two formats of the tile.  Hashed windows: T slots of {column id, partial sum} (EMPTY64 when free).  Dense windows
+    // (direct-indexed, every column owns its slot): 2*T 32-bit partial sums, EMPTY32 (a NaN pattern no sum of finite
+    // products has) marking a column nobody touched — twice the columns per window, half the windows per row, and the
+    // 32-bit LDS compare-and-swap is the faster one.  The tile is refilled only when consecutive windows differ in format.
+    unsigned *tabw = (unsigned *)smem;          // [2*T] the same bytes as 32-bit sums
+    constexpr unsigned EMPTY32 = 0xFFFFFFFFu;
+    bool tab32 = false;
     for (int i = tid; i < T; i += NT) tab[i] = EMPTY64;
     if (tid < 32) sh[tid] = 0;
     if (tid < 16) ph[tid] = 0;
@@ -197,13 +204,14 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
 
             // dense windows can never overflow (one slot per column); hash windows are sized from the
             // MACs bound and split on overflow.  Window width w; windows are [lo, lo+w).
+            const long long Td = 2LL * T;       // columns of a dense window (32-bit sums)
             long long width;
-            if (p.n_cols <= T) {
+            if (p.n_cols <= Td) {
                 width = p.n_cols;
             } else {
-                const long long p_dense = ((long long)p.n_cols + T - 1) / T;
+                const long long p_dense = ((long long)p.n_cols + Td - 1) / Td;
                 const long long p_hash = (long long)((macs + (u64)p.hash_fill - 1) / (u64)p.hash_fill);
-                if (p_hash < 1 || p_dense <= p_hash) width = T;
+                if (p_hash < 1 || p_dense <= p_hash) width = Td;
                 else width = ((long long)p.n_cols + p_hash - 1) / p_hash;
             }
 
@@ -212,8 +220,14 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                 long long hi = lo + width;
                 if (hi > p.n_cols) hi = p.n_cols;
                 const int wlo = (int)lo, whi = (int)hi;
-                const bool dense = (hi - lo) <= (long long)T;
+                const bool dense = (hi - lo) <= Td;
                 const bool whole = (wlo == 0 && whi == p.n_cols);
+                if (dense != tab32) {           // (uniform; the previous drain ended with a barrier)
+                    if (dense) { for (int i = tid; i < 2 * T; i += NT) tabw[i] = EMPTY32; }
+                    else       { for (int i = tid; i < T; i += NT) tab[i] = EMPTY64; }
+                    tab32 = dense;
+                    __syncthreads();
+                }
                 int t_eff = dense ? (whi - wlo) : T;
                 int hshift = 32 - p.logT;
                 if (!dense && whole) {
@@ -262,23 +276,22 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                             for (int j = 0; j < ACC_UNROLL; ++j) sink += x[j] + (float)c[j];
                             if (sink == 123.456f) sh[SH_OVF] = 2;  // keeps the loads alive, never true in practice
                         } else if (dense) {
-                            // direct-indexed window: every column owns its slot.  Optimistic update: read the
-                            // slot, then ONE 64-bit compare-and-swap writes {column, sum + x} (ds_cmpst_rtn_b64:
-                            // 3.3 lanes/clk against 0.33 for ds_add_f32); the lanes of a wave instruction hold 64
-                            // distinct columns of one m2 row, so only another wave can interfere — a lost race
-                            // falls back to the hardware float add on the sum half (the key half is already set
-                            // by whoever won), which cannot livelock on hot columns.
-                            u64 cur[ACC_UNROLL], prev[ACC_UNROLL];
+                            // direct-indexed window: every column owns its 32-bit sum.  Optimistic update: read the
+                            // slot, then ONE compare-and-swap writes sum + x (ds_cmpst_rtn_b32: 3-6 lanes/clk against
+                            // 0.33 for ds_add_f32); the lanes of a wave instruction hold 64 distinct columns of one
+                            // m2 row, so only another wave can interfere — a lost race falls back to the hardware
+                            // float add (whoever won left a real sum there), which cannot livelock on hot columns.
+                            unsigned cur[ACC_UNROLL], prev[ACC_UNROLL];
 #pragma unroll
-                            for (int j = 0; j < ACC_UNROLL; ++j) cur[j] = tab[c[j] - wlo];
+                            for (int j = 0; j < ACC_UNROLL; ++j) cur[j] = tabw[c[j] - wlo];
 #pragma unroll
                             for (int j = 0; j < ACC_UNROLL; ++j) {
-                                const float sum = __uint_as_float((unsigned)cur[j]) + x[j];
-                                prev[j] = atomicCAS(&tab[c[j] - wlo], cur[j], ((u64)(unsigned)c[j] << 32) | (u64)__float_as_uint(sum));
+                                const float sum = (cur[j] == EMPTY32 ? 0.f : __uint_as_float(cur[j])) + x[j];
+                                prev[j] = atomicCAS(&tabw[c[j] - wlo], cur[j], __float_as_uint(sum));
                             }
 #pragma unroll
                             for (int j = 0; j < ACC_UNROLL; ++j)
-                                if (prev[j] != cur[j]) atomicAdd((float *)&tab[c[j] - wlo], x[j]);
+                                if (prev[j] != cur[j]) atomicAdd((float *)&tabw[c[j] - wlo], x[j]);
                         } else {
                             // Hashed window.  One 64-bit compare-and-swap claims a free slot for a new column AND
                             // deposits its first product; finding the same column already there turns into a
@@ -347,6 +360,10 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                 // ================= drain: one barrier-free sweep, overflow-retry =================
                 for (;;) {
                     for (int base = 0; base < t_eff; base += NT * DRAIN_UNROLL) {
+                        // the candidate buffer is full: whatever is judged now cannot be stored, and it would be judged
+                        // without the k-th value the selection is about to give — stop, select, sweep again (the
+                        // slots already consumed are empty and cost a read)
+                        if (sh[SH_RETRY]) break;         // (one LDS word, the same for every lane: wave-uniform)
                         int c[DRAIN_UNROLL];
                         float xy[DRAIN_UNROLL];
                         unsigned occ = 0;
@@ -356,16 +373,24 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                             c[j] = EMPTY;
                             xy[j] = 0.f;
                             if (sidx < t_eff) {
-                                const u64 slot = tab[sidx];
-                                c[j] = (int)(slot >> 32);
-                                xy[j] = __uint_as_float((unsigned)slot);
+                                if (dense) {
+                                    const unsigned w = tabw[sidx];
+                                    if (w != EMPTY32) { c[j] = wlo + sidx; xy[j] = __uint_as_float(w); }
+                                } else {
+                                    const u64 slot = tab[sidx];
+                                    c[j] = (int)(slot >> 32);
+                                    xy[j] = __uint_as_float((unsigned)slot);
+                                }
                             }
                             if (c[j] != EMPTY) occ |= 1u << j;
                         }
-                        const unsigned done = emit_candidates<DRAIN_UNROLL>(p, rc, c, xy, occ, U, sh, p.cap);
+                        const unsigned done = (p.dbg & 32) ? occ : emit_candidates<DRAIN_UNROLL>(p, rc, c, xy, occ, U, sh, p.cap);   // (ablation: scan and clear only)
 #pragma unroll
                         for (int j = 0; j < DRAIN_UNROLL; ++j)
-                            if (done & (1u << j)) tab[base + j * NT + tid] = EMPTY64;
+                            if (done & (1u << j)) {
+                                if (dense) tabw[base + j * NT + tid] = EMPTY32;
+                                else tab[base + j * NT + tid] = EMPTY64;
+                            }
                     }
                     __syncthreads();  // sweep complete (also orders the slot clears before the next window)
                     const int retry = sh[SH_RETRY];
@@ -377,6 +402,7 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                     }
                     __syncthreads();
                     PHASE_END(PH_DRAIN);
+                    if (timing) ph[8] += 1;          // event count: sweeps repeated after a full candidate buffer
                     took_threshold(compact_topk<NT>(U, hist, sh, p.k));
                     PHASE_END(PH_SELECT);
                 }
