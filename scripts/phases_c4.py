@@ -21,6 +21,6 @@ for tun in [{}] + sweeps:
     i0 = prob.run(cols, vals, counts, time_kernel=True, phase_timers=False, **tun)
     info = prob.run(cols, vals, counts, time_kernel=True, **tun)
     ph = info["phase_cycles"]
-    tot = sum(ph[:8])
+    tot = sum(ph[:6])
     print(f"k={k} {tun}: kernel {i0['kernel_ms']:.2f} ms (with phase timers {info['kernel_ms']:.2f}), workgroups {info['num_wgs']}, windows {ph[11]}, repeated sweeps {ph[8]}, passes {info['passes_total']}")
     print("   " + "  ".join(f"{n} {100.0 * c / tot:.1f}%" for n, c in zip(names[:8], ph[:8]) if c))
