@@ -316,9 +316,33 @@ __device__ __forceinline__ void wave_push(unsigned mask, int *counter, int capac
 // reservation per wave.  Must be called from wave-uniform control flow.
 // Returns the candidates that are finished (rejected or stored).  A survivor that finds U full is not in
 // the returned mask and SH_RETRY is raised: the caller keeps it and re-offers it after a selection.
+// `simple` (wave-uniform): the value depends on the column through the raw dot only — no Tversky term, no column selector,
+// the column term folded into m2 or absent (cosine, asymmetric cosine, p3alpha, rp3beta, dot product of the plain calls).  Then
+// the row's inverted bound xy_cut is the whole pre-test (one compare per slot) and only survivors see the epilogue.
 template <int N>
 __device__ __forceinline__ unsigned emit_candidates(const KParams &p, const RowCtx &rc, const int (&c)[N], const float (&xy)[N],
-                                                    unsigned occ, u64 *U, int *sh, int cap) {
+                                                    unsigned occ, u64 *U, int *sh, int cap, bool simple = false) {
+    if (simple) {
+        unsigned live = 0;
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+            if ((occ & (1u << j)) && !(xy[j] <= rc.xy_cut)) live |= 1u << j;      // (a NaN dot stays live; the exact test drops it)
+        if (!__ballot(live != 0)) return occ;
+        unsigned want = 0;
+        unsigned key[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const float val = rc.epi(xy[j], 0.f, 1.f, 1.f);
+            key[j] = fkey(val);
+            if ((live & (1u << j)) && (val >= p.threshold) && (!rc.have_thr || key[j] > rc.thr_key)) want |= 1u << j;
+        }
+        unsigned stored = 0;
+        wave_push<N>(want, &sh[SH_CNT], cap, &sh[SH_RETRY], [&](int j, int pos) {
+            U[pos] = ((u64)key[j] << 32) | (u64)(unsigned)c[j];
+            stored |= 1u << j;
+        });
+        return occ & (~want | stored);
+    }
     unsigned live = 0;
 #pragma unroll
     for (int j = 0; j < N; ++j)
@@ -368,12 +392,13 @@ __device__ __forceinline__ unsigned emit_candidates(const KParams &p, const RowC
     unsigned key[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-        const float val = rc.epi(xy[j], ytv[j], ycos[j], ydep[j]);
+        const float val = (p.dbg & 128) ? xy[j] : rc.epi(xy[j], ytv[j], ycos[j], ydep[j]);      // (ablation: no epilogue)
         key[j] = fkey(val);
         if ((live & (1u << j)) && (val >= p.threshold) && (!rc.have_thr || key[j] > rc.thr_key)) want |= 1u << j;
     }
     // one aggregated reservation per wave
     unsigned stored = 0;
+    if (p.dbg & 64) return occ;                                                                    // (ablation: survivors are dropped, no reservation)
     wave_push<N>(want, &sh[SH_CNT], cap, &sh[SH_RETRY], [&](int j, int pos) {
         U[pos] = ((u64)key[j] << 32) | (u64)(unsigned)c[j];
         stored |= 1u << j;

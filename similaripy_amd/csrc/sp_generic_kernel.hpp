@@ -42,6 +42,9 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
     __syncthreads();
 
     const bool any_norm = (p.l1 != 0.f || p.l2 != 0.f || p.l3 != 0.f || p.stab != 0.f || p.bayes != 0.f);
+    // the candidate's value is a function of its raw dot and of row constants only (see emit_candidates)
+    const bool simple_judge = p.filter_mode != SP_SEL_MATRIX && p.target_mode != SP_SEL_MATRIX && p.l1 == 0.f && !(p.dbg & 256) &&
+                              (p.fold || (p.l2 == 0.f && p.l3 == 0.f));
     float ymin_tv = 0.f, ymin_cos = 0.f, ymin_dep = 0.f;
     if (p.bound_ok) {
         if (p.fold) { ymin_cos = 1.f; ymin_dep = 1.f; }     // folded column term: exactly 1 for every column
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                             }
                             if (c[j] != EMPTY) occ |= 1u << j;
                         }
-                        const unsigned done = (p.dbg & 32) ? occ : emit_candidates<DRAIN_UNROLL>(p, rc, c, xy, occ, U, sh, p.cap);   // (ablation: scan and clear only)
+                        const unsigned done = (p.dbg & 32) ? occ : emit_candidates<DRAIN_UNROLL>(p, rc, c, xy, occ, U, sh, p.cap, simple_judge);   // (ablation: scan and clear only)
 #pragma unroll
                         for (int j = 0; j < DRAIN_UNROLL; ++j)
                             if (done & (1u << j)) {
