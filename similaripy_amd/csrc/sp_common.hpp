@@ -67,6 +67,8 @@ struct KParams {
     const int *neg_flag;   // Bayesian shrink / Tversky with t1+t2 < 1 only: *neg_flag != 0 iff m1 or m2 holds a negative value (see RowCtx::set_cut)
     int sparse_path;       // 1 = rows with few expected collisions take the bitmap path
     int fold;              // 1 = the single active column term (Ycos or Ydep) is already divided into m2_data: treat it as 1
+    const int *splits;     // generic kernel, optional: [n_rows_m2][n_splits] position of the first entry of m2 row u with column >= (j+1)*2T
+    int n_splits;          //   (the boundaries of the standard dense windows, found once per call instead of once per use)
     unsigned long long *phase_cycles;  // optional [PH_N]
     int dbg;               // ablation bits for profiling only (results are WRONG when non-zero; 8 / 16: sweep 1 / sweep 2 of the sparse kernel
                            // load but do not process — compiled in only with -DSP_ABLATION=1: the test costs the sweeps 1 %):

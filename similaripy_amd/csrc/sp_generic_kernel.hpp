@@ -246,13 +246,20 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                 // Window slices chain (hi of window w == lo of window w+1), so when the m1 row fits one
                 // batch the previous slice end is kept in LDS and only one lower_bound per window is run.
                 const bool carry = (n1 <= NT);
+                const bool use_splits = p.splits != nullptr && width == Td && (lo % Td) == 0;     // a standard window (a hashed row halved down to Td may sit elsewhere)
                 for (int b0 = 0; b0 < n1; b0 += NT) {
                     const int nb = min(NT, n1 - b0);
                     int len = 0;
                     if (tid < nb) {
                         const int u = p.m1_indices[s1 + b0 + tid];
                         int r0 = p.m2_indptr[u], r1 = p.m2_indptr[u + 1];
-                        if (!whole) {
+                        if (!whole && use_splits) {
+                            // standard dense window number wlo / Td: its boundaries were found once per call (sp_m2_splits_kernel)
+                            const int *sp = p.splits + (size_t)u * (size_t)p.n_splits;
+                            const int jw = wlo / (int)Td;
+                            if (wlo != 0) r0 = sp[jw - 1];
+                            if (whi < p.n_cols) r1 = sp[jw];
+                        } else if (!whole) {
                             // slice of the sorted m2 row inside [wlo, whi)  (s_plus.h:385-394)
                             if (wlo != 0) {
                                 if (carry) r0 = retry_window ? seg_lo[tid] : seg_hi[tid];

@@ -101,6 +101,8 @@ struct Config {
     size_t ws_desc_offset;  // of the sparse queue inside that block (the generic queue follows it)
     int nb_log2;            // sparse kernel: bitmap bits (log2)
     size_t ws_total;
+    int n_splits;           // generic kernel: precomputed dense-window boundaries per m2 row (0 = none)
+    size_t ws_split_bytes;
     bool fold;
     bool mono;              // the sparse kernel's monotone variant applies (val = xy / den or the raw dot, no per-row target selector)
     bool ordered;
@@ -189,7 +191,14 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
     int nb = 10;
     while (nb < c->logT_s + 6 && (1LL << nb) < (long long)a->n_output_cols) ++nb;
     c->nb_log2 = nb;
-    c->ws_total = WS_QUEUE_BYTES + c->ws_gu_bytes + c->ws_fold_bytes + c->ws_rows_bytes;
+    // generic kernel, standard dense windows of 2T columns: their boundaries inside every m2 row, found once per call
+    {
+        const long long Td = 2LL * T;
+        const long long nsp = (long long)a->n_output_cols > Td ? ((long long)a->n_output_cols + Td - 1) / Td - 1 : 0;
+        c->n_splits = (nsp >= 1 && nsp <= 15 && a->n_rows_m2 > 0 && a->nnz_m2 > 0) ? (int)nsp : 0;
+        c->ws_split_bytes = c->n_splits ? (((size_t)a->n_rows_m2 * (size_t)c->n_splits * 4 + 255) & ~(size_t)255) : 0;
+    }
+    c->ws_total = WS_QUEUE_BYTES + c->ws_gu_bytes + c->ws_fold_bytes + c->ws_rows_bytes + c->ws_split_bytes;
     return SP_OK;
 }
 
@@ -321,6 +330,7 @@ int run_device_impl(sp_knn_args *a) {
     unsigned char *ws_gu = ws + WS_QUEUE_BYTES;
     unsigned char *ws_fold = ws_gu + c.ws_gu_bytes;
     unsigned char *ws_rows = ws_fold + c.ws_fold_bytes;
+    int *ws_split = (int *)(ws_rows + c.ws_rows_bytes);
 
     // minima of the column-term vectors feed the gather-free upper bound (Epi::upper); it is sound only
     // when every weight / shrink is non-negative (NaN parameters fail the comparisons and disable it)
@@ -416,6 +426,16 @@ int run_device_impl(sp_knn_args *a) {
     kp.neg_flag = sign_matters ? neg_flag : nullptr;
     kp.fold = c.fold ? 1 : 0;
     if (c.fold) kp.m2_data = folded;
+    kp.splits = nullptr;
+    kp.n_splits = 0;
+    if (c.n_splits) {
+        const long long n = (long long)a->n_rows_m2 * c.n_splits;
+        hipLaunchKernelGGL(sp_m2_splits_kernel, dim3((unsigned)std::min<long long>(256 * 16, (n + 255) / 256)), dim3(256), 0, stream, a->n_rows_m2, a->m2_indptr,
+                           a->m2_indices, 2 * c.T, c.n_splits, ws_split);
+        HIP_TRY(hipGetLastError());
+        kp.splits = ws_split;
+        kp.n_splits = c.n_splits;
+    }
     kp.phase_cycles = (timed && (a->flags & SP_FLAG_PHASE_TIMERS)) ? (unsigned long long *)(ws + WS_PHASE_OFFSET) : nullptr;   // inside the zeroed header
     kp.dbg = (int)a->reserved[0];
 

@@ -190,4 +190,16 @@ __global__ __launch_bounds__(256) void sp_fold_colterm_kernel(long long nnz, con
     }
 }
 
+// Boundaries of the generic kernel's standard dense windows [j*width, (j+1)*width) inside every (sorted) m2 row:
+// out[u*n_splits + j] = first position of row u whose column id is >= (j+1)*width  (s_plus.h:385-394 does this lower_bound
+// per target row and block; the boundaries do not depend on the target row)
+__global__ __launch_bounds__(256) void sp_m2_splits_kernel(int n_rows, const int *__restrict__ indptr, const int *__restrict__ indices, int width, int n_splits,
+                                                            int *__restrict__ out) {
+    const long long n = (long long)n_rows * n_splits;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int u = (int)(i / n_splits), j = (int)(i % n_splits);
+        out[i] = lower_bound_g(indices, indptr[u], indptr[u + 1], (j + 1) * width);
+    }
+}
+
 }  // namespace
