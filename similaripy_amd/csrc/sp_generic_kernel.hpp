@@ -196,6 +196,20 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                 rc.set_cut(p.threshold);
             }
         };
+        // Selection on the candidate buffer.  Small LDS buffers (what every k up to ~800 gets) take the register-resident
+        // radix selection of the sparse kernel: its four histograms live in seg_pre / seg_v1, which are dead from the end of the
+        // accumulate to the next window's segment scan.  exact = false: a conservative cutoff after two digits is enough mid-row.
+        auto select_now = [&](bool exact) __attribute__((always_inline)) -> long long {
+            if constexpr (U_LDS && NT >= 512) {
+                if (p.cap <= 2 * NT && !(p.dbg & 512)) {
+                    int *hist4 = seg_pre;
+                    for (int i = tid; i < 1024; i += NT) hist4[i] = 0;
+                    __syncthreads();
+                    return select_fast<NT, false, 2>(U, hist4, sh, p.k, exact, rc.have_thr ? rc.thr_key : 0u);
+                }
+            }
+            return compact_topk<NT>(U, hist, sh, p.k);
+        };
         const bool row_done = (macs == 0);
         PHASE_END(PH_SETUP);
 
@@ -413,7 +427,7 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                     __syncthreads();
                     PHASE_END(PH_DRAIN);
                     if (timing) ph[8] += 1;          // event count: sweeps repeated after a full candidate buffer
-                    took_threshold(compact_topk<NT>(U, hist, sh, p.k));
+                    took_threshold(select_now(false));
                     PHASE_END(PH_SELECT);
                 }
                 PHASE_END(PH_DRAIN);
@@ -426,7 +440,7 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
         __syncthreads();
         const int n_fin = sh[SH_CNT];
         __syncthreads();
-        if (n_fin > p.k) took_threshold(compact_topk<NT>(U, hist, sh, p.k));
+        if (n_fin > p.k) took_threshold(select_now(true));
         PHASE_END(PH_SELECT);
         const int n_out = sh[SH_CNT];
         const long long o = (long long)slot_i * (long long)p.k;
