@@ -535,7 +535,7 @@ def selected_device() -> int:
 def run_hip(call: KernelCall, device: Optional[int] = None, table_slots: int = 0, threads_per_wg: int = 0,
             num_wgs: int = 0, load_pct: int = 0, time_kernel: bool = False, static_sched: bool = False,
             no_sparse_path: bool = False, no_fold: bool = False, want_rows: bool = True,
-            check_zeros: bool = False, csr_out: bool = False):
+            check_zeros: bool = False, csr_out: bool = False, dbg: int = 0):
     """The `with nogil:` block of s_plus.pyx:359-384, on the GPU: host buffers in, host buffers out
     through the C ABI (include/sp_knn.h).  Returns rows, cols, values, counts[, info].
 
@@ -599,6 +599,7 @@ def run_hip(call: KernelCall, device: Optional[int] = None, table_slots: int = 0
     a.out_counts = counts.ctypes.data if counts is not None else None
     a.csr_indptr = csr_indptr.ctypes.data if csr_out else None
     a.table_slots, a.threads_per_wg, a.num_wgs, a.load_pct = table_slots, threads_per_wg, num_wgs, load_pct
+    a.reserved[0] = int(dbg)          # ablation word of the library (tests / profiling only; 1024 = force the 64-bit-offset kernel variant)
     if n > 0:
         _abi.call_knn(a)
     if csr_out:

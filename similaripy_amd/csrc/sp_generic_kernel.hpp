@@ -8,7 +8,9 @@
 
 namespace {
 
-template <int NT, bool U_LDS>
+// BIG: nnz(m2) >= 2^30 — the m2 streams are addressed with 64-bit byte offsets (one more VGPR and a 64-bit add per load);
+// the host launches this variant for such calls and sends every row to it (the sparse kernel's buffer loads stop at 4 GB).
+template <int NT, bool U_LDS, bool BIG = false>
 __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NW = NT / 64;
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
     // loads of trip i+1 are issued before trip i is processed (two register sets, no copies).
     // Per lane the current segment is cached in registers (end of segment, flat->m2 index delta, m1 value):
     // the common element costs one compare and one add.  m2 is addressed with 32-bit byte offsets from the
-    // scalar base pointers (the host only launches this kernel for nnz(m2) < 2^30).
+    // scalar base pointers (64-bit ones in the BIG variant, which the host launches for nnz(m2) >= 2^30).
     // body(c[], x[], v1[], valid): c = column id, x = m2 value (0 unless loadx), v1 = m1 value of the
     // element's segment; padding elements (bit clear in `valid`) repeat a real element of the lane, v1 = 0.
     const char *m2i_bytes = (const char *)p.m2_indices;
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
         float segv = seg_v1[seg];
         const int idx_safe = efirst + delta;
         auto fetch = [&](int ebase, int (&c)[AU], float (&x)[AU], float (&v1)[AU], unsigned &valid) {
-            unsigned off[AU];
+            typename std::conditional<BIG, unsigned long long, unsigned>::type off[AU];
             valid = 0;
 #pragma unroll
             for (int j = 0; j < AU; ++j) {
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                     delta = seg_lo[seg] - seg_pre[seg];
                     segv = seg_v1[seg];
                 }
-                off[j] = (unsigned)(ok ? ej + delta : idx_safe) << 2;
+                off[j] = (decltype(off[0] + 0))(unsigned)(ok ? ej + delta : idx_safe) << 2;
                 v1[j] = ok ? segv : 0.f;
                 valid |= ok ? (1u << j) : 0u;
             }

@@ -101,6 +101,7 @@ struct Config {
     size_t ws_desc_offset;  // of the sparse queue inside that block (the generic queue follows it)
     int nb_log2;            // sparse kernel: bitmap bits (log2)
     size_t ws_total;
+    bool big;               // nnz(m2) >= 2^30: every row goes to the generic kernel's 64-bit-offset variant
     int n_splits;           // generic kernel: precomputed dense-window boundaries per m2 row (0 = none)
     size_t ws_split_bytes;
     bool fold;
@@ -198,6 +199,9 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
         c->n_splits = (nsp >= 1 && nsp <= 15 && a->n_rows_m2 > 0 && a->nnz_m2 > 0) ? (int)nsp : 0;
         c->ws_split_bytes = c->n_splits ? (((size_t)a->n_rows_m2 * (size_t)c->n_splits * 4 + 255) & ~(size_t)255) : 0;
     }
+    // the sparse kernel reads m2 through buffer resources with 32-bit byte offsets: beyond 4 GB per stream the generic kernel's
+    // 64-bit variant takes every row (the reference's own limit is 2^31 - 1 entries, s_plus.pyx:241-244)
+    c->big = a->nnz_m2 >= (1LL << 30) - 1024 || (a->reserved[0] & 1024);      // (bit 1024 of the ablation word: force it, for tests at small sizes)
     c->ws_total = WS_QUEUE_BYTES + c->ws_gu_bytes + c->ws_fold_bytes + c->ws_rows_bytes + c->ws_split_bytes;
     return SP_OK;
 }
@@ -215,9 +219,6 @@ int validate(const sp_knn_args *a) {
     const bool m1t = (a->flags & SP_FLAG_M1_IS_M2_T) != 0;     // m1 = m2^T, built on the device: the m1_* pointers and nnz_m1 are ignored
     const bool dev_norms = (a->flags & SP_FLAG_NORMS_ON_DEVICE) != 0;
     if (m2t && m1t) return fail(SP_EINVAL, "SP_FLAG_M2_IS_M1_T and SP_FLAG_M1_IS_M2_T exclude each other");
-    if ((m2t ? a->nnz_m1 : a->nnz_m2) >= (1LL << 30) - 1024)
-        return fail(SP_EINVAL, "nnz(m2) = %lld: this build addresses m2 with 32-bit byte offsets and needs nnz(m2) < 2^30",
-                    (long long)(m2t ? a->nnz_m1 : a->nnz_m2));
     if ((a->flags & (SP_FLAG_P3_PREP | SP_FLAG_DEPOP_ROWSUM | SP_FLAG_NORMS_ON_DEVICE)) && !m2t && !m1t)
         return fail(SP_EINVAL, "SP_FLAG_P3_PREP / SP_FLAG_DEPOP_ROWSUM / SP_FLAG_NORMS_ON_DEVICE need SP_FLAG_M2_IS_M1_T or SP_FLAG_M1_IS_M2_T");
     if ((a->flags & SP_FLAG_DEPOP_ROWSUM) && !(a->flags & SP_FLAG_P3_PREP))
@@ -266,7 +267,8 @@ int launch_sparse(const KParams &kp, const Config &c, hipStream_t stream) {
 
 template <int NT>
 int launch_generic(const KParams &kp, const Config &c, hipStream_t stream) {
-    auto kg = c.u_lds ? sp_knn_generic_kernel<NT, true> : sp_knn_generic_kernel<NT, false>;
+    auto kg = c.big ? (c.u_lds ? sp_knn_generic_kernel<NT, true, true> : sp_knn_generic_kernel<NT, false, true>)
+                    : (c.u_lds ? sp_knn_generic_kernel<NT, true> : sp_knn_generic_kernel<NT, false>);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds_generic));
     hipLaunchKernelGGL(kg, dim3(c.wgs_generic), dim3(NT), c.lds_generic, stream, kp);
     HIP_TRY(hipGetLastError());
@@ -385,7 +387,7 @@ int run_device_impl(sp_knn_args *a) {
     kp.cap_s = c.cap_s;
     kp.gU = c.u_lds_s ? nullptr : (u64 *)ws_gu;
     kp.gU_g = c.u_lds ? nullptr : (u64 *)(ws_gu + c.ws_gu_s_bytes);
-    kp.sparse_path = (a->flags & SP_FLAG_NO_SPARSE_PATH) ? 0 : 1;
+    kp.sparse_path = ((a->flags & SP_FLAG_NO_SPARSE_PATH) || c.big) ? 0 : 1;
     {
         // work per row -> (optionally) descending-work order -> classified descriptor queues
         unsigned *bucket_count = (unsigned *)ws_rows;       // [32]

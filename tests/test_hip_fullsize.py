@@ -246,3 +246,36 @@ def test_config4_user_scoring_with_seen_filter():
     want = _oracle_slots(call, sample, drop_zeros=True)
     got = _slots_from_csr(res, sample)
     so.compare_topk(got, want, k, rtol=RTOL, atol=ATOL, what="C5 sample")
+
+
+# ------------------------------------------------------------------------------------------------------------
+# beyond every config: nnz(matrix2) >= 2^30 (the reference's limit is 2^31 - 1, s_plus.pyx:241-244)
+# ------------------------------------------------------------------------------------------------------------
+def test_matrix2_with_more_than_2_30_entries():
+    """4.3 GB per m2 stream: past what a 32-bit byte offset reaches.  The library sends such calls to the generic kernel's
+    64-bit-offset variant.  m2: 1 050 000 rows x 1024 entries (columns ascending inside a row, values from a small
+    set); the targets' m1 rows point at m2 rows over the whole range, the last ones beyond the 4 GB mark."""
+    R, L, n_cols, k = 1_050_000, 1024, 100_000, 50
+    assert R * L >= 2 ** 30
+    r = np.arange(R, dtype=np.int32)[:, None]
+    j = np.arange(L, dtype=np.int32)[None, :]
+    indices = (j * np.int32(97) + (r * np.int32(7)) % np.int32(672)).astype(np.int32, copy=False).ravel()      # < 99 328 + 672 = n_cols
+    data = (((r + j) % np.int32(13)) + np.int32(1)).astype(np.float32).ravel()
+    data *= np.float32(0.125)
+    indptr = np.arange(R + 1, dtype=np.int64) * L
+    assert indptr[-1] < 2 ** 31
+    m2 = sp.csr_array((data, indices, indptr.astype(np.int32)), shape=(R, n_cols))
+    rng = np.random.default_rng(3)
+    n_t, per = 48, 40
+    picks = [np.unique(np.concatenate([rng.choice(R - 2000, per - 8), rng.integers(R - 1400, R, 8)])) for _ in range(n_t)]   # ascending, duplicate-free
+    lens = np.array([p.size for p in picks])
+    u_all = np.concatenate(picks).astype(np.int32)
+    m1 = sp.csr_array((rng.random(u_all.size, dtype=np.float32) + np.float32(0.5), u_all,
+                       np.concatenate(([0], np.cumsum(lens))).astype(np.int32)), shape=(n_t, R))
+    assert all(int(p.max()) * L * 4 >= 2 ** 32 for p in picks), "every target row reads m2 beyond the 4 GB mark"
+    call = _host.prepare(m1, m2, k=k)
+    rows, cols, vals, counts = _host.run_hip(call)
+    got = so.canonical(rows, cols, vals, call.targets, k)
+    want = so.canonical(*so.run_kernel(call, "port"), call.targets, k)
+    so.compare_topk(got, want, k, rtol=RTOL, atol=ATOL, what="nnz(m2) >= 2^30")
+    assert counts.min() == k

@@ -122,6 +122,16 @@ def test_kernel_vs_oracle_hash_windows(name, kw):
     _check(call, name + "/T1024", table_slots=1024)       # several hash windows
 
 
+@pytest.mark.parametrize("name,kw", KERNEL_PARAMS[:5], ids=[p[0] for p in KERNEL_PARAMS[:5]])
+def test_generic_kernel_64bit_offset_variant(name, kw):
+    """nnz(m2) >= 2^30 sends every row to the generic kernel's variant that addresses m2 with 64-bit byte offsets
+    (tests/test_hip_fullsize.py runs a real one); here the variant is forced at small sizes (bit 1024 of the library's
+    ablation word): dense windows, hashed windows, and a shape the sparse kernel would otherwise take."""
+    _check(_host.prepare(_rand((5000, 400), 0.1, 7), k=64, **kw), name + "/dense", table_slots=1024, dbg=1024)
+    _check(_host.prepare(_rand((30000, 2000), 0.004, 8), k=50, target_rows=np.arange(0, 30000, 7), **kw), name + "/hash", table_slots=1024, dbg=1024)
+    _check(_host.prepare(_sparse_shape(), k=30, target_rows=np.arange(0, 40000, 11), **kw), name + "/sparse-shape", dbg=1024)
+
+
 def test_hash_overflow_retry():
     """Candidates concentrated in a narrow column range defeat the MACs-based window estimate: the
     hashed window overflows its probe budget, is discarded, halved and retried (several times, down
