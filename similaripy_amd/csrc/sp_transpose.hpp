@@ -93,16 +93,73 @@ __global__ __launch_bounds__(256) void sp_tr_sort_lds_kernel(int n_out_rows, int
     }
 }
 
-// rows longer than the LDS classes: the same network over the records in global memory (one workgroup per row: its own
-// stores are visible to it after the barrier)
+// rows longer than the LDS classes (a popular item of a ratings matrix: 10^5 entries): the same network with LDS tiles.
+// Tiles of TR_TILE records are sorted in LDS; a merge level then runs its long-distance steps (mirror step, j >= TR_TILE) on the
+// records in global memory and its short ones (j < TR_TILE, all inside aligned tiles) tile by tile in LDS again: 15 passes over
+// the row at 2^18 records instead of 171.  One workgroup per row: its own stores are visible to it after the barrier.
+constexpr int TR_TILE = 8192;
 __global__ __launch_bounds__(1024) void sp_tr_sort_global_kernel(int n_out_rows, int min_len, const int *__restrict__ out_indptr, tr_u64 *rec,
                                                                   int *__restrict__ out_indices, float *__restrict__ out_data) {
+    extern __shared__ tr_u64 tr_buf[];
     const int tid = threadIdx.x;
     for (int r = blockIdx.x; r < n_out_rows; r += gridDim.x) {
         const int b = out_indptr[r], len = out_indptr[r + 1] - b;
         if (len <= min_len) continue;       // (uniform)
         tr_u64 *buf = rec + b;
-        tr_bitonic(buf, len, tid, 1024);
+        int lp = 1;
+        while ((1ll << lp) < len) ++lp;
+        const long long half = 1ll << (lp - 1);
+        int lt = 1;
+        while ((1 << lt) < TR_TILE) ++lt;
+        // levels 1 .. lt: every tile sorted on its own
+        for (int t0 = 0; t0 < len; t0 += TR_TILE) {
+            const int n = min(TR_TILE, len - t0);
+            for (int i = tid; i < n; i += 1024) tr_buf[i] = buf[t0 + i];
+            __syncthreads();
+            if (n > 1) tr_bitonic(tr_buf, n, tid, 1024);
+            for (int i = tid; i < n; i += 1024) buf[t0 + i] = tr_buf[i];
+            __syncthreads();
+        }
+        for (int lk = lt + 1; lk <= lp; ++lk) {      // merge blocks of k = 2^lk records
+            const long long k = 1ll << lk, hk = k >> 1;
+            for (long long t = tid; t < half; t += 1024) {
+                const long long blk = t >> (lk - 1), off = t & (hk - 1);
+                const long long lo = (blk << lk) + off, hi = (blk << lk) + (k - 1 - off);
+                if (hi < len) {
+                    const tr_u64 a = buf[lo], c = buf[hi];
+                    if (a > c) { buf[lo] = c; buf[hi] = a; }
+                }
+            }
+            __syncthreads();
+            for (long long j = k >> 2; j >= TR_TILE; j >>= 1) {
+                for (long long t = tid; t < half; t += 1024) {
+                    const long long lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+                    if (hi < len) {
+                        const tr_u64 a = buf[lo], c = buf[hi];
+                        if (a > c) { buf[lo] = c; buf[hi] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+            // the steps j = TR_TILE/2 .. 1 pair records of one aligned tile
+            for (int t0 = 0; t0 < len; t0 += TR_TILE) {
+                const int n = min(TR_TILE, len - t0);
+                for (int i = tid; i < n; i += 1024) tr_buf[i] = buf[t0 + i];
+                __syncthreads();
+                for (int j = TR_TILE >> 1; j > 0; j >>= 1) {
+                    for (int t = tid; t < TR_TILE / 2; t += 1024) {
+                        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+                        if (hi < n) {
+                            const tr_u64 a = tr_buf[lo], c = tr_buf[hi];
+                            if (a > c) { tr_buf[lo] = c; tr_buf[hi] = a; }
+                        }
+                    }
+                    __syncthreads();
+                }
+                for (int i = tid; i < n; i += 1024) buf[t0 + i] = tr_buf[i];
+                __syncthreads();
+            }
+        }
         for (int i = tid; i < len; i += 1024) {
             const tr_u64 v = buf[i];
             out_indices[b + i] = (int)(unsigned)(v >> 32);
@@ -273,7 +330,8 @@ int transpose_device(int n_rows, int n_cols, long long nnz, const float *data, c
         // (per device, and cheap: set on every call like the row kernels' launchers do)
         HIP_TRY(hipFuncSetAttribute((const void *)sp_tr_sort_lds_kernel<TR_MEDIUM>, hipFuncAttributeMaxDynamicSharedMemorySize, TR_MEDIUM * 8));
         hipLaunchKernelGGL(sp_tr_sort_lds_kernel<TR_MEDIUM>, dim3(std::min(n_cols, 256 * 4)), dim3(256), TR_MEDIUM * 8, stream, n_cols, TR_SHORT, out_indptr, rec, out_indices, out_data);
-        hipLaunchKernelGGL(sp_tr_sort_global_kernel, dim3(std::min(n_cols, 256 * 2)), dim3(1024), 0, stream, n_cols, TR_MEDIUM, out_indptr, rec, out_indices, out_data);
+        HIP_TRY(hipFuncSetAttribute((const void *)sp_tr_sort_global_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TR_TILE * 8));
+        hipLaunchKernelGGL(sp_tr_sort_global_kernel, dim3(std::min(n_cols, 256 * 2)), dim3(1024), TR_TILE * 8, stream, n_cols, TR_MEDIUM, out_indptr, rec, out_indices, out_data);
     }
     HIP_TRY(hipGetLastError());
     return SP_OK;

@@ -526,7 +526,7 @@ def test_device_transpose_long_and_skewed_rows():
     rng = np.random.default_rng(11)
     n_rows, n_cols = 40_000, 600
     cols = [np.array([0], dtype=np.int64)] * n_rows                                       # column 0: 40 000 records
-    extra = [np.unique(np.concatenate(([1] if r % 3 == 0 else [], 2 + rng.integers(0, 400, size=rng.integers(0, 6))))).astype(np.int64) for r in range(n_rows)]
+    extra = [np.unique(np.concatenate(([1] if r % 3 == 0 else [], [401] if r % 2 == 1 or r < 17 else [], 2 + rng.integers(0, 399, size=rng.integers(0, 6))))).astype(np.int64) for r in range(n_rows)]   # column 401: 20 008 records
     indptr = np.zeros(n_rows + 1, dtype=np.int64)
     idx = []
     for r in range(n_rows):
