@@ -160,6 +160,9 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
         const int4 dC = desc[2 * (size_t)qi], wC = desc[2 * (size_t)qi + 1];
         // row-constant values are wave-uniform: v_readfirstlane moves them to scalar registers
         const int slot_i = __builtin_amdgcn_readfirstlane(dC.x);
+        // a piece of a heavy row: one standard dense window of it, results to the piece's own slot (sp_merge_pieces_kernel)
+        const int piece = slot_i < 0 ? -1 - slot_i : -1;
+        const int piece_window = piece >= 0 ? __builtin_amdgcn_readfirstlane(p.piece_info[piece].y) : 0;
         const int t = __builtin_amdgcn_readfirstlane(dC.y);
         const int s1 = __builtin_amdgcn_readfirstlane(dC.z);
         const int n1 = __builtin_amdgcn_readfirstlane(dC.w);
@@ -234,8 +237,13 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                 else width = ((long long)p.n_cols + p_hash - 1) / p_hash;
             }
 
-            long long lo = 0;
-            while (lo < (long long)p.n_cols) {
+            long long lo = 0, col_end = p.n_cols;
+            if (piece >= 0) {       // (the splitter only cuts rows of a call with standard windows: n_cols > Td)
+                width = Td;
+                lo = (long long)piece_window * Td;
+                col_end = min((long long)p.n_cols, lo + Td);
+            }
+            while (lo < col_end) {
                 long long hi = lo + width;
                 if (hi > p.n_cols) hi = p.n_cols;
                 const int wlo = (int)lo, whi = (int)hi;
@@ -445,6 +453,18 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
         if (n_fin > p.k) took_threshold(select_now(true));
         PHASE_END(PH_SELECT);
         const int n_out = sh[SH_CNT];
+        if (piece >= 0) {
+            const long long o = (long long)piece * (long long)p.k;
+            for (int j = tid; j < n_out; j += NT) {
+                const u64 it = U[j];
+                p.part_cols[o + j] = (int)(unsigned)(it & 0xFFFFFFFFull);
+                p.part_vals[o + j] = funkey((unsigned)(it >> 32));
+            }
+            if (tid == 0) {
+                p.part_counts[piece] = n_out;
+                sh[SH_QA] = next_q;
+            }
+        } else {
         const long long o = (long long)slot_i * (long long)p.k;
         for (int j = tid; j < p.k; j += NT) {
             int r = 0, c = 0;
@@ -462,6 +482,7 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
         if (tid == 0) {
             if (p.counts) p.counts[slot_i] = n_out;
             sh[SH_QA] = next_q;
+        }
         }
         __syncthreads();
         if (tid == 0) sh[SH_CNT] = 0;

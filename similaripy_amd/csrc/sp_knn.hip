@@ -104,6 +104,9 @@ struct Config {
     bool big;               // nnz(m2) >= 2^30: every row goes to the generic kernel's 64-bit-offset variant
     int n_splits;           // generic kernel: precomputed dense-window boundaries per m2 row (0 = none)
     size_t ws_split_bytes;
+    int split_pieces;       // heavy generic rows are queued as this many pieces (one per standard dense window), 0 = off
+    int split_cap;          // at most this many rows
+    size_t ws_piece_bytes;  // split_rows[cap] | piece_info[cap * pieces] | part_counts[cap * pieces] | part_cols / part_vals [cap * pieces * k]
     bool fold;
     bool mono;              // the sparse kernel's monotone variant applies (val = xy / den or the raw dot, no per-row target selector)
     bool ordered;
@@ -202,7 +205,17 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
     // the sparse kernel reads m2 through buffer resources with 32-bit byte offsets: beyond 4 GB per stream the generic kernel's
     // 64-bit variant takes every row (the reference's own limit is 2^31 - 1 entries, s_plus.pyx:241-244)
     c->big = a->nnz_m2 >= (1LL << 30) - 1024 || (a->reserved[0] & 1024);      // (bit 1024 of the ablation word: force it, for tests at small sizes)
-    c->ws_total = WS_QUEUE_BYTES + c->ws_gu_bytes + c->ws_fold_bytes + c->ws_rows_bytes + c->ws_split_bytes;
+    // heavy generic rows (a popular item of a ratings matrix: one row can be a third of the kernel's time on one workgroup) are
+    // queued as one piece per standard dense window; needs the per-call boundaries above and a merge buffer of pieces * k records
+    c->split_pieces = 0; c->split_cap = 0; c->ws_piece_bytes = 0;
+    if (c->n_splits >= 1 && (long long)(c->n_splits + 1) * a->k <= 8192 && !(a->reserved[0] & 4096)) {      // (bit 4096 of the ablation word: off)
+        c->split_pieces = c->n_splits + 1;
+        c->split_cap = std::min(a->n_targets, 2048);
+        const size_t np = (size_t)c->split_cap * (size_t)c->split_pieces;
+        c->ws_piece_bytes = (((size_t)c->split_cap * 4 + np * 8 + np * 4 + np * (size_t)a->k * 8) + 255) & ~(size_t)255;
+        c->ws_rows_bytes += (np * 32 + 255) & ~(size_t)255;       // room for the extra entries of the generic queue (the last array of that block)
+    }
+    c->ws_total = WS_QUEUE_BYTES + c->ws_gu_bytes + c->ws_fold_bytes + c->ws_rows_bytes + c->ws_split_bytes + c->ws_piece_bytes;
     return SP_OK;
 }
 
@@ -333,6 +346,7 @@ int run_device_impl(sp_knn_args *a) {
     unsigned char *ws_fold = ws_gu + c.ws_gu_bytes;
     unsigned char *ws_rows = ws_fold + c.ws_fold_bytes;
     int *ws_split = (int *)(ws_rows + c.ws_rows_bytes);
+    unsigned char *ws_piece = (unsigned char *)ws_split + c.ws_split_bytes;
 
     // minima of the column-term vectors feed the gather-free upper bound (Epi::upper); it is sound only
     // when every weight / shrink is non-negative (NaN parameters fail the comparisons and disable it)
@@ -411,6 +425,20 @@ int run_device_impl(sp_knn_args *a) {
         cp.mono = c.mono ? 1 : 0;
         cp.any_norm = (a->l1 != 0.f || a->l2 != 0.f || a->l3 != 0.f || a->stabilized_shrink != 0.f || a->bayesian_shrink != 0.f) ? 1 : 0;
         cp.l2 = a->l2; cp.l3 = a->l3;
+        cp.split_pieces = 0; cp.split_macs = 0u; cp.split_cap = 0; cp.split_count = nullptr; cp.split_rows = nullptr; cp.piece_info = nullptr;
+        if (c.split_pieces) {
+            const size_t np = (size_t)c.split_cap * (size_t)c.split_pieces;
+            cp.split_pieces = c.split_pieces;
+            cp.split_macs = (a->reserved[0] & 8192) ? 1u : (1u << 22);        // (bit 8192 of the ablation word: split every generic row, for tests)
+            cp.split_cap = c.split_cap;
+            cp.split_count = (int *)(ws + 16);                                  // (inside the zeroed header)
+            cp.split_rows = (int *)ws_piece;
+            cp.piece_info = (int2 *)(ws_piece + (size_t)c.split_cap * 4);
+            kp.piece_info = cp.piece_info;
+            kp.part_counts = (int *)((unsigned char *)cp.piece_info + np * 8);
+            kp.part_cols = kp.part_counts + np;
+            kp.part_vals = (float *)(kp.part_cols + np * (size_t)a->k);
+        }
         hipLaunchKernelGGL(sp_row_desc_kernel, dim3((a->n_targets + 255) / 256), dim3(256), 0, stream, a->n_targets, a->targets,
                            a->m1_indptr, work, c.ordered ? bucket_base + 32 : nullptr, order, a->l1 != 0.f ? a->Xtversky : nullptr,
                            a->l2 != 0.f ? a->Xcosine : nullptr, a->l3 != 0.f ? a->Xdepop : nullptr, cp, kp.qcount, desc_s, desc_g);
@@ -447,6 +475,13 @@ int run_device_impl(sp_knn_args *a) {
     kp_s.T = c.T_s; kp_s.logT = c.logT_s;
     rc = launch_rows(kp_s, kp, c, stream, timed ? kev : nullptr);
     if (rc) return rc;
+    if (c.split_pieces) {
+        const int n_rec = c.split_pieces * a->k;
+        hipLaunchKernelGGL(sp_merge_pieces_kernel, dim3(std::min(c.split_cap, 1024)), dim3(256), (size_t)n_rec * 8, stream, (const int *)(ws + 16), c.split_cap,
+                           (const int *)ws_piece, c.split_pieces, a->k, a->targets, (const int *)kp.part_cols, (const float *)kp.part_vals, (const int *)kp.part_counts,
+                           a->rows, a->cols, a->values, a->out_counts);
+        HIP_TRY(hipGetLastError());
+    }
 
     if (timed) {
         HIP_TRY(hipEventRecord(ev1, stream));

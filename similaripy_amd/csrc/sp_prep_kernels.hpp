@@ -88,6 +88,13 @@ struct ClassifyParams {
     int mono;              // the monotone sparse kernel runs: descriptor word 1.y carries den (val = xy / den), rows
     int any_norm;          //   with a normalised epilogue need den > 0 to be sparse
     float l2, l3;
+    // heavy generic rows are queued as `split_pieces` pieces (one per standard dense window) instead of one entry
+    int split_pieces;          // 0 = off
+    unsigned split_macs;       // rows with at least this many MACs
+    int split_cap;             // at most this many rows
+    int *split_count;          // [1] rows split so far (zero on entry)
+    int *split_rows;           // [split_cap] their output slots
+    int2 *piece_info;          // [split_cap * split_pieces] {output slot, window index}
 };
 
 __global__ __launch_bounds__(256) void sp_row_desc_kernel(int n_targets, const int *targets, const int *m1_indptr, const unsigned *work,
@@ -123,19 +130,114 @@ __global__ __launch_bounds__(256) void sp_row_desc_kernel(int n_targets, const i
             sparse = expect <= 0.30f * (float)cp.cs_slots;
         }
     }
-    const u64 ms = __ballot(valid && sparse), mg = __ballot(valid && !sparse);
+    // heavy generic rows: one queue entry per standard dense window
+    int split_id = -1;
+    if (valid && !sparse && cp.split_pieces > 1 && (unsigned)d1.x >= cp.split_macs) {
+        const int id = atomicAdd(cp.split_count, 1);
+        if (id < cp.split_cap) { split_id = id; cp.split_rows[id] = d0.x; }
+    }
+    const int n_g = (valid && !sparse) ? (split_id >= 0 ? cp.split_pieces : 1) : 0;     // generic queue entries of this lane
+    const u64 ms = __ballot(valid && sparse);
+    int incl = n_g;                                                                      // inclusive wave scan
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+    const int tot_g = __shfl(incl, 63, 64);
     unsigned bs = 0, bg = 0;
     if (lane == 0) {
         if (ms) bs = atomicAdd(&qcount[0], (unsigned)__popcll(ms));
-        if (mg) bg = atomicAdd(&qcount[1], (unsigned)__popcll(mg));
+        if (tot_g) bg = atomicAdd(&qcount[1], (unsigned)tot_g);
     }
     bs = (unsigned)__builtin_amdgcn_readfirstlane((int)bs);
     bg = (unsigned)__builtin_amdgcn_readfirstlane((int)bg);
     if (valid) {
         const u64 below = (1ull << lane) - 1ull;
-        int4 *dst = sparse ? desc_s + 2 * (size_t)(bs + (unsigned)__popcll(ms & below)) : desc_g + 2 * (size_t)(bg + (unsigned)__popcll(mg & below));
-        dst[0] = d0;
-        dst[1] = d1;
+        if (sparse) {
+            int4 *dst = desc_s + 2 * (size_t)(bs + (unsigned)__popcll(ms & below));
+            dst[0] = d0;
+            dst[1] = d1;
+        } else {
+            int4 *dst = desc_g + 2 * (size_t)(bg + (unsigned)(incl - n_g));
+            if (split_id < 0) { dst[0] = d0; dst[1] = d1; }
+            else {
+                for (int j = 0; j < cp.split_pieces; ++j) {
+                    const int piece = split_id * cp.split_pieces + j;
+                    cp.piece_info[piece] = make_int2(d0.x, j);
+                    int4 e0 = d0;
+                    e0.x = -1 - piece;
+                    dst[2 * j] = e0;
+                    dst[2 * j + 1] = d1;
+                }
+            }
+        }
+    }
+}
+
+// The top-k of a split row from its pieces' results (each a top-k of its own column window, threshold applied):
+// ascending sort of the pieces' {value key, column} records in LDS, the k largest go to the row's output slot.
+// One workgroup per split row; n_pieces * k <= 8192 records.
+__global__ __launch_bounds__(256) void sp_merge_pieces_kernel(const int *__restrict__ split_count, int split_cap, const int *__restrict__ split_rows, int n_pieces, int k,
+                                                               const int *__restrict__ targets, const int *__restrict__ part_cols, const float *__restrict__ part_vals,
+                                                               const int *__restrict__ part_counts, int *__restrict__ rows, int *__restrict__ cols,
+                                                               float *__restrict__ values, int *__restrict__ counts) {
+    extern __shared__ unsigned long long mg_buf[];
+    __shared__ int mg_n;
+    const int n_split = min(*split_count, split_cap);
+    const int tid = threadIdx.x;
+    for (int s = blockIdx.x; s < n_split; s += gridDim.x) {
+        if (tid == 0) mg_n = 0;
+        __syncthreads();
+        for (int j = 0; j < n_pieces; ++j) {
+            const int piece = s * n_pieces + j;
+            const int n = part_counts[piece];
+            int base = 0;
+            if (tid == 0) { base = mg_n; mg_n = base + n; }
+            __syncthreads();
+            base = mg_n - n;
+            for (int i = tid; i < n; i += 256)
+                mg_buf[base + i] = ((unsigned long long)fkey(part_vals[(size_t)piece * k + i]) << 32) | (unsigned long long)(unsigned)part_cols[(size_t)piece * k + i];
+            __syncthreads();
+        }
+        const int n = mg_n;
+        // ascending bitonic network with virtual padding (the transpose's, restated for this buffer)
+        if (n > 1) {
+            int lp = 1;
+            while ((1 << lp) < n) ++lp;
+            const int half = 1 << (lp - 1);
+            for (int lk = 1; lk <= lp; ++lk) {
+                const int kk = 1 << lk, hk = kk >> 1;
+                for (int t = tid; t < half; t += 256) {
+                    const int blk = t >> (lk - 1), off = t & (hk - 1);
+                    const int lo = (blk << lk) + off, hi = (blk << lk) + (kk - 1 - off);
+                    if (hi < n) { const unsigned long long a = mg_buf[lo], c = mg_buf[hi]; if (a > c) { mg_buf[lo] = c; mg_buf[hi] = a; } }
+                }
+                __syncthreads();
+                for (int j = kk >> 2; j > 0; j >>= 1) {
+                    for (int t = tid; t < half; t += 256) {
+                        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+                        if (hi < n) { const unsigned long long a = mg_buf[lo], c = mg_buf[hi]; if (a > c) { mg_buf[lo] = c; mg_buf[hi] = a; } }
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        const int slot = split_rows[s];
+        const int n_out = min(n, k);
+        const long long o = (long long)slot * (long long)k;
+        for (int j = tid; j < k; j += 256) {
+            int r = 0, c = 0;
+            float v = 0.f;
+            if (j < n_out) {
+                const unsigned long long it = mg_buf[n - 1 - j];
+                r = targets[slot];
+                c = (int)(unsigned)(it & 0xFFFFFFFFull);
+                v = funkey((unsigned)(it >> 32));
+            }
+            if (rows) rows[o + j] = r;
+            cols[o + j] = c;
+            values[o + j] = v;
+        }
+        if (tid == 0 && counts) counts[slot] = n_out;
+        __syncthreads();
     }
 }
 

@@ -132,6 +132,17 @@ def test_generic_kernel_64bit_offset_variant(name, kw):
     _check(_host.prepare(_sparse_shape(), k=30, target_rows=np.arange(0, 40000, 11), **kw), name + "/sparse-shape", dbg=1024)
 
 
+@pytest.mark.parametrize("name,kw", KERNEL_PARAMS, ids=[p[0] for p in KERNEL_PARAMS])
+def test_generic_kernel_heavy_rows_in_pieces(name, kw):
+    """Heavy rows of the generic kernel are queued as one piece per standard dense window (any workgroup takes a piece) and
+    merged afterwards; production splits rows of 2^22 MACs and more (tests/test_hip_fullsize.py::test_config3_* has such rows),
+    here every row is split (bit 8192 of the library's ablation word).  Also with target rows out of order and repeated."""
+    m = _rand((5000, 400), 0.1, 7)          # m2 = m.T: 400 x 5000; tile 1024 -> dense windows of 2048 columns -> 3 pieces
+    _check(_host.prepare(m, k=64, **kw), name, table_slots=1024, dbg=8192)
+    _check(_host.prepare(m, k=64, target_rows=np.array([4999, 3, 3, 77, 4000, 12], dtype=np.int32), **kw), name + "/targets", table_slots=1024, dbg=8192)
+    _check(_host.prepare(_rand((9000, 300), 0.05, 9), k=700, **kw), name + "/k700", table_slots=1024, dbg=8192)
+
+
 def test_hash_overflow_retry():
     """Candidates concentrated in a narrow column range defeat the MACs-based window estimate: the
     hashed window overflows its probe budget, is discarded, halved and retried (several times, down
