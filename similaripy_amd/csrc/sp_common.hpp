@@ -67,15 +67,16 @@ struct KParams {
     const int *neg_flag;   // Bayesian shrink / Tversky with t1+t2 < 1 only: *neg_flag != 0 iff m1 or m2 holds a negative value (see RowCtx::set_cut)
     int sparse_path;       // 1 = rows with few expected collisions take the bitmap path
     int fold;              // 1 = the single active column term (Ycos or Ydep) is already divided into m2_data: treat it as 1
-    // generic kernel, heavy rows cut into one piece per standard dense window (each piece is a queue entry of its own, any
+    // generic kernel, heavy rows cut into pieces — ranges of fine column windows (each piece is a queue entry of its own, any
     // workgroup takes it; sp_merge_pieces_kernel selects the row's top-k from the pieces' results): a queue entry whose slot
     // field is negative is piece number -1 - slot
-    const int2 *piece_info;    // [piece] {the row's output slot, window index}
+    const int2 *piece_info;    // [piece] {the row's output slot, first fine window | one past the last << 16}
     int *part_cols;            // [piece * k]
     float *part_vals;          // [piece * k]
     int *part_counts;          // [piece]
-    const int *splits;     // generic kernel, optional: [n_rows_m2][n_splits] position of the first entry of m2 row u with column >= (j+1)*2T
-    int n_splits;          //   (the boundaries of the standard dense windows, found once per call instead of once per use)
+    const int *splits;     // generic kernel, optional: [n_rows_m2][n_splits] position of the first entry of m2 row u with column >= (j+1)*split_w
+    int n_splits;          //   (the boundaries of the fine windows, found once per call instead of once per use)
+    int split_w;           //   fine window width: 2T / f, f in {1, 2, 4}; standard dense windows start at multiples of 2T
     unsigned long long *phase_cycles;  // optional [PH_N]
     int dbg;               // ablation bits for profiling only (results are WRONG when non-zero; 8 / 16: sweep 1 / sweep 2 of the sparse kernel
                            // load but do not process — compiled in only with -DSP_ABLATION=1: the test costs the sweeps 1 %):

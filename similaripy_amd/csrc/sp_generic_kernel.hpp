@@ -160,9 +160,9 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
         const int4 dC = desc[2 * (size_t)qi], wC = desc[2 * (size_t)qi + 1];
         // row-constant values are wave-uniform: v_readfirstlane moves them to scalar registers
         const int slot_i = __builtin_amdgcn_readfirstlane(dC.x);
-        // a piece of a heavy row: one standard dense window of it, results to the piece's own slot (sp_merge_pieces_kernel)
+        // a piece of a heavy row: a range of its fine column windows, results to the piece's own slot (sp_merge_pieces_kernel)
         const int piece = slot_i < 0 ? -1 - slot_i : -1;
-        const int piece_window = piece >= 0 ? __builtin_amdgcn_readfirstlane(p.piece_info[piece].y) : 0;
+        const int piece_range = piece >= 0 ? __builtin_amdgcn_readfirstlane(p.piece_info[piece].y) : 0;
         const int t = __builtin_amdgcn_readfirstlane(dC.y);
         const int s1 = __builtin_amdgcn_readfirstlane(dC.z);
         const int n1 = __builtin_amdgcn_readfirstlane(dC.w);
@@ -240,12 +240,12 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
             long long lo = 0, col_end = p.n_cols;
             if (piece >= 0) {       // (the splitter only cuts rows of a call with standard windows: n_cols > Td)
                 width = Td;
-                lo = (long long)piece_window * Td;
-                col_end = min((long long)p.n_cols, lo + Td);
+                lo = (long long)(piece_range & 0xFFFF) * p.split_w;
+                col_end = min((long long)p.n_cols, (long long)(piece_range >> 16) * p.split_w);
             }
             while (lo < col_end) {
                 long long hi = lo + width;
-                if (hi > p.n_cols) hi = p.n_cols;
+                if (hi > col_end) hi = col_end;
                 const int wlo = (int)lo, whi = (int)hi;
                 const bool dense = (hi - lo) <= Td;
                 const bool whole = (wlo == 0 && whi == p.n_cols);
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                 // Window slices chain (hi of window w == lo of window w+1), so when the m1 row fits one
                 // batch the previous slice end is kept in LDS and only one lower_bound per window is run.
                 const bool carry = (n1 <= NT);
-                const bool use_splits = p.splits != nullptr && width == Td && (lo % Td) == 0;     // a standard window (a hashed row halved down to Td may sit elsewhere)
+                const bool use_splits = p.splits != nullptr && width == Td && (lo % p.split_w) == 0 && (hi == p.n_cols || (hi % p.split_w) == 0);   // (a hashed row halved down to Td may sit elsewhere)
                 for (int b0 = 0; b0 < n1; b0 += NT) {
                     const int nb = min(NT, n1 - b0);
                     int len = 0;
@@ -278,11 +278,10 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                         const int u = p.m1_indices[s1 + b0 + tid];
                         int r0 = p.m2_indptr[u], r1 = p.m2_indptr[u + 1];
                         if (!whole && use_splits) {
-                            // standard dense window number wlo / Td: its boundaries were found once per call (sp_m2_splits_kernel)
+                            // both ends are multiples of the fine window width: their positions were found once per call (sp_m2_splits_kernel)
                             const int *sp = p.splits + (size_t)u * (size_t)p.n_splits;
-                            const int jw = wlo / (int)Td;
-                            if (wlo != 0) r0 = sp[jw - 1];
-                            if (whi < p.n_cols) r1 = sp[jw];
+                            if (wlo != 0) r0 = sp[wlo / p.split_w - 1];
+                            if (whi < p.n_cols) r1 = sp[whi / p.split_w - 1];
                         } else if (!whole) {
                             // slice of the sorted m2 row inside [wlo, whi)  (s_plus.h:385-394)
                             if (wlo != 0) {

@@ -104,9 +104,10 @@ struct Config {
     bool big;               // nnz(m2) >= 2^30: every row goes to the generic kernel's 64-bit-offset variant
     int n_splits;           // generic kernel: precomputed dense-window boundaries per m2 row (0 = none)
     size_t ws_split_bytes;
-    int split_pieces;       // heavy generic rows are queued as this many pieces (one per standard dense window), 0 = off
+    int split_w;            //   fine window width (2T / f)
+    int split_pmax;         // heavy generic rows are queued as up to this many pieces (ranges of fine windows), 0 = off
     int split_cap;          // at most this many rows
-    size_t ws_piece_bytes;  // split_rows[cap] | piece_info[cap * pieces] | part_counts[cap * pieces] | part_cols / part_vals [cap * pieces * k]
+    size_t ws_piece_bytes;  // split_rows[cap] | piece_info[cap * pmax] | part_counts[cap * pmax] | part_cols / part_vals [cap * pmax * k]
     bool fold;
     bool mono;              // the sparse kernel's monotone variant applies (val = xy / den or the raw dot, no per-row target selector)
     bool ordered;
@@ -195,25 +196,31 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
     int nb = 10;
     while (nb < c->logT_s + 6 && (1LL << nb) < (long long)a->n_output_cols) ++nb;
     c->nb_log2 = nb;
-    // generic kernel, standard dense windows of 2T columns: their boundaries inside every m2 row, found once per call
+    // generic kernel, standard dense windows of 2T columns: their boundaries inside every m2 row, found once per call — at a
+    // finer grain (2T / f) when that stays a short list, so that heavy rows can be cut into pieces narrower than a window
     {
         const long long Td = 2LL * T;
-        const long long nsp = (long long)a->n_output_cols > Td ? ((long long)a->n_output_cols + Td - 1) / Td - 1 : 0;
-        c->n_splits = (nsp >= 1 && nsp <= 15 && a->n_rows_m2 > 0 && a->nnz_m2 > 0) ? (int)nsp : 0;
+        c->n_splits = 0; c->split_w = (int)Td;
+        if ((long long)a->n_output_cols > Td && a->n_rows_m2 > 0 && a->nnz_m2 > 0) {
+            for (int f = 4; f >= 1; f >>= 1) {
+                const long long G = Td / f, nsp = ((long long)a->n_output_cols + G - 1) / G - 1;
+                if (nsp >= 1 && nsp <= 31) { c->n_splits = (int)nsp; c->split_w = (int)G; break; }
+            }
+        }
         c->ws_split_bytes = c->n_splits ? (((size_t)a->n_rows_m2 * (size_t)c->n_splits * 4 + 255) & ~(size_t)255) : 0;
     }
-    // the sparse kernel reads m2 through buffer resources with 32-bit byte offsets: beyond 4 GB per stream the generic kernel's
-    // 64-bit variant takes every row (the reference's own limit is 2^31 - 1 entries, s_plus.pyx:241-244)
-    c->big = a->nnz_m2 >= (1LL << 30) - 1024 || (a->reserved[0] & 1024);      // (bit 1024 of the ablation word: force it, for tests at small sizes)
     // heavy generic rows (a popular item of a ratings matrix: one row can be a third of the kernel's time on one workgroup) are
     // queued as one piece per standard dense window; needs the per-call boundaries above and a merge buffer of pieces * k records
-    c->split_pieces = 0; c->split_cap = 0; c->ws_piece_bytes = 0;
-    if (c->n_splits >= 1 && (long long)(c->n_splits + 1) * a->k <= 8192 && !(a->reserved[0] & 4096)) {      // (bit 4096 of the ablation word: off)
-        c->split_pieces = c->n_splits + 1;
-        c->split_cap = std::min(a->n_targets, 2048);
-        const size_t np = (size_t)c->split_cap * (size_t)c->split_pieces;
-        c->ws_piece_bytes = (((size_t)c->split_cap * 4 + np * 8 + np * 4 + np * (size_t)a->k * 8) + 255) & ~(size_t)255;
-        c->ws_rows_bytes += (np * 32 + 255) & ~(size_t)255;       // room for the extra entries of the generic queue (the last array of that block)
+    c->split_pmax = 0; c->split_cap = 0; c->ws_piece_bytes = 0;
+    {
+        const int pmax = (int)std::min<long long>(c->n_splits + 1, 8192 / std::max(1, a->k));
+        if (c->n_splits >= 1 && pmax >= 2 && !(a->reserved[0] & 4096)) {      // (bit 4096 of the ablation word: off)
+            c->split_pmax = pmax;
+            c->split_cap = std::min(a->n_targets, 2048);
+            const size_t np = (size_t)c->split_cap * (size_t)c->split_pmax;
+            c->ws_piece_bytes = (((size_t)c->split_cap * 16 + np * 8 + np * 4 + np * (size_t)a->k * 8) + 255) & ~(size_t)255;
+            c->ws_rows_bytes += (np * 32 + 255) & ~(size_t)255;       // room for the extra entries of the generic queue (the last array of that block)
+        }
     }
     c->ws_total = WS_QUEUE_BYTES + c->ws_gu_bytes + c->ws_fold_bytes + c->ws_rows_bytes + c->ws_split_bytes + c->ws_piece_bytes;
     return SP_OK;
@@ -425,15 +432,16 @@ int run_device_impl(sp_knn_args *a) {
         cp.mono = c.mono ? 1 : 0;
         cp.any_norm = (a->l1 != 0.f || a->l2 != 0.f || a->l3 != 0.f || a->stabilized_shrink != 0.f || a->bayesian_shrink != 0.f) ? 1 : 0;
         cp.l2 = a->l2; cp.l3 = a->l3;
-        cp.split_pieces = 0; cp.split_macs = 0u; cp.split_cap = 0; cp.split_count = nullptr; cp.split_rows = nullptr; cp.piece_info = nullptr;
-        if (c.split_pieces) {
-            const size_t np = (size_t)c.split_cap * (size_t)c.split_pieces;
-            cp.split_pieces = c.split_pieces;
-            cp.split_macs = (a->reserved[0] & 8192) ? 1u : (1u << 22);        // (bit 8192 of the ablation word: split every generic row, for tests)
+        cp.split_fine = 0; cp.split_pmax = 0; cp.split_macs = 0u; cp.split_cap = 0; cp.split_count = nullptr; cp.split_rows = nullptr; cp.piece_info = nullptr;
+        if (c.split_pmax) {
+            const size_t np = (size_t)c.split_cap * (size_t)c.split_pmax;
+            cp.split_fine = c.n_splits + 1;
+            cp.split_pmax = c.split_pmax;
+            cp.split_macs = (a->reserved[0] & 8192) ? 1u : (1u << 21);        // (bit 8192 of the ablation word: cut every generic row as finely as allowed, for tests)
             cp.split_cap = c.split_cap;
-            cp.split_count = (int *)(ws + 16);                                  // (inside the zeroed header)
-            cp.split_rows = (int *)ws_piece;
-            cp.piece_info = (int2 *)(ws_piece + (size_t)c.split_cap * 4);
+            cp.split_count = (int *)(ws + 16);                                  // two words inside the zeroed header
+            cp.split_rows = (int4 *)ws_piece;
+            cp.piece_info = (int2 *)(ws_piece + (size_t)c.split_cap * 16);
             kp.piece_info = cp.piece_info;
             kp.part_counts = (int *)((unsigned char *)cp.piece_info + np * 8);
             kp.part_cols = kp.part_counts + np;
@@ -458,13 +466,15 @@ int run_device_impl(sp_knn_args *a) {
     if (c.fold) kp.m2_data = folded;
     kp.splits = nullptr;
     kp.n_splits = 0;
+    kp.split_w = c.split_w;
     if (c.n_splits) {
         const long long n = (long long)a->n_rows_m2 * c.n_splits;
         hipLaunchKernelGGL(sp_m2_splits_kernel, dim3((unsigned)std::min<long long>(256 * 16, (n + 255) / 256)), dim3(256), 0, stream, a->n_rows_m2, a->m2_indptr,
-                           a->m2_indices, 2 * c.T, c.n_splits, ws_split);
+                           a->m2_indices, c.split_w, c.n_splits, ws_split);
         HIP_TRY(hipGetLastError());
         kp.splits = ws_split;
         kp.n_splits = c.n_splits;
+        kp.split_w = c.split_w;
     }
     kp.phase_cycles = (timed && (a->flags & SP_FLAG_PHASE_TIMERS)) ? (unsigned long long *)(ws + WS_PHASE_OFFSET) : nullptr;   // inside the zeroed header
     kp.dbg = (int)a->reserved[0];
@@ -475,10 +485,10 @@ int run_device_impl(sp_knn_args *a) {
     kp_s.T = c.T_s; kp_s.logT = c.logT_s;
     rc = launch_rows(kp_s, kp, c, stream, timed ? kev : nullptr);
     if (rc) return rc;
-    if (c.split_pieces) {
-        const int n_rec = c.split_pieces * a->k;
+    if (c.split_pmax) {
+        const int n_rec = c.split_pmax * a->k;
         hipLaunchKernelGGL(sp_merge_pieces_kernel, dim3(std::min(c.split_cap, 1024)), dim3(256), (size_t)n_rec * 8, stream, (const int *)(ws + 16), c.split_cap,
-                           (const int *)ws_piece, c.split_pieces, a->k, a->targets, (const int *)kp.part_cols, (const float *)kp.part_vals, (const int *)kp.part_counts,
+                           (const int4 *)ws_piece, a->k, a->targets, (const int *)kp.part_cols, (const float *)kp.part_vals, (const int *)kp.part_counts,
                            a->rows, a->cols, a->values, a->out_counts);
         HIP_TRY(hipGetLastError());
     }

@@ -88,13 +88,14 @@ struct ClassifyParams {
     int mono;              // the monotone sparse kernel runs: descriptor word 1.y carries den (val = xy / den), rows
     int any_norm;          //   with a normalised epilogue need den > 0 to be sparse
     float l2, l3;
-    // heavy generic rows are queued as `split_pieces` pieces (one per standard dense window) instead of one entry
-    int split_pieces;          // 0 = off
-    unsigned split_macs;       // rows with at least this many MACs
+    // heavy generic rows are queued as pieces (ranges of fine column windows, see sp_m2_splits_kernel) instead of one entry
+    int split_fine;            // fine windows per row (0 = off)
+    int split_pmax;            // pieces per row at most (the merge buffer holds split_pmax * k records)
+    unsigned split_macs;       // a row gets one piece per this many MACs (and is split at all from twice that on)
     int split_cap;             // at most this many rows
-    int *split_count;          // [1] rows split so far (zero on entry)
-    int *split_rows;           // [split_cap] their output slots
-    int2 *piece_info;          // [split_cap * split_pieces] {output slot, window index}
+    int *split_count;          // [2] rows split so far, pieces handed out so far (zero on entry)
+    int4 *split_rows;          // [split_cap] {output slot, first piece, pieces, 0}
+    int2 *piece_info;          // [split_cap * split_pmax] {output slot, first fine window | one past the last << 16}
 };
 
 __global__ __launch_bounds__(256) void sp_row_desc_kernel(int n_targets, const int *targets, const int *m1_indptr, const unsigned *work,
@@ -130,13 +131,22 @@ __global__ __launch_bounds__(256) void sp_row_desc_kernel(int n_targets, const i
             sparse = expect <= 0.30f * (float)cp.cs_slots;
         }
     }
-    // heavy generic rows: one queue entry per standard dense window
-    int split_id = -1;
-    if (valid && !sparse && cp.split_pieces > 1 && (unsigned)d1.x >= cp.split_macs) {
-        const int id = atomicAdd(cp.split_count, 1);
-        if (id < cp.split_cap) { split_id = id; cp.split_rows[id] = d0.x; }
+    // heavy generic rows: one queue entry per piece
+    int split_id = -1, n_pieces = 0, per_piece = 0, piece0 = 0;
+    if (valid && !sparse && cp.split_fine > 1 && (unsigned)d1.x >= 2u * cp.split_macs) {
+        const int wanted = (int)min((unsigned)cp.split_pmax, ((unsigned)d1.x + cp.split_macs - 1u) / cp.split_macs);
+        per_piece = (cp.split_fine + wanted - 1) / wanted;                  // fine windows per piece
+        n_pieces = (cp.split_fine + per_piece - 1) / per_piece;
+        if (n_pieces > 1) {
+            const int id = atomicAdd(&cp.split_count[0], 1);
+            if (id < cp.split_cap) {
+                split_id = id;
+                piece0 = atomicAdd(&cp.split_count[1], n_pieces);           // (never beyond split_cap * split_pmax: id < split_cap)
+                cp.split_rows[id] = make_int4(d0.x, piece0, n_pieces, 0);
+            }
+        }
     }
-    const int n_g = (valid && !sparse) ? (split_id >= 0 ? cp.split_pieces : 1) : 0;     // generic queue entries of this lane
+    const int n_g = (valid && !sparse) ? (split_id >= 0 ? n_pieces : 1) : 0;     // generic queue entries of this lane
     const u64 ms = __ballot(valid && sparse);
     int incl = n_g;                                                                      // inclusive wave scan
 #pragma unroll
@@ -159,9 +169,10 @@ __global__ __launch_bounds__(256) void sp_row_desc_kernel(int n_targets, const i
             int4 *dst = desc_g + 2 * (size_t)(bg + (unsigned)(incl - n_g));
             if (split_id < 0) { dst[0] = d0; dst[1] = d1; }
             else {
-                for (int j = 0; j < cp.split_pieces; ++j) {
-                    const int piece = split_id * cp.split_pieces + j;
-                    cp.piece_info[piece] = make_int2(d0.x, j);
+                for (int j = 0; j < n_pieces; ++j) {
+                    const int piece = piece0 + j;
+                    const int g0 = j * per_piece, g1 = min(cp.split_fine, g0 + per_piece);
+                    cp.piece_info[piece] = make_int2(d0.x, g0 | (g1 << 16));
                     int4 e0 = d0;
                     e0.x = -1 - piece;
                     dst[2 * j] = e0;
@@ -174,8 +185,8 @@ __global__ __launch_bounds__(256) void sp_row_desc_kernel(int n_targets, const i
 
 // The top-k of a split row from its pieces' results (each a top-k of its own column window, threshold applied):
 // ascending sort of the pieces' {value key, column} records in LDS, the k largest go to the row's output slot.
-// One workgroup per split row; n_pieces * k <= 8192 records.
-__global__ __launch_bounds__(256) void sp_merge_pieces_kernel(const int *__restrict__ split_count, int split_cap, const int *__restrict__ split_rows, int n_pieces, int k,
+// One workgroup per split row; at most split_pmax * k <= 8192 records.
+__global__ __launch_bounds__(256) void sp_merge_pieces_kernel(const int *__restrict__ split_count, int split_cap, const int4 *__restrict__ split_rows, int k,
                                                                const int *__restrict__ targets, const int *__restrict__ part_cols, const float *__restrict__ part_vals,
                                                                const int *__restrict__ part_counts, int *__restrict__ rows, int *__restrict__ cols,
                                                                float *__restrict__ values, int *__restrict__ counts) {
@@ -186,8 +197,9 @@ __global__ __launch_bounds__(256) void sp_merge_pieces_kernel(const int *__restr
     for (int s = blockIdx.x; s < n_split; s += gridDim.x) {
         if (tid == 0) mg_n = 0;
         __syncthreads();
-        for (int j = 0; j < n_pieces; ++j) {
-            const int piece = s * n_pieces + j;
+        const int4 sr = split_rows[s];
+        for (int j = 0; j < sr.z; ++j) {
+            const int piece = sr.y + j;
             const int n = part_counts[piece];
             int base = 0;
             if (tid == 0) { base = mg_n; mg_n = base + n; }
@@ -220,7 +232,7 @@ __global__ __launch_bounds__(256) void sp_merge_pieces_kernel(const int *__restr
                 }
             }
         }
-        const int slot = split_rows[s];
+        const int slot = sr.x;
         const int n_out = min(n, k);
         const long long o = (long long)slot * (long long)k;
         for (int j = tid; j < k; j += 256) {
