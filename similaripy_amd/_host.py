@@ -320,7 +320,23 @@ def filter_matrix_columns(data, indices, indptr, n_cols: int, keep_cols: np.ndar
 # output assembly (utils.pyx:43-173, coo_to_csr.h:28-71)
 # --------------------------------------------------------------------------------------------
 def build_coo(rows, cols, values, n_rows: int, n_cols: int) -> sp.coo_array:
-    """COO over the raw slot arrays, zero padding included (utils.pyx:43-64; SURVEY A.3 #2)."""
+    """COO over the raw slot arrays, zero padding included (utils.pyx:43-64).
+    The arrays come from the kernel (indices in range by construction): they are attached to an empty matrix instead of
+    going through the constructor, whose validation takes the minimum and maximum of both index arrays (50 ms at 10^8
+    entries).  Any scipy without these attributes gets the constructor."""
+    if (rows.dtype == np.int32 and cols.dtype == np.int32 and values.dtype == np.float32 and rows.ndim == 1
+            and rows.shape == cols.shape == values.shape and max(n_rows, n_cols) <= np.iinfo(np.int32).max):
+        try:
+            res = sp.coo_array((n_rows, n_cols), dtype=np.float32)
+            if not hasattr(res, "coords"):
+                raise AttributeError("coords")
+            res.coords = (rows, cols)
+            res.data = values
+            res.has_canonical_format = False
+            if res.nnz == values.shape[0] and res.shape == (n_rows, n_cols):
+                return res
+        except Exception:       # noqa: BLE001  (an older / newer scipy: the documented way)
+            pass
     return sp.coo_array((values, (rows, cols)), shape=(n_rows, n_cols), dtype=np.float32)
 
 

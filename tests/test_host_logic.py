@@ -201,6 +201,21 @@ def test_csc_matrix1_takes_the_direct_route(fn, kw, oracle_backend):
     np.testing.assert_allclose(getattr(sim, fn)(perm, k=6, verbose=False, format_output="csr", **kw).toarray(), b.toarray(), rtol=1e-6, atol=0)
 
 
+def test_coo_attached_without_the_constructor_equals_the_constructed_one():
+    rng = np.random.default_rng(0)
+    rows = np.repeat(np.arange(50, dtype=np.int32), 4)
+    cols = rng.integers(0, 70, 200).astype(np.int32)
+    vals = rng.random(200, dtype=np.float32)
+    a = _host.build_coo(rows, cols, vals, 50, 70)
+    b = sp.coo_array((vals, (rows, cols)), shape=(50, 70), dtype=np.float32)
+    assert isinstance(a, sp.coo_array) and a.shape == b.shape and a.nnz == b.nnz == 200 and a.dtype == np.float32
+    assert a.row.dtype == b.row.dtype and np.array_equal(a.row, b.row) and np.array_equal(a.col, b.col) and np.array_equal(a.data, b.data)
+    assert (a.tocsr() != b.tocsr()).nnz == 0 and np.allclose((a @ np.ones(70, np.float32)), (b @ np.ones(70, np.float32)))
+    # arrays that are not what the kernel returns take the constructor
+    c = _host.build_coo(rows.astype(np.int64), cols.astype(np.int64), vals, 50, 70)
+    assert (c.tocsr() != b.tocsr()).nnz == 0
+
+
 def test_csr_and_coo_assembly():
     targets = np.array([4, 1, 1], dtype=np.int32)           # unsorted, repeated
     k = 3
