@@ -77,6 +77,11 @@ struct KParams {
     const int *splits;     // generic kernel, optional: [n_rows_m2][n_splits] position of the first entry of m2 row u with column >= (j+1)*split_w
     int n_splits;          //   (the boundaries of the fine windows, found once per call instead of once per use)
     int split_w;           //   fine window width: 2T / f, f in {1, 2, 4}; standard dense windows start at multiples of 2T
+    // register-resident row kernel (sp_rowreg_kernel.hpp): its own queue of row descriptors and the rows' precomputed work items
+    const int4 *desc_r;        // [rr_cap * 2] same records as `desc`
+    const int4 *items_g;       // [rr_cap][RR_STRIDE] header {items, lanes of the first 16 items, 0, 0} + the items in wave-major order
+    unsigned int *rq;          // [0] next queue position (dynamic scheduling), [1] rows in the queue
+    int rr_cap;                // queue capacity (rows beyond it were classified for the bitmap kernel)
     unsigned long long *phase_cycles;  // optional [PH_N]
     int dbg;               // ablation bits for profiling only (results are WRONG when non-zero; 8 / 16: sweep 1 / sweep 2 of the sparse kernel
                            // load but do not process — compiled in only with -DSP_ABLATION=1: the test costs the sweeps 1 %):
@@ -752,6 +757,15 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// Workgroup barrier of the row kernels.  LDS_ONLY: waits for this wave's LDS operations only — not for its global loads,
+// which the register-resident row kernel keeps in flight across whole phases (__syncthreads() is a workgroup-scope
+// fence and would drain vmcnt too); everything the waves of a row exchange goes through LDS.
+template <bool LDS_ONLY>
+__device__ __forceinline__ void wg_sync() {
+    if constexpr (LDS_ONLY) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else __syncthreads();
+}
+
 // Selection for candidate buffers of at most E*NT entries: every thread keeps its (<= E) entries in registers,
 // one LDS histogram per radix pass (hist4 = 4 x 256 counters, zero on entry and on exit), every wave scans the
 // histogram redundantly (no broadcast barrier), 1 barrier per pass.
@@ -766,12 +780,13 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
 // second digit: the entries whose first byte exceeds the hint's are only counted, the others of its byte go straight
 // into the second histogram — one radix pass (fill, two barriers, walk) less whenever the k-th largest shares the
 // hint's first byte, which is the rule (else: the regular four passes).
-template <int NT, bool ZERO_TAIL = false, int E = 4>
-__device__ long long select_fast(u64 *U, int *hist4, int *sh, int k, bool exact, unsigned hint = 0u) {
-    const int tid = threadIdx.x, lane = tid & 63;
+template <int NT, bool ZERO_TAIL = false, int E = 4, bool LDSBAR = false>
+__device__ long long select_fast(u64 *U, int *hist4, int *sh, int k, bool exact, unsigned hint = 0u, int tid_in = -1) {
+    // (tid_in: a caller that keeps its thread id opaque to stop address computations from being hoisted out of its row loop)
+    const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x, lane = tid & 63;
     const int n = min(sh[SH_CNT], E * NT);
     if (tid == 0) { sh[SH_CNT2] = 0; sh[SH_EQ] = 0; sh[SH_NHI] = 0; }   // (the generic path's selection leaves them dirty)
-    __syncthreads();
+    wg_sync<LDSBAR>();
     if (n <= k) return -1;
     u64 e[E];
     unsigned key[E];
@@ -802,7 +817,7 @@ __device__ long long select_fast(u64 *U, int *hist4, int *sh, int k, bool exact,
         }
         const int tot = wave_incl_scan_dpp(mine);
         if (lane == 63 && tot) atomicAdd(&sh[SH_NHI], tot);
-        __syncthreads();
+        wg_sync<LDSBAR>();
         const int both = sh[SH_NHI];
         const int n_hi = both & 0xFFFF, n_top = both >> 16;
         if (n_hi < k && k - n_hi <= n_top) {
@@ -813,7 +828,7 @@ __device__ long long select_fast(u64 *U, int *hist4, int *sh, int k, bool exact,
             passes = 1;
         } else {                     // the k-th largest is not in the hint's byte: regular passes
             for (int i = tid; i < 256; i += NT) h1[i] = 0;
-            __syncthreads();
+            wg_sync<LDSBAR>();
         }
     }
     for (int ps = first_ps; ps < 4; ++ps) {
@@ -824,7 +839,7 @@ __device__ long long select_fast(u64 *U, int *hist4, int *sh, int k, bool exact,
 #pragma unroll
             for (int j = 0; j < E; ++j)
                 if (has[j] && ((key[j] ^ prefix) & hmask) == 0u) atomicAdd(&h[(key[j] >> shift) & 255u], 1);
-            __syncthreads();
+            wg_sync<LDSBAR>();
         }
         // ONE wave walks the histogram (the others would only repeat the same instructions) and publishes the digit
         if (tid < 64) {
@@ -849,7 +864,7 @@ __device__ long long select_fast(u64 *U, int *hist4, int *sh, int k, bool exact,
                 sh[SH_STOP] = (!exact && ps == 1 && 2 * (kept - k) <= (n - k)) ? 1 : 0;
             }
         }
-        __syncthreads();
+        wg_sync<LDSBAR>();
         prefix |= (unsigned)sh[SH_SEL] << shift;
         need = sh[SH_NEED];
         passes = ps + 1;
@@ -872,7 +887,7 @@ __device__ long long select_fast(u64 *U, int *hist4, int *sh, int k, bool exact,
             if (keep) U[wbase + mbcnt64(m)] = e[j];
         }
     }
-    __syncthreads();
+    wg_sync<LDSBAR>();
     if (ZERO_TAIL) {
         const int kept = sh[SH_CNT2];
 #pragma unroll
@@ -883,7 +898,7 @@ __device__ long long select_fast(u64 *U, int *hist4, int *sh, int k, bool exact,
     }
     for (int i = tid; i < passes * 256; i += NT) hist4[i] = 0;
     if (tid == 0) sh[SH_CNT] = sh[SH_CNT2];
-    __syncthreads();
+    wg_sync<LDSBAR>();
     return (long long)prefix;
 }
 
