@@ -84,9 +84,6 @@ extern "C" {
                                      (_build_squared_norms s_plus_utils.pyx:169-201 as sp_csr_row_sqsums_f32 does, sp_prep.h;
                                      _build_cosine_normalization :204-228 with norm_c1 / norm_c2 / norm_add) */
 
-/* ABI 4 */
-#define SP_FLAG_NO_ROWREG   16384u /* never use the register-resident row kernel (A/B testing): its rows go to the bitmap kernel */
-
 typedef struct sp_knn_args {
     uint32_t struct_size;      /* = sizeof(sp_knn_args); checked */
     uint32_t flags;            /* SP_FLAG_* */
@@ -153,13 +150,13 @@ typedef struct sp_knn_args {
                                   [0] row setup  [1] generic: segment scan | sparse: item list, bitmap clear + rank prefix
                                   [2] generic: accumulate | sparse: member products into the collision set
                                   [3] judge (column terms, epilogue, top-k buffer)  [4] selections  [5] write-out
-                                  [6] sparse sweep 1  [7] sparse sweep 2  [8] rows finished by the register-resident row kernel (a count); then event counts:
-                                  [9] rows finished by the two sparse kernels  [10] rows it handed to the generic kernel
+                                  [6] sparse sweep 1  [7] sparse sweep 2  [8] unused; then event counts:
+                                  [9] rows finished by the sparse kernel  [10] rows it handed to the generic kernel
                                   [11] generic column windows */
     int32_t num_wgs_used;      /* OUT with SP_FLAG_TIME_KERNEL */
-    int32_t rowreg_kernel_us;  /* OUT with SP_FLAG_TIME_KERNEL (ABI 4): duration of the register-resident row kernel of this call, microseconds */
+    int32_t _pad1;
     int64_t reserved[4];       /* [0] IN: kernel ablation bits, profiling only (0 in production)
-                                  [1], [2] OUT with SP_FLAG_TIME_KERNEL: duration of the bitmap (sparse) / generic row kernel of this
+                                  [1], [2] OUT with SP_FLAG_TIME_KERNEL: duration of the sparse / generic row kernel of this
                                   call in microseconds (hipEvents on `stream` around each launch)
                                   [3] OUT with SP_FLAG_TIME_KERNEL | SP_FLAG_M2_IS_M1_T: duration of the transpose, microseconds
                                   (kernel_ms includes it) */
@@ -199,7 +196,7 @@ const char *sp_last_error(void);
 int64_t sp_device_cache_trim(void);
 
 /* ABI version of this header. */
-#define SP_KNN_ABI_VERSION 4
+#define SP_KNN_ABI_VERSION 3
 int sp_abi_version(void);
 
 #ifdef __cplusplus

@@ -1,0 +1,41 @@
+"""C2-shaped problem (1M x 100k, 64 per row, cosine k=100) over the first N target rows, kernel-scope: which row kernel
+served the rows, how long it took, where the cycles went, parity on a sample.  `python scripts/rowreg_probe.py N [no_rowreg] [static]`"""
+import sys, json, copy
+import numpy as np
+sys.path.insert(0, '.')
+import torch
+from similaripy_amd import _host
+from similaripy_amd.device import DeviceProblem
+from similaripy_amd.workloads import fixed_degree_csr
+from oracle import splus_oracle as so
+
+n_t = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+tun = dict(no_rowreg=("no_rowreg" in sys.argv), dbg=next((int(a[4:]) for a in sys.argv if a.startswith("dbg=")), 0))
+static = "static" in sys.argv
+m = fixed_degree_csr(1_000_000, 100_000, 64, 12345)
+k = 100
+call = _host.prepare(m, k=k, l2=1, c1=0.5, c2=0.5, target_rows=np.arange(n_t))
+prob = DeviceProblem(call)
+cols, vals, counts, _ = prob.alloc_outputs()
+print("launch", n_t, tun, flush=True)
+prob.run(cols, vals, counts, static_sched=static, **tun); torch.cuda.synchronize()
+print("first pass done", flush=True)
+i1 = prob.run(cols, vals, counts, time_kernel=True, phase_timers=False, static_sched=static, **tun)
+i2 = prob.run(cols, vals, counts, time_kernel=True, static_sched=static, **tun)
+ph = i2["phase_cycles"]
+names = ("setup", "segments", "accumulate", "drain", "select", "output", "sweep1", "sweep2", "idswait")
+print(json.dumps({"rows": n_t, "call_ms": i1["kernel_ms"], "rowreg_ms": i1["rowreg_kernel_ms"], "sparse_ms": i1["sparse_kernel_ms"], "generic_ms": i1["generic_kernel_ms"],
+                  "rows_rowreg": i2["rows_rowreg"], "rows_sparse_both": ph[9], "given_up": ph[10]}), flush=True)
+tot = float(sum(ph[:9]))
+print("   cycles/row %.0f: " % (tot / n_t) + "  ".join(f"{n}={c / n_t:.0f}" for n, c in zip(names, ph[:9])), flush=True)
+if tun["dbg"]:
+    sys.exit(0)
+sample = np.sort(np.random.default_rng(1).choice(n_t, min(n_t, 150), replace=False)).astype(np.int32)
+c2 = copy.copy(call); c2.targets = sample
+want = so.canonical(*so.run_kernel(c2, "port"), sample, k)
+hc, hv, hn = cols.cpu().numpy(), vals.cpu().numpy(), counts.cpu().numpy()
+got = []
+for t in sample:
+    n = hn[t]; cc = hc[t*k:t*k+n]; vv = hv[t*k:t*k+n]; o = np.argsort(cc); got.append((cc[o], vv[o]))
+ties = so.compare_topk(got, want, k, rtol=1e-5, atol=1e-7, what="probe")
+print(f"   parity OK on {len(sample)} rows (boundary ties {ties})", flush=True)

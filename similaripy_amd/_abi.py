@@ -28,7 +28,6 @@ SP_FLAG_P3_PREP = 1024
 SP_FLAG_DEPOP_ROWSUM = 2048
 SP_FLAG_M1_IS_M2_T = 4096
 SP_FLAG_NORMS_ON_DEVICE = 8192
-SP_FLAG_NO_ROWREG = 16384
 SP_EZEROS = -6
 SP_EUNSORTED = -7
 SP_NORM_L1, SP_NORM_L2, SP_NORM_MAX, SP_NORM_TFIDF, SP_NORM_BM25PLUS = range(5)
@@ -100,7 +99,7 @@ class SpKnnArgs(C.Structure):
         ("passes_total", C.c_int32),
         ("phase_cycles", C.c_int64 * 12),
         ("num_wgs_used", C.c_int32),
-        ("rowreg_kernel_us", C.c_int32),
+        ("_pad1", C.c_int32),
         ("reserved", C.c_int64 * 4),
         ("p3_alpha", C.c_float),
         ("depop_p2", C.c_float),

@@ -52,7 +52,8 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         return LIB_PATH
     LIB_DIR.mkdir(parents=True, exist_ok=True)
     tmp = LIB_PATH.with_suffix(".so.tmp%d" % os.getpid())
-    cmd = [find_hipcc(), *HIPCC_FLAGS, "-I", str(REPO_DIR / "include"), "-o", str(tmp), *map(str, srcs)]
+    extra = os.environ.get("SIMILARIPY_AMD_HIPCC_EXTRA", "").split()      # profiling builds only, e.g. -DSP_ABLATION=1
+    cmd = [find_hipcc(), *HIPCC_FLAGS, *extra, "-I", str(REPO_DIR / "include"), "-o", str(tmp), *map(str, srcs)]
     if verbose:
         print(" ".join(cmd))
     proc = subprocess.run(cmd, capture_output=True, text=True)

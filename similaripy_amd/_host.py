@@ -551,7 +551,7 @@ def selected_device() -> int:
 def run_hip(call: KernelCall, device: Optional[int] = None, table_slots: int = 0, threads_per_wg: int = 0,
             num_wgs: int = 0, load_pct: int = 0, time_kernel: bool = False, static_sched: bool = False,
             no_sparse_path: bool = False, no_fold: bool = False, want_rows: bool = True,
-            check_zeros: bool = False, csr_out: bool = False, dbg: int = 0, no_rowreg: bool = False):
+            check_zeros: bool = False, csr_out: bool = False, dbg: int = 0):
     """The `with nogil:` block of s_plus.pyx:359-384, on the GPU: host buffers in, host buffers out
     through the C ABI (include/sp_knn.h).  Returns rows, cols, values, counts[, info].
 
@@ -570,7 +570,6 @@ def run_hip(call: KernelCall, device: Optional[int] = None, table_slots: int = 0
     a = _abi.SpKnnArgs()
     a.flags = ((0 if want_rows else _abi.SP_FLAG_NO_ROWS_OUT) | (_abi.SP_FLAG_TIME_KERNEL | _abi.SP_FLAG_PHASE_TIMERS if time_kernel else 0) | (_abi.SP_FLAG_STATIC_SCHED if static_sched else 0)
                | (_abi.SP_FLAG_NO_SPARSE_PATH if no_sparse_path else 0) | (_abi.SP_FLAG_NO_FOLD if no_fold else 0)
-               | (_abi.SP_FLAG_NO_ROWREG if no_rowreg else 0)
                | (_abi.SP_FLAG_CHECK_ZEROS if check_zeros else 0) | (_abi.SP_FLAG_CSR_OUT if csr_out else 0))
     if call.p3_alpha is not None:
         a.flags |= _abi.SP_FLAG_P3_PREP
@@ -624,8 +623,7 @@ def run_hip(call: KernelCall, device: Optional[int] = None, table_slots: int = 0
         return csr_indptr, cols[:nnz], values[:nnz]
     if time_kernel:
         return rows, cols, values, counts, {"kernel_ms": float(a.kernel_ms), "passes_total": int(a.passes_total), "phase_cycles": [int(x) for x in a.phase_cycles], "num_wgs": int(a.num_wgs_used),
-                                             "sparse_kernel_ms": int(a.reserved[1]) / 1e3, "generic_kernel_ms": int(a.reserved[2]) / 1e3, "transpose_ms": int(a.reserved[3]) / 1e3,
-                                             "rowreg_kernel_ms": int(a.rowreg_kernel_us) / 1e3}
+                                             "sparse_kernel_ms": int(a.reserved[1]) / 1e3, "generic_kernel_ms": int(a.reserved[2]) / 1e3, "transpose_ms": int(a.reserved[3]) / 1e3}
     return rows, cols, values, counts
 
 

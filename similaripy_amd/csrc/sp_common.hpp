@@ -77,11 +77,6 @@ struct KParams {
     const int *splits;     // generic kernel, optional: [n_rows_m2][n_splits] position of the first entry of m2 row u with column >= (j+1)*split_w
     int n_splits;          //   (the boundaries of the fine windows, found once per call instead of once per use)
     int split_w;           //   fine window width: 2T / f, f in {1, 2, 4}; standard dense windows start at multiples of 2T
-    // register-resident row kernel (sp_rowreg_kernel.hpp): its own queue of row descriptors and the rows' precomputed work items
-    const int4 *desc_r;        // [rr_cap * 2] same records as `desc`
-    const int4 *items_g;       // [rr_cap][RR_STRIDE] header {items, lanes of the first 16 items, 0, 0} + the items in wave-major order
-    unsigned int *rq;          // [0] next queue position (dynamic scheduling), [1] rows in the queue
-    int rr_cap;                // queue capacity (rows beyond it were classified for the bitmap kernel)
     unsigned long long *phase_cycles;  // optional [PH_N]
     int dbg;               // ablation bits for profiling only (results are WRONG when non-zero; 8 / 16: sweep 1 / sweep 2 of the sparse kernel
                            // load but do not process — compiled in only with -DSP_ABLATION=1: the test costs the sweeps 1 %):
@@ -425,6 +420,9 @@ __device__ __forceinline__ unsigned emit_candidates(const KParams &p, const RowC
 // helpers of the sparse path
 // ---------------------------------------------------------------------------------------------
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x32 __attribute__((ext_vector_type(32)));
 
 constexpr int ITEM = 256;         // m2 elements per work item: one 16-byte load per lane
 constexpr int ITEM_CAP = 1008;    // work items per row (LDS: 16 B each) of a 1024-thread workgroup

@@ -37,7 +37,6 @@
 #include "sp_prep_kernels.hpp"
 #include "sp_rowops.hpp"
 #include "sp_sparse_kernel.hpp"
-#include "sp_rowreg_kernel.hpp"
 #include "sp_generic_kernel.hpp"
 
 // ---------------------------------------------------------------------------------------------
@@ -109,31 +108,21 @@ struct Config {
     int split_pmax;         // heavy generic rows are queued as up to this many pieces (ranges of fine windows), 0 = off
     int split_cap;          // at most this many rows
     size_t ws_piece_bytes;  // split_rows[cap] | piece_info[cap * pmax] | part_counts[cap * pmax] | part_cols / part_vals [cap * pmax * k]
-    bool rowreg;            // the register-resident row kernel takes the rows that fit it (sp_rowreg_kernel.hpp)
-    int rr_cap;             //   its queue capacity in rows
-    int wgs_rowreg;
-    size_t lds_rowreg;
-    size_t ws_rr_bytes;     //   nitems[n] | its descriptor queue | the rows' work items
-    size_t ws_rr_desc_offset, ws_rr_items_offset;
     bool fold;
     bool mono;              // the sparse kernel's monotone variant applies (val = xy / den or the raw dot, no per-row target selector)
     bool ordered;
 };
 
-// workspace header: [0,8) queue heads sparse/generic | [8,16) queue lengths sparse/generic | [16,24) split rows / pieces handed out |
-// [24,32) register-resident kernel: queue head, queue length | [64,160) phase counters |
+// workspace header: [0,8) queue heads sparse/generic | [8,16) queue lengths sparse/generic | [64,160) phase counters |
 // [176,188) column-term minima
 constexpr size_t WS_QUEUE_BYTES = 256;
 constexpr size_t WS_PHASE_OFFSET = 64;
 constexpr size_t WS_YMIN_OFFSET = 176;
-constexpr size_t WS_RQ_OFFSET = 24;      // register-resident row kernel: next queue position, rows in its queue
 static_assert(WS_PHASE_OFFSET + PH_N * 8 <= WS_YMIN_OFFSET && WS_YMIN_OFFSET + 16 <= WS_QUEUE_BYTES, "workspace header layout");
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
 // LDS of the two kernels without the candidate buffer (see their carve-ups)
 size_t lds_fixed_sparse(int T, int NT) { return (size_t)T * 8 + (size_t)item_cap(NT) * 16 + 4096 + CBM_BYTES + PRE_BYTES + 32 * 4 + 16 * 8; }   // (its candidate buffer lives inside region A)
-size_t lds_fixed_rowreg(int T) { return (size_t)T * 8 + 4096 + CBM_BYTES + PRE_BYTES + 32 * 4 + 16 * 8; }                          // (no item list: the items live in registers)
-constexpr int RR_ROWS_MAX = 1 << 21;     // rows whose items are cut per call (3.6 KB each); rows beyond stay with the bitmap kernel
 size_t lds_fixed_generic(int T, int NT) { return (size_t)T * 8 + (size_t)16 * NT + 256 + 256 * 4 + 64 * 4 + 32 * 4 + 16 * 8; }
 
 int make_config(const sp_knn_args *a, int n_cus, Config *c) {
@@ -233,20 +222,7 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
             c->ws_rows_bytes += (np * 32 + 255) & ~(size_t)255;       // room for the extra entries of the generic queue (the last array of that block)
         }
     }
-    // register-resident row kernel: monotone epilogue, the 1024-thread shape with the candidate buffer in LDS, k within what its
-    // selection-free first stage handles
-    c->rowreg = c->mono && NT_s == RR_NT && T_s == 16384 && u_lds_s && a->k <= RR_KMAX && !(a->flags & (SP_FLAG_NO_ROWREG | SP_FLAG_NO_SPARSE_PATH)) &&
-                a->nnz_m2 > 0 && (size_t)a->nnz_m2 * 4 < ((size_t)1 << 32);
-    c->rr_cap = 0; c->wgs_rowreg = 0; c->lds_rowreg = 0; c->ws_rr_bytes = 0; c->ws_rr_desc_offset = 0; c->ws_rr_items_offset = 0;
-    if (c->rowreg) {
-        c->rr_cap = std::min(a->n_targets, RR_ROWS_MAX);
-        c->lds_rowreg = lds_fixed_rowreg(T_s);
-        c->wgs_rowreg = wgs_for(c->lds_rowreg, RR_NT);
-        c->ws_rr_desc_offset = ((size_t)a->n_targets * 4 + 31) & ~(size_t)31;
-        c->ws_rr_items_offset = c->ws_rr_desc_offset + (size_t)c->rr_cap * 64;
-        c->ws_rr_bytes = (c->ws_rr_items_offset + (size_t)c->rr_cap * RR_STRIDE * 16 + 255) & ~(size_t)255;
-    }
-    c->ws_total = WS_QUEUE_BYTES + c->ws_gu_bytes + c->ws_fold_bytes + c->ws_rows_bytes + c->ws_split_bytes + c->ws_piece_bytes + c->ws_rr_bytes;
+    c->ws_total = WS_QUEUE_BYTES + c->ws_gu_bytes + c->ws_fold_bytes + c->ws_rows_bytes + c->ws_split_bytes + c->ws_piece_bytes;
     return SP_OK;
 }
 
@@ -309,13 +285,6 @@ int launch_sparse(const KParams &kp, const Config &c, hipStream_t stream) {
     return SP_OK;
 }
 
-int launch_rowreg(const KParams &kp, const Config &c, hipStream_t stream) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(sp_knn_rowreg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds_rowreg));
-    hipLaunchKernelGGL(sp_knn_rowreg_kernel, dim3(c.wgs_rowreg), dim3(RR_NT), c.lds_rowreg, stream, kp);
-    HIP_TRY(hipGetLastError());
-    return SP_OK;
-}
-
 template <int NT>
 int launch_generic(const KParams &kp, const Config &c, hipStream_t stream) {
     auto kg = c.big ? (c.u_lds ? sp_knn_generic_kernel<NT, true, true> : sp_knn_generic_kernel<NT, false, true>)
@@ -327,14 +296,8 @@ int launch_generic(const KParams &kp, const Config &c, hipStream_t stream) {
 }
 
 // kp_s: the sparse kernel's parameters (its own tile), kp: the generic kernel's
-int launch_rows(const KParams &kp_s, const KParams &kp, const Config &c, hipStream_t stream, hipEvent_t *ev /* [6] or NULL: around the three row kernels */) {
-    // sparse rows first (register-resident kernel, then the bitmap kernel); what they cannot finish joins the generic queue, which the last launch drains
-    if (ev) HIP_TRY(hipEventRecord(ev[4], stream));
-    if (kp.sparse_path && c.rowreg) {
-        int rc = launch_rowreg(kp_s, c, stream);
-        if (rc) return rc;
-    }
-    if (ev) HIP_TRY(hipEventRecord(ev[5], stream));
+int launch_rows(const KParams &kp_s, const KParams &kp, const Config &c, hipStream_t stream, hipEvent_t *ev /* [4] or NULL: around the two row kernels */) {
+    // sparse rows first; what it cannot finish joins the generic queue, which the second launch drains
     if (ev) HIP_TRY(hipEventRecord(ev[0], stream));
     if (kp.sparse_path) {
         int rc;
@@ -391,7 +354,6 @@ int run_device_impl(sp_knn_args *a) {
     unsigned char *ws_rows = ws_fold + c.ws_fold_bytes;
     int *ws_split = (int *)(ws_rows + c.ws_rows_bytes);
     unsigned char *ws_piece = (unsigned char *)ws_split + c.ws_split_bytes;
-    unsigned char *ws_rr = ws_piece + c.ws_piece_bytes;
 
     // minima of the column-term vectors feed the gather-free upper bound (Epi::upper); it is sound only
     // when every weight / shrink is non-negative (NaN parameters fail the comparisons and disable it)
@@ -457,9 +419,8 @@ int run_device_impl(sp_knn_args *a) {
         int4 *desc_g = desc_s + 2 * (size_t)a->n_targets;               // [2n]
         HIP_TRY(hipMemsetAsync(ws_rows, 0, 512, stream));
         const int work_blocks = std::max(1, std::min((a->n_targets + 15) / 16, n_cus * 8));     // 16 rows (waves) per block and trip
-        unsigned *rr_nitems = c.rowreg ? (unsigned *)ws_rr : nullptr;
         hipLaunchKernelGGL(sp_row_work_kernel, dim3(work_blocks), dim3(1024), 0, stream,
-                           a->n_targets, a->targets, a->m1_indices, a->m1_indptr, a->m2_indptr, work, bucket_count, rr_nitems);
+                           a->n_targets, a->targets, a->m1_indices, a->m1_indptr, a->m2_indptr, work, bucket_count);
         if (c.ordered) {
             hipLaunchKernelGGL(sp_bucket_base_kernel, dim3(1), dim3(64), 0, stream, bucket_count, bucket_base);
             hipLaunchKernelGGL(sp_row_order_kernel, dim3((a->n_targets + 255) / 256), dim3(256), 0, stream, a->n_targets, work, bucket_base, order);
@@ -471,8 +432,6 @@ int run_device_impl(sp_knn_args *a) {
         cp.mono = c.mono ? 1 : 0;
         cp.any_norm = (a->l1 != 0.f || a->l2 != 0.f || a->l3 != 0.f || a->stabilized_shrink != 0.f || a->bayesian_shrink != 0.f) ? 1 : 0;
         cp.l2 = a->l2; cp.l3 = a->l3;
-        cp.rowreg = (c.rowreg && kp.sparse_path) ? 1 : 0; cp.rr_min = RR_NW; cp.rr_max = RR_ICAP; cp.rr_cap = c.rr_cap;
-        cp.nitems = rr_nitems; cp.rq = (unsigned *)(ws + WS_RQ_OFFSET); cp.desc_r = c.rowreg ? (int4 *)(ws_rr + c.ws_rr_desc_offset) : nullptr;
         cp.split_fine = 0; cp.split_pmax = 0; cp.split_macs = 0u; cp.split_cap = 0; cp.split_count = nullptr; cp.split_rows = nullptr; cp.piece_info = nullptr;
         if (c.split_pmax) {
             const size_t np = (size_t)c.split_cap * (size_t)c.split_pmax;
@@ -494,15 +453,6 @@ int run_device_impl(sp_knn_args *a) {
         HIP_TRY(hipGetLastError());
         kp.desc = desc_s;
         kp.desc_g = desc_g;
-        kp.rq = cp.rq; kp.rr_cap = c.rr_cap; kp.desc_r = cp.desc_r; kp.items_g = nullptr;
-        if (cp.rowreg) {
-            int4 *items_g = (int4 *)(ws_rr + c.ws_rr_items_offset);
-            const int item_blocks = std::max(1, std::min((c.rr_cap + 3) / 4, n_cus * 32));     // 4 rows (waves) per block and trip
-            hipLaunchKernelGGL(sp_row_items_kernel, dim3(item_blocks), dim3(256), 0, stream, (const unsigned *)cp.rq, c.rr_cap, (const int4 *)cp.desc_r,
-                               a->m1_indices, a->m1_data, a->m2_indptr, items_g);
-            HIP_TRY(hipGetLastError());
-            kp.items_g = items_g;
-        }
     }
     kp.m2_bytes = (unsigned)((size_t)a->nnz_m2 * 4);
     kp.nb_log2 = c.nb_log2;
@@ -529,8 +479,8 @@ int run_device_impl(sp_knn_args *a) {
     kp.phase_cycles = (timed && (a->flags & SP_FLAG_PHASE_TIMERS)) ? (unsigned long long *)(ws + WS_PHASE_OFFSET) : nullptr;   // inside the zeroed header
     kp.dbg = (int)a->reserved[0];
 
-    hipEvent_t kev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    if (timed) { for (int i = 0; i < 6; ++i) TRY(guard.event(&kev[i])); }
+    hipEvent_t kev[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (timed) { for (int i = 0; i < 4; ++i) TRY(guard.event(&kev[i])); }
     KParams kp_s = kp;
     kp_s.T = c.T_s; kp_s.logT = c.logT_s;
     rc = launch_rows(kp_s, kp, c, stream, timed ? kev : nullptr);
@@ -559,11 +509,8 @@ int run_device_impl(sp_knn_args *a) {
         float ks_ms = 0.f, kg_ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ks_ms, kev[0], kev[1]));
         HIP_TRY(hipEventElapsedTime(&kg_ms, kev[2], kev[3]));
-        float kr_ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&kr_ms, kev[4], kev[5]));
-        a->reserved[1] = (int64_t)(ks_ms * 1000.0f);      // bitmap (sparse) row kernel, microseconds
+        a->reserved[1] = (int64_t)(ks_ms * 1000.0f);      // sparse row kernel, microseconds
         a->reserved[2] = (int64_t)(kg_ms * 1000.0f);      // generic row kernel, microseconds
-        a->rowreg_kernel_us = (int32_t)(kr_ms * 1000.0f); // register-resident row kernel, microseconds
     }
     return SP_OK;      // (the guard waits for the stream before it frees an owned workspace)
 }

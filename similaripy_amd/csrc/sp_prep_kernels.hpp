@@ -13,7 +13,7 @@ namespace {
 // the end (a single global word only sustains ~88 atomics/us; one atomic per row-block cost 2.8 ms on 1M rows).
 __global__ __launch_bounds__(1024) void sp_row_work_kernel(int n_targets, const int *targets, const int *m1_indices,
                                                             const int *m1_indptr, const int *m2_indptr, unsigned *work,
-                                                            unsigned *bucket_count, unsigned *nitems /* optional: work items of the row (sp_rowreg_kernel.hpp) */) {
+                                                            unsigned *bucket_count) {
     __shared__ unsigned hist[32];
     if (threadIdx.x < 32) hist[threadIdx.x] = 0;
     __syncthreads();
@@ -23,17 +23,13 @@ __global__ __launch_bounds__(1024) void sp_row_work_kernel(int n_targets, const 
         const int t = targets[gw];
         const int s = m1_indptr[t], e = m1_indptr[t + 1];
         u64 acc = 0;
-        unsigned nit = 0;       // items of <= ITEM elements, one list per non-empty m2 row
         for (int j = s + lane; j < e; j += 64) {
             const int u = m1_indices[j];
-            const unsigned len = (unsigned)(m2_indptr[u + 1] - m2_indptr[u]);
-            acc += (u64)len;
-            nit += (len + ITEM - 1) / ITEM;
+            acc += (u64)(m2_indptr[u + 1] - m2_indptr[u]);
         }
 #pragma unroll
-        for (int d = 32; d > 0; d >>= 1) { acc += __shfl_xor(acc, d, 64); nit += __shfl_xor(nit, d, 64); }
+        for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
         if (lane == 0) {
-            if (nitems) nitems[gw] = nit;
             const unsigned w = acc > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)acc;
             work[gw] = w;
             atomicAdd(&hist[31 - __clz((int)(w | 1u))], 1u);
@@ -100,12 +96,6 @@ struct ClassifyParams {
     int *split_count;          // [2] rows split so far, pieces handed out so far (zero on entry)
     int4 *split_rows;          // [split_cap] {output slot, first piece, pieces, 0}
     int2 *piece_info;          // [split_cap * split_pmax] {output slot, first fine window | one past the last << 16}
-    // rows the register-resident kernel takes (sp_rowreg_kernel.hpp): sparse rows of <= 64 m1 entries and rr_min .. rr_max items
-    int rowreg;                // 0 = off
-    int rr_min, rr_max, rr_cap;
-    const unsigned *nitems;    // [n_targets] items per row (sp_row_work_kernel)
-    unsigned *rq;              // [1] = rows queued so far
-    int4 *desc_r;              // [rr_cap * 2]
 };
 
 __global__ __launch_bounds__(256) void sp_row_desc_kernel(int n_targets, const int *targets, const int *m1_indptr, const unsigned *work,
@@ -116,7 +106,7 @@ __global__ __launch_bounds__(256) void sp_row_desc_kernel(int n_targets, const i
     const int lane = threadIdx.x & 63;
     const bool valid = pos < n_targets;
     int4 d0 = make_int4(0, 0, 0, 0), d1 = d0;
-    bool sparse = false, rowreg = false;
+    bool sparse = false;
     if (valid) {
         const int slot = (ordered_flag != nullptr && ordered_flag[0] != 0u) ? order[pos] : pos;
         const int t = targets[slot];
@@ -139,30 +129,11 @@ __global__ __launch_bounds__(256) void sp_row_desc_kernel(int n_targets, const i
             const float alias = (cp.nb_log2 < 31 && (1 << cp.nb_log2) < cp.n_cols) ? 1.f / (float)(1 << cp.nb_log2) : 0.f;
             const float expect = 0.5f * m * m * (1.f / (float)cp.n_cols + alias);
             sparse = expect <= 0.30f * (float)cp.cs_slots;
-            if (sparse && cp.rowreg && (e - s) <= 64) {
-                const unsigned ni = cp.nitems[slot];
-                rowreg = ni >= (unsigned)cp.rr_min && ni <= (unsigned)cp.rr_max;
-            }
-        }
-    }
-    // register-resident queue first: rows beyond its capacity stay with the bitmap kernel
-    {
-        const u64 mr = __ballot(valid && rowreg);
-        unsigned br = 0;
-        if (lane == 0 && mr) br = atomicAdd(&cp.rq[1], (unsigned)__popcll(mr));
-        br = (unsigned)__builtin_amdgcn_readfirstlane((int)br);
-        if (valid && rowreg) {
-            const unsigned pos_r = br + (unsigned)__popcll(mr & ((1ull << lane) - 1ull));
-            if (pos_r < (unsigned)cp.rr_cap) {
-                cp.desc_r[2 * (size_t)pos_r] = d0;
-                cp.desc_r[2 * (size_t)pos_r + 1] = d1;
-                sparse = false;
-            } else rowreg = false;
         }
     }
     // heavy generic rows: one queue entry per piece
     int split_id = -1, n_pieces = 0, per_piece = 0, piece0 = 0;
-    if (valid && !sparse && !rowreg && cp.split_fine > 1 && (unsigned)d1.x >= 2u * cp.split_macs) {
+    if (valid && !sparse && cp.split_fine > 1 && (unsigned)d1.x >= 2u * cp.split_macs) {
         const int wanted = (int)min((unsigned)cp.split_pmax, ((unsigned)d1.x + cp.split_macs - 1u) / cp.split_macs);
         per_piece = (cp.split_fine + wanted - 1) / wanted;                  // fine windows per piece
         n_pieces = (cp.split_fine + per_piece - 1) / per_piece;
@@ -175,7 +146,7 @@ __global__ __launch_bounds__(256) void sp_row_desc_kernel(int n_targets, const i
             }
         }
     }
-    const int n_g = (valid && !sparse && !rowreg) ? (split_id >= 0 ? n_pieces : 1) : 0;     // generic queue entries of this lane
+    const int n_g = (valid && !sparse) ? (split_id >= 0 ? n_pieces : 1) : 0;     // generic queue entries of this lane
     const u64 ms = __ballot(valid && sparse);
     int incl = n_g;                                                                      // inclusive wave scan
 #pragma unroll
@@ -194,7 +165,7 @@ __global__ __launch_bounds__(256) void sp_row_desc_kernel(int n_targets, const i
             int4 *dst = desc_s + 2 * (size_t)(bs + (unsigned)__popcll(ms & below));
             dst[0] = d0;
             dst[1] = d1;
-        } else if (!rowreg) {
+        } else {
             int4 *dst = desc_g + 2 * (size_t)(bg + (unsigned)(incl - n_g));
             if (split_id < 0) { dst[0] = d0; dst[1] = d1; }
             else {

@@ -103,8 +103,6 @@ class DeviceProblem:
             flags |= _abi.SP_FLAG_NO_SPARSE_PATH
         if tuning.get("no_fold"):
             flags |= _abi.SP_FLAG_NO_FOLD
-        if tuning.get("no_rowreg"):
-            flags |= _abi.SP_FLAG_NO_ROWREG
         if tuning.get("no_row_order"):
             flags |= _abi.SP_FLAG_NO_ROW_ORDER
         with torch.cuda.device(self.device):
@@ -116,5 +114,4 @@ class DeviceProblem:
             a.workspace, a.workspace_bytes = self._ws.data_ptr(), self._ws.numel()
             _abi.call_knn(a)
         return {"kernel_ms": float(a.kernel_ms), "passes_total": int(a.passes_total), "phase_cycles": [int(x) for x in a.phase_cycles], "num_wgs": int(a.num_wgs_used),
-                "sparse_kernel_ms": int(a.reserved[1]) / 1e3, "generic_kernel_ms": int(a.reserved[2]) / 1e3, "transpose_ms": int(a.reserved[3]) / 1e3,
-                "rowreg_kernel_ms": int(a.rowreg_kernel_us) / 1e3}
+                "sparse_kernel_ms": int(a.reserved[1]) / 1e3, "generic_kernel_ms": int(a.reserved[2]) / 1e3, "transpose_ms": int(a.reserved[3]) / 1e3}
