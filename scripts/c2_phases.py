@@ -1,5 +1,6 @@
-"""C2-shaped problem (1M x 100k, 64 per row, cosine k=100) over the first N target rows, kernel-scope: which row kernel
-served the rows, how long it took, where the cycles went, parity on a sample.  `python scripts/rowreg_probe.py N [no_rowreg] [static]`"""
+"""C2-shaped problem (1M x 100k, 64 per row, cosine k=100; `c3` = the s_plus hybrid of configs[2]) over the first N target rows,
+kernel-scope: how long the row kernels took, where the cycles of a row went (in-kernel phase timers), parity on a sample.
+`python scripts/c2_phases.py N [c3] [static] [dbg=BITS]`"""
 import sys, json, copy
 import numpy as np
 sys.path.insert(0, '.')
@@ -10,11 +11,12 @@ from similaripy_amd.workloads import fixed_degree_csr
 from oracle import splus_oracle as so
 
 n_t = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-tun = dict(no_rowreg=("no_rowreg" in sys.argv), dbg=next((int(a[4:]) for a in sys.argv if a.startswith("dbg=")), 0))
+tun = dict(dbg=next((int(a[4:]) for a in sys.argv if a.startswith("dbg=")), 0))
+kw = dict(l1=0.5, l2=0.5, stabilized_shrink=10.0) if "c3" in sys.argv else dict(l2=1, c1=0.5, c2=0.5)
 static = "static" in sys.argv
 m = fixed_degree_csr(1_000_000, 100_000, 64, 12345)
 k = 100
-call = _host.prepare(m, k=k, l2=1, c1=0.5, c2=0.5, target_rows=np.arange(n_t))
+call = _host.prepare(m, k=k, target_rows=np.arange(n_t), **kw)
 prob = DeviceProblem(call)
 cols, vals, counts, _ = prob.alloc_outputs()
 print("launch", n_t, tun, flush=True)
@@ -23,9 +25,9 @@ print("first pass done", flush=True)
 i1 = prob.run(cols, vals, counts, time_kernel=True, phase_timers=False, static_sched=static, **tun)
 i2 = prob.run(cols, vals, counts, time_kernel=True, static_sched=static, **tun)
 ph = i2["phase_cycles"]
-names = ("setup", "segments", "accumulate", "drain", "select", "output", "sweep1", "sweep2", "idswait")
-print(json.dumps({"rows": n_t, "call_ms": i1["kernel_ms"], "rowreg_ms": i1["rowreg_kernel_ms"], "sparse_ms": i1["sparse_kernel_ms"], "generic_ms": i1["generic_kernel_ms"],
-                  "rows_rowreg": i2["rows_rowreg"], "rows_sparse_both": ph[9], "given_up": ph[10]}), flush=True)
+names = ("setup", "segments", "accumulate", "drain", "select", "output", "sweep1", "sweep2", "csdrain")
+print(json.dumps({"rows": n_t, "call_ms": i1["kernel_ms"], "sparse_ms": i1["sparse_kernel_ms"], "generic_ms": i1["generic_kernel_ms"],
+                  "rows_sparse": ph[9], "given_up": ph[10]}), flush=True)
 tot = float(sum(ph[:9]))
 print("   cycles/row %.0f: " % (tot / n_t) + "  ".join(f"{n}={c / n_t:.0f}" for n, c in zip(names, ph[:9])), flush=True)
 if tun["dbg"]:

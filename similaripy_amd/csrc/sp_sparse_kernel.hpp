@@ -129,6 +129,10 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         my_len = p.m2_indptr[u + 1] - my_r0;
     }
 
+    // Barriers of the row loop: everything the waves of a row exchange goes through LDS (U too, when U_LDS), so they wait for
+    // LDS traffic only (wg_sync<true>): __syncthreads() is a workgroup-scope fence and drains vmcnt as well, which made every
+    // barrier behind a row-pipeline prefetch (next row's m1 entries, descriptors, m2 bounds) and behind the write-out stores
+    // wait for those round trips (round 3: measured with the register-resident experiment, profiles/r03_exp_rowreg.txt).
     for (;;) {
         // row-constant values are wave-uniform: v_readfirstlane moves them to scalar registers
         const int slot_i = __builtin_amdgcn_readfirstlane(dC.x);
@@ -192,19 +196,19 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 if (key != 0u) { my_ib = scr[128 + pos]; my_fs = scr[192 + pos]; }
                 if (tid == 63) sh[SH_NITEMS] = ib_incl;
             }
-            __syncthreads();
+            wg_sync<U_LDS>();
             if (!p.static_sched) q_nn = sh[SH_QA];
             load_desc(q_nn, dNN, wNN);
             if (p.static_sched) q_nn += (int)gridDim.x;
             n_items = sh[SH_NITEMS];
-            __syncthreads();                    // scratch read before the items overwrite it
+            wg_sync<U_LDS>();                    // scratch read before the items overwrite it
         } else {
             // up to SORT_MAX entries: full descending order from one all-pairs pass spread over the whole workgroup:
             // thread (seg, part) adds up the segments that precede `seg`
             int *keyS = (int *)items, *lenS = keyS + SORT_MAX, *ibS = lenS + SORT_MAX, *fsS = ibS + SORT_MAX;
             if (tid < SORT_MAX) { ibS[tid] = 0; fsS[tid] = 0; }
             if (tid < n1) { keyS[tid] = (int)(__float_as_uint(my_v) & 0x7FFFFFFFu); lenS[tid] = my_len; }
-            __syncthreads();
+            wg_sync<U_LDS>();
             if (!p.static_sched) q_nn = sh[SH_QA];
             load_desc(q_nn, dNN, wNN);
             if (p.static_sched) q_nn += (int)gridDim.x;
@@ -225,10 +229,10 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 }
                 if (tid < n1 && my_len > 0) atomicAdd(&sh[SH_NITEMS], (my_len + ITEM - 1) / ITEM);
             }
-            __syncthreads();
+            wg_sync<U_LDS>();
             if (tid < n1) { my_ib = ibS[tid]; my_fs = fsS[tid]; }
             n_items = sh[SH_NITEMS];
-            __syncthreads();                    // scratch read before the items overwrite it
+            wg_sync<U_LDS>();                    // scratch read before the items overwrite it
         }
         bool failed = (n_items >= ICAP) || (n_items > 63 * NW);      // (a wave keeps its <= 63 item descriptors in one register)
         PHASE_END(PH_SETUP);
@@ -277,7 +281,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 for (int o = 0; o < my_len; o += ITEM, ++q)
                     items[my_ib + q] = make_int4((my_r0 + o) * 4, min(ITEM, my_len - o), (int)__float_as_uint(my_v), my_fs + o);
             }
-            __syncthreads();
+            wg_sync<U_LDS>();
             PHASE_END(PH_SEGMENTS);
             // ---- sweep 1: column ids only.  Branch-free: every product ORs its bit into the bitmap; the returned
             // word tells whether the column was there already, in which case (only then a non-zero operand) the
@@ -365,7 +369,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     }
                 }
             }
-            __syncthreads();
+            wg_sync<U_LDS>();
             PHASE_END(PH_SWEEP1);
             // next row's m2 row bounds (its m1 entries were requested at the top of this row)
             if (dN.x >= 0 && tid < dN.w) {
@@ -377,6 +381,27 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             // rank structure of the collision bitmap: pre16[w] = marked columns in the words below w.  The rank of a
             // marked column is its slot in the collision set: no hashing, no probing (columns that alias to one bit
             // share a rank and are told apart by their key; the loser probes an overflow area).
+            if constexpr (CBM_BYTES / 16 <= NT && NW <= 64) {
+                // one trip: CBM_BYTES / 16 threads hold four words each; the waves' totals are combined by a second DPP scan in
+                // every wave (lane w < NW reads wave w's total) instead of NW reads and adds per thread
+                const int4 w4 = (tid < CBM_BYTES / 16) ? ((const int4 *)cbm)[tid] : make_int4(0, 0, 0, 0);
+                const int p0 = __popc((unsigned)w4.x), p1 = p0 + __popc((unsigned)w4.y), p2 = p1 + __popc((unsigned)w4.z);
+                const int tot = p2 + __popc((unsigned)w4.w);
+                const int incl = wave_incl_scan_dpp(tot);
+                if (lane == 63) sh[SH_WSUM + wave] = incl;
+                wg_sync<U_LDS>();
+                const int ws = (lane < NW) ? sh[SH_WSUM + lane] : 0;
+                const int ws_incl = wave_incl_scan_dpp(ws);
+                const int all = __builtin_amdgcn_readlane(ws_incl, 63);
+                const int woff = __builtin_amdgcn_readlane(ws_incl - ws, wave);
+                const int ex = woff + incl - tot;
+                if (tid < CBM_BYTES / 16) {
+                    const u64 packed = (u64)(unsigned)(ex & 0xFFFF) | ((u64)(unsigned)((ex + p0) & 0xFFFF) << 16) |
+                                       ((u64)(unsigned)((ex + p1) & 0xFFFF) << 32) | ((u64)(unsigned)((ex + p2) & 0xFFFF) << 48);
+                    ((u64 *)pre16)[tid] = packed;
+                }
+                if (all > CSN / 2) failed = true;      // more marked columns than direct slots (uniform)
+            } else
             {
                 int carry = 0;
                 for (int base = 0; base < CBM_BYTES / 16; base += NT) {            // 4 words per thread and trip
@@ -386,7 +411,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     const int tot = p2 + __popc((unsigned)w4.w);
                     const int incl = wave_incl_scan_dpp(tot);
                     if (lane == 63) sh[SH_WSUM + wave] = incl;
-                    __syncthreads();
+                    wg_sync<U_LDS>();
                     int woff = carry, all = 0;
 #pragma unroll
                     for (int w = 0; w < NW; ++w) {
@@ -401,7 +426,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                         ((u64 *)pre16)[i] = packed;
                     }
                     carry += all;
-                    if (CBM_BYTES / 16 > NT) __syncthreads();     // (sh[SH_WSUM] is reused by the next trip)
+                    if (CBM_BYTES / 16 > NT) wg_sync<U_LDS>();     // (sh[SH_WSUM] is reused by the next trip)
                 }
                 if (carry > CSN / 2) failed = true;      // more marked columns than direct slots (uniform)
             }
@@ -484,7 +509,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                         rest = (rest >= mx) ? 0u : rest;
                     }
                     if (lane == 0 && tw != 0u) atomicMin((unsigned *)&sh[SH_SEL], tw);
-                    __syncthreads();
+                    wg_sync<U_LDS>();
                     const unsigned g = (unsigned)sh[SH_SEL];            // every product pushed below has key >= g
                     u64 G[4];
                     int cw = 0;
@@ -494,7 +519,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                         cw += __popcll(G[j]);
                     }
                     if (lane == 0 && cw) atomicAdd(&sh[SH_NEED], cw);
-                    __syncthreads();
+                    wg_sync<U_LDS>();
                     const int totalA = sh[SH_NEED];
                     const bool fits = totalA <= room / 2 && totalA >= p.k;   // uniform: k products reach g (so it is a valid cutoff) and they leave U half empty
                     const int nfull = max(1, (room / 2) / ITEM);        // fallback: the first nfull items, everything accepted (U at most half full)
@@ -534,7 +559,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                         rc.thr_key = g;
                         cutx = fmaxf(cutx0, funkey(g));
                     }
-                    __syncthreads();
+                    wg_sync<U_LDS>();
                     if (sh[SH_OVF]) failed = true;
                     // (not fitting: U now holds everything of the first nfull items; the next stage's selection trims it)
                     {
@@ -669,7 +694,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 }
                 i0 = i1;
                 last_stage = (i0 >= n_items);      // (an empty first round with i0 < n_items is never the last)
-                __syncthreads();
+                wg_sync<U_LDS>();
                 const int ext = min(sh[SH_PCTR], spcap);
                 const int mext = min(sh[SH_MCTR], mpcap);
                 if (sh[SH_OVF]) { failed = true; break; }     // a pool overflowed
@@ -687,6 +712,8 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     // the product through the hardware float add (slow on gfx950, 3 clk per lane, but a column with
                     // many products — the row itself in m * m^T — would make a compare-and-swap add retry once per
                     // product); another column's slot sends the entry to the next slot.
+                    // (Round 3 tried "32-bit compare-and-swap on the key word, then ALWAYS the hardware float add": one round
+                    // trip less per two-product column, but ds_add_f32 runs at 0.33 lanes/clk: 9.1k -> 11.6k cycles per C2 row.)
                     for (int base = 0; base < mext; base += 2 * NT) {
                         const int i0m = base + tid, i1m = base + NT + tid;
                         const u64 e0 = (i0m < mext) ? mpool[i0m] : 0ull;
@@ -729,7 +756,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                             if (++rounds > 4 * CS_MAXPROBE) { sh[SH_OVF] = 1; break; }     // set full
                         }
                     }
-                    __syncthreads();
+                    wg_sync<U_LDS>();
                     if (sh[SH_OVF]) { failed = true; break; }     // collision set full
                     PHASE_END(PH_ACCUM);
                 }
@@ -815,16 +842,16 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                             }
                         }
                     }
-                    __syncthreads();
+                    wg_sync<U_LDS>();
                     const int retry = sh[SH_RETRY];
                     const int n_now = sh[SH_CNT];
-                    __syncthreads();
+                    wg_sync<U_LDS>();
                     if (tid == 0) {
                         sh[SH_PCTR] = 0;
                         if (last_stage) sh[SH_MCTR] = 0;
                         if (retry) { sh[SH_RETRY] = 0; if (n_now > cap) sh[SH_CNT] = cap; }   // failed appends over-counted
                     }
-                    __syncthreads();         // counter fix-ups visible before the next pushes / the selection
+                    wg_sync<U_LDS>();         // counter fix-ups visible before the next pushes / the selection
                     PHASE_END(PH_DRAIN);
                     // selection: forced when U overflowed; exact after the last stage (final top-k); between stages
                     // when U is filling up (it raises the running k-th value, which is the cutoff of the next stage)
@@ -833,13 +860,13 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     force_sel = false;
                     if (want_sel) {
                         long long thr_new;
-                        if (cap <= SEL_E * NT) thr_new = select_fast<NT, true, SEL_E>(U, hist4, sh, p.k, last_stage && !retry, rc.have_thr ? rc.thr_key : 0u);
+                        if (cap <= SEL_E * NT) thr_new = select_fast<NT, true, SEL_E, U_LDS>(U, hist4, sh, p.k, last_stage && !retry, rc.have_thr ? rc.thr_key : 0u);
                         else {
                             thr_new = compact_topk<NT>(U, hist4, sh, p.k);
                             if constexpr (MONO) {     // block-wise reservations: nothing stale may stay behind the kept entries
                                 if (thr_new >= 0) {
                                     for (int i = sh[SH_CNT] + tid; i < n_eff; i += NT) U[i] = 0ull;
-                                    __syncthreads();
+                                    wg_sync<U_LDS>();
                                 }
                             }
                         }
@@ -869,7 +896,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
 
         if (!failed) {
             // ================= write-out =================
-            __syncthreads();
+            wg_sync<U_LDS>();
             const int n_sel = min(sh[SH_CNT], p.k);
             const long long o = (long long)slot_i * (long long)p.k;
             int n_out = n_sel;
@@ -877,7 +904,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 // epilogue on the winners (s_plus.h:129-156 with the column term already folded in: val = xy / den, or
                 // the raw dot), exact threshold test, compaction of what passes to the front of the slot
                 if (tid == 0) sh[SH_SEL] = 0;
-                __syncthreads();
+                wg_sync<U_LDS>();
                 for (int base = 0; base < n_sel; base += NT) {
                     const int j = base + tid;
                     const u64 it = (j < n_sel) ? U[j] : 0ull;
@@ -898,7 +925,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                         }
                     }
                 }
-                __syncthreads();
+                wg_sync<U_LDS>();
                 n_out = sh[SH_SEL];
                 for (int j = n_out + tid; j < p.k; j += NT) {
                     if (p.rows) p.rows[o + j] = 0;
@@ -933,7 +960,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             if (U_LDS || MONO) {
                 // U's storage is part of the next row's bitmap (LDS) / holes must read zero (MONO).  Every selection zeroes
                 // what lies behind the entries it keeps, so only the first k entries can be non-zero here.
-                __syncthreads();     // U read before it is cleared
+                wg_sync<U_LDS>();     // U read before it is cleared
                 const int dirty = (cap <= SEL_E * NT) ? min(cap, p.k + 2) : cap;
                 for (int i = tid; i < (dirty + 1) / 2; i += NT) ((int4 *)U)[i] = make_int4(0, 0, 0, 0);
             }
@@ -941,7 +968,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         } else {
             // a pool or the collision set overflowed (or the row has too many items): hand the row to the generic
             // kernel's queue and put the LDS state back to clean
-            __syncthreads();
+            wg_sync<U_LDS>();
             if (tid == 0) {
                 const unsigned g = atomicAdd(&p.qcount[1], 1u);
                 p.desc_g[2 * (size_t)g] = dC;
@@ -960,7 +987,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         wN = make_int4(__builtin_amdgcn_readfirstlane(wNN.x), __builtin_amdgcn_readfirstlane(wNN.y),
                        __builtin_amdgcn_readfirstlane(wNN.z), __builtin_amdgcn_readfirstlane(wNN.w));
         my_r0 = nx_r0; my_len = nx_len; my_v = nx_v;
-        __syncthreads();
+        wg_sync<U_LDS>();
         PHASE_END(PH_OUTPUT);
     }
     if (timing) {
