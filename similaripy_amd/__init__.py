@@ -18,6 +18,15 @@ from .similarity import (
     tversky,
 )
 
+
+
+def device_cache_trim() -> int:
+    """Give the device buffers the library keeps between host-mode calls (operands, outputs, workspace; at most
+    SIMILARIPY_AMD_DEVICE_CACHE_MB, default 16 GiB, per GPU) back to the driver.  Returns the bytes released."""
+    from . import _abi
+    return _abi.device_cache_trim()
+
+
 __version__ = "0.1.0"
 
 __all__ = [
@@ -35,4 +44,5 @@ __all__ = [
     "p3alpha",
     "rp3beta",
     "s_plus",
+    "device_cache_trim",
 ]

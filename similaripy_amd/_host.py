@@ -247,16 +247,22 @@ def build_depop_normalization(m1, m2, n_rows_m1, n_cols_m2, weight_spec1, weight
     m1/m2 are (data, indices, indptr, n_cols) tuples of the float32 (or binarised) matrices."""
     p1, p2 = float(np.float32(p1)), float(np.float32(p2))
 
+    def power(w, p):
+        # a negative weight under a fractional exponent is NaN here as in the reference (s_plus_utils.pyx:257-276: np.power on
+        # the same float32 values); NumPy's "invalid value" warning about it is the reference's too and says nothing new
+        with np.errstate(invalid="ignore"):
+            return np.power(w, p, dtype=np.float32)
+
     def one(spec, p, which):
         if isinstance(spec, (list, np.ndarray)):
-            return np.power(spec, p, dtype=np.float32)
+            return power(spec, p)
         if spec == 'none':
             return np.ones(n_rows_m1 if which == 1 else n_cols_m2, dtype=np.float32)
         if spec == 'sum':
             d, i, ptr, nc = m1 if which == 1 else m2
             if which == 2 and sums_on_device:      # column sums of m2: the device's np.bincount (sp_csr_col_sums_f32)
-                return np.power(col_sums_hip(d, i, nc, square=False), p, dtype=np.float32)
-            return np.power(csr_sum(d, i, ptr, nc, axis=1 if which == 1 else 0), p, dtype=np.float32)
+                return power(col_sums_hip(d, i, nc, square=False), p)
+            return power(csr_sum(d, i, ptr, nc, axis=1 if which == 1 else 0), p)
         raise ValueError(f"Invalid weight_spec{which}: {spec}")
 
     return one(weight_spec1, p1, 1), one(weight_spec2, p2, 2)

@@ -334,7 +334,13 @@ int run_device_impl(sp_knn_args *a) {
     CallGuard guard;
     guard.stream = stream;
     if (!ws) {
-        HIP_TRY(hipMalloc((void **)&ws, c.ws_total));
+        hipError_t me = hipMalloc((void **)&ws, c.ws_total);
+        if (me != hipSuccess) {      // out of memory: the host-mode buffer cache may be what holds it
+            (void)hipGetLastError();
+            (void)sp_device_cache_trim();
+            me = hipMalloc((void **)&ws, c.ws_total);
+        }
+        if (me != hipSuccess) return fail(SP_ENOMEM, "hipMalloc(%zu bytes of workspace) failed: %s", c.ws_total, hipGetErrorString(me));
         guard.ws = ws;
     } else if (a->workspace_bytes < (int64_t)c.ws_total) {
         return fail(SP_EWORKSPACE, "workspace too small: need %zu bytes, got %lld", c.ws_total, (long long)a->workspace_bytes);
@@ -487,6 +493,8 @@ int run_device_impl(sp_knn_args *a) {
     if (rc) return rc;
     if (c.split_pmax) {
         const int n_rec = c.split_pmax * a->k;
+        // (up to 8192 records of 8 bytes + the kernel's own static word: more than the 64 KiB a launch gets without asking)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(sp_merge_pieces_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, n_rec * 8));
         hipLaunchKernelGGL(sp_merge_pieces_kernel, dim3(std::min(c.split_cap, 1024)), dim3(256), (size_t)n_rec * 8, stream, (const int *)(ws + 16), c.split_cap,
                            (const int4 *)ws_piece, a->k, a->targets, (const int *)kp.part_cols, (const float *)kp.part_vals, (const int *)kp.part_counts,
                            a->rows, a->cols, a->values, a->out_counts);
@@ -657,6 +665,16 @@ int run_device(sp_knn_args *a) {
 struct DeviceCache {
     std::mutex mu;
     std::map<std::pair<int, size_t>, std::vector<void *>> free_blocks;      // (device, bucket bytes) -> idle blocks
+    std::map<int, size_t> idle_bytes;                                       // device -> bytes sitting in free_blocks
+    // Idle bytes kept per device at most: other allocators of the process (torch, a second library) never see this cache's
+    // hipMalloc fail, so it must not sit on an unbounded share of HBM.  SIMILARIPY_AMD_DEVICE_CACHE_MB overrides (0 = keep nothing).
+    static size_t cap_bytes() {
+        static const size_t cap = [] {
+            const char *e = getenv("SIMILARIPY_AMD_DEVICE_CACHE_MB");
+            return e ? (size_t)strtoull(e, nullptr, 10) << 20 : (size_t)16 << 30;
+        }();
+        return cap;
+    }
     static size_t bucket(size_t n) {
         n = std::max<size_t>(n, 256);
         size_t p = 256;
@@ -672,6 +690,7 @@ struct DeviceCache {
             if (it != free_blocks.end() && !it->second.empty()) {
                 *out = it->second.back();
                 it->second.pop_back();
+                idle_bytes[device] -= b;
                 *got = b;
                 return SP_OK;
             }
@@ -689,8 +708,15 @@ struct DeviceCache {
         return SP_OK;
     }
     void put(int device, size_t b, void *p) {
-        std::lock_guard<std::mutex> lk(mu);
-        free_blocks[{device, b}].push_back(p);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (idle_bytes[device] + b <= cap_bytes()) {
+                free_blocks[{device, b}].push_back(p);
+                idle_bytes[device] += b;
+                return;
+            }
+        }
+        (void)hipFree(p);      // over the cap: back to the driver
     }
     long long trim(int device) {
         std::vector<std::pair<size_t, void *>> victims;
@@ -701,6 +727,8 @@ struct DeviceCache {
                     for (void *p : kv.second) victims.push_back({kv.first.second, p});
                     kv.second.clear();
                 }
+            for (auto &kv : idle_bytes)
+                if (kv.first == device || device < 0) kv.second = 0;
         }
         long long n = 0;
         for (auto &v : victims) { (void)hipFree(v.second); n += (long long)v.first; }
@@ -749,19 +777,6 @@ struct DevPool {
     }
 };
 
-
-// structure of a host CSR: indptr[0] = 0, monotone, indptr[n] = nnz, every index in [0, n_cols)
-int check_csr(const char *what, const int32_t *indptr, const int32_t *indices, int n_rows, int64_t nnz, int n_cols) {
-    if (n_rows > 0 && !indptr) return fail(SP_EINVAL, "%s: indptr is NULL", what);
-    if (n_rows > 0 && indptr[0] != 0) return fail(SP_EINVAL, "%s: indptr[0] = %d, expected 0", what, indptr[0]);
-    for (int r = 0; r < n_rows; ++r)
-        if (indptr[r + 1] < indptr[r]) return fail(SP_EINVAL, "%s: indptr decreases at row %d", what, r);
-    if (n_rows > 0 && (int64_t)indptr[n_rows] != nnz) return fail(SP_EINVAL, "%s: indptr[%d] = %d but nnz = %lld", what, n_rows, indptr[n_rows], (long long)nnz);
-    int32_t lo = 0, hi = -1;
-    for (int64_t i = 0; i < nnz; ++i) { lo = std::min(lo, indices[i]); hi = std::max(hi, indices[i]); }
-    if (lo < 0 || hi >= n_cols) return fail(SP_EINVAL, "%s: column index out of range [0,%d) (min %d, max %d)", what, n_cols, lo, hi);
-    return SP_OK;
-}
 
 // host pointers in, host pointers out: the drop-in for s_plus.pyx:359-384
 // SIMILARIPY_AMD_TRACE=1: wall clock of the stages of a host-mode call on stderr (the device is synchronised at every mark)
@@ -1250,7 +1265,7 @@ int sp_csr_normalize(sp_csr_normalize_args *a) {
         else if (a->mode == SP_NORM_MAX) hipLaunchKernelGGL((sp_row_normalize_kernel<T, RO_MAX>), dim3(wb), dim3(256), 0, stream, a->n_rows, data, d_indptr, a->pow_alpha);
         else {
             // log_logbase = log(logbase) held in the data type (normalization.pyx:223, 296)
-            const T llb = (T)log(a->logbase);
+            const T llb = (T)log((double)(T)a->logbase);      // (the reference's float32 instantiation rounds logbase to float first: log((float)e) = 0.99999994)
             hipLaunchKernelGGL((sp_doc_stats_kernel<T>), dim3(wb), dim3(256), 0, stream, a->n_rows, (const T *)data, d_indices, d_indptr, (T *)doc_len, df);
             hipLaunchKernelGGL((sp_idf_kernel<T>), dim3((a->n_cols + 255) / 256), dim3(256), 0, stream, a->n_cols, (const int *)df, (T *)idf, a->n_rows, a->idf_mode, llb);
             hipLaunchKernelGGL((sp_avg_doc_len_kernel<T>), dim3(1), dim3(1024), 0, stream, a->n_rows, (const T *)doc_len, (T *)avg);

@@ -33,6 +33,14 @@ class DeviceProblem:
     def __init__(self, call: KernelCall, device=None):
         torch = _torch()
         _abi.require_device()
+        # the resident form launches the row kernels on operands that are already what they should be: a call that still
+        # carries device-side preprocessing (SP_FLAG_P3_PREP, a CSC matrix1, norms to be built by the library) belongs to
+        # _host.run_hip — dropping those options silently would compute something else
+        pending = [n for n, v in (("p3_alpha", call.p3_alpha), ("depop_rowsum_p2", call.depop_rowsum_p2),
+                                  ("m1_is_m2t", call.m1_is_m2t or None), ("norms_on_device", call.norms_on_device)) if v is not None]
+        if pending:
+            raise ValueError(f"DeviceProblem: the call leaves {', '.join(pending)} to the library's host-mode entry; prepare it without "
+                             f"those options (prepare(..., m2_on_device=...) only) or run it through _host.run_hip")
         self.call = call
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device, non_blocking=False)  # noqa: E731

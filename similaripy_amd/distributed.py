@@ -91,17 +91,20 @@ def slice_call(call: KernelCall, lo: int, hi: int, compact: bool = False) -> Ker
 
 
 def local_device() -> int:
-    """The GPU of this rank in the one-process-per-GPU layout: LOCAL_RANK (torchrun / multi_gpu.spawn), else torch's
-    current device, else SIMILARIPY_AMD_DEVICE / 0."""
+    """The GPU of this rank in the one-process-per-GPU layout: LOCAL_RANK (torchrun / multi_gpu.spawn), else
+    SIMILARIPY_AMD_DEVICE when it is set (every other entry point honours it: _host.selected_device), else torch's current
+    device, else 0."""
     if "LOCAL_RANK" in os.environ:
         return int(os.environ["LOCAL_RANK"])
+    if "SIMILARIPY_AMD_DEVICE" in os.environ:
+        return int(os.environ["SIMILARIPY_AMD_DEVICE"])
     try:
         import torch
         if torch.cuda.is_available():
             return int(torch.cuda.current_device())
     except Exception:
         pass
-    return int(os.environ.get("SIMILARIPY_AMD_DEVICE", "0"))
+    return 0
 
 
 def _gather_slabs(pad_cols, pad_vals, pad_cnt, dst, group):

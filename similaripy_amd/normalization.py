@@ -21,46 +21,37 @@ import scipy.sparse as sps
 
 from . import _abi
 
-_NORMALIZATIONS = ('l1', 'l2', 'max')
-_TF_MODES = ('binary', 'raw', 'sqrt', 'freq', 'log')
-_IDF_MODES = ('unary', 'base', 'smooth', 'prob', 'bm25')
 _NORM_MODE = {'l1': _abi.SP_NORM_L1, 'l2': _abi.SP_NORM_L2, 'max': _abi.SP_NORM_MAX}
 
 
-def _check_matrix(X):
-    # normalization.py:23-40: float32/float64 are kept, anything else becomes float32 CSR
-    if not sps.issparse(X):
-        raise TypeError("X must be a sparse matrix")
-    if X.data.dtype not in (np.float32, np.float64):
-        X = sps.csr_array(X, dtype=np.float32)
-    return X
+def _one_of(name: str, value, allowed) -> None:
+    """The reference's messages for a bad mode string (normalization.py:76-86, :106-107)."""
+    if value not in allowed:
+        raise ValueError(f"{name} must be one of {tuple(allowed)}, got '{value}'")
 
 
-def _prepare_csr(X, axis: int, inplace: bool):
-    # normalization.py:43-66
+def _rows_view(X, axis: int, inplace: bool):
+    """The CSR whose ROWS are the vectors to weight, and the way back to X's orientation.
+
+    What the reference does around its Cython kernels (normalization.py:23-73): float32 / float64 data are kept, any other
+    dtype becomes float32; `inplace=False` works on a copy; axis=0 weights the columns by transposing, which always
+    re-materialises the matrix (so `inplace` only reaches the caller's buffer for a CSR weighted along axis=1)."""
     if axis not in (0, 1):
         raise ValueError(f"axis must be 0 or 1, got {axis}")
-    X = _check_matrix(X)
+    if not sps.issparse(X):
+        raise TypeError("X must be a sparse matrix")
+    work = X if X.data.dtype in (np.float32, np.float64) else sps.csr_array(X, dtype=np.float32)
     if not inplace:
-        X = X.copy()
-    if axis == 0:
-        X = X.T
-    return X.tocsr()
+        work = work.copy()
+    if axis == 1:
+        return work.tocsr(), (lambda rows: rows)
+    return work.T.tocsr(), (lambda rows: rows.T.tocsr())
 
 
-def _finalize_csr(X, axis: int):
-    # normalization.py:69-73
-    if axis == 0:
-        X = X.T
-    return X.tocsr()
-
-
-def _validate_modes(tf_mode: str, idf_mode: str) -> None:
-    # normalization.py:76-86
-    if tf_mode not in _TF_MODES:
-        raise ValueError(f"tf_mode must be one of {_TF_MODES}, got '{tf_mode}'")
-    if idf_mode not in _IDF_MODES:
-        raise ValueError(f"idf_mode must be one of {_IDF_MODES}, got '{idf_mode}'")
+def _weighted(X, axis: int, inplace: bool, mode: int, **params):
+    rows, back = _rows_view(X, axis, inplace)
+    _run(rows, mode, **params)
+    return back(rows)
 
 
 def _device() -> int:
@@ -96,34 +87,26 @@ def _run(X: sps.csr_array, mode: int, *, tf_mode: str = 'raw', idf_mode: str = '
 def normalize(X, norm: str = 'l2', axis: int = 1, inplace: bool = False):
     """Normalize a sparse matrix along rows (axis=1) or columns (axis=0) using L1, L2 or max norm
     (normalization.py:91-113).  Rows whose norm is 0 are left alone."""
-    if norm not in _NORMALIZATIONS:
-        raise ValueError(f"norm must be one of {_NORMALIZATIONS}, got '{norm}'")
-    X = _prepare_csr(X, axis, inplace)
-    _run(X, _NORM_MODE[norm])
-    return _finalize_csr(X, axis)
+    _one_of("norm", norm, _NORM_MODE)
+    return _weighted(X, axis, inplace, _NORM_MODE[norm])
 
 
 def bm25(X, axis: int = 1, k1: float = 1.2, b: float = 0.75, logbase: float = e, tf_mode: str = 'raw',
          idf_mode: str = 'bm25', inplace: bool = False):
-    """BM25 weighting (normalization.py:116-148)."""
-    _validate_modes(tf_mode, idf_mode)
-    X = _prepare_csr(X, axis, inplace)
-    _run(X, _abi.SP_NORM_BM25PLUS, tf_mode=tf_mode, idf_mode=idf_mode, k1=k1, b=b, delta=0.0, logbase=logbase)
-    return _finalize_csr(X, axis)
+    """BM25 weighting (normalization.py:116-148): BM25+ with delta = 0."""
+    return bm25plus(X, axis=axis, k1=k1, b=b, delta=0.0, logbase=logbase, tf_mode=tf_mode, idf_mode=idf_mode, inplace=inplace)
 
 
 def bm25plus(X, axis: int = 1, k1: float = 1.2, b: float = 0.75, delta: float = 1.0, logbase: float = e,
              tf_mode: str = 'raw', idf_mode: str = 'bm25', inplace: bool = False):
     """BM25+ weighting (normalization.py:151-185)."""
-    _validate_modes(tf_mode, idf_mode)
-    X = _prepare_csr(X, axis, inplace)
-    _run(X, _abi.SP_NORM_BM25PLUS, tf_mode=tf_mode, idf_mode=idf_mode, k1=k1, b=b, delta=delta, logbase=logbase)
-    return _finalize_csr(X, axis)
+    _one_of("tf_mode", tf_mode, _abi.SP_TF_MODES)
+    _one_of("idf_mode", idf_mode, _abi.SP_IDF_MODES)
+    return _weighted(X, axis, inplace, _abi.SP_NORM_BM25PLUS, tf_mode=tf_mode, idf_mode=idf_mode, k1=k1, b=b, delta=delta, logbase=logbase)
 
 
 def tfidf(X, axis: int = 1, logbase: float = e, tf_mode: str = 'sqrt', idf_mode: str = 'smooth', inplace: bool = False):
     """TF-IDF weighting (normalization.py:188-218)."""
-    _validate_modes(tf_mode, idf_mode)
-    X = _prepare_csr(X, axis, inplace)
-    _run(X, _abi.SP_NORM_TFIDF, tf_mode=tf_mode, idf_mode=idf_mode, logbase=logbase)
-    return _finalize_csr(X, axis)
+    _one_of("tf_mode", tf_mode, _abi.SP_TF_MODES)
+    _one_of("idf_mode", idf_mode, _abi.SP_IDF_MODES)
+    return _weighted(X, axis, inplace, _abi.SP_NORM_TFIDF, tf_mode=tf_mode, idf_mode=idf_mode, logbase=logbase)

@@ -128,12 +128,21 @@ def _p3_inputs(matrix1, matrix2, alpha):
     return matrix1, matrix2, raw_m2
 
 
-def _p3_on_device(matrix1, matrix2, binary, filter_cols, target_cols) -> bool:
+def _p3_on_device(matrix1, matrix2, binary, filter_cols, target_cols, alpha=1.0) -> bool:
     """Can the whole preprocessing of p3alpha / rp3beta run inside the kernel call (SP_FLAG_P3_PREP, include/sp_knn.h)?
     Only for the plain call: matrix2 = matrix1.T, float32 data (float64 input is normalised in float64 by the reference),
-    no `binary` (which throws the normalised values away), no array-style column selectors (they edit m2 on the host)."""
+    no `binary` (which throws the normalised values away), no array-style column selectors (they edit m2 on the host),
+    alpha > 0.
+
+    Where the device form differs from similarity.py:410-415 / 477-483 (L1-normalise, `data ** alpha` on EVERY stored entry,
+    only then eliminate_zeros inside s_plus): stored zeros are dropped BEFORE the power.  For alpha > 0 that is the same
+    matrix (0 / norm = 0, 0 ** alpha = 0, the norm does not see zeros); for alpha <= 0 it is not (0 ** alpha is 1 or inf),
+    so those calls take the host statement below.  One deviation remains: an entry that underflows to 0 in the divide or the
+    power stays a stored candidate here (it can only show up as a 0.0 similarity at the very end of a short result row)."""
     from scipy.sparse import issparse
     if matrix2 is not None or binary or not issparse(matrix1) or matrix1.data.dtype != np.float32:
+        return False
+    if not (alpha > 0):
         return False
     if _host.multi_gpu_route() is not None:      # (the workers of the multi-GPU route get preprocessed matrices)
         return False
@@ -157,7 +166,7 @@ def p3alpha(matrix1: sparray, matrix2: Optional[sparray] = None, alpha: float = 
             filter_cols: _Cols = None, verbose: bool = True, format_output: _Fmt = 'coo',
             num_threads: int = 0, block_size: Optional[int] = 0) -> sparray:
     """Top-k P3alpha: product of the two row-stochastic transition matrices, entries ^alpha."""
-    if _p3_on_device(matrix1, matrix2, binary, filter_cols, target_cols):
+    if _p3_on_device(matrix1, matrix2, binary, filter_cols, target_cols, alpha):
         return _run_p3(matrix1, alpha, None, k, shrink, shrink_type, threshold, target_rows, target_cols, filter_cols, verbose, format_output)
     matrix1, matrix2, _ = _p3_inputs(matrix1, matrix2, alpha)
     return _run(matrix1, matrix2, {}, k, shrink, shrink_type, threshold, binary, target_rows, target_cols,
@@ -170,7 +179,7 @@ def rp3beta(matrix1: sparray, matrix2: Optional[sparray] = None, alpha: float = 
             filter_cols: _Cols = None, verbose: bool = True, format_output: _Fmt = 'coo',
             num_threads: int = 0, block_size: Optional[int] = 0) -> sparray:
     """Top-k RP3beta: P3alpha divided by (column popularity of the raw matrix2)^beta."""
-    if _p3_on_device(matrix1, matrix2, binary, filter_cols, target_cols):
+    if _p3_on_device(matrix1, matrix2, binary, filter_cols, target_cols, alpha):
         return _run_p3(matrix1, alpha, beta, k, shrink, shrink_type, threshold, target_rows, target_cols, filter_cols, verbose, format_output)
     if matrix2 is None:
         matrix2 = matrix1.T
