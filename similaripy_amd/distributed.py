@@ -8,9 +8,10 @@ The path shards exactly like the reference's only parallel loop — output rows 
     so skewed matrices (power-law item popularity) stay balanced;
   * m2 and the Y* vectors are replicated on every GPU, m1 / X* / selectors are indexed by absolute
     row id so every rank can hold them whole (they are small next to m2);
-  * no collective during compute; ONE gather of the (cols, values, counts) slabs at the end
-    (RCCL over xGMI when the backend is "nccl", gloo on CPU for tests).  Slabs are padded to the
-    largest slice so a plain `gather` works; `rows` is implied by the slot and rebuilt on the root.
+  * no collective during compute; ONE gather at the end (RCCL over xGMI when the backend is "nccl", gloo on CPU for
+    tests): a rank's result is ONE slab of 32-bit words [cols n_max*k | value bits n_max*k | counts n_max], padded to
+    the largest slice so a plain `gather` works — the kernel writes straight into views of it; `rows` is implied by the
+    slot and rebuilt on the root.  The root pulls the gathered slabs to the host through one pinned buffer.
 
 Two drivers share the partition, the slab layout and the gather:
 
@@ -43,6 +44,19 @@ def row_work(call: KernelCall) -> np.ndarray:
     csum = np.concatenate(([0], np.cumsum(per_entry)))
     macs_row = csum[call.m1_indptr[1:]] - csum[call.m1_indptr[:-1]]
     return macs_row[call.targets] + 1          # +1: an empty row still costs a slot
+
+
+def row_cost(call: KernelCall) -> np.ndarray:
+    """What a target slot costs a GPU, in MAC equivalents — the quantity `partition_targets` balances.
+
+    MACs alone under-price light rows: every row pays a fixed toll (queue, setup, bitmap / tile clear, selection, write-out:
+    ~30 k cycles against ~1 cycle per MAC in the sparse kernel, profiles/r03_c2_phases.txt; on the MovieLens-32M shape the
+    least-squares fit of scripts/strong_scaling_c4.py prices a slice almost entirely by its ROW count).  The toll keeps a
+    slice of many light rows from being handed as much raw work as a slice of few heavy ones."""
+    return row_work(call).astype(np.float64) + ROW_TOLL_MACS
+
+
+ROW_TOLL_MACS = 30_000.0       # fixed cost of a row, in MACs
 
 
 def partition_targets(work: np.ndarray, world_size: int) -> np.ndarray:
@@ -107,34 +121,57 @@ def local_device() -> int:
     return 0
 
 
-def _gather_slabs(pad_cols, pad_vals, pad_cnt, dst, group):
-    """THE collective of the path: every rank's padded (cols, values, counts) slab to rank `dst`."""
+def slab_words(n_max: int, k: int) -> int:
+    """32-bit words of one rank's result slab: cols | value bits | counts."""
+    return n_max * (2 * k + 1)
+
+
+def slab_views(slab, n_max: int, k: int):
+    """(cols int32, values float32, counts int32) views of a slab tensor."""
+    import torch
+    nk = n_max * k
+    return slab[:nk], slab[nk: 2 * nk].view(torch.float32), slab[2 * nk: 2 * nk + n_max]
+
+
+def _gather_slab(slab, dst, group):
+    """THE collective of the path: every rank's slab to rank `dst`, one `gather`."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    gc = [torch.empty_like(pad_cols) for _ in range(world)] if rank == dst else None
-    gv = [torch.empty_like(pad_vals) for _ in range(world)] if rank == dst else None
-    gn = [torch.empty_like(pad_cnt) for _ in range(world)] if rank == dst else None
-    dist.gather(pad_cols, gc, dst=dst, group=group)
-    dist.gather(pad_vals, gv, dst=dst, group=group)
-    dist.gather(pad_cnt, gn, dst=dst, group=group)
-    return gc, gv, gn
+    recv = [torch.empty_like(slab) for _ in range(world)] if dist.get_rank(group) == dst else None
+    dist.gather(slab, recv, dst=dst, group=group)
+    return recv
 
 
-def _assemble(call: KernelCall, bounds, gc, gv, gn):
+def _slabs_to_host(slabs):
+    """Root: the gathered slabs as one (world, words) int32 NumPy array.  Device slabs come down through ONE pinned buffer
+    with the copies queued back to back (no per-rank synchronous `.cpu()`)."""
+    import torch
+
+    if not slabs[0].is_cuda:
+        return np.stack([t.numpy() for t in slabs]) if len(slabs) > 1 else slabs[0].numpy()[None, :]
+    host = torch.empty((len(slabs), slabs[0].numel()), dtype=torch.int32, pin_memory=True)
+    for r, t in enumerate(slabs):
+        host[r].copy_(t, non_blocking=True)
+    torch.cuda.synchronize(slabs[0].device)
+    return host.numpy()
+
+
+def _assemble(call: KernelCall, bounds, slabs, n_max: int):
     """Root: slabs -> flat (rows, cols, values, counts) in the slot order of `call.targets`."""
     n, k = call.n_targets, call.k
     out_cols = np.zeros(n * k, dtype=np.int32)
     out_vals = np.zeros(n * k, dtype=np.float32)
     out_cnt = np.zeros(n, dtype=np.int32)
-    for r in range(len(gc)):
+    host = _slabs_to_host(slabs)
+    nk = n_max * k
+    for r in range(host.shape[0]):
         a, b = int(bounds[r]), int(bounds[r + 1])
         if b > a:
-            out_cols[a * k: b * k] = gc[r][: (b - a) * k].cpu().numpy()
-            out_vals[a * k: b * k] = gv[r][: (b - a) * k].cpu().numpy()
-            out_cnt[a:b] = gn[r][: b - a].cpu().numpy()
+            out_cols[a * k: b * k] = host[r, : (b - a) * k]
+            out_vals[a * k: b * k] = host[r, nk: nk + (b - a) * k].view(np.float32)
+            out_cnt[a:b] = host[r, 2 * nk: 2 * nk + (b - a)]
     # rows: slot i holds targets[i] in its first counts[i] entries, 0 in the padding (SURVEY A.3 #2)
     real = (np.arange(k, dtype=np.int32)[None, :] < out_cnt[:, None])
     out_rows = np.where(real, call.targets[:, None], 0).astype(np.int32).ravel()
@@ -155,7 +192,7 @@ def sharded_knn(call: KernelCall, compute: Callable[[KernelCall], Tuple[np.ndarr
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     k = call.k
-    bounds = partition_targets(row_work(call), world)
+    bounds = partition_targets(row_cost(call), world)
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
     n_max = int(np.max(np.diff(bounds))) if world else 0
 
@@ -166,16 +203,15 @@ def sharded_knn(call: KernelCall, compute: Callable[[KernelCall], Tuple[np.ndarr
         dev = torch.device("cuda", local_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
     else:
         dev = torch.device(device)
-    pad_cols = torch.zeros(n_max * k, dtype=torch.int32, device=dev)
-    pad_vals = torch.zeros(n_max * k, dtype=torch.float32, device=dev)
-    pad_cnt = torch.zeros(n_max, dtype=torch.int32, device=dev)
+    slab = torch.zeros(slab_words(n_max, k), dtype=torch.int32, device=dev)
+    pad_cols, pad_vals, pad_cnt = slab_views(slab, n_max, k)
     pad_cols[: n_loc * k] = torch.as_tensor(np.ascontiguousarray(cols), device=dev)
     pad_vals[: n_loc * k] = torch.as_tensor(np.ascontiguousarray(vals), device=dev)
     pad_cnt[:n_loc] = torch.as_tensor(np.ascontiguousarray(counts), device=dev)
-    gc, gv, gn = _gather_slabs(pad_cols, pad_vals, pad_cnt, dst, group)
+    recv = _gather_slab(slab, dst, group)
     if rank != dst:
         return None
-    return _assemble(call, bounds, gc, gv, gn)
+    return _assemble(call, bounds, recv, n_max)
 
 
 def hip_compute(device: Optional[int] = None, **tuning):
@@ -209,7 +245,7 @@ class ShardedDeviceProblem:
         self.world = dist.get_world_size(group) if self.distributed else 1
         self.rank = dist.get_rank(group) if self.distributed else 0
         self.device = torch.device("cuda", local_device()) if device is None else torch.device(device)
-        self.work = row_work(call)
+        self.work = row_cost(call)
         k = call.k
         self.chunk_rows = None if not chunk_rows or chunk_rows >= call.n_targets else int(chunk_rows)
         if self.chunk_rows is None:
@@ -231,11 +267,12 @@ class ShardedDeviceProblem:
             self.bounds = None
             self.lo, self.hi, self.n_loc, self.n_max = 0, 0, 0, n_max
             self.prob = DeviceProblem(call, self.device)
-        z = lambda n, dt: torch.zeros(n, dtype=dt, device=self.device)  # noqa: E731
-        self.pad_cols, self.pad_vals, self.pad_cnt = z(self.n_max * k, torch.int32), z(self.n_max * k, torch.float32), z(self.n_max, torch.int32)
+        # ONE slab per rank: the kernel writes its cols / values / counts straight into views of it, the gather moves it whole
+        self.slab = torch.zeros(slab_words(self.n_max, k), dtype=torch.int32, device=self.device)
+        self.pad_cols, self.pad_vals, self.pad_cnt = slab_views(self.slab, self.n_max, k)
         self.recv = None
         if self.rank == dst and self.world > 1:
-            self.recv = tuple([torch.empty_like(t) for _ in range(self.world)] for t in (self.pad_cols, self.pad_vals, self.pad_cnt))
+            self.recv = [torch.empty_like(self.slab) for _ in range(self.world)]
 
     def run(self, gather: bool = True, **kw):
         """One step.  Returns the kernel's info dict (see DeviceProblem.run)."""
@@ -248,15 +285,12 @@ class ShardedDeviceProblem:
         return info
 
     def gather(self):
-        """THE collective of the path: the padded slabs of every rank to the root (device to device)."""
+        """THE collective of the path: the slab of every rank to the root, ONE gather (device to device)."""
         import torch.distributed as dist
 
         if self.world == 1:
             return
-        root = self.rank == self.dst
-        dist.gather(self.pad_cols, self.recv[0] if root else None, dst=self.dst, group=self.group)
-        dist.gather(self.pad_vals, self.recv[1] if root else None, dst=self.dst, group=self.group)
-        dist.gather(self.pad_cnt, self.recv[2] if root else None, dst=self.dst, group=self.group)
+        dist.gather(self.slab, self.recv if self.rank == self.dst else None, dst=self.dst, group=self.group)
 
     # ---- streaming form: one resident problem, the target list in chunks (10M users x k do not fit host arrays at once) ----
     def chunks(self):
@@ -291,8 +325,7 @@ class ShardedDeviceProblem:
             return cols, vals, cnt
         b = self._chunk_bounds[(lo, hi)] - lo
         sub = slice_call(self.call, lo, hi)
-        slabs = ([self.pad_cols], [self.pad_vals], [self.pad_cnt]) if self.world == 1 else self.recv
-        _, cols, vals, cnt = _assemble(sub, b, *slabs)
+        _, cols, vals, cnt = _assemble(sub, b, [self.slab] if self.world == 1 else self.recv, self.n_max)
         return cols, vals, cnt
 
     def result(self):
@@ -302,6 +335,4 @@ class ShardedDeviceProblem:
         torch.cuda.synchronize(self.device)
         if self.rank != self.dst:
             return None
-        if self.world == 1:
-            return _assemble(self.call, self.bounds, [self.pad_cols], [self.pad_vals], [self.pad_cnt])
-        return _assemble(self.call, self.bounds, *self.recv)
+        return _assemble(self.call, self.bounds, [self.slab] if self.world == 1 else self.recv, self.n_max)
