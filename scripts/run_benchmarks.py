@@ -15,8 +15,12 @@ Mirrors tests/benchmarks/run_benchmarks.py + benchmark.py + dataset_loaders.py o
 Datasets: `--dataset movielens` reads `<data-dir>/ml-<version>/ratings.csv` exactly as the reference's loader does
 (dataset_loaders.py:45-133: userId / movieId remapped in order of appearance, float32 CSR) when the file exists; there is
 no network here, so without it `--dataset movielens-synthetic` (default when the file is missing) builds the seeded
-MovieLens-32M-shaped matrix of similaripy_amd.workloads (200 948 x 84 432, nnz 32 000 204).  `--dataset c2` is the
-fixed-degree matrix of BASELINE configs[1] (its URM is the transpose, so that URM.T is the 1M x 100k matrix).
+MovieLens-32M-shaped matrix of similaripy_amd.workloads (200 948 x 84 432, nnz 32 000 204).  `--dataset yambda` reads the
+Yandex Music Yambda interactions the reference pulls from the HuggingFace hub (dataset_loaders.py:136-232) from a LOCAL copy
+of that repository's layout, `<data-dir>/yambda/flat/<version>/<event-type>.parquet` (or the same name with .csv): uid / item_id
+mapped to their ranks (pandas Categorical codes: sorted ids), implicit 1.0 per event, repeated events summed by the COO -> CSR
+conversion.  `--dataset c2` is the fixed-degree matrix of BASELINE configs[1] (its URM is the transpose, so that URM.T is the
+1M x 100k matrix).
 """
 from __future__ import annotations
 
@@ -96,7 +100,38 @@ def load_movielens(data_dir: Path, version: str, verbose: bool):
     return URM
 
 
-def load_URM(dataset: str, version: str, data_dir: Path, verbose: bool):
+YAMBDA_VERSIONS = ("50m", "500m")                      # dataset_loaders.py:33-42
+YAMBDA_EVENTS = ("likes", "listens", "multi_event")     # dataset_loaders.py:146-147
+
+
+def load_yambda(data_dir: Path, version: str = "50m", event_type: str = "multi_event", verbose: bool = True):
+    """dataset_loaders.py:136-232 without the hub: the `flat/<version>/<event_type>.parquet` file of a local copy of
+    yandex/yambda -> users x items CSR of float32 event counts, ids replaced by their ranks (what pd.Categorical(...).codes are)."""
+    import pandas as pd
+    if version not in YAMBDA_VERSIONS:
+        raise ValueError(f"Unknown Yambda version '{version}'. Available: {list(YAMBDA_VERSIONS)}")
+    if event_type not in YAMBDA_EVENTS:
+        raise ValueError(f"Unknown Yambda event type '{event_type}'. Available: {list(YAMBDA_EVENTS)}")
+    base = data_dir / "yambda" / "flat" / version / event_type
+    if base.with_suffix(".parquet").exists():
+        df = pd.read_parquet(base.with_suffix(".parquet"), columns=["uid", "item_id"])
+    elif base.with_suffix(".csv").exists():
+        df = pd.read_csv(base.with_suffix(".csv"), usecols=["uid", "item_id"])
+    else:
+        raise FileNotFoundError(f"Yambda file not found at {base}.parquet (no network here: place a copy of the hub repository's flat/ tree there)")
+    uid = df["uid"].to_numpy(dtype=np.int64)
+    iid = df["item_id"].to_numpy(dtype=np.int64)
+    users, u = np.unique(uid, return_inverse=True)       # rank of every id among the sorted distinct ids = Categorical codes
+    items, i = np.unique(iid, return_inverse=True)
+    URM = sp.coo_array((np.ones(uid.shape[0], dtype=np.float32), (u, i)), shape=(users.shape[0], items.shape[0])).tocsr()
+    if verbose:
+        print(f"Loaded {uid.shape[0]} interactions: URM {URM.shape}, nnz {URM.nnz}")
+    return URM
+
+
+def load_URM(dataset: str, version: str, data_dir: Path, verbose: bool, event_type: str = "multi_event"):
+    if dataset == "yambda":
+        return load_yambda(data_dir, version, event_type, verbose), f"{version}-{event_type}"
     if dataset == "movielens":
         try:
             return load_movielens(data_dir, version, verbose), version
@@ -128,7 +163,8 @@ def benchmark_similarity(URM, similarity_type="cosine", k=100, shrink=0, thresho
 
 def main():
     ap = argparse.ArgumentParser(description="Benchmark suite of similaripy_amd with the reference's report schema")
-    ap.add_argument("--dataset", default="movielens", choices=["movielens", "movielens-synthetic", "c2"])
+    ap.add_argument("--dataset", default="movielens", choices=["movielens", "movielens-synthetic", "yambda", "c2"])
+    ap.add_argument("--event-type", type=str, default="multi_event", choices=list(YAMBDA_EVENTS), help="Yambda event file")
     ap.add_argument("--version", type=str, default="32m")
     ap.add_argument("--data-dir", type=str, default="datasets")
     ap.add_argument("--similarities", nargs="+", default=["dot_product", "cosine", "rp3beta"])
@@ -148,7 +184,7 @@ def main():
     block_size = None if args.block_size.lower() == "none" else int(args.block_size)
 
     sys_info = get_system_info()
-    URM, version = load_URM(args.dataset, args.version, Path(args.data_dir), verbose)
+    URM, version = load_URM(args.dataset, args.version, Path(args.data_dir), verbose, args.event_type)
     key = f"{args.dataset}:{version}"
     density = URM.nnz / (URM.shape[0] * URM.shape[1])
     if verbose:

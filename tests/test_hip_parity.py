@@ -610,7 +610,8 @@ def test_csc_matrix1_is_converted_on_the_device(name, kw):
     b = f(item.tocsr(), k=12, verbose=False, format_output="csr", **kw)
     _assert_same_topk(a, b, 12, rtol=2e-6, tied=bool(kw.get("binary")))
     c = f(item, k=12, verbose=False, format_output="coo", **kw)
-    assert abs(c.sum() - a.sum()) <= 1e-5 * abs(a.sum()) and c.nnz >= a.nnz
+    assert c.nnz >= a.nnz                                     # (the COO form keeps the padding of short rows)
+    _assert_same_topk(c, a, 12, rtol=2e-6, tied=bool(kw.get("binary")))
 
 
 @pytest.mark.gpu
@@ -815,8 +816,8 @@ def test_p3_preprocessing_on_device_matches_host_statement(fn, kw):
     res64 = getattr(sim, fn)(m.astype(np.float64), k=k, verbose=False, format_output="csr", **kw)
     res_m2 = getattr(sim, fn)(m, m.T.tocsr(), k=k, verbose=False, format_output="csr", **kw)
     for other in (res64, res_m2):
-        assert abs(other.sum() - res.sum()) <= 2e-5 * abs(res.sum())
         assert other.nnz == res.nnz
+        _assert_same_topk(other, res, k, rtol=2e-5)
 
 
 def test_device_norms_of_an_explicit_matrix2():
