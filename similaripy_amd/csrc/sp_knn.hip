@@ -222,6 +222,10 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
             c->ws_rows_bytes += (np * 32 + 255) & ~(size_t)255;       // room for the extra entries of the generic queue (the last array of that block)
         }
     }
+    // nnz(m2) >= 2^30: the sparse kernel's 32-bit buffer offsets do not reach; every row takes the generic kernel's 64-bit-offset
+    // variant.  (This assignment was lost in round 2's piece splitter commit: `big` was stack garbage from then on — the tests that
+    // need it passed by the accident of what the stack held; round 3's cache cap changed that accident and exposed it.)
+    c->big = a->nnz_m2 >= (1LL << 30) - 1024 || (a->reserved[0] & 1024);      // (bit 1024 of the ablation word: force it, for tests at small sizes)
     c->ws_total = WS_QUEUE_BYTES + c->ws_gu_bytes + c->ws_fold_bytes + c->ws_rows_bytes + c->ws_split_bytes + c->ws_piece_bytes;
     return SP_OK;
 }
@@ -325,7 +329,7 @@ int run_device_impl(sp_knn_args *a) {
     int n_cus = 256;
     int rc = device_cus(a->device, &n_cus);
     if (rc) return rc;
-    Config c;
+    Config c{};
     rc = make_config(a, n_cus, &c);
     if (rc) return rc;
 
@@ -537,7 +541,7 @@ int m2t_layout(const sp_knn_args *a, int n_cus, sp_knn_args *plain, M2tLayout *L
     *plain = *a;
     plain->flags &= ~(SP_FLAG_M2_IS_M1_T | SP_FLAG_M1_IS_M2_T | SP_FLAG_P3_PREP | SP_FLAG_DEPOP_ROWSUM | SP_FLAG_NORMS_ON_DEVICE);
     plain->nnz_m1 = plain->nnz_m2 = nnz;
-    Config c;
+    Config c{};
     TRY(make_config(plain, n_cus, &c));
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     L->knn = al(c.ws_total);
@@ -1045,7 +1049,7 @@ int64_t sp_knn_workspace_bytes(const sp_knn_args *a) {
         if (rc) return rc;
         return (int64_t)L.total;
     }
-    Config c;
+    Config c{};
     rc = make_config(a, n_cus, &c);
     if (rc) return rc;
     return (int64_t)c.ws_total;
