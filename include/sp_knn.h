@@ -64,7 +64,8 @@ extern "C" {
                                      (the reference calls eliminate_zeros() first, s_plus.pyx:210-211); if there are any, nothing is
                                      computed, explicit_zeros holds the count and SP_EZEROS is returned: the caller drops them and calls again */
 #define SP_FLAG_CSR_OUT       512u /* assemble the CSR result on the device (build_csr_matrix utils.pyx:141-173 -> coo_to_csr.h:28-71 ->
-                                     eliminate_zeros s_plus.pyx:424): `targets` must be strictly increasing; csr_indptr receives the
+                                     eliminate_zeros s_plus.pyx:424): any order of `targets`, repeats included (a row asked for twice holds its
+                                     slots one after the other, as the reference's stable counting sort leaves them); csr_indptr receives the
                                      n_rows_m1 + 1 row pointers, the first csr_nnz entries of `cols` / `values` the column ids and values of
                                      the non-zero entries in row order (slot order inside a row); rows / out_counts are not written */
 #define SP_FLAG_P3_PREP      1024u /* with SP_FLAG_M2_IS_M1_T or SP_FLAG_M1_IS_M2_T: the preprocessing of p3alpha / rp3beta (similarity.py:410-415, 477-483;

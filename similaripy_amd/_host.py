@@ -562,7 +562,7 @@ def run_hip(call: KernelCall, device: Optional[int] = None, table_slots: int = 0
     through the C ABI (include/sp_knn.h).  Returns rows, cols, values, counts[, info].
 
     check_zeros: SP_FLAG_CHECK_ZEROS — raises _abi.ExplicitZerosError when m1 / m2 hold stored zeros.
-    csr_out: SP_FLAG_CSR_OUT — the CSR result is assembled on the device (strictly increasing targets only); returns
+    csr_out: SP_FLAG_CSR_OUT — the CSR result is assembled on the device (any order of the targets, repeats included); returns
     (indptr, indices, data) of the final matrix instead (views of the buffers the library filled)."""
     _abi.require_device()
     n, k = call.n_targets, call.k
@@ -701,9 +701,9 @@ def _s_plus_impl(matrix1, matrix2, weight_depop_matrix1, weight_depop_matrix2, p
     opts = dict(check_zeros=not device_zero_check, csc_direct=True)
     while True:
         call = prepare(*args, m2_on_device=True, norms_on_device=True, **opts, **p3kw)
-        t = call.targets
-        csr_out = (format_output == 'csr' and call.n_targets > 0 and call.n_targets * call.k <= np.iinfo(np.int32).max
-                   and (call.n_targets == 1 or bool(np.all(t[1:] > t[:-1]))))
+        # CSR results are assembled on the device whatever the order of target_rows (SP_FLAG_CSR_OUT: the stable counting sort of
+        # coo_to_csr.h:28-71, repeats included)
+        csr_out = format_output == 'csr' and call.n_targets > 0 and call.n_targets * call.k <= np.iinfo(np.int32).max
         _say(verbose, "Computing")
         try:
             out = run_hip(call, want_rows=(format_output != 'csr'), check_zeros=not opts["check_zeros"], csr_out=csr_out)

@@ -77,6 +77,10 @@ struct KParams {
     const int *splits;     // generic kernel, optional: [n_rows_m2][n_splits] position of the first entry of m2 row u with column >= (j+1)*split_w
     int n_splits;          //   (the boundaries of the fine windows, found once per call instead of once per use)
     int split_w;           //   fine window width: 2T / f, f in {1, 2, 4}; standard dense windows start at multiples of 2T
+    // work items of the sparse kernel's rows, cut once per call by sp_row_items_kernel (optional): record 0 of an output slot's
+    // block is the header {items, 0, 0, 0} (0 = the row is set up in the kernel), records 1.. are the items of the row
+    const int4 *items_g;       // [items_rows][ITEMS_STRIDE]
+    int items_rows;            // output slots below this have a block
     unsigned long long *phase_cycles;  // optional [PH_N]
     int dbg;               // ablation bits for profiling only (results are WRONG when non-zero; 8 / 16: sweep 1 / sweep 2 of the sparse kernel
                            // load but do not process — compiled in only with -DSP_ABLATION=1: the test costs the sweeps 1 %):
@@ -435,6 +439,8 @@ constexpr int POOL_BLK = 64;      // pool entries a wave reserves at a time (>= 
 constexpr int CS_MAXPROBE = 64;   // linear-probe budget in the collision set
 constexpr unsigned OOB_SOFFSET = 0xFFFFF000u;   // buffer-load scalar offset beyond any m2 extent: every lane out of range
 constexpr int SEL_E = 4;          // candidate-buffer entries per thread the register-resident selection handles
+constexpr int ITEMS_PRE = 224;    // work items per row that the per-call prepass cuts (rows with more, or with more than 64 m1 entries: in the kernel)
+constexpr int ITEMS_STRIDE = ITEMS_PRE + 1;
 constexpr int SORT_MAX = 256;     // m1 rows up to this many entries are visited in descending |value| order
 
 __device__ __forceinline__ int mbcnt64(u64 m) {
@@ -451,7 +457,11 @@ struct WavePool { int pos, end; };
 // exhausted (flag raised: the row is redone on the generic path).  Wave-uniform.
 template <int BLK = POOL_BLK>
 __device__ __forceinline__ bool pool_reserve(WavePool &wp, int tot, int *ctr, int cap, int *ovf) {
-    if (wp.pos + tot <= wp.end) return true;
+    // (every read of the window goes through v_readfirstlane: the compiler then keeps pos / end in scalar registers and the
+    // test below is a scalar compare and branch — left to itself it held them in vector registers and wrapped the whole push
+    // sequence of a sweep body, which runs for nearly every body, in exec-mask saves and restores)
+    const int pos = __builtin_amdgcn_readfirstlane(wp.pos), end = __builtin_amdgcn_readfirstlane(wp.end);
+    if (pos + tot <= end) return true;
     const int blk = (tot + BLK - 1) & ~(BLK - 1);
     int base = 0;
     if ((threadIdx.x & 63) == 0) base = atomicAdd(ctr, blk);
@@ -719,17 +729,18 @@ __device__ __forceinline__ void lds_push64(u64 m_in, unsigned lo, unsigned hi, i
     // (the mask is wave-uniform, but under register pressure the compiler may keep it in vector registers, which an "s"
     // operand cannot take: readfirstlane pins it to scalar registers and folds away when it is there already)
     const u64 m = ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(m_in >> 32)) << 32) | (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)m_in);
+    // byte address of the list's entry `pos`: scalar arithmetic (one SALU instruction), so that a lane's own address is ONE
+    // v_lshl_add on its rank; both words go out in one ds_write2_b32
+    const unsigned first = base_off + ((unsigned)__builtin_amdgcn_readfirstlane(pos) << 3);
     asm volatile(
         "v_mbcnt_lo_u32_b32 %[t], %[mlo], 0\n\t"
         "v_mbcnt_hi_u32_b32 %[t], %[mhi], %[t]\n\t"
-        "v_add_u32 %[t], %[pos], %[t]\n\t"
-        "v_lshl_add_u32 %[t], %[t], 3, %[base]\n\t"
+        "v_lshl_add_u32 %[t], %[t], 3, %[first]\n\t"
         "s_and_saveexec_b64 %[sv], %[m]\n\t"
-        "ds_write_b32 %[t], %[lo]\n\t"
-        "ds_write_b32 %[t], %[hi] offset:4\n\t"
+        "ds_write2_b32 %[t], %[lo], %[hi] offset1:1\n\t"
         "s_mov_b64 exec, %[sv]\n\t"
         : [t] "=&v"(t), [sv] "=&s"(sv)
-        : [mlo] "s"((unsigned)m), [mhi] "s"((unsigned)(m >> 32)), [m] "s"(m), [pos] "s"(pos), [base] "s"(base_off), [lo] "v"(lo), [hi] "v"(hi)
+        : [mlo] "s"((unsigned)m), [mhi] "s"((unsigned)(m >> 32)), [m] "s"(m), [first] "s"(first), [lo] "v"(lo), [hi] "v"(hi)
         : "memory");
 }
 

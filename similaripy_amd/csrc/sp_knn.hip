@@ -108,6 +108,8 @@ struct Config {
     int split_pmax;         // heavy generic rows are queued as up to this many pieces (ranges of fine windows), 0 = off
     int split_cap;          // at most this many rows
     size_t ws_piece_bytes;  // split_rows[cap] | piece_info[cap * pmax] | part_counts[cap * pmax] | part_cols / part_vals [cap * pmax * k]
+    int items_rows;         // output slots whose work items are cut by the prepass (sp_row_items_kernel), 0 = off
+    size_t ws_items_bytes;
     bool fold;
     bool mono;              // the sparse kernel's monotone variant applies (val = xy / den or the raw dot, no per-row target selector)
     bool ordered;
@@ -120,6 +122,7 @@ constexpr size_t WS_PHASE_OFFSET = 64;
 constexpr size_t WS_YMIN_OFFSET = 176;
 static_assert(WS_PHASE_OFFSET + PH_N * 8 <= WS_YMIN_OFFSET && WS_YMIN_OFFSET + 16 <= WS_QUEUE_BYTES, "workspace header layout");
 constexpr size_t LDS_LIMIT = 160 * 1024;
+constexpr int ITEMS_ROWS_MAX = 1 << 21;
 
 // LDS of the two kernels without the candidate buffer (see their carve-ups)
 size_t lds_fixed_sparse(int T, int NT) { return (size_t)T * 8 + (size_t)item_cap(NT) * 16 + 4096 + CBM_BYTES + PRE_BYTES + 32 * 4 + 16 * 8; }   // (its candidate buffer lives inside region A)
@@ -226,7 +229,11 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
     // variant.  (This assignment was lost in round 2's piece splitter commit: `big` was stack garbage from then on — the tests that
     // need it passed by the accident of what the stack held; round 3's cache cap changed that accident and exposed it.)
     c->big = a->nnz_m2 >= (1LL << 30) - 1024 || (a->reserved[0] & 1024);      // (bit 1024 of the ablation word: force it, for tests at small sizes)
-    c->ws_total = WS_QUEUE_BYTES + c->ws_gu_bytes + c->ws_fold_bytes + c->ws_rows_bytes + c->ws_split_bytes + c->ws_piece_bytes;
+    // the sparse kernel's work items, cut once per call: 3.6 KB per output slot, for at most ITEMS_ROWS_MAX slots (the rows beyond
+    // are set up in the kernel, as are rows of more than 64 entries or more than ITEMS_PRE items)
+    c->items_rows = (!(a->flags & SP_FLAG_NO_SPARSE_PATH) && !c->big && !(a->reserved[0] & 2048) && a->nnz_m2 > 0) ? std::min(a->n_targets, ITEMS_ROWS_MAX) : 0;
+    c->ws_items_bytes = ((size_t)c->items_rows * ITEMS_STRIDE * 16 + 255) & ~(size_t)255;
+    c->ws_total = WS_QUEUE_BYTES + c->ws_gu_bytes + c->ws_fold_bytes + c->ws_rows_bytes + c->ws_split_bytes + c->ws_piece_bytes + c->ws_items_bytes;
     return SP_OK;
 }
 
@@ -364,6 +371,7 @@ int run_device_impl(sp_knn_args *a) {
     unsigned char *ws_rows = ws_fold + c.ws_fold_bytes;
     int *ws_split = (int *)(ws_rows + c.ws_rows_bytes);
     unsigned char *ws_piece = (unsigned char *)ws_split + c.ws_split_bytes;
+    unsigned char *ws_items = ws_piece + c.ws_piece_bytes;
 
     // minima of the column-term vectors feed the gather-free upper bound (Epi::upper); it is sound only
     // when every weight / shrink is non-negative (NaN parameters fail the comparisons and disable it)
@@ -463,6 +471,14 @@ int run_device_impl(sp_knn_args *a) {
         HIP_TRY(hipGetLastError());
         kp.desc = desc_s;
         kp.desc_g = desc_g;
+        kp.items_g = nullptr; kp.items_rows = 0;
+        if (c.items_rows > 0 && kp.sparse_path) {
+            const int item_blocks = std::max(1, std::min((a->n_targets + 3) / 4, n_cus * 32));     // 4 rows (waves) per block and trip
+            hipLaunchKernelGGL(sp_row_items_kernel, dim3(item_blocks), dim3(256), 0, stream, (const unsigned *)kp.qcount, c.items_rows, (const int4 *)desc_s,
+                               a->m1_indices, a->m1_data, a->m2_indptr, (int4 *)ws_items);
+            HIP_TRY(hipGetLastError());
+            kp.items_g = (const int4 *)ws_items; kp.items_rows = c.items_rows;
+        }
     }
     kp.m2_bytes = (unsigned)((size_t)a->nnz_m2 * 4);
     kp.nb_log2 = c.nb_log2;
@@ -926,9 +942,9 @@ int run_host(sp_knn_args *a) {
     }
 
     const bool csr_out = (a->flags & SP_FLAG_CSR_OUT) != 0;
+    bool targets_ascend = true;      // strictly increasing targets: the slots already are in row order
     if (csr_out) {
-        for (size_t i = 1; i < nt; ++i)
-            if (a->targets[i] <= a->targets[i - 1]) return fail(SP_EINVAL, "SP_FLAG_CSR_OUT needs strictly increasing targets (targets[%zu]=%d after %d)", i, a->targets[i], a->targets[i - 1]);
+        for (size_t i = 1; i < nt && targets_ascend; ++i) targets_ascend = a->targets[i] > a->targets[i - 1];
         if (nt * k > 0x7FFFFFFFull) return fail(SP_EINVAL, "SP_FLAG_CSR_OUT: n_targets * k = %zu does not fit int32 row pointers", nt * k);
         d.flags |= SP_FLAG_NO_ROWS_OUT;
     }
@@ -980,9 +996,31 @@ int run_host(sp_knn_args *a) {
         TRY(pool.alloc((size_t)SCAN_CHUNKS, &scan_part));
         HIP_TRY(hipMemsetAsync(indptr, 0, ((size_t)n_rows + 1) * 4, nullptr));
         const int wb = (int)std::max<size_t>(1, std::min<size_t>(256 * 16, (nt + 3) / 4));
-        hipLaunchKernelGGL(sp_slot_nnz_kernel, dim3(wb), dim3(256), 0, nullptr, (int)nt, (int)k, d.targets, d.out_counts, d.values, indptr);
-        scan_i32<true>((long long)n_rows + 1, indptr, indptr, nullptr, total, scan_part, nullptr);      // (indptr[0] = 0: in place it becomes the row pointers)
-        hipLaunchKernelGGL(sp_csr_compact_kernel, dim3(wb), dim3(256), 0, nullptr, (int)nt, (int)k, d.targets, d.out_counts, d.cols, d.values, indptr, o_idx, o_val);
+        if (targets_ascend) {
+            hipLaunchKernelGGL(sp_slot_nnz_kernel, dim3(wb), dim3(256), 0, nullptr, (int)nt, (int)k, d.targets, d.out_counts, d.values, indptr);
+            scan_i32<true>((long long)n_rows + 1, indptr, indptr, nullptr, total, scan_part, nullptr);      // (indptr[0] = 0: in place it becomes the row pointers)
+            hipLaunchKernelGGL(sp_csr_compact_kernel, dim3(wb), dim3(256), 0, nullptr, (int)nt, (int)k, d.targets, d.out_counts, d.cols, d.values, indptr, o_idx, o_val);
+        } else {
+            // any order, repeats included (target_rows=[7, 2, 7]): the stable counting sort by row of coo_to_csr.h:28-71
+            int *slot_nnz = nullptr, *slot_off = nullptr, *bstart = nullptr, *cursor = nullptr, *bucket = nullptr;
+            long long *total2 = nullptr;
+            TRY(pool.alloc(nt, &slot_nnz));
+            TRY(pool.alloc(nt, &slot_off));
+            TRY(pool.alloc((size_t)n_rows + 1, &bstart));
+            TRY(pool.alloc((size_t)n_rows + 1, &cursor));
+            TRY(pool.alloc(nt, &bucket));
+            TRY(pool.alloc(1, &total2));
+            HIP_TRY(hipMemsetAsync(bstart, 0, ((size_t)n_rows + 1) * 4, nullptr));
+            HIP_TRY(hipMemsetAsync(cursor, 0, ((size_t)n_rows + 1) * 4, nullptr));
+            hipLaunchKernelGGL(sp_slot_nnz_any_kernel, dim3(wb), dim3(256), 0, nullptr, (int)nt, (int)k, d.targets, d.out_counts, d.values, slot_nnz, indptr, bstart);
+            scan_i32<true>((long long)n_rows + 1, indptr, indptr, nullptr, total, scan_part, nullptr);
+            scan_i32<true>((long long)n_rows + 1, bstart, bstart, nullptr, total2, scan_part, nullptr);
+            const int tb = (int)std::max<size_t>(1, std::min<size_t>(256 * 16, (nt + 255) / 256));
+            const int rb = (int)std::max<size_t>(1, std::min<size_t>(256 * 16, ((size_t)n_rows + 255) / 256));
+            hipLaunchKernelGGL(sp_slot_scatter_kernel, dim3(tb), dim3(256), 0, nullptr, (int)nt, d.targets, bstart, cursor, bucket);
+            hipLaunchKernelGGL(sp_slot_offsets_kernel, dim3(rb), dim3(256), 0, nullptr, n_rows, bstart, bucket, slot_nnz, slot_off);
+            hipLaunchKernelGGL(sp_csr_compact_any_kernel, dim3(wb), dim3(256), 0, nullptr, (int)nt, (int)k, d.targets, d.out_counts, d.cols, d.values, indptr, slot_off, o_idx, o_val);
+        }
         HIP_TRY(hipGetLastError());
         long long nnz = 0;
         HIP_TRY(hipMemcpy(&nnz, total, sizeof(nnz), hipMemcpyDeviceToHost));

@@ -183,6 +183,56 @@ __global__ __launch_bounds__(256) void sp_row_desc_kernel(int n_targets, const i
     }
 }
 
+// Work items of the rows in the sparse queue, once per call (the sparse kernel's row setup — segment order, item and flat-start
+// prefixes, the item records — used to be ~4.7 k of a C2 row's 74 k cycles, done by one wave while fifteen waited).  One wave per
+// row: segment i = m1 entry i, visited in descending |m1 value| (each segment scales its m2 row by its m1 value: the large
+// products come first and the running k-th value starts high), cut into items of <= ITEM consecutive elements
+// {m2 byte offset, count, m1 value bits, flat start}.  Rows of more than 64 entries or more than ITEMS_PRE items get a 0 header:
+// the kernel sets those up itself.
+__global__ __launch_bounds__(256) void sp_row_items_kernel(const unsigned *__restrict__ qcount, int items_rows, const int4 *__restrict__ desc_s,
+                                                            const int *__restrict__ m1_indices, const float *__restrict__ m1_data,
+                                                            const int *__restrict__ m2_indptr, int4 *__restrict__ items_g) {
+    const int lane = threadIdx.x & 63;
+    const int n_rows = (int)qcount[0];
+    const int waves_total = (int)(gridDim.x * (blockDim.x >> 6));
+    for (int q = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); q < n_rows; q += waves_total) {
+        const int4 d = desc_s[2 * (size_t)q];
+        const int slot = __builtin_amdgcn_readfirstlane(d.x), s = __builtin_amdgcn_readfirstlane(d.z), n1 = __builtin_amdgcn_readfirstlane(d.w);
+        if (slot >= items_rows) continue;
+        int4 *row = items_g + (size_t)slot * ITEMS_STRIDE;
+        if (n1 > 64) { if (lane == 0) row[0] = make_int4(0, 0, 0, 0); continue; }
+        int r0 = 0, len = 0;
+        unsigned vbits = 0u;
+        if (lane < n1) {
+            const int u = m1_indices[s + lane];
+            vbits = __float_as_uint(m1_data[s + lane]);
+            r0 = m2_indptr[u];
+            len = m2_indptr[u + 1] - r0;
+        }
+        const unsigned key = (lane < n1 && len > 0) ? ((vbits & 0x7FFFFFFFu) | 1u) : 0u;      // 0 = no segment
+        // position of this lane's segment in descending key order (ties: lower lane first; empty lanes last): a permutation
+        int rank = 0;
+        for (int j = 0; j < 64; ++j) {
+            const unsigned kj = (unsigned)__builtin_amdgcn_readlane((int)key, j);
+            rank += (kj > key || (kj == key && j < lane)) ? 1 : 0;
+        }
+        const int nit = (len + ITEM - 1) / ITEM;
+        // values in position order (lane i sends to lane rank_i), scanned there, and read back
+        const int nit_p = __builtin_amdgcn_ds_permute(rank * 4, key != 0u ? nit : 0);
+        const int len_p = __builtin_amdgcn_ds_permute(rank * 4, key != 0u ? len : 0);
+        const int ib_incl = wave_incl_scan_dpp(nit_p), fs_incl = wave_incl_scan_dpp(len_p);
+        const int ib = __builtin_amdgcn_ds_bpermute(rank * 4, ib_incl - nit_p);
+        const int fs = __builtin_amdgcn_ds_bpermute(rank * 4, fs_incl - len_p);
+        const int n_items = __builtin_amdgcn_readlane(ib_incl, 63);
+        if (n_items > ITEMS_PRE || n_items == 0) { if (lane == 0) row[0] = make_int4(0, 0, 0, 0); continue; }
+        if (key != 0u) {
+            int n = ib;
+            for (int o = 0; o < len; o += ITEM, ++n) row[1 + n] = make_int4((r0 + o) * 4, min(ITEM, len - o), (int)vbits, fs + o);
+        }
+        if (lane == 0) row[0] = make_int4(n_items, 0, 0, 0);
+    }
+}
+
 // The top-k of a split row from its pieces' results (each a top-k of its own column window, threshold applied):
 // ascending sort of the pieces' {value key, column} records in LDS, the k largest go to the row's output slot.
 // One workgroup per split row; at most split_pmax * k <= 8192 records.

@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void sp_f64_to_f32_kernel(int n, const double 
     if (i < n) out[i] = (float)in[i];
 }
 
-// ---- CSR assembly of the kernel's slots (coo_to_csr.h:28-71 + eliminate_zeros) for strictly increasing targets ----
+// ---- CSR assembly of the kernel's slots (coo_to_csr.h:28-71 + eliminate_zeros), fast form for strictly increasing targets ----
 // row_nnz[targets[i] + 1] = number of NON-ZERO values among the first counts[i] entries of slot i   (row_nnz pre-zeroed, n_rows + 1 long;
 // an exclusive... inclusive scan over it then gives indptr directly)
 __global__ __launch_bounds__(256) void sp_slot_nnz_kernel(int n_targets, int k, const int *__restrict__ targets, const int *__restrict__ counts,
@@ -266,6 +266,80 @@ __global__ __launch_bounds__(256) void sp_csr_compact_kernel(int n_targets, int 
         const int n = counts[s];
         const long long src = s * (long long)k;
         long long dst = indptr[targets[s]];
+        for (int j0 = 0; j0 < n; j0 += 64) {
+            const int j = j0 + lane;
+            const float v = (j < n) ? values[src + j] : 0.f;
+            const int c = (j < n) ? cols[src + j] : 0;
+            const unsigned long long m = __ballot(v != 0.f);
+            if (v != 0.f) {
+                const long long q = dst + __popcll(m & ((1ull << lane) - 1ull));
+                out_indices[q] = c;
+                out_data[q] = v;
+            }
+            dst += __popcll(m);
+        }
+    }
+}
+
+// ---- the same for ANY order of the targets (unsorted, repeated: `target_rows=[7, 2, 7]`): coo_to_csr.h:28-71 is a STABLE counting
+// sort of the slots by row, so the entries of a row that is asked for twice appear slot after slot.  Per slot: its non-zero
+// count, the row's total (atomic) and the number of slots of its row; per row with more than one slot: its slots in slot order
+// (a scatter with an atomic cursor, then an insertion sort of the handful of slot ids) and each slot's offset inside the row. ----
+__global__ __launch_bounds__(256) void sp_slot_nnz_any_kernel(int n_targets, int k, const int *__restrict__ targets, const int *__restrict__ counts,
+                                                               const float *__restrict__ values, int *__restrict__ slot_nnz,
+                                                               int *__restrict__ row_nnz_shifted, int *__restrict__ row_slots_shifted) {
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6, n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long s = wave0; s < n_targets; s += n_waves) {
+        const int n = counts[s];
+        const float *v = values + s * (long long)k;
+        int c = 0;
+        for (int j = lane; j < n; j += 64) c += (v[j] != 0.f) ? 1 : 0;
+        c = ro_wave_sum(c);
+        if (lane == 0) {
+            slot_nnz[s] = c;
+            atomicAdd(&row_nnz_shifted[targets[s] + 1], c);
+            atomicAdd(&row_slots_shifted[targets[s] + 1], 1);
+        }
+    }
+}
+
+// bucket[bstart[t] + (arrival order)] = slot id, for every slot of row t
+__global__ __launch_bounds__(256) void sp_slot_scatter_kernel(int n_targets, const int *__restrict__ targets, const int *__restrict__ bstart,
+                                                               int *__restrict__ cursor, int *__restrict__ bucket) {
+    for (long long s = blockIdx.x * (long long)blockDim.x + threadIdx.x; s < n_targets; s += (long long)gridDim.x * blockDim.x) {
+        const int t = targets[s];
+        bucket[bstart[t] + atomicAdd(&cursor[t], 1)] = (int)s;
+    }
+}
+
+// slot_off[slot] = non-zero entries of the EARLIER slots of the same row (one thread per row; rows asked for once: 0)
+__global__ __launch_bounds__(256) void sp_slot_offsets_kernel(int n_rows, const int *__restrict__ bstart, int *__restrict__ bucket,
+                                                               const int *__restrict__ slot_nnz, int *__restrict__ slot_off) {
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n_rows; t += (long long)gridDim.x * blockDim.x) {
+        const int b0 = bstart[t], b1 = bstart[t + 1];
+        if (b1 - b0 == 1) { slot_off[bucket[b0]] = 0; continue; }
+        for (int i = b0 + 1; i < b1; ++i) {          // insertion sort by slot id: the scatter's arrival order is arbitrary
+            const int x = bucket[i];
+            int j = i - 1;
+            while (j >= b0 && bucket[j] > x) { bucket[j + 1] = bucket[j]; --j; }
+            bucket[j + 1] = x;
+        }
+        int run = 0;
+        for (int i = b0; i < b1; ++i) { slot_off[bucket[i]] = run; run += slot_nnz[bucket[i]]; }
+    }
+}
+
+// non-zero entries of slot i, in slot order, to [indptr[targets[i]] + slot_off[i], ...)
+__global__ __launch_bounds__(256) void sp_csr_compact_any_kernel(int n_targets, int k, const int *__restrict__ targets, const int *__restrict__ counts,
+                                                                  const int *__restrict__ cols, const float *__restrict__ values, const int *__restrict__ indptr,
+                                                                  const int *__restrict__ slot_off, int *__restrict__ out_indices, float *__restrict__ out_data) {
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6, n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long s = wave0; s < n_targets; s += n_waves) {
+        const int n = counts[s];
+        const long long src = s * (long long)k;
+        long long dst = (long long)indptr[targets[s]] + slot_off[s];
         for (int j0 = 0; j0 < n; j0 += 64) {
             const int j = j0 + lane;
             const float v = (j < n) ? values[src + j] : 0.f;

@@ -119,6 +119,20 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         load_desc(sh[SH_QB], dN, wN);
         __syncthreads();
     }
+    // precomputed work items of a row (sp_row_items_kernel): thread i holds record i of the row's block — record 0 the header,
+    // records 1.. the items — loaded a row ahead like the rest of the row pipeline
+    auto load_items = [&](int slot, int4 &rec, int &n_pre) {
+        rec = make_int4(0, 0, 0, 0);
+        n_pre = 0;
+        if (p.items_g != nullptr && slot >= 0 && slot < p.items_rows) {
+            const int4 *row = p.items_g + (size_t)slot * ITEMS_STRIDE;
+            n_pre = row[0].x;
+            if (tid < ITEMS_STRIDE) rec = row[tid];
+        }
+    };
+    int4 recC, recN;
+    int preC = 0, preN = 0;
+    load_items(dC.x, recC, preC);
     // m1 entry / m2 row bounds of segment `tid` of the current row (rows of this kernel have <= SORT_MAX <= NT entries)
     int my_r0 = 0, my_len = 0;
     float my_v = 0.f;
@@ -153,6 +167,8 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             nx_v = p.m1_data[dN.z + tid];
         }
         int nx_r0 = 0, nx_len = 0;
+        load_items(dN.x, recN, preN);
+        const int n_pre = __builtin_amdgcn_readfirstlane(preC);      // > 0: the row's items were cut by the prepass
 
         if (tid == 0) { sh[SH_PCTR] = 0; sh[SH_MCTR] = 0; sh[SH_NITEMS] = 0; sh[SH_CNT] = 0; sh[SH_SEL] = -1; sh[SH_NEED] = 0; }
         // Segment order.  The heaviest segments (largest |m1 value|: each segment scales its m2 row by its own m1 value)
@@ -161,7 +177,14 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         int my_ib = 0, my_fs = 0;       // first item / flat start of segment `tid`
         int n_items = 0;
         int4 dNN, wNN;
-        if (n1 <= 64) {
+        if (n_pre > 0) {
+            // nothing to set up: the records are in registers (they go to LDS below); the row pipeline's descriptor load stays
+            wg_sync<U_LDS>();
+            if (!p.static_sched) q_nn = sh[SH_QA];
+            load_desc(q_nn, dNN, wNN);
+            if (p.static_sched) q_nn += (int)gridDim.x;
+            n_items = n_pre;
+        } else if (n1 <= 64) {
             // One wave, one segment per lane, no barrier inside: the (up to) 8 largest |values| are found with 8 wave-max
             // rounds; heavy segments first, the others behind, both in their original order (ballot + mbcnt); item and
             // flat-start prefixes by one trip through LDS into position order and a DPP scan there.
@@ -276,7 +299,9 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         if (!failed) {
             // sentinel item behind the last one: a prefetch past the end loads nothing (every lane out of range)
             if (tid == NT - 1) items[n_items] = make_int4((int)OOB_SOFFSET, 0, 0, (int)macs32);
-            if (tid < n1) {
+            if (n_pre > 0) {
+                if (tid >= 1 && tid <= n_pre) items[tid - 1] = recC;
+            } else if (tid < n1) {
                 int q = 0;
                 for (int o = 0; o < my_len; o += ITEM, ++q)
                     items[my_ib + q] = make_int4((my_r0 + o) * 4, min(ITEM, my_len - o), (int)__float_as_uint(my_v), my_fs + o);
@@ -623,14 +648,22 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                         }
 #pragma unroll
                         for (int j = 0; j < 4; ++j) S[j] &= ~M[j];
+#if SP_ABLATION
+                        if (p.dbg & 32) { M[0] = M[1] = M[2] = M[3] = 0ull; }      // ablation: members are dropped
+                        if (p.dbg & 64) { S[0] = S[1] = S[2] = S[3] = 0ull; }      // ablation: survivors are dropped
+                        asm volatile("" ::"v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]));
+#endif
                         if ((M[0] | M[1]) | (M[2] | M[3])) {
                             const int n0 = __popcll(M[0]), n1 = __popcll(M[1]), n2 = __popcll(M[2]), n3 = __popcll(M[3]);
                             if (pool_reserve(wpm, n0 + n1 + n2 + n3, &sh[SH_MCTR], mpcap, &sh[SH_OVF])) {
-                                int pos = wpm.pos;
-                                lds_push64(M[0], __float_as_uint(x[0]), c[0] + 1u, pos, mpool_off); pos += n0;
-                                lds_push64(M[1], __float_as_uint(x[1]), c[1] + 1u, pos, mpool_off); pos += n1;
-                                lds_push64(M[2], __float_as_uint(x[2]), c[2] + 1u, pos, mpool_off); pos += n2;
-                                lds_push64(M[3], __float_as_uint(x[3]), c[3] + 1u, pos, mpool_off);
+                                int pos = __builtin_amdgcn_readfirstlane(wpm.pos);
+                                if (n0) lds_push64(M[0], __float_as_uint(x[0]), c[0] + 1u, pos, mpool_off);
+                                pos += n0;
+                                if (n1) lds_push64(M[1], __float_as_uint(x[1]), c[1] + 1u, pos, mpool_off);
+                                pos += n1;
+                                if (n2) lds_push64(M[2], __float_as_uint(x[2]), c[2] + 1u, pos, mpool_off);
+                                pos += n2;
+                                if (n3) lds_push64(M[3], __float_as_uint(x[3]), c[3] + 1u, pos, mpool_off);
                                 wpm.pos = pos + n3;
                             }
                         }
@@ -639,12 +672,16 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                             if constexpr (MONO) {
                                 // straight into the candidate buffer, keyed by the raw dot
                                 if (pool_reserve<16>(wps, n0 + n1 + n2 + n3, &sh[SH_CNT], cap, &sh[SH_OVF])) {     // small blocks: U is short of room
-                                    int pos = wps.pos;
+                                    int pos = __builtin_amdgcn_readfirstlane(wps.pos);
                                     if constexpr (U_LDS) {
-                                        lds_push64(S[0], c[0], fkey(x[0]), pos, u_off); pos += n0;
-                                        lds_push64(S[1], c[1], fkey(x[1]), pos, u_off); pos += n1;
-                                        lds_push64(S[2], c[2], fkey(x[2]), pos, u_off); pos += n2;
-                                        lds_push64(S[3], c[3], fkey(x[3]), pos, u_off);
+                                        // (survivors are rare once the cutoff has settled: most of the four masks are empty)
+                                        if (n0) lds_push64(S[0], c[0], fkey(x[0]), pos, u_off);
+                                        pos += n0;
+                                        if (n1) lds_push64(S[1], c[1], fkey(x[1]), pos, u_off);
+                                        pos += n1;
+                                        if (n2) lds_push64(S[2], c[2], fkey(x[2]), pos, u_off);
+                                        pos += n2;
+                                        if (n3) lds_push64(S[3], c[3], fkey(x[3]), pos, u_off);
                                     } else {
                                         if ((S[0] >> lane) & 1ull) U[pos + mbcnt64(S[0])] = ((u64)fkey(x[0]) << 32) | (u64)c[0];
                                         pos += n0;
@@ -987,6 +1024,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         wN = make_int4(__builtin_amdgcn_readfirstlane(wNN.x), __builtin_amdgcn_readfirstlane(wNN.y),
                        __builtin_amdgcn_readfirstlane(wNN.z), __builtin_amdgcn_readfirstlane(wNN.w));
         my_r0 = nx_r0; my_len = nx_len; my_v = nx_v;
+        recC = recN; preC = preN;
         wg_sync<U_LDS>();
         PHASE_END(PH_OUTPUT);
     }

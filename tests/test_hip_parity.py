@@ -738,11 +738,32 @@ def test_device_csr_assembly_equals_host_assembly(shape, density, k):
     want = _host.build_csr(call.targets, cols, vals, counts, 4, 4, 4)
     indptr, indices, data = _host.run_hip(call, csr_out=True)
     _csr_equal(sp.csr_array((data, indices, indptr), shape=(4, 4)), want)
-    # unsorted / repeated targets are refused by the device path (the wrappers then assemble on the host)
-    bad = _host.prepare(m, k=3, target_rows=[7, 2])
-    with pytest.raises(_abi.HipLibraryError, match="strictly increasing"):
-        _host.run_hip(bad, csr_out=True)
-    res = sim.cosine(m, k=3, target_rows=[7, 2, 7], verbose=False, format_output="csr")      # host assembly, rows added up slot after slot
+    # unsorted / repeated targets (coo_to_csr.h:28-71 is a stable counting sort by row: a row asked for twice holds its slots one
+    # after the other): assembled on the device like the sorted case, equal to the host assembly of the same call's slots
+    rng = np.random.default_rng(9)
+    for tr in ([7, 2], [7, 2, 7], [40, 3, 3, 3, 63, 2, 40], rng.integers(0, m.shape[0], min(300, m.shape[0])), np.arange(m.shape[0])[::-1].copy()):
+        for kw in (dict(l2=1), dict(l1=1, threshold=0.3)):
+            call = _host.prepare(m, k=k, target_rows=tr, **kw)
+            rows, cols, vals, counts = _host.run_hip(call)
+            want = _host.build_csr(call.targets, cols, vals, counts, call.k, call.n_rows_m1, call.n_output_cols)
+            indptr, indices, data = _host.run_hip(call, csr_out=True)
+            got = sp.csr_array((data, indices, indptr), shape=want.shape)
+            assert indptr[-1] == data.shape[0] == indices.shape[0] == want.nnz
+            np.testing.assert_array_equal(got.indptr, want.indptr)
+            # (the order of the entries INSIDE a slot is unspecified in both; the order of the slots of a row is not: a row that
+            # is asked for n times holds n consecutive copies of its top-k)
+            tl = list(call.targets)
+            for r in set(tl):
+                n_rep = tl.count(r)
+                gi, wi = got.indices[got.indptr[r]:got.indptr[r + 1]], want.indices[want.indptr[r]:want.indptr[r + 1]]
+                gd, wd = got.data[got.indptr[r]:got.indptr[r + 1]], want.data[want.indptr[r]:want.indptr[r + 1]]
+                assert gi.shape[0] % n_rep == 0
+                per = gi.shape[0] // n_rep
+                for q in range(n_rep):
+                    og, ow = np.argsort(gi[q * per:(q + 1) * per], kind="stable"), np.argsort(wi[q * per:(q + 1) * per], kind="stable")
+                    np.testing.assert_array_equal(gi[q * per:(q + 1) * per][og], wi[q * per:(q + 1) * per][ow])
+                    np.testing.assert_allclose(gd[q * per:(q + 1) * per][og], wd[q * per:(q + 1) * per][ow], rtol=1e-6, atol=0)
+    res = sim.cosine(m, k=3, target_rows=[7, 2, 7], verbose=False, format_output="csr")      # through the public wrapper
     assert res[[7], :].nnz == 6 and res[[2], :].nnz == 3
 
 
