@@ -173,6 +173,12 @@ typedef struct sp_knn_args {
     float    norm_c1, norm_c2; /* SP_FLAG_NORMS_ON_DEVICE: Xcosine = (sum x^2 + norm_add)^norm_c1, Ycosine = (sum y^2 + norm_add)^norm_c2 */
     float    norm_add;         /* additive_shrink */
     int32_t  _pad2;
+
+    /* ABI 4 */
+    const uint8_t *col_keep;   /* optional, with SP_FLAG_M2_IS_M1_T: [n_rows_m1] bytes; output columns c (= rows of m1) with col_keep[c] == 0
+                                  are left out of the m2 built on the device — the ARRAY form of filter_cols / target_cols
+                                  (compute_target_columns + _filter_matrix_columns, s_plus_utils.pyx:364-490), which the reference applies to
+                                  matrix2 on the host.  NULL: every column stays. */
 } sp_knn_args;
 
 /* The hot path.  Replaces compute_similarities_parallel<int,float> (s_plus.h:265). */
@@ -197,7 +203,7 @@ const char *sp_last_error(void);
 int64_t sp_device_cache_trim(void);
 
 /* ABI version of this header. */
-#define SP_KNN_ABI_VERSION 3
+#define SP_KNN_ABI_VERSION 4
 int sp_abi_version(void);
 
 #ifdef __cplusplus

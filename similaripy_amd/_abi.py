@@ -107,6 +107,7 @@ class SpKnnArgs(C.Structure):
         ("csr_nnz", C.c_int64),
         ("explicit_zeros", C.c_int64),
         ("norm_c1", C.c_float), ("norm_c2", C.c_float), ("norm_add", C.c_float), ("_pad2", C.c_int32),
+        ("col_keep", C.c_void_p),
     ]
 
 

@@ -82,6 +82,7 @@ class KernelCall:
     depop_rowsum_p2: Optional[float] = None  # SP_FLAG_DEPOP_ROWSUM: Ydepop = (row sums of the raw m1)^p2, built on the device
     m1_is_m2t: bool = False    # m1 = m2^T is built on the device (SP_FLAG_M1_IS_M2_T, matrix1 came as CSC): the m1_* arrays are empty
     norms_on_device: Optional[tuple] = None  # SP_FLAG_NORMS_ON_DEVICE: (c1, c2, additive_shrink); X/Y tversky / cosine vectors are empty
+    col_keep: Optional[np.ndarray] = None    # with m2_is_m1t: uint8 [n_rows_m1], 0 = the output column is dropped while m2 is built (ARRAY selectors)
 
     @property
     def n_targets(self) -> int:
@@ -242,9 +243,13 @@ def build_cosine_normalization(m1_sq, m2_sq, c1, c2, additive_shrink):
             np.power(m2_sq + add, c2, dtype=np.float32))
 
 
-def build_depop_normalization(m1, m2, n_rows_m1, n_cols_m2, weight_spec1, weight_spec2, p1, p2, sums_on_device: bool = False):
+def build_depop_normalization(m1, m2, n_rows_m1, n_cols_m2, weight_spec1, weight_spec2, p1, p2, sums_on_device: bool = False,
+                              m2_is_m1t: bool = False):
     """w^p, 'none' -> ones, 'sum' -> csr_sum^p — s_plus_utils.pyx:231-278.
-    m1/m2 are (data, indices, indptr, n_cols) tuples of the float32 (or binarised) matrices."""
+    m1/m2 are (data, indices, indptr, n_cols) tuples of the float32 (or binarised) matrices.
+    m2_is_m1t: m2 = m1^T is never built on the host (m2 is ignored): its column sums are taken from the rows of m1 with the
+    arithmetic the reference applies to the columns of m2 (np.bincount: float64 running sum in storage order — the storage
+    order of a column of m1^T is the order of the row of m1)."""
     p1, p2 = float(np.float32(p1)), float(np.float32(p2))
 
     def power(w, p):
@@ -259,6 +264,10 @@ def build_depop_normalization(m1, m2, n_rows_m1, n_cols_m2, weight_spec1, weight
         if spec == 'none':
             return np.ones(n_rows_m1 if which == 1 else n_cols_m2, dtype=np.float32)
         if spec == 'sum':
+            if which == 2 and m2_is_m1t:
+                d, _, ptr, _ = m1
+                row_of = np.repeat(np.arange(n_rows_m1, dtype=np.int32), np.diff(ptr))
+                return power(np.bincount(row_of, weights=d, minlength=n_rows_m1).astype(np.float32, copy=False), p)
             d, i, ptr, nc = m1 if which == 1 else m2
             if which == 2 and sums_on_device:      # column sums of m2: the device's np.bincount (sp_csr_col_sums_f32)
                 return power(col_sums_hip(d, i, nc, square=False), p)
@@ -422,8 +431,9 @@ def prepare(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_mat
 
     m2_on_device: for the `matrix2=None` call, leave the transpose (s_plus.pyx:169-170, 205-206) to the device
     (SP_FLAG_M2_IS_M1_T, include/sp_prep.h): m2 is never built on the host, its column norms are taken from the
-    rows of m1 with the arithmetic the reference applies to the columns of m2.  Falls back to the host
-    transpose when the call needs m2 on the host (ARRAY column selectors, depopularisation weights).
+    rows of m1 with the arithmetic the reference applies to the columns of m2.  ARRAY column selectors become a mask the
+    device applies while it builds m2 (KernelCall.col_keep); depopularisation weights ('none' / 'sum' / arrays) are taken
+    from m1.  Only p3_alpha with ARRAY selectors needs m2 on the host (similarity.p3alpha / rp3beta then preprocess there).
 
     norms_on_device: with the device-side transpose, leave _build_squared_norms / _build_cosine_normalization to the same
     library call (SP_FLAG_NORMS_ON_DEVICE): the call carries (c1, c2, additive_shrink) instead of the vectors.
@@ -450,11 +460,15 @@ def prepare(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_mat
     sel_f = build_column_selector(filter_cols)
     sel_t = build_column_selector(target_cols)
     p3 = p3_alpha is not None
-    on_dev = bool(m2_on_device) and m2_from_m1 and (l3 == 0 or (p3 and p3_depop_beta is not None)) and sel_f[0] != MODE_ARRAY and sel_t[0] != MODE_ARRAY
+    # ARRAY selectors drop whole columns of m2 (s_plus_utils.pyx:364-490): with the device-side transpose that is a mask over
+    # the rows of m1 it reads (KernelCall.col_keep).  Not together with p3_alpha: the reference normalises the rows of m2
+    # first and drops the columns afterwards, the mask would change the row sums.
+    arr_sel = sel_f[0] == MODE_ARRAY or sel_t[0] == MODE_ARRAY
+    on_dev = bool(m2_on_device) and m2_from_m1 and (l3 == 0 or not p3 or p3_depop_beta is not None) and not (p3 and arr_sel)
     if p3 and not on_dev:
         raise ValueError("p3_alpha needs the device-side transpose (matrix2=None, no array selectors)")
     dev_norms = on_dev and bool(norms_on_device) and (l1 != 0 or l2 != 0)
-    csc = (on_dev and bool(csc_direct) and getattr(matrix1, "format", None) == "csc" and (dev_norms or (l1 == 0 and l2 == 0))
+    csc = (on_dev and bool(csc_direct) and not arr_sel and getattr(matrix1, "format", None) == "csc" and (dev_norms or (l1 == 0 and l2 == 0))
            and matrix1.nnz <= np.iinfo(np.int32).max
            and not (check_zeros and matrix1.data.shape[0] and np.count_nonzero(matrix1.data) != matrix1.data.shape[0]))
     if csc:
@@ -511,13 +525,17 @@ def prepare(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_mat
     elif l3 != 0:
         call.Xdepop, call.Ydepop = build_depop_normalization(
             (m1_data, m1_indices, m1_indptr, n_rows_m2), (m2_data, m2_indices, m2_indptr, n_output_cols),
-            n_rows_m1, n_output_cols, weight_depop_matrix1, weight_depop_matrix2, p1, p2, sums_on_device=bool(m2_on_device))
+            n_rows_m1, n_output_cols, weight_depop_matrix1, weight_depop_matrix2, p1, p2, sums_on_device=bool(m2_on_device),
+            m2_is_m1t=on_dev and not csc)
         call.Xdepop = np.ascontiguousarray(call.Xdepop, dtype=np.float32)
         call.Ydepop = np.ascontiguousarray(call.Ydepop, dtype=np.float32)
 
     call.filter_mode, call.filter_m_indptr, call.filter_m_indices = sel_f
     call.target_col_mode, call.target_col_m_indptr, call.target_col_m_indices = sel_t
     if on_dev:
+        if arr_sel:
+            call.col_keep = np.zeros(n_output_cols, dtype=np.uint8)
+            call.col_keep[compute_target_columns(filter_cols, target_cols, n_output_cols)] = 1
         return call        # (the device builds m2 with ascending column ids; SP_FLAG_M1_IS_M2_T checks those of the caller's)
     if call.filter_mode == MODE_ARRAY or call.target_col_mode == MODE_ARRAY:
         keep = compute_target_columns(filter_cols, target_cols, n_output_cols)
@@ -603,6 +621,9 @@ def run_hip(call: KernelCall, device: Optional[int] = None, table_slots: int = 0
         x = _abi.as_i32(x); keep.append(x); return x.ctypes.data if x.size else None
 
     a.targets = i32(call.targets)
+    if call.col_keep is not None:
+        ck = np.ascontiguousarray(call.col_keep, dtype=np.uint8); keep.append(ck)
+        a.col_keep = ck.ctypes.data if ck.size else None
     a.m1_data, a.m1_indices, a.m1_indptr = f32(call.m1_data), i32(call.m1_indices), i32(call.m1_indptr)
     a.m2_data, a.m2_indices, a.m2_indptr = f32(call.m2_data), i32(call.m2_indices), i32(call.m2_indptr)
     a.Xtversky, a.Ytversky = f32(call.Xtversky), f32(call.Ytversky)

@@ -254,6 +254,9 @@ int validate(const sp_knn_args *a) {
         return fail(SP_EINVAL, "SP_FLAG_P3_PREP / SP_FLAG_DEPOP_ROWSUM / SP_FLAG_NORMS_ON_DEVICE need SP_FLAG_M2_IS_M1_T or SP_FLAG_M1_IS_M2_T");
     if ((a->flags & SP_FLAG_DEPOP_ROWSUM) && !(a->flags & SP_FLAG_P3_PREP))
         return fail(SP_EINVAL, "SP_FLAG_DEPOP_ROWSUM needs SP_FLAG_P3_PREP");
+    if (a->col_keep && !m2t) return fail(SP_EINVAL, "col_keep needs SP_FLAG_M2_IS_M1_T (an explicit m2 is filtered by its owner)");
+    if (a->col_keep && (a->flags & SP_FLAG_P3_PREP))
+        return fail(SP_EINVAL, "col_keep excludes SP_FLAG_P3_PREP (the reference normalises the rows of matrix2 before it drops columns)");
     if ((a->flags & (SP_FLAG_CSR_OUT | SP_FLAG_CHECK_ZEROS)) && a->on_device)
         return fail(SP_EINVAL, "SP_FLAG_CSR_OUT / SP_FLAG_CHECK_ZEROS are host-mode flags (on_device = 0)");
     if ((a->flags & SP_FLAG_CSR_OUT) && a->n_targets > 0 && !a->csr_indptr) return fail(SP_EINVAL, "SP_FLAG_CSR_OUT needs csr_indptr");
@@ -557,6 +560,7 @@ int m2t_layout(const sp_knn_args *a, int n_cus, sp_knn_args *plain, M2tLayout *L
     *plain = *a;
     plain->flags &= ~(SP_FLAG_M2_IS_M1_T | SP_FLAG_M1_IS_M2_T | SP_FLAG_P3_PREP | SP_FLAG_DEPOP_ROWSUM | SP_FLAG_NORMS_ON_DEVICE);
     plain->nnz_m1 = plain->nnz_m2 = nnz;
+    plain->col_keep = nullptr;                 // (applied while m2 is built)
     Config c{};
     TRY(make_config(plain, n_cus, &c));
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -612,7 +616,7 @@ int run_device(sp_knn_args *a) {
     float *t_data = (float *)(ws + L.data);
     int *t_indices = (int *)(ws + L.indices), *t_indptr = (int *)(ws + L.indptr);
     int rc = m2t ? transpose_device(a->n_rows_m1, a->n_rows_m2, nnz, a->m1_data, a->m1_indices, a->m1_indptr,
-                                    t_data, t_indices, t_indptr, ws + L.tr, L.total - L.tr, stream)
+                                    t_data, t_indices, t_indptr, ws + L.tr, L.total - L.tr, stream, a->col_keep)
                  : transpose_device(a->n_rows_m2, a->n_rows_m1, nnz, a->m2_data, a->m2_indices, a->m2_indptr,
                                     t_data, t_indices, t_indptr, ws + L.tr, L.total - L.tr, stream);
     float tr_ms = 0.f;
@@ -869,6 +873,7 @@ int run_host(sp_knn_args *a) {
     }
     if (m2t) {                                 // m2 never exists on the host: built on the device from m1
         d.m2_data = nullptr; d.m2_indices = nullptr; d.m2_indptr = nullptr;
+        if (a->col_keep) TRY(pool.up(a->col_keep, (size_t)a->n_rows_m1, &d.col_keep));
     } else {
         TRY(pool.up(a->m2_data, (size_t)a->nnz_m2, &d.m2_data));
         TRY(pool.up(a->m2_indices, (size_t)a->nnz_m2, &d.m2_indices));

@@ -25,12 +25,26 @@ __global__ __launch_bounds__(256) void sp_tr_count_kernel(long long nnz, const i
         atomicAdd(&cnt[indices[i]], 1);
 }
 
-// one wave per input row
-__global__ __launch_bounds__(256) void sp_tr_scatter_kernel(int n_rows, const float *__restrict__ data, const int *__restrict__ indices,
-                                                             const int *__restrict__ indptr, int *__restrict__ cursor, tr_u64 *__restrict__ rec) {
+// the same with a mask over the INPUT rows (keep_rows[r] == 0: row r contributes nothing): one wave per input row
+__global__ __launch_bounds__(256) void sp_tr_count_rows_kernel(int n_rows, const int *__restrict__ indices, const int *__restrict__ indptr,
+                                                                const unsigned char *__restrict__ keep_rows, int *__restrict__ cnt) {
     const int lane = threadIdx.x & 63;
     const long long wave0 = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6, n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
     for (long long r = wave0; r < n_rows; r += n_waves) {
+        if (!keep_rows[r]) continue;
+        const int b = indptr[r], e = indptr[r + 1];
+        for (int i = b + lane; i < e; i += 64) atomicAdd(&cnt[indices[i]], 1);
+    }
+}
+
+// one wave per input row
+__global__ __launch_bounds__(256) void sp_tr_scatter_kernel(int n_rows, const float *__restrict__ data, const int *__restrict__ indices,
+                                                             const int *__restrict__ indptr, const unsigned char *__restrict__ keep_rows,
+                                                             int *__restrict__ cursor, tr_u64 *__restrict__ rec) {
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6, n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long r = wave0; r < n_rows; r += n_waves) {
+        if (keep_rows != nullptr && !keep_rows[r]) continue;
         const int b = indptr[r], e = indptr[r + 1];
         for (int i = b + lane; i < e; i += 64) {
             const int pos = atomicAdd(&cursor[indices[i]], 1);
@@ -308,15 +322,24 @@ size_t transpose_ws_bytes(long long nnz, int n_cols) {
     return (((size_t)n_cols + 1) * 4 * 2 + 255 & ~(size_t)255) + (((size_t)nnz * 8 + 255) & ~(size_t)255) + SCAN_SCRATCH_BYTES;
 }
 
-// all pointers on the device; asynchronous on `stream`
+// all pointers on the device; asynchronous on `stream`.  keep_rows (optional, [n_rows] bytes): input rows with a 0 are left out —
+// i.e. the COLUMNS of the result they would have become are empty: the ARRAY form of filter_cols / target_cols applied to
+// m2 = m1^T (_filter_matrix_columns, s_plus_utils.pyx:424-490) costs nothing when m2 is built here.  The output arrays then
+// hold fewer than nnz entries; their tails are zeroed (flat passes over "nnz(m2)" entries read them).
 int transpose_device(int n_rows, int n_cols, long long nnz, const float *data, const int *indices, const int *indptr,
-                     float *out_data, int *out_indices, int *out_indptr, void *ws, size_t ws_bytes, hipStream_t stream) {
+                     float *out_data, int *out_indices, int *out_indptr, void *ws, size_t ws_bytes, hipStream_t stream,
+                     const unsigned char *keep_rows = nullptr) {
     if (ws_bytes < transpose_ws_bytes(nnz, n_cols)) return fail(SP_EWORKSPACE, "transpose workspace too small");
     int *cnt = (int *)ws;
     int *cursor = cnt + ((size_t)n_cols + 1);
     tr_u64 *rec = (tr_u64 *)((unsigned char *)ws + (((size_t)n_cols + 1) * 4 * 2 + 255 & ~(size_t)255));
     HIP_TRY(hipMemsetAsync(cnt, 0, ((size_t)n_cols + 1) * 4, stream));
-    if (nnz > 0) {
+    if (nnz > 0 && keep_rows != nullptr) {
+        HIP_TRY(hipMemsetAsync(out_data, 0, (size_t)nnz * 4, stream));
+        HIP_TRY(hipMemsetAsync(out_indices, 0, (size_t)nnz * 4, stream));
+        const int blocks = (int)std::min<long long>(256 * 32, ((long long)n_rows + 3) / 4);
+        hipLaunchKernelGGL(sp_tr_count_rows_kernel, dim3(blocks), dim3(256), 0, stream, n_rows, indices, indptr, keep_rows, cnt);
+    } else if (nnz > 0) {
         const int blocks = (int)std::min<long long>(256 * 16, (nnz + 255) / 256);
         hipLaunchKernelGGL(sp_tr_count_kernel, dim3(blocks), dim3(256), 0, stream, nnz, indices, cnt);
     }
@@ -324,7 +347,7 @@ int transpose_device(int n_rows, int n_cols, long long nnz, const float *data, c
     scan_i32<false>(n_cols, cnt, out_indptr, cursor, nullptr, (unsigned char *)rec + (((size_t)nnz * 8 + 255) & ~(size_t)255), stream);
     if (nnz > 0 && n_rows > 0) {
         const int blocks = (int)std::min<long long>(256 * 32, ((long long)n_rows + 3) / 4);
-        hipLaunchKernelGGL(sp_tr_scatter_kernel, dim3(blocks), dim3(256), 0, stream, n_rows, data, indices, indptr, cursor, rec);
+        hipLaunchKernelGGL(sp_tr_scatter_kernel, dim3(blocks), dim3(256), 0, stream, n_rows, data, indices, indptr, keep_rows, cursor, rec);
         const int sb = std::min(n_cols, 256 * 32);
         hipLaunchKernelGGL(sp_tr_sort_lds_kernel<TR_SHORT>, dim3(sb), dim3(256), TR_SHORT * 8, stream, n_cols, 0, out_indptr, rec, out_indices, out_data);
         // (per device, and cheap: set on every call like the row kernels' launchers do)

@@ -50,6 +50,7 @@ class DeviceProblem:
                      "filter_m_indptr", "filter_m_indices", "target_col_m_indptr", "target_col_m_indices"):
             arr = getattr(call, name)
             self.t[name] = up(arr) if arr.size else None
+        self.t["col_keep"] = up(call.col_keep) if call.col_keep is not None and call.col_keep.size else None
         self._ws = None
 
     # ------------------------------------------------------------------
@@ -63,6 +64,7 @@ class DeviceProblem:
         a.nnz_m1, a.nnz_m2 = int(c.m1_data.shape[0]), int(c.m2_data.shape[0])
         p = lambda t: (t.data_ptr() if t is not None else None)  # noqa: E731
         a.targets = p(targets_t)
+        a.col_keep = p(self.t["col_keep"])
         a.m1_data, a.m1_indices, a.m1_indptr = p(self.t["m1_data"]), p(self.t["m1_indices"]), p(self.t["m1_indptr"])
         a.m2_data, a.m2_indices, a.m2_indptr = p(self.t["m2_data"]), p(self.t["m2_indices"]), p(self.t["m2_indptr"])
         a.Xtversky, a.Ytversky = p(self.t["Xtversky"]), p(self.t["Ytversky"])

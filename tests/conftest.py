@@ -134,9 +134,12 @@ def oracle_backend(monkeypatch):
             # the product leaves m1^T to the device (SP_FLAG_M2_IS_M1_T); the oracle gets it from scipy, as the reference does
             m2 = sp.csr_array((call.m1_data, call.m1_indices, call.m1_indptr), shape=(call.n_rows_m1, call.n_rows_m2)).T.tocsr()
             m2.sort_indices()
-            call = dataclasses.replace(call, m2_data=np.ascontiguousarray(m2.data, dtype=np.float32),
-                                       m2_indices=np.ascontiguousarray(m2.indices, dtype=np.int32),
-                                       m2_indptr=np.ascontiguousarray(m2.indptr, dtype=np.int32), m2_is_m1t=False)
+            d2, i2, p2 = (np.ascontiguousarray(m2.data, dtype=np.float32), np.ascontiguousarray(m2.indices, dtype=np.int32),
+                          np.ascontiguousarray(m2.indptr, dtype=np.int32))
+            if call.col_keep is not None:
+                # sp_knn_args.col_keep: the reference's _filter_matrix_columns on that m2 (s_plus_utils.pyx:424-490)
+                d2, i2, p2 = _host.filter_matrix_columns(d2, i2, p2, call.n_output_cols, np.flatnonzero(call.col_keep).astype(np.int32))
+            call = dataclasses.replace(call, m2_data=d2, m2_indices=i2, m2_indptr=p2, m2_is_m1t=False, col_keep=None)
         rows, cols, values = so.run_kernel(call, "port")
         counts, _ = so.slot_counts(rows, cols, values, call.targets, call.k) if call.n_targets else (np.zeros(0, np.int32), None)
         if kw.get("csr_out"):

@@ -19,7 +19,7 @@ PREP_HEADER = (ROOT / "include" / "sp_prep.h").read_text()
 
 def test_library_builds_and_loads():
     lib = _abi.load()
-    assert lib.sp_abi_version() == 3
+    assert lib.sp_abi_version() == 4
 
 
 def test_every_declared_symbol_is_exported():

@@ -865,3 +865,51 @@ def test_device_norms_of_an_explicit_matrix2():
             o = np.argsort(c)
             got.append((c[o].astype(np.int32), v[o].astype(np.float32)))
         so.compare_topk(got, want, 12, rtol=RTOL, atol=ATOL, what=fn.__name__)
+
+
+@pytest.mark.parametrize("shape,density", [((900, 500), 0.04), ((30000, 2500), 0.004)], ids=["generic_kernel", "sparse_kernel"])
+def test_array_selectors_and_depop_weights_with_the_device_transpose(shape, density):
+    """ARRAY filter_cols / target_cols and depopularisation weights on the `matrix2=None` call: m2 = m1^T is built on the
+    device with the dropped columns left out (sp_knn_args.col_keep) instead of on the host followed by
+    _filter_matrix_columns (s_plus_utils.pyx:364-490).  Against the oracle run on the host-prepared call (m2 built and
+    filtered by scipy / NumPy as the reference does it)."""
+    m = _rand(shape, density, 77)
+    m.data[::5] *= -1
+    n = shape[0]
+    rng = np.random.default_rng(5)
+    fc = rng.choice(n, n // 3, replace=False).tolist() + [n + 10, -3]          # out-of-range ids are dropped silently (:411, :418)
+    tc = rng.choice(n, n // 2, replace=False).tolist()
+    pop1, pop2 = rng.random(n).astype(np.float32) + 0.5, rng.random(n).astype(np.float32) + 0.5
+    targets = np.arange(0, n, max(1, n // 700), dtype=np.int32)
+    cases = [("filter", dict(l2=1, filter_cols=fc)), ("target", dict(l2=1, target_cols=tc)), ("both", dict(l1=0.5, l2=0.5, t1=0.7, t2=0.3, filter_cols=fc, target_cols=tc)),
+             ("all dropped", dict(l2=1, filter_cols=list(range(n)))),
+             ("sum weights", dict(l2=0.5, l3=1, weight_depop_matrix1="sum", weight_depop_matrix2="sum", p1=0.4, p2=0.6, filter_cols=fc)),
+             ("array weights", dict(l1=0.2, l2=0.2, l3=1, weight_depop_matrix1=pop1, weight_depop_matrix2=pop2, p1=0.4, p2=0.6))]
+    for what, kw in cases:
+        if "sum" in what:
+            mm = m.copy(); mm.data = np.abs(mm.data)      # (a negative sum under a fractional power is NaN in both)
+        else:
+            mm = m
+        dev = _host.prepare(mm, k=15, target_rows=targets, m2_on_device=True, norms_on_device=True, **kw)
+        host = _host.prepare(mm, k=15, target_rows=targets, **kw)
+        assert dev.m2_is_m1t and dev.m2_data.size == 0 and not host.m2_is_m1t, what
+        assert (dev.col_keep is not None) == ("filter_cols" in kw or "target_cols" in kw), what
+        rows, cols, vals, counts = _host.run_hip(dev)
+        got = so.canonical(rows, cols, vals, dev.targets, 15)
+        want = so.canonical(*so.run_kernel(host, "port"), host.targets, 15)
+        so.compare_topk(got, want, 15, rtol=RTOL, atol=ATOL, what=what)
+        if what == "all dropped":
+            assert not counts.any() and not vals.any()
+        # the same through the resident form (device pointers in, device pointers out)
+        if what in ("both", "sum weights"):
+            from similaripy_amd.device import DeviceProblem
+            prob = DeviceProblem(_host.prepare(mm, k=15, target_rows=targets, m2_on_device=True, **kw))
+            c2, v2, n2, _ = prob.alloc_outputs()
+            prob.run(c2, v2, n2)
+            np.testing.assert_array_equal(n2.cpu().numpy(), counts)
+    # and through a public wrapper, CSR assembled on the device
+    res = sim.cosine(m, k=15, filter_cols=fc, target_cols=tc, verbose=False, format_output="csr")
+    keep = _host.compute_target_columns(fc, tc, n)
+    assert np.isin(res.indices, keep).all() and res.nnz > 0
+    ref = sim.cosine(m, m.T.tocsr(), k=15, filter_cols=fc, target_cols=tc, verbose=False, format_output="csr")      # explicit m2: filtered on the host
+    _assert_same_topk(res, ref, 15) if n <= 2000 else np.testing.assert_array_equal(np.diff(res.indptr), np.diff(ref.indptr))

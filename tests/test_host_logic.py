@@ -201,6 +201,35 @@ def test_csc_matrix1_takes_the_direct_route(fn, kw, oracle_backend):
     np.testing.assert_allclose(getattr(sim, fn)(perm, k=6, verbose=False, format_output="csr", **kw).toarray(), b.toarray(), rtol=1e-6, atol=0)
 
 
+def test_array_selectors_and_depop_weights_keep_the_device_transpose(golden):
+    """ARRAY filter_cols / target_cols (compute_target_columns + _filter_matrix_columns, s_plus_utils.pyx:364-490) and the
+    depopularisation weights (:231-278) no longer need m2 on the host: the call carries a column mask for the device-side
+    transpose, and the 'sum' weights of m2 = m1^T come from the rows of m1 with np.bincount's arithmetic."""
+    A = golden.inputs["A"]
+    n = A.shape[0]
+    fc, tc = list(range(0, 300, 3)), [1, 2, 3, 4, 5, 6, 50, 51, 250, 1000, -4]
+    call = _host.prepare(A, k=10, filter_cols=fc, target_cols=tc, m2_on_device=True)
+    assert call.m2_is_m1t and call.m2_data.size == 0 and call.col_keep.dtype == np.uint8 and call.col_keep.shape == (n,)
+    np.testing.assert_array_equal(np.flatnonzero(call.col_keep), _host.compute_target_columns(fc, tc, n))
+    assert _host.prepare(A, k=10, m2_on_device=True).col_keep is None
+    # the host route (multi-GPU staging) still filters m2 itself
+    host = _host.prepare(A, k=10, l2=1.0, filter_cols=fc, target_cols=tc, m2_on_device=False)
+    assert not host.m2_is_m1t and host.col_keep is None and host.m2_data.size < A.nnz
+    # weights: 'sum' of m2's columns == what the reference takes from the host transpose, bit for bit
+    d1, i1, p1 = _csr(A)
+    m2 = A.T.tocsr()
+    d2, i2, p2 = _csr(m2)
+    for w1, w2 in (("sum", "sum"), ("none", golden.inputs["pop2"]), (golden.inputs["pop1"], "none")):
+        dev = _host.prepare(A, k=10, l3=1.0, weight_depop_matrix1=w1, weight_depop_matrix2=w2, p1=0.7, p2=0.3, m2_on_device=True)
+        ref = _host.prepare(A, k=10, l3=1.0, weight_depop_matrix1=w1, weight_depop_matrix2=w2, p1=0.7, p2=0.3, m2_on_device=False)
+        assert dev.m2_is_m1t and not ref.m2_is_m1t
+        np.testing.assert_array_equal(dev.Xdepop, ref.Xdepop)
+        np.testing.assert_array_equal(dev.Ydepop, ref.Ydepop)
+    # p3alpha preprocessing inside the call excludes the mask (rows of m2 are normalised BEFORE columns are dropped)
+    with pytest.raises(ValueError):
+        _host.prepare(A, k=10, filter_cols=fc, m2_on_device=True, p3_alpha=1.0)
+
+
 def test_coo_attached_without_the_constructor_equals_the_constructed_one():
     rng = np.random.default_rng(0)
     rows = np.repeat(np.arange(50, dtype=np.int32), 4)
