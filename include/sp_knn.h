@@ -175,10 +175,12 @@ typedef struct sp_knn_args {
     int32_t  _pad2;
 
     /* ABI 4 */
-    const uint8_t *col_keep;   /* optional, with SP_FLAG_M2_IS_M1_T: [n_rows_m1] bytes; output columns c (= rows of m1) with col_keep[c] == 0
-                                  are left out of the m2 built on the device — the ARRAY form of filter_cols / target_cols
-                                  (compute_target_columns + _filter_matrix_columns, s_plus_utils.pyx:364-490), which the reference applies to
-                                  matrix2 on the host.  NULL: every column stays. */
+    const uint8_t *col_keep;   /* optional: [n_output_cols] bytes; output columns c with col_keep[c] == 0 are dropped from m2 before the
+                                  row kernels run — the ARRAY form of filter_cols / target_cols (compute_target_columns +
+                                  _filter_matrix_columns, s_plus_utils.pyx:364-490), which the reference applies to matrix2 on the host.
+                                  With SP_FLAG_M2_IS_M1_T (host or device pointers): the rows of m1 with a 0 are skipped while m2 = m1^T
+                                  is built.  With an explicit m2: host mode only (the uploaded copy is compacted; a device-resident m2
+                                  belongs to the caller).  Not with SP_FLAG_P3_PREP / SP_FLAG_M1_IS_M2_T.  NULL: every column stays. */
 } sp_knn_args;
 
 /* The hot path.  Replaces compute_similarities_parallel<int,float> (s_plus.h:265). */

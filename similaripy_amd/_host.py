@@ -422,7 +422,7 @@ def prepare(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_mat
             stabilized_shrink=0.0, bayesian_shrink=0.0, additive_shrink=0.0, threshold=0.0,
             binary=False, target_rows=None, filter_cols=None, target_cols=None,
             verbose=False, format_output='csr', m2_on_device=False, check_zeros=True,
-            p3_alpha=None, p3_depop_beta=None, norms_on_device=False, csc_direct=False) -> KernelCall:
+            p3_alpha=None, p3_depop_beta=None, norms_on_device=False, csc_direct=False, keep_on_device=False) -> KernelCall:
     """Everything s_plus.pyx does before the `with nogil:` block (:168-353).
 
     check_zeros=False: stored zeros are looked for on the device (run_hip(check_zeros=True)) instead of here.
@@ -439,7 +439,9 @@ def prepare(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_mat
     library call (SP_FLAG_NORMS_ON_DEVICE): the call carries (c1, c2, additive_shrink) instead of the vectors.
     csc_direct: a CSC matrix1 (`URM.T` of a CSR URM: the documented item-item call) is not converted on the host
     (matrix1.tocsr(), s_plus.pyx:205-206): its arrays ARE the CSR of matrix2 = matrix1.T, and m1 is built from them on
-    the device (SP_FLAG_M1_IS_M2_T).  Needs norms_on_device (there is no m1 on the host to take norms from)."""
+    the device (SP_FLAG_M1_IS_M2_T).  Needs norms_on_device (there is no m1 on the host to take norms from).
+    keep_on_device: ARRAY selectors on an EXPLICIT matrix2 are left to the library's host-mode entry too (col_keep: the
+    uploaded m2 is compacted on the device) instead of _filter_matrix_columns here; such a call cannot go to DeviceProblem."""
     m2_from_m1 = matrix2 is None
     if matrix2 is None:
         matrix2 = matrix1.T
@@ -537,7 +539,10 @@ def prepare(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_mat
             call.col_keep = np.zeros(n_output_cols, dtype=np.uint8)
             call.col_keep[compute_target_columns(filter_cols, target_cols, n_output_cols)] = 1
         return call        # (the device builds m2 with ascending column ids; SP_FLAG_M1_IS_M2_T checks those of the caller's)
-    if call.filter_mode == MODE_ARRAY or call.target_col_mode == MODE_ARRAY:
+    if arr_sel and keep_on_device:
+        call.col_keep = np.zeros(n_output_cols, dtype=np.uint8)
+        call.col_keep[compute_target_columns(filter_cols, target_cols, n_output_cols)] = 1
+    elif arr_sel:
         keep = compute_target_columns(filter_cols, target_cols, n_output_cols)
         call.m2_data, call.m2_indices, call.m2_indptr = filter_matrix_columns(
             m2_data, m2_indices, m2_indptr, n_output_cols, keep)
@@ -721,7 +726,7 @@ def _s_plus_impl(matrix1, matrix2, weight_depop_matrix1, weight_depop_matrix2, p
     device_zero_check = not binary
     opts = dict(check_zeros=not device_zero_check, csc_direct=True)
     while True:
-        call = prepare(*args, m2_on_device=True, norms_on_device=True, **opts, **p3kw)
+        call = prepare(*args, m2_on_device=True, norms_on_device=True, keep_on_device=True, **opts, **p3kw)
         # CSR results are assembled on the device whatever the order of target_rows (SP_FLAG_CSR_OUT: the stable counting sort of
         # coo_to_csr.h:28-71, repeats included)
         csr_out = format_output == 'csr' and call.n_targets > 0 and call.n_targets * call.k <= np.iinfo(np.int32).max

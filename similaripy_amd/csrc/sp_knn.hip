@@ -254,7 +254,8 @@ int validate(const sp_knn_args *a) {
         return fail(SP_EINVAL, "SP_FLAG_P3_PREP / SP_FLAG_DEPOP_ROWSUM / SP_FLAG_NORMS_ON_DEVICE need SP_FLAG_M2_IS_M1_T or SP_FLAG_M1_IS_M2_T");
     if ((a->flags & SP_FLAG_DEPOP_ROWSUM) && !(a->flags & SP_FLAG_P3_PREP))
         return fail(SP_EINVAL, "SP_FLAG_DEPOP_ROWSUM needs SP_FLAG_P3_PREP");
-    if (a->col_keep && !m2t) return fail(SP_EINVAL, "col_keep needs SP_FLAG_M2_IS_M1_T (an explicit m2 is filtered by its owner)");
+    if (a->col_keep && !m2t && (a->on_device || m1t))
+        return fail(SP_EINVAL, "col_keep with an explicit m2 is a host-mode option (device-resident m2 is filtered by its owner)");
     if (a->col_keep && (a->flags & SP_FLAG_P3_PREP))
         return fail(SP_EINVAL, "col_keep excludes SP_FLAG_P3_PREP (the reference normalises the rows of matrix2 before it drops columns)");
     if ((a->flags & (SP_FLAG_CSR_OUT | SP_FLAG_CHECK_ZEROS)) && a->on_device)
@@ -945,6 +946,32 @@ int run_host(sp_knn_args *a) {
         }
         if (h[18]) return fail(SP_EUNSORTED, "SP_FLAG_M1_IS_M2_T: %d rows of m2 do not have ascending column ids", h[18]);
     }
+
+    if (a->col_keep && !m2t && a->nnz_m2 > 0) {
+        // ARRAY selectors on an explicit m2: the uploaded copy is compacted here (only now: its row pointers and column ids have
+        // just been validated)
+        const unsigned char *keep = nullptr;
+        int *n_indptr = nullptr, *n_idx = nullptr;
+        float *n_val = nullptr;
+        long long *kept = nullptr, *scan_part = nullptr;
+        TRY(pool.up(a->col_keep, (size_t)a->n_output_cols, &keep));
+        TRY(pool.alloc((size_t)a->n_rows_m2 + 1, &n_indptr));
+        TRY(pool.alloc((size_t)a->nnz_m2, &n_idx));
+        TRY(pool.alloc((size_t)a->nnz_m2, &n_val));
+        TRY(pool.alloc(1, &kept));
+        TRY(pool.alloc((size_t)SCAN_CHUNKS, &scan_part));
+        HIP_TRY(hipMemsetAsync(n_indptr, 0, ((size_t)a->n_rows_m2 + 1) * 4, nullptr));
+        const int wb = std::max(1, std::min(256 * 16, (a->n_rows_m2 + 3) / 4));
+        hipLaunchKernelGGL(sp_keep_count_kernel, dim3(wb), dim3(256), 0, nullptr, a->n_rows_m2, d.m2_indptr, d.m2_indices, keep, n_indptr);
+        scan_i32<true>((long long)a->n_rows_m2 + 1, n_indptr, n_indptr, nullptr, kept, scan_part, nullptr);
+        hipLaunchKernelGGL(sp_keep_compact_kernel, dim3(wb), dim3(256), 0, nullptr, a->n_rows_m2, d.m2_indptr, d.m2_indices, d.m2_data, keep, n_indptr, n_idx, n_val);
+        HIP_TRY(hipGetLastError());
+        long long n_kept = 0;
+        HIP_TRY(hipMemcpy(&n_kept, kept, sizeof(n_kept), hipMemcpyDeviceToHost));
+        d.m2_indptr = n_indptr; d.m2_indices = n_idx; d.m2_data = n_val;
+        d.nnz_m2 = n_kept;
+    }
+    d.col_keep = m2t ? d.col_keep : nullptr;
 
     const bool csr_out = (a->flags & SP_FLAG_CSR_OUT) != 0;
     bool targets_ascend = true;      // strictly increasing targets: the slots already are in row order

@@ -281,6 +281,45 @@ __global__ __launch_bounds__(256) void sp_csr_compact_kernel(int n_targets, int 
     }
 }
 
+// ---- ARRAY column selectors on an explicit m2 (_filter_matrix_columns, s_plus_utils.pyx:424-490): entries whose column has
+// keep[c] == 0 are dropped, the order inside a row stays.  One wave per row: kept entries per row (shifted by one: an inclusive
+// scan gives the new row pointers), then the compaction. ----
+__global__ __launch_bounds__(256) void sp_keep_count_kernel(int n_rows, const int *__restrict__ indptr, const int *__restrict__ indices,
+                                                             const unsigned char *__restrict__ keep, int *__restrict__ row_nnz_shifted) {
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6, n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long r = wave0; r < n_rows; r += n_waves) {
+        const int b = indptr[r], e = indptr[r + 1];
+        int c = 0;
+        for (int i = b + lane; i < e; i += 64) c += keep[indices[i]] ? 1 : 0;
+        c = ro_wave_sum(c);
+        if (lane == 0) row_nnz_shifted[r + 1] = c;
+    }
+}
+
+__global__ __launch_bounds__(256) void sp_keep_compact_kernel(int n_rows, const int *__restrict__ indptr, const int *__restrict__ indices,
+                                                               const float *__restrict__ data, const unsigned char *__restrict__ keep,
+                                                               const int *__restrict__ new_indptr, int *__restrict__ out_indices, float *__restrict__ out_data) {
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6, n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long r = wave0; r < n_rows; r += n_waves) {
+        const int b = indptr[r], e = indptr[r + 1];
+        int dst = new_indptr[r];
+        for (int i0 = b; i0 < e; i0 += 64) {
+            const int i = i0 + lane;
+            const int c = (i < e) ? indices[i] : 0;
+            const bool kept = (i < e) && keep[c] != 0;
+            const unsigned long long m = __ballot(kept);
+            if (kept) {
+                const int q = dst + __popcll(m & ((1ull << lane) - 1ull));
+                out_indices[q] = c;
+                out_data[q] = data[i];
+            }
+            dst += __popcll(m);
+        }
+    }
+}
+
 // ---- the same for ANY order of the targets (unsorted, repeated: `target_rows=[7, 2, 7]`): coo_to_csr.h:28-71 is a STABLE counting
 // sort of the slots by row, so the entries of a row that is asked for twice appear slot after slot.  Per slot: its non-zero
 // count, the row's total (atomic) and the number of slots of its row; per row with more than one slot: its slots in slot order

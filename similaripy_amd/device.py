@@ -38,6 +38,8 @@ class DeviceProblem:
         # _host.run_hip — dropping those options silently would compute something else
         pending = [n for n, v in (("p3_alpha", call.p3_alpha), ("depop_rowsum_p2", call.depop_rowsum_p2),
                                   ("m1_is_m2t", call.m1_is_m2t or None), ("norms_on_device", call.norms_on_device)) if v is not None]
+        if call.col_keep is not None and not call.m2_is_m1t:
+            pending.append("col_keep on an explicit matrix2")
         if pending:
             raise ValueError(f"DeviceProblem: the call leaves {', '.join(pending)} to the library's host-mode entry; prepare it without "
                              f"those options (prepare(..., m2_on_device=...) only) or run it through _host.run_hip")

@@ -140,6 +140,10 @@ def oracle_backend(monkeypatch):
                 # sp_knn_args.col_keep: the reference's _filter_matrix_columns on that m2 (s_plus_utils.pyx:424-490)
                 d2, i2, p2 = _host.filter_matrix_columns(d2, i2, p2, call.n_output_cols, np.flatnonzero(call.col_keep).astype(np.int32))
             call = dataclasses.replace(call, m2_data=d2, m2_indices=i2, m2_indptr=p2, m2_is_m1t=False, col_keep=None)
+        if call.col_keep is not None:
+            # ... and on an explicit matrix2 (host mode compacts the uploaded copy)
+            d2, i2, p2 = _host.filter_matrix_columns(call.m2_data, call.m2_indices, call.m2_indptr, call.n_output_cols, np.flatnonzero(call.col_keep).astype(np.int32))
+            call = dataclasses.replace(call, m2_data=d2, m2_indices=i2, m2_indptr=p2, col_keep=None)
         rows, cols, values = so.run_kernel(call, "port")
         counts, _ = so.slot_counts(rows, cols, values, call.targets, call.k) if call.n_targets else (np.zeros(0, np.int32), None)
         if kw.get("csr_out"):

@@ -913,3 +913,24 @@ def test_array_selectors_and_depop_weights_with_the_device_transpose(shape, dens
     assert np.isin(res.indices, keep).all() and res.nnz > 0
     ref = sim.cosine(m, m.T.tocsr(), k=15, filter_cols=fc, target_cols=tc, verbose=False, format_output="csr")      # explicit m2: filtered on the host
     _assert_same_topk(res, ref, 15) if n <= 2000 else np.testing.assert_array_equal(np.diff(res.indptr), np.diff(ref.indptr))
+
+
+def test_array_selectors_on_an_explicit_matrix2_are_applied_on_the_device():
+    """An explicit matrix2 with ARRAY selectors: the uploaded m2 is compacted by the library's host-mode entry (col_keep)
+    instead of _filter_matrix_columns on the host (s_plus_utils.pyx:424-490).  Against the oracle on the host-filtered call."""
+    m1 = _rand((800, 350), 0.05, 61)
+    m2 = _rand((350, 1200), 0.05, 62)
+    rng = np.random.default_rng(9)
+    fc = rng.choice(1200, 500, replace=False).tolist() + [5000]
+    tc = rng.choice(1200, 700, replace=False).tolist()
+    for kw in (dict(filter_cols=fc), dict(target_cols=tc), dict(filter_cols=fc, target_cols=tc), dict(filter_cols=list(range(1200)))):
+        dev = _host.prepare(m1, m2, k=9, l2=1, m2_on_device=True, keep_on_device=True, **kw)
+        host = _host.prepare(m1, m2, k=9, l2=1, **kw)
+        assert dev.col_keep is not None and dev.m2_data.size == m2.nnz and host.col_keep is None and host.m2_data.size < m2.nnz
+        rows, cols, vals, counts = _host.run_hip(dev)
+        so.compare_topk(so.canonical(rows, cols, vals, dev.targets, 9), so.canonical(*so.run_kernel(host, "port"), host.targets, 9), 9, rtol=RTOL, atol=ATOL, what=str(list(kw)))
+        from similaripy_amd.device import DeviceProblem
+        with pytest.raises(ValueError):
+            DeviceProblem(dev)
+    res = sim.cosine(m1, m2, k=9, filter_cols=fc, target_cols=tc, verbose=False, format_output="csr")
+    assert res.nnz > 0 and np.isin(res.indices, _host.compute_target_columns(fc, tc, 1200)).all()
