@@ -659,9 +659,21 @@ def run_hip(call: KernelCall, device: Optional[int] = None, table_slots: int = 0
     return rows, cols, values, counts
 
 
+def slot_rows(targets: np.ndarray, counts: np.ndarray, k: int) -> np.ndarray:
+    """The `rows` array of the kernel's slots without downloading it: every entry of slot i is in row targets[i], the
+    padding behind counts[i] is (0, 0, 0.0) (s_plus.h:246-262 leaves the calloc'ed tail untouched)."""
+    n = int(targets.shape[0])
+    rows = np.repeat(np.asarray(targets, dtype=np.int32), k)
+    if n and not bool((counts == k).all()):
+        rows.reshape(n, k)[np.arange(k, dtype=np.int32)[None, :] >= counts[:, None]] = 0
+    return rows
+
+
 def finish(call: KernelCall, rows, cols, values, counts, format_output: str):
-    """Everything after the kernel in s_plus.pyx:386-433."""
+    """Everything after the kernel in s_plus.pyx:386-433.  rows=None: rebuilt from the targets and the per-slot counts."""
     if format_output == 'coo':
+        if rows is None:
+            rows = slot_rows(call.targets, counts, call.k)
         return build_coo(rows, cols, values, call.n_rows_m1, call.n_output_cols)
     return build_csr(call.targets, cols, values, counts, call.k, call.n_rows_m1, call.n_output_cols)
 
@@ -732,7 +744,8 @@ def _s_plus_impl(matrix1, matrix2, weight_depop_matrix1, weight_depop_matrix2, p
         csr_out = format_output == 'csr' and call.n_targets > 0 and call.n_targets * call.k <= np.iinfo(np.int32).max
         _say(verbose, "Computing")
         try:
-            out = run_hip(call, want_rows=(format_output != 'csr'), check_zeros=not opts["check_zeros"], csr_out=csr_out)
+            # (the row id of every slot entry is known on the host: a third of the COO download is never made)
+            out = run_hip(call, want_rows=False, check_zeros=not opts["check_zeros"], csr_out=csr_out)
             break
         except _abi.ExplicitZerosError:
             if opts["check_zeros"]:
