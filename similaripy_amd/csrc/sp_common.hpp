@@ -439,8 +439,9 @@ constexpr int POOL_BLK = 64;      // pool entries a wave reserves at a time (>= 
 constexpr int CS_MAXPROBE = 64;   // linear-probe budget in the collision set
 constexpr unsigned OOB_SOFFSET = 0xFFFFF000u;   // buffer-load scalar offset beyond any m2 extent: every lane out of range
 constexpr int SEL_E = 4;          // candidate-buffer entries per thread the register-resident selection handles
-constexpr int ITEMS_PRE = 224;    // work items per row that the per-call prepass cuts (rows with more, or with more than 64 m1 entries: in the kernel)
+constexpr int ITEMS_PRE = 511;    // item records per row that the per-call prepass cuts (rows with more, or with more than 64 m1 entries: in the kernel)
 constexpr int ITEMS_STRIDE = ITEMS_PRE + 1;
+constexpr int ITEM_W_BITS = 20;   // item record .w: products before the trip in the low bits, index of the trip's B record above
 constexpr int SORT_MAX = 256;     // m1 rows up to this many entries are visited in descending |value| order
 
 __device__ __forceinline__ int mbcnt64(u64 m) {
@@ -545,9 +546,9 @@ __device__ __forceinline__ void s1_core(const unsigned (&c)[4], const unsigned (
 }
 
 // The same for eight columns (two items) per lane: twice the LDS atomics in flight per wait, address registers reused
-// as soon as their atomic is issued.  MASKED: element j of item i is real iff 4*lane + j < cnt_i (padding ORs nothing).
+// as soon as their atomic is issued.  MASKED: element j of item i is real iff j < d_i (per lane; padding ORs nothing).
 template <int BM_OFF, bool MASKED>
-__device__ __forceinline__ void s1_core8(const unsigned (&c)[8], int lane4, int cnt0, int cnt1, unsigned amask, unsigned (&seen)[8]) {
+__device__ __forceinline__ void s1_core8(const unsigned (&c)[8], int d0, int d1, unsigned amask, unsigned (&seen)[8]) {
     unsigned a0, a1;
     if (!MASKED) {
         asm volatile(
@@ -596,7 +597,6 @@ __device__ __forceinline__ void s1_core8(const unsigned (&c)[8], int lane4, int 
             : [c0] "v"(c[0]), [c1] "v"(c[1]), [c2] "v"(c[2]), [c3] "v"(c[3]), [c4] "v"(c[4]), [c5] "v"(c[5]), [c6] "v"(c[6]), [c7] "v"(c[7]), [am] "s"(amask), [off] "i"(BM_OFF)
             : "memory");
     } else {
-        const int d0 = cnt0 - lane4, d1 = cnt1 - lane4;      // element j is real iff j < d
         asm volatile(
             "v_cmp_lt_i32 vcc, 0, %[d0]\n\t"
             "v_cndmask_b32 %[b0], 0, 1, vcc\n\t"
@@ -677,7 +677,8 @@ __device__ __forceinline__ void s1_core8(const unsigned (&c)[8], int lane4, int 
     }
 }
 
-// Sweep 2, four products per lane: x = value * segv, M[j] = lanes whose column is marked in the collision bitmap
+// Sweep 2, four products per lane: x = value * segv (segv per lane: the two pieces of a packed trip belong to different m1
+// entries), M[j] = lanes whose column is marked in the collision bitmap
 // (LDS offset 0, CBM_BYTES long), L[j] = lanes with !(x <= cut)  (NaN counts as above the cutoff).
 __device__ __forceinline__ void s2_core(const unsigned (&c)[4], const float (&v)[4], float segv, float cut, float (&x)[4], u64 (&M)[4], u64 (&L)[4]) {
     unsigned a0, a1, a2, a3;
@@ -717,7 +718,7 @@ __device__ __forceinline__ void s2_core(const unsigned (&c)[4], const float (&v)
           [M0] "=&s"(M[0]), [M1] "=&s"(M[1]), [M2] "=&s"(M[2]), [M3] "=&s"(M[3]),
           [L0] "=&s"(L[0]), [L1] "=&s"(L[1]), [L2] "=&s"(L[2]), [L3] "=&s"(L[3])
         : [c0] "v"(c[0]), [c1] "v"(c[1]), [c2] "v"(c[2]), [c3] "v"(c[3]),
-          [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]), [sv] "s"(segv), [cut] "s"(cut)
+          [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]), [sv] "v"(segv), [cut] "s"(cut)
         : "memory");
 }
 

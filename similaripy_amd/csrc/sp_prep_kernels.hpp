@@ -183,15 +183,28 @@ __global__ __launch_bounds__(256) void sp_row_desc_kernel(int n_targets, const i
     }
 }
 
-// Work items of the rows in the sparse queue, once per call (the sparse kernel's row setup — segment order, item and flat-start
-// prefixes, the item records — used to be ~4.7 k of a C2 row's 74 k cycles, done by one wave while fifteen waited).  One wave per
-// row: segment i = m1 entry i, visited in descending |m1 value| (each segment scales its m2 row by its m1 value: the large
-// products come first and the running k-th value starts high), cut into items of <= ITEM consecutive elements
-// {m2 byte offset, count, m1 value bits, flat start}.  Rows of more than 64 entries or more than ITEMS_PRE items get a 0 header:
-// the kernel sets those up itself.
+// Work items ("trips") of the rows in the sparse queue, once per call (the sparse kernel's row setup — segment order, item and
+// flat-start prefixes, the item records — used to be ~4.7 k of a C2 row's 74 k cycles, done by one wave while fifteen waited).
+// One wave per row: segment i = m1 entry i, visited in descending |m1 value| (each segment scales its m2 row by its m1 value: the
+// large products come first and the running k-th value starts high).
+//
+// A TRIP is what one wave fetches with one 16-byte load per lane: 64 lanes x 4 consecutive elements.  Cutting every m2 row into
+// its own trips leaves the last trip of each row partly empty (C2: rows of ~640 elements = 2.5 trips, a sixth of all lanes idle;
+// a user-scoring row of 100 elements fills 25 lanes of 64) — and the sweeps' time goes with the NUMBER of trips (each is a memory
+// round trip for its wave), not with the bytes.  So the segments are laid end to end on a virtual lane axis (a segment of `len`
+// elements takes ceil(len/4) lanes) and a trip is a window of 64 lanes of that axis: the lanes [0, sB) continue (or start) one
+// segment — piece A — and the lanes [sB, 64) start the next one — piece B.  At most TWO pieces per trip: a segment that would be
+// the third one in a window starts at the next window instead (only segments shorter than 64 lanes ever cause that).
+// Records (16 B each), the image of the kernel's LDS item area:
+//   [T] for T < n_trips:  {byte offset of A's first element in m2, elements of A in this trip, m1 value bits of A,
+//                          products before this trip | (index of the B record << 20, 0 = no B)}
+//   [n_trips]             the sentinel {OOB_SOFFSET, 0, 0, all products}
+//   [n_trips + 1 ...]     B records {byte offset, elements, m1 value bits, first lane sB}
+// row[0] = {n_trips, n_records, 0, 0}; rows of more than 64 entries, more than ITEMS_PRE records or 2^20 products get a 0 header:
+// the kernel sets those up itself (one piece per trip).  pack = 0: one piece per trip for every row (the 1024-thread shape).
 __global__ __launch_bounds__(256) void sp_row_items_kernel(const unsigned *__restrict__ qcount, int items_rows, const int4 *__restrict__ desc_s,
                                                             const int *__restrict__ m1_indices, const float *__restrict__ m1_data,
-                                                            const int *__restrict__ m2_indptr, int4 *__restrict__ items_g) {
+                                                            const int *__restrict__ m2_indptr, int4 *__restrict__ items_g, int pack) {
     const int lane = threadIdx.x & 63;
     const int n_rows = (int)qcount[0];
     const int waves_total = (int)(gridDim.x * (blockDim.x >> 6));
@@ -201,35 +214,81 @@ __global__ __launch_bounds__(256) void sp_row_items_kernel(const unsigned *__res
         if (slot >= items_rows) continue;
         int4 *row = items_g + (size_t)slot * ITEMS_STRIDE;
         if (n1 > 64) { if (lane == 0) row[0] = make_int4(0, 0, 0, 0); continue; }
-        int r0 = 0, len = 0;
-        unsigned vbits = 0u;
+        int r0_in = 0, len_in = 0;
+        unsigned vbits_in = 0u;
         if (lane < n1) {
             const int u = m1_indices[s + lane];
-            vbits = __float_as_uint(m1_data[s + lane]);
-            r0 = m2_indptr[u];
-            len = m2_indptr[u + 1] - r0;
+            vbits_in = __float_as_uint(m1_data[s + lane]);
+            r0_in = m2_indptr[u];
+            len_in = m2_indptr[u + 1] - r0_in;
         }
-        const unsigned key = (lane < n1 && len > 0) ? ((vbits & 0x7FFFFFFFu) | 1u) : 0u;      // 0 = no segment
+        const unsigned key = (lane < n1 && len_in > 0) ? ((vbits_in & 0x7FFFFFFFu) | 1u) : 0u;      // 0 = no segment
         // position of this lane's segment in descending key order (ties: lower lane first; empty lanes last): a permutation
         int rank = 0;
         for (int j = 0; j < 64; ++j) {
             const unsigned kj = (unsigned)__builtin_amdgcn_readlane((int)key, j);
             rank += (kj > key || (kj == key && j < lane)) ? 1 : 0;
         }
-        const int nit = (len + ITEM - 1) / ITEM;
-        // values in position order (lane i sends to lane rank_i), scanned there, and read back
-        const int nit_p = __builtin_amdgcn_ds_permute(rank * 4, key != 0u ? nit : 0);
-        const int len_p = __builtin_amdgcn_ds_permute(rank * 4, key != 0u ? len : 0);
-        const int ib_incl = wave_incl_scan_dpp(nit_p), fs_incl = wave_incl_scan_dpp(len_p);
-        const int ib = __builtin_amdgcn_ds_bpermute(rank * 4, ib_incl - nit_p);
-        const int fs = __builtin_amdgcn_ds_bpermute(rank * 4, fs_incl - len_p);
-        const int n_items = __builtin_amdgcn_readlane(ib_incl, 63);
-        if (n_items > ITEMS_PRE || n_items == 0) { if (lane == 0) row[0] = make_int4(0, 0, 0, 0); continue; }
-        if (key != 0u) {
-            int n = ib;
-            for (int o = 0; o < len; o += ITEM, ++n) row[1 + n] = make_int4((r0 + o) * 4, min(ITEM, len - o), (int)vbits, fs + o);
+        // from here on in POSITION order: lane i holds the i-th segment visited
+        const int r0 = __builtin_amdgcn_ds_permute(rank * 4, key != 0u ? r0_in : 0);
+        const int len = __builtin_amdgcn_ds_permute(rank * 4, key != 0u ? len_in : 0);
+        const unsigned vbits = (unsigned)__builtin_amdgcn_ds_permute(rank * 4, key != 0u ? (int)vbits_in : 0);
+        const int n_seg = __popcll(__ballot(key != 0u));
+        const int L = (len + 3) >> 2;                                   // lanes of the virtual axis
+        const int fs_incl = wave_incl_scan_dpp(len);
+        const int E = fs_incl - len;                                    // products of the segments before this one
+        const int total = __builtin_amdgcn_readlane(fs_incl, 63);
+        // first virtual lane of every segment: a sequential walk in scalar registers (<= 64 steps)
+        int V = 0, cur = 0, last_b = -1;
+        for (int j = 0; pack && j < n_seg; ++j) {
+            const int Lj = __builtin_amdgcn_readlane(L, j);
+            int at = cur;
+            if ((at & 63) != 0 && last_b == (at >> 6)) at = (at + 63) & ~63;      // that window has its second piece already
+            if ((at & 63) != 0) last_b = at >> 6;
+            if (lane == j) V = at;
+            cur = at + Lj;
         }
-        if (lane == 0) row[0] = make_int4(n_items, 0, 0, 0);
+        // Packing costs the sweeps ~25 instructions per trip (per-lane offsets, counts and m1 values instead of scalars): it pays
+        // when it removes a quarter of the trips or more (user-scoring rows of ~100 elements: half of them); otherwise (C2: rows of
+        // ~640 elements, 14 % fewer trips, no gain measured) every segment starts its own window, i.e. one piece per trip
+        {
+            const int t_incl = wave_incl_scan_dpp((L + 63) >> 6);
+            const int unpacked = __builtin_amdgcn_readlane(t_incl, 63);
+            if (!pack || 4 * ((cur + 63) >> 6) > 3 * unpacked) {
+                V = (t_incl - ((L + 63) >> 6)) * 64;
+                cur = unpacked * 64;
+            }
+        }
+        const int n_trips = (cur + 63) >> 6;
+        // the segment behind this one (it may be this segment's piece B in this segment's last window)
+        const int nx = ((lane + 1) & 63) * 4;
+        const int Vn = __builtin_amdgcn_ds_bpermute(nx, V), Ln = __builtin_amdgcn_ds_bpermute(nx, L);
+        const int r0n = __builtin_amdgcn_ds_bpermute(nx, r0), lenn = __builtin_amdgcn_ds_bpermute(nx, len);
+        const int vbn = __builtin_amdgcn_ds_bpermute(nx, (int)vbits);
+        const bool mine = lane < n_seg;
+        const bool has_b = mine && (lane + 1 < n_seg) && (Vn & 63) != 0;
+        const int b_incl = wave_incl_scan_dpp(has_b ? 1 : 0);
+        const int n_b = __builtin_amdgcn_readlane(b_incl, 63);
+        const int n_rec = n_trips + 1 + n_b;
+        if (n_seg == 0 || n_rec > ITEMS_PRE || total >= (1 << 20)) { if (lane == 0) row[0] = make_int4(0, 0, 0, 0); continue; }
+        if (mine) {
+            const int bidx = n_trips + 1 + (b_incl - 1);                // (only read when has_b)
+            const int t_first = (V >> 6) + ((V & 63) != 0 ? 1 : 0);     // first window whose lane 0 lies inside this segment
+            const int t_last = (V + L - 1) >> 6;
+            for (int T = t_first; T <= t_last; ++T) {
+                const int a = 64 * T - V;                               // lanes of the segment before this window
+                const int cnt = min(4 * min(64, L - a), len - 4 * a);
+                row[1 + T] = make_int4((r0 + 4 * a) * 4, cnt, (int)vbits, (E + 4 * a) | ((T == t_last && has_b) ? (bidx << 20) : 0));
+            }
+            if (has_b) {
+                const int sb = Vn & 63;
+                row[1 + bidx] = make_int4(r0n * 4, min(4 * min(64 - sb, Ln), lenn), vbn, sb);
+            }
+        }
+        if (lane == 0) {
+            row[1 + n_trips] = make_int4((int)OOB_SOFFSET, 0, 0, total);
+            row[0] = make_int4(n_trips, n_rec, 0, 0);
+        }
     }
 }
 

@@ -85,6 +85,12 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         else { ymin_tv = p.ymin[0]; ymin_cos = p.ymin[1]; ymin_dep = p.ymin[2]; }
     }
 
+#if SP_ABLATION
+    if (p.dbg & 128) {      // ablation: workgroups start staggered over ~one row time (are the CUs' phases locked to each other?)
+        const u64 until = (u64)clock64() + (u64)((blockIdx.x * 2654435761u) >> 16);      // 0 .. 65535 cycles
+        while ((u64)clock64() < until) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
     const bool timing = (p.phase_cycles != nullptr) && tid == 0;
     u64 tmark = timing ? (u64)clock64() : 0;
 #define PHASE_END(which) do { if (timing) { const u64 _n = (u64)clock64(); ph[which] += _n - tmark; tmark = _n; } } while (0)
@@ -121,18 +127,41 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
     }
     // precomputed work items of a row (sp_row_items_kernel): thread i holds record i of the row's block — record 0 the header,
     // records 1.. the items — loaded a row ahead like the rest of the row pipeline
-    auto load_items = [&](int slot, int4 &rec, int &n_pre) {
+    constexpr bool REC2 = NT < ITEMS_STRIDE;      // a small workgroup holds two records per thread
+    constexpr bool PACK_OK = NT == 256;
+    auto load_items = [&](int slot, int4 &rec, int4 &rec2, int2 &n_pre) {
         rec = make_int4(0, 0, 0, 0);
-        n_pre = 0;
+        rec2 = make_int4(0, 0, 0, 0);
+        n_pre = make_int2(0, 0);
         if (p.items_g != nullptr && slot >= 0 && slot < p.items_rows) {
             const int4 *row = p.items_g + (size_t)slot * ITEMS_STRIDE;
-            n_pre = row[0].x;
-            if (tid < ITEMS_STRIDE) rec = row[tid];
+            const int4 h = row[0];
+            n_pre = make_int2(h.x, h.y);
+            // the first 256 records without waiting for the header (the usual row has fewer); the others by load_items_hi, later in
+            // the row: a load that depends on the header here would put two memory round trips into the top of the row
+            if (tid < 256) rec = row[tid];
         }
     };
-    int4 recC, recN;
-    int preC = 0, preN = 0;
-    load_items(dC.x, recC, preC);
+    auto load_items_hi = [&](int slot, int4 &rec, int4 &rec2, int n_rec) {
+        if (n_rec >= 256) {
+            const int4 *row = p.items_g + (size_t)slot * ITEMS_STRIDE;
+            if (tid >= 256 && tid <= n_rec) rec = row[tid];
+            if (REC2 && tid + NT <= n_rec) rec2 = row[tid + NT];
+        }
+    };
+    // One trip of a wave: piece A = record `a` in lanes [0, sB), piece B (packed trips of the prepass only) in lanes [sB, 64).
+    // Per lane: byte offset of its quad in m2, the number of its real elements (<= 0: none), its m1 value.
+    auto trip_lane = [&](int offA, int cntA, unsigned svA, int offB, int cntB, unsigned svB, int sB, int &vo, int &d, float &sv) __attribute__((always_inline)) {
+        vo = offA + lane * 16;
+        d = cntA - 4 * lane;
+        sv = __uint_as_float(svA);
+        if (lane >= sB) { vo = offB + (lane - sB) * 16; d = cntB - 4 * (lane - sB); sv = __uint_as_float(svB); }
+        if (d <= 0) vo = (int)OOB_SOFFSET;          // lanes beyond the pieces fetch nothing
+    };
+    int4 recC, recN, recC2, recN2;
+    int2 preC = make_int2(0, 0), preN = make_int2(0, 0);
+    load_items(dC.x, recC, recC2, preC);
+    load_items_hi(dC.x, recC, recC2, preC.x > 0 ? preC.y : 0);
     // m1 entry / m2 row bounds of segment `tid` of the current row (rows of this kernel have <= SORT_MAX <= NT entries)
     int my_r0 = 0, my_len = 0;
     float my_v = 0.f;
@@ -167,8 +196,12 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             nx_v = p.m1_data[dN.z + tid];
         }
         int nx_r0 = 0, nx_len = 0;
-        load_items(dN.x, recN, preN);
-        const int n_pre = __builtin_amdgcn_readfirstlane(preC);      // > 0: the row's items were cut by the prepass
+        load_items(dN.x, recN, recN2, preN);
+        const int n_pre = __builtin_amdgcn_readfirstlane(preC.x);    // > 0: the row's trips were cut (and packed) by the prepass
+        const int n_rec = __builtin_amdgcn_readfirstlane(preC.y);    //      ... into this many records
+        // some trips carry a second piece (B records behind the sentinel).  Only the 256-thread shape is launched on packed rows
+        // (sp_row_items_kernel's `pack`): the per-lane bookkeeping costs the 1024-thread shape 2.4 % on C2 rows it never packs
+        const bool two_piece = PACK_OK && n_pre > 0 && n_rec > n_pre + 1;
 
         if (tid == 0) { sh[SH_PCTR] = 0; sh[SH_MCTR] = 0; sh[SH_NITEMS] = 0; sh[SH_CNT] = 0; sh[SH_SEL] = -1; sh[SH_NEED] = 0; }
         // Segment order.  The heaviest segments (largest |m1 value|: each segment scales its m2 row by its own m1 value)
@@ -257,7 +290,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             n_items = sh[SH_NITEMS];
             wg_sync<U_LDS>();                    // scratch read before the items overwrite it
         }
-        bool failed = (n_items >= ICAP) || (n_items > 63 * NW);      // (a wave keeps its <= 63 item descriptors in one register)
+        bool failed = (n_items >= ICAP) || (n_items > 63 * NW) || (n_pre > 0 && n_rec > ICAP);      // (a wave keeps its <= 63 item descriptors in one register)
         PHASE_END(PH_SETUP);
 
         RowCtx rc;
@@ -300,7 +333,9 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             // sentinel item behind the last one: a prefetch past the end loads nothing (every lane out of range)
             if (tid == NT - 1) items[n_items] = make_int4((int)OOB_SOFFSET, 0, 0, (int)macs32);
             if (n_pre > 0) {
-                if (tid >= 1 && tid <= n_pre) items[tid - 1] = recC;
+                // (the image holds the sentinel too: the same 16 bytes as the store above)
+                if (tid >= 1 && tid <= n_rec) items[tid - 1] = recC;
+                if (REC2 && tid + NT <= n_rec) items[tid + NT - 1] = recC2;
             } else if (tid < n1) {
                 int q = 0;
                 for (int o = 0; o < my_len; o += ITEM, ++q)
@@ -321,12 +356,29 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 // visited back to front: what sweep 1 reads last is what sweep 2 reads first (L2 still holds it)
                 const int n_mine = (n_items - wave + NW - 1) / NW;       // items wave, wave+NW, ...
                 const int4 myd = items[(lane < n_mine) ? wave + NW * (n_mine - 1 - lane) : n_items];
-                // a trip = two items (eight columns per lane): twice the loads and twice the LDS atomics in flight per wait
-                auto ld = [&](int trip, unsigned (&c)[8], int &cnt0, int &cnt1) __attribute__((always_inline)) {
+                // second piece of the item (packed trips of the prepass: lanes [sB, 64) belong to the NEXT segment); none: sB = 64
+                int3 mydB = make_int3(0, 0, 64);
+                if (two_piece) {
+                    const int bix = (int)((unsigned)myd.w >> ITEM_W_BITS);
+                    if (bix) { const int4 b = items[bix]; mydB = make_int3(b.x, b.y, b.w); }
+                }
+                // a trip = two items (eight columns per lane): twice the loads and twice the LDS atomics in flight per wait.
+                // d0 / d1: elements of this lane's quad that are real (<= 0: none)
+                auto ld = [&](int trip, unsigned (&c)[8], int &cnt0, int &cnt1, int &d0, int &d1) __attribute__((always_inline)) {
                     const int t0 = min(2 * trip, 63), t1 = min(2 * trip + 1, 63);
                     const int off0 = __builtin_amdgcn_readlane(myd.x, t0), off1 = __builtin_amdgcn_readlane(myd.x, t1);
                     cnt0 = __builtin_amdgcn_readlane(myd.y, t0);
                     cnt1 = __builtin_amdgcn_readlane(myd.y, t1);
+                    int vo0 = off0 + lane * 16, vo1 = off1 + lane * 16;
+                    d0 = cnt0 - 4 * lane;
+                    d1 = cnt1 - 4 * lane;
+                    if (two_piece) {
+                        const int sb0 = __builtin_amdgcn_readlane(mydB.z, t0), sb1 = __builtin_amdgcn_readlane(mydB.z, t1);
+                        const int ob0 = __builtin_amdgcn_readlane(mydB.x, t0), ob1 = __builtin_amdgcn_readlane(mydB.x, t1);
+                        const int cb0 = __builtin_amdgcn_readlane(mydB.y, t0), cb1 = __builtin_amdgcn_readlane(mydB.y, t1);
+                        if (lane >= sb0) { vo0 = ob0 + (lane - sb0) * 16; d0 = cb0 - 4 * (lane - sb0); }
+                        if (lane >= sb1) { vo1 = ob1 + (lane - sb1) * 16; d1 = cb1 - 4 * (lane - sb1); }
+                    }
                     // lanes beyond a partial item's end get an out-of-range offset: they fetch nothing (instead of the next m2 row)
                     // (lanes beyond a partial item's end read on into the next m2 row: in sweep 1 that over-fetch is cheaper than
                     // the instructions the out-of-range trick of sweep 2 costs here — measured 14.5k -> 15.6k cycles per row at C2.
@@ -336,12 +388,12 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     // static share 15.4k / 31.3k (it halves the 3.5k cycles the waves wait at the closing barrier, and spends
                     // more than that on the counter and descriptor round trips).  With the sweep bodies removed (dbg bits 8 | 16)
                     // the loads alone take 10.4k / 24.4k: the bodies do not overlap with the loads of the other waves.)
-                    const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, lane * 16, off0, 0);
-                    const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, lane * 16, off1, 0);
+                    const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, vo0, 0, 0);
+                    const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, vo1, 0, 0);
                     c[0] = v0.x; c[1] = v0.y; c[2] = v0.z; c[3] = v0.w;
                     c[4] = v1.x; c[5] = v1.y; c[6] = v1.z; c[7] = v1.w;
                 };
-                auto body = [&](const unsigned (&c)[8], int cnt0, int cnt1) __attribute__((always_inline)) {
+                auto body = [&](const unsigned (&c)[8], int cnt0, int cnt1, int d0, int d1) __attribute__((always_inline)) {
                     if (cnt0 == 0) return;                 // sentinel pair (wave-uniform; the second item of a pair may be the sentinel)
 #if SP_ABLATION
                     if (p.dbg & 8) { asm volatile("" ::"v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7])); return; }   // ablation: loads only
@@ -351,8 +403,8 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     // both at two levels, gains half of that)
                     __builtin_amdgcn_s_setprio(3);
                     unsigned seen[8];
-                    if (cnt0 == ITEM && cnt1 == ITEM) s1_core8<CBM_BYTES + PRE_BYTES, false>(c, 4 * lane, cnt0, cnt1, amask, seen);
-                    else s1_core8<CBM_BYTES + PRE_BYTES, true>(c, 4 * lane, cnt0, cnt1, amask, seen);      // padding ORs nothing
+                    if (cnt0 == ITEM && cnt1 == ITEM) s1_core8<CBM_BYTES + PRE_BYTES, false>(c, d0, d1, amask, seen);      // (an A piece of 256 fills the trip)
+                    else s1_core8<CBM_BYTES + PRE_BYTES, true>(c, d0, d1, amask, seen);      // padding ORs nothing
                     // ~2 % of the products find their column already there: mark it in the collision bitmap
                     if (__ballot(((seen[0] | seen[1]) | (seen[2] | seen[3]) | (seen[4] | seen[5]) | (seen[6] | seen[7])) != 0u)) {
 #pragma unroll
@@ -362,23 +414,33 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     __builtin_amdgcn_s_setprio(0);
                 };
                 unsigned cA[8], cB[8];
-                int nA0 = 0, nA1 = 0, nB0 = 0, nB1 = 0;
+                int nA0 = 0, nA1 = 0, nB0 = 0, nB1 = 0, dA0 = 0, dA1 = 0, dB0 = 0, dB1 = 0;
                 const int n_trips = (n_mine + 1) / 2;
                 int trip = 0;
-                ld(0, cA, nA0, nA1);
+#if SP_ABLATION
+                if (p.dbg & 256) {      // ablation: a loads-only pass first — what does the sweep cost when its lines are warm in L2 / MALL?
+                    for (int w = 0; w < n_trips; ++w) {
+                        ld(w, cA, nA0, nA1, dA0, dA1);
+                        asm volatile("" ::"v"(cA[0]), "v"(cA[1]), "v"(cA[2]), "v"(cA[3]), "v"(cA[4]), "v"(cA[5]), "v"(cA[6]), "v"(cA[7]));
+                    }
+                    wg_sync<U_LDS>();
+                    PHASE_END(PH_CSDRAIN);
+                }
+#endif
+                ld(0, cA, nA0, nA1, dA0, dA1);
                 while (trip < n_trips) {      // two pairs (4 KiB) in flight per wave (a third measured slower); bodies skip the sentinel
-                    ld(trip + 1, cB, nB0, nB1);
+                    ld(trip + 1, cB, nB0, nB1, dB0, dB1);
                     __builtin_amdgcn_sched_barrier(0);     // the prefetch is issued before the current pair is waited for
 #if SP_TRIPTIMERS
                     { const u64 w0 = clock64(); asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); const u64 w1 = clock64(); if (timing) ph[CT_PASSES] += w1 - w0; }
 #endif
-                    body(cA, nA0, nA1);
-                    ld(trip + 2, cA, nA0, nA1);
+                    body(cA, nA0, nA1, dA0, dA1);
+                    ld(trip + 2, cA, nA0, nA1, dA0, dA1);
                     __builtin_amdgcn_sched_barrier(0);
 #if SP_TRIPTIMERS
                     { const u64 w0 = clock64(); asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); const u64 w1 = clock64(); if (timing) ph[CT_PASSES] += w1 - w0; }
 #endif
-                    body(cB, nB0, nB1);
+                    body(cB, nB0, nB1, dB0, dB1);
                     trip += 2;
                 }
             }
@@ -401,6 +463,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 nx_r0 = p.m2_indptr[nx_u];
                 nx_len = p.m2_indptr[nx_u + 1] - nx_r0;
             }
+            load_items_hi(dN.x, recN, recN2, preN.x > 0 ? preN.y : 0);
             // the bitmap has done its job: back to zero (16-byte stores); its storage now serves sweep 2
             for (int i = tid; i < (nb_bytes >> 4); i += NT) ((int4 *)rA)[i] = make_int4(0, 0, 0, 0);
             // rank structure of the collision bitmap: pre16[w] = marked columns in the words below w.  The rank of a
@@ -461,6 +524,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 nx_r0 = p.m2_indptr[nx_u];
                 nx_len = p.m2_indptr[nx_u + 1] - nx_r0;
             }
+            load_items_hi(dN.x, recN, recN2, preN.x > 0 ? preN.y : 0);
         }
 
         if (!failed) {
@@ -497,19 +561,25 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     unsigned lmax = 0u;
                     const int4 d = items[wave];
                     const int cntA = __builtin_amdgcn_readfirstlane(d.y);
+                    int dq;      // real elements of this lane's quad
                     {
-                        const int off = __builtin_amdgcn_readfirstlane(d.x);
-                        const float segv = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane(d.z));
-                        const int vo = (4 * lane < cntA) ? lane * 16 : (int)(OOB_SOFFSET - (unsigned)off);
-                        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, vo, off, 0);
-                        const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs_val, vo, off, 0);
+                        int4 b4 = make_int4(0, 0, 0, 64);
+                        const int bix = two_piece ? (int)((unsigned)__builtin_amdgcn_readfirstlane(d.w) >> ITEM_W_BITS) : 0;
+                        if (bix) b4 = items[bix];
+                        int vo;
+                        float segv;
+                        trip_lane(__builtin_amdgcn_readfirstlane(d.x), cntA, (unsigned)__builtin_amdgcn_readfirstlane(d.z),
+                                  __builtin_amdgcn_readfirstlane(b4.x), __builtin_amdgcn_readfirstlane(b4.y), (unsigned)__builtin_amdgcn_readfirstlane(b4.z),
+                                  __builtin_amdgcn_readfirstlane(b4.w), vo, dq, segv);
+                        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, vo, 0, 0);
+                        const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs_val, vo, 0, 0);
                         c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w;
                         v[0] = __uint_as_float(b.x); v[1] = __uint_as_float(b.y); v[2] = __uint_as_float(b.z); v[3] = __uint_as_float(b.w);
                         s2_core(c, v, segv, cutx, x, M, S);
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const u64 ok = (cntA == ITEM) ? ~0ull : __ballot(4 * lane + j < cntA);
+                        const u64 ok = (cntA == ITEM) ? ~0ull : __ballot(j < dq);
                         M[j] &= ok;
                         S[j] &= ok & ~M[j];
                         if ((S[j] >> lane) & 1ull) lmax = max(lmax, fkey(x[j]));
@@ -521,10 +591,16 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     // no reduction needed), k + 2*NW ranks in total
                     int my_rounds;
                     {
-                        const int lw = (lane < NW) ? (items[lane].y + 3) / 4 : 0;              // lanes of item `lane`
+                        int lw = 0;                                                            // lanes of item `lane`
+                        if (lane < NW) {
+                            const int4 it = items[lane];
+                            lw = (it.y + 3) / 4;
+                            const int bix = two_piece ? (int)((unsigned)it.w >> ITEM_W_BITS) : 0;
+                            if (bix) lw += (items[bix].y + 3) / 4;
+                        }
                         const int lanes_all = wave_incl_scan_dpp(lw);                          // lane 63: the sum
                         const int L = max(1, __builtin_amdgcn_readlane(lanes_all, 63));
-                        const int mine = (cntA + 3) / 4;
+                        const int mine = max(1, __builtin_amdgcn_readlane(lw, wave));
                         my_rounds = max(1, min(24, ((p.k + 2 * NW) * mine + L - 1) / L));
                     }
                     unsigned rest = lmax, tw = 0u;
@@ -590,7 +666,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     {
                         // (float arithmetic: a 64-bit integer division is ~100 instructions on every wave)
                         const float left = (float)(cap - min(sh[SH_CNT], cap));
-                        const float pos = (float)items[min(i0, n_items)].w;
+                        const float pos = (float)(items[min(i0, n_items)].w & ((1 << ITEM_W_BITS) - 1));
                         const float ch = fits ? 2.f * pos * left / (float)max(2 * p.k, totalA) : 0.5f * left;      // !fits: no cutoff yet, everything is accepted
                         chunk_items = max(1, (int)fminf(ch * (1.f / ITEM), 1e6f));
                         force_sel = fits && totalA > 8 * p.k;
@@ -610,24 +686,40 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     WavePool wps{0, -1};
                     // item i0 + wave + NW*i of this stage in lane i (beyond the stage: the sentinel)
                     int4 myd;
+                    int4 mydB = make_int4(0, 0, 0, 64);       // second piece of the item (packed trips of the prepass); none: sB = 64
                     {
                         const int mine = i0 + wave + NW * lane;
                         myd = items[(mine < i1) ? mine : n_items];
+                        if (two_piece) {
+                            const int bix = (int)((unsigned)myd.w >> ITEM_W_BITS);
+                            if (bix) mydB = items[bix];
+                        }
                     }
-                    auto ld = [&](int trip, unsigned (&c)[4], float (&v)[4], int &cnt, float &segv) __attribute__((always_inline)) {
+                    // cnt: elements of piece A (0: the sentinel; ITEM: the trip is full, no masks); dq: real elements of this lane's quad
+                    auto ld = [&](int trip, unsigned (&c)[4], float (&v)[4], int &cnt, int &dq, float &segv) __attribute__((always_inline)) {
                         const int tl = min(trip, 63);
-                        const int off = __builtin_amdgcn_readlane(myd.x, tl);
                         cnt = __builtin_amdgcn_readlane(myd.y, tl);
-                        segv = __uint_as_float((unsigned)__builtin_amdgcn_readlane(myd.z, tl));
-                        // lanes beyond a partial item's end get an out-of-range offset: they fetch nothing
-                        const int vo = (4 * lane < cnt) ? lane * 16 : (int)(OOB_SOFFSET - (unsigned)off);
-                        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, vo, off, 0);
-                        const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs_val, vo, off, 0);
+                        int vo;
+                        if (two_piece) {
+                            trip_lane(__builtin_amdgcn_readlane(myd.x, tl), cnt, (unsigned)__builtin_amdgcn_readlane(myd.z, tl),
+                                      __builtin_amdgcn_readlane(mydB.x, tl), __builtin_amdgcn_readlane(mydB.y, tl), (unsigned)__builtin_amdgcn_readlane(mydB.z, tl),
+                                      __builtin_amdgcn_readlane(mydB.w, tl), vo, dq, segv);
+                        }
+                        int so = 0;
+                        if (!two_piece) {
+                            // one piece: its offset stays scalar; lanes beyond a partial item's end get an out-of-range offset (they fetch nothing)
+                            so = __builtin_amdgcn_readlane(myd.x, tl);
+                            dq = cnt - 4 * lane;
+                            segv = __uint_as_float((unsigned)__builtin_amdgcn_readlane(myd.z, tl));
+                            vo = (dq > 0) ? lane * 16 : (int)(OOB_SOFFSET - (unsigned)so);
+                        }
+                        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, vo, so, 0);
+                        const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs_val, vo, so, 0);
                         c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w;
                         v[0] = __uint_as_float(b.x); v[1] = __uint_as_float(b.y); v[2] = __uint_as_float(b.z); v[3] = __uint_as_float(b.w);
                     };
                     const float cut = MONO ? cutx : rc.xy_cut;
-                    auto body = [&](const unsigned (&c)[4], const float (&v)[4], int cnt, float segv) __attribute__((always_inline)) {
+                    auto body = [&](const unsigned (&c)[4], const float (&v)[4], int cnt, int dq, float segv) __attribute__((always_inline)) {
                         if (cnt == 0) return;                  // sentinel (wave-uniform)
 #if SP_ABLATION
                         if (p.dbg & 16) { asm volatile("" ::"v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); return; }   // ablation: loads only
@@ -641,7 +733,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                         if (cnt != ITEM) {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
-                                const u64 ok = __ballot(4 * lane + j < cnt);
+                                const u64 ok = __ballot(j < dq);
                                 M[j] &= ok;
                                 S[j] &= ok;
                             }
@@ -708,24 +800,24 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     };
                     unsigned cA[4], cB[4];
                     float vA[4], vB[4];
-                    int nA = 0, nB = 0;
+                    int nA = 0, nB = 0, qA = 0, qB = 0;
                     float sA = 0.f, sB = 0.f;
                     const int n_trips = (i1 - i0 - wave + NW - 1) / NW;
                     int trip = 0;
-                    ld(0, cA, vA, nA, sA);
+                    ld(0, cA, vA, nA, qA, sA);
                     while (trip < n_trips) {      // two items (4 KiB) in flight per wave; bodies skip the sentinel
-                        ld(trip + 1, cB, vB, nB, sB);
+                        ld(trip + 1, cB, vB, nB, qB, sB);
                         __builtin_amdgcn_sched_barrier(0);     // the prefetch is issued before the current item is waited for
 #if SP_TRIPTIMERS
                         { const u64 w0 = clock64(); asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); const u64 w1 = clock64(); if (timing) ph[PH_CSDRAIN] += w1 - w0; }
 #endif
-                        body(cA, vA, nA, sA);
-                        ld(trip + 2, cA, vA, nA, sA);
+                        body(cA, vA, nA, qA, sA);
+                        ld(trip + 2, cA, vA, nA, qA, sA);
                         __builtin_amdgcn_sched_barrier(0);
 #if SP_TRIPTIMERS
                         { const u64 w0 = clock64(); asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); const u64 w1 = clock64(); if (timing) ph[PH_CSDRAIN] += w1 - w0; }
 #endif
-                        body(cB, vB, nB, sB);
+                        body(cB, vB, nB, qB, sB);
                         trip += 2;
                     }
                 }
@@ -920,7 +1012,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 // next chunk: with the k-th best of `pos` products as cutoff, an exchangeable stream lets k*m/pos of the
                 // next m products through; keep that below half of the room left in U (far fewer pass when the
                 // segments come in descending weight)
-                const float pos = (i0 < n_items) ? (float)items[i0].w : (float)macs32;
+                const float pos = (i0 < n_items) ? (float)(items[i0].w & ((1 << ITEM_W_BITS) - 1)) : (float)macs32;
                 const float left = (float)max(64, cap - min(sh[SH_CNT], cap));
                 // (the cutoff is the value that `cnt` of the `pos` products offered so far reach: cnt ~ k after a selection, more
                 // after the selection-free first stage)
@@ -1024,7 +1116,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         wN = make_int4(__builtin_amdgcn_readfirstlane(wNN.x), __builtin_amdgcn_readfirstlane(wNN.y),
                        __builtin_amdgcn_readfirstlane(wNN.z), __builtin_amdgcn_readfirstlane(wNN.w));
         my_r0 = nx_r0; my_len = nx_len; my_v = nx_v;
-        recC = recN; preC = preN;
+        recC = recN; recC2 = recN2; preC = preN;
         wg_sync<U_LDS>();
         PHASE_END(PH_OUTPUT);
     }
