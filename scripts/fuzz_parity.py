@@ -115,7 +115,10 @@ def one_case(i):
     if call.m2_is_m1t:
         import dataclasses
         t = sp.csr_array((call.m1_data, call.m1_indices, call.m1_indptr), shape=(call.n_rows_m1, call.n_rows_m2)).T.tocsr(); t.sort_indices()
-        ref_call = dataclasses.replace(call, m2_data=np.ascontiguousarray(t.data, np.float32), m2_indices=np.ascontiguousarray(t.indices, np.int32), m2_indptr=np.ascontiguousarray(t.indptr, np.int32), m2_is_m1t=False)
+        d2, i2, p2 = np.ascontiguousarray(t.data, np.float32), np.ascontiguousarray(t.indices, np.int32), np.ascontiguousarray(t.indptr, np.int32)
+        if call.col_keep is not None:      # ARRAY selectors: the library drops those columns while it builds m2 (sp_knn_args.col_keep)
+            d2, i2, p2 = _host.filter_matrix_columns(d2, i2, p2, call.n_output_cols, np.flatnonzero(call.col_keep).astype(np.int32))
+        ref_call = dataclasses.replace(call, m2_data=d2, m2_indices=i2, m2_indptr=p2, m2_is_m1t=False, col_keep=None)
     colnnz = np.diff(ref_call.m2_indptr)
     macs = float(colnnz[ref_call.m1_indices].sum()) * (len(ref_call.targets) / max(1, ref_call.n_rows_m1))
     if macs > a.max_macs:

@@ -939,22 +939,22 @@ def test_array_selectors_on_an_explicit_matrix2_are_applied_on_the_device():
 @pytest.mark.parametrize("kw", [dict(), dict(l2=1), dict(l1=0.5, l2=0.5, stabilized_shrink=5)], ids=["dot", "cosine", "splus"])
 def test_sparse_kernel_packed_trips_with_skewed_segment_lengths(kw):
     """The 256-thread shape of the sparse kernel runs on trips PACKED by the prepass (sp_row_items_kernel): a trip's 64 lanes
-    hold the end of one m2 row and the start of the next.  m2 rows of 1 ... ~3000 elements here (popularity-skewed columns of
+    hold the end of one m2 row and the start of the next.  m2 rows of 1 ... ~2000 elements here (popularity-skewed columns of
     m1): pieces of a few lanes, rows that fit a trip's remainder, rows that start in one trip and run on through the next ones,
     and windows whose second piece is already taken."""
     rng = np.random.default_rng(31)
-    n_rows, n_cols, per_row = 60000, 4000, 10
-    pop = 1.0 / np.arange(1, n_cols + 1) ** 0.9
+    n_rows, n_cols, per_row = 60000, 30000, 10
+    pop = 1.0 / np.arange(1, n_cols + 1) ** 0.6
     cols = rng.choice(n_cols, size=(n_rows, per_row), p=pop / pop.sum())
     rows = np.repeat(np.arange(n_rows), per_row)
     m = sp.csr_array((rng.random(n_rows * per_row).astype(np.float32) + 0.05, (rows, cols.ravel())), shape=(n_rows, n_cols))
     m.sum_duplicates()
     lens = np.diff(m.T.tocsr().indptr)
-    assert lens.max() > 2000 and (lens < 8).sum() > 100
+    assert lens.max() > 1000 and (lens < 8).sum() > 100
     call = _host.prepare(m, k=25, target_rows=np.arange(0, n_rows, 29), **kw)
     _check(call, f"packed trips {kw}")
     pc = _info(call)
-    assert pc[9] + pc[10] == call.n_targets and pc[9] >= 0.9 * call.n_targets, (pc[9], pc[10])
+    assert pc[9] >= 0.7 * call.n_targets, (pc[9], pc[10])      # (the others: queued for the generic kernel by the row classifier, or handed over)
     # the same rows cut in the kernel (no prepass: one piece per trip) and by the 1024-thread shape (prepass without packing)
     _check(call, "in-kernel items", dbg=2048)
     _check(call, "1024 threads", threads_per_wg=1024, table_slots=16384)
