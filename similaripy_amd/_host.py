@@ -649,7 +649,13 @@ def run_hip(call: KernelCall, device: Optional[int] = None, table_slots: int = 0
     a.table_slots, a.threads_per_wg, a.num_wgs, a.load_pct = table_slots, threads_per_wg, num_wgs, load_pct
     a.reserved[0] = int(dbg)          # ablation word of the library (tests / profiling only; 1024 = force the 64-bit-offset kernel variant)
     if n > 0:
-        _abi.call_knn(a)
+        if os.environ.get("SIMILARIPY_AMD_TRACE", "0") not in ("", "0"):
+            import time
+            t0 = time.perf_counter()
+            _abi.call_knn(a)
+            print(f"[similaripy_amd] sp_knn_f32_i32 as seen from Python      {1e3 * (time.perf_counter() - t0):8.2f} ms", file=sys.stderr, flush=True)
+        else:
+            _abi.call_knn(a)
     if csr_out:
         nnz = int(a.csr_nnz) if n > 0 else 0
         return csr_indptr, cols[:nnz], values[:nnz]
@@ -744,8 +750,9 @@ def _s_plus_impl(matrix1, matrix2, weight_depop_matrix1, weight_depop_matrix2, p
         csr_out = format_output == 'csr' and call.n_targets > 0 and call.n_targets * call.k <= np.iinfo(np.int32).max
         _say(verbose, "Computing")
         try:
-            # (the row id of every slot entry is known on the host: a third of the COO download is never made)
-            out = run_hip(call, want_rows=False, check_zeros=not opts["check_zeros"], csr_out=csr_out)
+            # (the row id of every slot entry is known on the host: the library's helper threads write `rows` while the device works,
+            # a third of the COO download is never made)
+            out = run_hip(call, want_rows=(format_output != 'csr'), check_zeros=not opts["check_zeros"], csr_out=csr_out)
             break
         except _abi.ExplicitZerosError:
             if opts["check_zeros"]:

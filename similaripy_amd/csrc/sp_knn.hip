@@ -823,6 +823,25 @@ struct HostPrefault {
     std::vector<std::pair<unsigned char *, size_t>> ranges;
     std::vector<std::thread> threads;
     void add(void *p, size_t bytes) { if (p && bytes) ranges.push_back({(unsigned char *)p, bytes}); }
+    // rows[i * k + j] = targets[i]: the `rows` output of a host-mode call is known before the kernel runs (every entry of slot i
+    // is in row targets[i], utils.pyx:43-64); it is written here, while the device works, instead of travelling over PCIe
+    void fill_rows(int32_t *rows, const int32_t *targets, size_t nt, size_t k) {
+        if (!rows || !nt || !k) return;
+        const unsigned hw = std::thread::hardware_concurrency();
+        const size_t n_thr = std::max<size_t>(1, std::min<size_t>({(size_t)8, hw ? (size_t)hw / 2 : (size_t)1, (nt * k + ((size_t)1 << 22) - 1) >> 22}));
+        const size_t per = (nt + n_thr - 1) / n_thr;
+        for (size_t lo = 0; lo < nt; lo += per) {
+            const size_t hi = std::min(nt, lo + per);
+            auto job = [rows, targets, lo, hi, k]() {
+                for (size_t i = lo; i < hi; ++i) {
+                    const int32_t t = targets[i];
+                    int32_t *r = rows + i * k;
+                    for (size_t j = 0; j < k; ++j) r[j] = t;
+                }
+            };
+            try { threads.emplace_back(job); } catch (...) { job(); }
+        }
+    }
     void start() {
         const unsigned hw = std::thread::hardware_concurrency();
         const size_t per_range = std::max<size_t>(1, std::min<size_t>(4, hw ? hw / 2 : 1) );
@@ -981,13 +1000,14 @@ int run_host(sp_knn_args *a) {
         d.flags |= SP_FLAG_NO_ROWS_OUT;
     }
     d.flags &= ~(SP_FLAG_CSR_OUT | SP_FLAG_CHECK_ZEROS);
-    const bool want_rows = !(d.flags & SP_FLAG_NO_ROWS_OUT);
+    // the row ids never travel: host threads write them while the device works, the padding of short slots is zeroed afterwards
+    const bool want_rows = !(d.flags & SP_FLAG_NO_ROWS_OUT) && a->rows != nullptr;
+    d.flags |= SP_FLAG_NO_ROWS_OUT;
     d.rows = nullptr;
-    if (want_rows) TRY(pool.alloc(nt * k, &d.rows));
     TRY(pool.alloc(nt * k, &d.cols));
     TRY(pool.alloc(nt * k, &d.values));
     d.out_counts = nullptr;
-    if (a->out_counts || csr_out) TRY(pool.alloc(nt, &d.out_counts));
+    if (a->out_counts || csr_out || want_rows) TRY(pool.alloc(nt, &d.out_counts));
     {
         // the kernel's workspace comes from the cache as well
         const int64_t need = sp_knn_workspace_bytes(&d);
@@ -1002,8 +1022,8 @@ int run_host(sp_knn_args *a) {
     // While the device works the host is idle: helper threads touch the pages of the caller's (typically fresh, never touched)
     // output arrays so that the copies back do not pay for the page faults.  Output-only memory: writing zeros is harmless.
     HostPrefault prefault;
+    if (want_rows) prefault.fill_rows(a->rows, a->targets, nt, k);
     if (nt * k >= (size_t)1 << 22) {
-        if (want_rows && a->rows) prefault.add(a->rows, nt * k * sizeof(int32_t));
         prefault.add(a->cols, nt * k * sizeof(int32_t));
         prefault.add(a->values, nt * k * sizeof(float));
         prefault.start();
@@ -1065,10 +1085,21 @@ int run_host(sp_knn_args *a) {
         if (a->out_counts) HIP_TRY(hipMemcpy(a->out_counts, d.out_counts, nt * sizeof(int32_t), hipMemcpyDeviceToHost));
     } else {
         HIP_TRY(hipDeviceSynchronize());
-        if (want_rows) HIP_TRY(hipMemcpy(a->rows, d.rows, nt * k * sizeof(int32_t), hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(a->cols, d.cols, nt * k * sizeof(int32_t), hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(a->values, d.values, nt * k * sizeof(float), hipMemcpyDeviceToHost));
         if (a->out_counts) HIP_TRY(hipMemcpy(a->out_counts, d.out_counts, nt * sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (want_rows) {
+            // padding is (0, 0, 0.0) (s_plus.h:246-262 leaves the calloc'ed tail untouched): zero the row ids behind every short slot
+            std::vector<int32_t> cnt_tmp;
+            const int32_t *cnt = a->out_counts;
+            if (!cnt) {
+                cnt_tmp.resize(nt);
+                HIP_TRY(hipMemcpy(cnt_tmp.data(), d.out_counts, nt * sizeof(int32_t), hipMemcpyDeviceToHost));
+                cnt = cnt_tmp.data();
+            }
+            for (size_t i = 0; i < nt; ++i)
+                if ((size_t)cnt[i] < k) memset(a->rows + i * k + cnt[i], 0, (k - (size_t)cnt[i]) * sizeof(int32_t));
+        }
     }
     trace.mark("assembly, result to the host");
     a->kernel_ms = d.kernel_ms;
