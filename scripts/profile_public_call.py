@@ -10,7 +10,9 @@ which = sys.argv[1] if len(sys.argv) > 1 else "c2"
 if which == "c2":
     m = workloads.fixed_degree_csr(1_000_000, 100_000, 64, 12345)
     calls = [("cosine csr", lambda: sim.cosine(m, k=100, verbose=False, format_output="csr")),
-             ("cosine coo", lambda: sim.cosine(m, k=100, verbose=False, format_output="coo"))]
+             ("cosine coo", lambda: sim.cosine(m, k=100, verbose=False, format_output="coo")),
+             # ARRAY selector: a tenth of the columns dropped while m2 = m1^T is built on the device (sp_knn_args.col_keep)
+             ("cosine csr filter_cols=list", lambda: sim.cosine(m, k=100, verbose=False, format_output="csr", filter_cols=list(range(0, 1_000_000, 10))))]
 else:
     m = workloads.movielens_like_urm().T.tocsr()
     calls = [("cosine", lambda: sim.cosine(m, k=200, verbose=False, format_output="csr")),
