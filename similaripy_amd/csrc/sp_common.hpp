@@ -722,6 +722,15 @@ __device__ __forceinline__ void s2_core(const unsigned (&c)[4], const float (&v)
         : "memory");
 }
 
+// per lane: `if_set` where the lane's bit of the wave-uniform mask `m` is set, else `if_clear` — ONE v_cndmask on the mask
+// in scalar registers (the compiler's form of `(m >> lane) & 1 ? a : b` is a 64-bit shift, an and and a compare in front of it)
+__device__ __forceinline__ unsigned mask_select(u64 m_in, unsigned if_set, unsigned if_clear) {
+    const u64 m = ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(m_in >> 32)) << 32) | (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)m_in);
+    unsigned r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
+    return r;
+}
+
 // Append the 8-byte entries {lo, hi} of the lanes in `m` to an LDS list at byte offset `base_off` (wave-uniform),
 // starting at entry `pos` (wave-uniform): lane rank by v_mbcnt, exec narrowed to `m` around the two stores.
 __device__ __forceinline__ void lds_push64(u64 m_in, unsigned lo, unsigned hi, int pos, unsigned base_off) {
@@ -742,7 +751,7 @@ __device__ __forceinline__ void lds_push64(u64 m_in, unsigned lo, unsigned hi, i
         "s_mov_b64 exec, %[sv]\n\t"
         : [t] "=&v"(t), [sv] "=&s"(sv)
         : [mlo] "s"((unsigned)m), [mhi] "s"((unsigned)(m >> 32)), [m] "s"(m), [first] "s"(first), [lo] "v"(lo), [hi] "v"(hi)
-        : "memory");
+        : "memory", "scc");      // (s_and_saveexec writes SCC: without the clobber the compiler kept a compare's result across a push)
 }
 
 // inclusive wave64 scan on the DPP crossbar (row_shr 1/2/4/8, row_bcast 15/31): no LDS round trips

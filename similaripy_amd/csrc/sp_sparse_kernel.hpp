@@ -738,26 +738,42 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                                 S[j] &= ok;
                             }
                         }
+#if SP_ABLATION
 #pragma unroll
                         for (int j = 0; j < 4; ++j) S[j] &= ~M[j];
-#if SP_ABLATION
                         if (p.dbg & 32) { M[0] = M[1] = M[2] = M[3] = 0ull; }      // ablation: members are dropped
                         if (p.dbg & 64) { S[0] = S[1] = S[2] = S[3] = 0ull; }      // ablation: survivors are dropped
                         asm volatile("" ::"v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]));
 #endif
-                        if ((M[0] | M[1]) | (M[2] | M[3])) {
-                            const int n0 = __popcll(M[0]), n1 = __popcll(M[1]), n2 = __popcll(M[2]), n3 = __popcll(M[3]);
+                        const u64 Many = (M[0] | M[1]) | (M[2] | M[3]);
+                        if (Many) {
+                            // A trip nearly always holds members (~14 of its 256 products at C2), a LANE rarely more than one: the
+                            // first member of every lane goes out in ONE push (picked with three v_cndmask on the masks), second and
+                            // later members of a lane (R1..R3) in the rare pushes behind it — the instructions of a trip, not its bytes,
+                            // are what the sweep's time follows
+                            const u64 R1 = M[1] & M[0], R2 = M[2] & (M[0] | M[1]), R3 = M[3] & ((M[0] | M[1]) | M[2]);
+                            const int n0 = __popcll(Many), n1 = __popcll(R1), n2 = __popcll(R2), n3 = __popcll(R3);
                             if (pool_reserve(wpm, n0 + n1 + n2 + n3, &sh[SH_MCTR], mpcap, &sh[SH_OVF])) {
                                 int pos = __builtin_amdgcn_readfirstlane(wpm.pos);
-                                if (n0) lds_push64(M[0], __float_as_uint(x[0]), c[0] + 1u, pos, mpool_off);
+                                const unsigned xm = mask_select(M[0], __float_as_uint(x[0]), mask_select(M[1], __float_as_uint(x[1]), mask_select(M[2], __float_as_uint(x[2]), __float_as_uint(x[3]))));
+                                const unsigned cm = mask_select(M[0], c[0], mask_select(M[1], c[1], mask_select(M[2], c[2], c[3])));
+                                lds_push64(Many, xm, cm + 1u, pos, mpool_off);
                                 pos += n0;
-                                if (n1) lds_push64(M[1], __float_as_uint(x[1]), c[1] + 1u, pos, mpool_off);
-                                pos += n1;
-                                if (n2) lds_push64(M[2], __float_as_uint(x[2]), c[2] + 1u, pos, mpool_off);
-                                pos += n2;
-                                if (n3) lds_push64(M[3], __float_as_uint(x[3]), c[3] + 1u, pos, mpool_off);
-                                wpm.pos = pos + n3;
+                                if ((R1 | R2) | R3) {
+                                    if (n1) lds_push64(R1, __float_as_uint(x[1]), c[1] + 1u, pos, mpool_off);
+                                    pos += n1;
+                                    if (n2) lds_push64(R2, __float_as_uint(x[2]), c[2] + 1u, pos, mpool_off);
+                                    pos += n2;
+                                    if (n3) lds_push64(R3, __float_as_uint(x[3]), c[3] + 1u, pos, mpool_off);
+                                    pos += n3;
+                                }
+                                wpm.pos = pos;
                             }
+                        }
+                        // (a product of a marked column is no survivor; the masks are only cut when there is something to cut)
+                        if ((S[0] | S[1]) | (S[2] | S[3])) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) S[j] &= ~M[j];
                         }
                         if ((S[0] | S[1]) | (S[2] | S[3])) {
                             const int n0 = __popcll(S[0]), n1 = __popcll(S[1]), n2 = __popcll(S[2]), n3 = __popcll(S[3]);
