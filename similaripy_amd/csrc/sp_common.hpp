@@ -29,7 +29,7 @@ constexpr int U_SLACK = 1024;    // candidate-buffer entries beyond k (room betw
 #define DRAIN_UNROLL (NT >= 1024 ? 2 : NT >= 768 ? 4 : 8)
 
 // scalar slots in LDS
-enum { SH_CNT = 0, SH_OVF, SH_SEL, SH_NEED, SH_EQ, SH_CNT2, SH_RETRY, SH_QA, SH_QB, SH_PCTR, SH_MCTR, SH_NITEMS, SH_STOP, SH_WSUM, SH_NHI = SH_WSUM + 16, SH_N };   // SH_CNT2/SEL/NEED/EQ belong to the selections
+enum { SH_CNT = 0, SH_OVF, SH_SEL, SH_NEED, SH_EQ, SH_CNT2, SH_RETRY, SH_QA, SH_QB, SH_PCTR, SH_MCTR, SH_NITEMS, SH_STOP, SH_WSUM, SH_NHI = SH_WSUM + 16, SH_BINCNT, SH_LIST, SH_N };   // SH_CNT2/SEL/NEED/EQ belong to the selections
 
 // phases timed by lane 0 of every workgroup when KParams::phase_cycles != NULL, then event counters
 enum { PH_SETUP = 0, PH_SEGMENTS, PH_ACCUM, PH_DRAIN, PH_SELECT, PH_OUTPUT, PH_SWEEP1, PH_SWEEP2, PH_CSDRAIN,
@@ -880,6 +880,7 @@ __device__ long long select_fast(u64 *U, int *hist4, int *sh, int k, bool exact,
                 const int kept = (k - r) + cb;
                 sh[SH_SEL] = d;
                 sh[SH_NEED] = r;
+                sh[SH_BINCNT] = cb;
                 sh[SH_STOP] = (!exact && ps == 1 && 2 * (kept - k) <= (n - k)) ? 1 : 0;
             }
         }
@@ -888,6 +889,40 @@ __device__ long long select_fast(u64 *U, int *hist4, int *sh, int k, bool exact,
         need = sh[SH_NEED];
         passes = ps + 1;
         if (sh[SH_STOP]) break;     // uniform
+        if (exact && ps < 3) {
+            // The k-th largest is one of the `cb` entries of the bin just chosen.  Once that is at most a wave's worth (after the
+            // second byte the rule: a few hundred entries over 65 536 prefixes) the remaining bytes need no histogram passes: the
+            // bin's keys are gathered in a list, ONE wave ranks them against each other and publishes the full key of the need-th
+            // largest — two barriers instead of two per remaining byte.
+            const int cb = sh[SH_BINCNT];
+            if (cb <= 64) {     // uniform
+                unsigned *lst = (unsigned *)(hist4 + 3 * 256);      // the last pass's histogram: not needed any more (zeroed again below)
+                const unsigned bmask = 0xFFFFFFFFu << shift;
+#pragma unroll
+                for (int j = 0; j < E; ++j)
+                    if (has[j] && ((key[j] ^ prefix) & bmask) == 0u) lst[atomicAdd(&sh[SH_LIST], 1)] = key[j];
+                wg_sync<LDSBAR>();
+                if (tid < 64) {
+                    const unsigned mine = (lane < cb) ? lst[lane] : 0u;
+                    int gt = 0, eq_before = 0;
+                    for (int j = 0; j < cb; ++j) {
+                        const unsigned kj = (unsigned)__builtin_amdgcn_readlane((int)mine, j);
+                        gt += (kj > mine) ? 1 : 0;
+                        eq_before += (kj == mine && j < lane) ? 1 : 0;
+                    }
+                    if (lane < cb && gt + eq_before == need - 1) {      // exactly one lane
+                        sh[SH_SEL] = (int)mine;
+                        sh[SH_NEED] = need - gt;                         // of the entries equal to it, this many are kept
+                        sh[SH_LIST] = 0;
+                    }
+                }
+                wg_sync<LDSBAR>();
+                prefix = (unsigned)sh[SH_SEL];
+                need = sh[SH_NEED];
+                passes = 4;
+                break;
+            }
+        }
     }
     const bool all_passes = (passes == 4);
 #pragma unroll
