@@ -859,44 +859,50 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     // product); another column's slot sends the entry to the next slot.
                     // (Round 3 tried "32-bit compare-and-swap on the key word, then ALWAYS the hardware float add": one round
                     // trip less per two-product column, but ds_add_f32 runs at 0.33 lanes/clk: 9.1k -> 11.6k cycles per C2 row.)
-                    for (int base = 0; base < mext; base += 2 * NT) {
-                        const int i0m = base + tid, i1m = base + NT + tid;
-                        const u64 e0 = (i0m < mext) ? mpool[i0m] : 0ull;
-                        const u64 e1 = (i1m < mext) ? mpool[i1m] : 0ull;
-                        if (e0 != 0ull) mpool[i0m] = 0ull;
-                        if (e1 != 0ull) mpool[i1m] = 0ull;
-                        const unsigned k0 = (unsigned)(e0 >> 32), k1 = (unsigned)(e1 >> 32);
-                        const float x0 = __uint_as_float((unsigned)e0), x1 = __uint_as_float((unsigned)e1);
-                        // direct slot = rank of the column's bit in the collision bitmap
-                        const unsigned c0m = k0 - 1u, c1m = k1 - 1u;
-                        const unsigned wi0 = (c0m >> 5) & (unsigned)(CBM_BYTES / 4 - 1), wi1 = (c1m >> 5) & (unsigned)(CBM_BYTES / 4 - 1);
-                        const unsigned bw0 = ((const unsigned *)cbm)[wi0], bw1 = ((const unsigned *)cbm)[wi1];
-                        unsigned h0 = (unsigned)pre16[wi0] + (unsigned)__popc(bw0 & ((1u << (c0m & 31u)) - 1u));
-                        unsigned h1 = (unsigned)pre16[wi1] + (unsigned)__popc(bw1 & ((1u << (c1m & 31u)) - 1u));
-                        bool a0 = (e0 != 0ull), a1 = (e1 != 0ull);
-                        u64 cur0 = 0ull, cur1 = 0ull, want0 = e0, want1 = e1;     // expected slot content -> new content
+                    // Three entries per thread and pass (four spill at the 128-register budget): a C2 row's ~2.3 k members are ONE pass (with two per thread the last
+                    // 250 entries were a second pass of their own — three more rounds of round trips for a quarter of the waves
+                    // while the others waited at the barrier below).
+                    constexpr int JA = MONO ? 3 : 2;      // (the general variant is over the register budget already: C3 180.2 against 178.3 ms with three)
+                    for (int base = 0; base < mext; base += JA * NT) {
+                        u64 e[JA], cur[JA], want[JA];
+                        unsigned kk[JA], h[JA];
+                        float xx[JA];
+                        bool act[JA];
+#pragma unroll
+                        for (int j = 0; j < JA; ++j) {
+                            const int i = base + j * NT + tid;
+                            e[j] = (i < mext) ? mpool[i] : 0ull;
+                            if (e[j] != 0ull) mpool[i] = 0ull;
+                        }
+#pragma unroll
+                        for (int j = 0; j < JA; ++j) {
+                            kk[j] = (unsigned)(e[j] >> 32);
+                            xx[j] = __uint_as_float((unsigned)e[j]);
+                            // direct slot = rank of the column's bit in the collision bitmap
+                            const unsigned cm = kk[j] - 1u;
+                            const unsigned wi = (cm >> 5) & (unsigned)(CBM_BYTES / 4 - 1);
+                            const unsigned bw = ((const unsigned *)cbm)[wi];
+                            h[j] = (unsigned)pre16[wi] + (unsigned)__popc(bw & ((1u << (cm & 31u)) - 1u));
+                            act[j] = (e[j] != 0ull);
+                            cur[j] = 0ull;                 // expected slot content -> new content
+                            want[j] = e[j];
+                        }
                         int rounds = 0;
-                        while (__ballot(a0 | a1)) {
-                            u64 r0 = 0ull, r1 = 0ull;
-                            if (a0) r0 = atomicCAS(&cs[h0], cur0, want0);
-                            if (a1) r1 = atomicCAS(&cs[h1], cur1, want1);
-                            if (a0) {
-                                if (r0 == cur0) a0 = false;                                  // claimed (cur = 0) or added (cur = the sum seen)
-                                else if ((unsigned)(r0 >> 32) == k0) {
-                                    if (cur0 == 0ull) {                                      // the column's slot: one compare-and-swap add
-                                        cur0 = r0;
-                                        want0 = (r0 & 0xFFFFFFFF00000000ull) | (u64)__float_as_uint(__uint_as_float((unsigned)r0) + x0);
-                                    } else { atomicAdd((float *)&cs[h0], x0); a0 = false; }  // contended (a column with many products): hardware add
-                                } else { h0 = next_slot(h0, k0); cur0 = 0ull; want0 = e0; }  // another column's slot
-                            }
-                            if (a1) {
-                                if (r1 == cur1) a1 = false;
-                                else if ((unsigned)(r1 >> 32) == k1) {
-                                    if (cur1 == 0ull) {
-                                        cur1 = r1;
-                                        want1 = (r1 & 0xFFFFFFFF00000000ull) | (u64)__float_as_uint(__uint_as_float((unsigned)r1) + x1);
-                                    } else { atomicAdd((float *)&cs[h1], x1); a1 = false; }
-                                } else { h1 = next_slot(h1, k1); cur1 = 0ull; want1 = e1; }
+                        while (__ballot((act[0] | act[1]) | act[JA - 1])) {
+                            u64 r[JA];
+#pragma unroll
+                            for (int j = 0; j < JA; ++j) { r[j] = 0ull; if (act[j]) r[j] = atomicCAS(&cs[h[j]], cur[j], want[j]); }
+#pragma unroll
+                            for (int j = 0; j < JA; ++j) {
+                                if (act[j]) {
+                                    if (r[j] == cur[j]) act[j] = false;                          // claimed (cur = 0) or added (cur = the sum seen)
+                                    else if ((unsigned)(r[j] >> 32) == kk[j]) {
+                                        if (cur[j] == 0ull) {                                    // the column's slot: one compare-and-swap add
+                                            cur[j] = r[j];
+                                            want[j] = (r[j] & 0xFFFFFFFF00000000ull) | (u64)__float_as_uint(__uint_as_float((unsigned)r[j]) + xx[j]);
+                                        } else { atomicAdd((float *)&cs[h[j]], xx[j]); act[j] = false; }  // contended (a column with many products): hardware add
+                                    } else { h[j] = next_slot(h[j], kk[j]); cur[j] = 0ull; want[j] = e[j]; }  // another column's slot
+                                }
                             }
                             if (++rounds > 4 * CS_MAXPROBE) { sh[SH_OVF] = 1; break; }     // set full
                         }
