@@ -25,6 +25,9 @@ HIPCC_FLAGS = [
     "-O3",
     "-std=c++17",
     "-munsafe-fp-atomics",  # LDS float adds must lower to ds_add_f32, never a CAS loop
+    # one lane's returning atomic on the row queue must stay PENDING until its value is used a row later: the atomic optimizer
+    # rewrites it into a wave-aggregated form whose lanes need the result at once (s_waitcnt vmcnt(0) right behind the atomic)
+    "-mllvm", "-amdgpu-atomic-optimizer-strategy=None",
     "-fPIC",
     "-shared",
     "-Wno-unused-function",

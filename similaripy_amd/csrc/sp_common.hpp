@@ -441,6 +441,10 @@ constexpr unsigned OOB_SOFFSET = 0xFFFFF000u;   // buffer-load scalar offset bey
 constexpr int SEL_E = 4;          // candidate-buffer entries per thread the register-resident selection handles
 constexpr int ITEMS_PRE = 511;    // item records per row that the per-call prepass cuts (rows with more, or with more than 64 m1 entries: in the kernel)
 constexpr int ITEMS_STRIDE = ITEMS_PRE + 1;
+// descriptor word .w of a sparse-queue row: m1 entries | trips cut by the prepass << 9 | item records << 19 (0 / 0: cut in the kernel)
+__host__ __device__ constexpr int desc_n1(int w) { return w & 0x1FF; }
+__host__ __device__ constexpr int desc_n_trips(int w) { return (w >> 9) & 0x3FF; }
+__host__ __device__ constexpr int desc_n_rec(int w) { return (int)((unsigned)w >> 19); }
 constexpr int ITEM_W_BITS = 20;   // item record .w: products before the trip in the low bits, index of the trip's B record above
 constexpr int SORT_MAX = 256;     // m1 rows up to this many entries are visited in descending |value| order
 

@@ -200,9 +200,9 @@ __global__ __launch_bounds__(256) void sp_row_desc_kernel(int n_targets, const i
 //                          products before this trip | (index of the B record << 20, 0 = no B)}
 //   [n_trips]             the sentinel {OOB_SOFFSET, 0, 0, all products}
 //   [n_trips + 1 ...]     B records {byte offset, elements, m1 value bits, first lane sB}
-// row[0] = {n_trips, n_records, 0, 0}; rows of more than 64 entries, more than ITEMS_PRE records or 2^20 products get a 0 header:
-// the kernel sets those up itself (one piece per trip).  pack = 0: one piece per trip for every row (the 1024-thread shape).
-__global__ __launch_bounds__(256) void sp_row_items_kernel(const unsigned *__restrict__ qcount, int items_rows, const int4 *__restrict__ desc_s,
+// row[0] is unused; n_trips and n_records go into the row's queue descriptor (desc_n_trips / desc_n_rec of its .w); rows of more
+// than 64 entries, more than ITEMS_PRE records or 2^20 products keep 0 / 0 there: the kernel sets those up itself (one piece per trip).  pack = 0: one piece per trip for every row (the 1024-thread shape).
+__global__ __launch_bounds__(256) void sp_row_items_kernel(const unsigned *__restrict__ qcount, int items_rows, int4 *__restrict__ desc_s,
                                                             const int *__restrict__ m1_indices, const float *__restrict__ m1_data,
                                                             const int *__restrict__ m2_indptr, int4 *__restrict__ items_g, int pack) {
     const int lane = threadIdx.x & 63;
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void sp_row_items_kernel(const unsigned *__res
         const int slot = __builtin_amdgcn_readfirstlane(d.x), s = __builtin_amdgcn_readfirstlane(d.z), n1 = __builtin_amdgcn_readfirstlane(d.w);
         if (slot >= items_rows) continue;
         int4 *row = items_g + (size_t)slot * ITEMS_STRIDE;
-        if (n1 > 64) { if (lane == 0) row[0] = make_int4(0, 0, 0, 0); continue; }
+        if (n1 > 64) continue;
         int r0_in = 0, len_in = 0;
         unsigned vbits_in = 0u;
         if (lane < n1) {
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void sp_row_items_kernel(const unsigned *__res
         const int b_incl = wave_incl_scan_dpp(has_b ? 1 : 0);
         const int n_b = __builtin_amdgcn_readlane(b_incl, 63);
         const int n_rec = n_trips + 1 + n_b;
-        if (n_seg == 0 || n_rec > ITEMS_PRE || total >= (1 << 20)) { if (lane == 0) row[0] = make_int4(0, 0, 0, 0); continue; }
+        if (n_seg == 0 || n_rec > ITEMS_PRE || n_trips > 0x3FF || total >= (1 << 20)) continue;
         if (mine) {
             const int bidx = n_trips + 1 + (b_incl - 1);                // (only read when has_b)
             const int t_first = (V >> 6) + ((V & 63) != 0 ? 1 : 0);     // first window whose lane 0 lies inside this segment
@@ -287,7 +287,8 @@ __global__ __launch_bounds__(256) void sp_row_items_kernel(const unsigned *__res
         }
         if (lane == 0) {
             row[1 + n_trips] = make_int4((int)OOB_SOFFSET, 0, 0, total);
-            row[0] = make_int4(n_trips, n_rec, 0, 0);
+            // the counts travel in the row's descriptor (the row kernel has it in scalar registers two rows ahead)
+            ((int *)&desc_s[2 * (size_t)q])[3] = n1 | (n_trips << 9) | (n_rec << 19);
         }
     }
 }

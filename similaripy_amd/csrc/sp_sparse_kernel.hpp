@@ -125,30 +125,30 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         load_desc(sh[SH_QB], dN, wN);
         __syncthreads();
     }
-    // precomputed work items of a row (sp_row_items_kernel): thread i holds record i of the row's block — record 0 the header,
-    // records 1.. the items — loaded a row ahead like the rest of the row pipeline
+    // precomputed work items of a row (sp_row_items_kernel): thread i holds record i of the row's block (records 1 ..: the items),
+    // loaded a row ahead like the rest of the row pipeline
     constexpr bool REC2 = NT < ITEMS_STRIDE;      // a small workgroup holds two records per thread
-    constexpr bool PACK_OK = NT == 256;
-    auto load_items = [&](int slot, int4 &rec, int4 &rec2, int2 &n_pre) {
+    // Row-pipeline loads must stay PENDING until their values are needed a row (or half a row) later.  The compiler ended that in
+    // four ways, each a full memory round trip on the row's critical path (found in the ISA, round 3): a load from a uniform
+    // address is moved to scalar registers at once (s_waitcnt vmcnt(0) + v_readfirstlane right behind it) — the record counts of
+    // a row therefore travel in its DESCRIPTOR (DESC_* below, written by sp_row_items_kernel) instead of a header of their own;
+    // an index is sign-extended for its later use as soon as it arrives; a difference of two loaded values is formed where the
+    // loads are issued; the atomic optimizer turns one lane's returning atomic into a form that needs the result at once
+    // (-amdgpu-atomic-optimizer-strategy=None in _build.py).  A register SPILL does the same: its reload counts in vmcnt.
+    auto load_items = [&](int slot, int n_rec, int4 &rec, int4 &rec2) {
         rec = make_int4(0, 0, 0, 0);
         rec2 = make_int4(0, 0, 0, 0);
-        n_pre = make_int2(0, 0);
-        if (p.items_g != nullptr && slot >= 0 && slot < p.items_rows) {
+        if (n_rec > 0) {
+            // (the thread's index is made opaque here: left alone, `items_g + tid` is hoisted out of the row loop as a 64-bit
+            // per-thread pointer, which at this kernel's register budget is spilled and reloaded at every row top)
+            int t_o = tid;
+            asm volatile("" : "+v"(t_o));
             const int4 *row = p.items_g + (size_t)slot * ITEMS_STRIDE;
-            const int4 h = row[0];
-            n_pre = make_int2(h.x, h.y);
-            // the first 256 records without waiting for the header (the usual row has fewer); the others by load_items_hi, later in
-            // the row: a load that depends on the header here would put two memory round trips into the top of the row
-            if (tid < 256) rec = row[tid];
+            if (t_o >= 1 && t_o <= n_rec) rec = row[t_o];
+            if (REC2 && t_o + NT <= n_rec) rec2 = row[t_o + NT];
         }
     };
-    auto load_items_hi = [&](int slot, int4 &rec, int4 &rec2, int n_rec) {
-        if (n_rec >= 256) {
-            const int4 *row = p.items_g + (size_t)slot * ITEMS_STRIDE;
-            if (tid >= 256 && tid <= n_rec) rec = row[tid];
-            if (REC2 && tid + NT <= n_rec) rec2 = row[tid + NT];
-        }
-    };
+    constexpr bool PACK_OK = NT == 256;
     // One trip of a wave: piece A = record `a` in lanes [0, sB), piece B (packed trips of the prepass only) in lanes [sB, 64).
     // Per lane: byte offset of its quad in m2, the number of its real elements (<= 0: none), its m1 value.
     auto trip_lane = [&](int offA, int cntA, unsigned svA, int offB, int cntB, unsigned svB, int sB, int &vo, int &d, float &sv) __attribute__((always_inline)) {
@@ -159,13 +159,11 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         if (d <= 0) vo = (int)OOB_SOFFSET;          // lanes beyond the pieces fetch nothing
     };
     int4 recC, recN, recC2, recN2;
-    int2 preC = make_int2(0, 0), preN = make_int2(0, 0);
-    load_items(dC.x, recC, recC2, preC);
-    load_items_hi(dC.x, recC, recC2, preC.x > 0 ? preC.y : 0);
+    load_items(dC.x, desc_n_rec(dC.w), recC, recC2);
     // m1 entry / m2 row bounds of segment `tid` of the current row (rows of this kernel have <= SORT_MAX <= NT entries)
     int my_r0 = 0, my_len = 0;
     float my_v = 0.f;
-    if (dC.x >= 0 && tid < dC.w) {
+    if (dC.x >= 0 && tid < desc_n1(dC.w)) {
         const int u = p.m1_indices[dC.z + tid];
         my_v = p.m1_data[dC.z + tid];
         my_r0 = p.m2_indptr[u];
@@ -181,7 +179,8 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         const int slot_i = __builtin_amdgcn_readfirstlane(dC.x);
         if (slot_i < 0) break;
         const int t = __builtin_amdgcn_readfirstlane(dC.y);
-        const int n1 = __builtin_amdgcn_readfirstlane(dC.w);
+        const int dw = __builtin_amdgcn_readfirstlane(dC.w);
+        const int n1 = desc_n1(dw);
         const unsigned macs32 = (unsigned)__builtin_amdgcn_readfirstlane(wC.x);
 
         // prefetch: queue slot three rows ahead, m1 entries of the next row
@@ -191,14 +190,14 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         }
         int nx_u = 0;
         float nx_v = 0.f;
-        if (dN.x >= 0 && tid < dN.w) {
+        if (dN.x >= 0 && tid < desc_n1(dN.w)) {
             nx_u = p.m1_indices[dN.z + tid];
             nx_v = p.m1_data[dN.z + tid];
         }
-        int nx_r0 = 0, nx_len = 0;
-        load_items(dN.x, recN, recN2, preN);
-        const int n_pre = __builtin_amdgcn_readfirstlane(preC.x);    // > 0: the row's trips were cut (and packed) by the prepass
-        const int n_rec = __builtin_amdgcn_readfirstlane(preC.y);    //      ... into this many records
+        int nx_r0 = 0, nx_r1 = 0;
+        load_items(dN.x, (dN.x >= 0) ? desc_n_rec(dN.w) : 0, recN, recN2);
+        const int n_pre = desc_n_trips(dw);       // > 0: the row's trips were cut (and packed) by the prepass
+        const int n_rec = desc_n_rec(dw);         //      ... into this many records
         // some trips carry a second piece (B records behind the sentinel).  Only the 256-thread shape is launched on packed rows
         // (sp_row_items_kernel's `pack`): the per-lane bookkeeping costs the 1024-thread shape 2.4 % on C2 rows it never packs
         const bool two_piece = PACK_OK && n_pre > 0 && n_rec > n_pre + 1;
@@ -459,11 +458,12 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             wg_sync<U_LDS>();
             PHASE_END(PH_SWEEP1);
             // next row's m2 row bounds (its m1 entries were requested at the top of this row)
-            if (dN.x >= 0 && tid < dN.w) {
-                nx_r0 = p.m2_indptr[nx_u];
-                nx_len = p.m2_indptr[nx_u + 1] - nx_r0;
+            if (dN.x >= 0 && tid < desc_n1(dN.w)) {
+                int u = nx_u;
+                asm volatile("" : "+v"(u));      // (the index is needed HERE: no address arithmetic where it was loaded)
+                nx_r0 = p.m2_indptr[u];
+                nx_r1 = p.m2_indptr[u + 1];
             }
-            load_items_hi(dN.x, recN, recN2, preN.x > 0 ? preN.y : 0);
             // the bitmap has done its job: back to zero (16-byte stores); its storage now serves sweep 2
             for (int i = tid; i < (nb_bytes >> 4); i += NT) ((int4 *)rA)[i] = make_int4(0, 0, 0, 0);
             // rank structure of the collision bitmap: pre16[w] = marked columns in the words below w.  The rank of a
@@ -520,11 +520,12 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             }
             PHASE_END(PH_SEGMENTS);  // (bitmap clear)
         } else {
-            if (dN.x >= 0 && tid < dN.w) {
-                nx_r0 = p.m2_indptr[nx_u];
-                nx_len = p.m2_indptr[nx_u + 1] - nx_r0;
+            if (dN.x >= 0 && tid < desc_n1(dN.w)) {
+                int u = nx_u;
+                asm volatile("" : "+v"(u));      // (the index is needed HERE: no address arithmetic where it was loaded)
+                nx_r0 = p.m2_indptr[u];
+                nx_r1 = p.m2_indptr[u + 1];
             }
-            load_items_hi(dN.x, recN, recN2, preN.x > 0 ? preN.y : 0);
         }
 
         if (!failed) {
@@ -864,44 +865,51 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     // while the others waited at the barrier below).
                     constexpr int JA = MONO ? 3 : 2;      // (the general variant is over the register budget already: C3 180.2 against 178.3 ms with three)
                     for (int base = 0; base < mext; base += JA * NT) {
-                        u64 e[JA], cur[JA], want[JA];
+                        // per entry: key, product, slot and the slot content last seen (0: none yet) — what to write is formed
+                        // from those at the compare-and-swap (registers: a spill's reload would count in vmcnt and end the
+                        // row pipeline's pending loads)
+                        u64 cur[JA];
                         unsigned kk[JA], h[JA];
                         float xx[JA];
                         bool act[JA];
 #pragma unroll
                         for (int j = 0; j < JA; ++j) {
                             const int i = base + j * NT + tid;
-                            e[j] = (i < mext) ? mpool[i] : 0ull;
-                            if (e[j] != 0ull) mpool[i] = 0ull;
+                            const u64 e = (i < mext) ? mpool[i] : 0ull;
+                            if (e != 0ull) mpool[i] = 0ull;
+                            kk[j] = (unsigned)(e >> 32);
+                            xx[j] = __uint_as_float((unsigned)e);
+                            act[j] = (e != 0ull);
                         }
 #pragma unroll
                         for (int j = 0; j < JA; ++j) {
-                            kk[j] = (unsigned)(e[j] >> 32);
-                            xx[j] = __uint_as_float((unsigned)e[j]);
                             // direct slot = rank of the column's bit in the collision bitmap
                             const unsigned cm = kk[j] - 1u;
                             const unsigned wi = (cm >> 5) & (unsigned)(CBM_BYTES / 4 - 1);
                             const unsigned bw = ((const unsigned *)cbm)[wi];
                             h[j] = (unsigned)pre16[wi] + (unsigned)__popc(bw & ((1u << (cm & 31u)) - 1u));
-                            act[j] = (e[j] != 0ull);
-                            cur[j] = 0ull;                 // expected slot content -> new content
-                            want[j] = e[j];
+                            cur[j] = 0ull;
                         }
                         int rounds = 0;
                         while (__ballot((act[0] | act[1]) | act[JA - 1])) {
                             u64 r[JA];
 #pragma unroll
-                            for (int j = 0; j < JA; ++j) { r[j] = 0ull; if (act[j]) r[j] = atomicCAS(&cs[h[j]], cur[j], want[j]); }
+                            for (int j = 0; j < JA; ++j) {
+                                r[j] = 0ull;
+                                if (act[j]) {
+                                    // empty slot expected: claim it with the product; the column's slot with sum s expected: s + x
+                                    const float add = (cur[j] == 0ull) ? xx[j] : __uint_as_float((unsigned)cur[j]) + xx[j];
+                                    r[j] = atomicCAS(&cs[h[j]], cur[j], ((u64)kk[j] << 32) | (u64)__float_as_uint(add));
+                                }
+                            }
 #pragma unroll
                             for (int j = 0; j < JA; ++j) {
                                 if (act[j]) {
                                     if (r[j] == cur[j]) act[j] = false;                          // claimed (cur = 0) or added (cur = the sum seen)
                                     else if ((unsigned)(r[j] >> 32) == kk[j]) {
-                                        if (cur[j] == 0ull) {                                    // the column's slot: one compare-and-swap add
-                                            cur[j] = r[j];
-                                            want[j] = (r[j] & 0xFFFFFFFF00000000ull) | (u64)__float_as_uint(__uint_as_float((unsigned)r[j]) + xx[j]);
-                                        } else { atomicAdd((float *)&cs[h[j]], xx[j]); act[j] = false; }  // contended (a column with many products): hardware add
-                                    } else { h[j] = next_slot(h[j], kk[j]); cur[j] = 0ull; want[j] = e[j]; }  // another column's slot
+                                        if (cur[j] == 0ull) cur[j] = r[j];                       // the column's slot: one compare-and-swap add
+                                        else { atomicAdd((float *)&cs[h[j]], xx[j]); act[j] = false; }  // contended (a column with many products): hardware add
+                                    } else { h[j] = next_slot(h[j], kk[j]); cur[j] = 0ull; }     // another column's slot
                                 }
                             }
                             if (++rounds > 4 * CS_MAXPROBE) { sh[SH_OVF] = 1; break; }     // set full
@@ -1122,7 +1130,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             wg_sync<U_LDS>();
             if (tid == 0) {
                 const unsigned g = atomicAdd(&p.qcount[1], 1u);
-                p.desc_g[2 * (size_t)g] = dC;
+                p.desc_g[2 * (size_t)g] = make_int4(dC.x, dC.y, dC.z, n1);      // (without the record counts)
                 p.desc_g[2 * (size_t)g + 1] = wC;
                 sh[SH_OVF] = 0; sh[SH_RETRY] = 0; sh[SH_CNT2] = 0; sh[SH_EQ] = 0;
             }
@@ -1137,8 +1145,9 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                        __builtin_amdgcn_readfirstlane(dNN.z), __builtin_amdgcn_readfirstlane(dNN.w));
         wN = make_int4(__builtin_amdgcn_readfirstlane(wNN.x), __builtin_amdgcn_readfirstlane(wNN.y),
                        __builtin_amdgcn_readfirstlane(wNN.z), __builtin_amdgcn_readfirstlane(wNN.w));
-        my_r0 = nx_r0; my_len = nx_len; my_v = nx_v;
-        recC = recN; recC2 = recN2; preC = preN;
+        asm volatile("" : "+v"(nx_r1));      // (the length is formed here, not where the two bounds were requested)
+        my_r0 = nx_r0; my_len = nx_r1 - nx_r0; my_v = nx_v;
+        recC = recN; recC2 = recN2;
         wg_sync<U_LDS>();
         PHASE_END(PH_OUTPUT);
     }
