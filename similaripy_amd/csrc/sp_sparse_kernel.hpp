@@ -135,15 +135,17 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
     // an index is sign-extended for its later use as soon as it arrives; a difference of two loaded values is formed where the
     // loads are issued; the atomic optimizer turns one lane's returning atomic into a form that needs the result at once
     // (-amdgpu-atomic-optimizer-strategy=None in _build.py).  A register SPILL does the same: its reload counts in vmcnt.
-    auto load_items = [&](int slot, int n_rec, int4 &rec, int4 &rec2) {
-        rec = make_int4(0, 0, 0, 0);
-        rec2 = make_int4(0, 0, 0, 0);
+    // (the records live in native 128-bit vectors so that ONE opaque asm operand can consume them at the row's end — per-component
+    // operands split the tuple and the load's result is copied out, i.e. waited for, right behind the load)
+    auto load_items = [&](int slot, int n_rec, u32x4 &rec, u32x4 &rec2) {
+        rec = u32x4{0u, 0u, 0u, 0u};
+        rec2 = u32x4{0u, 0u, 0u, 0u};
         if (n_rec > 0) {
             // (the thread's index is made opaque here: left alone, `items_g + tid` is hoisted out of the row loop as a 64-bit
             // per-thread pointer, which at this kernel's register budget is spilled and reloaded at every row top)
             int t_o = tid;
             asm volatile("" : "+v"(t_o));
-            const int4 *row = p.items_g + (size_t)slot * ITEMS_STRIDE;
+            const u32x4 *row = (const u32x4 *)(p.items_g + (size_t)slot * ITEMS_STRIDE);
             if (t_o >= 1 && t_o <= n_rec) rec = row[t_o];
             if (REC2 && t_o + NT <= n_rec) rec2 = row[t_o + NT];
         }
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         if (lane >= sB) { vo = offB + (lane - sB) * 16; d = cntB - 4 * (lane - sB); sv = __uint_as_float(svB); }
         if (d <= 0) vo = (int)OOB_SOFFSET;          // lanes beyond the pieces fetch nothing
     };
-    int4 recC, recN, recC2, recN2;
+    u32x4 recC, recN, recC2, recN2;
     load_items(dC.x, desc_n_rec(dC.w), recC, recC2);
     // m1 entry / m2 row bounds of segment `tid` of the current row (rows of this kernel have <= SORT_MAX <= NT entries)
     int my_r0 = 0, my_len = 0;
@@ -333,8 +335,8 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             if (tid == NT - 1) items[n_items] = make_int4((int)OOB_SOFFSET, 0, 0, (int)macs32);
             if (n_pre > 0) {
                 // (the image holds the sentinel too: the same 16 bytes as the store above)
-                if (tid >= 1 && tid <= n_rec) items[tid - 1] = recC;
-                if (REC2 && tid + NT <= n_rec) items[tid + NT - 1] = recC2;
+                if (tid >= 1 && tid <= n_rec) ((u32x4 *)items)[tid - 1] = recC;
+                if (REC2 && tid + NT <= n_rec) ((u32x4 *)items)[tid + NT - 1] = recC2;
             } else if (tid < n1) {
                 int q = 0;
                 for (int o = 0; o < my_len; o += ITEM, ++q)
@@ -1146,6 +1148,11 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         wN = make_int4(__builtin_amdgcn_readfirstlane(wNN.x), __builtin_amdgcn_readfirstlane(wNN.y),
                        __builtin_amdgcn_readfirstlane(wNN.z), __builtin_amdgcn_readfirstlane(wNN.w));
         asm volatile("" : "+v"(nx_r1));      // (the length is formed here, not where the two bounds were requested)
+        // Everything prefetched during this row is consumed HERE, at the row's end, where it arrived long ago: across the loop's back
+        // edge the compiler cannot count what was issued since and waits with vmcnt(0) at the first use in the next row — i.e.
+        // for the loads that row has just issued (the item records' copy into LDS and the queue slot's store waited ~2 k cycles)
+        asm volatile("" : "+v"(recN), "+v"(nx_v), "+v"(pend_q));
+        if constexpr (REC2) asm volatile("" : "+v"(recN2));
         my_r0 = nx_r0; my_len = nx_r1 - nx_r0; my_v = nx_v;
         recC = recN; recC2 = recN2;
         wg_sync<U_LDS>();
