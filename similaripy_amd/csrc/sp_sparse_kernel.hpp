@@ -459,13 +459,6 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             }
             wg_sync<U_LDS>();
             PHASE_END(PH_SWEEP1);
-            // next row's m2 row bounds (its m1 entries were requested at the top of this row)
-            if (dN.x >= 0 && tid < desc_n1(dN.w)) {
-                int u = nx_u;
-                asm volatile("" : "+v"(u));      // (the index is needed HERE: no address arithmetic where it was loaded)
-                nx_r0 = p.m2_indptr[u];
-                nx_r1 = p.m2_indptr[u + 1];
-            }
             // the bitmap has done its job: back to zero (16-byte stores); its storage now serves sweep 2
             for (int i = tid; i < (nb_bytes >> 4); i += NT) ((int4 *)rA)[i] = make_int4(0, 0, 0, 0);
             // rank structure of the collision bitmap: pre16[w] = marked columns in the words below w.  The rank of a
@@ -521,13 +514,14 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 if (carry > CSN / 2) failed = true;      // more marked columns than direct slots (uniform)
             }
             PHASE_END(PH_SEGMENTS);  // (bitmap clear)
-        } else {
-            if (dN.x >= 0 && tid < desc_n1(dN.w)) {
-                int u = nx_u;
-                asm volatile("" : "+v"(u));      // (the index is needed HERE: no address arithmetic where it was loaded)
-                nx_r0 = p.m2_indptr[u];
-                nx_r1 = p.m2_indptr[u + 1];
-            }
+        }
+        // next row's m2 row bounds (its m1 entries were requested at the top of this row).  Requested here, behind the bitmap's
+        // clearing loop: in front of it the compiler drained vmcnt at the loop's exit, i.e. wave 0 waited out the round trip
+        if (dN.x >= 0 && tid < desc_n1(dN.w)) {
+            int u = nx_u;
+            asm volatile("" : "+v"(u));      // (the index is needed HERE: no address arithmetic where it was loaded)
+            nx_r0 = p.m2_indptr[u];
+            nx_r1 = p.m2_indptr[u + 1];
         }
 
         if (!failed) {
