@@ -479,7 +479,8 @@ int run_device_impl(sp_knn_args *a) {
         if (c.items_rows > 0 && kp.sparse_path) {
             const int item_blocks = std::max(1, std::min((a->n_targets + 3) / 4, n_cus * 32));     // 4 rows (waves) per block and trip
             hipLaunchKernelGGL(sp_row_items_kernel, dim3(item_blocks), dim3(256), 0, stream, (const unsigned *)kp.qcount, c.items_rows, (int4 *)desc_s,
-                               a->m1_indices, a->m1_data, a->m2_indptr, (int4 *)ws_items, c.NT_s == 256 ? 1 : 0);
+                               a->m1_indices, a->m1_data, a->m2_indptr, (int4 *)ws_items, c.NT_s == 256 ? 1 : 0,
+                               (c.mono && a->filter_mode == SP_SEL_MATRIX) ? a->filter_m_indptr : nullptr);
             HIP_TRY(hipGetLastError());
             kp.items_g = (const int4 *)ws_items; kp.items_rows = c.items_rows;
         }

@@ -200,17 +200,19 @@ __global__ __launch_bounds__(256) void sp_row_desc_kernel(int n_targets, const i
 //                          products before this trip | (index of the B record << 20, 0 = no B)}
 //   [n_trips]             the sentinel {OOB_SOFFSET, 0, 0, all products}
 //   [n_trips + 1 ...]     B records {byte offset, elements, m1 value bits, first lane sB}
-// row[0] is unused; n_trips and n_records go into the row's queue descriptor (desc_n_trips / desc_n_rec of its .w); rows of more
+// row[0] = {first index, length} of the row's MATRIX-filter list (0, 0 without one); n_trips and n_records go into the row's queue descriptor (desc_n_trips / desc_n_rec of its .w); rows of more
 // than 64 entries, more than ITEMS_PRE records or 2^20 products keep 0 / 0 there: the kernel sets those up itself (one piece per trip).  pack = 0: one piece per trip for every row (the 1024-thread shape).
 __global__ __launch_bounds__(256) void sp_row_items_kernel(const unsigned *__restrict__ qcount, int items_rows, int4 *__restrict__ desc_s,
                                                             const int *__restrict__ m1_indices, const float *__restrict__ m1_data,
-                                                            const int *__restrict__ m2_indptr, int4 *__restrict__ items_g, int pack) {
+                                                            const int *__restrict__ m2_indptr, int4 *__restrict__ items_g, int pack,
+                                                            const int *__restrict__ f_indptr) {
     const int lane = threadIdx.x & 63;
     const int n_rows = (int)qcount[0];
     const int waves_total = (int)(gridDim.x * (blockDim.x >> 6));
     for (int q = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); q < n_rows; q += waves_total) {
         const int4 d = desc_s[2 * (size_t)q];
         const int slot = __builtin_amdgcn_readfirstlane(d.x), s = __builtin_amdgcn_readfirstlane(d.z), n1 = __builtin_amdgcn_readfirstlane(d.w);
+        const int t_row = __builtin_amdgcn_readfirstlane(d.y);
         if (slot >= items_rows) continue;
         int4 *row = items_g + (size_t)slot * ITEMS_STRIDE;
         if (n1 > 64) continue;
@@ -286,6 +288,11 @@ __global__ __launch_bounds__(256) void sp_row_items_kernel(const unsigned *__res
             }
         }
         if (lane == 0) {
+            // record 0: where the row's MATRIX-filter list starts and how long it is (monotone variant: the row kernel then has
+            // the list's columns on their way before its first sweep)
+            int f0 = 0, fl = 0;
+            if (f_indptr != nullptr) { f0 = f_indptr[t_row]; fl = f_indptr[t_row + 1] - f0; }
+            row[0] = make_int4(f0, fl, 0, 0);
             row[1 + n_trips] = make_int4((int)OOB_SOFFSET, 0, 0, total);
             // the counts travel in the row's descriptor (the row kernel has it in scalar registers two rows ahead)
             ((int *)&desc_s[2 * (size_t)q])[3] = n1 | (n_trips << 9) | (n_rec << 19);

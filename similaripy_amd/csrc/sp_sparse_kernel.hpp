@@ -49,6 +49,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
     int *hist4 = (int *)(items + ICAP);
     int *sh = hist4 + 1024;
     u64 *ph = (u64 *)(sh + 32);
+    int *shx = (int *)(ph + PH_N);      // two more scalars (the phase-timer area has 16 slots, PH_N are in use)
     u64 *U = U_LDS ? (u64 *)(rA + (A_bytes / 4) * 3) : (p.gU + (size_t)blockIdx.x * (size_t)p.cap_s);
     const int cap = p.cap_s;
 
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             int t_o = tid;
             asm volatile("" : "+v"(t_o));
             const u32x4 *row = (const u32x4 *)(p.items_g + (size_t)slot * ITEMS_STRIDE);
-            if (t_o >= 1 && t_o <= n_rec) rec = row[t_o];
+            if (t_o <= n_rec) rec = row[t_o];          // (record 0: the bounds of the row's MATRIX-filter list, see below)
             if (REC2 && t_o + NT <= n_rec) rec2 = row[t_o + NT];
         }
     };
@@ -337,6 +338,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 // (the image holds the sentinel too: the same 16 bytes as the store above)
                 if (tid >= 1 && tid <= n_rec) ((u32x4 *)items)[tid - 1] = recC;
                 if (REC2 && tid + NT <= n_rec) ((u32x4 *)items)[tid + NT - 1] = recC2;
+                if (MONO && tid == 0) { shx[0] = (int)recC.x; shx[1] = (int)recC.y; }
             } else if (tid < n1) {
                 int q = 0;
                 for (int o = 0; o < my_len; o += ITEM, ++q)
@@ -344,6 +346,23 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             }
             wg_sync<U_LDS>();
             PHASE_END(PH_SEGMENTS);
+            // MATRIX filter of the monotone variant (s_plus.h:159-171).  The row's excluded columns are (a) marked in the collision
+            // bitmap, so all their products gather in the collision set, and (b) given a pseudo-member of value -inf each: the
+            // column's sum is then -inf, below any cutoff, and the set's scan drops it like any other low sum — no look-up of the
+            // candidate in the filter list (six dependent global loads per candidate before round 3).  A row whose list came with
+            // its item records (record 0: first index and length, sp_row_items_kernel) has every thread's column on its way
+            // from here on; other rows read the list where they need it.
+            int my_fc = -1;
+            bool f_regs = false;      // uniform: the list (<= NT columns) is in my_fc
+            if constexpr (MONO) {
+                if (p.filter_mode == SP_SEL_MATRIX && n_pre > 0) {
+                    const int f0 = shx[0], fl = shx[1];
+                    if (fl <= NT) {
+                        f_regs = true;
+                        if (tid < fl) my_fc = p.f_indices[f0 + tid];
+                    }
+                }
+            }
             // ---- sweep 1: column ids only.  Branch-free: every product ORs its bit into the bitmap; the returned
             // word tells whether the column was there already, in which case (only then a non-zero operand) the
             // column's bit is ORed into the collision bitmap as well. ----
@@ -450,10 +469,14 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 // their products gather in the collision set, where the excluded columns are dropped at the scan
                 // (the filter row's bounds are re-read where they are needed instead of living in registers through the sweeps)
                 if (p.filter_mode == SP_SEL_MATRIX) {
-                    const int f0 = __builtin_amdgcn_readfirstlane(p.f_indptr[t]), f1 = __builtin_amdgcn_readfirstlane(p.f_indptr[t + 1]);
-                    for (int i = f0 + tid; i < f1; i += NT) {
-                        const unsigned c = (unsigned)p.f_indices[i];
-                        atomicOr((unsigned *)(cbm + ((c >> 3) & cmask)), 1u << (c & 31u));
+                    if (f_regs) {
+                        if (my_fc >= 0) atomicOr((unsigned *)(cbm + (((unsigned)my_fc >> 3) & cmask)), 1u << ((unsigned)my_fc & 31u));
+                    } else {
+                        const int f0 = __builtin_amdgcn_readfirstlane(p.f_indptr[t]), f1 = __builtin_amdgcn_readfirstlane(p.f_indptr[t + 1]);
+                        for (int i = f0 + tid; i < f1; i += NT) {
+                            const unsigned c = (unsigned)p.f_indices[i];
+                            atomicOr((unsigned *)(cbm + ((c >> 3) & cmask)), 1u << (c & 31u));
+                        }
                     }
                 }
             }
@@ -512,6 +535,22 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     if (CBM_BYTES / 16 > NT) wg_sync<U_LDS>();     // (sh[SH_WSUM] is reused by the next trip)
                 }
                 if (carry > CSN / 2) failed = true;      // more marked columns than direct slots (uniform)
+            }
+            if constexpr (MONO) {
+                if (p.filter_mode == SP_SEL_MATRIX && !failed) {
+                    // (the member pool is part of the region just cleared: the clearing stores of all waves must be done)
+                    wg_sync<U_LDS>();
+                    auto pseudo = [&](unsigned c) {
+                        const int pos = atomicAdd(&sh[SH_MCTR], 1);
+                        if (pos < mpcap) mpool[pos] = ((u64)(c + 1u) << 32) | (u64)0xFF800000u;      // {column + 1 : -inf}
+                        else sh[SH_OVF] = 1;
+                    };
+                    if (f_regs) { if (my_fc >= 0) pseudo((unsigned)my_fc); }
+                    else {
+                        const int f0 = __builtin_amdgcn_readfirstlane(p.f_indptr[t]), f1 = __builtin_amdgcn_readfirstlane(p.f_indptr[t + 1]);
+                        for (int i = f0 + tid; i < f1; i += NT) pseudo((unsigned)p.f_indices[i]);
+                    }
+                }
             }
             PHASE_END(PH_SEGMENTS);  // (bitmap clear)
         }
@@ -933,11 +972,17 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                             }
 #pragma unroll
                             for (int j = 0; j < 4; ++j) want[j] = (e[j] != 0ull) && !(__uint_as_float((unsigned)e[j]) <= cutx);
-                            if (p.filter_mode == SP_SEL_MATRIX) {      // (uniform) excluded columns of this row
-                                const int f0 = __builtin_amdgcn_readfirstlane(p.f_indptr[t]), f1 = __builtin_amdgcn_readfirstlane(p.f_indptr[t + 1]);
+                            if (p.filter_mode == SP_SEL_MATRIX) {      // (uniform) excluded columns of this row: their sums are -inf ...
+                                bool odd = false;                      // ... unless an infinite product made one NaN: the list decides
 #pragma unroll
-                                for (int j = 0; j < 4; ++j)
-                                    if (want[j] && range_has(p.f_indices, f0, f1, (int)((unsigned)(e[j] >> 32) - 1u))) want[j] = false;
+                                for (int j = 0; j < 4; ++j) odd |= want[j] && (__uint_as_float((unsigned)e[j]) != __uint_as_float((unsigned)e[j]));
+                                if (__ballot(odd)) {
+                                    const int f0 = __builtin_amdgcn_readfirstlane(p.f_indptr[t]), f1 = __builtin_amdgcn_readfirstlane(p.f_indptr[t + 1]);
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j)
+                                        if (want[j] && (__uint_as_float((unsigned)e[j]) != __uint_as_float((unsigned)e[j])) &&
+                                            range_has(p.f_indices, f0, f1, (int)((unsigned)(e[j] >> 32) - 1u))) want[j] = false;
+                                }
                             }
                             const u64 m0 = __ballot(want[0]), m1 = __ballot(want[1]), m2 = __ballot(want[2]), m3 = __ballot(want[3]);
                             const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
@@ -1103,15 +1148,8 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 }
             }
             if (tid == 0 && p.counts) p.counts[slot_i] = n_out;
-            if constexpr (MONO) {
-                if (p.filter_mode == SP_SEL_MATRIX) {      // marks of excluded columns that no product reached
-                    const int f0 = __builtin_amdgcn_readfirstlane(p.f_indptr[t]), f1 = __builtin_amdgcn_readfirstlane(p.f_indptr[t + 1]);
-                    for (int i = f0 + tid; i < f1; i += NT) {
-                        const unsigned c = (unsigned)p.f_indices[i];
-                        atomicAnd((unsigned *)(cbm + ((c >> 3) & cmask)), ~(1u << (c & 31u)));
-                    }
-                }
-            }
+            // (MATRIX filter: every excluded column has a slot in the collision set — its pseudo-member — so the set's scan has
+            // cleared its mark like any other column's)
             if (U_LDS || MONO) {
                 // U's storage is part of the next row's bitmap (LDS) / holes must read zero (MONO).  Every selection zeroes
                 // what lies behind the entries it keeps, so only the first k entries can be non-zero here.
