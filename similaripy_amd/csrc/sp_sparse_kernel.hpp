@@ -108,6 +108,11 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         d1 = make_int4(0, 0, 0, 0);
         if (q < n_rows) { d0 = desc[2 * (size_t)q]; d1 = desc[2 * (size_t)q + 1]; }
     };
+    auto load_desc_v = [&](int q, u32x4 &d0, u32x4 &d1) {
+        d0 = u32x4{0xFFFFFFFFu, 0u, 0u, 0u};
+        d1 = u32x4{0u, 0u, 0u, 0u};
+        if (q < n_rows) { d0 = ((const u32x4 *)desc)[2 * (size_t)q]; d1 = ((const u32x4 *)desc)[2 * (size_t)q + 1]; }
+    };
     int q_nn = 0;      // queue index two rows ahead (static schedule: computed; dynamic: through LDS)
     int pend_q = 0;    // (tid 0) claimed queue index three rows ahead
     int4 dC, dN, wC, wN;   // descriptors (both halves) of the current and the next row
@@ -173,6 +178,17 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         my_len = p.m2_indptr[u + 1] - my_r0;
     }
 
+    // (what was loaded in front of the loop is consumed in front of it: a value still pending at the loop's header makes the compiler
+    // wait with vmcnt(0) at its first use in EVERY iteration — in the later ones for the previous row's result stores)
+    asm volatile("" : "+v"(recC), "+v"(my_r0), "+v"(my_len), "+v"(my_v));
+    if constexpr (REC2) asm volatile("" : "+v"(recC2));
+    {
+        auto scalar4 = [](int4 v) {
+            return make_int4(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y), __builtin_amdgcn_readfirstlane(v.z), __builtin_amdgcn_readfirstlane(v.w));
+        };
+        dC = scalar4(dC); wC = scalar4(wC); dN = scalar4(dN); wN = scalar4(wN);
+    }
+
     // Barriers of the row loop: everything the waves of a row exchange goes through LDS (U too, when U_LDS), so they wait for
     // LDS traffic only (wg_sync<true>): __syncthreads() is a workgroup-scope fence and drains vmcnt as well, which made every
     // barrier behind a row-pipeline prefetch (next row's m1 entries, descriptors, m2 bounds) and behind the write-out stores
@@ -211,12 +227,13 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         // of everything after — starts high.
         int my_ib = 0, my_fs = 0;       // first item / flat start of segment `tid`
         int n_items = 0;
-        int4 dNN, wNN;
+        u32x4 dNN, wNN;       // (native vectors: one opaque operand each where they are consumed)
+        int4 dR = make_int4(-1, 0, 0, 0), wR = make_int4(0, 0, 0, 0);      // ... and moved to scalar registers there, for the rotation
         if (n_pre > 0) {
             // nothing to set up: the records are in registers (they go to LDS below); the row pipeline's descriptor load stays
             wg_sync<U_LDS>();
             if (!p.static_sched) q_nn = sh[SH_QA];
-            load_desc(q_nn, dNN, wNN);
+            load_desc_v(q_nn, dNN, wNN);
             if (p.static_sched) q_nn += (int)gridDim.x;
             n_items = n_pre;
         } else if (n1 <= 64) {
@@ -256,7 +273,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             }
             wg_sync<U_LDS>();
             if (!p.static_sched) q_nn = sh[SH_QA];
-            load_desc(q_nn, dNN, wNN);
+            load_desc_v(q_nn, dNN, wNN);
             if (p.static_sched) q_nn += (int)gridDim.x;
             n_items = sh[SH_NITEMS];
             wg_sync<U_LDS>();                    // scratch read before the items overwrite it
@@ -268,7 +285,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             if (tid < n1) { keyS[tid] = (int)(__float_as_uint(my_v) & 0x7FFFFFFFu); lenS[tid] = my_len; }
             wg_sync<U_LDS>();
             if (!p.static_sched) q_nn = sh[SH_QA];
-            load_desc(q_nn, dNN, wNN);
+            load_desc_v(q_nn, dNN, wNN);
             if (p.static_sched) q_nn += (int)gridDim.x;
             {
                 const int lg = (n1 <= 128) ? 7 : 8;       // segments padded to a power of two
@@ -1097,6 +1114,16 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         if (!failed) {
             // ================= write-out =================
             wg_sync<U_LDS>();
+            // Everything prefetched during this row is consumed HERE — where it arrived long ago, and BEFORE the write-out's stores are
+            // issued: across the loop's back edge the compiler cannot count what was issued since and waits with vmcnt(0) at the
+            // first use in the next row, i.e. for that row's fresh loads (the item records' copy into LDS and the queue slot's store
+            // waited ~2 k cycles) or, consumed at the very end of this row, for its result stores.
+            asm volatile("" : "+v"(recN), "+v"(nx_v), "+v"(pend_q), "+v"(nx_r0), "+v"(nx_r1), "+v"(dNN), "+v"(wNN));
+            if constexpr (REC2) asm volatile("" : "+v"(recN2));
+            dR = make_int4(__builtin_amdgcn_readfirstlane((int)dNN.x), __builtin_amdgcn_readfirstlane((int)dNN.y),
+                           __builtin_amdgcn_readfirstlane((int)dNN.z), __builtin_amdgcn_readfirstlane((int)dNN.w));
+            wR = make_int4(__builtin_amdgcn_readfirstlane((int)wNN.x), __builtin_amdgcn_readfirstlane((int)wNN.y),
+                           __builtin_amdgcn_readfirstlane((int)wNN.z), __builtin_amdgcn_readfirstlane((int)wNN.w));
             const int n_sel = min(sh[SH_CNT], p.k);
             const long long o = (long long)slot_i * (long long)p.k;
             int n_out = n_sel;
@@ -1161,6 +1188,13 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         } else {
             // a pool or the collision set overflowed (or the row has too many items): hand the row to the generic
             // kernel's queue and put the LDS state back to clean
+            // (this path's copy of the consumption above: on every path in front of the path's own stores)
+            asm volatile("" : "+v"(recN), "+v"(nx_v), "+v"(pend_q), "+v"(nx_r0), "+v"(nx_r1), "+v"(dNN), "+v"(wNN));
+            if constexpr (REC2) asm volatile("" : "+v"(recN2));
+            dR = make_int4(__builtin_amdgcn_readfirstlane((int)dNN.x), __builtin_amdgcn_readfirstlane((int)dNN.y),
+                           __builtin_amdgcn_readfirstlane((int)dNN.z), __builtin_amdgcn_readfirstlane((int)dNN.w));
+            wR = make_int4(__builtin_amdgcn_readfirstlane((int)wNN.x), __builtin_amdgcn_readfirstlane((int)wNN.y),
+                           __builtin_amdgcn_readfirstlane((int)wNN.z), __builtin_amdgcn_readfirstlane((int)wNN.w));
             wg_sync<U_LDS>();
             if (tid == 0) {
                 const unsigned g = atomicAdd(&p.qcount[1], 1u);
@@ -1175,16 +1209,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         }
         // rotate the row pipeline (descriptors are wave-uniform: keep them in scalar registers)
         dC = dN; wC = wN;
-        dN = make_int4(__builtin_amdgcn_readfirstlane(dNN.x), __builtin_amdgcn_readfirstlane(dNN.y),
-                       __builtin_amdgcn_readfirstlane(dNN.z), __builtin_amdgcn_readfirstlane(dNN.w));
-        wN = make_int4(__builtin_amdgcn_readfirstlane(wNN.x), __builtin_amdgcn_readfirstlane(wNN.y),
-                       __builtin_amdgcn_readfirstlane(wNN.z), __builtin_amdgcn_readfirstlane(wNN.w));
-        asm volatile("" : "+v"(nx_r1));      // (the length is formed here, not where the two bounds were requested)
-        // Everything prefetched during this row is consumed HERE, at the row's end, where it arrived long ago: across the loop's back
-        // edge the compiler cannot count what was issued since and waits with vmcnt(0) at the first use in the next row — i.e.
-        // for the loads that row has just issued (the item records' copy into LDS and the queue slot's store waited ~2 k cycles)
-        asm volatile("" : "+v"(recN), "+v"(nx_v), "+v"(pend_q));
-        if constexpr (REC2) asm volatile("" : "+v"(recN2));
+        dN = dR; wN = wR;
         my_r0 = nx_r0; my_len = nx_r1 - nx_r0; my_v = nx_v;
         recC = recN; recC2 = recN2;
         wg_sync<U_LDS>();
