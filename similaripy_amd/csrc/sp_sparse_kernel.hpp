@@ -29,7 +29,7 @@ template <int NT, bool U_LDS, bool MONO>
 __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NW = NT / 64;
-    const int tid = threadIdx.x;
+    int tid = threadIdx.x;      // (made opaque at every row top, see there)
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int A_bytes = p.T * 8;
@@ -195,6 +195,9 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
     // wait for those round trips (round 3: measured with the register-resident experiment, profiles/r03_exp_rowreg.txt).
     for (;;) {
         // row-constant values are wave-uniform: v_readfirstlane moves them to scalar registers
+        // (the thread index is opaque per row: addresses derived from it are recomputed where they are used instead of being
+        // hoisted out of the row loop, held in registers through the sweeps and — at this kernel's budget — spilled)
+        if constexpr (!MONO) asm volatile("" : "+v"(tid));
         const int slot_i = __builtin_amdgcn_readfirstlane(dC.x);
         if (slot_i < 0) break;
         const int t = __builtin_amdgcn_readfirstlane(dC.y);
