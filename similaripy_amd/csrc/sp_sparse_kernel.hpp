@@ -197,7 +197,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         // row-constant values are wave-uniform: v_readfirstlane moves them to scalar registers
         // (the thread index is opaque per row: addresses derived from it are recomputed where they are used instead of being
         // hoisted out of the row loop, held in registers through the sweeps and — at this kernel's budget — spilled)
-        if constexpr (!MONO) asm volatile("" : "+v"(tid));
+        asm volatile("" : "+v"(tid));
         const int slot_i = __builtin_amdgcn_readfirstlane(dC.x);
         if (slot_i < 0) break;
         const int t = __builtin_amdgcn_readfirstlane(dC.y);
