@@ -610,35 +610,50 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             if constexpr (MONO) {
                 const int NA = min(n_items, NW);
                 const int mrounds = (p.k + NA - 1) / NA + 2;
-                if (NA == NW && mrounds <= 16) {     // (k <= 14*NW; larger k: the accept-everything first stage of the loop below)
-                    unsigned c[4];
-                    float v[4], x[4];
-                    u64 M[4], S[4];
+                // FS trips per wave in this stage.  The 256-thread shape takes two when the row has them: its four waves see 800
+                // products of a user-scoring row with one trip each, the 100th largest of which is a loose cutoff — the rest of
+                // the row then half-fills U two or three times, each time a selection (a fifth of the row's cycles); with 1 600
+                // products the cutoff lets a few hundred through and the row needs its final selection only.
+                constexpr int FS = (NT == 256) ? 2 : 1;
+                const int fs = (FS == 2 && n_items >= 2 * NW) ? 2 : 1;      // uniform
+                // (k <= 14*NW, for the four waves of the 256-thread shape k <= 30*NW: there a round costs less than the extra selections;
+                // larger k: the accept-everything first stage of the loop below)
+                constexpr int MAXR = (NT == 256) ? 32 : 16;
+                if (NA == NW && mrounds <= MAXR) {
+                    unsigned c[FS][4];
+                    float x[FS][4];
+                    u64 M[FS][4], S[FS][4];
                     unsigned lmax = 0u;
-                    const int4 d = items[wave];
-                    const int cntA = __builtin_amdgcn_readfirstlane(d.y);
-                    int dq;      // real elements of this lane's quad
-                    {
-                        int4 b4 = make_int4(0, 0, 0, 64);
-                        const int bix = two_piece ? (int)((unsigned)__builtin_amdgcn_readfirstlane(d.w) >> ITEM_W_BITS) : 0;
-                        if (bix) b4 = items[bix];
-                        int vo;
-                        float segv;
-                        trip_lane(__builtin_amdgcn_readfirstlane(d.x), cntA, (unsigned)__builtin_amdgcn_readfirstlane(d.z),
-                                  __builtin_amdgcn_readfirstlane(b4.x), __builtin_amdgcn_readfirstlane(b4.y), (unsigned)__builtin_amdgcn_readfirstlane(b4.z),
-                                  __builtin_amdgcn_readfirstlane(b4.w), vo, dq, segv);
-                        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, vo, 0, 0);
-                        const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs_val, vo, 0, 0);
-                        c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w;
-                        v[0] = __uint_as_float(b.x); v[1] = __uint_as_float(b.y); v[2] = __uint_as_float(b.z); v[3] = __uint_as_float(b.w);
-                        s2_core(c, v, segv, cutx, x, M, S);
-                    }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const u64 ok = (cntA == ITEM) ? ~0ull : __ballot(j < dq);
-                        M[j] &= ok;
-                        S[j] &= ok & ~M[j];
-                        if ((S[j] >> lane) & 1ull) lmax = max(lmax, fkey(x[j]));
+                    for (int f = 0; f < FS; ++f) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { c[f][j] = 0u; x[f][j] = 0.f; M[f][j] = 0ull; S[f][j] = 0ull; }
+                        if (f < fs) {
+                            float v[4];
+                            const int4 d = items[wave + f * NW];
+                            const int cntA = __builtin_amdgcn_readfirstlane(d.y);
+                            int dq;      // real elements of this lane's quad
+                            int4 b4 = make_int4(0, 0, 0, 64);
+                            const int bix = two_piece ? (int)((unsigned)__builtin_amdgcn_readfirstlane(d.w) >> ITEM_W_BITS) : 0;
+                            if (bix) b4 = items[bix];
+                            int vo;
+                            float segv;
+                            trip_lane(__builtin_amdgcn_readfirstlane(d.x), cntA, (unsigned)__builtin_amdgcn_readfirstlane(d.z),
+                                      __builtin_amdgcn_readfirstlane(b4.x), __builtin_amdgcn_readfirstlane(b4.y), (unsigned)__builtin_amdgcn_readfirstlane(b4.z),
+                                      __builtin_amdgcn_readfirstlane(b4.w), vo, dq, segv);
+                            const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, vo, 0, 0);
+                            const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs_val, vo, 0, 0);
+                            c[f][0] = a.x; c[f][1] = a.y; c[f][2] = a.z; c[f][3] = a.w;
+                            v[0] = __uint_as_float(b.x); v[1] = __uint_as_float(b.y); v[2] = __uint_as_float(b.z); v[3] = __uint_as_float(b.w);
+                            s2_core(c[f], v, segv, cutx, x[f], M[f], S[f]);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const u64 ok = (cntA == ITEM) ? ~0ull : __ballot(j < dq);
+                                M[f][j] &= ok;
+                                S[f][j] &= ok & ~M[f][j];
+                                if ((S[f][j] >> lane) & 1ull) lmax = max(lmax, fkey(x[f][j]));
+                            }
+                        }
                     }
                     // m-th largest (distinct) lane maximum of this wave — fewer rounds for a wave with fewer candidate lanes
                     // (a partial item), so that its looser statistics do not drag the common cutoff down; whether k
@@ -647,17 +662,19 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     // no reduction needed), k + 2*NW ranks in total
                     int my_rounds;
                     {
-                        int lw = 0;                                                            // lanes of item `lane`
+                        int lw = 0;                                                            // lanes of the trips of wave `lane`
                         if (lane < NW) {
-                            const int4 it = items[lane];
-                            lw = (it.y + 3) / 4;
-                            const int bix = two_piece ? (int)((unsigned)it.w >> ITEM_W_BITS) : 0;
-                            if (bix) lw += (items[bix].y + 3) / 4;
+                            for (int f = 0; f < fs; ++f) {
+                                const int4 it = items[lane + f * NW];
+                                lw += (it.y + 3) / 4;
+                                const int bix = two_piece ? (int)((unsigned)it.w >> ITEM_W_BITS) : 0;
+                                if (bix) lw += (items[bix].y + 3) / 4;
+                            }
                         }
                         const int lanes_all = wave_incl_scan_dpp(lw);                          // lane 63: the sum
                         const int L = max(1, __builtin_amdgcn_readlane(lanes_all, 63));
                         const int mine = max(1, __builtin_amdgcn_readlane(lw, wave));
-                        my_rounds = max(1, min(24, ((p.k + 2 * NW) * mine + L - 1) / L));
+                        my_rounds = max(1, min(MAXR + 8, ((p.k + 2 * NW) * mine + L - 1) / L));
                     }
                     unsigned rest = lmax, tw = 0u;
                     for (int r = 0; r < my_rounds; ++r) {
@@ -668,49 +685,50 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     if (lane == 0 && tw != 0u) atomicMin((unsigned *)&sh[SH_SEL], tw);
                     wg_sync<U_LDS>();
                     const unsigned g = (unsigned)sh[SH_SEL];            // every product pushed below has key >= g
-                    u64 G[4];
                     int cw = 0;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        G[j] = S[j] & __ballot(fkey(x[j]) >= g);
-                        cw += __popcll(G[j]);
-                    }
+                    for (int f = 0; f < FS; ++f)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) cw += __popcll(S[f][j] & __ballot(fkey(x[f][j]) >= g));
                     if (lane == 0 && cw) atomicAdd(&sh[SH_NEED], cw);
                     wg_sync<U_LDS>();
                     const int totalA = sh[SH_NEED];
                     const bool fits = totalA <= room / 2 && totalA >= p.k;   // uniform: k products reach g (so it is a valid cutoff) and they leave U half empty
                     const int nfull = max(1, (room / 2) / ITEM);        // fallback: the first nfull items, everything accepted (U at most half full)
-                    if (fits || wave < nfull) {
-                        if (!fits) {
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) G[j] = S[j];
-                        }
-                        const int m0 = __popcll(M[0]), m1 = __popcll(M[1]), m2 = __popcll(M[2]), m3 = __popcll(M[3]);
-                        if (m0 + m1 + m2 + m3) {
-                            if (pool_reserve(wpm, m0 + m1 + m2 + m3, &sh[SH_MCTR], mpcap, &sh[SH_OVF])) {
-                                int pos = wpm.pos;
-                                lds_push64(M[0], __float_as_uint(x[0]), c[0] + 1u, pos, mpool_off); pos += m0;
-                                lds_push64(M[1], __float_as_uint(x[1]), c[1] + 1u, pos, mpool_off); pos += m1;
-                                lds_push64(M[2], __float_as_uint(x[2]), c[2] + 1u, pos, mpool_off); pos += m2;
-                                lds_push64(M[3], __float_as_uint(x[3]), c[3] + 1u, pos, mpool_off);
-                                wpm.pos = pos + m3;
+                    for (int f = 0; f < FS; ++f) {
+                        // (not fitting: only the waves' FIRST trips are items [0, nfull); the others are offered again by the loop below)
+                        if (f < fs && (fits || (f == 0 && wave < nfull))) {
+                            u64 G[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) G[j] = fits ? (S[f][j] & __ballot(fkey(x[f][j]) >= g)) : S[f][j];
+                            const int m0 = __popcll(M[f][0]), m1 = __popcll(M[f][1]), m2 = __popcll(M[f][2]), m3 = __popcll(M[f][3]);
+                            if (m0 + m1 + m2 + m3) {
+                                if (pool_reserve(wpm, m0 + m1 + m2 + m3, &sh[SH_MCTR], mpcap, &sh[SH_OVF])) {
+                                    int pos = wpm.pos;
+                                    lds_push64(M[f][0], __float_as_uint(x[f][0]), c[f][0] + 1u, pos, mpool_off); pos += m0;
+                                    lds_push64(M[f][1], __float_as_uint(x[f][1]), c[f][1] + 1u, pos, mpool_off); pos += m1;
+                                    lds_push64(M[f][2], __float_as_uint(x[f][2]), c[f][2] + 1u, pos, mpool_off); pos += m2;
+                                    lds_push64(M[f][3], __float_as_uint(x[f][3]), c[f][3] + 1u, pos, mpool_off);
+                                    wpm.pos = pos + m3;
+                                }
+                            }
+                            const int n0 = __popcll(G[0]), n1 = __popcll(G[1]), n2 = __popcll(G[2]), n3 = __popcll(G[3]);
+                            if (n0 + n1 + n2 + n3) {
+                                int ubase = 0;
+                                if (lane == 0) ubase = atomicAdd(&sh[SH_CNT], n0 + n1 + n2 + n3);     // exact: no holes in this stage
+                                int pos = __builtin_amdgcn_readfirstlane(ubase);
+                                if ((G[0] >> lane) & 1ull) U[pos + mbcnt64(G[0])] = ((u64)fkey(x[f][0]) << 32) | (u64)c[f][0];
+                                pos += n0;
+                                if ((G[1] >> lane) & 1ull) U[pos + mbcnt64(G[1])] = ((u64)fkey(x[f][1]) << 32) | (u64)c[f][1];
+                                pos += n1;
+                                if ((G[2] >> lane) & 1ull) U[pos + mbcnt64(G[2])] = ((u64)fkey(x[f][2]) << 32) | (u64)c[f][2];
+                                pos += n2;
+                                if ((G[3] >> lane) & 1ull) U[pos + mbcnt64(G[3])] = ((u64)fkey(x[f][3]) << 32) | (u64)c[f][3];
                             }
                         }
-                        const int n0 = __popcll(G[0]), n1 = __popcll(G[1]), n2 = __popcll(G[2]), n3 = __popcll(G[3]);
-                        if (n0 + n1 + n2 + n3) {
-                            int ubase = 0;
-                            if (lane == 0) ubase = atomicAdd(&sh[SH_CNT], n0 + n1 + n2 + n3);     // exact: no holes in this stage
-                            int pos = __builtin_amdgcn_readfirstlane(ubase);
-                            if ((G[0] >> lane) & 1ull) U[pos + mbcnt64(G[0])] = ((u64)fkey(x[0]) << 32) | (u64)c[0];
-                            pos += n0;
-                            if ((G[1] >> lane) & 1ull) U[pos + mbcnt64(G[1])] = ((u64)fkey(x[1]) << 32) | (u64)c[1];
-                            pos += n1;
-                            if ((G[2] >> lane) & 1ull) U[pos + mbcnt64(G[2])] = ((u64)fkey(x[2]) << 32) | (u64)c[2];
-                            pos += n2;
-                            if ((G[3] >> lane) & 1ull) U[pos + mbcnt64(G[3])] = ((u64)fkey(x[3]) << 32) | (u64)c[3];
-                        }
                     }
-                    i0 = fits ? NW : nfull;
+                    i0 = fits ? fs * NW : nfull;
                     if (fits) {
                         rc.have_thr = true;
                         rc.thr_key = g;
