@@ -549,6 +549,66 @@ __device__ __forceinline__ void s1_core(const unsigned (&c)[4], const unsigned (
     seen[0] = b0; seen[1] = b1; seen[2] = b2; seen[3] = b3;
 }
 
+// Eight columns (two items) per lane, padding at QUAD granularity: a lane whose quad of item i holds no real element
+// (d_i <= 0) ORs nothing and reports nothing — its operand is 0 << c and the width of its v_bfe is 0; ONE compare per item
+// instead of one per element.  The lane that holds a partial item's LAST elements treats its whole quad as real: the up to
+// three ids behind the item's end (the next m2 row's first ids, or 0 behind the array's end) set bits nobody asked for.
+// That is safe — a column marked without a second product only takes the collision-set route, where the sum of its one
+// product is exact — and rare (<= 3 of a 256-element item).
+template <int BM_OFF>
+__device__ __forceinline__ void s1_core8q(const unsigned (&c)[8], int d0, int d1, unsigned amask, unsigned (&seen)[8]) {
+    unsigned a0, a1, o0, o1;
+    asm volatile(
+        "v_cmp_lt_i32 vcc, 0, %[d0]\n\t"
+        "v_cndmask_b32 %[o0], 0, 1, vcc\n\t"
+        "v_cmp_lt_i32 vcc, 0, %[d1]\n\t"
+        "v_cndmask_b32 %[o1], 0, 1, vcc\n\t"
+        "v_lshlrev_b32 %[b0], %[c0], %[o0]\n\t"
+        "v_lshrrev_b32 %[a0], 3, %[c0]\n\t"
+        "v_and_b32 %[a0], %[am], %[a0]\n\t"
+        "ds_or_rtn_b32 %[b0], %[a0], %[b0] offset:%[off]\n\t"
+        "v_lshlrev_b32 %[b1], %[c1], %[o0]\n\t"
+        "v_lshrrev_b32 %[a1], 3, %[c1]\n\t"
+        "v_and_b32 %[a1], %[am], %[a1]\n\t"
+        "ds_or_rtn_b32 %[b1], %[a1], %[b1] offset:%[off]\n\t"
+        "v_lshlrev_b32 %[b2], %[c2], %[o0]\n\t"
+        "v_lshrrev_b32 %[a0], 3, %[c2]\n\t"
+        "v_and_b32 %[a0], %[am], %[a0]\n\t"
+        "ds_or_rtn_b32 %[b2], %[a0], %[b2] offset:%[off]\n\t"
+        "v_lshlrev_b32 %[b3], %[c3], %[o0]\n\t"
+        "v_lshrrev_b32 %[a1], 3, %[c3]\n\t"
+        "v_and_b32 %[a1], %[am], %[a1]\n\t"
+        "ds_or_rtn_b32 %[b3], %[a1], %[b3] offset:%[off]\n\t"
+        "v_lshlrev_b32 %[b4], %[c4], %[o1]\n\t"
+        "v_lshrrev_b32 %[a0], 3, %[c4]\n\t"
+        "v_and_b32 %[a0], %[am], %[a0]\n\t"
+        "ds_or_rtn_b32 %[b4], %[a0], %[b4] offset:%[off]\n\t"
+        "v_lshlrev_b32 %[b5], %[c5], %[o1]\n\t"
+        "v_lshrrev_b32 %[a1], 3, %[c5]\n\t"
+        "v_and_b32 %[a1], %[am], %[a1]\n\t"
+        "ds_or_rtn_b32 %[b5], %[a1], %[b5] offset:%[off]\n\t"
+        "v_lshlrev_b32 %[b6], %[c6], %[o1]\n\t"
+        "v_lshrrev_b32 %[a0], 3, %[c6]\n\t"
+        "v_and_b32 %[a0], %[am], %[a0]\n\t"
+        "ds_or_rtn_b32 %[b6], %[a0], %[b6] offset:%[off]\n\t"
+        "v_lshlrev_b32 %[b7], %[c7], %[o1]\n\t"
+        "v_lshrrev_b32 %[a1], 3, %[c7]\n\t"
+        "v_and_b32 %[a1], %[am], %[a1]\n\t"
+        "ds_or_rtn_b32 %[b7], %[a1], %[b7] offset:%[off]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_bfe_u32 %[b0], %[b0], %[c0], %[o0]\n\t"
+        "v_bfe_u32 %[b1], %[b1], %[c1], %[o0]\n\t"
+        "v_bfe_u32 %[b2], %[b2], %[c2], %[o0]\n\t"
+        "v_bfe_u32 %[b3], %[b3], %[c3], %[o0]\n\t"
+        "v_bfe_u32 %[b4], %[b4], %[c4], %[o1]\n\t"
+        "v_bfe_u32 %[b5], %[b5], %[c5], %[o1]\n\t"
+        "v_bfe_u32 %[b6], %[b6], %[c6], %[o1]\n\t"
+        "v_bfe_u32 %[b7], %[b7], %[c7], %[o1]\n\t"
+        : [a0] "=&v"(a0), [a1] "=&v"(a1), [o0] "=&v"(o0), [o1] "=&v"(o1), [b0] "=&v"(seen[0]), [b1] "=&v"(seen[1]), [b2] "=&v"(seen[2]), [b3] "=&v"(seen[3]), [b4] "=&v"(seen[4]), [b5] "=&v"(seen[5]), [b6] "=&v"(seen[6]), [b7] "=&v"(seen[7])
+        : [c0] "v"(c[0]), [c1] "v"(c[1]), [c2] "v"(c[2]), [c3] "v"(c[3]), [c4] "v"(c[4]), [c5] "v"(c[5]), [c6] "v"(c[6]), [c7] "v"(c[7]), [d0] "v"(d0), [d1] "v"(d1), [am] "s"(amask), [off] "i"(BM_OFF)
+        : "memory", "vcc");
+}
+
 // The same for eight columns (two items) per lane: twice the LDS atomics in flight per wait, address registers reused
 // as soon as their atomic is issued.  MASKED: element j of item i is real iff j < d_i (per lane; padding ORs nothing).
 template <int BM_OFF, bool MASKED>

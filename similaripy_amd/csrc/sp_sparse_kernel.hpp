@@ -443,13 +443,36 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     // both at two levels, gains half of that)
                     __builtin_amdgcn_s_setprio(3);
                     unsigned seen[8];
-                    if (cnt0 == ITEM && cnt1 == ITEM) s1_core8<CBM_BYTES + PRE_BYTES, false>(c, d0, d1, amask, seen);      // (an A piece of 256 fills the trip)
-                    else s1_core8<CBM_BYTES + PRE_BYTES, true>(c, d0, d1, amask, seen);      // padding ORs nothing
-                    // ~2 % of the products find their column already there: mark it in the collision bitmap
-                    if (__ballot(((seen[0] | seen[1]) | (seen[2] | seen[3]) | (seen[4] | seen[5]) | (seen[6] | seen[7])) != 0u)) {
+                    // (padding at quad granularity, one compare per item: the per-element form cost 32 instructions more on every
+                    // trip that holds a partial item — more than half of a C2 row's)
+                    s1_core8q<CBM_BYTES + PRE_BYTES>(c, d0, d1, amask, seen);
+                    // ~2 % of the products find their column already there: mark it in the collision bitmap.  A trip nearly always
+                    // holds such products (~10 of its 512), a LANE rarely more than one: the lane's column is then the sum of
+                    // seen[j] * c[j] (seen is 0 / 1; v_mad_u32_u24: the mark needs the low 16 bits of the column only) and goes out
+                    // in ONE masked atomic; lanes with two or more (about every third trip has one) take the per-element path.
+                    // (eight exec-masked tests and branches per trip before: as many instructions as the sweep's core)
+                    const unsigned cnt = ((seen[0] + seen[1]) + (seen[2] + seen[3])) + ((seen[4] + seen[5]) + (seen[6] + seen[7]));
+                    if (__ballot(cnt != 0u)) {
+                        unsigned cs;      // (one asm statement: the compiler's own form is v_mul_lo_u32, quarter rate)
+                        asm("v_mul_u32_u24 %0, %1, %9\n\t"
+                            "v_mad_u32_u24 %0, %2, %10, %0\n\t"
+                            "v_mad_u32_u24 %0, %3, %11, %0\n\t"
+                            "v_mad_u32_u24 %0, %4, %12, %0\n\t"
+                            "v_mad_u32_u24 %0, %5, %13, %0\n\t"
+                            "v_mad_u32_u24 %0, %6, %14, %0\n\t"
+                            "v_mad_u32_u24 %0, %7, %15, %0\n\t"
+                            "v_mad_u32_u24 %0, %8, %16, %0"
+                            : "=&v"(cs)
+                            : "v"(seen[0]), "v"(seen[1]), "v"(seen[2]), "v"(seen[3]), "v"(seen[4]), "v"(seen[5]), "v"(seen[6]), "v"(seen[7]),
+                              "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]));
+                        if (cnt == 1u) atomicOr((unsigned *)(cbm + ((cs >> 3) & cmask)), 1u << (cs & 31u));
+                        if (__ballot(cnt > 1u)) {
+                            if (cnt > 1u) {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            if (seen[j]) atomicOr((unsigned *)(cbm + ((c[j] >> 3) & cmask)), 1u << (c[j] & 31u));
+                                for (int j = 0; j < 8; ++j)
+                                    if (seen[j]) atomicOr((unsigned *)(cbm + ((c[j] >> 3) & cmask)), 1u << (c[j] & 31u));
+                            }
+                        }
                     }
                     __builtin_amdgcn_s_setprio(0);
                 };
