@@ -351,6 +351,15 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             if (p.target_mode == SP_SEL_MATRIX) { rc.g0 = __builtin_amdgcn_readfirstlane(p.t_indptr[t]); rc.g1 = __builtin_amdgcn_readfirstlane(p.t_indptr[t + 1]); }
         }
 
+        // MONO: the first stage's trips (one or two items per wave, see there) are requested in front of the bitmap's clearing loop and
+        // the rank prefix: the round trip (~3.5 k cycles, in which no wave had anything else to do) runs under those ~3.6 k cycles
+        // (zero-initialised: undefined on some path, the registers' last contents would be live around the whole row loop)
+        constexpr int FS1 = (NT == 256) ? 2 : 1;
+        constexpr int MAXR1 = (NT == 256) ? 32 : 16;
+        u32x4 fsa[FS1], fsb[FS1];
+#pragma unroll
+        for (int f = 0; f < FS1; ++f) { fsa[f] = u32x4{0u, 0u, 0u, 0u}; fsb[f] = u32x4{0u, 0u, 0u, 0u}; }
+        bool fs_early = false;      // uniform
         if (!failed) {
             // sentinel item behind the last one: a prefetch past the end loads nothing (every lane out of range)
             if (tid == NT - 1) items[n_items] = make_int4((int)OOB_SOFFSET, 0, 0, (int)macs32);
@@ -525,6 +534,30 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             }
             wg_sync<U_LDS>();
             PHASE_END(PH_SWEEP1);
+            if constexpr (MONO) {
+                const int NA = min(n_items, NW);
+                if (NA == NW && (p.k + NA - 1) / NA + 2 <= MAXR1) {      // (the first stage's own condition)
+                    fs_early = true;
+                    const int fs = (FS1 == 2 && n_items >= 2 * NW) ? 2 : 1;      // uniform
+#pragma unroll
+                    for (int f = 0; f < FS1; ++f) {
+                        if (f < fs) {
+                            const int4 d = items[wave + f * NW];
+                            int4 b4 = make_int4(0, 0, 0, 64);
+                            const int bix = two_piece ? (int)((unsigned)__builtin_amdgcn_readfirstlane(d.w) >> ITEM_W_BITS) : 0;
+                            if (bix) b4 = items[bix];
+                            int vo, dq;
+                            float segv;
+                            trip_lane(__builtin_amdgcn_readfirstlane(d.x), __builtin_amdgcn_readfirstlane(d.y), (unsigned)__builtin_amdgcn_readfirstlane(d.z),
+                                      __builtin_amdgcn_readfirstlane(b4.x), __builtin_amdgcn_readfirstlane(b4.y), (unsigned)__builtin_amdgcn_readfirstlane(b4.z),
+                                      __builtin_amdgcn_readfirstlane(b4.w), vo, dq, segv);
+                            fsa[f] = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, vo, 0, 0);
+                            fsb[f] = __builtin_amdgcn_raw_buffer_load_b128(rs_val, vo, 0, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
             // the bitmap has done its job: back to zero (16-byte stores); its storage now serves sweep 2
             for (int i = tid; i < (nb_bytes >> 4); i += NT) ((int4 *)rA)[i] = make_int4(0, 0, 0, 0);
             // rank structure of the collision bitmap: pre16[w] = marked columns in the words below w.  The rank of a
@@ -637,12 +670,12 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 // products of a user-scoring row with one trip each, the 100th largest of which is a loose cutoff — the rest of
                 // the row then half-fills U two or three times, each time a selection (a fifth of the row's cycles); with 1 600
                 // products the cutoff lets a few hundred through and the row needs its final selection only.
-                constexpr int FS = (NT == 256) ? 2 : 1;
+                constexpr int FS = FS1;
                 const int fs = (FS == 2 && n_items >= 2 * NW) ? 2 : 1;      // uniform
                 // (k <= 14*NW, for the four waves of the 256-thread shape k <= 30*NW: there a round costs less than the extra selections;
                 // larger k: the accept-everything first stage of the loop below)
-                constexpr int MAXR = (NT == 256) ? 32 : 16;
-                if (NA == NW && mrounds <= MAXR) {
+                constexpr int MAXR = MAXR1;
+                if (fs_early) {      // (= NA == NW && mrounds <= MAXR, decided where the stage's loads were issued)
                     unsigned c[FS][4];
                     float x[FS][4];
                     u64 M[FS][4], S[FS][4];
@@ -664,8 +697,8 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                             trip_lane(__builtin_amdgcn_readfirstlane(d.x), cntA, (unsigned)__builtin_amdgcn_readfirstlane(d.z),
                                       __builtin_amdgcn_readfirstlane(b4.x), __builtin_amdgcn_readfirstlane(b4.y), (unsigned)__builtin_amdgcn_readfirstlane(b4.z),
                                       __builtin_amdgcn_readfirstlane(b4.w), vo, dq, segv);
-                            const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, vo, 0, 0);
-                            const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs_val, vo, 0, 0);
+                            (void)vo;      // (requested in front of the bitmap's clearing loop)
+                            const u32x4 a = fsa[f], b = fsb[f];
                             c[f][0] = a.x; c[f][1] = a.y; c[f][2] = a.z; c[f][3] = a.w;
                             v[0] = __uint_as_float(b.x); v[1] = __uint_as_float(b.y); v[2] = __uint_as_float(b.z); v[3] = __uint_as_float(b.w);
                             s2_core(c[f], v, segv, cutx, x[f], M[f], S[f]);
