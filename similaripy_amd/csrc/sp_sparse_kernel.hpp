@@ -108,10 +108,12 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         d1 = make_int4(0, 0, 0, 0);
         if (q < n_rows) { d0 = desc[2 * (size_t)q]; d1 = desc[2 * (size_t)q + 1]; }
     };
-    auto load_desc_v = [&](int q, u32x4 &d0, u32x4 &d1) {
-        d0 = u32x4{0xFFFFFFFFu, 0u, 0u, 0u};
-        d1 = u32x4{0u, 0u, 0u, 0u};
-        if (q < n_rows) { d0 = ((const u32x4 *)desc)[2 * (size_t)q]; d1 = ((const u32x4 *)desc)[2 * (size_t)q + 1]; }
+    // (the descriptor two rows ahead stays pending through a whole row: ONE register — lane i < 8 holds its dword i — instead
+    // of eight registers with the same 32 bytes in every lane; ln: the caller's per-row lane id, so that no per-lane pointer is
+    // hoisted out of the row loop)
+    auto load_desc_v = [&](int q, int ln, unsigned &dv) {
+        dv = (ln == 0) ? 0xFFFFFFFFu : 0u;
+        if (q < n_rows && ln < 8) dv = (((const unsigned *)desc) + 8 * (size_t)q)[ln];
     };
     int q_nn = 0;      // queue index two rows ahead (static schedule: computed; dynamic: through LDS)
     int pend_q = 0;    // (tid 0) claimed queue index three rows ahead
@@ -230,13 +232,13 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         // of everything after — starts high.
         int my_ib = 0, my_fs = 0;       // first item / flat start of segment `tid`
         int n_items = 0;
-        u32x4 dNN, wNN;       // (native vectors: one opaque operand each where they are consumed)
+        unsigned dNN;         // descriptor two rows ahead, dword i in lane i
         int4 dR = make_int4(-1, 0, 0, 0), wR = make_int4(0, 0, 0, 0);      // ... and moved to scalar registers there, for the rotation
         if (n_pre > 0) {
             // nothing to set up: the records are in registers (they go to LDS below); the row pipeline's descriptor load stays
             wg_sync<U_LDS>();
             if (!p.static_sched) q_nn = sh[SH_QA];
-            load_desc_v(q_nn, dNN, wNN);
+            load_desc_v(q_nn, tid & 63, dNN);
             if (p.static_sched) q_nn += (int)gridDim.x;
             n_items = n_pre;
         } else if (n1 <= 64) {
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             }
             wg_sync<U_LDS>();
             if (!p.static_sched) q_nn = sh[SH_QA];
-            load_desc_v(q_nn, dNN, wNN);
+            load_desc_v(q_nn, tid & 63, dNN);
             if (p.static_sched) q_nn += (int)gridDim.x;
             n_items = sh[SH_NITEMS];
             wg_sync<U_LDS>();                    // scratch read before the items overwrite it
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             if (tid < n1) { keyS[tid] = (int)(__float_as_uint(my_v) & 0x7FFFFFFFu); lenS[tid] = my_len; }
             wg_sync<U_LDS>();
             if (!p.static_sched) q_nn = sh[SH_QA];
-            load_desc_v(q_nn, dNN, wNN);
+            load_desc_v(q_nn, tid & 63, dNN);
             if (p.static_sched) q_nn += (int)gridDim.x;
             {
                 const int lg = (n1 <= 128) ? 7 : 8;       // segments padded to a power of two
@@ -655,6 +657,11 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             bool last_stage = false;
             bool force_sel = false;
             WavePool wpm{0, -1};      // member-pool window: lives across the stages of the row
+            // MONO: the first trip of the stage BEHIND the selection-free first stage (item pre_i0 + wave) is requested as soon as that
+            // stage's own data has arrived, i.e. in front of its statistics rounds and three barriers: the sweep that follows is
+            // bound by its bodies, so a trip that is there when it starts moves the whole stage forward by one body
+            u32x4 pre_a = u32x4{0u, 0u, 0u, 0u}, pre_b = u32x4{0u, 0u, 0u, 0u};
+            int pre_i0 = -1;          // uniform; -1: nothing requested
 
             // ---- MONO, first stage without any selection.  One item per wave (the first NW items: the heaviest
             // segments).  Every wave finds, among the per-lane maxima of its single products, the m-th largest
@@ -710,6 +717,28 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                                 if ((S[f][j] >> lane) & 1ull) lmax = max(lmax, fkey(x[f][j]));
                             }
                         }
+                    }
+                    if (fs * NW < n_items) {      // (uniform) the next stage starts at item fs * NW if this one fits — the rule
+                        const int ip = fs * NW + wave;
+                        const int4 d = items[(ip < n_items) ? ip : n_items];       // (beyond the end: the sentinel, nothing is fetched)
+                        int vo, so = 0;
+                        if (two_piece) {
+                            int4 b4 = make_int4(0, 0, 0, 64);
+                            const int bix = (int)((unsigned)__builtin_amdgcn_readfirstlane(d.w) >> ITEM_W_BITS);
+                            if (bix) b4 = items[bix];
+                            int dq_;
+                            float sv_;
+                            trip_lane(__builtin_amdgcn_readfirstlane(d.x), __builtin_amdgcn_readfirstlane(d.y), (unsigned)__builtin_amdgcn_readfirstlane(d.z),
+                                      __builtin_amdgcn_readfirstlane(b4.x), __builtin_amdgcn_readfirstlane(b4.y), (unsigned)__builtin_amdgcn_readfirstlane(b4.z),
+                                      __builtin_amdgcn_readfirstlane(b4.w), vo, dq_, sv_);
+                        } else {
+                            so = __builtin_amdgcn_readfirstlane(d.x);
+                            vo = (__builtin_amdgcn_readfirstlane(d.y) - 4 * lane > 0) ? lane * 16 : (int)(OOB_SOFFSET - (unsigned)so);
+                        }
+                        pre_a = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, vo, so, 0);
+                        pre_b = __builtin_amdgcn_raw_buffer_load_b128(rs_val, vo, so, 0);
+                        pre_i0 = fs * NW;
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                     // m-th largest (distinct) lane maximum of this wave — fewer rounds for a wave with fewer candidate lanes
                     // (a partial item), so that its looser statistics do not drag the common cutoff down; whether k
@@ -826,7 +855,8 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                         }
                     }
                     // cnt: elements of piece A (0: the sentinel; ITEM: the trip is full, no masks); dq: real elements of this lane's quad
-                    auto ld = [&](int trip, unsigned (&c)[4], float (&v)[4], int &cnt, int &dq, float &segv) __attribute__((always_inline)) {
+                    // (pre: the trip's data was requested during the first stage)
+                    auto ld = [&](int trip, unsigned (&c)[4], float (&v)[4], int &cnt, int &dq, float &segv, bool pre = false) __attribute__((always_inline)) {
                         const int tl = min(trip, 63);
                         cnt = __builtin_amdgcn_readlane(myd.y, tl);
                         int vo;
@@ -843,8 +873,11 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                             segv = __uint_as_float((unsigned)__builtin_amdgcn_readlane(myd.z, tl));
                             vo = (dq > 0) ? lane * 16 : (int)(OOB_SOFFSET - (unsigned)so);
                         }
-                        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, vo, so, 0);
-                        const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs_val, vo, so, 0);
+                        u32x4 a = pre_a, b = pre_b;
+                        if (!pre) {
+                            a = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, vo, so, 0);
+                            b = __builtin_amdgcn_raw_buffer_load_b128(rs_val, vo, so, 0);
+                        }
                         c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w;
                         v[0] = __uint_as_float(b.x); v[1] = __uint_as_float(b.y); v[2] = __uint_as_float(b.z); v[3] = __uint_as_float(b.w);
                     };
@@ -950,7 +983,12 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     float sA = 0.f, sB = 0.f;
                     const int n_trips = (i1 - i0 - wave + NW - 1) / NW;
                     int trip = 0;
-                    ld(0, cA, vA, nA, qA, sA);
+                    {
+                        // (the wave's first item of this stage is the one requested during the first stage: same i0, and the stage is long enough)
+                        const bool use_pre = MONO && pre_i0 == i0 && i0 + wave < i1;      // uniform
+                        pre_i0 = -1;
+                        ld(0, cA, vA, nA, qA, sA, use_pre);
+                    }
                     while (trip < n_trips) {      // two items (4 KiB) in flight per wave; bodies skip the sentinel
                         ld(trip + 1, cB, vB, nB, qB, sB);
                         __builtin_amdgcn_sched_barrier(0);     // the prefetch is issued before the current item is waited for
@@ -1195,12 +1233,12 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             // issued: across the loop's back edge the compiler cannot count what was issued since and waits with vmcnt(0) at the
             // first use in the next row, i.e. for that row's fresh loads (the item records' copy into LDS and the queue slot's store
             // waited ~2 k cycles) or, consumed at the very end of this row, for its result stores.
-            asm volatile("" : "+v"(recN), "+v"(nx_v), "+v"(pend_q), "+v"(nx_r0), "+v"(nx_r1), "+v"(dNN), "+v"(wNN));
+            asm volatile("" : "+v"(recN), "+v"(nx_v), "+v"(pend_q), "+v"(nx_r0), "+v"(nx_r1), "+v"(dNN));
             if constexpr (REC2) asm volatile("" : "+v"(recN2));
-            dR = make_int4(__builtin_amdgcn_readfirstlane((int)dNN.x), __builtin_amdgcn_readfirstlane((int)dNN.y),
-                           __builtin_amdgcn_readfirstlane((int)dNN.z), __builtin_amdgcn_readfirstlane((int)dNN.w));
-            wR = make_int4(__builtin_amdgcn_readfirstlane((int)wNN.x), __builtin_amdgcn_readfirstlane((int)wNN.y),
-                           __builtin_amdgcn_readfirstlane((int)wNN.z), __builtin_amdgcn_readfirstlane((int)wNN.w));
+            dR = make_int4(__builtin_amdgcn_readlane((int)dNN, 0), __builtin_amdgcn_readlane((int)dNN, 1),
+                           __builtin_amdgcn_readlane((int)dNN, 2), __builtin_amdgcn_readlane((int)dNN, 3));
+            wR = make_int4(__builtin_amdgcn_readlane((int)dNN, 4), __builtin_amdgcn_readlane((int)dNN, 5),
+                           __builtin_amdgcn_readlane((int)dNN, 6), __builtin_amdgcn_readlane((int)dNN, 7));
             const int n_sel = min(sh[SH_CNT], p.k);
             const long long o = (long long)slot_i * (long long)p.k;
             int n_out = n_sel;
@@ -1266,12 +1304,12 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             // a pool or the collision set overflowed (or the row has too many items): hand the row to the generic
             // kernel's queue and put the LDS state back to clean
             // (this path's copy of the consumption above: on every path in front of the path's own stores)
-            asm volatile("" : "+v"(recN), "+v"(nx_v), "+v"(pend_q), "+v"(nx_r0), "+v"(nx_r1), "+v"(dNN), "+v"(wNN));
+            asm volatile("" : "+v"(recN), "+v"(nx_v), "+v"(pend_q), "+v"(nx_r0), "+v"(nx_r1), "+v"(dNN));
             if constexpr (REC2) asm volatile("" : "+v"(recN2));
-            dR = make_int4(__builtin_amdgcn_readfirstlane((int)dNN.x), __builtin_amdgcn_readfirstlane((int)dNN.y),
-                           __builtin_amdgcn_readfirstlane((int)dNN.z), __builtin_amdgcn_readfirstlane((int)dNN.w));
-            wR = make_int4(__builtin_amdgcn_readfirstlane((int)wNN.x), __builtin_amdgcn_readfirstlane((int)wNN.y),
-                           __builtin_amdgcn_readfirstlane((int)wNN.z), __builtin_amdgcn_readfirstlane((int)wNN.w));
+            dR = make_int4(__builtin_amdgcn_readlane((int)dNN, 0), __builtin_amdgcn_readlane((int)dNN, 1),
+                           __builtin_amdgcn_readlane((int)dNN, 2), __builtin_amdgcn_readlane((int)dNN, 3));
+            wR = make_int4(__builtin_amdgcn_readlane((int)dNN, 4), __builtin_amdgcn_readlane((int)dNN, 5),
+                           __builtin_amdgcn_readlane((int)dNN, 6), __builtin_amdgcn_readlane((int)dNN, 7));
             wg_sync<U_LDS>();
             if (tid == 0) {
                 const unsigned g = atomicAdd(&p.qcount[1], 1u);
