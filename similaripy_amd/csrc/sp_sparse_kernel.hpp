@@ -234,8 +234,18 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         int n_items = 0;
         unsigned dNN;         // descriptor two rows ahead, dword i in lane i
         int4 dR = make_int4(-1, 0, 0, 0), wR = make_int4(0, 0, 0, 0);      // ... and moved to scalar registers there, for the rotation
+        // a row with prepass records that fit: the records go to LDS right here, in front of the row's ONE setup barrier (the previous row
+        // is done with `items`; that barrier also publishes the queue slot and the counters reset above)
+        const bool precut_ok = n_pre > 0 && n_pre < ICAP && n_pre <= 63 * NW && n_rec <= ICAP;      // uniform
         if (n_pre > 0) {
-            // nothing to set up: the records are in registers (they go to LDS below); the row pipeline's descriptor load stays
+            if (precut_ok) {
+                // sentinel item behind the last one: a prefetch past the end loads nothing (every lane out of range)
+                // (the image holds the sentinel too: the same 16 bytes as this store)
+                if (tid == NT - 1) items[n_pre] = make_int4((int)OOB_SOFFSET, 0, 0, (int)macs32);
+                if (tid >= 1 && tid <= n_rec) ((u32x4 *)items)[tid - 1] = recC;
+                if (REC2 && tid + NT <= n_rec) ((u32x4 *)items)[tid + NT - 1] = recC2;
+                if (MONO && tid == 0) { shx[0] = (int)recC.x; shx[1] = (int)recC.y; }
+            }
             wg_sync<U_LDS>();
             if (!p.static_sched) q_nn = sh[SH_QA];
             load_desc_v(q_nn, tid & 63, dNN);
@@ -363,19 +373,16 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         for (int f = 0; f < FS1; ++f) { fsa[f] = u32x4{0u, 0u, 0u, 0u}; fsb[f] = u32x4{0u, 0u, 0u, 0u}; }
         bool fs_early = false;      // uniform
         if (!failed) {
-            // sentinel item behind the last one: a prefetch past the end loads nothing (every lane out of range)
-            if (tid == NT - 1) items[n_items] = make_int4((int)OOB_SOFFSET, 0, 0, (int)macs32);
-            if (n_pre > 0) {
-                // (the image holds the sentinel too: the same 16 bytes as the store above)
-                if (tid >= 1 && tid <= n_rec) ((u32x4 *)items)[tid - 1] = recC;
-                if (REC2 && tid + NT <= n_rec) ((u32x4 *)items)[tid + NT - 1] = recC2;
-                if (MONO && tid == 0) { shx[0] = (int)recC.x; shx[1] = (int)recC.y; }
-            } else if (tid < n1) {
-                int q = 0;
-                for (int o = 0; o < my_len; o += ITEM, ++q)
-                    items[my_ib + q] = make_int4((my_r0 + o) * 4, min(ITEM, my_len - o), (int)__float_as_uint(my_v), my_fs + o);
+            if (n_pre == 0) {      // (a row with prepass records that is not failed has them in LDS since its setup barrier)
+                // sentinel item behind the last one: a prefetch past the end loads nothing (every lane out of range)
+                if (tid == NT - 1) items[n_items] = make_int4((int)OOB_SOFFSET, 0, 0, (int)macs32);
+                if (tid < n1) {
+                    int q = 0;
+                    for (int o = 0; o < my_len; o += ITEM, ++q)
+                        items[my_ib + q] = make_int4((my_r0 + o) * 4, min(ITEM, my_len - o), (int)__float_as_uint(my_v), my_fs + o);
+                }
+                wg_sync<U_LDS>();
             }
-            wg_sync<U_LDS>();
             PHASE_END(PH_SEGMENTS);
             // MATRIX filter of the monotone variant (s_plus.h:159-171).  The row's excluded columns are (a) marked in the collision
             // bitmap, so all their products gather in the collision set, and (b) given a pseudo-member of value -inf each: the
@@ -1327,7 +1334,9 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         dN = dR; wN = wR;
         my_r0 = nx_r0; my_len = nx_r1 - nx_r0; my_v = nx_v;
         recC = recN; recC2 = recN2;
-        wg_sync<U_LDS>();
+        // (no barrier here: every path of the next row's setup has one in front of its first use of the storage cleared above, and its
+        // writes in front of that barrier — the counters of thread 0, the item records, the sort scratch — touch nothing this row's
+        // tail still reads: the last reads of sh[] lie in front of the "U read" barrier above)
         PHASE_END(PH_OUTPUT);
     }
     if (timing) {
