@@ -120,7 +120,8 @@ struct Config {
 constexpr size_t WS_QUEUE_BYTES = 256;
 constexpr size_t WS_PHASE_OFFSET = 64;
 constexpr size_t WS_YMIN_OFFSET = 176;
-static_assert(WS_PHASE_OFFSET + PH_N * 8 <= WS_YMIN_OFFSET && WS_YMIN_OFFSET + 16 <= WS_QUEUE_BYTES, "workspace header layout");
+constexpr size_t WS_FOLDZERO_OFFSET = 160;      // int: a stored entry of m2 met a zero column term while it was folded in
+static_assert(WS_PHASE_OFFSET + PH_N * 8 <= WS_FOLDZERO_OFFSET && WS_FOLDZERO_OFFSET + 4 <= WS_YMIN_OFFSET && WS_YMIN_OFFSET + 16 <= WS_QUEUE_BYTES, "workspace header layout");
 constexpr size_t LDS_LIMIT = 160 * 1024;
 constexpr int ITEMS_ROWS_MAX = 1 << 21;
 
@@ -386,9 +387,25 @@ int run_device_impl(sp_knn_args *a) {
     float4 *ypack = nullptr;
     if (c.fold) {
         folded = (float *)ws_fold;
+        // (a depopularisation weight can be exactly 0 on a column that has entries — a 'sum' weight of signed data — and the reference
+        // then reports value 0 for every column a product touches, s_plus.h:144-150: the folded stream cannot, see the kernel; the
+        // call is redone without folding.  One 4-byte read-back per rp3beta-type call; a cosine term is 0 for empty columns only)
+        const bool check_zero = a->l3 != 0.f;
         hipLaunchKernelGGL(sp_fold_colterm_kernel, dim3(256 * 8), dim3(256), 0, stream, (long long)a->nnz_m2, a->m2_indices,
-                           a->m2_data, a->l2 != 0.f ? a->Ycosine : a->Ydepop, folded);
+                           a->m2_data, a->l2 != 0.f ? a->Ycosine : a->Ydepop, folded, check_zero ? (int *)(ws + WS_FOLDZERO_OFFSET) : (int *)nullptr);
         HIP_TRY(hipGetLastError());
+        if (check_zero) {
+            int zero_term = 0;
+            HIP_TRY(hipMemcpyAsync(&zero_term, ws + WS_FOLDZERO_OFFSET, sizeof(int), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (zero_term) {
+                const uint32_t flags0 = a->flags;
+                a->flags |= SP_FLAG_NO_FOLD;
+                const int rc2 = run_device_impl(a);
+                a->flags = flags0;
+                return rc2;
+            }
+        }
     } else if (c.pack) {
         ypack = (float4 *)ws_fold;
         hipLaunchKernelGGL(sp_pack_colterms_kernel, dim3(std::min(2048, (a->n_output_cols + 255) / 256)), dim3(256), 0, stream, a->n_output_cols,

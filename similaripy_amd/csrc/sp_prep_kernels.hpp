@@ -412,13 +412,21 @@ __global__ __launch_bounds__(256) void sp_any_negative_kernel(long long nnz, con
 
 // Fold the column term of a product-form epilogue into the m2 stream:  out[i] = data[i] / Y[indices[i]]
 // (0 where Y is 0: the reference returns 0 for a zero denominator, s_plus.h:147-150).  One streaming pass.
+// *zero_term (optional) is raised when a STORED entry meets a zero column term: the reference then reports the column with value 0
+// (the column is a candidate as soon as one product touches it), the folded stream would lose it (all its products become 0, the
+// column looks untouched) — the caller redoes the call without folding.  Only the depopularisation term can do that (a 'sum'
+// weight of signed data that cancels to exactly 0); a cosine term is 0 for empty columns only.
 __global__ __launch_bounds__(256) void sp_fold_colterm_kernel(long long nnz, const int *__restrict__ indices,
                                                                const float *__restrict__ data, const float *__restrict__ Y,
-                                                               float *__restrict__ out) {
+                                                               float *__restrict__ out, int *__restrict__ zero_term) {
+    bool bad = false;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nnz; i += (long long)gridDim.x * blockDim.x) {
         const float y = Y[indices[i]];
-        out[i] = (y != 0.f) ? data[i] / y : 0.f;
+        const float d = data[i];
+        out[i] = (y != 0.f) ? d / y : 0.f;
+        bad |= (y == 0.f) && (d != 0.f);
     }
+    if (zero_term != nullptr && bad) *zero_term = 1;
 }
 
 // Boundaries of the generic kernel's standard dense windows [j*width, (j+1)*width) inside every (sorted) m2 row:

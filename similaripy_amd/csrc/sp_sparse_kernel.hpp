@@ -226,7 +226,9 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         // (sp_row_items_kernel's `pack`): the per-lane bookkeeping costs the 1024-thread shape 2.4 % on C2 rows it never packs
         const bool two_piece = PACK_OK && n_pre > 0 && n_rec > n_pre + 1;
 
-        if (tid == 0) { sh[SH_PCTR] = 0; sh[SH_MCTR] = 0; sh[SH_NITEMS] = 0; sh[SH_CNT] = 0; sh[SH_SEL] = -1; sh[SH_NEED] = 0; }
+        // (MONO: SH_PCTR is the write-out's compaction counter — zero whenever a row reaches its write-out, reset behind every stage's
+        // drain — and must not be touched here: the previous row's threads may still be reading it, there is no barrier in between)
+        if (tid == 0) { if (!MONO) sh[SH_PCTR] = 0; sh[SH_MCTR] = 0; sh[SH_NITEMS] = 0; sh[SH_CNT] = 0; sh[SH_SEL] = -1; sh[SH_NEED] = 0; }
         // Segment order.  The heaviest segments (largest |m1 value|: each segment scales its m2 row by its own m1 value)
         // go first, so that the first stage of sweep 2 sees the large products and the running k-th value — the cutoff
         // of everything after — starts high.
@@ -1252,11 +1254,16 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             if constexpr (MONO) {
                 // epilogue on the winners (s_plus.h:129-156 with the column term already folded in: val = xy / den, or
                 // the raw dot), exact threshold test, compaction of what passes to the front of the slot
-                if (tid == 0) sh[SH_SEL] = 0;
-                wg_sync<U_LDS>();
-                for (int base = 0; base < n_sel; base += NT) {
+                // (compaction counter: SH_PCTR, which the monotone variant leaves at zero — no reset, no barrier in front of the loop.
+                // LDS U: every thread zeroes the entries it has read — U's storage is part of the next row's bitmap; every selection
+                // zeroes what lies behind the entries it keeps, so only the first k (+2) entries can be non-zero — no barrier between
+                // "U read" and "U cleared" either)
+                constexpr bool OWN_CLEAR = U_LDS;      // (cap <= SEL_E * NT there)
+                const int n_cl = OWN_CLEAR ? min(cap, p.k + 2) : n_sel;
+                for (int base = 0; base < n_cl; base += NT) {
                     const int j = base + tid;
                     const u64 it = (j < n_sel) ? U[j] : 0ull;
+                    if (OWN_CLEAR && j < n_cl) U[j] = 0ull;
                     const float xv = funkey((unsigned)(it >> 32));
                     float val = xv;
                     if (any_norm) val = (den != 0.f) ? xv / den : 0.f;
@@ -1264,7 +1271,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     const u64 m = __ballot(keep);
                     if (m) {
                         int wbase = 0;
-                        if (lane == 0) wbase = atomicAdd(&sh[SH_SEL], __popcll(m));
+                        if (lane == 0) wbase = atomicAdd(&sh[SH_PCTR], __popcll(m));
                         wbase = __builtin_amdgcn_readfirstlane(wbase);
                         if (keep) {
                             const long long q = o + wbase + mbcnt64(m);
@@ -1275,7 +1282,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     }
                 }
                 wg_sync<U_LDS>();
-                n_out = sh[SH_SEL];
+                n_out = sh[SH_PCTR];
                 for (int j = n_out + tid; j < p.k; j += NT) {
                     if (p.rows) p.rows[o + j] = 0;
                     p.cols[o + j] = 0;
@@ -1299,7 +1306,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             if (tid == 0 && p.counts) p.counts[slot_i] = n_out;
             // (MATRIX filter: every excluded column has a slot in the collision set — its pseudo-member — so the set's scan has
             // cleared its mark like any other column's)
-            if (U_LDS || MONO) {
+            if ((U_LDS || MONO) && !(MONO && U_LDS)) {      // (MONO with U in LDS: cleared in the loop above)
                 // U's storage is part of the next row's bitmap (LDS) / holes must read zero (MONO).  Every selection zeroes
                 // what lies behind the entries it keeps, so only the first k entries can be non-zero here.
                 wg_sync<U_LDS>();     // U read before it is cleared
@@ -1322,7 +1329,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 const unsigned g = atomicAdd(&p.qcount[1], 1u);
                 p.desc_g[2 * (size_t)g] = make_int4(dC.x, dC.y, dC.z, n1);      // (without the record counts)
                 p.desc_g[2 * (size_t)g + 1] = wC;
-                sh[SH_OVF] = 0; sh[SH_RETRY] = 0; sh[SH_CNT2] = 0; sh[SH_EQ] = 0;
+                sh[SH_OVF] = 0; sh[SH_RETRY] = 0; sh[SH_CNT2] = 0; sh[SH_EQ] = 0; sh[SH_PCTR] = 0;
             }
             for (int i = tid; i < (CBM_BYTES + PRE_BYTES + A_bytes) / 16; i += NT) ((int4 *)smem)[i] = make_int4(0, 0, 0, 0);
             for (int i = tid; i < 1024; i += NT) hist4[i] = 0;

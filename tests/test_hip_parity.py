@@ -399,6 +399,28 @@ def _f64_value_bounds(m, rows, kw):
     return v0, bound
 
 
+@pytest.mark.parametrize("shape,density,k", [((30000, 1500), 0.002, 200), ((600, 300), 0.05, 150)], ids=["sparse_kernel", "generic_kernel"])
+def test_zero_depop_weight_on_a_column_with_entries(shape, density, k):
+    """A 'sum' depopularisation weight of signed data can cancel to exactly 0 on a column that HAS entries.  The reference then
+    reports the column with value 0 whenever a product touches it (s_plus.h:112-150: candidate on first touch, zero denominator
+    -> 0).  A column term folded into the m2 stream would lose those columns (all their products become 0): the library sees
+    the zero term while folding and redoes the call without folding."""
+    rng = np.random.default_rng(7)
+    m = _rand(shape, density, 7).tolil()
+    zero_rows = rng.choice(shape[0], size=shape[0] // 10, replace=False)
+    for j in zero_rows:
+        cols = rng.choice(shape[1], size=4, replace=False)
+        m[j, :] = 0
+        m[j, cols[0]] = 0.5; m[j, cols[1]] = -0.5; m[j, cols[2]] = 0.25; m[j, cols[3]] = -0.25
+    m = m.tocsr().astype(np.float32); m.eliminate_zeros(); m.sort_indices()
+    targets = np.sort(rng.choice(shape[0], size=min(shape[0], 400), replace=False)).astype(np.int32)
+    call = _host.prepare(m, k=k, l3=1.0, weight_depop_matrix2="sum", p2=0.5, target_rows=targets)
+    assert (call.Ydepop == 0).sum() >= len(zero_rows) and not np.isnan(call.Ydepop).any()
+    want = so.canonical(*so.run_kernel(call, "port"), call.targets, call.k)
+    assert sum(int(((wv == 0) & np.isin(wc, zero_rows)).sum()) for wc, wv in want) > 0      # the case is not vacuous
+    _check(call, f"zero depop weight {shape}")
+
+
 @pytest.mark.parametrize("shape,density", [((40000, 2000), 0.005), ((1500, 2500), 0.04)], ids=["sparse_kernel", "generic_kernel"])
 def test_bayesian_shrink_with_negative_values(shape, density):
     """xy/(xy+b) is not monotone for a negative raw dot: xy in (-b, 0) gives large POSITIVE values, so no raw-dot cutoff may
