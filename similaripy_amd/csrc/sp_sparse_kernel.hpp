@@ -753,7 +753,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     // (a partial item), so that its looser statistics do not drag the common cutoff down; whether k
                     // products reach the cutoff is counted exactly below
                     // rounds in proportion to the wave's share of the stage's lanes (item lengths are in the descriptors:
-                    // no reduction needed), k + 2*NW ranks in total
+                    // no reduction needed), k ranks in total
                     int my_rounds;
                     {
                         int lw = 0;                                                            // lanes of the trips of wave `lane`
@@ -768,7 +768,10 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                         const int lanes_all = wave_incl_scan_dpp(lw);                          // lane 63: the sum
                         const int L = max(1, __builtin_amdgcn_readlane(lanes_all, 63));
                         const int mine = max(1, __builtin_amdgcn_readlane(lw, wave));
-                        my_rounds = max(1, min(MAXR + 8, ((p.k + 2 * NW) * mine + L - 1) / L));
+                        // (exactly k ranks, each wave's share rounded up: every rank beyond them loosens the cutoff — with k + 2*NW ranks a
+                        // C2 row spent 1.6 % more cycles on survivors and their selection; a wave with fewer candidate lanes than rounds only
+                        // makes the count below fall short, i.e. the stage falls back)
+                        my_rounds = max(1, min(MAXR + 8, (p.k * mine + L - 1) / L));
                     }
                     unsigned rest = lmax, tw = 0u;
                     for (int r = 0; r < my_rounds; ++r) {
