@@ -863,14 +863,21 @@ __device__ __forceinline__ void wg_sync() {
 // second digit: the entries whose first byte exceeds the hint's are only counted, the others of its byte go straight
 // into the second histogram — one radix pass (fill, two barriers, walk) less whenever the k-th largest shares the
 // hint's first byte, which is the rule (else: the regular four passes).
-template <int NT, bool ZERO_TAIL = false, int E = 4, bool LDSBAR = false>
+// CLEAN: the caller's kernel uses SH_CNT2 / SH_EQ / SH_NHI through this function only, which then leaves them at zero on its way
+// out instead of resetting them (+ a barrier) on its way in.
+template <int NT, bool ZERO_TAIL = false, int E = 4, bool LDSBAR = false, bool CLEAN = false>
 __device__ long long select_fast(u64 *U, int *hist4, int *sh, int k, bool exact, unsigned hint = 0u, int tid_in = -1) {
     // (tid_in: a caller that keeps its thread id opaque to stop address computations from being hoisted out of its row loop)
     const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x, lane = tid & 63;
     const int n = min(sh[SH_CNT], E * NT);
-    if (tid == 0) { sh[SH_CNT2] = 0; sh[SH_EQ] = 0; sh[SH_NHI] = 0; }   // (the generic path's selection leaves them dirty)
-    wg_sync<LDSBAR>();
-    if (n <= k) return -1;
+    if (!CLEAN) {
+        if (tid == 0) { sh[SH_CNT2] = 0; sh[SH_EQ] = 0; sh[SH_NHI] = 0; }   // (the generic path's selection leaves them dirty)
+        wg_sync<LDSBAR>();
+        if (n <= k) return -1;
+    } else if (n <= k) {      // (uniform; rare: callers ask for a selection when there is something to select)
+        wg_sync<LDSBAR>();    // nobody may append (and change SH_CNT) before everyone has read n
+        return -1;
+    }
     u64 e[E];
     unsigned key[E];
     bool has[E];
@@ -1015,7 +1022,10 @@ __device__ long long select_fast(u64 *U, int *hist4, int *sh, int k, bool exact,
         }
     }
     for (int i = tid; i < passes * 256; i += NT) hist4[i] = 0;
-    if (tid == 0) sh[SH_CNT] = sh[SH_CNT2];
+    if (tid == 0) {
+        sh[SH_CNT] = sh[SH_CNT2];
+        if (CLEAN) { sh[SH_CNT2] = 0; sh[SH_EQ] = 0; sh[SH_NHI] = 0; }
+    }
     wg_sync<LDSBAR>();
     return (long long)prefix;
 }

@@ -1204,7 +1204,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     force_sel = false;
                     if (want_sel) {
                         long long thr_new;
-                        if (cap <= SEL_E * NT) thr_new = select_fast<NT, true, SEL_E, U_LDS>(U, hist4, sh, p.k, last_stage && !retry, rc.have_thr ? rc.thr_key : 0u);
+                        if (cap <= SEL_E * NT) thr_new = select_fast<NT, true, SEL_E, U_LDS, true>(U, hist4, sh, p.k, last_stage && !retry, rc.have_thr ? rc.thr_key : 0u);
                         else {
                             thr_new = compact_topk<NT>(U, hist4, sh, p.k);
                             if constexpr (MONO) {     // block-wise reservations: nothing stale may stay behind the kept entries
