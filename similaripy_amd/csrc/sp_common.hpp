@@ -1022,11 +1022,12 @@ __device__ long long select_fast(u64 *U, int *hist4, int *sh, int k, bool exact,
         }
     }
     for (int i = tid; i < passes * 256; i += NT) hist4[i] = 0;
-    if (tid == 0) {
-        sh[SH_CNT] = sh[SH_CNT2];
-        if (CLEAN) { sh[SH_CNT2] = 0; sh[SH_EQ] = 0; sh[SH_NHI] = 0; }
-    }
+    if (tid == 0) sh[SH_CNT] = sh[SH_CNT2];
     wg_sync<LDSBAR>();
+    // (BEHIND the barrier: every thread reads SH_CNT2 above — zeroed in front of it, a slower wave saw 0 kept entries and wiped its
+    // share of the buffer; found by repeating a fuzz seed.  The next reader of the three counters is the next selection, at least one
+    // barrier of the caller away)
+    if (CLEAN && tid == 0) { sh[SH_CNT2] = 0; sh[SH_EQ] = 0; sh[SH_NHI] = 0; }
     return (long long)prefix;
 }
 

@@ -1346,7 +1346,9 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         recC = recN; recC2 = recN2;
         // (no barrier here: every path of the next row's setup has one in front of its first use of the storage cleared above, and its
         // writes in front of that barrier — the counters of thread 0, the item records, the sort scratch — touch nothing this row's
-        // tail still reads: the last reads of sh[] lie in front of the "U read" barrier above)
+        // tail still reads: the last reads of sh[] lie in front of a barrier of the write-out.  The one variant whose write-out has no
+        // barrier behind its read of SH_CNT — general epilogue, U in global memory — keeps this one)
+        if (!(U_LDS || MONO)) wg_sync<U_LDS>();
         PHASE_END(PH_OUTPUT);
     }
     if (timing) {
