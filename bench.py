@@ -2,8 +2,9 @@
 """Benchmark of the hot path: top-k sparse row similarity on MI355X.
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W
-  N == 1: this process.  N > 1: launched by torch.distributed.run, one rank per GPU (RCCL).
-  One JSON line on stdout from rank 0.
+  N == 1: this process.  N > 1: one rank per GPU over RCCL — launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the
+  environment), or, when `python bench.py --gpus N` is started plain, by this script itself (it re-executes under
+  torch.distributed.run on 127.0.0.1).  One JSON line on stdout from rank 0.
 
 Metric (BASELINE.json): similarity rows/s (+ achieved algorithmic HBM GB/s), cosine k=100 on CSR.
 Workload at N=1 = BASELINE.json configs[1] ("C2"): cosine, m1 = 1M x 100k fixed-degree 64 nnz/row
@@ -11,15 +12,20 @@ Workload at N=1 = BASELINE.json configs[1] ("C2"): cosine, m1 = 1M x 100k fixed-
 over all target rows with every operand already resident in HBM.
 --workload c1 | c3 | c4 | c5 time the other BASELINE configs the same way (not the headline line): c4 = rp3beta(alpha .8,
 beta .4) item-item on the MovieLens-32M-shaped URM, k = 200 (p3alpha timed beside it); c5 = dot_product(urm, W.T,
-filter_cols=urm), 1M users x 100k items per GPU, W = cosine top-100 of a 200k-user sample.
+filter_cols=urm), 1M users x 100k items per GPU, W = cosine top-100 of a 200k-user sample.  The default run (c2, N = 1)
+appends them as `other_workloads` {c3, c4, c5}: 3 steps each, behind the headline's timed region.
 
 N > 1 goes through the shipped multi-GPU driver, `similaripy_amd.distributed.ShardedDeviceProblem`: every rank builds
 the same problem, `partition_targets` cuts the target list into N contiguous work-balanced slices, each rank's slice is
-resident on its own GPU (m2 / Y* replicated), no collective during compute, and the step ends with the single RCCL
-gather of the (cols, values, counts) slabs on rank 0 — inside the timed region.
-  --scaling weak (default): m1 = the 1M x 100k matrix of C2 stacked N times (N*1M rows), m2 = the transpose of ONE copy:
-      N*1M output rows, exactly 1M per rank, every rank does the work of the N=1 run (at N=1 it IS the N=1 run).
-  --scaling strong: the 1M rows of C2, cut N ways.
+resident on its own GPU (m2 / Y* replicated), no collective during compute, and the (cols, values, counts) slabs are
+gathered on rank 0 over RCCL inside the timed region — split-phase: the rank's slice runs as `--phases`
+sub-launches and sub-slab j travels on a communication stream while sub-slice j + 1 computes (`gather_exposed_ms` = what
+of the gather the step still shows).  `world_size_seen` = dist.get_world_size(); `config.per_rank[*].device` = every rank's GPU.
+  --scaling strong (default, the headline): the 1M rows of C2, cut N ways — `value` at N over `value` at 1 is the speed-up.
+  --scaling weak: m1 = the 1M x 100k matrix of C2 stacked N times (N*1M rows), m2 = the transpose of ONE copy:
+      N*1M output rows, exactly 1M per rank.  Whichever is not the headline is reported in `other_scaling`.
+  --backend gloo: functional check of the N > 1 path on a box with fewer GPUs than ranks (ranks share devices, slabs go
+      through the host); never a performance number.
 
 Extra objects on the JSON line:
   roofline     — algorithmic bytes per launch (16*nnz1 + 8*MACs + 8*k per row) over the average
@@ -31,6 +37,9 @@ Extra objects on the JSON line:
                  runtime sees them) on a bounded sample of the same workload: warm-up + 3 rounds, mean +- std, for the
                  reference's default column blocking (block_size=0 -> 262144: the headline `value`) and for blocking off
                  (rank 0, N=1 only).
+  roofline.traffic — HBM-side bytes of one launch of the dominant kernel, measured BY THIS RUN: two child processes of the same
+                 resident problem under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (+ --kernel-trace only), corrected as
+                 MI355X_MICROARCH.md prescribes (KiB units; gfx950 FETCH_SIZE x2 for 16 B/lane streams); null when rocprofv3 is missing.
   end_to_end_s — wall clock of the public call `similaripy_amd.cosine(m, k=100, format_output="csr")` (the reference
                  harness's definition, benchmark.py:168-189), host preprocessing and output assembly included.
 """
@@ -81,13 +90,128 @@ def lib_source_sha() -> str:
     return h.hexdigest()[:16]
 
 
+def free_port() -> int:
+    import socket
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        return s_.getsockname()[1]
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with no rank environment: start the N ranks ourselves (one process per GPU, torch.distributed.run on
+    127.0.0.1) and pass their output through — rank 0 prints the JSON line."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), str(Path(__file__).resolve()), *sys.argv[1:]]
+    log(f"--gpus {args.gpus} without WORLD_SIZE: launching the ranks: {' '.join(cmd)}")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+class Workload:
+    """One BASELINE config as a benchable problem: make_call(reps) -> the prepared kernel call (reps > 1: the weak-scaling form)."""
+    name = sim_name = gen = ""
+    n_rows = n_cols = nnz_row = k = 0
+    baseline_config = 0
+    make_call = public_call = p3alpha_call = None
+    weak_ok = True
+
+    def text(self, reps: int) -> str:
+        return self._text + (self._weak_text.format(reps=reps, rows=self.n_rows * reps) if reps > 1 else "")
+
+
+def build_workload(name: str, args) -> Workload:
+    from similaripy_amd import _host
+    w = Workload()
+    w.name = name
+    if name in ("c1", "c2", "c3"):
+        if name in ("c2", "c3"):
+            n_rows, n_cols, nnz_row, k = 1_000_000, 100_000, 64, 100
+        else:  # c1: BASELINE configs[0], sps.random 10k x 20k d=0.01, k=50
+            n_rows, n_cols, nnz_row, k = 10_000, 20_000, 200, 50
+        n_rows, n_cols, nnz_row, k = args.rows or n_rows, args.cols or n_cols, args.nnz_row or nnz_row, args.k or k
+        kern_kw = dict(l2=1, c1=0.5, c2=0.5) if name != "c3" else dict(l1=0.5, l2=0.5, stabilized_shrink=10.0)
+        w.sim_name = "cosine" if name != "c3" else "s_plus(l1=.5,l2=.5,shrink=10)"
+        if name == "c1" and not (args.rows or args.cols or args.nnz_row):
+            m1 = c1_matrix()                                     # configs[0] exactly: sps.random
+            gen = "sps.random d=0.01"
+        else:
+            m1 = fixed_degree_csr(n_rows, n_cols, nnz_row, 12345)
+            gen = f"fixed-degree CSR nnz/row={nnz_row}"
+        # the same problem on every rank (seeded); weak scaling: the matrix stacked `world` times over one copy's transpose
+        m2 = m1.T.tocsr()
+        w.make_call = lambda r: _host.prepare(sp.vstack([m1] * r, format="csr") if r > 1 else m1, m2, k=k, **kern_kw)
+        w.baseline_config = {"c1": 0, "c2": 1, "c3": 2}[name]
+        w._text = f"{w.sim_name} on {gen} {n_rows}x{n_cols}, k={k}, m2=m1.T (BASELINE configs[{w.baseline_config}])"
+        w._weak_text = "; weak scaling: m1 = that matrix stacked {reps} times ({rows} rows, " + str(n_rows) + " per rank), m2 = one copy's transpose"
+        if name == "c3":
+            w.public_call = ("similaripy_amd.s_plus(m, l1=.5, l2=.5, shrink=10, k=%d, format_output='csr')" % k,
+                             lambda sim: sim.s_plus(m1, l1=0.5, l2=0.5, shrink=10, k=k, verbose=False, format_output="csr"))
+        else:
+            w.public_call = ("similaripy_amd.cosine(m, k=%d, format_output='csr')" % k, lambda sim: sim.cosine(m1, k=k, verbose=False, format_output="csr"))
+    elif name == "c4":
+        # BASELINE configs[3]: p3alpha + rp3beta, item-item on the MovieLens-32M URM (its seeded stand-in: no network), k = 200.
+        # The step is the rp3beta call (p3alpha's stream + the popularity term); p3alpha is timed beside it (config.p3alpha_ms).
+        from similaripy_amd.normalization import normalize
+        from similaripy_amd.workloads import movielens_like_urm
+        k, alpha, beta = args.k or 200, 0.8, 0.4
+        urm = movielens_like_urm()
+        m1 = urm.T.tocsr()
+        n_rows, n_cols, nnz_row = m1.shape[0], m1.shape[1], int(round(m1.nnz / m1.shape[0]))
+        pop_m2 = np.asarray(m1.T.sum(axis=0)).ravel()               # similarity.py:479 — BEFORE normalisation
+        a_ = normalize(m1, norm="l1", axis=1); a_.data = np.power(a_.data, np.float32(alpha))
+        b_ = normalize(m1.T.tocsr(), norm="l1", axis=1); b_.data = np.power(b_.data, np.float32(alpha))
+        w.sim_name = f"rp3beta(alpha={alpha}, beta={beta})"
+
+        def make_call(r):
+            if r > 1:
+                raise SystemExit("c4 has no weak-scaling form (one catalogue): use --scaling strong")
+            return _host.prepare(a_, b_, k=k, weight_depop_matrix2=pop_m2, p2=beta, l3=1)
+        w.make_call = make_call
+        w.weak_ok = False
+        w.p3alpha_call = lambda: _host.prepare(a_, b_, k=k)
+        w.baseline_config = 3
+        w._text = (f"{w.sim_name} item-item on the MovieLens-32M-shaped URM {urm.shape[0]}x{urm.shape[1]} nnz {urm.nnz} "
+                   f"(workloads.movielens_like_urm, seed 0), k={k} (BASELINE configs[3]; p3alpha timed beside it)")
+        w._weak_text = ""
+        w.public_call = (f"similaripy_amd.rp3beta(URM.T, alpha={alpha}, beta={beta}, k={k}, format_output='csr')",
+                         lambda sim: sim.rp3beta(m1, alpha=alpha, beta=beta, k=k, verbose=False, format_output="csr"))
+    else:
+        # BASELINE configs[4]: dot_product(urm, W.T, k=100, filter_cols=urm) — user scoring with the seen items excluded; one GPU's
+        # share of the 10M-user job: 1M users x 100k items, 64 per user; W = cosine top-100 item model of a 200k-user sample
+        import similaripy_amd as sim_pkg
+        n_rows, n_cols, nnz_row, k = args.rows or 1_000_000, args.cols or 100_000, args.nnz_row or 64, args.k or 100
+        urm = fixed_degree_csr(n_rows, n_cols, nnz_row, 12345)
+        W = sim_pkg.cosine(urm[: min(n_rows, 200_000)].T.tocsr(), k=100, verbose=False, format_output="csr")
+        Wt = W.T.tocsr()
+        w.sim_name = "dot_product(urm, W.T, filter_cols=urm)"
+
+        def make_call(r):
+            u = sp.vstack([urm] * r, format="csr") if r > 1 else urm
+            return _host.prepare(u, Wt, k=k, filter_cols=u)
+        w.make_call = make_call
+        w.baseline_config = 4
+        w._text = (f"{w.sim_name} on fixed-degree URM {n_rows}x{n_cols} nnz/row={nnz_row}, W = cosine top-100 of a 200k-user sample "
+                   f"(nnz {W.nnz}), k={k} (BASELINE configs[4], one GPU's share)")
+        w._weak_text = "; weak scaling: the URM stacked {reps} times"
+        w.public_call = (f"similaripy_amd.dot_product(urm, W.T, k={k}, filter_cols=urm, format_output='csr')",
+                         lambda sim: sim.dot_product(urm, Wt, k=k, filter_cols=urm, verbose=False, format_output="csr"))
+    w.n_rows, w.n_cols, w.nnz_row, w.k = n_rows, n_cols, nnz_row, k
+    return w
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c1", "c4", "c5"])
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="N > 1: strong (default, the headline: the N = 1 job cut N ways) or weak (the matrix stacked N times); the other one is reported in other_scaling")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: functional check of the N > 1 path on a box with fewer GPUs than ranks (ranks share devices, slabs gathered through the host)")
+    ap.add_argument("--phases", type=int, default=4, help="N > 1: sub-slices of the split-phase gather (1 = one launch, one gather)")
     ap.add_argument("--rows", type=int, default=0)
     ap.add_argument("--cols", type=int, default=0)
     ap.add_argument("--nnz-row", type=int, default=0)
@@ -102,8 +226,13 @@ def main():
     ap.add_argument("--dbg", type=int, default=0, help="kernel ablation bits (profiling only; results invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the c3 / c4 / c5 lines the default (c2, N = 1) run appends")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child passes behind roofline.traffic")
     ap.add_argument("--cpu-seconds", type=float, default=3.0, help="target wall time of ONE cpu_baseline round")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
     import torch
     import torch.distributed as dist
@@ -111,103 +240,29 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    n_dev = torch.cuda.device_count()
     if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl" and n_dev < world:
+            raise SystemExit(f"--gpus {world} under RCCL needs {world} GPUs, this box has {n_dev} "
+                             f"(functional check of the N > 1 path on fewer GPUs: --backend gloo)")
+        dev_index = local_rank % max(1, n_dev)
+        torch.cuda.set_device(dev_index)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo")
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
-    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    world_seen = dist.get_world_size() if world > 1 else 1
+    assert world_seen == world
 
-    from similaripy_amd import _abi, _host
+    from similaripy_amd import _abi
     from similaripy_amd.distributed import ShardedDeviceProblem
 
     _abi.require_device()
-
-    # ---------------- workload ----------------
-    t0 = time.perf_counter()
-    reps = world if args.scaling == "weak" else 1
-    extra_cfg = {}
-    public_call = None
-    if args.workload in ("c1", "c2", "c3"):
-        if args.workload in ("c2", "c3"):
-            n_rows, n_cols, nnz_row, k = 1_000_000, 100_000, 64, 100
-        else:  # c1: BASELINE configs[0], sps.random 10k x 20k d=0.01, k=50
-            n_rows, n_cols, nnz_row, k = 10_000, 20_000, 200, 50
-        n_rows = args.rows or n_rows
-        n_cols = args.cols or n_cols
-        nnz_row = args.nnz_row or nnz_row
-        k = args.k or k
-        kern_kw = dict(l2=1, c1=0.5, c2=0.5) if args.workload != "c3" else dict(l1=0.5, l2=0.5, stabilized_shrink=10.0)
-        sim_name = "cosine" if args.workload != "c3" else "s_plus(l1=.5,l2=.5,shrink=10)"
-        if args.workload == "c1" and not (args.rows or args.cols or args.nnz_row):
-            m1 = c1_matrix()                                     # configs[0] exactly: sps.random
-            gen = "sps.random d=0.01"
-        else:
-            m1 = fixed_degree_csr(n_rows, n_cols, nnz_row, 12345)
-            gen = f"fixed-degree CSR nnz/row={nnz_row}"
-        # the same problem on every rank (seeded); weak scaling: the matrix stacked `world` times over one copy's transpose
-        m2 = m1.T.tocsr()
-
-        def make_call(r):
-            return _host.prepare(sp.vstack([m1] * r, format="csr") if r > 1 else m1, m2, k=k, **kern_kw)
-        workload_txt = (f"{sim_name} on {gen} {n_rows}x{n_cols}, k={k}, m2=m1.T (BASELINE configs[{ {'c1': 0, 'c2': 1, 'c3': 2}[args.workload] }])"
-                        + (f"; weak scaling: m1 = that matrix stacked {reps} times ({n_rows * reps} rows, {n_rows} per rank), m2 = one copy's transpose" if reps > 1 else ""))
-        if args.workload == "c3":
-            public_call = ("similaripy_amd.s_plus(m, l1=.5, l2=.5, shrink=10, k=%d, format_output='csr')" % k,
-                           lambda sim: sim.s_plus(m1, l1=0.5, l2=0.5, shrink=10, k=k, verbose=False, format_output="csr"))
-        else:
-            public_call = ("similaripy_amd.cosine(m, k=%d, format_output='csr')" % k, lambda sim: sim.cosine(m1, k=k, verbose=False, format_output="csr"))
-    elif args.workload == "c4":
-        # BASELINE configs[3]: p3alpha + rp3beta, item-item on the MovieLens-32M URM (its seeded stand-in: no network), k = 200.
-        # The step is the rp3beta call (p3alpha's stream + the popularity term); p3alpha is timed beside it (config.p3alpha_ms).
-        from similaripy_amd.normalization import normalize
-        from similaripy_amd.workloads import movielens_like_urm
-        k, alpha, beta = args.k or 200, 0.8, 0.4
-        urm = movielens_like_urm()
-        m1 = urm.T.tocsr()
-        n_rows, n_cols, nnz_row = m1.shape[0], m1.shape[1], int(round(m1.nnz / m1.shape[0]))
-        pop_m2 = np.asarray(m1.T.sum(axis=0)).ravel()               # similarity.py:479 — BEFORE normalisation
-        a_ = normalize(m1, norm="l1", axis=1); a_.data = np.power(a_.data, np.float32(alpha))
-        b_ = normalize(m1.T.tocsr(), norm="l1", axis=1); b_.data = np.power(b_.data, np.float32(alpha))
-        sim_name = f"rp3beta(alpha={alpha}, beta={beta})"
-
-        def make_call(r):
-            if r > 1:
-                raise SystemExit("c4 has no weak-scaling form (one catalogue): use --scaling strong")
-            return _host.prepare(a_, b_, k=k, weight_depop_matrix2=pop_m2, p2=beta, l3=1)
-        extra_cfg["_p3alpha_call"] = lambda: _host.prepare(a_, b_, k=k)
-        workload_txt = (f"{sim_name} item-item on the MovieLens-32M-shaped URM {urm.shape[0]}x{urm.shape[1]} nnz {urm.nnz} "
-                        f"(workloads.movielens_like_urm, seed 0), k={k} (BASELINE configs[3]; p3alpha timed beside it)")
-        public_call = (f"similaripy_amd.rp3beta(URM.T, alpha={alpha}, beta={beta}, k={k}, format_output='csr')",
-                       lambda sim: sim.rp3beta(m1, alpha=alpha, beta=beta, k=k, verbose=False, format_output="csr"))
-        if args.scaling == "weak" and world > 1:
-            raise SystemExit("c4 has no weak-scaling form (one catalogue): use --scaling strong")
-        reps = 1
-    else:
-        # BASELINE configs[4]: dot_product(urm, W.T, k=100, filter_cols=urm) — user scoring with the seen items excluded; one GPU's
-        # share of the 10M-user job: 1M users x 100k items, 64 per user; W = cosine top-100 item model of a 200k-user sample
-        import similaripy_amd as sim_pkg
-        n_rows, n_cols, nnz_row, k = args.rows or 1_000_000, args.cols or 100_000, args.nnz_row or 64, args.k or 100
-        urm = fixed_degree_csr(n_rows, n_cols, nnz_row, 12345)
-        W = sim_pkg.cosine(urm[: min(n_rows, 200_000)].T.tocsr(), k=100, verbose=False, format_output="csr")
-        Wt = W.T.tocsr()
-        sim_name = "dot_product(urm, W.T, filter_cols=urm)"
-
-        def make_call(r):
-            u = sp.vstack([urm] * r, format="csr") if r > 1 else urm
-            return _host.prepare(u, Wt, k=k, filter_cols=u)
-        workload_txt = (f"{sim_name} on fixed-degree URM {n_rows}x{n_cols} nnz/row={nnz_row}, W = cosine top-100 of a 200k-user sample "
-                        f"(nnz {W.nnz}), k={k} (BASELINE configs[4], one GPU's share)"
-                        + (f"; weak scaling: the URM stacked {reps} times" if reps > 1 else ""))
-        public_call = (f"similaripy_amd.dot_product(urm, W.T, k={k}, filter_cols=urm, format_output='csr')",
-                       lambda sim: sim.dot_product(urm, Wt, k=k, filter_cols=urm, verbose=False, format_output="csr"))
-    call = make_call(reps)
-    t_prep = time.perf_counter() - t0
-    nbytes, macs = algorithmic_bytes(call)                   # over ALL target slots of the job
-    total_rows = call.n_targets
-    log(f"rank {rank}: {sim_name} {n_rows}x{n_cols} nnz/row~{nnz_row} k={k}, {total_rows} target slots: "
-        f"MACs/row={macs / total_rows:.0f}, algorithmic {nbytes / 1e9:.1f} GB/step, host prep {t_prep:.1f}s")
 
     tuning = dict(table_slots=args.table_slots, threads_per_wg=args.threads, num_wgs=args.num_wgs, load_pct=args.load_pct, dbg=args.dbg,
                   no_sparse_path=args.no_sparse_path, no_fold=args.no_fold)
@@ -218,22 +273,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(x: float) -> float:
+        if world == 1:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
     def measure(the_call, steps, warmup, detail):
         """K timed steps of the sharded problem (barrier + synchronize on both sides, max over ranks), then the per-kernel
         and per-rank figures from K more passes outside the timed region."""
-        shard = ShardedDeviceProblem(the_call, device=dev)           # partition_targets + DeviceProblem of this rank's slice
+        shard = ShardedDeviceProblem(the_call, device=dev, phases=args.phases)      # partition_targets + DeviceProblem of this rank's slice
         ev_pairs = []
 
-        def step(timed: bool):
+        def step(timed: bool, gather: bool = True):
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record()                                    # torch's current stream == the launch stream
-            shard.run(gather=False, static_sched=args.static_sched, **tuning)
+            # N > 1: the sub-launches of the rank's slice, every sub-slab gathered to rank 0 (THE collective of the path) while
+            # the next one computes; the step ends when the last sub-slab has arrived
+            shard.run(gather=gather and world > 1, static_sched=args.static_sched, **tuning)
             e1.record()
             if timed:
                 ev_pairs.append((e0, e1))
-            if world > 1:                                  # the ONE collective of the path: slabs -> rank 0
-                shard.gather()
 
         for _ in range(warmup):
             step(False)
@@ -242,33 +304,30 @@ def main():
         for _ in range(steps):
             step(True)
         fence()
-        elapsed = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            elapsed = float(tt.item())
+        elapsed = max_over_ranks(time.perf_counter() - t0)
         res = {"elapsed": elapsed, "step_ms": [a.elapsed_time(b) for a, b in ev_pairs], "shard": shard}
         if not detail:
             return res
         # dominant kernel: hipEvents around its launch inside the library, K more passes of the same step (untimed region)
         infos = [shard.run(gather=False, time_kernel=True, static_sched=args.static_sched, phase_timers=False, **tuning) for _ in range(max(1, steps))]
         res["info"] = shard.run(gather=False, time_kernel=True, static_sched=args.static_sched, **tuning)     # one pass with the in-kernel phase timers
-        res["sparse_ms"] = float(np.mean([i["sparse_kernel_ms"] for i in infos]))
-        res["generic_ms"] = float(np.mean([i["generic_kernel_ms"] for i in infos]))
+        res["sparse_ms"] = float(np.mean([i.get("sparse_kernel_ms", 0.0) for i in infos]))
+        res["generic_ms"] = float(np.mean([i.get("generic_kernel_ms", 0.0) for i in infos]))
         res["call_ms"] = float(np.mean([i["kernel_ms"] for i in infos]))
-        gather_ms = 0.0
-        if world > 1:                                      # the gather alone, on the stream it runs on
-            g = []
-            for _ in range(max(1, steps)):
-                fence()
-                t1 = time.perf_counter()
-                shard.gather()
-                torch.cuda.synchronize()
-                g.append((time.perf_counter() - t1) * 1e3)
-            gather_ms = float(np.mean(g))
+        compute_only_ms = None
+        if world > 1:                                      # the same K steps without the gather: what of it the step exposes
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                step(False, gather=False)
+            fence()
+            compute_only_ms = max_over_ranks(time.perf_counter() - t1) / steps * 1e3
+            res["gather_exposed_ms"] = elapsed / steps * 1e3 - compute_only_ms
+            res["compute_only_ms_per_step"] = compute_only_ms
         local_bytes, local_macs = algorithmic_bytes(shard.prob.call)
-        mine = {"rank": rank, "rows": int(shard.n_loc), "macs": int(local_macs), "algorithmic_bytes": int(local_bytes), "call_ms": res["call_ms"],
-                "sparse_kernel_ms": res["sparse_ms"], "generic_kernel_ms": res["generic_ms"], "gather_ms": gather_ms}
+        mine = {"rank": rank, "device": f"cuda:{dev.index} {torch.cuda.get_device_name(dev)}", "rows": int(shard.n_loc), "macs": int(local_macs),
+                "algorithmic_bytes": int(local_bytes), "call_ms": res["call_ms"],
+                "sparse_kernel_ms": res["sparse_ms"], "generic_kernel_ms": res["generic_ms"], "step_ms_on_stream": float(np.mean(res["step_ms"]))}
         if world > 1:
             allr = [None] * world
             dist.all_gather_object(allr, mine)
@@ -278,99 +337,220 @@ def main():
         res["local_bytes"] = local_bytes
         return res
 
+    def line_of(wl, the_call, res, steps, with_phases: bool):
+        """The figures of one measured workload: throughput, the dominant kernel, its roofline."""
+        sparse_ms, generic_ms = res["sparse_ms"], res["generic_ms"]
+        dominant = "sp_knn_sparse_kernel" if sparse_ms >= generic_ms else "sp_knn_generic_kernel"
+        kern_s = max(sparse_ms, generic_ms) / 1e3
+        # (N > 1: rank 0's slice and rank 0's kernel time)
+        achieved = res["local_bytes"] / kern_s / 1e9 if kern_s > 0 else 0.0
+        d = {"value": the_call.n_targets * steps / res["elapsed"], "unit": "rows/s", "ms_per_step": res["elapsed"] / steps * 1e3,
+             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                          "kernel": dominant, "kernel_ms_avg": kern_s * 1e3, "algorithmic_bytes_per_launch": res["local_bytes"],
+                          "step_ms_avg_on_stream": float(np.mean(res["step_ms"])), "sparse_kernel_ms": sparse_ms, "generic_kernel_ms": generic_ms}}
+        if with_phases:
+            d["phase_share"] = phase_share(res["info"])
+        return d
+
+    # ---------------- workload ----------------
+    t0 = time.perf_counter()
+    wl = build_workload(args.workload, args)
+    if world > 1 and args.scaling == "weak" and not wl.weak_ok:
+        raise SystemExit(f"{args.workload} has no weak-scaling form: use --scaling strong")
+    reps = world if args.scaling == "weak" else 1
+    call = wl.make_call(reps)
+    t_prep = time.perf_counter() - t0
+    nbytes, macs = algorithmic_bytes(call)                   # over ALL target slots of the job
+    total_rows = call.n_targets
+    n_rows, n_cols, nnz_row, k = wl.n_rows, wl.n_cols, wl.nnz_row, wl.k
+    log(f"rank {rank}: {wl.sim_name} {n_rows}x{n_cols} nnz/row~{nnz_row} k={k}, {total_rows} target slots: "
+        f"MACs/row={macs / total_rows:.0f}, algorithmic {nbytes / 1e9:.1f} GB/step, host prep {t_prep:.1f}s")
+
     main_res = measure(call, args.steps, args.warmup, True)
     shard, info = main_res["shard"], main_res["info"]
-    elapsed, step_ms = main_res["elapsed"], main_res["step_ms"]
-    sparse_ms, generic_ms = main_res["sparse_ms"], main_res["generic_ms"]
-    dominant = "sp_knn_sparse_kernel" if sparse_ms >= generic_ms else "sp_knn_generic_kernel"
-    kern_avg_s = max(sparse_ms, generic_ms) / 1e3
-    n_kept = int(shard.pad_cnt.sum().item())
-    local_bytes = main_res["local_bytes"]
-    # the other scaling mode of the same workload, so that one multi-GPU run answers both questions: weak (per-GPU work fixed;
-    # the headline line keeps the contract's default) and strong (the N = 1 job cut N ways: what ">= 6x at 8 GPUs" is about)
+    elapsed = main_res["elapsed"]
+    n_kept = shard.kept_entries()
+    head = line_of(wl, call, main_res, args.steps, False)
+    # the other scaling mode of the same workload, so that one multi-GPU run answers both questions: strong (the N = 1 job cut N
+    # ways — the headline: what ">= 6x at 8 GPUs" is about) and weak (per-GPU work fixed)
     other = None
-    if world > 1 and args.workload in ("c1", "c2", "c3", "c5"):
+    if world > 1 and wl.weak_ok:
         other_mode = "strong" if args.scaling == "weak" else "weak"
         del shard
         main_res["shard"] = None
         torch.cuda.empty_cache()
-        oc = make_call(1 if other_mode == "strong" else world)
-        orows = oc.n_targets
+        oc = wl.make_call(1 if other_mode == "strong" else world)
         ores = measure(oc, args.steps, args.warmup, True)
-        other = {"scaling": other_mode, "value": orows * args.steps / ores["elapsed"], "unit": "rows/s", "ms_per_step": ores["elapsed"] / args.steps * 1e3,
-                 "target_slots": orows, "per_rank": ores["per_rank"]}
+        other = {"scaling": other_mode, "value": oc.n_targets * args.steps / ores["elapsed"], "unit": "rows/s", "ms_per_step": ores["elapsed"] / args.steps * 1e3,
+                 "target_slots": oc.n_targets, "gather_exposed_ms": ores.get("gather_exposed_ms"), "per_rank": ores["per_rank"]}
         ores["shard"] = None
         shard = None
+        del oc, ores
 
     if rank != 0:
+        dist.barrier()
         dist.destroy_process_group()
         return
 
-    value = total_rows * args.steps / elapsed
-    achieved = local_bytes / kern_avg_s / 1e9
-    traffic, traffic_source = None, None
-    tfile = ROOT / "profiles" / "hbm_traffic.json"
-    if tfile.exists():       # PMC passes cannot run inside this process: taken from the committed profile of THIS build only
-        try:
-            ent = json.loads(tfile.read_text()).get(f"{args.workload}:{n_rows}x{n_cols}x{nnz_row}:k{k}", {})
-            if ent.get("lib_source_sha") == lib_source_sha() and world == 1:
-                traffic = ent.get("bytes_per_launch")
-                traffic_source = (f"profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build (kernel sources sha "
-                                  f"{ent.get('lib_source_sha')}), not of this process")
-        except Exception:
-            traffic = None
-    par = f"row-sharded x{world} (distributed.partition_targets, contiguous cost-balanced slices)" + (", ONE gather of the packed slabs to rank 0 in the step" if world > 1 else "")
+    par = (f"row-sharded x{world} (distributed.partition_targets, contiguous cost-balanced slices)"
+           + (f", the packed slabs gathered to rank 0 inside the step in {shard_phases(args, world)} sub-slabs behind their sub-launches "
+              f"({args.backend}{' = RCCL over xGMI' if args.backend == 'nccl' else ', through the host: functional check only'})" if world > 1 else ""))
     out = {
-        "metric": "similarity rows/sec, cosine k=100 on CSR" if args.workload == "c2" else f"similarity rows/sec, {sim_name} k={k} on CSR",
-        "value": value,
+        "metric": "similarity rows/sec, cosine k=100 on CSR" if args.workload == "c2" else f"similarity rows/sec, {wl.sim_name} k={k} on CSR",
+        "value": head["value"],
         "unit": "rows/s",
         "n_gpus": world,
+        "world_size_seen": world_seen,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
+        "ms_per_step": head["ms_per_step"],
         "higher_is_better": True,
         "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": workload_txt,
+            "workload": wl.text(reps),
             "target_slots": total_rows, "rows_per_gpu": total_rows // world, "cols": n_cols, "nnz_per_row": nnz_row, "k": k,
             "macs_per_row": macs / total_rows,
-            "parallelism": par,
+            "parallelism": par, "backend": args.backend if world > 1 else None,
             "kept_entries_rank0": n_kept, "generic_windows_per_row": info["passes_total"] / max(1, main_res["per_rank"][0]["rows"]),
             "phase_share": phase_share(info),
             "per_rank": main_res["per_rank"],
         },
-        "roofline": {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
-            "kernel": dominant, "kernel_ms_avg": kern_avg_s * 1e3, "algorithmic_bytes_per_launch": local_bytes,
-            "step_ms_avg_on_stream": float(np.mean(step_ms)), "sparse_kernel_ms": sparse_ms, "generic_kernel_ms": generic_ms,
-        },
+        "roofline": dict(head["roofline"], traffic=None, traffic_source=None),
     }
+    if world > 1:
+        out["gather_exposed_ms"] = main_res.get("gather_exposed_ms")
+        out["compute_only_ms_per_step"] = main_res.get("compute_only_ms_per_step")
     if other is not None:
         out["other_scaling"] = other
-    if "_p3alpha_call" in extra_cfg:
-        pres = measure(extra_cfg["_p3alpha_call"](), max(1, args.steps), 1, False)
+    if wl.p3alpha_call is not None and world == 1:
+        pres = measure(wl.p3alpha_call(), max(1, args.steps), 1, False)
         out["config"]["p3alpha_ms_per_step"] = pres["elapsed"] / max(1, args.steps) * 1e3
         pres["shard"] = None
+    if world == 1 and not args.no_traffic and not args.dbg:
+        main_res["shard"] = None
+        shard = None
+        torch.cuda.empty_cache()
+        try:
+            tr = measure_traffic(call, head["roofline"]["kernel"], tuning)
+        except Exception as exc:        # no rocprofv3 on the box, counters unavailable, ...: the bench line does not depend on it
+            tr = {"traffic": None, "traffic_source": f"not measured: {type(exc).__name__}: {str(exc)[:200]}"}
+        out["roofline"].update(tr)
     if world == 1 and not args.no_end_to_end:
         import similaripy_amd as sim
         sim.cosine(sp.csr_array(sp.random_array((2000, 500), density=0.02, format="csr", dtype=np.float32, random_state=np.random.default_rng(0))), k=10, verbose=False)   # (library / allocator warm-up)
         ts = []
         for _ in range(2):
             t0 = time.perf_counter()
-            res = public_call[1](sim)
+            res = wl.public_call[1](sim)
             ts.append(time.perf_counter() - t0)
         out["end_to_end_s"] = min(ts)
-        out["end_to_end"] = {"call": public_call[0], "seconds": ts, "rows_per_s": n_rows / min(ts), "out_nnz": int(res.nnz)}
+        out["end_to_end"] = {"call": wl.public_call[0], "seconds": ts, "rows_per_s": n_rows / min(ts), "out_nnz": int(res.nnz)}
         del res
+    if world == 1 and args.workload == "c2" and not args.no_other_workloads and not (args.rows or args.cols or args.nnz_row or args.k or args.dbg):
+        # the other BASELINE configs, driver-timed: 3 steps each behind the headline's timed region
+        main_res["shard"] = None
+        shard = None
+        others = {}
+        for name in ("c3", "c5", "c4"):
+            try:
+                torch.cuda.empty_cache()
+                t1 = time.perf_counter()
+                w2 = build_workload(name, args)
+                c2_ = w2.make_call(1)
+                r2 = measure(c2_, 3, 1, True)
+                d = line_of(w2, c2_, r2, 3, True)
+                d["workload"] = w2.text(1)
+                d["steps"], d["warmup"] = 3, 1
+                d["build_s"] = time.perf_counter() - t1
+                if w2.p3alpha_call is not None:
+                    r2["shard"] = None
+                    pres = measure(w2.p3alpha_call(), 3, 1, False)
+                    d["p3alpha_ms_per_step"] = pres["elapsed"] / 3 * 1e3
+                    pres["shard"] = None
+                others[name] = d
+                log(f"other workload {name}: {d['ms_per_step']:.2f} ms/step, {d['roofline']['kernel']} {d['roofline']['kernel_ms_avg']:.2f} ms, frac {d['roofline']['frac']:.3f}")
+                r2["shard"] = None
+                del w2, c2_, r2
+            except Exception as exc:
+                others[name] = {"error": f"{type(exc).__name__}: {str(exc)[:300]}"}
+        out["other_workloads"] = others
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(call, args.cpu_seconds)
     print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def shard_phases(args, world) -> int:
+    return max(1, args.phases) if world > 1 else 1
+
+
+_PMC_CHILD = r"""
+import json, sys, types
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import torch
+from similaripy_amd._host import KernelCall
+from similaripy_amd.device import DeviceProblem
+d = np.load(sys.argv[2])
+meta = json.loads(str(d["meta"]))
+call = KernelCall(**{k: d[k] for k in d.files if k != "meta"}, **meta["scalars"])
+torch.cuda.set_device(0)
+prob = DeviceProblem(call)
+cols, vals, counts, _ = prob.alloc_outputs()
+prob.run(cols, vals, counts, **meta["tuning"])
+torch.cuda.synchronize()
+"""
+
+
+def measure_traffic(call, kernel_name: str, tuning: dict) -> dict:
+    """HBM-side bytes of ONE launch of the dominant kernel on this box, this build, this workload: two child processes under
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes: the TCC counters do not fit one), each running one
+    step of the same resident problem.  Corrections as MI355X_MICROARCH.md's HBM section prescribes: the counters are in
+    KiB, and on gfx950 FETCH_SIZE reports half of a coalesced 16-byte-per-lane stream (this kernel's only streaming loads)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not rp:
+        raise RuntimeError("rocprofv3 not found")
+    names = ("targets", "m1_data", "m1_indices", "m1_indptr", "m2_data", "m2_indices", "m2_indptr",
+             "Xtversky", "Ytversky", "Xcosine", "Ycosine", "Xdepop", "Ydepop",
+             "filter_m_indptr", "filter_m_indices", "target_col_m_indptr", "target_col_m_indices")
+    scal = {n: getattr(call, n) for n in ("n_rows_m1", "n_rows_m2", "n_output_cols", "a1", "l1", "l2", "l3", "t1", "t2", "stabilized_shrink", "bayesian_shrink",
+                                          "threshold", "k", "filter_mode", "target_col_mode")}
+    vals = {}
+    t0 = time.perf_counter()
+    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
+        f = os.path.join(td, "call.npz")
+        np.savez(f, meta=json.dumps({"scalars": scal, "tuning": {k_: v for k_, v in tuning.items() if v}}), **{n: getattr(call, n) for n in names})
+        script = os.path.join(td, "pmc_child.py")
+        Path(script).write_text(_PMC_CHILD)
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            odir = os.path.join(td, "rp_" + counter)
+            cmd = [rp, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", odir, "-o", "pmc", "--", sys.executable, script, str(ROOT), f]
+            proc = subprocess.run(cmd, capture_output=True, text=True, cwd=td, env=dict(os.environ, TMPDIR=td), timeout=600)
+            files = glob.glob(os.path.join(odir, "**", "*counter_collection.csv"), recursive=True)
+            if proc.returncode != 0 or not files:
+                raise RuntimeError(f"rocprofv3 --pmc {counter} failed (rc {proc.returncode}): {proc.stderr[-300:]}")
+            rows = [r for r in csv.DictReader(open(files[0])) if r["Counter_Name"] == counter and kernel_name in r["Kernel_Name"]]
+            if not rows:
+                raise RuntimeError(f"no {counter} rows for {kernel_name}")
+            last = max(int(r["Dispatch_Id"]) for r in rows)
+            vals[counter] = sum(float(r["Counter_Value"]) for r in rows if int(r["Dispatch_Id"]) == last)
+    traffic = vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024
+    log(f"traffic: FETCH_SIZE {vals['FETCH_SIZE']:.0f} KiB, WRITE_SIZE {vals['WRITE_SIZE']:.0f} KiB -> {traffic / 1e9:.1f} GB per launch ({time.perf_counter() - t0:.0f}s)")
+    return {"traffic": traffic, "traffic_fetch_size_kib": vals["FETCH_SIZE"], "traffic_write_size_kib": vals["WRITE_SIZE"],
+            "traffic_source": "measured by this run: two child passes of the same resident problem under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE "
+                              "--kernel-trace, one launch each; traffic = FETCH_SIZE*1024*2 + WRITE_SIZE*1024 (KiB units; gfx950 reports half of a "
+                              "coalesced 16 B/lane stream, MI355X_MICROARCH.md HBM section)"}
 
 
 def phase_share(info) -> dict:

@@ -85,6 +85,15 @@ extern "C" {
                                      (_build_squared_norms s_plus_utils.pyx:169-201 as sp_csr_row_sqsums_f32 does, sp_prep.h;
                                      _build_cosine_normalization :204-228 with norm_c1 / norm_c2 / norm_add) */
 
+/* ABI 5 */
+#define SP_FLAG_REUSE_M2_PREP 16384u /* device mode with a caller workspace: the workspace still holds the per-call passes over m2 / Y* of an
+                                     earlier call (column term folded into the m2 values or the packed column terms and their minima, the
+                                     dense-window boundaries inside every m2 row, the sign flag) and they are not redone.  The caller vouches
+                                     that m2, the Y* vectors, every scalar parameter, k and the tuning fields are those of that call and that
+                                     nothing else wrote the workspace in between; only `targets` / n_targets and the outputs may differ (they
+                                     must not need a larger workspace than that call had).  This is how one step over a slice of target rows
+                                     is cut into sub-launches whose results travel while the next one computes (distributed.py). */
+
 typedef struct sp_knn_args {
     uint32_t struct_size;      /* = sizeof(sp_knn_args); checked */
     uint32_t flags;            /* SP_FLAG_* */
@@ -181,6 +190,17 @@ typedef struct sp_knn_args {
                                   With SP_FLAG_M2_IS_M1_T (host or device pointers): the rows of m1 with a 0 are skipped while m2 = m1^T
                                   is built.  With an explicit m2: host mode only (the uploaded copy is compacted; a device-resident m2
                                   belongs to the caller).  Not with SP_FLAG_P3_PREP / SP_FLAG_M1_IS_M2_T.  NULL: every column stays. */
+
+    /* ABI 5: several devices behind ONE host-mode call */
+    int32_t  n_devices;        /* host mode only.  0 or 1: the call runs on `device`.  N > 1: `targets` is cut into N contiguous slices of
+                                  equal cost (MACs(t) + a fixed toll per row: what the row kernels schedule on) and slice r runs on
+                                  device_ids[r] — one host thread per device, every device gets its own copy of the operands over its own
+                                  PCIe link (m2 / Y* replicated, as in the one-process-per-GPU layout), no exchange during compute, and
+                                  every device writes its slots straight into the caller's output arrays.  The row loop being sharded is
+                                  the reference's own parallel loop (s_plus.h:313, 337).  With SP_FLAG_CSR_OUT the targets must ascend
+                                  strictly (each device assembles the CSR rows of its slice; the pieces are joined on the host). */
+    int32_t  _pad3;
+    const int32_t *device_ids; /* [n_devices] distinct HIP ordinals; NULL = 0 .. n_devices-1 */
 } sp_knn_args;
 
 /* The hot path.  Replaces compute_similarities_parallel<int,float> (s_plus.h:265). */
@@ -205,7 +225,7 @@ const char *sp_last_error(void);
 int64_t sp_device_cache_trim(void);
 
 /* ABI version of this header. */
-#define SP_KNN_ABI_VERSION 4
+#define SP_KNN_ABI_VERSION 5
 int sp_abi_version(void);
 
 #ifdef __cplusplus

@@ -3,8 +3,9 @@ shapes that hit both row kernels, every epilogue family, shrinks, thresholds, si
 data), target rows, ARRAY / MATRIX selectors, explicit and implicit m2, small tiles (forces windows / give-ups).
 Tie-aware comparison as in tests/test_hip_parity.py (identical sets where untied, values within 1e-5 relative).
     python scripts/fuzz_parity.py --cases 300 --seed 1
-Test infrastructure: the oracle is only the checker here."""
-import argparse, sys, time, traceback
+As a library (tests/test_hip_stress.py):  run_seed(seed, cases) -> (stats, failures); the case sequence of a seed is the
+same either way.  Test infrastructure: the oracle is only the checker here."""
+import argparse, sys, time, traceback, types
 from pathlib import Path
 import numpy as np, scipy.sparse as sp
 ROOT = Path(__file__).resolve().parent.parent
@@ -12,16 +13,23 @@ sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 from oracle import splus_oracle as so
 from similaripy_amd import _host
 
-ap = argparse.ArgumentParser()
-ap.add_argument("--cases", type=int, default=200)
-ap.add_argument("--seed", type=int, default=1)
-ap.add_argument("--only", type=int, default=-1, help="run only this case of the seed's sequence (the others are generated and skipped)")
-ap.add_argument("--dump-slot", type=int, default=-1, help="with --only: print both sides of this slot")
-ap.add_argument("--tuning", default="", help="with --only: override the case's tuning, e.g. table_slots=2048,no_sparse_path=1")
-ap.add_argument("--dbg", type=int, default=0)
-ap.add_argument("--huge", action="store_true", help="add shapes with more than 2^18 output columns (changes the case sequence of a seed)")
-ap.add_argument("--max-macs", type=float, default=4e8, help="skip cases whose oracle run would take too long")
-a = ap.parse_args()
+
+
+def _parser():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=200)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--only", type=int, default=-1, help="run only this case of the seed's sequence (the others are generated and skipped)")
+    ap.add_argument("--dump-slot", type=int, default=-1, help="with --only: print both sides of this slot")
+    ap.add_argument("--tuning", default="", help="with --only: override the case's tuning, e.g. table_slots=2048,no_sparse_path=1")
+    ap.add_argument("--dbg", type=int, default=0)
+    ap.add_argument("--huge", action="store_true", help="add shapes with more than 2^18 output columns (changes the case sequence of a seed)")
+    ap.add_argument("--max-macs", type=float, default=4e8, help="skip cases whose oracle run would take too long")
+    return ap
+
+
+# the options and the generator of the running sweep (set by run_seed)
+a = _parser().parse_args([])
 rng = np.random.default_rng(a.seed)
 
 
@@ -187,17 +195,38 @@ def one_case(i):
     return "ok", desc
 
 
-t0 = time.time()
-stats = {"ok": 0, "skipped": 0, "failed": 0}
-for i in range(a.cases):
-    state = rng.bit_generator.state
-    try:
-        r, desc = one_case(i)
-        stats[r] += 1
-    except Exception as exc:      # keep going: report every failing case with what it takes to reproduce it
-        stats["failed"] += 1
-        print(f"FAILED case {i} (seed {a.seed}): {type(exc).__name__}: {str(exc)[:600]}", flush=True)
-        if not isinstance(exc, AssertionError):
-            traceback.print_exc()
-print(f"fuzz: {stats} in {time.time() - t0:.0f}s (seed {a.seed})")
-sys.exit(1 if stats["failed"] else 0)
+
+def run_seed(seed, cases, verbose=True, **opts):
+    """The first `cases` cases of `seed`'s sequence.  Returns (stats, [messages of the failed cases])."""
+    global a, rng
+    a = _parser().parse_args([])
+    a.seed, a.cases = int(seed), int(cases)
+    for k_, v_ in opts.items():
+        setattr(a, k_, v_)
+    rng = np.random.default_rng(a.seed)
+    stats = {"ok": 0, "skipped": 0, "failed": 0}
+    failures = []
+    for i in range(a.cases):
+        try:
+            r, desc = one_case(i)
+            stats[r] += 1
+        except Exception as exc:      # keep going: report every failing case with what it takes to reproduce it
+            stats["failed"] += 1
+            failures.append(f"case {i} (seed {a.seed}): {type(exc).__name__}: {str(exc)[:600]}")
+            if verbose:
+                print("FAILED " + failures[-1], flush=True)
+                if not isinstance(exc, AssertionError):
+                    traceback.print_exc()
+    return stats, failures
+
+
+def main():
+    o = _parser().parse_args()
+    t0 = time.time()
+    stats, _ = run_seed(o.seed, o.cases, only=o.only, dump_slot=o.dump_slot, tuning=o.tuning, dbg=o.dbg, huge=o.huge, max_macs=o.max_macs)
+    print(f"fuzz: {stats} in {time.time() - t0:.0f}s (seed {o.seed})")
+    sys.exit(1 if stats["failed"] else 0)
+
+
+if __name__ == "__main__":
+    main()

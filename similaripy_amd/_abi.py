@@ -28,6 +28,7 @@ SP_FLAG_P3_PREP = 1024
 SP_FLAG_DEPOP_ROWSUM = 2048
 SP_FLAG_M1_IS_M2_T = 4096
 SP_FLAG_NORMS_ON_DEVICE = 8192
+SP_FLAG_REUSE_M2_PREP = 16384
 SP_EZEROS = -6
 SP_EUNSORTED = -7
 SP_NORM_L1, SP_NORM_L2, SP_NORM_MAX, SP_NORM_TFIDF, SP_NORM_BM25PLUS = range(5)
@@ -108,6 +109,8 @@ class SpKnnArgs(C.Structure):
         ("explicit_zeros", C.c_int64),
         ("norm_c1", C.c_float), ("norm_c2", C.c_float), ("norm_add", C.c_float), ("_pad2", C.c_int32),
         ("col_keep", C.c_void_p),
+        ("n_devices", C.c_int32), ("_pad3", C.c_int32),
+        ("device_ids", C.c_void_p),
     ]
 
 

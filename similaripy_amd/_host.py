@@ -470,7 +470,10 @@ def prepare(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_mat
     if p3 and not on_dev:
         raise ValueError("p3_alpha needs the device-side transpose (matrix2=None, no array selectors)")
     dev_norms = on_dev and bool(norms_on_device) and (l1 != 0 or l2 != 0)
-    csc = (on_dev and bool(csc_direct) and not arr_sel and getattr(matrix1, "format", None) == "csc" and (dev_norms or (l1 == 0 and l2 == 0))
+    # (a 'sum' weight of matrix1 is its ROW sums in the reference's float32 reduceat order, s_plus_utils.pyx:128-158: that needs the
+    # CSR of matrix1 on the host, which the CSC route never builds)
+    w1_rowsum = l3 != 0 and isinstance(weight_depop_matrix1, str) and weight_depop_matrix1 == 'sum'
+    csc = (on_dev and bool(csc_direct) and not arr_sel and not w1_rowsum and getattr(matrix1, "format", None) == "csc" and (dev_norms or (l1 == 0 and l2 == 0))
            and matrix1.nnz <= np.iinfo(np.int32).max
            and not (check_zeros and matrix1.data.shape[0] and np.count_nonzero(matrix1.data) != matrix1.data.shape[0]))
     if csc:
@@ -580,13 +583,18 @@ def selected_device() -> int:
 def run_hip(call: KernelCall, device: Optional[int] = None, table_slots: int = 0, threads_per_wg: int = 0,
             num_wgs: int = 0, load_pct: int = 0, time_kernel: bool = False, static_sched: bool = False,
             no_sparse_path: bool = False, no_fold: bool = False, want_rows: bool = True,
-            check_zeros: bool = False, csr_out: bool = False, dbg: int = 0):
+            check_zeros: bool = False, csr_out: bool = False, dbg: int = 0, devices=None):
     """The `with nogil:` block of s_plus.pyx:359-384, on the GPU: host buffers in, host buffers out
     through the C ABI (include/sp_knn.h).  Returns rows, cols, values, counts[, info].
 
     check_zeros: SP_FLAG_CHECK_ZEROS — raises _abi.ExplicitZerosError when m1 / m2 hold stored zeros.
     csr_out: SP_FLAG_CSR_OUT — the CSR result is assembled on the device (any order of the targets, repeats included); returns
-    (indptr, indices, data) of the final matrix instead (views of the buffers the library filled)."""
+    (indptr, indices, data) of the final matrix instead (views of the buffers the library filled).
+    devices: a list of HIP ordinals — sp_knn_args.n_devices / device_ids (ABI 5): the library cuts the target list into
+    cost-balanced contiguous slices and runs slice r on devices[r], one host thread per device, inside this ONE call
+    (with csr_out the targets must ascend strictly)."""
+    if devices is not None and len(list(devices)) == 0:
+        raise ValueError("devices is empty")
     _abi.require_device()
     n, k = call.n_targets, call.k
     want_rows = want_rows and not csr_out
@@ -618,6 +626,11 @@ def run_hip(call: KernelCall, device: Optional[int] = None, table_slots: int = 0
         a.flags |= _abi.SP_FLAG_NORMS_ON_DEVICE
         a.norm_c1, a.norm_c2, a.norm_add = call.norms_on_device
     keep = []  # keep converted arrays alive across the call
+    if devices is not None:
+        dv = np.ascontiguousarray(np.asarray(list(devices), dtype=np.int32))
+        keep.append(dv)
+        a.n_devices, a.device_ids = int(dv.size), dv.ctypes.data
+        a.device = int(dv[0])
 
     def f32(x):
         x = _abi.as_f32(x); keep.append(x); return x.ctypes.data if x.size else None
@@ -704,16 +717,23 @@ _MULTI_GPU_ROUTE: list = []      # set by multi_gpu.similarity() around a wrappe
 
 
 def multi_gpu_route():
-    """(devices, chunk_rows) when the kernel stage is to be sharded over several GPUs (similaripy_amd.multi_gpu), else None:
-    an explicit multi_gpu.similarity(...) call, or SIMILARIPY_AMD_DEVICES=0,1,... in the environment."""
+    """(devices, chunk_rows, mode) when the kernel stage is to be sharded over several GPUs, else None: an explicit
+    multi_gpu.similarity(...) call, or SIMILARIPY_AMD_DEVICES=0,1,... in the environment.
+
+    mode "threads" (default): the library's own multi-device call (sp_knn_args.n_devices, ABI 5) — one process, one host thread
+    per device, nothing spawned, every device-side stage of the single-GPU path kept.  mode "processes" (chunk_rows given, or
+    SIMILARIPY_AMD_MULTI_GPU_MODE=processes): one worker process per GPU under torch.distributed, the slabs gathered over RCCL
+    (multi_gpu.run_call) — what streams a 10M-user job in chunks."""
     if _MULTI_GPU_ROUTE:
         r = _MULTI_GPU_ROUTE[-1]
-        return r.devices, r.chunk_rows
+        return r.devices, r.chunk_rows, r.mode
     from .multi_gpu import devices_from_env
     d = devices_from_env()
     if d:
         c = os.environ.get("SIMILARIPY_AMD_CHUNK_ROWS", "")
-        return d, (int(c) if c else None)
+        chunk = int(c) if c else None
+        mode = os.environ.get("SIMILARIPY_AMD_MULTI_GPU_MODE", "") or ("processes" if chunk else "threads")
+        return d, chunk, mode
     return None
 
 
@@ -730,6 +750,10 @@ def _s_plus_impl(matrix1, matrix2, weight_depop_matrix1, weight_depop_matrix2, p
             binary, target_rows, filter_cols, target_cols, verbose, format_output)
     p3kw = dict(p3_alpha=p3_alpha, p3_depop_beta=p3_depop_beta)
     route = multi_gpu_route()
+    devices = None
+    if route is not None and route[2] == "threads":
+        devices = list(range(route[0])) if isinstance(route[0], int) else [int(d) for d in route[0]]
+        route = None
     if route is not None:
         # several GPUs: the host stages once, here; the kernel stage in one worker process per GPU (multi_gpu.run_call)
         if p3_alpha is not None:
@@ -748,11 +772,13 @@ def _s_plus_impl(matrix1, matrix2, weight_depop_matrix1, weight_depop_matrix2, p
         # CSR results are assembled on the device whatever the order of target_rows (SP_FLAG_CSR_OUT: the stable counting sort of
         # coo_to_csr.h:28-71, repeats included)
         csr_out = format_output == 'csr' and call.n_targets > 0 and call.n_targets * call.k <= np.iinfo(np.int32).max
+        if csr_out and devices is not None and len(devices) > 1 and call.n_targets > 1 and not bool(np.all(call.targets[1:] > call.targets[:-1])):
+            csr_out = False          # (several devices assemble the CSR rows of their own slices: needs ascending targets; else the slots come back)
         _say(verbose, "Computing")
         try:
             # (the row id of every slot entry is known on the host: the library's helper threads write `rows` while the device works,
             # a third of the COO download is never made)
-            out = run_hip(call, want_rows=(format_output != 'csr'), check_zeros=not opts["check_zeros"], csr_out=csr_out)
+            out = run_hip(call, want_rows=(format_output != 'csr'), check_zeros=not opts["check_zeros"], csr_out=csr_out, devices=devices)
             break
         except _abi.ExplicitZerosError:
             if opts["check_zeros"]:

@@ -26,6 +26,7 @@
 #include <chrono>
 #include <map>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <type_traits>
 #include <vector>
@@ -123,6 +124,13 @@ constexpr size_t WS_YMIN_OFFSET = 176;
 constexpr size_t WS_FOLDZERO_OFFSET = 160;      // int: a stored entry of m2 met a zero column term while it was folded in
 static_assert(WS_PHASE_OFFSET + PH_N * 8 <= WS_FOLDZERO_OFFSET && WS_FOLDZERO_OFFSET + 4 <= WS_YMIN_OFFSET && WS_YMIN_OFFSET + 16 <= WS_QUEUE_BYTES, "workspace header layout");
 constexpr size_t LDS_LIMIT = 160 * 1024;
+
+// What the zero-term check of a folding call found, per caller workspace: a SP_FLAG_REUSE_M2_PREP call on the same workspace must take the
+// same route (folded or not) without a read-back of its own.
+std::mutex g_foldzero_mu;
+std::map<const void *, int> g_foldzero;
+void foldzero_store(const void *ws, int v) { std::lock_guard<std::mutex> lk(g_foldzero_mu); g_foldzero[ws] = v; }
+int foldzero_lookup(const void *ws) { std::lock_guard<std::mutex> lk(g_foldzero_mu); auto it = g_foldzero.find(ws); return it == g_foldzero.end() ? -1 : it->second; }
 constexpr int ITEMS_ROWS_MAX = 1 << 21;
 
 // LDS of the two kernels without the candidate buffer (see their carve-ups)
@@ -281,6 +289,9 @@ int validate(const sp_knn_args *a) {
     }
     if (a->filter_mode < 0 || a->filter_mode > 2 || a->target_col_mode < 0 || a->target_col_mode > 2)
         return fail(SP_EINVAL, "bad selector mode");
+    if (a->n_devices < 0 || a->n_devices > 64) return fail(SP_EINVAL, "n_devices must be in [0, 64] (got %d)", a->n_devices);
+    if ((a->flags & SP_FLAG_REUSE_M2_PREP) && (!a->on_device || !a->workspace))
+        return fail(SP_EINVAL, "SP_FLAG_REUSE_M2_PREP needs device mode and the caller workspace of the call whose passes are reused");
     return SP_OK;
 }
 
@@ -370,12 +381,31 @@ int run_device_impl(sp_knn_args *a) {
         HIP_TRY(hipEventRecord(ev0, stream));
     }
 
-    HIP_TRY(hipMemsetAsync(ws, 0, WS_QUEUE_BYTES, stream));
-    unsigned char *ws_gu = ws + WS_QUEUE_BYTES;
-    unsigned char *ws_fold = ws_gu + c.ws_gu_bytes;
-    unsigned char *ws_rows = ws_fold + c.ws_fold_bytes;
-    int *ws_split = (int *)(ws_rows + c.ws_rows_bytes);
-    unsigned char *ws_piece = (unsigned char *)ws_split + c.ws_split_bytes;
+    // SP_FLAG_REUSE_M2_PREP: an earlier call on this workspace left the per-call passes over m2 / Y* behind (folded values or packed
+    // column terms, their minima, the dense-window boundaries, the sign flag); only the per-target state is rebuilt
+    const bool reuse = (a->flags & SP_FLAG_REUSE_M2_PREP) != 0 && a->workspace != nullptr;
+    if (reuse && c.fold && a->l3 != 0.f) {
+        // the call whose passes are reused may have found a zero column term under a stored entry and gone on without folding
+        int z = foldzero_lookup(ws);
+        if (z < 0) {
+            HIP_TRY(hipMemcpyAsync(&z, ws + WS_FOLDZERO_OFFSET, sizeof(int), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+        }
+        if (z) {
+            const uint32_t flags0 = a->flags;
+            a->flags |= SP_FLAG_NO_FOLD;
+            const int rc2 = run_device_impl(a);
+            a->flags = flags0;
+            return rc2;
+        }
+    }
+    HIP_TRY(hipMemsetAsync(ws, 0, reuse ? WS_FOLDZERO_OFFSET : WS_QUEUE_BYTES, stream));
+    // header | blocks that depend on m2 and the parameters only (same offsets whatever the target list) | blocks sized by n_targets
+    unsigned char *ws_fold = ws + WS_QUEUE_BYTES;
+    int *ws_split = (int *)(ws_fold + c.ws_fold_bytes);
+    unsigned char *ws_gu = (unsigned char *)ws_split + c.ws_split_bytes;
+    unsigned char *ws_rows = ws_gu + c.ws_gu_bytes;
+    unsigned char *ws_piece = ws_rows + c.ws_rows_bytes;
     unsigned char *ws_items = ws_piece + c.ws_piece_bytes;
 
     // minima of the column-term vectors feed the gather-free upper bound (Epi::upper); it is sound only
@@ -390,14 +420,15 @@ int run_device_impl(sp_knn_args *a) {
         // (a depopularisation weight can be exactly 0 on a column that has entries — a 'sum' weight of signed data — and the reference
         // then reports value 0 for every column a product touches, s_plus.h:144-150: the folded stream cannot, see the kernel; the
         // call is redone without folding.  One 4-byte read-back per rp3beta-type call; a cosine term is 0 for empty columns only)
-        const bool check_zero = a->l3 != 0.f;
-        hipLaunchKernelGGL(sp_fold_colterm_kernel, dim3(256 * 8), dim3(256), 0, stream, (long long)a->nnz_m2, a->m2_indices,
+        const bool check_zero = a->l3 != 0.f && !reuse;
+        if (!reuse) hipLaunchKernelGGL(sp_fold_colterm_kernel, dim3(256 * 8), dim3(256), 0, stream, (long long)a->nnz_m2, a->m2_indices,
                            a->m2_data, a->l2 != 0.f ? a->Ycosine : a->Ydepop, folded, check_zero ? (int *)(ws + WS_FOLDZERO_OFFSET) : (int *)nullptr);
         HIP_TRY(hipGetLastError());
         if (check_zero) {
             int zero_term = 0;
             HIP_TRY(hipMemcpyAsync(&zero_term, ws + WS_FOLDZERO_OFFSET, sizeof(int), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
+            if (a->workspace) foldzero_store(ws, zero_term);
             if (zero_term) {
                 const uint32_t flags0 = a->flags;
                 a->flags |= SP_FLAG_NO_FOLD;
@@ -408,12 +439,12 @@ int run_device_impl(sp_knn_args *a) {
         }
     } else if (c.pack) {
         ypack = (float4 *)ws_fold;
-        hipLaunchKernelGGL(sp_pack_colterms_kernel, dim3(std::min(2048, (a->n_output_cols + 255) / 256)), dim3(256), 0, stream, a->n_output_cols,
+        if (!reuse) hipLaunchKernelGGL(sp_pack_colterms_kernel, dim3(std::min(2048, (a->n_output_cols + 255) / 256)), dim3(256), 0, stream, a->n_output_cols,
                            a->l1 != 0.f ? a->Ytversky : nullptr, a->l2 != 0.f ? a->Ycosine : nullptr,
                            a->l3 != 0.f ? a->Ydepop : nullptr, ypack);
         HIP_TRY(hipGetLastError());
     }
-    if (!c.fold && bound_ok && (a->l1 != 0.f || a->l2 != 0.f || a->l3 != 0.f)) {
+    if (!reuse && !c.fold && bound_ok && (a->l1 != 0.f || a->l2 != 0.f || a->l3 != 0.f)) {
         hipLaunchKernelGGL(sp_colterm_min_kernel, dim3(1), dim3(1024), 0, stream, a->n_output_cols,
                            a->l1 != 0.f ? a->Ytversky : nullptr, a->l2 != 0.f ? a->Ycosine : nullptr,
                            a->l3 != 0.f ? a->Ydepop : nullptr, ymin_dev);
@@ -422,7 +453,7 @@ int run_device_impl(sp_knn_args *a) {
 
     int *neg_flag = (int *)(ws + WS_YMIN_OFFSET + 12);      // (inside the zeroed header)
     const bool sign_matters = a->bayesian_shrink != 0.f || a->l1 * (1.f - a->t1 - a->t2) > 0.f;      // (see RowCtx::set_cut)
-    if (sign_matters) {
+    if (sign_matters && !reuse) {
         if (a->nnz_m1 > 0) hipLaunchKernelGGL(sp_any_negative_kernel, dim3(1024), dim3(256), 0, stream, (long long)a->nnz_m1, a->m1_data, neg_flag);
         if (a->nnz_m2 > 0) hipLaunchKernelGGL(sp_any_negative_kernel, dim3(1024), dim3(256), 0, stream, (long long)a->nnz_m2, a->m2_data, neg_flag);
         HIP_TRY(hipGetLastError());
@@ -517,7 +548,7 @@ int run_device_impl(sp_knn_args *a) {
     kp.split_w = c.split_w;
     if (c.n_splits) {
         const long long n = (long long)a->n_rows_m2 * c.n_splits;
-        hipLaunchKernelGGL(sp_m2_splits_kernel, dim3((unsigned)std::min<long long>(256 * 16, (n + 255) / 256)), dim3(256), 0, stream, a->n_rows_m2, a->m2_indptr,
+        if (!reuse) hipLaunchKernelGGL(sp_m2_splits_kernel, dim3((unsigned)std::min<long long>(256 * 16, (n + 255) / 256)), dim3(256), 0, stream, a->n_rows_m2, a->m2_indptr,
                            a->m2_indices, c.split_w, c.n_splits, ws_split);
         HIP_TRY(hipGetLastError());
         kp.splits = ws_split;
@@ -1128,6 +1159,184 @@ int run_host(sp_knn_args *a) {
     return SP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// ABI 5: one host-mode call over several devices (sp_knn_args::n_devices / device_ids)
+// ---------------------------------------------------------------------------------------------
+template <typename F>
+void parallel_ranges(size_t n, size_t min_chunk, F &&f) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t n_thr = std::max<size_t>(1, std::min<size_t>({(size_t)32, hw ? (size_t)hw : (size_t)1, (n + min_chunk - 1) / std::max<size_t>(1, min_chunk)}));
+    if (n_thr <= 1) { f((size_t)0, n); return; }
+    const size_t per = (n + n_thr - 1) / n_thr;
+    std::vector<std::thread> th;
+    for (size_t lo = 0; lo < n; lo += per) {
+        const size_t hi = std::min(n, lo + per);
+        try { th.emplace_back([&f, lo, hi]() { f(lo, hi); }); } catch (...) { f(lo, hi); }
+    }
+    for (auto &t : th) t.join();
+}
+
+// cost[i] of target slot i in MAC equivalents: MACs(targets[i]) + a fixed toll per row — the quantity the row kernels schedule on and
+// what the one-process-per-GPU driver balances (distributed.row_cost)
+constexpr double ROW_TOLL_MACS = 30000.0;
+int target_costs(const sp_knn_args *a, std::vector<double> *cost) {
+    const size_t nt = (size_t)a->n_targets;
+    cost->assign(nt, ROW_TOLL_MACS);
+    const bool m2t = (a->flags & SP_FLAG_M2_IS_M1_T) != 0, m1t = (a->flags & SP_FLAG_M1_IS_M2_T) != 0;
+    if (m1t) {
+        // m1 = m2^T does not exist on the host: MACs(t) = sum over the entries (u, t) of m2 of len(m2 row u), scattered by column
+        std::vector<double> macs((size_t)a->n_rows_m1, 0.0);
+        for (int u = 0; u < a->n_rows_m2; ++u) {
+            const int lo = std::max(0, a->m2_indptr[u]), hi = (int)std::min<int64_t>(a->nnz_m2, a->m2_indptr[u + 1]);
+            const double len = (double)std::max(0, hi - lo);
+            for (int p = lo; p < hi; ++p) {
+                const int t = a->m2_indices[p];
+                if (t >= 0 && t < a->n_rows_m1) macs[(size_t)t] += len;
+            }
+        }
+        for (size_t i = 0; i < nt; ++i) (*cost)[i] += macs[(size_t)a->targets[i]];
+        return SP_OK;
+    }
+    std::vector<int> len2((size_t)a->n_rows_m2, 0);
+    if (m2t) {
+        // m2 = m1^T does not exist on the host: the length of its row u is the number of m1 entries in column u
+        const size_t nnz = (size_t)a->nnz_m1;
+        std::vector<std::vector<int>> part;
+        std::mutex mu;
+        parallel_ranges(nnz, (size_t)1 << 22, [&](size_t lo, size_t hi) {
+            std::vector<int> loc((size_t)a->n_rows_m2, 0);
+            for (size_t p = lo; p < hi; ++p) {
+                const int u = a->m1_indices[p];
+                if (u >= 0 && u < a->n_rows_m2) ++loc[(size_t)u];
+            }
+            std::lock_guard<std::mutex> lk(mu);
+            part.push_back(std::move(loc));
+        });
+        for (auto &v : part) for (size_t u = 0; u < v.size(); ++u) len2[u] += v[u];
+    } else {
+        for (int u = 0; u < a->n_rows_m2; ++u) len2[(size_t)u] = a->m2_indptr[u + 1] - a->m2_indptr[u];
+    }
+    parallel_ranges(nt, (size_t)1 << 16, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            const int t = a->targets[i];
+            double m = 0.0;
+            // (the arrays are validated on the device later: a malformed row pointer must not take the host down here)
+            const int p_lo = std::max(0, a->m1_indptr[t]), p_hi = (int)std::min<int64_t>(a->nnz_m1, a->m1_indptr[t + 1]);
+            for (int p = p_lo; p < p_hi; ++p) {
+                const int u = a->m1_indices[p];
+                if (u >= 0 && u < a->n_rows_m2) m += (double)len2[(size_t)u];
+            }
+            (*cost)[i] += m;
+        }
+    });
+    return SP_OK;
+}
+
+int run_host_multi(sp_knn_args *a) {
+    const int nd = a->n_devices;
+    const size_t nt = (size_t)a->n_targets, k = (size_t)a->k;
+    const int ndev = sp_device_count();
+    std::vector<int> devs((size_t)nd);
+    for (int i = 0; i < nd; ++i) {
+        devs[(size_t)i] = a->device_ids ? a->device_ids[i] : i;
+        if (devs[(size_t)i] < 0 || devs[(size_t)i] >= ndev) return fail(SP_EINVAL, "device_ids[%d] = %d out of range (have %d)", i, devs[(size_t)i], ndev);
+        for (int j = 0; j < i; ++j)
+            if (devs[(size_t)j] == devs[(size_t)i]) return fail(SP_EINVAL, "device_ids holds device %d twice", devs[(size_t)i]);
+    }
+    for (size_t i = 0; i < nt; ++i)
+        if (a->targets[i] < 0 || a->targets[i] >= a->n_rows_m1)
+            return fail(SP_EINVAL, "targets[%zu]=%d out of range [0,%d)", i, a->targets[i], a->n_rows_m1);
+    const bool csr_out = (a->flags & SP_FLAG_CSR_OUT) != 0;
+    if (csr_out)
+        for (size_t i = 1; i < nt; ++i)
+            if (a->targets[i] <= a->targets[i - 1])
+                return fail(SP_EINVAL, "SP_FLAG_CSR_OUT over several devices needs strictly increasing targets (targets[%zu] = %d follows %d)", i, a->targets[i], a->targets[i - 1]);
+    // contiguous slices of equal cumulative cost (distributed.partition_targets)
+    std::vector<double> cost;
+    TRY(target_costs(a, &cost));
+    std::vector<size_t> bounds((size_t)nd + 1, 0);
+    {
+        double total = 0.0;
+        for (double c : cost) total += c;
+        double run = 0.0;
+        size_t i = 0;
+        for (int r = 1; r < nd; ++r) {
+            const double want = total * (double)r / (double)nd;
+            while (i < nt && run < want) run += cost[i++];
+            bounds[(size_t)r] = i;
+        }
+        bounds[(size_t)nd] = nt;
+    }
+    struct Part { sp_knn_args args; int rc = SP_OK; std::string err; std::vector<int32_t> indptr; };
+    std::vector<Part> parts((size_t)nd);
+    std::vector<std::thread> th;
+    for (int r = 0; r < nd; ++r) {
+        Part &P = parts[(size_t)r];
+        const size_t lo = bounds[(size_t)r], hi = bounds[(size_t)r + 1];
+        P.args = *a;
+        P.args.n_devices = 0; P.args.device_ids = nullptr;
+        P.args.device = devs[(size_t)r];
+        P.args.n_targets = (int32_t)(hi - lo);
+        P.args.targets = a->targets + lo;
+        if (a->rows) P.args.rows = a->rows + lo * k;
+        P.args.cols = a->cols + lo * k;
+        P.args.values = a->values + lo * k;
+        if (a->out_counts) P.args.out_counts = a->out_counts + lo;
+        if (csr_out) { P.indptr.assign((size_t)a->n_rows_m1 + 1, 0); P.args.csr_indptr = P.indptr.data(); P.args.csr_nnz = 0; }
+        if (hi == lo) continue;
+        th.emplace_back([&P]() {
+            P.rc = run_host(&P.args);
+            if (P.rc) P.err = g_err;            // (g_err is the worker thread's)
+        });
+    }
+    for (auto &t : th) t.join();
+    for (int r = 0; r < nd; ++r) {
+        Part &P = parts[(size_t)r];
+        if (P.rc) {
+            a->explicit_zeros = P.args.explicit_zeros;
+            return fail(P.rc, "device %d: %s", devs[(size_t)r], P.err.c_str());
+        }
+    }
+    a->kernel_ms = 0.f; a->passes_total = 0; a->num_wgs_used = 0; a->explicit_zeros = 0;
+    memset(a->phase_cycles, 0, sizeof(a->phase_cycles));
+    a->reserved[1] = a->reserved[2] = a->reserved[3] = 0;
+    for (int r = 0; r < nd; ++r) {
+        const Part &P = parts[(size_t)r];
+        if (bounds[(size_t)r + 1] == bounds[(size_t)r]) continue;
+        a->kernel_ms = std::max(a->kernel_ms, P.args.kernel_ms);                       // the devices run side by side
+        a->passes_total += P.args.passes_total;
+        a->num_wgs_used += P.args.num_wgs_used;
+        for (int i = 0; i < 12; ++i) a->phase_cycles[i] += P.args.phase_cycles[i];
+        for (int i = 1; i <= 3; ++i) a->reserved[i] = std::max(a->reserved[i], P.args.reserved[i]);
+    }
+    if (csr_out) {
+        // the targets ascend and the slices are contiguous: device r's entries follow device r-1's, and the row pointers add up
+        // (every piece's indptr counts that piece's entries in the rows below i)
+        int64_t total = 0;
+        for (int r = 0; r < nd; ++r) {
+            Part &P = parts[(size_t)r];
+            const size_t lo = bounds[(size_t)r], hi = bounds[(size_t)r + 1];
+            if (hi == lo) continue;
+            const int64_t n = P.args.csr_nnz;
+            if (n > 0 && (size_t)total != lo * k) {
+                memmove(a->cols + total, a->cols + lo * k, (size_t)n * sizeof(int32_t));
+                memmove(a->values + total, a->values + lo * k, (size_t)n * sizeof(float));
+            }
+            total += n;
+        }
+        if (total > 0x7FFFFFFFLL) return fail(SP_EINVAL, "SP_FLAG_CSR_OUT: %lld entries do not fit int32 row pointers", (long long)total);
+        parallel_ranges((size_t)a->n_rows_m1 + 1, (size_t)1 << 18, [&](size_t lo_, size_t hi_) {
+            for (size_t i = lo_; i < hi_; ++i) {
+                int32_t v = 0;
+                for (int r = 0; r < nd; ++r) if (!parts[(size_t)r].indptr.empty()) v += parts[(size_t)r].indptr[i];
+                a->csr_indptr[i] = v;
+            }
+        });
+        a->csr_nnz = total;
+    }
+    return SP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1417,6 +1626,19 @@ int sp_knn_f32_i32(sp_knn_args *a) {
     const int ndev = sp_device_count();
     if (ndev <= 0) return fail(SP_ENODEVICE, "no HIP device visible: similaripy_amd has no CPU fallback");
     if (a->device < 0 || a->device >= ndev) return fail(SP_EINVAL, "device %d out of range (have %d)", a->device, ndev);
+    if (a->n_devices > 1) {
+        if (a->on_device) return fail(SP_EINVAL, "n_devices > 1 is a host-mode option (device-resident operands live on ONE device)");
+        if (a->n_targets == 0) return SP_OK;
+        return run_host_multi(a);
+    }
+    if (a->n_devices == 1 && a->device_ids) {
+        if (a->device_ids[0] < 0 || a->device_ids[0] >= ndev) return fail(SP_EINVAL, "device_ids[0] = %d out of range (have %d)", a->device_ids[0], ndev);
+        const int32_t dev0 = a->device;
+        a->device = a->device_ids[0];
+        rc = a->on_device ? run_device(a) : run_host(a);
+        a->device = dev0;
+        return rc;
+    }
     return a->on_device ? run_device(a) : run_host(a);
 }
 

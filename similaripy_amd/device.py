@@ -117,12 +117,15 @@ class DeviceProblem:
             flags |= _abi.SP_FLAG_NO_FOLD
         if tuning.get("no_row_order"):
             flags |= _abi.SP_FLAG_NO_ROW_ORDER
+        if tuning.get("reuse_m2_prep") and self._ws is not None:
+            flags |= _abi.SP_FLAG_REUSE_M2_PREP
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream().cuda_stream
             a = self._args(targets_t, n, cols, vals, counts, rows, stream, flags, tuning)
             need = _abi.workspace_bytes(a)
             if self._ws is None or self._ws.numel() < need:
                 self._ws = torch.empty(max(need, 4096), dtype=torch.uint8, device=self.device)
+                a.flags &= ~_abi.SP_FLAG_REUSE_M2_PREP       # (a fresh workspace holds nothing to reuse)
             a.workspace, a.workspace_bytes = self._ws.data_ptr(), self._ws.numel()
             _abi.call_knn(a)
         return {"kernel_ms": float(a.kernel_ms), "passes_total": int(a.passes_total), "phase_cycles": [int(x) for x in a.phase_cycles], "num_wgs": int(a.num_wgs_used),

@@ -228,13 +228,21 @@ class ShardedDeviceProblem:
     """This rank's slice of a row-sharded problem, resident on its GPU.
 
     Every rank constructs it with the same `call`; the constructor partitions `call.targets` by work, uploads the
-    operands once (`DeviceProblem`: m2 / Y* replicated, m1 / X* / selectors whole) and allocates the padded output slabs
-    — on the root also the receive buffers.  `run()` = one step: the kernel over the rank's slice on torch's current
-    stream, then the one gather (device to device; RCCL over xGMI under the nccl backend).  `result()` on the root copies
-    the gathered slabs to the host in the slot order of `call.targets`.
+    operands once (`DeviceProblem`: m2 / Y* replicated, the rank's own rows of m1 / X* / selectors) and allocates the padded
+    output slab — on the root also the receive buffers.  `run()` = one step: the kernel over the rank's slice, then the
+    gather (device to device; RCCL over xGMI under the nccl backend).  `result()` on the root copies the gathered slabs to
+    the host in the slot order of `call.targets`.
+
+    Split-phase gather (`phases` > 1): the rank's slice is cut into `phases` sub-slices of equal row count; sub-slice j
+    is its own launch on the compute stream (the per-call passes over the replicated m2 run once per step: sub-launches
+    behind the first reuse them, SP_FLAG_REUSE_M2_PREP), and the moment it has finished its sub-slab — a contiguous
+    [cols | value bits | counts] block — is gathered on a communication stream while sub-slice j + 1 computes.  Only the
+    last sub-slab's transfer is exposed.  The step's ONE logical gather becomes `phases` messages of 1/phases
+    the size; there is still no exchange that compute waits for.
     """
 
-    def __init__(self, call: KernelCall, group=None, device=None, dst: int = 0, compact: bool = True, chunk_rows: Optional[int] = None):
+    def __init__(self, call: KernelCall, group=None, device=None, dst: int = 0, compact: bool = True, chunk_rows: Optional[int] = None,
+                 phases: int = 1):
         import torch
         import torch.distributed as dist
 
@@ -245,6 +253,8 @@ class ShardedDeviceProblem:
         self.world = dist.get_world_size(group) if self.distributed else 1
         self.rank = dist.get_rank(group) if self.distributed else 0
         self.device = torch.device("cuda", local_device()) if device is None else torch.device(device)
+        # gloo has no device-tensor gather: the slab goes through the host (CPU tests, and HIP kernels at world_size > 1 on ONE GPU)
+        self.host_gather = self.distributed and dist.get_backend(group) != "nccl"
         self.work = row_cost(call)
         k = call.k
         self.chunk_rows = None if not chunk_rows or chunk_rows >= call.n_targets else int(chunk_rows)
@@ -267,30 +277,100 @@ class ShardedDeviceProblem:
             self.bounds = None
             self.lo, self.hi, self.n_loc, self.n_max = 0, 0, 0, n_max
             self.prob = DeviceProblem(call, self.device)
-        # ONE slab per rank: the kernel writes its cols / values / counts straight into views of it, the gather moves it whole
-        self.slab = torch.zeros(slab_words(self.n_max, k), dtype=torch.int32, device=self.device)
-        self.pad_cols, self.pad_vals, self.pad_cnt = slab_views(self.slab, self.n_max, k)
+        # sub-slices of the split-phase gather: `phases` blocks of n_sub slots, the same on every rank (the last ones may be short or empty)
+        self.phases = max(1, min(int(phases), max(1, self.n_max))) if (self.world > 1 and self.chunk_rows is None) else 1
+        self.n_sub = -(-self.n_max // self.phases) if self.n_max else 0
+        self.n_pad = self.n_sub * self.phases                      # slots of the padded slab
+        # ONE slab per rank = `phases` sub-slabs: the kernel writes its cols / values / counts straight into views of them
+        self.slab = torch.zeros(slab_words(self.n_pad, k), dtype=torch.int32, device=self.device)
+        self.sub = [self.slab[j * slab_words(self.n_sub, k): (j + 1) * slab_words(self.n_sub, k)] for j in range(self.phases)]
+        self.sub_views = [slab_views(t, self.n_sub, k) for t in self.sub]
+        self.pad_cols, self.pad_vals, self.pad_cnt = self.sub_views[0] if self.phases == 1 else (None, None, None)
         self.recv = None
         if self.rank == dst and self.world > 1:
-            self.recv = [torch.empty_like(self.slab) for _ in range(self.world)]
+            rdev = torch.device("cpu") if self.host_gather else self.device
+            self.recv = [torch.empty(self.slab.numel(), dtype=torch.int32, device=rdev) for _ in range(self.world)]
+            w = slab_words(self.n_sub, k)
+            self._recv_sub = [[r[j * w: (j + 1) * w] for r in self.recv] for j in range(self.phases)]
+        self._host_slab = torch.empty(self.slab.numel(), dtype=torch.int32, pin_memory=True) if self.host_gather else None
+        self.comm_stream = torch.cuda.Stream(device=self.device) if (self.world > 1 and not self.host_gather) else None
+        self._pending = []
+        self.gather_exposed_ms = None
+
+    # ---- one step -----------------------------------------------------------------------------------------------------
+    def _sub_range(self, j: int):
+        a = min(self.n_loc, j * self.n_sub)
+        return a, min(self.n_loc, a + self.n_sub)
 
     def run(self, gather: bool = True, **kw):
-        """One step.  Returns the kernel's info dict (see DeviceProblem.run)."""
+        """One step.  Returns the kernel's info dict (see DeviceProblem.run); with `phases` > 1 the dict of the last
+        non-empty sub-launch, `kernel_ms` / per-kernel times summed over the sub-launches."""
+        import torch
+
         k = self.call.k
         info = {"kernel_ms": 0.0, "passes_total": 0}
-        if self.n_loc:
-            info = self.prob.run(self.pad_cols[: self.n_loc * k], self.pad_vals[: self.n_loc * k], self.pad_cnt[: self.n_loc], **kw)
+        if self.phases == 1:
+            if self.n_loc:
+                info = self.prob.run(self.pad_cols[: self.n_loc * k], self.pad_vals[: self.n_loc * k], self.pad_cnt[: self.n_loc], **kw)
+            if gather:
+                self.gather()
+            return info
+        tot = {}
+        first = True
+        for j in range(self.phases):
+            a, b = self._sub_range(j)
+            if b > a:
+                c, v, n = self.sub_views[j]
+                info = self.prob.run(c[: (b - a) * k], v[: (b - a) * k], n[: b - a], targets=self.prob.t["targets"][a:b],
+                                     reuse_m2_prep=not first, **kw)
+                first = False
+                for key in ("kernel_ms", "sparse_kernel_ms", "generic_kernel_ms", "passes_total"):
+                    tot[key] = tot.get(key, 0) + info.get(key, 0)
+            if gather:
+                self._gather_sub(j)
+        info = dict(info, **tot)
         if gather:
-            self.gather()
+            self._finish_gathers()
         return info
 
-    def gather(self):
-        """THE collective of the path: the slab of every rank to the root, ONE gather (device to device)."""
+    def _gather_sub(self, j: int):
+        """Sub-slab j to the root, behind the sub-launch that fills it and beside the ones that follow."""
+        import torch
         import torch.distributed as dist
 
         if self.world == 1:
             return
-        dist.gather(self.slab, self.recv if self.rank == self.dst else None, dst=self.dst, group=self.group)
+        if self.host_gather:
+            torch.cuda.synchronize(self.device)
+            w = self.sub[j].numel()
+            h = self._host_slab[j * w: (j + 1) * w]
+            h.copy_(self.sub[j])
+            dist.gather(h, self._recv_sub[j] if self.rank == self.dst else None, dst=self.dst, group=self.group)
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.comm_stream):
+            self.comm_stream.wait_event(ev)
+            wk = dist.gather(self.sub[j], self._recv_sub[j] if self.rank == self.dst else None, dst=self.dst, group=self.group, async_op=True)
+        self._pending.append(wk)
+
+    def _finish_gathers(self):
+        """The step ends when every sub-slab has arrived: the compute stream waits for the communication stream."""
+        import torch
+
+        for wk in self._pending:
+            wk.wait()                        # (stream-level wait under nccl: nothing blocks on the host)
+        self._pending = []
+        if self.comm_stream is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+
+    def gather(self):
+        """THE collective of the path: the slab of every rank to the root (device to device; `phases` messages when split)."""
+        if self.world == 1:
+            return
+        for j in range(self.phases):
+            self._gather_sub(j)
+        self._finish_gathers()
 
     # ---- streaming form: one resident problem, the target list in chunks (10M users x k do not fit host arrays at once) ----
     def chunks(self):
@@ -313,6 +393,19 @@ class ShardedDeviceProblem:
         self.gather()
         return info
 
+    def _slabs(self):
+        """Root: one (cols, values, counts)-layout slab per rank with the sub-slabs folded back into slot order."""
+        import torch
+
+        src = [self.slab] if self.world == 1 else self.recv
+        if self.phases == 1:
+            return src, self.n_sub
+        k, ns, out = self.call.k, self.n_sub, []
+        for t in src:
+            parts = [slab_views(t[j * slab_words(ns, k): (j + 1) * slab_words(ns, k)], ns, k) for j in range(self.phases)]
+            out.append(torch.cat([torch.cat([p[0] for p in parts]), torch.cat([p[1].view(torch.int32) for p in parts]), torch.cat([p[2] for p in parts])]))
+        return out, self.n_pad
+
     def chunk_result(self, lo: int, hi: int):
         """Root: (cols, values, counts) of target slots [lo, hi) as host arrays; None elsewhere."""
         import torch
@@ -325,7 +418,8 @@ class ShardedDeviceProblem:
             return cols, vals, cnt
         b = self._chunk_bounds[(lo, hi)] - lo
         sub = slice_call(self.call, lo, hi)
-        _, cols, vals, cnt = _assemble(sub, b, [self.slab] if self.world == 1 else self.recv, self.n_max)
+        slabs, n_pad = self._slabs()
+        _, cols, vals, cnt = _assemble(sub, b, slabs, n_pad)
         return cols, vals, cnt
 
     def result(self):
@@ -335,4 +429,9 @@ class ShardedDeviceProblem:
         torch.cuda.synchronize(self.device)
         if self.rank != self.dst:
             return None
-        return _assemble(self.call, self.bounds, [self.slab] if self.world == 1 else self.recv, self.n_max)
+        slabs, n_pad = self._slabs()
+        return _assemble(self.call, self.bounds, slabs, n_pad)
+
+    def kept_entries(self) -> int:
+        """Entries this rank's slice kept (sum of its slot counts)."""
+        return int(sum(int(v[2].sum().item()) for v in self.sub_views))

@@ -166,12 +166,20 @@ def run_call(call: KernelCall, devices: Union[int, Sequence[int]], format_output
     return _host.finish(call, rows, cols, vals, counts, format_output)
 
 
-def similarity(name: str, matrix1, matrix2=None, *, devices: Union[int, Sequence[int]], chunk_rows: Optional[int] = None, **kwargs):
-    """`similaripy_amd.<name>(matrix1, matrix2, **kwargs)` with the kernel stage sharded over `devices`."""
+def similarity(name: str, matrix1, matrix2=None, *, devices: Union[int, Sequence[int]], chunk_rows: Optional[int] = None,
+               mode: Optional[str] = None, **kwargs):
+    """`similaripy_amd.<name>(matrix1, matrix2, **kwargs)` with the kernel stage sharded over `devices`.
+
+    mode "threads" (default without chunk_rows): the library's multi-device call (sp_knn_args.n_devices / device_ids, ABI 5) —
+    this process, one host thread per device, no spawn, no process group, every device-side stage of the single-GPU path.
+    mode "processes" (default with chunk_rows): one spawned worker per GPU, RCCL gather (run_call)."""
     from . import similarity as S
 
     fn = getattr(S, name)
-    token = _Route(devices, chunk_rows)
+    mode = mode or ("processes" if chunk_rows else "threads")
+    if mode not in ("threads", "processes"):
+        raise ValueError("mode must be 'threads' or 'processes'")
+    token = _Route(devices, chunk_rows, mode)
     _host._MULTI_GPU_ROUTE.append(token)
     try:
         return fn(matrix1, matrix2, **kwargs)
@@ -180,5 +188,5 @@ def similarity(name: str, matrix1, matrix2=None, *, devices: Union[int, Sequence
 
 
 class _Route:
-    def __init__(self, devices, chunk_rows):
-        self.devices, self.chunk_rows = devices, chunk_rows
+    def __init__(self, devices, chunk_rows, mode="threads"):
+        self.devices, self.chunk_rows, self.mode = devices, chunk_rows, mode

@@ -19,7 +19,7 @@ PREP_HEADER = (ROOT / "include" / "sp_prep.h").read_text()
 
 def test_library_builds_and_loads():
     lib = _abi.load()
-    assert lib.sp_abi_version() == 4
+    assert lib.sp_abi_version() == 5
 
 
 def test_every_declared_symbol_is_exported():
@@ -183,3 +183,27 @@ def test_workspace_query():
     for f in ("targets", "m1_indptr", "m2_indptr", "cols", "values", "rows"):
         setattr(a, f, dummy.ctypes.data)
     assert _abi.workspace_bytes(a) > n
+
+
+def test_abi5_multi_device_fields_are_validated():
+    """sp_knn_args.n_devices / device_ids (ABI 5) and SP_FLAG_REUSE_M2_PREP: argument checks that need no device."""
+    lib = _abi.load()
+    assert [f[0] for f in _abi.SpKnnArgs._fields_][-3:] == ["n_devices", "_pad3", "device_ids"]
+    assert _abi.SP_FLAG_REUSE_M2_PREP == int(re.search(r"#define\s+SP_FLAG_REUSE_M2_PREP\s+(\d+)u", HEADER).group(1))
+    a = _abi.SpKnnArgs()
+    a.struct_size = C.sizeof(_abi.SpKnnArgs)
+    a.k = 3
+    a.n_devices = -1
+    assert lib.sp_knn_f32_i32(C.byref(a)) == -1 and b"n_devices" in lib.sp_last_error()
+    a.n_devices = 65
+    assert lib.sp_knn_f32_i32(C.byref(a)) == -1 and b"n_devices" in lib.sp_last_error()
+    a.n_devices = 2
+    a.flags = _abi.SP_FLAG_REUSE_M2_PREP                  # host mode, no workspace: refused
+    assert lib.sp_knn_f32_i32(C.byref(a)) == -1 and b"SP_FLAG_REUSE_M2_PREP" in lib.sp_last_error()
+    a.flags = 0
+    if lib.sp_device_count() == 0:
+        assert lib.sp_knn_f32_i32(C.byref(a)) == -2       # SP_ENODEVICE: several devices asked for, none there, no CPU fallback
+        with pytest.raises(_abi.HipLibraryError, match="no HIP device"):
+            _host.run_hip(_call(), devices=[0, 1])
+    with pytest.raises(ValueError, match="devices is empty"):
+        _host.run_hip(_call(), devices=[])

@@ -230,3 +230,96 @@ def test_multi_gpu_entry_one_device_nccl():
     r0 = sim.rp3beta(m, alpha=0.8, beta=0.4, k=10, verbose=False, format_output="csr")
     assert r1.nnz == r0.nnz
     _same_topk(r1, r0, 10, "rp3beta: spawned route vs single process")
+
+
+# ---- the HIP kernels at world_size 2 on the ONE GPU of the test box ---------------------------------------------------------------
+def _hip_problem(which: str):
+    """Problems for the two-rank HIP test: both row kernels, MATRIX selectors, a target_rows subset, skewed work."""
+    rng = np.random.default_rng(21)
+    if which == "sparse+filter":          # wide output, light rows: the sparse row kernel (monotone variant) with a MATRIX filter
+        m = sp.random_array((30000, 1500), density=0.004, format="csr", dtype=np.float32, random_state=rng)
+        filt = sp.random_array((30000, 30000), density=20.0 / 30000, format="csr", dtype=np.float32, random_state=rng)
+        tg = np.sort(rng.choice(30000, size=9000, replace=False)).astype(np.int32)
+        return _host.prepare(m, k=20, l2=1.0, c1=0.5, c2=0.5, filter_cols=filt, target_rows=tg)
+    if which == "general+target":         # Tversky + shrink (general variant, judge) with a MATRIX target selector, explicit m2
+        m = sp.random_array((12000, 900), density=0.01, format="csr", dtype=np.float32, random_state=rng)
+        m2 = sp.random_array((900, 20000), density=0.01, format="csr", dtype=np.float32, random_state=rng)
+        tcols = sp.random_array((12000, 20000), density=300.0 / 20000, format="csr", dtype=np.float32, random_state=rng)
+        return _host.prepare(m, m2, k=15, l1=0.6, l2=0.4, t1=0.7, t2=0.3, stabilized_shrink=2.0, target_cols=tcols,
+                             target_rows=np.arange(500, 11500, dtype=np.int32))
+    # dense rows over few columns: the generic row kernel; the last rows are much heavier (the partition is by work)
+    # (the heavy rows hold ones only: sums of 1500 products are then exact in any order — the oracle adds sequentially, the device
+    # does not, and 1e-5 is not a bar a 1500-term float32 sum of random values can be held to)
+    m = sp.random_array((2500, 3000), density=0.02, format="csr", dtype=np.float32, random_state=rng).tolil()
+    m[2300:, :] = 0.0
+    m[2300:, :1500] = 1.0
+    return _host.prepare(sp.csr_array(m.tocsr()), k=30, l2=1.0)
+
+
+def _hip_worker(rank, world, port, q, which):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["SIMILARIPY_AMD_DEVICE"] = "0"
+    torch.cuda.set_device(0)                                   # both ranks on the one GPU
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        call = _hip_problem(which)
+        out = {}
+        # (1) host-array driver with the HIP library as compute
+        out["sharded_knn"] = D.sharded_knn(call, D.hip_compute(device=0), dst=0)
+        # (2) the shipped class: compact slice resident on the device, slabs through the host for the gloo gather;
+        #     one launch + one gather, and the split-phase form (3 sub-launches, sub-slab j gathered behind sub-launch j)
+        for phases in (1, 3):
+            sh = D.ShardedDeviceProblem(call, device=torch.device("cuda", 0), phases=phases)
+            assert sh.world == 2 and sh.host_gather and sh.phases == phases
+            assert sh.prob.call.n_rows_m1 <= call.n_rows_m1              # compact: only the slice's own rows of m1 went up
+            sh.run()
+            sh.run()                                                      # (a second step reuses the resident problem and its workspace)
+            out[f"sdp{phases}"] = sh.result()
+            out[f"n_loc{phases}"] = sh.n_loc
+        if rank == 0:
+            q.put(out)
+        else:
+            assert all(v is None for k_, v in out.items() if not k_.startswith("n_loc"))
+            q.put({"n_loc": out["n_loc1"]})
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["sparse+filter", "general+target", "generic+skew"])
+def test_hip_kernels_at_world_size_2_on_one_gpu(which):
+    """the HIP path had never run at world_size >= 2.  Two spawned ranks over gloo, both on device 0: `sharded_knn` with
+    `hip_compute`, and `ShardedDeviceProblem` (compact slice resident, per-rank `partition_targets` slices on the HIP kernels, slabs
+    padded to n_max, split-phase sub-slabs) against the ORACLE on the whole problem (s_plus.h:313, 337: the row loop that is sharded)."""
+    from oracle import splus_oracle as so
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_hip_worker, args=(r, world, port, q, which)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    root = next(g for g in got if "sharded_knn" in g)
+    other = next(g for g in got if "sharded_knn" not in g)
+    call = _hip_problem(which)
+    k = call.k
+    assert 0 < root["n_loc1"] < call.n_targets and root["n_loc1"] + other["n_loc"] == call.n_targets       # both ranks had rows
+    want_raw = so.run_kernel(call, "port")
+    want = so.canonical(*want_raw, call.targets, k)
+    wcnt = so.slot_counts(*want_raw, call.targets, k)[0]
+    for key in ("sharded_knn", "sdp1", "sdp3"):
+        rows, cols, vals, counts = root[key]
+        so.compare_topk(so.canonical(rows, cols, vals, call.targets, k), want, k, rtol=1e-5, atol=1e-7, what=f"{which}: {key} at world 2 vs oracle")
+        np.testing.assert_array_equal(counts, wcnt)
+        r = rows.reshape(-1, k)
+        assert np.all((r == call.targets[:, None]) | (r == 0))

@@ -828,10 +828,13 @@ def test_stored_zeros_found_on_device_and_eliminated():
                                    ("rp3beta", dict(alpha=1.7, beta=1.0, shrink=2.0))], ids=["p3alpha", "p3alpha_a1", "rp3beta", "rp3beta_shrink"])
 def test_p3_preprocessing_on_device_matches_host_statement(fn, kw):
     """SP_FLAG_P3_PREP / SP_FLAG_DEPOP_ROWSUM: the public p3alpha / rp3beta leave L1 normalisation, ^alpha and the column
-    popularity to the device.  Checked against the oracle kernel fed with the reference's host preprocessing in NumPy
-    (similarity.py:410-415, 477-483).  Tolerance: normalised values differ by an ulp (reordered float32 sums), the rest is
-    the kernel's 1e-5."""
+    popularity to the device.  Two links, each at its own bar (no widened tolerance):
+      (1) the preprocessing: the device's normalised ^alpha values (the same `sp_row_normalize_kernel<L1>` + pow the flag runs, reached
+          through `normalization._run`) against the reference's host statement in NumPy (similarity.py:410-415, 477-483;
+          normalization.pyx:131-161) — the normalisers' bar, 3e-6 (float32 row sums reordered by an ulp);
+      (2) the kernel: the public call against the oracle kernel on THOSE inputs — the north-star bar, 1e-5 relative."""
     from oracle import norm_oracle
+    from similaripy_amd import normalization
     m = _rand((700, 500), 0.03, 12).tolil()
     m[3, :] = 0                                            # an empty row and an empty column
     m[:, 9] = 0
@@ -839,10 +842,12 @@ def test_p3_preprocessing_on_device_matches_host_statement(fn, kw):
     k = 15
     res = getattr(sim, fn)(m, k=k, verbose=False, format_output="csr", **kw)
     m2 = m.T.tocsr()
-    a = norm_oracle.normalize(m, norm="l1")
-    a.data = np.power(a.data, np.float32(kw["alpha"]))
-    b = norm_oracle.normalize(m2, norm="l1")
-    b.data = np.power(b.data, np.float32(kw["alpha"]))
+    a, b = sp.csr_array(m.copy()), sp.csr_array(m2.copy())
+    for dev_m in (a, b):
+        normalization._run(dev_m, _abi.SP_NORM_L1, pow_alpha=kw["alpha"])
+    for dev_m, raw in ((a, m), (b, m2)):
+        host = norm_oracle.normalize(raw, norm="l1")
+        np.testing.assert_allclose(dev_m.data, np.power(host.data, np.float32(kw["alpha"])), rtol=3e-6, atol=0)
     extra = dict(stabilized_shrink=kw.get("shrink", 0.0))
     if fn == "rp3beta":
         extra.update(weight_depop_matrix2=np.asarray(m2.sum(axis=0)).ravel(), p2=kw["beta"], l3=1)
@@ -854,13 +859,13 @@ def test_p3_preprocessing_on_device_matches_host_statement(fn, kw):
         c, v = res.indices[res.indptr[t]:res.indptr[t + 1]], res.data[res.indptr[t]:res.indptr[t + 1]]
         o = np.argsort(c)
         got.append((c[o].astype(np.int32), v[o].astype(np.float32)))
-    so.compare_topk(got, want, k, rtol=2e-5, atol=1e-9, what=fn)
+    so.compare_topk(got, want, k, rtol=RTOL, atol=1e-9, what=fn)
     # the call did not touch the caller's matrix, and float64 / explicit matrix2 / binary calls (host preprocessing) agree with it
     res64 = getattr(sim, fn)(m.astype(np.float64), k=k, verbose=False, format_output="csr", **kw)
     res_m2 = getattr(sim, fn)(m, m.T.tocsr(), k=k, verbose=False, format_output="csr", **kw)
     for other in (res64, res_m2):
         assert other.nnz == res.nnz
-        _assert_same_topk(other, res, k, rtol=2e-5)
+        _assert_same_topk(other, res, k, rtol=RTOL)
 
 
 def test_device_norms_of_an_explicit_matrix2():
@@ -980,3 +985,61 @@ def test_sparse_kernel_packed_trips_with_skewed_segment_lengths(kw):
     # the same rows cut in the kernel (no prepass: one piece per trip) and by the 1024-thread shape (prepass without packing)
     _check(call, "in-kernel items", dbg=2048)
     _check(call, "1024 threads", threads_per_wg=1024, table_slots=16384)
+
+
+@pytest.mark.parametrize("fmt", ["csr", "coo"])
+def test_multi_device_call_behind_the_boundary(fmt):
+    """sp_knn_args.n_devices / device_ids (ABI 5): ONE host-mode call shards `targets` over the listed devices inside the
+    library.  The test box has one GPU: `devices=[0]` runs the entry's own path (device taken from device_ids), and the public route
+    (`multi_gpu.similarity(..., devices=[0])`, mode "threads": no spawn) must equal the plain call and the oracle."""
+    m = _rand((9000, 1200), 0.006, 77)
+    tg = np.sort(np.random.default_rng(1).choice(9000, size=4000, replace=False)).astype(np.int32)
+    call = _host.prepare(m, k=25, l2=1.0, target_rows=tg)
+    want = so.canonical(*so.run_kernel(call, "port"), call.targets, call.k)
+    rows, cols, vals, counts = _host.run_hip(call, devices=[0])
+    so.compare_topk(so.canonical(rows, cols, vals, call.targets, call.k), want, call.k, rtol=RTOL, atol=ATOL, what="devices=[0]")
+    with pytest.raises(_abi.HipLibraryError, match="out of range"):
+        _host.run_hip(call, devices=[0, 99])
+    with pytest.raises(_abi.HipLibraryError, match="twice"):
+        _host.run_hip(call, devices=[0, 0])
+    plain = sim.cosine(m, k=25, target_rows=tg, verbose=False, format_output=fmt)
+    routed = sim.multi_gpu.similarity("cosine", m, k=25, target_rows=tg, verbose=False, format_output=fmt, devices=[0])
+    assert type(routed) is type(plain) and routed.shape == plain.shape and routed.nnz == plain.nnz
+    _assert_same_topk(sp.csr_array(routed), sp.csr_array(plain), 25, rtol=RTOL)
+
+
+@pytest.mark.parametrize("name,kw,shape,density", [
+    ("cosine_fold", dict(l2=1.0), (20000, 1500), 0.004),
+    ("splus_pack", dict(l1=0.5, l2=0.5, stabilized_shrink=3.0), (20000, 1500), 0.004),
+    ("rp3like_fold_l3", dict(l3=1.0, weight_depop_matrix2="sum", p2=0.4), (20000, 1500), 0.004),
+    ("bayes_sign_flag", dict(l2=1.0, bayesian_shrink=2.0), (20000, 1500), 0.004),
+    ("generic_splits", dict(l2=1.0), (1500, 2500), 0.03),
+], ids=lambda x: x if isinstance(x, str) else "")
+def test_sub_launches_reuse_the_passes_over_m2(name, kw, shape, density):
+    """SP_FLAG_REUSE_M2_PREP (ABI 5): one step cut into sub-launches over slices of the target list — what the split-phase gather
+    of the multi-GPU driver does — gives the slots of the one-launch step: the folded m2 values / packed column terms, their
+    minima, the window boundaries and the sign flag of the FIRST sub-launch are what the later ones read."""
+    import torch
+    from similaripy_amd.device import DeviceProblem
+    m = _rand(shape, density, 5)
+    if name == "generic_splits":
+        m = sp.csr_array(sp.vstack([m, _rand((40, shape[1]), 0.5, 6)]))       # a few heavy rows: pieces
+    call = _host.prepare(m, k=30, **kw)
+    n, k = call.n_targets, call.k
+    prob = DeviceProblem(call)
+    c0, v0, n0, _ = prob.alloc_outputs()
+    prob.run(c0, v0, n0)
+    c1, v1, n1, _ = prob.alloc_outputs()
+    c1.zero_(); v1.zero_(); n1.zero_()
+    cuts = [0, n // 3, n // 3 + 7, n]
+    for j in range(3):
+        a, b = cuts[j], cuts[j + 1]
+        prob.run(c1[a * k: b * k], v1[a * k: b * k], n1[a:b], targets=prob.t["targets"][a:b], reuse_m2_prep=j > 0)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(n0.cpu().numpy(), n1.cpu().numpy())
+    rows = _host.slot_rows(call.targets, n0.cpu().numpy(), k)
+    got = so.canonical(rows, c1.cpu().numpy(), v1.cpu().numpy(), call.targets, k)
+    one = so.canonical(rows, c0.cpu().numpy(), v0.cpu().numpy(), call.targets, k)
+    so.compare_topk(got, one, k, rtol=1e-6, atol=0, what=f"{name}: sub-launches vs one launch")
+    want = so.canonical(*so.run_kernel(call, "port"), call.targets, k)
+    so.compare_topk(got, want, k, rtol=RTOL, atol=ATOL, what=f"{name}: sub-launches vs oracle")

@@ -175,7 +175,11 @@ def test_trailing_empty_rows_do_not_raise(oracle_backend):
 
 
 @pytest.mark.parametrize("fn,kw", [("cosine", {}), ("jaccard", {"binary": True}), ("tversky", {"alpha": 0.6, "beta": 0.3}), ("dot_product", {}),
-                                   ("p3alpha", {"alpha": 0.7}), ("rp3beta", {"alpha": 0.7, "beta": 0.5}), ("s_plus", {"l2": 1.0, "shrink": 2.0, "shrink_type": "additive", "c1": 0.3, "c2": 0.7})])
+                                   ("p3alpha", {"alpha": 0.7}), ("rp3beta", {"alpha": 0.7, "beta": 0.5}), ("s_plus", {"l2": 1.0, "shrink": 2.0, "shrink_type": "additive", "c1": 0.3, "c2": 0.7}),
+                                   # depopularisation 'sum' weights with a CSC matrix1 (pop1='sum' crashed in prepare on the CSC route)
+                                   ("s_plus", {"l1": 0.0, "l2": 0.0, "l3": 1.0, "pop1": "sum", "beta1": 0.5}),
+                                   ("s_plus", {"l1": 0.0, "l2": 0.5, "l3": 0.5, "pop2": "sum", "beta2": 0.4}),
+                                   ("s_plus", {"l1": 0.3, "l2": 0.3, "l3": 0.4, "pop1": "sum", "pop2": "sum", "beta1": 0.5, "beta2": 0.7})])
 def test_csc_matrix1_takes_the_direct_route(fn, kw, oracle_backend):
     """A CSC matrix1 (`URM.T`) is handed over as the CSR of matrix2 (SP_FLAG_M1_IS_M2_T) with the norms left to the callee
     (SP_FLAG_NORMS_ON_DEVICE); the result is the one of the host-converted CSR call (s_plus.pyx:205-206)."""
