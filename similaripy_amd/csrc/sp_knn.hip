@@ -38,6 +38,7 @@
 #include "sp_prep_kernels.hpp"
 #include "sp_rowops.hpp"
 #include "sp_sparse_kernel.hpp"
+#include "sp_wave_kernel.hpp"
 #include "sp_generic_kernel.hpp"
 
 // ---------------------------------------------------------------------------------------------
@@ -112,6 +113,7 @@ struct Config {
     int items_rows;         // output slots whose work items are cut by the prepass (sp_row_items_kernel), 0 = off
     size_t ws_items_bytes;
     bool fold;
+    bool wave;              // light rows: the wave-per-row kernel (sp_wave_kernel.hpp) runs instead of the workgroup-per-row sparse kernel
     bool mono;              // the sparse kernel's monotone variant applies (val = xy / den or the raw dot, no per-row target selector)
     bool ordered;
 };
@@ -138,8 +140,10 @@ size_t lds_fixed_sparse(int T, int NT) { return (size_t)T * 8 + (size_t)item_cap
 size_t lds_fixed_generic(int T, int NT) { return (size_t)T * 8 + (size_t)16 * NT + 256 + 256 * 4 + 64 * 4 + 32 * 4 + 16 * 8; }
 
 int make_config(const sp_knn_args *a, int n_cus, Config *c) {
-    int NT = a->threads_per_wg ? a->threads_per_wg : 1024;   // measured best on MI355X (16 waves/CU hide the LDS/HBM round trips)
-    if (NT != 256 && NT != 512 && NT != 768 && NT != 1024) return fail(SP_EINVAL, "threads_per_wg must be 256, 512, 768 or 1024 (got %d)", NT);
+    // (threads_per_wg = 64: ask for the wave-per-row kernel wherever the call qualifies for it, whatever its average row looks like)
+    const bool want_wave = a->threads_per_wg == 64;
+    int NT = (a->threads_per_wg && !want_wave) ? a->threads_per_wg : 1024;   // measured best on MI355X (16 waves/CU hide the LDS/HBM round trips)
+    if (NT != 256 && NT != 512 && NT != 768 && NT != 1024) return fail(SP_EINVAL, "threads_per_wg must be 64, 256, 512, 768 or 1024 (got %d)", NT);
     int T = a->table_slots ? a->table_slots : 16384;
     if (T < 1024 || (T & (T - 1))) return fail(SP_EINVAL, "table_slots must be a power of two >= 1024 (got %d)", T);
     int logT = 0;
@@ -171,7 +175,7 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
     const double avg_macs = (a->n_rows_m1 > 0 && a->n_rows_m2 > 0) ? ((double)a->nnz_m1 / a->n_rows_m1) * ((double)a->nnz_m2 / a->n_rows_m2) : 0.0;
     // (beyond 2^18 columns the bitmap aliases — columns modulo its size — which only adds expected collisions)
     const bool small_rows = avg_macs * avg_macs / (2.0 * std::max(1, std::min(a->n_output_cols, 1 << 18))) <= 0.25 * 1024.0;
-    if (!a->threads_per_wg && !a->table_slots && (long long)a->k + 512 <= (long long)SEL_E * 256 && small_rows) {
+    if ((!a->threads_per_wg || want_wave) && !a->table_slots && (long long)a->k + 512 <= (long long)SEL_E * 256 && small_rows) {
         NT_s = 256; T_s = 4096; logT_s = 12;
     }
     const bool u_lds_s = ((size_t)SEL_E * NT_s * 8 <= (size_t)T_s * 2) && ((long long)a->k + 512 <= (long long)SEL_E * NT_s);
@@ -242,6 +246,14 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
     // are set up in the kernel, as are rows of more than 64 entries or more than ITEMS_PRE items)
     c->items_rows = (!(a->flags & SP_FLAG_NO_SPARSE_PATH) && !c->big && !(a->reserved[0] & 2048) && a->nnz_m2 > 0) ? std::min(a->n_targets, ITEMS_ROWS_MAX) : 0;
     c->ws_items_bytes = ((size_t)c->items_rows * ITEMS_STRIDE * 16 + 255) & ~(size_t)255;
+    // Light rows (user scoring: a few thousand products over <= 2^17 columns, k <= 128, monotone epilogue): one WAVE per row, eight rows
+    // in flight per CU (sp_wave_kernel.hpp) — when the average row fits its 63 packed trips with room to spare, or on request
+    c->wave = c->items_rows > 0 && c->mono && NT_s == 256 && a->n_output_cols <= (1 << WV_BM_LOG2) && a->n_output_cols > T && a->k <= WV_KMAX &&
+              !(a->reserved[0] & 16384) && (want_wave || avg_macs <= 10000.0);
+    if (c->wave) {
+        c->nb_log2 = WV_BM_LOG2;
+        c->wgs_sparse = std::max(1, std::min(a->num_wgs > 0 ? a->num_wgs : n_cus * (int)(LDS_LIMIT / WV_LDS_BYTES), std::max(1, a->n_targets)));
+    }
     c->ws_total = WS_QUEUE_BYTES + c->ws_gu_bytes + c->ws_fold_bytes + c->ws_rows_bytes + c->ws_split_bytes + c->ws_piece_bytes + c->ws_items_bytes;
     return SP_OK;
 }
@@ -290,8 +302,6 @@ int validate(const sp_knn_args *a) {
     if (a->filter_mode < 0 || a->filter_mode > 2 || a->target_col_mode < 0 || a->target_col_mode > 2)
         return fail(SP_EINVAL, "bad selector mode");
     if (a->n_devices < 0 || a->n_devices > 64) return fail(SP_EINVAL, "n_devices must be in [0, 64] (got %d)", a->n_devices);
-    if ((a->flags & SP_FLAG_REUSE_M2_PREP) && (!a->on_device || !a->workspace))
-        return fail(SP_EINVAL, "SP_FLAG_REUSE_M2_PREP needs device mode and the caller workspace of the call whose passes are reused");
     return SP_OK;
 }
 
@@ -326,7 +336,11 @@ int launch_generic(const KParams &kp, const Config &c, hipStream_t stream) {
 int launch_rows(const KParams &kp_s, const KParams &kp, const Config &c, hipStream_t stream, hipEvent_t *ev /* [4] or NULL: around the two row kernels */) {
     // sparse rows first; what it cannot finish joins the generic queue, which the second launch drains
     if (ev) HIP_TRY(hipEventRecord(ev[0], stream));
-    if (kp.sparse_path) {
+    if (kp.sparse_path && c.wave) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(sp_knn_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WV_LDS_BYTES));
+        hipLaunchKernelGGL(sp_knn_wave_kernel, dim3(c.wgs_sparse), dim3(64), WV_LDS_BYTES, stream, kp_s);
+        HIP_TRY(hipGetLastError());
+    } else if (kp.sparse_path) {
         int rc;
         if (c.NT_s == 256) rc = launch_sparse<256>(kp_s, c, stream);
         else if (c.NT_s == 512) rc = launch_sparse<512>(kp_s, c, stream);
@@ -498,7 +512,7 @@ int run_device_impl(sp_knn_args *a) {
         ClassifyParams cp;
         cp.sparse_path = kp.sparse_path;
         cp.n_cols = a->n_output_cols; cp.T = c.T; cp.nb_log2 = c.nb_log2;
-        cp.cs_slots = c.T_s / 4;
+        cp.cs_slots = c.wave ? WV_CSN : c.T_s / 4;
         cp.mono = c.mono ? 1 : 0;
         cp.any_norm = (a->l1 != 0.f || a->l2 != 0.f || a->l3 != 0.f || a->stabilized_shrink != 0.f || a->bayesian_shrink != 0.f) ? 1 : 0;
         cp.l2 = a->l2; cp.l3 = a->l3;
@@ -1626,6 +1640,8 @@ int sp_knn_f32_i32(sp_knn_args *a) {
     const int ndev = sp_device_count();
     if (ndev <= 0) return fail(SP_ENODEVICE, "no HIP device visible: similaripy_amd has no CPU fallback");
     if (a->device < 0 || a->device >= ndev) return fail(SP_EINVAL, "device %d out of range (have %d)", a->device, ndev);
+    if ((a->flags & SP_FLAG_REUSE_M2_PREP) && (!a->on_device || !a->workspace))      // (checked here, not in validate(): the workspace query runs without one)
+        return fail(SP_EINVAL, "SP_FLAG_REUSE_M2_PREP needs device mode and the caller workspace of the call whose passes are reused");
     if (a->n_devices > 1) {
         if (a->on_device) return fail(SP_EINVAL, "n_devices > 1 is a host-mode option (device-resident operands live on ONE device)");
         if (a->n_targets == 0) return SP_OK;

@@ -1,0 +1,537 @@
+// sp_wave_kernel.hpp — LIGHT rows, one WAVE per row: the user-scoring shape of BASELINE configs[4]
+// (dot_product(urm, W.T, filter_cols=urm): 64 m1 entries x ~100-element m2 rows = 6.4 k products over 100 k columns, k = 100).
+//
+// The workgroup-per-row kernel (sp_sparse_kernel.hpp) spends a light row's time at barriers and on memory round trips nobody
+// overlaps: 59 k cycles for 6.4 k products, three 4-wave workgroups per CU (round 3: 3.9 B/clk/CU against the 13-16 B/clk a CU
+// can pull).  Here a row belongs to ONE wave64 and the workgroup IS that wave: no barrier anywhere, every counter a scalar
+// register, 20 KB of LDS per wave, i.e. EIGHT independent rows in flight per CU, and each wave keeps several trips of its row in
+// flight (it has the registers: two waves per SIMD).
+//
+// Same algorithm as the monotone variant of the sparse kernel (s_plus.h:71-127 dense sums[] -> column BITMAP + two sweeps;
+// s_plus.h:39-64 heap -> radix selection; s_plus.h:129-156 epilogue on the winners; s_plus.h:159-171 MATRIX filter):
+//   sweep 1 (column ids)      one bit per output column (n_cols <= 2^17: exact); a product that finds its bit set marks its
+//                             column in the 8 k-bit collision bitmap (columns alias modulo its size: an aliased column is only
+//                             summed where it need not be);
+//   clear + rank prefix       the bitmap's storage becomes [collision set 1024 slots | member pool 1024 entries];
+//   sweep 2 (ids + values)    x = value * m1 value; products of marked columns -> member pool; every other product is the only
+//                             one of its column and goes to the candidate buffer U (256 entries) iff x beats the running k-th
+//                             value; a full U is cut back to its k largest by a wave-local MSD radix selection;
+//   accumulate, drain         members find their slot by the rank of their column's bit (64-bit compare-and-swap claims / adds),
+//                             complete sums above the cutoff join U; excluded (filter) columns carry a -inf pseudo member;
+//   select, write-out         exact top-k, epilogue val = xy / den (or the raw dot), threshold, compaction.
+// Work items: the packed trips sp_row_items_kernel cuts once per call (lane T of the wave holds trip T's record: at most 63
+// trips, i.e. rows of up to ~16 k products; others go to the generic kernel's queue, as does any row whose pools overflow).
+#pragma once
+#include "sp_common.hpp"
+
+namespace {
+
+constexpr int WV_BM_LOG2 = 17;                                  // column bitmap: 2^17 bits
+constexpr int WV_CBM_BYTES = 1024;                              // collision bitmap: 8192 bits
+constexpr int WV_PRE_BYTES = 512;                               // u16 rank prefix per collision-bitmap word
+constexpr int WV_A_BYTES = (1 << WV_BM_LOG2) / 8;               // region A = the bitmap = 16 KB
+constexpr int WV_CSN = 1024;                                    // collision-set slots: [0, 512) by rank, [512, 1024) overflow
+constexpr int WV_MPCAP = 1024;                                  // member pool entries
+constexpr int WV_UCAP = 256;                                    // candidate buffer entries (four per lane)
+constexpr int WV_KMAX = 128;                                    // k + 64 <= UCAP must hold with room to spare
+constexpr int WV_OFF_PRE = WV_CBM_BYTES;
+constexpr int WV_OFF_A = WV_CBM_BYTES + WV_PRE_BYTES;
+constexpr int WV_OFF_MP = WV_OFF_A + WV_CSN * 8;
+constexpr int WV_OFF_U = WV_OFF_A + WV_A_BYTES;
+constexpr int WV_LDS_BYTES = WV_OFF_U + WV_UCAP * 8;            // 19 968 B: eight waves per CU
+static_assert(WV_CSN * 8 + WV_MPCAP * 8 == WV_A_BYTES, "collision set + member pool = the bitmap's storage");
+static_assert(8 * WV_LDS_BYTES <= 160 * 1024, "eight rows per CU");
+
+// Sweep 2 core for a collision bitmap of WV_CBM_BYTES at LDS offset 0 (sp_common.hpp's s2_core with this kernel's mask).
+__device__ __forceinline__ void s2_core_w(const unsigned (&c)[4], const float (&v)[4], float segv, float cut, float (&x)[4], u64 (&M)[4], u64 (&L)[4]) {
+    unsigned a0, a1, a2, a3;
+    asm volatile(
+        "v_lshrrev_b32 %[a0], 3, %[c0]\n\t"
+        "v_lshrrev_b32 %[a1], 3, %[c1]\n\t"
+        "v_lshrrev_b32 %[a2], 3, %[c2]\n\t"
+        "v_lshrrev_b32 %[a3], 3, %[c3]\n\t"
+        "v_and_b32 %[a0], 0x3fc, %[a0]\n\t"
+        "v_and_b32 %[a1], 0x3fc, %[a1]\n\t"
+        "v_and_b32 %[a2], 0x3fc, %[a2]\n\t"
+        "v_and_b32 %[a3], 0x3fc, %[a3]\n\t"
+        "ds_read_b32 %[a0], %[a0]\n\t"
+        "ds_read_b32 %[a1], %[a1]\n\t"
+        "ds_read_b32 %[a2], %[a2]\n\t"
+        "ds_read_b32 %[a3], %[a3]\n\t"
+        "v_mul_f32 %[x0], %[sv], %[v0]\n\t"
+        "v_mul_f32 %[x1], %[sv], %[v1]\n\t"
+        "v_mul_f32 %[x2], %[sv], %[v2]\n\t"
+        "v_mul_f32 %[x3], %[sv], %[v3]\n\t"
+        "v_cmp_nle_f32_e64 %[L0], %[x0], %[cut]\n\t"
+        "v_cmp_nle_f32_e64 %[L1], %[x1], %[cut]\n\t"
+        "v_cmp_nle_f32_e64 %[L2], %[x2], %[cut]\n\t"
+        "v_cmp_nle_f32_e64 %[L3], %[x3], %[cut]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_bfe_u32 %[a0], %[a0], %[c0], 1\n\t"
+        "v_bfe_u32 %[a1], %[a1], %[c1], 1\n\t"
+        "v_bfe_u32 %[a2], %[a2], %[c2], 1\n\t"
+        "v_bfe_u32 %[a3], %[a3], %[c3], 1\n\t"
+        "v_cmp_ne_u32_e64 %[M0], 0, %[a0]\n\t"
+        "v_cmp_ne_u32_e64 %[M1], 0, %[a1]\n\t"
+        "v_cmp_ne_u32_e64 %[M2], 0, %[a2]\n\t"
+        "v_cmp_ne_u32_e64 %[M3], 0, %[a3]\n\t"
+        : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3),
+          [x0] "=&v"(x[0]), [x1] "=&v"(x[1]), [x2] "=&v"(x[2]), [x3] "=&v"(x[3]),
+          [M0] "=&s"(M[0]), [M1] "=&s"(M[1]), [M2] "=&s"(M[2]), [M3] "=&s"(M[3]),
+          [L0] "=&s"(L[0]), [L1] "=&s"(L[1]), [L2] "=&s"(L[2]), [L3] "=&s"(L[3])
+        : [c0] "v"(c[0]), [c1] "v"(c[1]), [c2] "v"(c[2]), [c3] "v"(c[3]),
+          [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]), [sv] "v"(segv), [cut] "s"(cut)
+        : "memory");
+}
+
+// Wave-local exact selection: the n (> k) entries {key : column} of U[0, n) are cut back to the k with the largest keys (ties at
+// the k-th place resolved arbitrarily, as the reference's heap does), compacted to U[0, k), the tail zeroed.  MSD radix select,
+// four 8-bit digits: every lane holds four entries in registers; one 256-counter histogram per digit in LDS (`hist`: zero on
+// entry and on exit), each lane reads four counters back, a DPP scan finds the digit of the k-th largest.  Returns its key.
+__device__ __forceinline__ unsigned wave_select(u64 *U, int *hist, int n, int k, int lane) {
+    u64 e[4];
+    unsigned key[4];
+    bool live[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = lane + 64 * j;
+        live[j] = i < n;
+        e[j] = live[j] ? U[i] : 0ull;
+        key[j] = (unsigned)(e[j] >> 32);
+    }
+    unsigned prefix = 0u, pmask = 0u;
+    int need = k;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (live[j] && (key[j] & pmask) == prefix) atomicAdd(&hist[(key[j] >> shift) & 255u], 1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const int4 h = ((const int4 *)hist)[lane];            // counters 4*lane .. 4*lane + 3 (LDS executes a wave's accesses in order)
+        ((int4 *)hist)[lane] = make_int4(0, 0, 0, 0);
+        const int tot = (h.x + h.y) + (h.z + h.w);
+        const int incl = wave_incl_scan_dpp(tot);
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        const int a3 = total - incl, a2 = a3 + h.w, a1 = a2 + h.z, a0 = a1 + h.y;      // entries with a larger digit
+        int my_d = -1, my_above = 0;
+        if (a0 < need && need <= a0 + h.x) { my_d = 0; my_above = a0; }
+        if (a1 < need && need <= a1 + h.y) { my_d = 1; my_above = a1; }
+        if (a2 < need && need <= a2 + h.z) { my_d = 2; my_above = a2; }
+        if (a3 < need && need <= a3 + h.w) { my_d = 3; my_above = a3; }
+        const u64 ball = __ballot(my_d >= 0);                  // exactly one lane: the matching entries number >= need
+        const int src = ball ? __builtin_ctzll(ball) : 0;
+        const int d = 4 * src + __builtin_amdgcn_readlane(my_d, src);
+        need -= __builtin_amdgcn_readlane(my_above, src);
+        prefix |= (unsigned)d << shift;
+        pmask |= 0xFFu << shift;
+    }
+    // keys above the k-th largest, then `need` of its equals
+    int pos = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool gt = live[j] && key[j] > prefix;
+        const u64 m = __ballot(gt);
+        if (gt) U[pos + mbcnt64(m)] = e[j];
+        pos += __popcll(m);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool eq = live[j] && key[j] == prefix;
+        const u64 m = __ballot(eq);
+        const int r = mbcnt64(m);
+        if (eq && r < need) U[pos + r] = e[j];
+        const int taken = min(__popcll(m), need);
+        pos += taken;
+        need -= taken;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = lane + 64 * j;
+        if (i >= pos && i < n) U[i] = 0ull;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    return prefix;
+}
+
+__global__ __launch_bounds__(64) void sp_knn_wave_kernel(const KParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    unsigned char *cbm = smem;
+    unsigned short *pre16 = (unsigned short *)(smem + WV_OFF_PRE);
+    unsigned char *rA = smem + WV_OFF_A;
+    u64 *cs = (u64 *)rA;
+    u64 *mpool = (u64 *)(smem + WV_OFF_MP);
+    u64 *U = (u64 *)(smem + WV_OFF_U);
+    int *hist = (int *)rA;                     // the selections' histogram: the collision set's first KB (empty whenever a selection runs)
+    if ((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();
+    const __amdgpu_buffer_rsrc_t rs_idx = __builtin_amdgcn_make_buffer_rsrc((void *)p.m2_indices, 0, (int)p.m2_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_val = __builtin_amdgcn_make_buffer_rsrc((void *)p.m2_data, 0, (int)p.m2_bytes, 0x00020000);
+    for (int i = lane; i < WV_LDS_BYTES / 16; i += 64) ((int4 *)smem)[i] = make_int4(0, 0, 0, 0);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+    const bool any_norm = (p.l1 != 0.f || p.l2 != 0.f || p.l3 != 0.f || p.stab != 0.f || p.bayes != 0.f);
+    const unsigned amask = (unsigned)(WV_A_BYTES - 1) & ~3u;
+    const bool timing = (p.phase_cycles != nullptr) && lane == 0;
+    u64 ph[PH_N];
+#pragma unroll
+    for (int i = 0; i < PH_N; ++i) ph[i] = 0;
+    u64 tmark = timing ? (u64)clock64() : 0;
+#define WV_PHASE_END(which) do { if (timing) { const u64 _n = (u64)clock64(); ph[which] += _n - tmark; tmark = _n; } } while (0)
+
+    const int n_rows = (int)p.qcount[0];
+    const int k = p.k;
+    int q_next = 0;
+    if (p.static_sched) q_next = (int)blockIdx.x;
+    else { if (lane == 0) q_next = (int)atomicAdd(&p.queue[0], 1u); q_next = __builtin_amdgcn_readfirstlane(q_next); }
+
+    for (;;) {
+        const int q = q_next;
+        if (q >= n_rows) break;
+        // the next row's queue position is claimed now and arrives while this row runs
+        int q_claim = 0;
+        if (p.static_sched) q_claim = q + (int)gridDim.x;
+        else if (lane == 0) q_claim = (int)atomicAdd(&p.queue[0], 1u);
+
+        const int4 d0 = p.desc[2 * (size_t)q], d1 = p.desc[2 * (size_t)q + 1];
+        const int slot = __builtin_amdgcn_readfirstlane(d0.x), t = __builtin_amdgcn_readfirstlane(d0.y);
+        const int dw = __builtin_amdgcn_readfirstlane(d0.w);
+        const int n1 = desc_n1(dw), n_tr = desc_n_trips(dw);
+        const float den = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane(d1.y));
+        bool failed = (n_tr <= 0 || n_tr > 63 || slot >= p.items_rows);
+
+        // trip records: lane T holds trip T (piece A) and, for a packed trip, its second piece B; lanes beyond: the sentinel
+        int4 recA = make_int4((int)OOB_SOFFSET, 0, 0, 0), recB = make_int4(0, 0, 0, 64);
+        int f0 = 0, fl = 0;
+        if (!failed) {
+            const int4 *row = p.items_g + (size_t)slot * ITEMS_STRIDE;
+            if (lane < n_tr) recA = row[1 + lane];
+            if (p.filter_mode == SP_SEL_MATRIX) { const int4 r0 = row[0]; f0 = __builtin_amdgcn_readfirstlane(r0.x); fl = __builtin_amdgcn_readfirstlane(r0.y); }
+            const int bix = (int)((unsigned)recA.w >> ITEM_W_BITS);
+            if (bix) recB = row[1 + bix];
+        }
+        // x <= cutx0  =>  val(x) < threshold for sure (the exact test is repeated on the winners at write-out)
+        float cutx0;
+        if (!any_norm) cutx0 = __uint_as_float(RowCtx::funkey_inv_below(p.threshold));
+        else {
+            const float c0 = p.threshold * den;
+            cutx0 = c0 - fabsf(c0) * 2e-6f - 1e-37f;
+            if (!(c0 == c0)) cutx0 = -__builtin_inff();
+        }
+        float cutx = cutx0;
+        int ucnt = 0, mcnt = 0;
+        WV_PHASE_END(PH_SETUP);
+
+        // one trip of the wave: this lane's byte offset into m2, the number of its real elements (<= 0: none), its m1 value
+        auto trip_lane = [&](int T, int &vo, int &d, float &sv) __attribute__((always_inline)) {
+            const int tl = min(T, 63);                 // (lane 63 always holds the sentinel: n_tr <= 63)
+            const int oA = __builtin_amdgcn_readlane(recA.x, tl), cA = __builtin_amdgcn_readlane(recA.y, tl);
+            const int oB = __builtin_amdgcn_readlane(recB.x, tl), cB = __builtin_amdgcn_readlane(recB.y, tl);
+            const int sB = __builtin_amdgcn_readlane(recB.w, tl);
+            vo = oA + lane * 16;
+            d = cA - 4 * lane;
+            sv = __uint_as_float((unsigned)__builtin_amdgcn_readlane(recA.z, tl));
+            if (lane >= sB) { vo = oB + (lane - sB) * 16; d = cB - 4 * (lane - sB); sv = __uint_as_float((unsigned)__builtin_amdgcn_readlane(recB.z, tl)); }
+            if (d <= 0) vo = (int)OOB_SOFFSET;         // lanes beyond the pieces fetch nothing
+        };
+
+        if (!failed) {
+            // ---- MATRIX filter (s_plus.h:159-171): the row's excluded columns, requested before the first sweep ----
+            int my_fc = -1;
+            if (p.filter_mode == SP_SEL_MATRIX && lane < fl) my_fc = p.f_indices[f0 + lane];
+
+            // ---- sweep 1: column ids only, four trips in flight ----
+            {
+                auto ld = [&](int T, u32x4 &ids, int &d) __attribute__((always_inline)) {
+                    int vo; float sv;
+                    trip_lane(T, vo, d, sv);
+                    ids = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, vo, 0, 0);
+                };
+                auto body = [&](int T, const u32x4 &ids, int d) __attribute__((always_inline)) {
+                    if (T >= n_tr) return;
+                    const unsigned c[4] = {ids.x, ids.y, ids.z, ids.w};
+                    const unsigned one[4] = {d > 0 ? 1u : 0u, d > 1 ? 1u : 0u, d > 2 ? 1u : 0u, d > 3 ? 1u : 0u};
+                    unsigned seen[4];
+                    s1_core<WV_OFF_A, true>(c, one, amask, seen);
+                    if (__ballot(((seen[0] | seen[1]) | (seen[2] | seen[3])) != 0u)) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (seen[j]) atomicOr((unsigned *)(cbm + ((c[j] >> 3) & (unsigned)(WV_CBM_BYTES - 4))), 1u << (c[j] & 31u));
+                    }
+                };
+                u32x4 b0, b1, b2, b3;
+                int e0, e1, e2, e3;
+                ld(0, b0, e0); ld(1, b1, e1); ld(2, b2, e2); ld(3, b3, e3);
+                for (int T = 0; T < n_tr; T += 4) {
+                    body(T, b0, e0); ld(T + 4, b0, e0);
+                    body(T + 1, b1, e1); ld(T + 5, b1, e1);
+                    body(T + 2, b2, e2); ld(T + 6, b2, e2);
+                    body(T + 3, b3, e3); ld(T + 7, b3, e3);
+                }
+            }
+            // excluded columns: marked in the collision bitmap, so all their products gather in the collision set
+            if (p.filter_mode == SP_SEL_MATRIX) {
+                if (my_fc >= 0) atomicOr((unsigned *)(cbm + (((unsigned)my_fc >> 3) & (unsigned)(WV_CBM_BYTES - 4))), 1u << ((unsigned)my_fc & 31u));
+                for (int i = 64 + lane; i < fl; i += 64) {
+                    const unsigned c = (unsigned)p.f_indices[f0 + i];
+                    atomicOr((unsigned *)(cbm + ((c >> 3) & (unsigned)(WV_CBM_BYTES - 4))), 1u << (c & 31u));
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            WV_PHASE_END(PH_SWEEP1);
+
+            // ---- the bitmap has done its job: back to zero; rank prefix of the collision bitmap ----
+#pragma unroll
+            for (int i = 0; i < WV_A_BYTES / (64 * 16); ++i) ((int4 *)rA)[i * 64 + lane] = make_int4(0, 0, 0, 0);
+            {
+                const int4 w4 = ((const int4 *)cbm)[lane];           // 256 words: four per lane
+                const int p0 = __popc((unsigned)w4.x), p1 = p0 + __popc((unsigned)w4.y), p2 = p1 + __popc((unsigned)w4.z);
+                const int tot = p2 + __popc((unsigned)w4.w);
+                const int incl = wave_incl_scan_dpp(tot);
+                const int ex = incl - tot;
+                ((u64 *)pre16)[lane] = (u64)(unsigned)(ex & 0xFFFF) | ((u64)(unsigned)((ex + p0) & 0xFFFF) << 16) |
+                                       ((u64)(unsigned)((ex + p1) & 0xFFFF) << 32) | ((u64)(unsigned)((ex + p2) & 0xFFFF) << 48);
+                if (__builtin_amdgcn_readlane(incl, 63) > WV_CSN / 2) failed = true;      // more marked columns than direct slots
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            // every excluded column gets a pseudo member of value -inf: its sum is then below any cutoff
+            if (p.filter_mode == SP_SEL_MATRIX && !failed) {
+                if (fl > WV_MPCAP / 2) failed = true;
+                else {
+                    for (int i0 = 0; i0 < fl; i0 += 64) {
+                        const int c = (i0 == 0) ? my_fc : ((i0 + lane < fl) ? p.f_indices[f0 + i0 + lane] : -1);
+                        const u64 m = __ballot(c >= 0);
+                        if (c >= 0) mpool[mcnt + mbcnt64(m)] = ((u64)((unsigned)c + 1u) << 32) | (u64)0xFF800000u;
+                        mcnt += __popcll(m);
+                    }
+                }
+            }
+            WV_PHASE_END(PH_SEGMENTS);
+        }
+
+        if (!failed) {
+            // ---- sweep 2: ids + values, four trips in flight ----
+            auto ld = [&](int T, u32x4 &ids, u32x4 &vals, int &d, float &sv) __attribute__((always_inline)) {
+                int vo;
+                trip_lane(T, vo, d, sv);
+                ids = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, vo, 0, 0);
+                vals = __builtin_amdgcn_raw_buffer_load_b128(rs_val, vo, 0, 0);
+            };
+            auto body = [&](int T, const u32x4 &ids, const u32x4 &vals, int d, float sv) __attribute__((always_inline)) {
+                if (T >= n_tr || failed) return;
+                const unsigned c[4] = {ids.x, ids.y, ids.z, ids.w};
+                const float v[4] = {__uint_as_float(vals.x), __uint_as_float(vals.y), __uint_as_float(vals.z), __uint_as_float(vals.w)};
+                float x[4];
+                u64 M[4], S[4];
+                s2_core_w(c, v, sv, cutx, x, M, S);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const u64 ok = __ballot(j < d);
+                    M[j] &= ok;
+                    S[j] &= ok & ~M[j];
+                }
+                // products of marked columns: the member pool
+                const u64 Many = (M[0] | M[1]) | (M[2] | M[3]);
+                if (Many) {
+                    const int nm = (__popcll(M[0]) + __popcll(M[1])) + (__popcll(M[2]) + __popcll(M[3]));
+                    if (mcnt + nm > WV_MPCAP) { failed = true; return; }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (M[j]) { lds_push64(M[j], __float_as_uint(x[j]), c[j] + 1u, mcnt, (unsigned)WV_OFF_MP); mcnt += __popcll(M[j]); }
+                    }
+                }
+                // every other product is the only one of its column: into U iff it beats the running k-th value
+                if ((S[0] | S[1]) | (S[2] | S[3])) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        int ns = __popcll(S[j]);
+                        if (ns && ucnt + ns > WV_UCAP) {
+                            // U is full: back to its k largest; their smallest is the new cutoff, applied to what is left of this trip
+                            const unsigned tk = wave_select(U, hist, ucnt, k, lane);
+                            ucnt = min(ucnt, k);
+                            cutx = fmaxf(cutx0, funkey(tk));
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj) if (jj >= j) S[jj] &= __ballot(!(x[jj] <= cutx));
+                            ns = __popcll(S[j]);
+                        }
+                        if (ns) { lds_push64(S[j], c[j], fkey(x[j]), ucnt, (unsigned)WV_OFF_U); ucnt += ns; }
+                    }
+                }
+            };
+            u32x4 i0, i1, i2, i3, v0, v1, v2, v3;
+            int e0, e1, e2, e3;
+            float s0, s1, s2, s3;
+            ld(0, i0, v0, e0, s0); ld(1, i1, v1, e1, s1); ld(2, i2, v2, e2, s2); ld(3, i3, v3, e3, s3);
+            for (int T = 0; T < n_tr; T += 4) {
+                body(T, i0, v0, e0, s0); ld(T + 4, i0, v0, e0, s0);
+                body(T + 1, i1, v1, e1, s1); ld(T + 5, i1, v1, e1, s1);
+                body(T + 2, i2, v2, e2, s2); ld(T + 6, i2, v2, e2, s2);
+                body(T + 3, i3, v3, e3, s3); ld(T + 7, i3, v3, e3, s3);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            WV_PHASE_END(PH_SWEEP2);
+        }
+
+        if (!failed) {
+            // ---- members: find-or-insert in the collision set, {column + 1 : sum} slots, 0 = free.  The direct slot is the rank of
+            // the column's bit in the collision bitmap; a slot taken by another column (bits alias) sends the entry to a hashed
+            // start in the overflow half, then on linearly.  One 64-bit compare-and-swap claims a free slot with the product in it
+            // or adds to the sum last seen; a lost race against another product of the column falls back to the hardware add. ----
+            auto next_slot = [&](unsigned h, unsigned key) __attribute__((always_inline)) -> unsigned {
+                const unsigned half = (unsigned)(WV_CSN / 2);
+                return (h < half) ? half + hash_bits((int)key, 2654435761u, 32 - 9) : half + ((h + 1u) & (half - 1u));
+            };
+            constexpr int JA = 4;
+            for (int base = 0; base < mcnt && !failed; base += JA * 64) {
+                u64 cur[JA];
+                unsigned kk[JA], h[JA];
+                float xx[JA];
+                bool act[JA];
+#pragma unroll
+                for (int j = 0; j < JA; ++j) {
+                    const int i = base + j * 64 + lane;
+                    const u64 e = (i < mcnt) ? mpool[i] : 0ull;
+                    kk[j] = (unsigned)(e >> 32);
+                    xx[j] = __uint_as_float((unsigned)e);
+                    act[j] = (e != 0ull);
+                    const unsigned cm = kk[j] - 1u;
+                    const unsigned wi = (cm >> 5) & (unsigned)(WV_CBM_BYTES / 4 - 1);
+                    const unsigned bw = ((const unsigned *)cbm)[wi];
+                    h[j] = (unsigned)pre16[wi] + (unsigned)__popc(bw & ((1u << (cm & 31u)) - 1u));
+                    cur[j] = 0ull;
+                }
+                int rounds = 0;
+                while (__ballot((act[0] | act[1]) | (act[2] | act[3]))) {
+                    u64 r[JA];
+#pragma unroll
+                    for (int j = 0; j < JA; ++j) {
+                        r[j] = 0ull;
+                        if (act[j]) {
+                            const float add = (cur[j] == 0ull) ? xx[j] : __uint_as_float((unsigned)cur[j]) + xx[j];
+                            r[j] = atomicCAS(&cs[h[j]], cur[j], ((u64)kk[j] << 32) | (u64)__float_as_uint(add));
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < JA; ++j) {
+                        if (act[j]) {
+                            if (r[j] == cur[j]) act[j] = false;
+                            else if ((unsigned)(r[j] >> 32) == kk[j]) {
+                                if (cur[j] == 0ull) cur[j] = r[j];
+                                else { atomicAdd((float *)&cs[h[j]], xx[j]); act[j] = false; }
+                            } else { h[j] = next_slot(h[j], kk[j]); cur[j] = 0ull; }
+                        }
+                    }
+                    if (++rounds > 4 * CS_MAXPROBE) { failed = true; break; }      // set full
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            // the member pool is consumed: its storage (and the collision bitmap) go back to zero at the row's end
+            WV_PHASE_END(PH_ACCUM);
+        }
+
+        if (!failed) {
+            // ---- the collision set's complete sums above the cutoff join U (an excluded column's sum is -inf ... unless an infinite
+            // product made it NaN: then the filter list decides) ----
+            for (int base = 0; base < WV_CSN; base += 4 * 64) {
+                u64 e[4];
+                bool want[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) e[j] = cs[base + j * 64 + lane];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    cs[base + j * 64 + lane] = 0ull;
+                    want[j] = (e[j] != 0ull) && !(__uint_as_float((unsigned)e[j]) <= cutx);
+                }
+                if (p.filter_mode == SP_SEL_MATRIX) {
+                    bool odd = false;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) odd |= want[j] && (__uint_as_float((unsigned)e[j]) != __uint_as_float((unsigned)e[j]));
+                    if (__ballot(odd)) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (want[j] && (__uint_as_float((unsigned)e[j]) != __uint_as_float((unsigned)e[j])) &&
+                                range_has(p.f_indices, f0, f0 + fl, (int)((unsigned)(e[j] >> 32) - 1u))) want[j] = false;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    u64 m = __ballot(want[j]);
+                    int ns = __popcll(m);
+                    if (ns && ucnt + ns > WV_UCAP) {
+                        // (the histogram lives in the set's first KB: those slots have been read and zeroed above)
+                        const unsigned tk = wave_select(U, hist, ucnt, k, lane);
+                        ucnt = min(ucnt, k);
+                        cutx = fmaxf(cutx0, funkey(tk));
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) if (jj >= j) want[jj] = want[jj] && !(__uint_as_float((unsigned)e[jj]) <= cutx);
+                        m = __ballot(want[j]);
+                        ns = __popcll(m);
+                    }
+                    if (ns) {
+                        if (want[j]) U[ucnt + mbcnt64(m)] = ((u64)fkey(__uint_as_float((unsigned)e[j])) << 32) | (u64)((unsigned)(e[j] >> 32) - 1u);
+                        ucnt += ns;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            WV_PHASE_END(PH_DRAIN);
+            if (ucnt > k) {
+                wave_select(U, hist, ucnt, k, lane);
+                ucnt = k;
+            }
+            WV_PHASE_END(PH_SELECT);
+
+            // ---- write-out: epilogue on the winners (s_plus.h:129-156 with the column term folded in: val = xy / den, or the raw
+            // dot), exact threshold test, compaction to the front of the slot, zero padding behind (s_plus.h:444-450) ----
+            const long long o = (long long)slot * (long long)k;
+            int n_out = 0;
+            for (int base = 0; base < ucnt; base += 64) {
+                const int j = base + lane;
+                const u64 it = (j < ucnt) ? U[j] : 0ull;
+                const float xv = funkey((unsigned)(it >> 32));
+                float val = xv;
+                if (any_norm) val = (den != 0.f) ? xv / den : 0.f;
+                const bool keep = (it != 0ull) && (val >= p.threshold);
+                const u64 m = __ballot(keep);
+                if (keep) {
+                    const long long qo = o + n_out + mbcnt64(m);
+                    if (p.rows) p.rows[qo] = t;
+                    p.cols[qo] = (int)(unsigned)(it & 0xFFFFFFFFull);
+                    p.values[qo] = val;
+                }
+                n_out += __popcll(m);
+            }
+            for (int j = n_out + lane; j < k; j += 64) {
+                if (p.rows) p.rows[o + j] = 0;
+                p.cols[o + j] = 0;
+                p.values[o + j] = 0.f;
+            }
+            if (lane == 0 && p.counts) p.counts[slot] = n_out;
+            if (timing) ph[CT_ROWS_SPARSE] += 1;
+        } else {
+            // not a row for this kernel (no trip records, too many trips) or a pool overflowed: the generic kernel's queue takes it
+            if (lane == 0) {
+                const unsigned g = atomicAdd(&p.qcount[1], 1u);
+                p.desc_g[2 * (size_t)g] = make_int4(d0.x, d0.y, d0.z, n1);      // (without the record counts)
+                p.desc_g[2 * (size_t)g + 1] = d1;
+            }
+            if (timing) ph[CT_ROWS_FALLBACK] += 1;
+        }
+        // LDS back to clean: collision bitmap, what is left of the member pool / collision set, U
+        ((int4 *)cbm)[lane] = make_int4(0, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < WV_A_BYTES / (64 * 16); ++i) ((int4 *)rA)[i * 64 + lane] = make_int4(0, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < WV_UCAP * 8 / (64 * 16); ++i) ((int4 *)U)[i * 64 + lane] = make_int4(0, 0, 0, 0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        q_next = __builtin_amdgcn_readfirstlane(q_claim);
+        WV_PHASE_END(PH_OUTPUT);
+    }
+    if (timing) {
+#pragma unroll
+        for (int i = 0; i < PH_N; ++i) if (ph[i]) atomicAdd(&p.phase_cycles[i], ph[i]);
+    }
+#undef WV_PHASE_END
+}
+
+}  // namespace

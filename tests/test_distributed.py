@@ -262,8 +262,10 @@ def _hip_worker(rank, world, port, q, which):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["SIMILARIPY_AMD_DEVICE"] = "0"
+    import datetime
+    import traceback
     torch.cuda.set_device(0)                                   # both ranks on the one GPU
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
     try:
         call = _hip_problem(which)
         out = {}
@@ -285,6 +287,9 @@ def _hip_worker(rank, world, port, q, which):
             assert all(v is None for k_, v in out.items() if not k_.startswith("n_loc"))
             q.put({"n_loc": out["n_loc1"]})
         dist.barrier()
+    except Exception:                                          # (reported to the parent: a dead rank must not leave the other one waiting)
+        q.put({"error": f"rank {rank}: {traceback.format_exc()[-1500:]}"})
+        raise
     finally:
         dist.destroy_process_group()
 
@@ -305,9 +310,17 @@ def test_hip_kernels_at_world_size_2_on_one_gpu(which):
     procs = [ctx.Process(target=_hip_worker, args=(r, world, port, q, which)) for r in range(world)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=600) for _ in range(world)]
+    got = []
+    try:
+        for _ in range(world):
+            got.append(q.get(timeout=200))
+            assert "error" not in got[-1], got[-1]["error"]
+    finally:
+        for p in procs:
+            p.join(timeout=30 if len(got) == world and "error" not in got[-1] else 1)
+            if p.is_alive():
+                p.kill()
     for p in procs:
-        p.join(timeout=120)
         assert p.exitcode == 0
     root = next(g for g in got if "sharded_knn" in g)
     other = next(g for g in got if "sharded_knn" not in g)

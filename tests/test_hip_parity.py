@@ -1043,3 +1043,87 @@ def test_sub_launches_reuse_the_passes_over_m2(name, kw, shape, density):
     so.compare_topk(got, one, k, rtol=1e-6, atol=0, what=f"{name}: sub-launches vs one launch")
     want = so.canonical(*so.run_kernel(call, "port"), call.targets, k)
     so.compare_topk(got, want, k, rtol=RTOL, atol=ATOL, what=f"{name}: sub-launches vs oracle")
+
+
+# ---- the wave-per-row kernel for light rows (sp_wave_kernel.hpp; BASELINE configs[4]'s shape) -------------------------------------------
+def _scoring_problem(n_users=6000, n_items=40000, per_user=40, per_item=60, seed=3, signed=False):
+    """urm (users x items) and an item model W.T (items x items): the user-scoring call dot_product(urm, W.T, filter_cols=urm)."""
+    rng = np.random.default_rng(seed)
+    urm = sp.random_array((n_users, n_items), density=per_user / n_items, format="csr", dtype=np.float32, random_state=rng)
+    wt = sp.random_array((n_items, n_items), density=per_item / n_items, format="csr", dtype=np.float32, random_state=rng)
+    if signed:
+        wt.data[:] = (wt.data - 0.3)
+    return urm, wt
+
+
+def _ran_on_the_wave_kernel(call, **tuning):
+    info = _host.run_hip(call, time_kernel=True, **tuning)[4]
+    cus = int(_abi.backend_info(0).split("CUs=")[1].split()[0])
+    return info["num_wgs"] == min(call.n_targets, 8 * cus), info
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("scoring_filter", dict(filter="urm")),
+    ("scoring_plain", dict()),
+    ("scoring_k1", dict(k=1, filter="urm")),
+    ("scoring_k128_threshold", dict(k=128, threshold=0.05)),
+    ("scoring_signed_negative_threshold", dict(signed=True, threshold=-0.2, filter="urm")),
+    ("cosine_folded", dict(l2=1.0, c1=0.5, c2=0.5)),
+    ("asym_folded_target_rows", dict(l2=1.0, c1=0.3, c2=0.7, targets=True)),
+], ids=lambda x: x if isinstance(x, str) else "")
+def test_wave_kernel_light_rows(name, kw):
+    """One wave per row (threads_per_wg=64 asks for it; the library picks it by itself when the average row is light): monotone
+    epilogues, MATRIX filter through -inf pseudo members, k from 1 to 128, thresholds, signed values — against the oracle."""
+    kw = dict(kw)
+    urm, wt = _scoring_problem(signed=kw.pop("signed", False))
+    filt = urm if kw.pop("filter", None) else None
+    tg = np.sort(np.random.default_rng(9).choice(urm.shape[0], size=2500, replace=False)).astype(np.int32) if kw.pop("targets", False) else None
+    k = kw.pop("k", 50)
+    call = _host.prepare(urm, wt, k=k, filter_cols=filt, target_rows=tg, **kw)
+    ran, info = _ran_on_the_wave_kernel(call, threads_per_wg=64)
+    assert ran, f"{name}: the wave kernel was not chosen ({info['num_wgs']} workgroups)"
+    assert info["phase_cycles"][9] >= 0.98 * call.n_targets, f"{name}: rows finished by the wave kernel: {info['phase_cycles'][9]} of {call.n_targets}"
+    _check(call, f"wave kernel {name}", threads_per_wg=64)
+    # the library's own choice for this shape is the same kernel
+    assert _ran_on_the_wave_kernel(call)[0]
+
+
+def test_wave_kernel_hands_heavy_and_odd_rows_to_the_generic_kernel():
+    """Rows the wave kernel cannot take — more than 63 trips, more than 64 m1 entries (no trip records), collision set or member
+    pool overflow (many products on few columns) — join the generic queue; empty rows and rows pointing at empty m2 rows stay."""
+    urm, wt = _scoring_problem(n_users=3000, seed=5)
+    urm = urm.tolil()
+    urm[10, :] = 0                                          # an empty row
+    urm[11, :3000:10] = 1.0                                 # 300 m1 entries: no trip records
+    wt = wt.tolil()
+    wt[7, :] = 0                                            # an empty m2 row ...
+    urm[12, 7] = 2.0                                        # ... that a row points at
+    wt[100, ::40] = 0.5                                     # a 1000-element m2 row: 4 trips of one segment
+    urm[13, 100] = 1.0
+    wt[200:232, 5000:5200] = 0.25                           # 32 m2 rows hitting the same 200 columns: 6400 products on 200 columns
+    urm[14, 200:232] = 1.0
+    urm, wt = sp.csr_array(urm.tocsr()), sp.csr_array(wt.tocsr())
+    call = _host.prepare(urm, wt, k=40, filter_cols=urm)
+    ran, info = _ran_on_the_wave_kernel(call, threads_per_wg=64)
+    assert ran
+    assert info["phase_cycles"][10] >= 1, "no row was handed to the generic kernel"
+    _check(call, "wave kernel odd rows", threads_per_wg=64)
+
+
+def test_wave_kernel_tied_values_and_repeated_calls():
+    """Binary data: every product is 1, the k-th place is a mass tie (the selection keeps exactly k, any of the tied); and the same
+    call repeated gives the same kept VALUES every time (no LDS state leaks from row to row or call to call)."""
+    urm, wt = _scoring_problem(n_users=4000, seed=8)
+    call = _host.prepare(urm, wt, k=30, filter_cols=urm, binary=True)
+    assert _ran_on_the_wave_kernel(call, threads_per_wg=64)[0]
+    _check(call, "wave kernel binary", threads_per_wg=64)
+    call2 = _host.prepare(urm, wt, k=64)
+    first = None
+    for _ in range(5):
+        rows, cols, vals, counts = _host.run_hip(call2, threads_per_wg=64)
+        kept = np.sort(vals.reshape(call2.n_targets, call2.k), axis=1)
+        if first is None:
+            first = kept
+            _check(call2, "wave kernel repeat", threads_per_wg=64)
+        else:
+            np.testing.assert_allclose(kept, first, rtol=1e-6, atol=0)
