@@ -14,7 +14,7 @@ for G in "${PMCG[@]}"; do
   i=$((i+1))
   rocprofv3 --pmc $G --kernel-trace --output-format csv -d /tmp/rp_${TAG}_$i -o pmc -- $BENCH > /dev/null 2> "$OUT/pass$i.log"
   f=$(find /tmp/rp_${TAG}_$i -name "*counter_collection.csv" | head -1)
-  if [ -n "$f" ]; then (head -1 "$f"; grep sp_knn_sparse "$f") > "$OUT/pass$i.csv"; fi
+  if [ -n "$f" ]; then (head -1 "$f"; grep -E "sp_knn_(sparse|wave)" "$f") > "$OUT/pass$i.csv"; fi
 done
 python - "$OUT" <<'PY'
 import csv, sys, glob, collections

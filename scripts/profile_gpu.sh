@@ -23,7 +23,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   f=$(find /tmp/rp_pmc_${C}_$TAG -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then
     # keep only our kernel's rows (header + sp_knn rows)
-    (head -1 "$f"; grep sp_knn_sparse "$f") > "$OUT/pmc_$C.csv"
+    (head -1 "$f"; grep -E "sp_knn_(sparse|wave)" "$f") > "$OUT/pmc_$C.csv"
   fi
 done
 ls -la "$OUT"

@@ -249,10 +249,11 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
     // Light rows (user scoring: a few thousand products over <= 2^17 columns, k <= 128, monotone epilogue): one WAVE per row, eight rows
     // in flight per CU (sp_wave_kernel.hpp) — when the average row fits its 63 packed trips with room to spare, or on request
     c->wave = c->items_rows > 0 && c->mono && NT_s == 256 && a->n_output_cols <= (1 << WV_BM_LOG2) && a->n_output_cols > T && a->k <= WV_KMAX &&
-              !(a->reserved[0] & 16384) && (want_wave || avg_macs <= 10000.0);
+              !(a->reserved[0] & 16384) && (want_wave || (!a->threads_per_wg && avg_macs <= 10000.0));
     if (c->wave) {
         c->nb_log2 = WV_BM_LOG2;
-        c->wgs_sparse = std::max(1, std::min(a->num_wgs > 0 ? a->num_wgs : n_cus * (int)(LDS_LIMIT / WV_LDS_BYTES), std::max(1, a->n_targets)));
+        const int wv_a = a->n_output_cols <= 8 * WV_A_SMALL ? WV_A_SMALL : WV_A_LARGE;      // the column bitmap: eleven or nine rows in flight per CU
+        c->wgs_sparse = std::max(1, std::min(a->num_wgs > 0 ? a->num_wgs : n_cus * (int)(LDS_LIMIT / wv_lds_bytes(wv_a)), std::max(1, a->n_targets)));
     }
     c->ws_total = WS_QUEUE_BYTES + c->ws_gu_bytes + c->ws_fold_bytes + c->ws_rows_bytes + c->ws_split_bytes + c->ws_piece_bytes + c->ws_items_bytes;
     return SP_OK;
@@ -337,8 +338,13 @@ int launch_rows(const KParams &kp_s, const KParams &kp, const Config &c, hipStre
     // sparse rows first; what it cannot finish joins the generic queue, which the second launch drains
     if (ev) HIP_TRY(hipEventRecord(ev[0], stream));
     if (kp.sparse_path && c.wave) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(sp_knn_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WV_LDS_BYTES));
-        hipLaunchKernelGGL(sp_knn_wave_kernel, dim3(c.wgs_sparse), dim3(64), WV_LDS_BYTES, stream, kp_s);
+        if (kp_s.n_cols <= 8 * WV_A_SMALL) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(sp_knn_wave_kernel<WV_A_SMALL>), hipFuncAttributeMaxDynamicSharedMemorySize, wv_lds_bytes(WV_A_SMALL)));
+            hipLaunchKernelGGL(sp_knn_wave_kernel<WV_A_SMALL>, dim3(c.wgs_sparse), dim3(64), wv_lds_bytes(WV_A_SMALL), stream, kp_s);
+        } else {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(sp_knn_wave_kernel<WV_A_LARGE>), hipFuncAttributeMaxDynamicSharedMemorySize, wv_lds_bytes(WV_A_LARGE)));
+            hipLaunchKernelGGL(sp_knn_wave_kernel<WV_A_LARGE>, dim3(c.wgs_sparse), dim3(64), wv_lds_bytes(WV_A_LARGE), stream, kp_s);
+        }
         HIP_TRY(hipGetLastError());
     } else if (kp.sparse_path) {
         int rc;

@@ -16,7 +16,7 @@
 //   sweep 2 (ids + values)    x = value * m1 value; products of marked columns -> member pool; every other product is the only
 //                             one of its column and goes to the candidate buffer U (256 entries) iff x beats the running k-th
 //                             value; a full U is cut back to its k largest by a wave-local MSD radix selection;
-//   accumulate, drain         members find their slot by the rank of their column's bit (64-bit compare-and-swap claims / adds),
+//   accumulate, drain         members find their slot by the rank of their column's bit (32-bit compare-and-swap claims, float add),
 //                             complete sums above the cutoff join U; excluded (filter) columns carry a -inf pseudo member;
 //   select, write-out         exact top-k, epilogue val = xy / den (or the raw dot), threshold, compaction.
 // Work items: the packed trips sp_row_items_kernel cuts once per call (lane T of the wave holds trip T's record: at most 63
@@ -26,21 +26,32 @@
 
 namespace {
 
-constexpr int WV_BM_LOG2 = 17;                                  // column bitmap: 2^17 bits
+#ifndef WV_D1
+#define WV_D1 8      // trips in flight per wave, sweep 1 / sweep 2
+#endif
+#ifndef WV_D2
+#define WV_D2 6
+#endif
+constexpr int WV_BM_LOG2 = 17;                                  // column bitmap: up to 2^17 bits
 constexpr int WV_CBM_BYTES = 1024;                              // collision bitmap: 8192 bits
 constexpr int WV_PRE_BYTES = 512;                               // u16 rank prefix per collision-bitmap word
-constexpr int WV_A_BYTES = (1 << WV_BM_LOG2) / 8;               // region A = the bitmap = 16 KB
 constexpr int WV_CSN = 1024;                                    // collision-set slots: [0, 512) by rank, [512, 1024) overflow
-constexpr int WV_MPCAP = 1024;                                  // member pool entries
 constexpr int WV_UCAP = 256;                                    // candidate buffer entries (four per lane)
 constexpr int WV_KMAX = 128;                                    // k + 64 <= UCAP must hold with room to spare
 constexpr int WV_OFF_PRE = WV_CBM_BYTES;
 constexpr int WV_OFF_A = WV_CBM_BYTES + WV_PRE_BYTES;
 constexpr int WV_OFF_MP = WV_OFF_A + WV_CSN * 8;
-constexpr int WV_OFF_U = WV_OFF_A + WV_A_BYTES;
-constexpr int WV_LDS_BYTES = WV_OFF_U + WV_UCAP * 8;            // 19 968 B: eight waves per CU
-static_assert(WV_CSN * 8 + WV_MPCAP * 8 == WV_A_BYTES, "collision set + member pool = the bitmap's storage");
-static_assert(8 * WV_LDS_BYTES <= 160 * 1024, "eight rows per CU");
+// Region A is the column bitmap during sweep 1 and afterwards [collision set 8 KB | member pool | U 2 KB].  Two sizes:
+//   12 800 B (102 400 columns): member pool 320 entries, 14 336 B of LDS per wave = ELEVEN rows in flight per CU;
+//   16 384 B (131 072 columns): member pool 768 entries, 17 920 B per wave = nine rows per CU.
+// The member pool is small on purpose: when a trip's members do not fit, the pool is folded into the collision set right away
+// (wave_accumulate) and starts over — LDS per wave is what bounds the rows in flight, and those are what hides this kernel's latencies.
+constexpr int WV_A_SMALL = 12800, WV_A_LARGE = 16384;
+__host__ __device__ constexpr int wv_mpcap(int a_bytes) { return (a_bytes - WV_CSN * 8 - WV_UCAP * 8) / 8; }
+__host__ __device__ constexpr int wv_off_u(int a_bytes) { return WV_OFF_A + a_bytes - WV_UCAP * 8; }
+__host__ __device__ constexpr int wv_lds_bytes(int a_bytes) { return WV_OFF_A + a_bytes; }
+static_assert(wv_mpcap(WV_A_SMALL) >= 256 + 64, "a trip's members (<= 256) fit an empty pool, the filter's pseudo members a fresh one");
+static_assert(11 * wv_lds_bytes(WV_A_SMALL) <= 160 * 1024 && 9 * wv_lds_bytes(WV_A_LARGE) <= 160 * 1024, "rows per CU");
 
 // Sweep 2 core for a collision bitmap of WV_CBM_BYTES at LDS offset 0 (sp_common.hpp's s2_core with this kernel's mask).
 __device__ __forceinline__ void s2_core_w(const unsigned (&c)[4], const float (&v)[4], float segv, float cut, float (&x)[4], u64 (&M)[4], u64 (&L)[4]) {
@@ -86,9 +97,10 @@ __device__ __forceinline__ void s2_core_w(const unsigned (&c)[4], const float (&
 
 // Wave-local exact selection: the n (> k) entries {key : column} of U[0, n) are cut back to the k with the largest keys (ties at
 // the k-th place resolved arbitrarily, as the reference's heap does), compacted to U[0, k), the tail zeroed.  MSD radix select,
-// four 8-bit digits: every lane holds four entries in registers; one 256-counter histogram per digit in LDS (`hist`: zero on
-// entry and on exit), each lane reads four counters back, a DPP scan finds the digit of the k-th largest.  Returns its key.
-__device__ __forceinline__ unsigned wave_select(u64 *U, int *hist, int n, int k, int lane) {
+// four 8-bit digits: every lane holds four entries in registers; one 256-counter histogram per digit in LDS (U's first KB), each lane reads four counters back, a DPP scan finds the digit of the k-th largest.  Returns its key.
+// (a real call: four or five selections per row, ten call sites in the unrolled sweeps — inlined they are 15 k lines of ISA and the
+// sweeps' load pipeline falls apart)
+__device__ __attribute__((noinline)) unsigned wave_select(u64 *U, int n, int k, int lane) {
     u64 e[4];
     unsigned key[4];
     bool live[4];
@@ -99,6 +111,10 @@ __device__ __forceinline__ unsigned wave_select(u64 *U, int *hist, int n, int k,
         e[j] = live[j] ? U[i] : 0ull;
         key[j] = (unsigned)(e[j] >> 32);
     }
+    // the histogram lives in U's own first KB: the entries are in registers now (no other LDS of the wave is free at every call site)
+    int *hist = (int *)U;
+    ((int4 *)hist)[lane] = make_int4(0, 0, 0, 0);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     unsigned prefix = 0u, pmask = 0u;
     int need = k;
 #pragma unroll
@@ -154,7 +170,82 @@ __device__ __forceinline__ unsigned wave_select(u64 *U, int *hist, int n, int k,
     return prefix;
 }
 
-__global__ __launch_bounds__(64) void sp_knn_wave_kernel(const KParams p) {
+// The rare side of a sweep-2 trip: its survivors do not fit U.  U is cut back to its k largest (their smallest is the new cutoff,
+// applied to what is left of the trip), quad by quad: k + 64 <= WV_UCAP, so one quad always fits behind a selection.
+// A real call (one site per unrolled trip body): values in, the new {entries in U, cutoff} out.
+struct WaveUState { int ucnt; float cutx; };
+__device__ __attribute__((noinline)) WaveUState wave_push_slow(u64 *U, unsigned u_off, unsigned c0, unsigned c1, unsigned c2, unsigned c3, float x0, float x1, float x2,
+                                                               float x3, u64 S0, u64 S1, u64 S2, u64 S3, int ucnt, float cutx, float cutx0, int k, int lane) {
+    const unsigned c[4] = {c0, c1, c2, c3};
+    const float x[4] = {x0, x1, x2, x3};
+    u64 S[4] = {S0, S1, S2, S3};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int ns = __popcll(S[j]);
+        if (ns && ucnt + ns > WV_UCAP) {
+            const unsigned tk = wave_select(U, ucnt, k, lane);
+            ucnt = min(ucnt, k);
+            cutx = fmaxf(cutx0, funkey(tk));
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) if (jj >= j) S[jj] &= __ballot(!(x[jj] <= cutx));
+            ns = __popcll(S[j]);
+        }
+        if (ns) { lds_push64(S[j], c[j], fkey(x[j]), ucnt, u_off); ucnt += ns; }
+    }
+    return WaveUState{ucnt, cutx};
+}
+
+// Members -> collision set: find-or-insert, {column + 1 : sum} slots, key word 0 = free.  The direct slot is the rank of the column's
+// bit in the collision bitmap; a slot taken by another column (bits alias) sends the entry to a hashed start in the overflow half,
+// then on linearly.  ONE wave owns the set: a 32-bit compare-and-swap on the key word claims the slot (or finds it the column's
+// already), then the product goes in with the hardware float add — 0.33 lanes/clk on gfx950 (profiles/r02_lds_atomics_bench.txt),
+// ~2 k cycles for a row's ~700 members, against five dependent round trips per pass of the 64-bit compare-and-swap form the 16-wave
+// kernel needs (its slots are contended).  Returns true when the set is full (the row goes to the generic kernel).
+__device__ __attribute__((noinline)) bool wave_accumulate(u64 *cs, const u64 *mpool, const unsigned char *cbm, const unsigned short *pre16, int mcnt, int lane) {
+    auto next_slot = [&](unsigned h, unsigned key) __attribute__((always_inline)) -> unsigned {
+        const unsigned half = (unsigned)(WV_CSN / 2);
+        return (h < half) ? half + hash_bits((int)key, 2654435761u, 32 - 9) : half + ((h + 1u) & (half - 1u));
+    };
+    constexpr int JA = 4;
+    unsigned *csw = (unsigned *)cs;                      // word 2h: the sum, word 2h + 1: the key
+    bool failed = false;
+    for (int base = 0; base < mcnt && !failed; base += JA * 64) {
+        unsigned kk[JA], h[JA];
+        float xx[JA];
+        bool act[JA];
+#pragma unroll
+        for (int j = 0; j < JA; ++j) {
+            const int i = base + j * 64 + lane;
+            const u64 e = (i < mcnt) ? mpool[i] : 0ull;
+            kk[j] = (unsigned)(e >> 32);
+            xx[j] = __uint_as_float((unsigned)e);
+            act[j] = (e != 0ull);
+            const unsigned cm = kk[j] - 1u;
+            const unsigned wi = (cm >> 5) & (unsigned)(WV_CBM_BYTES / 4 - 1);
+            const unsigned bw = ((const unsigned *)cbm)[wi];
+            h[j] = (unsigned)pre16[wi] + (unsigned)__popc(bw & ((1u << (cm & 31u)) - 1u));
+        }
+        int rounds = 0;
+        while (__ballot((act[0] | act[1]) | (act[2] | act[3]))) {
+            unsigned r[JA];
+#pragma unroll
+            for (int j = 0; j < JA; ++j) r[j] = act[j] ? atomicCAS(&csw[2 * h[j] + 1], 0u, kk[j]) : 0u;
+#pragma unroll
+            for (int j = 0; j < JA; ++j) {
+                if (act[j]) {
+                    if (r[j] == 0u || r[j] == kk[j]) { atomicAdd((float *)&csw[2 * h[j]], xx[j]); act[j] = false; }
+                    else h[j] = next_slot(h[j], kk[j]);          // another column's slot
+                }
+            }
+            if (++rounds > 4 * CS_MAXPROBE) { failed = true; break; }      // set full
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    return failed;
+}
+
+template <int A_BYTES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void sp_knn_wave_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
     unsigned char *cbm = smem;
@@ -162,22 +253,22 @@ __global__ __launch_bounds__(64) void sp_knn_wave_kernel(const KParams p) {
     unsigned char *rA = smem + WV_OFF_A;
     u64 *cs = (u64 *)rA;
     u64 *mpool = (u64 *)(smem + WV_OFF_MP);
-    u64 *U = (u64 *)(smem + WV_OFF_U);
-    int *hist = (int *)rA;                     // the selections' histogram: the collision set's first KB (empty whenever a selection runs)
+    constexpr int MPCAP = wv_mpcap(A_BYTES);
+    constexpr unsigned U_OFF = (unsigned)wv_off_u(A_BYTES);
+    constexpr int LDS_BYTES = wv_lds_bytes(A_BYTES);
+    u64 *U = (u64 *)(smem + U_OFF);
     if ((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();
     const __amdgpu_buffer_rsrc_t rs_idx = __builtin_amdgcn_make_buffer_rsrc((void *)p.m2_indices, 0, (int)p.m2_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_val = __builtin_amdgcn_make_buffer_rsrc((void *)p.m2_data, 0, (int)p.m2_bytes, 0x00020000);
-    for (int i = lane; i < WV_LDS_BYTES / 16; i += 64) ((int4 *)smem)[i] = make_int4(0, 0, 0, 0);
+    for (int i = lane; i < LDS_BYTES / 16; i += 64) ((int4 *)smem)[i] = make_int4(0, 0, 0, 0);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
     const bool any_norm = (p.l1 != 0.f || p.l2 != 0.f || p.l3 != 0.f || p.stab != 0.f || p.bayes != 0.f);
-    const unsigned amask = (unsigned)(WV_A_BYTES - 1) & ~3u;
+    const unsigned amask = (unsigned)((1 << (WV_BM_LOG2 - 3)) - 1) & ~3u;      // (column ids are below n_cols <= 8 * A_BYTES)
+    // phase timers (profiling passes only): lane 0 adds every interval straight to the global counters — no registers held for them
     const bool timing = (p.phase_cycles != nullptr) && lane == 0;
-    u64 ph[PH_N];
-#pragma unroll
-    for (int i = 0; i < PH_N; ++i) ph[i] = 0;
     u64 tmark = timing ? (u64)clock64() : 0;
-#define WV_PHASE_END(which) do { if (timing) { const u64 _n = (u64)clock64(); ph[which] += _n - tmark; tmark = _n; } } while (0)
+#define WV_PHASE_END(which) do { if (timing) { const u64 _n = (u64)clock64(); atomicAdd(&p.phase_cycles[which], _n - tmark); tmark = _n; } } while (0)
 
     const int n_rows = (int)p.qcount[0];
     const int k = p.k;
@@ -233,6 +324,9 @@ __global__ __launch_bounds__(64) void sp_knn_wave_kernel(const KParams p) {
             sv = __uint_as_float((unsigned)__builtin_amdgcn_readlane(recA.z, tl));
             if (lane >= sB) { vo = oB + (lane - sB) * 16; d = cB - 4 * (lane - sB); sv = __uint_as_float((unsigned)__builtin_amdgcn_readlane(recB.z, tl)); }
             if (d <= 0) vo = (int)OOB_SOFFSET;         // lanes beyond the pieces fetch nothing
+#if SP_ABLATION
+            if ((p.dbg & 512) && d > 0) vo = lane * 16 + (T & 3) * 1024;      // ablation: every trip reads the same 4 KB (cache hits only)
+#endif
         };
 
         if (!failed) {
@@ -249,24 +343,56 @@ __global__ __launch_bounds__(64) void sp_knn_wave_kernel(const KParams p) {
                 };
                 auto body = [&](int T, const u32x4 &ids, int d) __attribute__((always_inline)) {
                     if (T >= n_tr) return;
+#if SP_ABLATION
+                    if (p.dbg & 8) { asm volatile("" ::"v"(ids)); return; }      // ablation: loads only
+#endif
                     const unsigned c[4] = {ids.x, ids.y, ids.z, ids.w};
-                    const unsigned one[4] = {d > 0 ? 1u : 0u, d > 1 ? 1u : 0u, d > 2 ? 1u : 0u, d > 3 ? 1u : 0u};
+                    // padding at QUAD granularity (as s1_core8q): a lane without a real element ORs nothing and reports nothing; the lane
+                    // that holds a piece's last elements treats its whole quad as real — the up to three ids behind the piece's end
+                    // (the next m2 row's first ids, or 0 behind the array's end) set bits nobody asked for, which is safe: a column
+                    // marked without a second product only takes the collision-set route, where the sum of its one product is exact
+                    const unsigned o = d > 0 ? 1u : 0u;
+                    const unsigned one[4] = {o, o, o, o};
                     unsigned seen[4];
                     s1_core<WV_OFF_A, true>(c, one, amask, seen);
-                    if (__ballot(((seen[0] | seen[1]) | (seen[2] | seen[3])) != 0u)) {
+                    // a few of a trip's products find their column's bit set; a LANE rarely has two: its column is then the sum of
+                    // seen[j] * c[j] (v_mad_u32_u24: columns are below 2^17) and goes out in ONE masked atomic
+                    const unsigned cnt = (seen[0] + seen[1]) + (seen[2] + seen[3]);
+                    if (__ballot(cnt != 0u)) {
+                        unsigned cs1;
+                        asm("v_mul_u32_u24 %0, %1, %5\n\t"
+                            "v_mad_u32_u24 %0, %2, %6, %0\n\t"
+                            "v_mad_u32_u24 %0, %3, %7, %0\n\t"
+                            "v_mad_u32_u24 %0, %4, %8, %0"
+                            : "=&v"(cs1)
+                            : "v"(seen[0]), "v"(seen[1]), "v"(seen[2]), "v"(seen[3]), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]));
+                        if (cnt == 1u) atomicOr((unsigned *)(cbm + ((cs1 >> 3) & (unsigned)(WV_CBM_BYTES - 4))), 1u << (cs1 & 31u));
+                        if (__ballot(cnt > 1u)) {
+                            if (cnt > 1u) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (seen[j]) atomicOr((unsigned *)(cbm + ((c[j] >> 3) & (unsigned)(WV_CBM_BYTES - 4))), 1u << (c[j] & 31u));
+                                for (int j = 0; j < 4; ++j)
+                                    if (seen[j]) atomicOr((unsigned *)(cbm + ((c[j] >> 3) & (unsigned)(WV_CBM_BYTES - 4))), 1u << (c[j] & 31u));
+                            }
+                        }
                     }
                 };
-                u32x4 b0, b1, b2, b3;
-                int e0, e1, e2, e3;
-                ld(0, b0, e0); ld(1, b1, e1); ld(2, b2, e2); ld(3, b3, e3);
-                for (int T = 0; T < n_tr; T += 4) {
-                    body(T, b0, e0); ld(T + 4, b0, e0);
-                    body(T + 1, b1, e1); ld(T + 5, b1, e1);
-                    body(T + 2, b2, e2); ld(T + 6, b2, e2);
-                    body(T + 3, b3, e3); ld(T + 7, b3, e3);
+                // D1 trips in flight.  The order "body of trip T, then the load of trip T + D1 into the registers it freed" is pinned
+                // with scheduling barriers: left alone the compiler sinks the loads to the loop's end and waits for ALL of them
+                // (s_waitcnt vmcnt(0)) at its top — a batch, not a pipeline
+                constexpr int D1 = WV_D1;
+                u32x4 b[D1];
+                int e[D1];
+#pragma unroll
+                for (int i = 0; i < D1; ++i) ld(i, b[i], e[i]);
+                __builtin_amdgcn_sched_barrier(0);
+                for (int T = 0; T < n_tr; T += D1) {
+#pragma unroll
+                    for (int i = 0; i < D1; ++i) {
+                        body(T + i, b[i], e[i]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        ld(T + i + D1, b[i], e[i]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             }
             // excluded columns: marked in the collision bitmap, so all their products gather in the collision set
@@ -281,8 +407,7 @@ __global__ __launch_bounds__(64) void sp_knn_wave_kernel(const KParams p) {
             WV_PHASE_END(PH_SWEEP1);
 
             // ---- the bitmap has done its job: back to zero; rank prefix of the collision bitmap ----
-#pragma unroll
-            for (int i = 0; i < WV_A_BYTES / (64 * 16); ++i) ((int4 *)rA)[i * 64 + lane] = make_int4(0, 0, 0, 0);
+            for (int i = lane; i < A_BYTES / 16; i += 64) ((int4 *)rA)[i] = make_int4(0, 0, 0, 0);
             {
                 const int4 w4 = ((const int4 *)cbm)[lane];           // 256 words: four per lane
                 const int p0 = __popc((unsigned)w4.x), p1 = p0 + __popc((unsigned)w4.y), p2 = p1 + __popc((unsigned)w4.z);
@@ -296,14 +421,12 @@ __global__ __launch_bounds__(64) void sp_knn_wave_kernel(const KParams p) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             // every excluded column gets a pseudo member of value -inf: its sum is then below any cutoff
             if (p.filter_mode == SP_SEL_MATRIX && !failed) {
-                if (fl > WV_MPCAP / 2) failed = true;
-                else {
-                    for (int i0 = 0; i0 < fl; i0 += 64) {
-                        const int c = (i0 == 0) ? my_fc : ((i0 + lane < fl) ? p.f_indices[f0 + i0 + lane] : -1);
-                        const u64 m = __ballot(c >= 0);
-                        if (c >= 0) mpool[mcnt + mbcnt64(m)] = ((u64)((unsigned)c + 1u) << 32) | (u64)0xFF800000u;
-                        mcnt += __popcll(m);
-                    }
+                for (int i0 = 0; i0 < fl && !failed; i0 += 64) {
+                    const int c = (i0 == 0) ? my_fc : ((i0 + lane < fl) ? p.f_indices[f0 + i0 + lane] : -1);
+                    const u64 m = __ballot(c >= 0);
+                    if (mcnt + __popcll(m) > MPCAP) { failed = wave_accumulate(cs, mpool, cbm, pre16, mcnt, lane); mcnt = 0; }
+                    if (c >= 0) mpool[mcnt + mbcnt64(m)] = ((u64)((unsigned)c + 1u) << 32) | (u64)0xFF800000u;
+                    mcnt += __popcll(m);
                 }
             }
             WV_PHASE_END(PH_SEGMENTS);
@@ -319,6 +442,9 @@ __global__ __launch_bounds__(64) void sp_knn_wave_kernel(const KParams p) {
             };
             auto body = [&](int T, const u32x4 &ids, const u32x4 &vals, int d, float sv) __attribute__((always_inline)) {
                 if (T >= n_tr || failed) return;
+#if SP_ABLATION
+                if (p.dbg & 16) { asm volatile("" ::"v"(ids), "v"(vals)); return; }      // ablation: loads only
+#endif
                 const unsigned c[4] = {ids.x, ids.y, ids.z, ids.w};
                 const float v[4] = {__uint_as_float(vals.x), __uint_as_float(vals.y), __uint_as_float(vals.z), __uint_as_float(vals.w)};
                 float x[4];
@@ -328,103 +454,80 @@ __global__ __launch_bounds__(64) void sp_knn_wave_kernel(const KParams p) {
                 for (int j = 0; j < 4; ++j) {
                     const u64 ok = __ballot(j < d);
                     M[j] &= ok;
-                    S[j] &= ok & ~M[j];
+                    S[j] &= ok;
                 }
-                // products of marked columns: the member pool
+                // products of marked columns: the member pool.  A trip nearly always holds some, a LANE rarely more than one: the first
+                // member of every lane goes out in ONE push, second and later members of a lane in the rare pushes behind it
                 const u64 Many = (M[0] | M[1]) | (M[2] | M[3]);
                 if (Many) {
-                    const int nm = (__popcll(M[0]) + __popcll(M[1])) + (__popcll(M[2]) + __popcll(M[3]));
-                    if (mcnt + nm > WV_MPCAP) { failed = true; return; }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (M[j]) { lds_push64(M[j], __float_as_uint(x[j]), c[j] + 1u, mcnt, (unsigned)WV_OFF_MP); mcnt += __popcll(M[j]); }
+                    const u64 R1 = M[1] & M[0], R2 = M[2] & (M[0] | M[1]), R3 = M[3] & ((M[0] | M[1]) | M[2]);
+                    const int n0 = __popcll(Many), n1 = __popcll(R1), n2 = __popcll(R2), n3 = __popcll(R3);
+                    if (mcnt + (n0 + n1) + (n2 + n3) > MPCAP) {
+                        // the pool is folded into the collision set right away and starts over
+                        failed = wave_accumulate(cs, mpool, cbm, pre16, mcnt, lane);
+                        mcnt = 0;
+                        if (failed) return;
+                    }
+                    const unsigned xm = mask_select(M[0], __float_as_uint(x[0]), mask_select(M[1], __float_as_uint(x[1]), mask_select(M[2], __float_as_uint(x[2]), __float_as_uint(x[3]))));
+                    const unsigned cm = mask_select(M[0], c[0], mask_select(M[1], c[1], mask_select(M[2], c[2], c[3])));
+                    lds_push64(Many, xm, cm + 1u, mcnt, (unsigned)WV_OFF_MP);
+                    mcnt += n0;
+                    if ((R1 | R2) | R3) {
+                        if (n1) lds_push64(R1, __float_as_uint(x[1]), c[1] + 1u, mcnt, (unsigned)WV_OFF_MP);
+                        mcnt += n1;
+                        if (n2) lds_push64(R2, __float_as_uint(x[2]), c[2] + 1u, mcnt, (unsigned)WV_OFF_MP);
+                        mcnt += n2;
+                        if (n3) lds_push64(R3, __float_as_uint(x[3]), c[3] + 1u, mcnt, (unsigned)WV_OFF_MP);
+                        mcnt += n3;
                     }
                 }
-                // every other product is the only one of its column: into U iff it beats the running k-th value
+                // every other product is the only one of its column: into U iff it beats the running k-th value (rare once the cutoff
+                // has settled: the masks are only cut when there is something to cut)
                 if ((S[0] | S[1]) | (S[2] | S[3])) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        int ns = __popcll(S[j]);
-                        if (ns && ucnt + ns > WV_UCAP) {
-                            // U is full: back to its k largest; their smallest is the new cutoff, applied to what is left of this trip
-                            const unsigned tk = wave_select(U, hist, ucnt, k, lane);
-                            ucnt = min(ucnt, k);
-                            cutx = fmaxf(cutx0, funkey(tk));
-#pragma unroll
-                            for (int jj = 0; jj < 4; ++jj) if (jj >= j) S[jj] &= __ballot(!(x[jj] <= cutx));
-                            ns = __popcll(S[j]);
+                    for (int j = 0; j < 4; ++j) S[j] &= ~M[j];
+                    if ((S[0] | S[1]) | (S[2] | S[3])) {
+                        const int n0 = __popcll(S[0]), n1 = __popcll(S[1]), n2 = __popcll(S[2]), n3 = __popcll(S[3]);
+                        if (ucnt + (n0 + n1) + (n2 + n3) > WV_UCAP) {
+                            const WaveUState r = wave_push_slow(U, U_OFF, c[0], c[1], c[2], c[3], x[0], x[1], x[2], x[3], S[0], S[1], S[2], S[3], ucnt, cutx, cutx0, k, lane);
+                            ucnt = __builtin_amdgcn_readfirstlane(r.ucnt);
+                            cutx = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(r.cutx)));
+                        } else {
+                            if (n0) lds_push64(S[0], c[0], fkey(x[0]), ucnt, U_OFF);
+                            ucnt += n0;
+                            if (n1) lds_push64(S[1], c[1], fkey(x[1]), ucnt, U_OFF);
+                            ucnt += n1;
+                            if (n2) lds_push64(S[2], c[2], fkey(x[2]), ucnt, U_OFF);
+                            ucnt += n2;
+                            if (n3) lds_push64(S[3], c[3], fkey(x[3]), ucnt, U_OFF);
+                            ucnt += n3;
                         }
-                        if (ns) { lds_push64(S[j], c[j], fkey(x[j]), ucnt, (unsigned)WV_OFF_U); ucnt += ns; }
                     }
                 }
             };
-            u32x4 i0, i1, i2, i3, v0, v1, v2, v3;
-            int e0, e1, e2, e3;
-            float s0, s1, s2, s3;
-            ld(0, i0, v0, e0, s0); ld(1, i1, v1, e1, s1); ld(2, i2, v2, e2, s2); ld(3, i3, v3, e3, s3);
-            for (int T = 0; T < n_tr; T += 4) {
-                body(T, i0, v0, e0, s0); ld(T + 4, i0, v0, e0, s0);
-                body(T + 1, i1, v1, e1, s1); ld(T + 5, i1, v1, e1, s1);
-                body(T + 2, i2, v2, e2, s2); ld(T + 6, i2, v2, e2, s2);
-                body(T + 3, i3, v3, e3, s3); ld(T + 7, i3, v3, e3, s3);
+            constexpr int D2 = WV_D2;
+            u32x4 bi[D2], bv[D2];
+            int e[D2];
+            float sg[D2];
+#pragma unroll
+            for (int i = 0; i < D2; ++i) ld(i, bi[i], bv[i], e[i], sg[i]);
+            __builtin_amdgcn_sched_barrier(0);
+            for (int T = 0; T < n_tr; T += D2) {
+#pragma unroll
+                for (int i = 0; i < D2; ++i) {
+                    body(T + i, bi[i], bv[i], e[i], sg[i]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ld(T + i + D2, bi[i], bv[i], e[i], sg[i]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             WV_PHASE_END(PH_SWEEP2);
         }
 
         if (!failed) {
-            // ---- members: find-or-insert in the collision set, {column + 1 : sum} slots, 0 = free.  The direct slot is the rank of
-            // the column's bit in the collision bitmap; a slot taken by another column (bits alias) sends the entry to a hashed
-            // start in the overflow half, then on linearly.  One 64-bit compare-and-swap claims a free slot with the product in it
-            // or adds to the sum last seen; a lost race against another product of the column falls back to the hardware add. ----
-            auto next_slot = [&](unsigned h, unsigned key) __attribute__((always_inline)) -> unsigned {
-                const unsigned half = (unsigned)(WV_CSN / 2);
-                return (h < half) ? half + hash_bits((int)key, 2654435761u, 32 - 9) : half + ((h + 1u) & (half - 1u));
-            };
-            constexpr int JA = 4;
-            for (int base = 0; base < mcnt && !failed; base += JA * 64) {
-                u64 cur[JA];
-                unsigned kk[JA], h[JA];
-                float xx[JA];
-                bool act[JA];
-#pragma unroll
-                for (int j = 0; j < JA; ++j) {
-                    const int i = base + j * 64 + lane;
-                    const u64 e = (i < mcnt) ? mpool[i] : 0ull;
-                    kk[j] = (unsigned)(e >> 32);
-                    xx[j] = __uint_as_float((unsigned)e);
-                    act[j] = (e != 0ull);
-                    const unsigned cm = kk[j] - 1u;
-                    const unsigned wi = (cm >> 5) & (unsigned)(WV_CBM_BYTES / 4 - 1);
-                    const unsigned bw = ((const unsigned *)cbm)[wi];
-                    h[j] = (unsigned)pre16[wi] + (unsigned)__popc(bw & ((1u << (cm & 31u)) - 1u));
-                    cur[j] = 0ull;
-                }
-                int rounds = 0;
-                while (__ballot((act[0] | act[1]) | (act[2] | act[3]))) {
-                    u64 r[JA];
-#pragma unroll
-                    for (int j = 0; j < JA; ++j) {
-                        r[j] = 0ull;
-                        if (act[j]) {
-                            const float add = (cur[j] == 0ull) ? xx[j] : __uint_as_float((unsigned)cur[j]) + xx[j];
-                            r[j] = atomicCAS(&cs[h[j]], cur[j], ((u64)kk[j] << 32) | (u64)__float_as_uint(add));
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < JA; ++j) {
-                        if (act[j]) {
-                            if (r[j] == cur[j]) act[j] = false;
-                            else if ((unsigned)(r[j] >> 32) == kk[j]) {
-                                if (cur[j] == 0ull) cur[j] = r[j];
-                                else { atomicAdd((float *)&cs[h[j]], xx[j]); act[j] = false; }
-                            } else { h[j] = next_slot(h[j], kk[j]); cur[j] = 0ull; }
-                        }
-                    }
-                    if (++rounds > 4 * CS_MAXPROBE) { failed = true; break; }      // set full
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            // ---- what is left in the member pool joins the collision set ----
+            failed = wave_accumulate(cs, mpool, cbm, pre16, mcnt, lane);
             // the member pool is consumed: its storage (and the collision bitmap) go back to zero at the row's end
             WV_PHASE_END(PH_ACCUM);
         }
@@ -458,8 +561,7 @@ __global__ __launch_bounds__(64) void sp_knn_wave_kernel(const KParams p) {
                     u64 m = __ballot(want[j]);
                     int ns = __popcll(m);
                     if (ns && ucnt + ns > WV_UCAP) {
-                        // (the histogram lives in the set's first KB: those slots have been read and zeroed above)
-                        const unsigned tk = wave_select(U, hist, ucnt, k, lane);
+                        const unsigned tk = wave_select(U, ucnt, k, lane);
                         ucnt = min(ucnt, k);
                         cutx = fmaxf(cutx0, funkey(tk));
 #pragma unroll
@@ -476,7 +578,7 @@ __global__ __launch_bounds__(64) void sp_knn_wave_kernel(const KParams p) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             WV_PHASE_END(PH_DRAIN);
             if (ucnt > k) {
-                wave_select(U, hist, ucnt, k, lane);
+                wave_select(U, ucnt, k, lane);
                 ucnt = k;
             }
             WV_PHASE_END(PH_SELECT);
@@ -507,7 +609,7 @@ __global__ __launch_bounds__(64) void sp_knn_wave_kernel(const KParams p) {
                 p.values[o + j] = 0.f;
             }
             if (lane == 0 && p.counts) p.counts[slot] = n_out;
-            if (timing) ph[CT_ROWS_SPARSE] += 1;
+            if (timing) atomicAdd(&p.phase_cycles[CT_ROWS_SPARSE], 1ull);
         } else {
             // not a row for this kernel (no trip records, too many trips) or a pool overflowed: the generic kernel's queue takes it
             if (lane == 0) {
@@ -515,21 +617,14 @@ __global__ __launch_bounds__(64) void sp_knn_wave_kernel(const KParams p) {
                 p.desc_g[2 * (size_t)g] = make_int4(d0.x, d0.y, d0.z, n1);      // (without the record counts)
                 p.desc_g[2 * (size_t)g + 1] = d1;
             }
-            if (timing) ph[CT_ROWS_FALLBACK] += 1;
+            if (timing) atomicAdd(&p.phase_cycles[CT_ROWS_FALLBACK], 1ull);
         }
         // LDS back to clean: collision bitmap, what is left of the member pool / collision set, U
         ((int4 *)cbm)[lane] = make_int4(0, 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < WV_A_BYTES / (64 * 16); ++i) ((int4 *)rA)[i * 64 + lane] = make_int4(0, 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < WV_UCAP * 8 / (64 * 16); ++i) ((int4 *)U)[i * 64 + lane] = make_int4(0, 0, 0, 0);
+        for (int i = lane; i < A_BYTES / 16; i += 64) ((int4 *)rA)[i] = make_int4(0, 0, 0, 0);      // (U is its last 2 KB)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         q_next = __builtin_amdgcn_readfirstlane(q_claim);
         WV_PHASE_END(PH_OUTPUT);
-    }
-    if (timing) {
-#pragma unroll
-        for (int i = 0; i < PH_N; ++i) if (ph[i]) atomicAdd(&p.phase_cycles[i], ph[i]);
     }
 #undef WV_PHASE_END
 }

@@ -1059,7 +1059,7 @@ def _scoring_problem(n_users=6000, n_items=40000, per_user=40, per_item=60, seed
 def _ran_on_the_wave_kernel(call, **tuning):
     info = _host.run_hip(call, time_kernel=True, **tuning)[4]
     cus = int(_abi.backend_info(0).split("CUs=")[1].split()[0])
-    return info["num_wgs"] == min(call.n_targets, 8 * cus), info
+    return info["num_wgs"] in (min(call.n_targets, 11 * cus), min(call.n_targets, 9 * cus)), info      # (eleven / nine single-wave workgroups per CU)
 
 
 @pytest.mark.parametrize("name,kw", [
