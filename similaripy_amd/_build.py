@@ -60,6 +60,11 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     if verbose:
         print(" ".join(cmd))
     proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0 and "-mllvm" in cmd and ("amdgpu-atomic-optimizer-strategy" in proc.stderr or "Unknown command line argument" in proc.stderr):
+        # the -mllvm option is an LLVM internal, not a stable hipcc interface: a toolchain that no longer knows it still builds the
+        # library (a performance detail of the row queue's prefetch is lost, nothing else)
+        cmd = [c for i, c in enumerate(cmd) if c != "-mllvm" and (i == 0 or cmd[i - 1] != "-mllvm")]
+        proc = subprocess.run(cmd, capture_output=True, text=True)
     if proc.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + proc.stdout + proc.stderr)
     os.replace(tmp, LIB_PATH)

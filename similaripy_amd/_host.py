@@ -772,6 +772,10 @@ def _s_plus_impl(matrix1, matrix2, weight_depop_matrix1, weight_depop_matrix2, p
         # CSR results are assembled on the device whatever the order of target_rows (SP_FLAG_CSR_OUT: the stable counting sort of
         # coo_to_csr.h:28-71, repeats included)
         csr_out = format_output == 'csr' and call.n_targets > 0 and call.n_targets * call.k <= np.iinfo(np.int32).max
+        if csr_out and call.n_targets > 4096 and not bool(np.all(call.targets[1:] > call.targets[:-1])) and int(np.bincount(call.targets).max()) > 1024:
+            # (a row asked for thousands of times: the device assembly orders a row's slots with a one-thread insertion sort, fine for the
+            # handful of repeats real calls have, quadratic here — the slots come back and the host assembles, coo_to_csr.h:28-71)
+            csr_out = False
         if csr_out and devices is not None and len(devices) > 1 and call.n_targets > 1 and not bool(np.all(call.targets[1:] > call.targets[:-1])):
             csr_out = False          # (several devices assemble the CSR rows of their own slices: needs ascending targets; else the slots come back)
         _say(verbose, "Computing")
