@@ -24,6 +24,7 @@
 #include <stdarg.h>
 #include <algorithm>
 #include <chrono>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -365,6 +366,15 @@ int launch_rows(const KParams &kp_s, const KParams &kp, const Config &c, hipStre
     return SP_OK;
 }
 
+// A host-mode call may cut its target list into chunks (sub-launches that reuse the first one's passes over m2, SP_FLAG_REUSE_M2_PREP)
+// so that a chunk's results travel to the host while the next chunk computes: after_launch(j) is called when chunk j's launches are
+// queued (it records an event on the stream).
+struct ChunkHook {
+    int n_chunks = 1;
+    std::vector<size_t> bounds;                     // [n_chunks + 1] slots
+    std::function<int(int)> after_launch;
+};
+
 // all pointers in `a` are device pointers here
 int run_device_impl(sp_knn_args *a) {
     HIP_TRY(hipSetDevice(a->device));
@@ -655,9 +665,32 @@ __global__ __launch_bounds__(256) void sp_add_pow_f32_kernel(int n, const float 
 
 // device pointers in, device pointers out; with SP_FLAG_M2_IS_M1_T / SP_FLAG_M1_IS_M2_T the transpose (s_plus.pyx:169-170,
 // 205-206) is built first, on the same stream, into scratch behind the kernel's workspace
-int run_device(sp_knn_args *a) {
+// the row kernels of a call whose operands are what they should be (`b`), in one launch chain or chunk by chunk
+int run_rows(sp_knn_args *b, const ChunkHook *hook) {
+    if (!hook || hook->n_chunks <= 1) {
+        TRY(run_device_impl(b));
+        return (hook && hook->after_launch) ? hook->after_launch(0) : SP_OK;
+    }
+    const size_t k = (size_t)b->k;
+    for (int j = 0; j < hook->n_chunks; ++j) {
+        const size_t s0 = hook->bounds[(size_t)j], s1 = hook->bounds[(size_t)j + 1];
+        sp_knn_args sub = *b;
+        sub.n_targets = (int32_t)(s1 - s0);
+        sub.targets = b->targets + s0;
+        if (b->rows) sub.rows = b->rows + s0 * k;
+        sub.cols = b->cols + s0 * k;
+        sub.values = b->values + s0 * k;
+        if (b->out_counts) sub.out_counts = b->out_counts + s0;
+        if (j > 0) sub.flags |= SP_FLAG_REUSE_M2_PREP;
+        if (s1 > s0) TRY(run_device_impl(&sub));
+        if (hook->after_launch) TRY(hook->after_launch(j));
+    }
+    return SP_OK;
+}
+
+int run_device(sp_knn_args *a, const ChunkHook *hook = nullptr) {
     const bool m2t = (a->flags & SP_FLAG_M2_IS_M1_T) != 0, m1t = (a->flags & SP_FLAG_M1_IS_M2_T) != 0;
-    if (!m2t && !m1t) return run_device_impl(a);
+    if (!m2t && !m1t) return run_rows(a, hook);
     HIP_TRY(hipSetDevice(a->device));
     if (a->n_targets == 0) { a->kernel_ms = 0.f; return SP_OK; }
     int n_cus = 256;
@@ -742,7 +775,7 @@ int run_device(sp_knn_args *a) {
     }
     b.workspace = ws;
     b.workspace_bytes = (int64_t)L.knn;
-    rc = run_device_impl(&b);
+    rc = run_rows(&b, hook);
     a->kernel_ms = b.kernel_ms + tr_ms;
     a->passes_total = b.passes_total;
     a->num_wgs_used = b.num_wgs_used;
@@ -1097,8 +1130,109 @@ int run_host(sp_knn_args *a) {
         prefault.add(a->values, nt * k * sizeof(float));
         prefault.start();
     }
-    int rc = run_device(&d);
+    // Large results leave in CHUNKS: the target list is cut into four sub-launches (the passes over m2 run once), and while chunk j + 1
+    // computes, chunk j is assembled (CSR: its slots' non-zeros compacted; strictly increasing targets make slot order row order) and
+    // copied to the host on a second stream — of the ~16 ms that assembly + 0.8 GB of PCIe cost at the C2 size only the last chunk's
+    // share stays exposed (44 % of the public call was transfers and glue, serial with the kernel).
+    // (SIMILARIPY_AMD_CHUNK_MIN_ENTRIES: the threshold in output entries, for tests at small sizes; SIMILARIPY_AMD_NO_CHUNKS: off)
+    const char *cmin_env = getenv("SIMILARIPY_AMD_CHUNK_MIN_ENTRIES");
+    const size_t chunk_min = cmin_env ? (size_t)strtoull(cmin_env, nullptr, 10) : ((size_t)1 << 24);
+    const bool chunked = !(d.flags & SP_FLAG_TIME_KERNEL) && nt * k >= chunk_min && nt >= 64 && (!csr_out || targets_ascend) &&
+                         getenv("SIMILARIPY_AMD_NO_CHUNKS") == nullptr;
+    ChunkHook hook;
+    struct ChunkSync {
+        hipStream_t s2 = nullptr;
+        std::vector<hipEvent_t> ev;
+        ~ChunkSync() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); if (s2) { (void)hipStreamSynchronize(s2); (void)hipStreamDestroy(s2); } }
+    } cs_;
+    if (chunked) {
+        hook.n_chunks = 4;
+        for (int j = 0; j <= hook.n_chunks; ++j) hook.bounds.push_back(nt * (size_t)j / (size_t)hook.n_chunks);
+        HIP_TRY(hipStreamCreateWithFlags(&cs_.s2, hipStreamNonBlocking));
+        cs_.ev.resize((size_t)hook.n_chunks, nullptr);
+        for (auto &e : cs_.ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        hook.after_launch = [&](int j) -> int { HIP_TRY(hipEventRecord(cs_.ev[(size_t)j], nullptr)); return SP_OK; };
+    }
+    int rc = run_device(&d, chunked ? &hook : nullptr);
     if (rc) return rc;
+    if (chunked) {
+        // (every chunk's launches are queued; the host now follows them chunk by chunk on the second stream)
+        int *slot_nnz = nullptr, *slot_off = nullptr, *o_idx = nullptr;
+        float *o_val = nullptr;
+        long long *totals = nullptr, *scan_part = nullptr;
+        if (csr_out) {
+            TRY(pool.alloc(nt, &slot_nnz));
+            TRY(pool.alloc(nt + (size_t)hook.n_chunks, &slot_off));
+            TRY(pool.alloc(nt * k, &o_idx));
+            TRY(pool.alloc(nt * k, &o_val));
+            TRY(pool.alloc((size_t)hook.n_chunks, &totals));
+            TRY(pool.alloc((size_t)SCAN_CHUNKS, &scan_part));
+        }
+        size_t running = 0;
+        for (int j = 0; j < hook.n_chunks; ++j) {
+            const size_t s0 = hook.bounds[(size_t)j], s1 = hook.bounds[(size_t)j + 1], ns = s1 - s0;
+            HIP_TRY(hipStreamWaitEvent(cs_.s2, cs_.ev[(size_t)j], 0));
+            if (!ns) continue;
+            if (csr_out) {
+                const int wb = (int)std::max<size_t>(1, std::min<size_t>(256 * 16, (ns + 3) / 4));
+                int *off_j = slot_off + s0 + (size_t)j;                      // (ns + 1 entries)
+                hipLaunchKernelGGL(sp_chunk_slot_nnz_kernel, dim3(wb), dim3(256), 0, cs_.s2, (int)ns, (int)k, d.out_counts + s0, d.values + s0 * k, slot_nnz + s0);
+                scan_i32<false>((long long)ns, slot_nnz + s0, off_j, nullptr, totals + j, scan_part, cs_.s2);
+                hipLaunchKernelGGL(sp_chunk_compact_kernel, dim3(wb), dim3(256), 0, cs_.s2, (int)ns, (int)k, d.out_counts + s0, d.cols + s0 * k, d.values + s0 * k,
+                                   (const int *)off_j, o_idx + s0 * k, o_val + s0 * k);
+                HIP_TRY(hipGetLastError());
+                long long nnz_j = 0;
+                HIP_TRY(hipMemcpyAsync(&nnz_j, totals + j, sizeof(nnz_j), hipMemcpyDeviceToHost, cs_.s2));
+                HIP_TRY(hipStreamSynchronize(cs_.s2));
+                if (j == 0) prefault.join();
+                if (nnz_j > 0) {
+                    HIP_TRY(hipMemcpyAsync(a->cols + running, o_idx + s0 * k, (size_t)nnz_j * 4, hipMemcpyDeviceToHost, cs_.s2));
+                    HIP_TRY(hipMemcpyAsync(a->values + running, o_val + s0 * k, (size_t)nnz_j * 4, hipMemcpyDeviceToHost, cs_.s2));
+                }
+                running += (size_t)nnz_j;
+            } else {
+                if (j == 0) { HIP_TRY(hipStreamSynchronize(cs_.s2)); prefault.join(); }
+                HIP_TRY(hipMemcpyAsync(a->cols + s0 * k, d.cols + s0 * k, ns * k * sizeof(int32_t), hipMemcpyDeviceToHost, cs_.s2));
+                HIP_TRY(hipMemcpyAsync(a->values + s0 * k, d.values + s0 * k, ns * k * sizeof(float), hipMemcpyDeviceToHost, cs_.s2));
+            }
+        }
+        if (csr_out) {
+            // the row pointers: one count over all slots + one scan (the entries are on their way already, in row order)
+            const int n_rows = a->n_rows_m1;
+            int *indptr = nullptr;
+            long long *total = nullptr;
+            TRY(pool.alloc((size_t)n_rows + 1, &indptr));
+            TRY(pool.alloc(1, &total));
+            HIP_TRY(hipMemsetAsync(indptr, 0, ((size_t)n_rows + 1) * 4, cs_.s2));
+            const int wb = (int)std::max<size_t>(1, std::min<size_t>(256 * 16, (nt + 3) / 4));
+            hipLaunchKernelGGL(sp_slot_nnz_kernel, dim3(wb), dim3(256), 0, cs_.s2, (int)nt, (int)k, d.targets, d.out_counts, d.values, indptr);
+            scan_i32<true>((long long)n_rows + 1, indptr, indptr, nullptr, total, scan_part, cs_.s2);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(a->csr_indptr, indptr, ((size_t)n_rows + 1) * 4, hipMemcpyDeviceToHost, cs_.s2));
+            a->csr_nnz = (int64_t)running;
+        }
+        if (a->out_counts) HIP_TRY(hipMemcpyAsync(a->out_counts, d.out_counts, nt * sizeof(int32_t), hipMemcpyDeviceToHost, cs_.s2));
+        HIP_TRY(hipStreamSynchronize(cs_.s2));
+        trace.mark("row kernels, chunked assembly + result to the host");
+        if (want_rows) {
+            prefault.join();
+            std::vector<int32_t> cnt_tmp;
+            const int32_t *cnt = a->out_counts;
+            if (!cnt) {
+                cnt_tmp.resize(nt);
+                HIP_TRY(hipMemcpy(cnt_tmp.data(), d.out_counts, nt * sizeof(int32_t), hipMemcpyDeviceToHost));
+                cnt = cnt_tmp.data();
+            }
+            for (size_t i = 0; i < nt; ++i)
+                if ((size_t)cnt[i] < k) memset(a->rows + i * k + cnt[i], 0, (k - (size_t)cnt[i]) * sizeof(int32_t));
+        }
+        a->kernel_ms = d.kernel_ms;
+        a->passes_total = d.passes_total;
+        a->num_wgs_used = d.num_wgs_used;
+        memcpy(a->phase_cycles, d.phase_cycles, sizeof(a->phase_cycles));
+        a->reserved[1] = d.reserved[1]; a->reserved[2] = d.reserved[2]; a->reserved[3] = d.reserved[3];
+        return SP_OK;
+    }
     trace.mark("transpose, norms, row kernels");
     prefault.join();
     trace.mark("output pages touched (host)");

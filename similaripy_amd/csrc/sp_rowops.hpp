@@ -256,6 +256,44 @@ __global__ __launch_bounds__(256) void sp_slot_nnz_kernel(int n_targets, int k, 
     }
 }
 
+// Chunked CSR assembly (strictly increasing targets: slot order IS row order): non-zero entries per slot of a chunk of slots, and their
+// compaction to the front of the chunk's own output range at the slots' scanned offsets — what lets a chunk's rows travel to the host
+// while the next chunk's rows are still being computed (run_host).
+__global__ __launch_bounds__(256) void sp_chunk_slot_nnz_kernel(int n_slots, int k, const int *__restrict__ counts, const float *__restrict__ values, int *__restrict__ slot_nnz) {
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6, n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long s = wave0; s < n_slots; s += n_waves) {
+        const int n = counts[s];
+        const float *v = values + s * (long long)k;
+        int c = 0;
+        for (int j = lane; j < n; j += 64) c += (v[j] != 0.f) ? 1 : 0;
+        c = ro_wave_sum(c);
+        if (lane == 0) slot_nnz[s] = c;
+    }
+}
+__global__ __launch_bounds__(256) void sp_chunk_compact_kernel(int n_slots, int k, const int *__restrict__ counts, const int *__restrict__ cols, const float *__restrict__ values,
+                                                                const int *__restrict__ slot_off, int *__restrict__ out_indices, float *__restrict__ out_data) {
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6, n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long s = wave0; s < n_slots; s += n_waves) {
+        const int n = counts[s];
+        const long long src = s * (long long)k;
+        long long dst = slot_off[s];
+        for (int j0 = 0; j0 < n; j0 += 64) {
+            const int j = j0 + lane;
+            const float v = (j < n) ? values[src + j] : 0.f;
+            const int c = (j < n) ? cols[src + j] : 0;
+            const unsigned long long m = __ballot(v != 0.f);
+            if (v != 0.f) {
+                const long long q = dst + __popcll(m & ((1ull << lane) - 1ull));
+                out_indices[q] = c;
+                out_data[q] = v;
+            }
+            dst += __popcll(m);
+        }
+    }
+}
+
 // non-zero entries of slot i, in slot order, to [indptr[targets[i]], ...)
 __global__ __launch_bounds__(256) void sp_csr_compact_kernel(int n_targets, int k, const int *__restrict__ targets, const int *__restrict__ counts,
                                                               const int *__restrict__ cols, const float *__restrict__ values, const int *__restrict__ indptr,

@@ -1127,3 +1127,31 @@ def test_wave_kernel_tied_values_and_repeated_calls():
             _check(call2, "wave kernel repeat", threads_per_wg=64)
         else:
             np.testing.assert_allclose(kept, first, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("fmt", ["csr", "coo"])
+def test_host_mode_results_leave_in_chunks(fmt, monkeypatch):
+    """Large host-mode calls run as four sub-launches (SP_FLAG_REUSE_M2_PREP) whose results are assembled and copied to the host while
+    the next chunk computes (run_host).  Forced here at a small size: same result as the one-launch call and as the oracle — device
+    transpose + norms (m2 built once, reused by the later chunks), a MATRIX filter, ascending target rows, rp3beta (fold + zero check)."""
+    m = _rand((9000, 1500), 0.006, 31)
+    filt = _rand((9000, 9000), 15.0 / 9000, 32)
+    tg = np.sort(np.random.default_rng(3).choice(9000, size=7001, replace=False)).astype(np.int32)
+    cases = [("cosine", dict(k=25)), ("cosine", dict(k=25, target_rows=tg, filter_cols=filt)), ("rp3beta", dict(k=12, alpha=0.9, beta=0.5)),
+             ("s_plus", dict(k=18, l1=0.4, l2=0.6, shrink=1.5))]
+    for name, kw in cases:
+        monkeypatch.setenv("SIMILARIPY_AMD_NO_CHUNKS", "1")
+        one = getattr(sim, name)(m, verbose=False, format_output=fmt, **kw)
+        monkeypatch.delenv("SIMILARIPY_AMD_NO_CHUNKS")
+        monkeypatch.setenv("SIMILARIPY_AMD_CHUNK_MIN_ENTRIES", "1")
+        four = getattr(sim, name)(m, verbose=False, format_output=fmt, **kw)
+        monkeypatch.delenv("SIMILARIPY_AMD_CHUNK_MIN_ENTRIES")
+        assert type(four) is type(one) and four.shape == one.shape and four.nnz == one.nnz, name
+        a, b = sp.csr_array(four), sp.csr_array(one)
+        if fmt == "csr":
+            np.testing.assert_array_equal(a.indptr, b.indptr)
+        _assert_same_topk(a, b, kw["k"], rtol=1e-6)
+    # ... and the kernel boundary against the oracle, slots and padding included (COO with the row ids filled by the host threads)
+    call = _host.prepare(m, k=25, l2=1.0, target_rows=tg, filter_cols=filt)
+    monkeypatch.setenv("SIMILARIPY_AMD_CHUNK_MIN_ENTRIES", "1")
+    _check(call, "chunked host-mode call")
