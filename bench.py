@@ -340,7 +340,8 @@ def main():
     def line_of(wl, the_call, res, steps, with_phases: bool):
         """The figures of one measured workload: throughput, the dominant kernel, its roofline."""
         sparse_ms, generic_ms = res["sparse_ms"], res["generic_ms"]
-        dominant = "sp_knn_sparse_kernel" if sparse_ms >= generic_ms else "sp_knn_generic_kernel"
+        wave = bool(res["info"].get("phase_cycles", [0] * 12)[8])
+        dominant = ("sp_knn_wave_kernel" if wave else "sp_knn_sparse_kernel") if sparse_ms >= generic_ms else "sp_knn_generic_kernel"
         kern_s = max(sparse_ms, generic_ms) / 1e3
         # (N > 1: rank 0's slice and rank 0's kernel time)
         achieved = res["local_bytes"] / kern_s / 1e9 if kern_s > 0 else 0.0
@@ -379,13 +380,19 @@ def main():
         del shard
         main_res["shard"] = None
         torch.cuda.empty_cache()
-        oc = wl.make_call(1 if other_mode == "strong" else world)
-        ores = measure(oc, args.steps, args.warmup, True)
-        other = {"scaling": other_mode, "value": oc.n_targets * args.steps / ores["elapsed"], "unit": "rows/s", "ms_per_step": ores["elapsed"] / args.steps * 1e3,
-                 "target_slots": oc.n_targets, "gather_exposed_ms": ores.get("gather_exposed_ms"), "per_rank": ores["per_rank"]}
-        ores["shard"] = None
         shard = None
-        del oc, ores
+        try:
+            # (host-side and identical on every rank: a failure here — memory for the N-times stacked matrix — is every rank's, before any collective)
+            oc = wl.make_call(1 if other_mode == "strong" else world)
+        except Exception as exc:
+            oc = None
+            other = {"scaling": other_mode, "error": f"{type(exc).__name__}: {str(exc)[:200]}"}
+        if oc is not None:
+            ores = measure(oc, args.steps, args.warmup, True)
+            other = {"scaling": other_mode, "value": oc.n_targets * args.steps / ores["elapsed"], "unit": "rows/s", "ms_per_step": ores["elapsed"] / args.steps * 1e3,
+                     "target_slots": oc.n_targets, "gather_exposed_ms": ores.get("gather_exposed_ms"), "per_rank": ores["per_rank"]}
+            ores["shard"] = None
+            del oc, ores
 
     if rank != 0:
         dist.barrier()
@@ -556,10 +563,11 @@ def measure_traffic(call, kernel_name: str, tuning: dict) -> dict:
 def phase_share(info) -> dict:
     """Share of workgroup-lane-0 shader cycles per kernel phase (in-kernel s_memtime counters)."""
     # (names of include/sp_knn.h phase_cycles[0..8]; see there for what each covers in the two row kernels)
-    names = ("setup", "segments", "accumulate", "drain", "select", "output", "sweep1", "sweep2", "csdrain")
+    names = ("setup", "segments", "accumulate", "drain", "select", "output", "sweep1", "sweep2")
     cyc = info.get("phase_cycles", [0] * 12)
-    tot = float(sum(cyc[:9])) or 1.0
-    d = {n: round(c / tot, 4) for n, c in zip(names, cyc[:9])}
+    tot = float(sum(cyc[:8])) or 1.0
+    d = {n: round(c / tot, 4) for n, c in zip(names, cyc[:8])}
+    d["wave_per_row_kernel"] = bool(cyc[8])
     d["cycles_per_wg"] = tot / max(1, info.get("num_wgs", 1))
     d["rows_sparse_path"], d["generic_windows"] = cyc[9], cyc[11]
     d["rows_fallback_cs_full"], d["rows_fallback_u_overflow"] = cyc[10] & 0xFFFFFFFF, cyc[10] >> 32

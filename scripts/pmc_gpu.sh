@@ -8,7 +8,7 @@ export TMPDIR=/tmp; cd /tmp
 PMCG=()
 while [ $# -gt 0 ] && [ "$1" != "--" ]; do PMCG+=("$1"); shift; done
 [ $# -gt 0 ] && shift
-BENCH="python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline $*"
+BENCH="python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-traffic --no-other-workloads --no-end-to-end $*"
 i=0
 for G in "${PMCG[@]}"; do
   i=$((i+1))

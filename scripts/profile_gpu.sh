@@ -12,7 +12,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline $*"
+BENCH="python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-traffic --no-other-workloads --no-end-to-end $*"
 
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_stats_$TAG -o stats -- $BENCH > "$OUT/bench_under_rocprof.json" 2> "$OUT/bench_under_rocprof.log"
 find /tmp/rp_stats_$TAG -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;

@@ -615,6 +615,7 @@ int run_device_impl(sp_knn_args *a) {
         const unsigned long long *phc = (const unsigned long long *)(qb + WS_PHASE_OFFSET);
         static_assert(PH_N == 12, "sp_knn_args::phase_cycles has 12 entries");
         for (int i = 0; i < PH_N; ++i) a->phase_cycles[i] = (int64_t)phc[i];
+        a->phase_cycles[PH_CSDRAIN] = c.wave ? 1 : 0;        // (slot 8 carries no timer: which sparse-row kernel ran)
         a->passes_total = (int32_t)phc[CT_PASSES];
         a->num_wgs_used = c.wgs_sparse;
         float ks_ms = 0.f, kg_ms = 0.f;

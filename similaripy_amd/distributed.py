@@ -242,7 +242,7 @@ class ShardedDeviceProblem:
     """
 
     def __init__(self, call: KernelCall, group=None, device=None, dst: int = 0, compact: bool = True, chunk_rows: Optional[int] = None,
-                 phases: int = 1):
+                 phases: int = 1, gather_alone: bool = False):
         import torch
         import torch.distributed as dist
 
@@ -278,7 +278,9 @@ class ShardedDeviceProblem:
             self.lo, self.hi, self.n_loc, self.n_max = 0, 0, 0, n_max
             self.prob = DeviceProblem(call, self.device)
         # sub-slices of the split-phase gather: `phases` blocks of n_sub slots, the same on every rank (the last ones may be short or empty)
-        self.phases = max(1, min(int(phases), max(1, self.n_max))) if (self.world > 1 and self.chunk_rows is None) else 1
+        # (gather_alone: a group of ONE rank still runs the split-phase gather — the RCCL calls of the N > 1 path on a one-GPU box, for tests)
+        self.gathers = self.world > 1 or (bool(gather_alone) and self.distributed)
+        self.phases = max(1, min(int(phases), max(1, self.n_max))) if (self.gathers and self.chunk_rows is None) else 1
         self.n_sub = -(-self.n_max // self.phases) if self.n_max else 0
         self.n_pad = self.n_sub * self.phases                      # slots of the padded slab
         # ONE slab per rank = `phases` sub-slabs: the kernel writes its cols / values / counts straight into views of them
@@ -287,13 +289,13 @@ class ShardedDeviceProblem:
         self.sub_views = [slab_views(t, self.n_sub, k) for t in self.sub]
         self.pad_cols, self.pad_vals, self.pad_cnt = self.sub_views[0] if self.phases == 1 else (None, None, None)
         self.recv = None
-        if self.rank == dst and self.world > 1:
+        if self.rank == dst and self.gathers:
             rdev = torch.device("cpu") if self.host_gather else self.device
             self.recv = [torch.empty(self.slab.numel(), dtype=torch.int32, device=rdev) for _ in range(self.world)]
             w = slab_words(self.n_sub, k)
             self._recv_sub = [[r[j * w: (j + 1) * w] for r in self.recv] for j in range(self.phases)]
         self._host_slab = torch.empty(self.slab.numel(), dtype=torch.int32, pin_memory=True) if self.host_gather else None
-        self.comm_stream = torch.cuda.Stream(device=self.device) if (self.world > 1 and not self.host_gather) else None
+        self.comm_stream = torch.cuda.Stream(device=self.device) if (self.gathers and not self.host_gather) else None
         self._pending = []
         self.gather_exposed_ms = None
 
@@ -338,7 +340,7 @@ class ShardedDeviceProblem:
         import torch
         import torch.distributed as dist
 
-        if self.world == 1:
+        if not self.gathers:
             return
         if self.host_gather:
             torch.cuda.synchronize(self.device)
@@ -366,7 +368,7 @@ class ShardedDeviceProblem:
 
     def gather(self):
         """THE collective of the path: the slab of every rank to the root (device to device; `phases` messages when split)."""
-        if self.world == 1:
+        if not self.gathers:
             return
         for j in range(self.phases):
             self._gather_sub(j)
@@ -397,7 +399,7 @@ class ShardedDeviceProblem:
         """Root: one (cols, values, counts)-layout slab per rank with the sub-slabs folded back into slot order."""
         import torch
 
-        src = [self.slab] if self.world == 1 else self.recv
+        src = [self.slab] if not self.gathers else self.recv
         if self.phases == 1:
             return src, self.n_sub
         k, ns, out = self.call.k, self.n_sub, []

@@ -158,6 +158,15 @@ def test_sharded_device_problem_nccl_world1_equals_single_call():
         np.testing.assert_array_equal(counts, n1)
         want = so.canonical(*so.run_kernel(call, "port"), call.targets, k)
         so.compare_topk(so.canonical(rows, cols, vals, call.targets, k), want, k, rtol=1e-5, atol=1e-7, what="sharded vs oracle")
+        # the RCCL calls of the N > 1 step on this one-GPU box: a group of one rank that still gathers — three sub-launches, sub-slab j
+        # sent with an asynchronous gather on the communication stream behind sub-launch j, the step closed by the stream-level waits
+        sh3 = D.ShardedDeviceProblem(call, phases=3, gather_alone=True)
+        assert sh3.phases == 3 and sh3.comm_stream is not None and sh3.recv is not None and not sh3.host_gather
+        for _ in range(3):
+            sh3.run()
+        r3, c3, v3, n3 = sh3.result()
+        so.compare_topk(so.canonical(r3, c3, v3, call.targets, k), want, k, rtol=1e-5, atol=1e-7, what="split-phase gather over nccl vs oracle")
+        np.testing.assert_array_equal(n3, n1)
         # hip_compute() defaults to the rank's own device, and sharded_knn puts its gather tensors there
         out = D.sharded_knn(call, D.hip_compute())
         np.testing.assert_array_equal(out[3], n1)
