@@ -190,7 +190,9 @@ typedef struct sp_knn_args {
                                   _filter_matrix_columns, s_plus_utils.pyx:364-490), which the reference applies to matrix2 on the host.
                                   With SP_FLAG_M2_IS_M1_T (host or device pointers): the rows of m1 with a 0 are skipped while m2 = m1^T
                                   is built.  With an explicit m2: host mode only (the uploaded copy is compacted; a device-resident m2
-                                  belongs to the caller).  Not with SP_FLAG_P3_PREP / SP_FLAG_M1_IS_M2_T.  NULL: every column stays. */
+                                  belongs to the caller).  With SP_FLAG_P3_PREP (and SP_FLAG_M2_IS_M1_T): the columns are dropped from the NORMALISED m2, as the
+                                  reference does it (similarity.py:410-415 before s_plus_utils.pyx:424-490).  Not with SP_FLAG_M1_IS_M2_T.
+                                  NULL: every column stays. */
 
     /* ABI 5: several devices behind ONE host-mode call */
     int32_t  n_devices;        /* host mode only.  0 or 1: the call runs on `device`.  N > 1: `targets` is cut into N contiguous slices of

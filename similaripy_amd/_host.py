@@ -433,7 +433,7 @@ def prepare(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_mat
     (SP_FLAG_M2_IS_M1_T, include/sp_prep.h): m2 is never built on the host, its column norms are taken from the
     rows of m1 with the arithmetic the reference applies to the columns of m2.  ARRAY column selectors become a mask the
     device applies while it builds m2 (KernelCall.col_keep); depopularisation weights ('none' / 'sum' / arrays) are taken
-    from m1.  Only p3_alpha with ARRAY selectors needs m2 on the host (similarity.p3alpha / rp3beta then preprocess there).
+    from m1; with p3_alpha the mask is applied after the rows of m2 were normalised.
 
     norms_on_device: with the device-side transpose, leave _build_squared_norms / _build_cosine_normalization to the same
     library call (SP_FLAG_NORMS_ON_DEVICE): the call carries (c1, c2, additive_shrink) instead of the vectors.
@@ -463,12 +463,12 @@ def prepare(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_mat
     sel_t = build_column_selector(target_cols)
     p3 = p3_alpha is not None
     # ARRAY selectors drop whole columns of m2 (s_plus_utils.pyx:364-490): with the device-side transpose that is a mask over
-    # the rows of m1 it reads (KernelCall.col_keep).  Not together with p3_alpha: the reference normalises the rows of m2
-    # first and drops the columns afterwards, the mask would change the row sums.
+    # the rows of m1 it reads (KernelCall.col_keep).  With p3_alpha the library applies the mask to the NORMALISED m2 instead (the
+    # reference normalises the rows of m2 first and drops the columns afterwards: masking earlier would change the row sums).
     arr_sel = sel_f[0] == MODE_ARRAY or sel_t[0] == MODE_ARRAY
-    on_dev = bool(m2_on_device) and m2_from_m1 and (l3 == 0 or not p3 or p3_depop_beta is not None) and not (p3 and arr_sel)
+    on_dev = bool(m2_on_device) and m2_from_m1 and (l3 == 0 or not p3 or p3_depop_beta is not None)
     if p3 and not on_dev:
-        raise ValueError("p3_alpha needs the device-side transpose (matrix2=None, no array selectors)")
+        raise ValueError("p3_alpha needs the device-side transpose (matrix2=None)")
     dev_norms = on_dev and bool(norms_on_device) and (l1 != 0 or l2 != 0)
     # (a 'sum' weight of matrix1 is its ROW sums in the reference's float32 reduceat order, s_plus_utils.pyx:128-158: that needs the
     # CSR of matrix1 on the host, which the CSC route never builds)

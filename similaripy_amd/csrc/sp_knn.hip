@@ -279,8 +279,8 @@ int validate(const sp_knn_args *a) {
         return fail(SP_EINVAL, "SP_FLAG_DEPOP_ROWSUM needs SP_FLAG_P3_PREP");
     if (a->col_keep && !m2t && (a->on_device || m1t))
         return fail(SP_EINVAL, "col_keep with an explicit m2 is a host-mode option (device-resident m2 is filtered by its owner)");
-    if (a->col_keep && (a->flags & SP_FLAG_P3_PREP))
-        return fail(SP_EINVAL, "col_keep excludes SP_FLAG_P3_PREP (the reference normalises the rows of matrix2 before it drops columns)");
+    if (a->col_keep && (a->flags & SP_FLAG_P3_PREP) && !m2t)
+        return fail(SP_EINVAL, "col_keep with SP_FLAG_P3_PREP needs SP_FLAG_M2_IS_M1_T (the columns are dropped from the m2 built here, after its rows were normalised)");
     if ((a->flags & (SP_FLAG_CSR_OUT | SP_FLAG_CHECK_ZEROS)) && a->on_device)
         return fail(SP_EINVAL, "SP_FLAG_CSR_OUT / SP_FLAG_CHECK_ZEROS are host-mode flags (on_device = 0)");
     if ((a->flags & SP_FLAG_CSR_OUT) && a->n_targets > 0 && !a->csr_indptr) return fail(SP_EINVAL, "SP_FLAG_CSR_OUT needs csr_indptr");
@@ -633,7 +633,7 @@ namespace {
 
 // Layout of the extra scratch a SP_FLAG_M2_IS_M1_T / SP_FLAG_M1_IS_M2_T call needs behind the kernel's own workspace: the
 // three arrays of the matrix built here (m2 = m1^T or m1 = m2^T), the optional vectors, then the transpose's scratch.
-struct M2tLayout { size_t knn, data, indices, indptr, p3copy, ydepop, norms, tr, total; };
+struct M2tLayout { size_t knn, data, indices, indptr, p3copy, ydepop, norms, keep, tr, total; };
 int m2t_layout(const sp_knn_args *a, int n_cus, sp_knn_args *plain, M2tLayout *L) {
     const bool m1t = (a->flags & SP_FLAG_M1_IS_M2_T) != 0;
     const int64_t nnz = m1t ? a->nnz_m2 : a->nnz_m1;
@@ -653,7 +653,11 @@ int m2t_layout(const sp_knn_args *a, int n_cus, sp_knn_args *plain, M2tLayout *L
     L->p3copy = L->indptr + al(((size_t)built_rows + 1) * 4);
     L->ydepop = L->p3copy + ((a->flags & SP_FLAG_P3_PREP) ? al((size_t)nnz * 4) : 0);
     L->norms = L->ydepop + ((a->flags & SP_FLAG_DEPOP_ROWSUM) ? al((size_t)a->n_rows_m1 * 4) : 0);
-    L->tr = L->norms + ((a->flags & SP_FLAG_NORMS_ON_DEVICE) ? 4 * al((size_t)a->n_rows_m1 * 4) : 0);
+    L->keep = L->norms + ((a->flags & SP_FLAG_NORMS_ON_DEVICE) ? 4 * al((size_t)a->n_rows_m1 * 4) : 0);
+    // SP_FLAG_P3_PREP with a column mask: the mask is applied to the NORMALISED m2 (the reference normalises the rows of matrix2 before
+    // it drops columns, similarity.py:410-415 then s_plus_utils.pyx:424-490): a second copy of m2's three arrays, scan scratch, total
+    const bool p3_keep = (a->flags & SP_FLAG_P3_PREP) && a->col_keep != nullptr && !m1t;
+    L->tr = L->keep + (p3_keep ? al(((size_t)built_rows + 1) * 4) + 2 * al((size_t)nnz * 4) + al(SCAN_SCRATCH_BYTES) + 256 : 0);
     L->total = L->tr + transpose_ws_bytes(nnz, built_rows);
     return SP_OK;
 }
@@ -719,8 +723,9 @@ int run_device(sp_knn_args *a, const ChunkHook *hook = nullptr) {
     const int64_t nnz = b.nnz_m1;
     float *t_data = (float *)(ws + L.data);
     int *t_indices = (int *)(ws + L.indices), *t_indptr = (int *)(ws + L.indptr);
+    const bool p3_keep = m2t && (a->flags & SP_FLAG_P3_PREP) && a->col_keep != nullptr;      // (the mask waits for the normalised m2)
     int rc = m2t ? transpose_device(a->n_rows_m1, a->n_rows_m2, nnz, a->m1_data, a->m1_indices, a->m1_indptr,
-                                    t_data, t_indices, t_indptr, ws + L.tr, L.total - L.tr, stream, a->col_keep)
+                                    t_data, t_indices, t_indptr, ws + L.tr, L.total - L.tr, stream, p3_keep ? nullptr : a->col_keep)
                  : transpose_device(a->n_rows_m2, a->n_rows_m1, nnz, a->m2_data, a->m2_indices, a->m2_indptr,
                                     t_data, t_indices, t_indptr, ws + L.tr, L.total - L.tr, stream);
     float tr_ms = 0.f;
@@ -773,6 +778,26 @@ int run_device(sp_knn_args *a, const ChunkHook *hook = nullptr) {
         HIP_TRY(hipGetLastError());
         b.m1_data = m1n;
         b.m2_data = m2n;
+        if (p3_keep) {
+            // _filter_matrix_columns on the normalised m2 (s_plus_utils.pyx:424-490): kept entries compacted row by row, order kept; the
+            // tails of the new arrays are zero (flat passes over nnz entries read them)
+            auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+            int *n_indptr = (int *)(ws + L.keep);
+            int *n_idx = (int *)(ws + L.keep + al(((size_t)a->n_rows_m2 + 1) * 4));
+            float *n_val = (float *)((unsigned char *)n_idx + al((size_t)nnz * 4));
+            long long *scan_part = (long long *)((unsigned char *)n_val + al((size_t)nnz * 4));
+            long long *kept = (long long *)((unsigned char *)scan_part + al(SCAN_SCRATCH_BYTES));
+            HIP_TRY(hipMemsetAsync(n_indptr, 0, ((size_t)a->n_rows_m2 + 1) * 4, stream));
+            HIP_TRY(hipMemsetAsync(n_idx, 0, (size_t)nnz * 4, stream));
+            HIP_TRY(hipMemsetAsync(n_val, 0, (size_t)nnz * 4, stream));
+            const int wb = std::max(1, std::min(256 * 16, (a->n_rows_m2 + 3) / 4));
+            hipLaunchKernelGGL(sp_keep_count_kernel, dim3(wb), dim3(256), 0, stream, a->n_rows_m2, (const int *)t_indptr, (const int *)t_indices, a->col_keep, n_indptr);
+            scan_i32<true>((long long)a->n_rows_m2 + 1, n_indptr, n_indptr, nullptr, kept, scan_part, stream);
+            hipLaunchKernelGGL(sp_keep_compact_kernel, dim3(wb), dim3(256), 0, stream, a->n_rows_m2, (const int *)t_indptr, (const int *)t_indices, (const float *)m2n, a->col_keep,
+                               (const int *)n_indptr, n_idx, n_val);
+            HIP_TRY(hipGetLastError());
+            b.m2_indptr = n_indptr; b.m2_indices = n_idx; b.m2_data = n_val;
+        }
     }
     b.workspace = ws;
     b.workspace_bytes = (int64_t)L.knn;

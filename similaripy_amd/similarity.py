@@ -131,8 +131,7 @@ def _p3_inputs(matrix1, matrix2, alpha):
 def _p3_on_device(matrix1, matrix2, binary, filter_cols, target_cols, alpha=1.0) -> bool:
     """Can the whole preprocessing of p3alpha / rp3beta run inside the kernel call (SP_FLAG_P3_PREP, include/sp_knn.h)?
     Only for the plain call: matrix2 = matrix1.T, float32 data (float64 input is normalised in float64 by the reference),
-    no `binary` (which throws the normalised values away), no array-style column selectors (they edit m2 on the host),
-    alpha > 0.
+    no `binary` (which throws the normalised values away), alpha > 0.
 
     Where the device form differs from similarity.py:410-415 / 477-483 (L1-normalise, `data ** alpha` on EVERY stored entry,
     only then eliminate_zeros inside s_plus): stored zeros are dropped BEFORE the power.  For alpha > 0 that is the same
@@ -146,10 +145,7 @@ def _p3_on_device(matrix1, matrix2, binary, filter_cols, target_cols, alpha=1.0)
         return False
     if _host.multi_gpu_route() is not None:      # (the workers of the multi-GPU route get preprocessed matrices)
         return False
-    for sel in (filter_cols, target_cols):
-        if isinstance(sel, (list, np.ndarray)) and len(sel) != 0:
-            return False
-    return True
+    return True      # (array-style column selectors too: the library drops those columns from the normalised m2, sp_knn_args.col_keep)
 
 
 def _run_p3(matrix1, alpha, beta, k, shrink, shrink_type, threshold, target_rows, target_cols, filter_cols, verbose, format_output):

@@ -229,9 +229,24 @@ def test_array_selectors_and_depop_weights_keep_the_device_transpose(golden):
         assert dev.m2_is_m1t and not ref.m2_is_m1t
         np.testing.assert_array_equal(dev.Xdepop, ref.Xdepop)
         np.testing.assert_array_equal(dev.Ydepop, ref.Ydepop)
-    # p3alpha preprocessing inside the call excludes the mask (rows of m2 are normalised BEFORE columns are dropped)
-    with pytest.raises(ValueError):
-        _host.prepare(A, k=10, filter_cols=fc, m2_on_device=True, p3_alpha=1.0)
+    # p3alpha preprocessing inside the call carries the mask too (round 4): the library drops the columns from the NORMALISED m2
+    p3 = _host.prepare(A, k=10, filter_cols=fc, m2_on_device=True, p3_alpha=1.0)
+    assert p3.m2_is_m1t and p3.p3_alpha == 1.0 and p3.col_keep is not None and not p3.col_keep[fc].any()
+
+
+@pytest.mark.parametrize("fn,kw", [("p3alpha", dict(alpha=0.8)), ("rp3beta", dict(alpha=0.8, beta=0.4)), ("rp3beta", dict(alpha=1.3, beta=0.6, shrink=2.0))])
+def test_p3_with_array_selectors_equals_the_reference_order_of_operations(fn, kw, oracle_backend, golden):
+    """p3alpha / rp3beta with ARRAY filter_cols / target_cols: the reference L1-normalises the rows of matrix2 FIRST and drops the
+    columns afterwards (similarity.py:410-415, then s_plus_utils.pyx:424-490 inside s_plus).  The device route (SP_FLAG_P3_PREP with
+    col_keep) must give what the host statement of that order gives: compared here through the oracle backend with the explicit
+    `matrix2 = matrix1.T` call, which preprocesses on the host."""
+    A = golden.inputs["A"]
+    fc, tc = list(range(0, 300, 7)), list(range(5, 290))
+    a = getattr(sim, fn)(A, k=8, filter_cols=fc, target_cols=tc, verbose=False, format_output="csr", **kw)
+    b = getattr(sim, fn)(A, sp.csr_array(A.T), k=8, filter_cols=fc, target_cols=tc, verbose=False, format_output="csr", **kw)
+    assert a.nnz == b.nnz and a.nnz > 0
+    np.testing.assert_allclose(a.toarray(), b.toarray(), rtol=2e-6, atol=0)
+    assert not a[:, fc].nnz and not a[:, [0, 1, 2, 3, 4, 295, 299]].nnz
 
 
 def test_coo_attached_without_the_constructor_equals_the_constructed_one():
