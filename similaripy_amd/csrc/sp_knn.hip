@@ -519,8 +519,12 @@ int run_device_impl(sp_knn_args *a) {
         int4 *desc_g = desc_s + 2 * (size_t)a->n_targets;               // [2n]
         HIP_TRY(hipMemsetAsync(ws_rows, 0, 512, stream));
         const int work_blocks = std::max(1, std::min((a->n_targets + 15) / 16, n_cus * 8));     // 16 rows (waves) per block and trip
+        unsigned *long_count = bucket_count + 100;          // (inside the 512 bytes zeroed above; the list borrows `order`, written later)
         hipLaunchKernelGGL(sp_row_work_kernel, dim3(work_blocks), dim3(1024), 0, stream,
-                           a->n_targets, a->targets, a->m1_indices, a->m1_indptr, a->m2_indptr, work, bucket_count);
+                           a->n_targets, a->targets, a->m1_indices, a->m1_indptr, a->m2_indptr, work, bucket_count, order, long_count);
+        if (a->nnz_m1 > ROW_WORK_LONG)                       // (only a matrix with that many entries can hold such a row)
+            hipLaunchKernelGGL(sp_row_work_long_kernel, dim3(std::min(n_cus * 2, 1024)), dim3(1024), 0, stream, a->targets, a->m1_indices, a->m1_indptr,
+                               a->m2_indptr, work, bucket_count, (const int *)order, (const unsigned *)long_count);
         if (c.ordered) {
             hipLaunchKernelGGL(sp_bucket_base_kernel, dim3(1), dim3(64), 0, stream, bucket_count, bucket_base);
             hipLaunchKernelGGL(sp_row_order_kernel, dim3((a->n_targets + 255) / 256), dim3(256), 0, stream, a->n_targets, work, bucket_base, order);
@@ -1396,6 +1400,9 @@ int target_costs(const sp_knn_args *a, std::vector<double> *cost) {
     } else {
         for (int u = 0; u < a->n_rows_m2; ++u) len2[(size_t)u] = a->m2_indptr[u + 1] - a->m2_indptr[u];
     }
+    // (the toll of a row: 30 k for a row of the sparse kernels, ~3 per output column for a row of the generic kernel, which walks every
+    // column window whatever the row holds — distributed.row_cost, same rule)
+    const double n_cols_d = (double)std::max(1, a->n_output_cols);
     parallel_ranges(nt, (size_t)1 << 16, [&](size_t lo, size_t hi) {
         for (size_t i = lo; i < hi; ++i) {
             const int t = a->targets[i];
@@ -1406,7 +1413,8 @@ int target_costs(const sp_knn_args *a, std::vector<double> *cost) {
                 const int u = a->m1_indices[p];
                 if (u >= 0 && u < a->n_rows_m2) m += (double)len2[(size_t)u];
             }
-            (*cost)[i] += m;
+            const bool sparse_row = 0.5 * m * m / n_cols_d <= 0.30 * 4096.0 && (p_hi - p_lo) <= 256 && a->n_output_cols > 16384;
+            (*cost)[i] = m + (sparse_row ? ROW_TOLL_MACS : 3.0 * n_cols_d);
         }
     });
     return SP_OK;

@@ -11,9 +11,13 @@ namespace {
 // the target list cannot become the tail of the launch on skewed (power-law) matrices.
 // One wave per row, grid-stride: a workgroup keeps its bucket histogram in LDS and adds it to the global one ONCE at
 // the end (a single global word only sustains ~88 atomics/us; one atomic per row-block cost 2.8 ms on 1M rows).
+// Rows of more than ROW_WORK_LONG entries (a popular item of a ratings matrix: 10^5 - 10^6) are only LISTED here (long_list, counted in
+// *long_count) and summed by sp_row_work_long_kernel, a workgroup per row: one wave walking 800 k entries was 1.3 ms at the end of a
+// 10 k-row call — the per-launch constant that kept the MovieLens-32M shape at x4.75 on eight slices (round 3, "Open").
+constexpr int ROW_WORK_LONG = 8192;
 __global__ __launch_bounds__(1024) void sp_row_work_kernel(int n_targets, const int *targets, const int *m1_indices,
                                                             const int *m1_indptr, const int *m2_indptr, unsigned *work,
-                                                            unsigned *bucket_count) {
+                                                            unsigned *bucket_count, int *long_list, unsigned *long_count) {
     __shared__ unsigned hist[32];
     if (threadIdx.x < 32) hist[threadIdx.x] = 0;
     __syncthreads();
@@ -22,6 +26,10 @@ __global__ __launch_bounds__(1024) void sp_row_work_kernel(int n_targets, const 
     for (int gw = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); gw < n_targets; gw += waves_total) {
         const int t = targets[gw];
         const int s = m1_indptr[t], e = m1_indptr[t + 1];
+        if (e - s > ROW_WORK_LONG) {          // (wave-uniform)
+            if (lane == 0) long_list[atomicAdd(long_count, 1u)] = gw;
+            continue;
+        }
         u64 acc = 0;
         for (int j = s + lane; j < e; j += 64) {
             const int u = m1_indices[j];
@@ -37,6 +45,35 @@ __global__ __launch_bounds__(1024) void sp_row_work_kernel(int n_targets, const 
     }
     __syncthreads();
     if (threadIdx.x < 32 && hist[threadIdx.x]) atomicAdd(&bucket_count[threadIdx.x], hist[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(1024) void sp_row_work_long_kernel(const int *targets, const int *m1_indices, const int *m1_indptr, const int *m2_indptr,
+                                                                 unsigned *work, unsigned *bucket_count, const int *long_list, const unsigned *long_count) {
+    __shared__ u64 part[16];
+    const int n_long = (int)*long_count;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = blockIdx.x; i < n_long; i += gridDim.x) {
+        const int gw = long_list[i];
+        const int t = targets[gw];
+        const int s = m1_indptr[t], e = m1_indptr[t + 1];
+        u64 acc = 0;
+        for (int j = s + (int)threadIdx.x; j < e; j += 1024) {
+            const int u = m1_indices[j];
+            acc += (u64)(m2_indptr[u + 1] - m2_indptr[u]);
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+        __syncthreads();
+        if (lane == 0) part[wave] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            u64 tot = 0;
+            for (int w = 0; w < 16; ++w) tot += part[w];
+            const unsigned w32 = tot > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)tot;
+            work[gw] = w32;
+            atomicAdd(&bucket_count[31 - __clz((int)(w32 | 1u))], 1u);
+        }
+    }
 }
 
 // bucket_count[0..32) -> bucket_base[0..32): start of each bucket when buckets are laid out heaviest first

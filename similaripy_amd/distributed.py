@@ -49,14 +49,21 @@ def row_work(call: KernelCall) -> np.ndarray:
 def row_cost(call: KernelCall) -> np.ndarray:
     """What a target slot costs a GPU, in MAC equivalents — the quantity `partition_targets` balances.
 
-    MACs alone under-price light rows: every row pays a fixed toll (queue, setup, bitmap / tile clear, selection, write-out:
-    ~30 k cycles against ~1 cycle per MAC in the sparse kernel, profiles/r03_c2_phases.txt; on the MovieLens-32M shape the
-    least-squares fit of scripts/strong_scaling_c4.py prices a slice almost entirely by its ROW count).  The toll keeps a
-    slice of many light rows from being handed as much raw work as a slice of few heavy ones."""
-    return row_work(call).astype(np.float64) + ROW_TOLL_MACS
+    MACs alone under-price light rows: every row pays a fixed toll whatever its length.  For a row of the SPARSE kernels (few
+    colliding products: the classification of sp_row_desc_kernel, restated from sizes) that is queue, setup, bitmap clear, selection,
+    write-out: ~30 k MAC equivalents (profiles/r03_c2_phases.txt).  A row of the GENERIC kernel walks every column window of the
+    output whatever it holds: segment slices, the drain over 32 k slots per window, its selections — half of such a row's time on
+    the MovieLens-32M shape, where the average row has 140 k MACs over 84 k columns: ~3 MAC equivalents per output column
+    (profiles/r04_exp_strong_scaling_c4.txt: tolls of 0.8 ... 9 per column timed; the slices are balanced to +-8 % from 1.6 up)."""
+    macs = row_work(call).astype(np.float64)
+    n_cols = float(max(1, call.n_output_cols))
+    nnz1 = np.diff(call.m1_indptr).astype(np.int64)[call.targets] if call.m1_indptr.size else np.zeros(call.n_targets, np.int64)
+    sparse = (0.5 * macs * macs / n_cols <= 0.30 * 4096.0) & (nnz1 <= 256) & (call.n_output_cols > 16384)
+    return macs + np.where(sparse, ROW_TOLL_MACS, GENERIC_TOLL_PER_COL * n_cols)
 
 
-ROW_TOLL_MACS = 30_000.0       # fixed cost of a row, in MACs
+ROW_TOLL_MACS = 30_000.0       # fixed cost of a sparse-kernel row, in MACs
+GENERIC_TOLL_PER_COL = float(os.environ.get("SIMILARIPY_AMD_GENERIC_TOLL_PER_COL", "3.0"))      # fixed cost of a generic-kernel row per output column
 
 
 def partition_targets(work: np.ndarray, world_size: int) -> np.ndarray:
