@@ -437,7 +437,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             auto ld = [&](int T, u32x4 &ids, u32x4 &vals, int &d, float &sv) __attribute__((always_inline)) {
                 int vo;
                 trip_lane(T, vo, d, sv);
-                ids = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, vo, 0, 0);
+                int vo_i = vo;
+#if SP_ABLATION
+                if ((p.dbg & 32768) && d > 0) vo_i = lane * 16 + (T & 3) * 1024;      // ablation: sweep 2's id loads hit the cache (what would ids kept in registers gain?)
+#endif
+                ids = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, vo_i, 0, 0);
                 vals = __builtin_amdgcn_raw_buffer_load_b128(rs_val, vo, 0, 0);
             };
             auto body = [&](int T, const u32x4 &ids, const u32x4 &vals, int d, float sv) __attribute__((always_inline)) {
