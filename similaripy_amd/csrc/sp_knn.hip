@@ -1428,7 +1428,8 @@ int run_host_multi(sp_knn_args *a) {
     for (int i = 0; i < nd; ++i) {
         devs[(size_t)i] = a->device_ids ? a->device_ids[i] : i;
         if (devs[(size_t)i] < 0 || devs[(size_t)i] >= ndev) return fail(SP_EINVAL, "device_ids[%d] = %d out of range (have %d)", i, devs[(size_t)i], ndev);
-        for (int j = 0; j < i; ++j)
+        // (SIMILARIPY_AMD_ALLOW_REPEATED_DEVICES: the sharding, the per-device threads and the joins of the pieces on a one-GPU box — tests)
+        for (int j = 0; j < i && getenv("SIMILARIPY_AMD_ALLOW_REPEATED_DEVICES") == nullptr; ++j)
             if (devs[(size_t)j] == devs[(size_t)i]) return fail(SP_EINVAL, "device_ids holds device %d twice", devs[(size_t)i]);
     }
     for (size_t i = 0; i < nt; ++i)

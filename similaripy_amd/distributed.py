@@ -249,7 +249,7 @@ class ShardedDeviceProblem:
     """
 
     def __init__(self, call: KernelCall, group=None, device=None, dst: int = 0, compact: bool = True, chunk_rows: Optional[int] = None,
-                 phases: int = 1, gather_alone: bool = False):
+                 phases: int = 1, gather_alone: bool = False, persist_prep: bool = False):
         import torch
         import torch.distributed as dist
 
@@ -262,6 +262,11 @@ class ShardedDeviceProblem:
         self.device = torch.device("cuda", local_device()) if device is None else torch.device(device)
         # gloo has no device-tensor gather: the slab goes through the host (CPU tests, and HIP kernels at world_size > 1 on ONE GPU)
         self.host_gather = self.distributed and dist.get_backend(group) != "nccl"
+        # persist_prep: the per-call passes over the REPLICATED operands (column term folded into m2 / packed column terms and their
+        # minima, window boundaries, sign flag) are built by the first step and reused by every later one (SP_FLAG_REUSE_M2_PREP): the
+        # resident problem's operands do not change between steps — a caller who rewrites them in place calls invalidate_prep()
+        self.persist_prep = bool(persist_prep)
+        self._prep_done = False
         self.work = row_cost(call)
         k = call.k
         self.chunk_rows = None if not chunk_rows or chunk_rows >= call.n_targets else int(chunk_rows)
@@ -318,14 +323,16 @@ class ShardedDeviceProblem:
 
         k = self.call.k
         info = {"kernel_ms": 0.0, "passes_total": 0}
+        keep = self.persist_prep and self._prep_done and not kw.get("time_kernel")
         if self.phases == 1:
             if self.n_loc:
-                info = self.prob.run(self.pad_cols[: self.n_loc * k], self.pad_vals[: self.n_loc * k], self.pad_cnt[: self.n_loc], **kw)
+                info = self.prob.run(self.pad_cols[: self.n_loc * k], self.pad_vals[: self.n_loc * k], self.pad_cnt[: self.n_loc], reuse_m2_prep=keep, **kw)
+                self._prep_done = True
             if gather:
                 self.gather()
             return info
         tot = {}
-        first = True
+        first = not keep
         for j in range(self.phases):
             a, b = self._sub_range(j)
             if b > a:
@@ -333,6 +340,7 @@ class ShardedDeviceProblem:
                 info = self.prob.run(c[: (b - a) * k], v[: (b - a) * k], n[: b - a], targets=self.prob.t["targets"][a:b],
                                      reuse_m2_prep=not first, **kw)
                 first = False
+                self._prep_done = True
                 for key in ("kernel_ms", "sparse_kernel_ms", "generic_kernel_ms", "passes_total"):
                     tot[key] = tot.get(key, 0) + info.get(key, 0)
             if gather:
@@ -341,6 +349,10 @@ class ShardedDeviceProblem:
         if gather:
             self._finish_gathers()
         return info
+
+    def invalidate_prep(self):
+        """The resident operands were rewritten in place: the next step rebuilds the passes over m2 / Y*."""
+        self._prep_done = False
 
     def _gather_sub(self, j: int):
         """Sub-slab j to the root, behind the sub-launch that fills it and beside the ones that follow."""

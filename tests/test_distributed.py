@@ -283,7 +283,7 @@ def _hip_worker(rank, world, port, q, which):
         # (2) the shipped class: compact slice resident on the device, slabs through the host for the gloo gather;
         #     one launch + one gather, and the split-phase form (3 sub-launches, sub-slab j gathered behind sub-launch j)
         for phases in (1, 3):
-            sh = D.ShardedDeviceProblem(call, device=torch.device("cuda", 0), phases=phases)
+            sh = D.ShardedDeviceProblem(call, device=torch.device("cuda", 0), phases=phases, persist_prep=(phases == 3))      # (the second step then reuses the first one's passes over m2)
             assert sh.world == 2 and sh.host_gather and sh.phases == phases
             assert sh.prob.call.n_rows_m1 <= call.n_rows_m1              # compact: only the slice's own rows of m1 went up
             sh.run()

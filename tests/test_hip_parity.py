@@ -1193,3 +1193,44 @@ def test_p3_with_array_selectors_on_the_device(fn, kw):
     host = getattr(sim, fn)(m, m2, k=k, filter_cols=fc, target_cols=tc, verbose=False, format_output="csr", **kw)
     assert host.nnz == res.nnz
     _assert_same_topk(host, res, k, rtol=RTOL)
+
+
+def test_multi_device_sharding_inside_the_library(monkeypatch):
+    """run_host_multi end to end on the one GPU of the test box: three "devices" that are all device 0 (test switch
+    SIMILARIPY_AMD_ALLOW_REPEATED_DEVICES) — the cost-balanced partition of `targets`, one host thread per slice running the
+    single-device entry concurrently, slots written into the caller's arrays at their offsets, CSR pieces joined on the host (row
+    pointers add up, entries move down), explicit-zero and error reports — against the plain call and the oracle."""
+    monkeypatch.setenv("SIMILARIPY_AMD_ALLOW_REPEATED_DEVICES", "1")
+    rng = np.random.default_rng(12)
+    m = _rand((12000, 1300), 0.006, 55).tolil()
+    m[11000:, :] = 0.0
+    m[11000:, :600] = 0.5                                   # a heavy tail: the slices differ in rows, not in work (one exact value: sums of 600 products in any order)
+    m = sp.csr_array(m.tocsr())
+    filt = _rand((12000, 12000), 12.0 / 12000, 56)
+    tg = np.sort(rng.choice(12000, size=9000, replace=False)).astype(np.int32)
+    devs = [0, 0, 0]
+    # the kernel boundary: slots, counts, padding
+    call = _host.prepare(m, k=20, l2=1.0, target_rows=tg, filter_cols=filt)
+    rows, cols, vals, counts = _host.run_hip(call, devices=devs)
+    want_raw = so.run_kernel(call, "port")
+    so.compare_topk(so.canonical(rows, cols, vals, call.targets, call.k), so.canonical(*want_raw, call.targets, call.k), call.k, rtol=RTOL, atol=ATOL, what="three slices")
+    np.testing.assert_array_equal(counts, so.slot_counts(*want_raw, call.targets, call.k)[0])
+    pad = np.arange(call.k)[None, :] >= counts[:, None]
+    assert not rows.reshape(-1, call.k)[pad].any() and not cols.reshape(-1, call.k)[pad].any() and not vals.reshape(-1, call.k)[pad].any()
+    # the public route: device transpose + norms per slice, CSR pieces joined; COO; rp3beta (device preprocessing per slice)
+    for name, kw in (("cosine", dict(k=20, target_rows=tg, filter_cols=filt)), ("cosine", dict(k=20)), ("rp3beta", dict(k=10, alpha=0.8, beta=0.4)),
+                     ("s_plus", dict(k=15, l1=0.5, l2=0.5, shrink=2.0, target_rows=tg[::-1].copy()))):      # (descending targets: the slots come back, host assembly)
+        for fmt in ("csr", "coo"):
+            one = getattr(sim, name)(m, verbose=False, format_output=fmt, **kw)
+            three = sim.multi_gpu.similarity(name, m, verbose=False, format_output=fmt, devices=devs, **kw)
+            assert type(three) is type(one) and three.shape == one.shape and three.nnz == one.nnz, (name, fmt)
+            a, b = sp.csr_array(three), sp.csr_array(one)
+            if fmt == "csr":
+                np.testing.assert_array_equal(a.indptr, b.indptr)
+            _assert_same_topk(a, b, kw["k"], rtol=1e-6, tied=True)      # (the thousand identical heavy rows tie en masse: kept VALUES are compared)
+    # a stored zero is reported from whichever slice finds it, and the caller's fallback (eliminate on the host, call again) still works
+    mz = m.copy()
+    mz.data[7] = 0.0
+    z = sim.multi_gpu.similarity("cosine", mz, k=5, verbose=False, format_output="csr", devices=devs)
+    mz.eliminate_zeros()
+    _assert_same_topk(z, sim.cosine(mz, k=5, verbose=False, format_output="csr"), 5, rtol=1e-6, tied=True)
