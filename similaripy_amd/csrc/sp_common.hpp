@@ -55,6 +55,7 @@ struct KParams {
     u64 *gU, *gU_g;        // candidate buffers in global memory (only when they do not fit LDS): sparse / generic kernel
     unsigned int *queue;   // [0] / [1] = next queue position of the sparse / generic kernel (dynamic scheduling)
     unsigned int *qcount;  // [0] / [1] = rows in the sparse / generic queue (the sparse kernel appends its give-ups to [1])
+    unsigned int *qcount_g; // rows in the generic queue: where a sparse-row kernel (workgroup- or wave-per-row: each has its own queue, [0] above) appends its give-ups
     const int4 *desc;      // sparse queue: two int4 per row {slot, m1 row, m1 start, m1 length}, {MACs (saturated), Xtv[row], Xcos[row], Xdep[row]}
     int4 *desc_g;          // generic queue, same records
     unsigned m2_bytes;     // nnz(m2) * 4: extent of the m2 index / value buffers (buffer-load range check)

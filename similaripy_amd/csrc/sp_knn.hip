@@ -94,6 +94,7 @@ struct Config {
     int T_s, logT_s, NT_s;             // sparse kernel: tile (region A = 8*T_s bytes) and workgroup size
     int cap_s;                     // sparse kernel's candidate buffer capacity
     int wgs_sparse, wgs_generic;   // persistent workgroups of the two row kernels
+    int wgs_wave;                  // ... and of the wave-per-row kernel (single-wave workgroups), when it runs
     bool u_lds, u_lds_s;           // candidate buffer in LDS: generic / sparse kernel
     size_t lds_sparse, lds_generic;
     size_t ws_gu_bytes;     // candidate buffers in global memory for both kernels (0 when they live in LDS)
@@ -206,9 +207,9 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
     c->pack = !c->fold && ((a->l1 != 0.f) + (a->l2 != 0.f) + (a->l3 != 0.f) >= 2) && a->n_output_cols > 0;
     c->ws_fold_bytes = c->fold ? (((size_t)a->nnz_m2 * 4 + 255) & ~(size_t)255) : c->pack ? (((size_t)a->n_output_cols * 16 + 255) & ~(size_t)255) : 0;
     c->ordered = !(a->flags & (SP_FLAG_STATIC_SCHED | SP_FLAG_NO_ROW_ORDER)) && a->n_targets > std::min(c->wgs_sparse, c->wgs_generic);
-    // 512 B of bucket counters | work[n] | order[n] | (32-byte aligned) sparse queue n x 32 B | generic queue n x 32 B
+    // 512 B of bucket counters | work[n] | order[n] | (32-byte aligned) sparse queue n x 32 B | wave queue n x 32 B | generic queue n x 32 B
     c->ws_desc_offset = (512 + (size_t)a->n_targets * 8 + 31) & ~(size_t)31;
-    c->ws_rows_bytes = (c->ws_desc_offset + (size_t)a->n_targets * 64 + 255) & ~(size_t)255;
+    c->ws_rows_bytes = (c->ws_desc_offset + (size_t)a->n_targets * 96 + 255) & ~(size_t)255;
     // sparse kernel: one bit per column while the columns fit region A, else columns alias modulo the bitmap size
     int nb = 10;
     while (nb < c->logT_s + 6 && (1LL << nb) < (long long)a->n_output_cols) ++nb;
@@ -251,10 +252,12 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
     // in flight per CU (sp_wave_kernel.hpp) — when the average row fits its 63 packed trips with room to spare, or on request
     c->wave = c->items_rows > 0 && c->mono && NT_s == 256 && a->n_output_cols <= (1 << WV_BM_LOG2) && a->n_output_cols > T && a->k <= WV_KMAX &&
               !(a->reserved[0] & 16384) && (want_wave || (!a->threads_per_wg && avg_macs <= 10000.0));
+    c->wgs_wave = 0;
     if (c->wave) {
-        c->nb_log2 = WV_BM_LOG2;
+        // (the workgroup-per-row kernel keeps its 256-thread shape beside it: sparse rows the wave kernel does not take — more than 64 m1
+        // entries, more products than its 63 trips hold — have a queue of their own and run there, as in round 3)
         const int wv_a = a->n_output_cols <= 8 * WV_A_SMALL ? WV_A_SMALL : WV_A_LARGE;      // the column bitmap: eleven or nine rows in flight per CU
-        c->wgs_sparse = std::max(1, std::min(a->num_wgs > 0 ? a->num_wgs : n_cus * (int)(LDS_LIMIT / wv_lds_bytes(wv_a)), std::max(1, a->n_targets)));
+        c->wgs_wave = std::max(1, std::min(a->num_wgs > 0 ? a->num_wgs : n_cus * (int)(LDS_LIMIT / wv_lds_bytes(wv_a)), std::max(1, a->n_targets)));
     }
     c->ws_total = WS_QUEUE_BYTES + c->ws_gu_bytes + c->ws_fold_bytes + c->ws_rows_bytes + c->ws_split_bytes + c->ws_piece_bytes + c->ws_items_bytes;
     return SP_OK;
@@ -339,15 +342,20 @@ int launch_rows(const KParams &kp_s, const KParams &kp, const Config &c, hipStre
     // sparse rows first; what it cannot finish joins the generic queue, which the second launch drains
     if (ev) HIP_TRY(hipEventRecord(ev[0], stream));
     if (kp.sparse_path && c.wave) {
+        KParams kp_w = kp_s;                       // its own queue: head, length, descriptors
+        kp_w.queue = kp_s.queue + 6;
+        kp_w.qcount = kp_s.queue + 7;
+        kp_w.desc = kp_s.desc + 2 * (size_t)kp_s.n_targets;
         if (kp_s.n_cols <= 8 * WV_A_SMALL) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(sp_knn_wave_kernel<WV_A_SMALL>), hipFuncAttributeMaxDynamicSharedMemorySize, wv_lds_bytes(WV_A_SMALL)));
-            hipLaunchKernelGGL(sp_knn_wave_kernel<WV_A_SMALL>, dim3(c.wgs_sparse), dim3(64), wv_lds_bytes(WV_A_SMALL), stream, kp_s);
+            hipLaunchKernelGGL(sp_knn_wave_kernel<WV_A_SMALL>, dim3(c.wgs_wave), dim3(64), wv_lds_bytes(WV_A_SMALL), stream, kp_w);
         } else {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(sp_knn_wave_kernel<WV_A_LARGE>), hipFuncAttributeMaxDynamicSharedMemorySize, wv_lds_bytes(WV_A_LARGE)));
-            hipLaunchKernelGGL(sp_knn_wave_kernel<WV_A_LARGE>, dim3(c.wgs_sparse), dim3(64), wv_lds_bytes(WV_A_LARGE), stream, kp_s);
+            hipLaunchKernelGGL(sp_knn_wave_kernel<WV_A_LARGE>, dim3(c.wgs_wave), dim3(64), wv_lds_bytes(WV_A_LARGE), stream, kp_w);
         }
         HIP_TRY(hipGetLastError());
-    } else if (kp.sparse_path) {
+    }
+    if (kp.sparse_path) {
         int rc;
         if (c.NT_s == 256) rc = launch_sparse<256>(kp_s, c, stream);
         else if (c.NT_s == 512) rc = launch_sparse<512>(kp_s, c, stream);
@@ -505,6 +513,7 @@ int run_device_impl(sp_knn_args *a) {
     kp.T = c.T; kp.logT = c.logT; kp.cap = c.cap;
     kp.queue = (unsigned int *)ws;
     kp.qcount = (unsigned int *)(ws + 8);
+    kp.qcount_g = (unsigned int *)(ws + 12);
     kp.cap_s = c.cap_s;
     kp.gU = c.u_lds_s ? nullptr : (u64 *)ws_gu;
     kp.gU_g = c.u_lds ? nullptr : (u64 *)(ws_gu + c.ws_gu_s_bytes);
@@ -516,7 +525,8 @@ int run_device_impl(sp_knn_args *a) {
         unsigned *work = (unsigned *)(ws_rows + 512);       // [n]
         int *order = (int *)(work + a->n_targets);          // [n]
         int4 *desc_s = (int4 *)(ws_rows + c.ws_desc_offset);            // [2n]
-        int4 *desc_g = desc_s + 2 * (size_t)a->n_targets;               // [2n]
+        int4 *desc_w = desc_s + 2 * (size_t)a->n_targets;               // [2n] the wave kernel's queue (launch_rows finds it there)
+        int4 *desc_g = desc_w + 2 * (size_t)a->n_targets;               // [2n]
         HIP_TRY(hipMemsetAsync(ws_rows, 0, 512, stream));
         const int work_blocks = std::max(1, std::min((a->n_targets + 15) / 16, n_cus * 8));     // 16 rows (waves) per block and trip
         unsigned *long_count = bucket_count + 100;          // (inside the 512 bytes zeroed above; the list borrows `order`, written later)
@@ -532,7 +542,11 @@ int run_device_impl(sp_knn_args *a) {
         ClassifyParams cp;
         cp.sparse_path = kp.sparse_path;
         cp.n_cols = a->n_output_cols; cp.T = c.T; cp.nb_log2 = c.nb_log2;
-        cp.cs_slots = c.wave ? WV_CSN : c.T_s / 4;
+        cp.cs_slots = c.T_s / 4;
+        cp.wave = c.wave ? 1 : 0;
+        cp.wave_macs_max = 10000u;
+        cp.qcount_w = (unsigned *)(ws + 28);          // header words 6 / 7: head and length of the wave kernel's queue (zeroed with the header)
+        cp.desc_w = desc_w;
         cp.mono = c.mono ? 1 : 0;
         cp.any_norm = (a->l1 != 0.f || a->l2 != 0.f || a->l3 != 0.f || a->stabilized_shrink != 0.f || a->bayesian_shrink != 0.f) ? 1 : 0;
         cp.l2 = a->l2; cp.l3 = a->l3;
@@ -564,6 +578,12 @@ int run_device_impl(sp_knn_args *a) {
                                a->m1_indices, a->m1_data, a->m2_indptr, (int4 *)ws_items, c.NT_s == 256 ? 1 : 0,
                                (c.mono && a->filter_mode == SP_SEL_MATRIX) ? a->filter_m_indptr : nullptr);
             HIP_TRY(hipGetLastError());
+            if (c.wave) {
+                hipLaunchKernelGGL(sp_row_items_kernel, dim3(item_blocks), dim3(256), 0, stream, (const unsigned *)cp.qcount_w, c.items_rows, (int4 *)desc_w,
+                                   a->m1_indices, a->m1_data, a->m2_indptr, (int4 *)ws_items, 1,
+                                   (c.mono && a->filter_mode == SP_SEL_MATRIX) ? a->filter_m_indptr : nullptr);
+                HIP_TRY(hipGetLastError());
+            }
             kp.items_g = (const int4 *)ws_items; kp.items_rows = c.items_rows;
         }
     }
@@ -621,7 +641,7 @@ int run_device_impl(sp_knn_args *a) {
         for (int i = 0; i < PH_N; ++i) a->phase_cycles[i] = (int64_t)phc[i];
         a->phase_cycles[PH_CSDRAIN] = c.wave ? 1 : 0;        // (slot 8 carries no timer: which sparse-row kernel ran)
         a->passes_total = (int32_t)phc[CT_PASSES];
-        a->num_wgs_used = c.wgs_sparse;
+        a->num_wgs_used = c.wave ? c.wgs_wave : c.wgs_sparse;
         float ks_ms = 0.f, kg_ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ks_ms, kev[0], kev[1]));
         HIP_TRY(hipEventElapsedTime(&kg_ms, kev[2], kev[3]));

@@ -131,6 +131,11 @@ struct ClassifyParams {
     unsigned split_macs;       // a row gets one piece per this many MACs (and is split at all from twice that on)
     int split_cap;             // at most this many rows
     int *split_count;          // [2] rows split so far, pieces handed out so far (zero on entry)
+    // light sparse rows have a kernel (and a queue) of their own: one wave per row (sp_wave_kernel.hpp)
+    int wave;                  // 1 = that kernel runs in this call
+    unsigned wave_macs_max;    // a sparse row goes to it with at most this many MACs and at most 64 m1 entries (its trips come from the prepass)
+    unsigned *qcount_w;        // rows in its queue
+    int4 *desc_w;              // its queue
     int4 *split_rows;          // [split_cap] {output slot, first piece, pieces, 0}
     int2 *piece_info;          // [split_cap * split_pmax] {output slot, first fine window | one past the last << 16}
 };
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(256) void sp_row_desc_kernel(int n_targets, const i
     const int lane = threadIdx.x & 63;
     const bool valid = pos < n_targets;
     int4 d0 = make_int4(0, 0, 0, 0), d1 = d0;
-    bool sparse = false;
+    bool sparse = false, wavey = false;
     if (valid) {
         const int slot = (ordered_flag != nullptr && ordered_flag[0] != 0u) ? order[pos] : pos;
         const int t = targets[slot];
@@ -167,6 +172,7 @@ __global__ __launch_bounds__(256) void sp_row_desc_kernel(int n_targets, const i
             const float expect = 0.5f * m * m * (1.f / (float)cp.n_cols + alias);
             sparse = expect <= 0.30f * (float)cp.cs_slots;
         }
+        wavey = sparse && cp.wave && (e - s) <= 64 && macs <= cp.wave_macs_max;
     }
     // heavy generic rows: one queue entry per piece
     int split_id = -1, n_pieces = 0, per_piece = 0, piece0 = 0;
@@ -184,21 +190,27 @@ __global__ __launch_bounds__(256) void sp_row_desc_kernel(int n_targets, const i
         }
     }
     const int n_g = (valid && !sparse) ? (split_id >= 0 ? n_pieces : 1) : 0;     // generic queue entries of this lane
-    const u64 ms = __ballot(valid && sparse);
+    const u64 ms = __ballot(valid && sparse && !wavey), mw = __ballot(valid && wavey);
     int incl = n_g;                                                                      // inclusive wave scan
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
     const int tot_g = __shfl(incl, 63, 64);
-    unsigned bs = 0, bg = 0;
+    unsigned bs = 0, bg = 0, bw = 0;
     if (lane == 0) {
+        if (mw) bw = atomicAdd(cp.qcount_w, (unsigned)__popcll(mw));
         if (ms) bs = atomicAdd(&qcount[0], (unsigned)__popcll(ms));
         if (tot_g) bg = atomicAdd(&qcount[1], (unsigned)tot_g);
     }
     bs = (unsigned)__builtin_amdgcn_readfirstlane((int)bs);
     bg = (unsigned)__builtin_amdgcn_readfirstlane((int)bg);
+    bw = (unsigned)__builtin_amdgcn_readfirstlane((int)bw);
     if (valid) {
         const u64 below = (1ull << lane) - 1ull;
-        if (sparse) {
+        if (wavey) {
+            int4 *dst = cp.desc_w + 2 * (size_t)(bw + (unsigned)__popcll(mw & below));
+            dst[0] = d0;
+            dst[1] = d1;
+        } else if (sparse) {
             int4 *dst = desc_s + 2 * (size_t)(bs + (unsigned)__popcll(ms & below));
             dst[0] = d0;
             dst[1] = d1;

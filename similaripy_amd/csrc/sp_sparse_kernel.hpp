@@ -1329,7 +1329,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                            __builtin_amdgcn_readlane((int)dNN, 6), __builtin_amdgcn_readlane((int)dNN, 7));
             wg_sync<U_LDS>();
             if (tid == 0) {
-                const unsigned g = atomicAdd(&p.qcount[1], 1u);
+                const unsigned g = atomicAdd(p.qcount_g, 1u);
                 p.desc_g[2 * (size_t)g] = make_int4(dC.x, dC.y, dC.z, n1);      // (without the record counts)
                 p.desc_g[2 * (size_t)g + 1] = wC;
                 sh[SH_OVF] = 0; sh[SH_RETRY] = 0; sh[SH_CNT2] = 0; sh[SH_EQ] = 0; sh[SH_PCTR] = 0;

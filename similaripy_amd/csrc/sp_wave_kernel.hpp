@@ -617,7 +617,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         } else {
             // not a row for this kernel (no trip records, too many trips) or a pool overflowed: the generic kernel's queue takes it
             if (lane == 0) {
-                const unsigned g = atomicAdd(&p.qcount[1], 1u);
+                const unsigned g = atomicAdd(p.qcount_g, 1u);
                 p.desc_g[2 * (size_t)g] = make_int4(d0.x, d0.y, d0.z, n1);      // (without the record counts)
                 p.desc_g[2 * (size_t)g + 1] = d1;
             }
