@@ -4,23 +4,24 @@
 // The workgroup-per-row kernel (sp_sparse_kernel.hpp) spends a light row's time at barriers and on memory round trips nobody
 // overlaps: 59 k cycles for 6.4 k products, three 4-wave workgroups per CU (round 3: 3.9 B/clk/CU against the 13-16 B/clk a CU
 // can pull).  Here a row belongs to ONE wave64 and the workgroup IS that wave: no barrier anywhere, every counter a scalar
-// register, 20 KB of LDS per wave, i.e. EIGHT independent rows in flight per CU, and each wave keeps several trips of its row in
-// flight (it has the registers: two waves per SIMD).
+// register, 14 KB of LDS per wave, i.e. ELEVEN independent rows in flight per CU, and each wave keeps several trips of its row in
+// flight.
 //
 // Same algorithm as the monotone variant of the sparse kernel (s_plus.h:71-127 dense sums[] -> column BITMAP + two sweeps;
 // s_plus.h:39-64 heap -> radix selection; s_plus.h:129-156 epilogue on the winners; s_plus.h:159-171 MATRIX filter):
 //   sweep 1 (column ids)      one bit per output column (n_cols <= 2^17: exact); a product that finds its bit set marks its
 //                             column in the 8 k-bit collision bitmap (columns alias modulo its size: an aliased column is only
 //                             summed where it need not be);
-//   clear + rank prefix       the bitmap's storage becomes [collision set 1024 slots | member pool 1024 entries];
+//   clear + rank prefix       the bitmap's storage becomes [collision set 1024 slots | member pool | U];
 //   sweep 2 (ids + values)    x = value * m1 value; products of marked columns -> member pool; every other product is the only
 //                             one of its column and goes to the candidate buffer U (256 entries) iff x beats the running k-th
 //                             value; a full U is cut back to its k largest by a wave-local MSD radix selection;
 //   accumulate, drain         members find their slot by the rank of their column's bit (32-bit compare-and-swap claims, float add),
 //                             complete sums above the cutoff join U; excluded (filter) columns carry a -inf pseudo member;
 //   select, write-out         exact top-k, epilogue val = xy / den (or the raw dot), threshold, compaction.
-// Work items: the packed trips sp_row_items_kernel cuts once per call (lane T of the wave holds trip T's record: at most 63
-// trips, i.e. rows of up to ~16 k products; others go to the generic kernel's queue, as does any row whose pools overflow).
+// Work items: the packed trips sp_row_items_kernel cuts once per call (lane T of the wave holds trip T's record: at most 63 trips).
+// The kernel has its own queue: sp_row_desc_kernel sends it the sparse rows with at most 64 m1 entries and 10 k products, the other
+// sparse rows run on the workgroup-per-row kernel in the same call; a row that fails here (collision set full) joins the generic queue.
 #pragma once
 #include "sp_common.hpp"
 
