@@ -98,7 +98,12 @@ typedef struct sp_knn_args {
     uint32_t struct_size;      /* = sizeof(sp_knn_args); checked */
     uint32_t flags;            /* SP_FLAG_* */
     int32_t  on_device;        /* 0: every pointer below is host memory (the drop-in call: H2D, compute, D2H)
-                                  1: every pointer is device memory on `device`, resident before the call */
+                                  1: every pointer is device memory on `device`, resident before the call; the launches are queued on
+                                     `stream` and the call returns without waiting — with ONE exception: a depopularisation-only epilogue
+                                     (l3 != 0, l1 = l2 = 0, no shrink: rp3beta) folds the column term into a copy of m2 and reads a 4-byte
+                                     flag back first (a stored entry over a zero term forces the unfolded route, s_plus.h:144-150), i.e.
+                                     such a call synchronises `stream` once and cannot be stream-captured; SP_FLAG_NO_FOLD avoids the fold
+                                     and the wait, SP_FLAG_REUSE_M2_PREP calls reuse the answer without waiting */
     int32_t  device;           /* HIP device ordinal */
 
     /* problem shape (the reference infers these from NumPy arrays it never passes down) */

@@ -22,11 +22,15 @@ constexpr int EMPTY = -1;                        // key of a free slot (column i
 constexpr u64 EMPTY64 = 0xFFFFFFFF00000000ull;   // free accumulator slot: key EMPTY, partial sum +0.0f
 constexpr int MAX_PROBE = 128;   // probe budget of one element before a hashed window is declared overflowed
 // m2 elements per lane and trip (two trips are in flight); 1024-thread workgroups have half the VGPR budget
+#ifndef ACC_UNROLL
 #define ACC_UNROLL (NT >= 1024 ? 2 : NT >= 768 ? 4 : 8)
+#endif
 constexpr int U_SLACK = 1024;    // candidate-buffer entries beyond k (room between two selections)
 // table slots per thread per drain iteration (their Y gathers fly together); 1024-thread workgroups have
 // half the VGPR budget (128), where 8 would spill
+#ifndef DRAIN_UNROLL
 #define DRAIN_UNROLL (NT >= 1024 ? 2 : NT >= 768 ? 4 : 8)
+#endif
 
 // scalar slots in LDS
 enum { SH_CNT = 0, SH_OVF, SH_SEL, SH_NEED, SH_EQ, SH_CNT2, SH_RETRY, SH_QA, SH_QB, SH_PCTR, SH_MCTR, SH_NITEMS, SH_STOP, SH_WSUM, SH_NHI = SH_WSUM + 16, SH_BINCNT, SH_LIST, SH_N };   // SH_CNT2/SEL/NEED/EQ belong to the selections
