@@ -444,7 +444,9 @@ constexpr int POOL_BLK = 64;      // pool entries a wave reserves at a time (>= 
 constexpr int CS_MAXPROBE = 64;   // linear-probe budget in the collision set
 constexpr unsigned OOB_SOFFSET = 0xFFFFF000u;   // buffer-load scalar offset beyond any m2 extent: every lane out of range
 constexpr int SEL_E = 4;          // candidate-buffer entries per thread the register-resident selection handles
-constexpr int ITEMS_PRE = 511;    // item records per row that the per-call prepass cuts (rows with more, or with more than 64 m1 entries: in the kernel)
+constexpr int ITEMS_PRE = 255;    // item records per row that the per-call prepass cuts (rows with more, or with more than 64 m1 entries: in the kernel).
+                                  // 256 records x 16 B = 4 KB of workspace per output slot (8 KB before; a C2 row has 193 records, a
+                                  // user-scoring row 65; rows beyond 255 trips — 65 k products — are set up in the kernel as they were before the prepass)
 constexpr int ITEMS_STRIDE = ITEMS_PRE + 1;
 // descriptor word .w of a sparse-queue row: m1 entries | trips cut by the prepass << 9 | item records << 19 (0 / 0: cut in the kernel)
 __host__ __device__ constexpr int desc_n1(int w) { return w & 0x1FF; }

@@ -244,7 +244,7 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
     // variant.  (This assignment was lost in round 2's piece splitter commit: `big` was stack garbage from then on — the tests that
     // need it passed by the accident of what the stack held; round 3's cache cap changed that accident and exposed it.)
     c->big = a->nnz_m2 >= (1LL << 30) - 1024 || (a->reserved[0] & 1024);      // (bit 1024 of the ablation word: force it, for tests at small sizes)
-    // the sparse kernel's work items, cut once per call: ITEMS_STRIDE * 16 B = 8 KB per output slot, for at most ITEMS_ROWS_MAX slots (the rows beyond
+    // the sparse kernel's work items, cut once per call: ITEMS_STRIDE * 16 B = 4 KB per output slot, for at most ITEMS_ROWS_MAX slots (the rows beyond
     // are set up in the kernel, as are rows of more than 64 entries or more than ITEMS_PRE items)
     c->items_rows = (!(a->flags & SP_FLAG_NO_SPARSE_PATH) && !c->big && !(a->reserved[0] & 2048) && a->nnz_m2 > 0) ? std::min(a->n_targets, ITEMS_ROWS_MAX) : 0;
     c->ws_items_bytes = ((size_t)c->items_rows * ITEMS_STRIDE * 16 + 255) & ~(size_t)255;
