@@ -1344,6 +1344,25 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         dN = dR; wN = wR;
         my_r0 = nx_r0; my_len = nx_r1 - nx_r0; my_v = nx_v;
         recC = recN; recC2 = recN2;
+        // Removed barrier (round 3), the audit VERDICT r3 asked to have written down — every LDS word thread 0 (or any thread) of the NEXT
+        // row writes in front of that row's first barrier, and the LAST read of it in this row:
+        //   sh[SH_QA]                    written at the next row's top by thread 0;  last read: this row's setup, behind its setup barrier
+        //   sh[SH_MCTR], sh[SH_NITEMS]   reset at the top;  last reads: the last stage's `mext` / the setup's `n_items`, each behind a
+        //                                barrier that every thread passes before the write-out's closing barrier
+        //   sh[SH_CNT]                   reset at the top;  last read: `n_sel` at the write-out's head, IN FRONT of its closing barrier
+        //                                (MONO: wg_sync behind the compaction loop; general + LDS U: the "U read before it is cleared"
+        //                                barrier) — the variant without such a barrier is the one that keeps the barrier below
+        //   sh[SH_SEL], sh[SH_NEED]      reset at the top;  last reads: the first stage / a selection, each closed by its own barrier
+        //   sh[SH_PCTR]                  general: reset at the top, last read `ext` behind a stage barrier; MONO: never reset here — it IS
+        //                                the write-out's compaction counter, read (n_out) behind the closing barrier and then left at
+        //                                the value the next write-out expects only because every stage's drain resets it (see there)
+        //   items[] / sort scratch       written by the next row's setup (records, sentinel, scratch);  last reads: this row's sweeps
+        //                                and stage set-up (`items[i0].w`), all in front of the write-out's closing barrier
+        //   shx[0..1]                    (MONO filter bounds) written with the records;  last read: sweep 1's head
+        //   U / region A                 zeroed by this row's own threads in front of the closing barrier (MONO + LDS U: each thread the
+        //                                entries it read), so the next row's bitmap finds zeros without a barrier of its own
+        // select_fast (CLEAN) leaves SH_CNT2 / SH_EQ / SH_NHI at zero BEHIND its closing barrier for the same reason (the race of
+        // commit 5b758b7 was exactly a reset in FRONT of a barrier that slower waves still read behind).
         // (no barrier here: every path of the next row's setup has one in front of its first use of the storage cleared above, and its
         // writes in front of that barrier — the counters of thread 0, the item records, the sort scratch — touch nothing this row's
         // tail still reads: the last reads of sh[] lie in front of a barrier of the write-out.  The one variant whose write-out has no
