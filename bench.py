@@ -212,6 +212,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: functional check of the N > 1 path on a box with fewer GPUs than ranks (ranks share devices, slabs gathered through the host)")
     ap.add_argument("--phases", type=int, default=4, help="N > 1: sub-slices of the split-phase gather (1 = one launch, one gather)")
+    ap.add_argument("--reserve-cus", type=int, default=8, help="N > 1 under RCCL: CUs the persistent row kernels leave free, so that the gather's kernels can run beside the next sub-launch (0 = none)")
     ap.add_argument("--rows", type=int, default=0)
     ap.add_argument("--cols", type=int, default=0)
     ap.add_argument("--nnz-row", type=int, default=0)
@@ -256,6 +257,8 @@ def main():
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
+    if world > 1 and args.backend == "nccl" and args.reserve_cus > 0 and args.phases > 1:
+        os.environ["SIMILARIPY_AMD_RESERVE_CUS"] = str(args.reserve_cus)      # (read by the library at every call)
     world_seen = dist.get_world_size() if world > 1 else 1
     assert world_seen == world
 
@@ -423,6 +426,7 @@ def main():
             "target_slots": total_rows, "rows_per_gpu": total_rows // world, "cols": n_cols, "nnz_per_row": nnz_row, "k": k,
             "macs_per_row": macs / total_rows,
             "parallelism": par, "backend": args.backend if world > 1 else None,
+            "reserved_cus": int(os.environ.get("SIMILARIPY_AMD_RESERVE_CUS", "0")),
             "m2_prep": "every step" if world == 1 else "once per resident problem (SP_FLAG_REUSE_M2_PREP: the replicated operands do not change between steps)",
             "kept_entries_rank0": n_kept, "generic_windows_per_row": info["passes_total"] / max(1, main_res["per_rank"][0]["rows"]),
             "phase_share": phase_share(info),

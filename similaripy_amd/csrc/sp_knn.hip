@@ -314,6 +314,13 @@ int device_cus(int device, int *n_cus) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     *n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    // SIMILARIPY_AMD_RESERVE_CUS=n: the persistent row kernels are sized for n CUs fewer.  They fill every CU they are given (LDS), and a
+    // kernel of another stream — the RCCL gather of a finished sub-slab in the multi-GPU step — only starts when workgroups retire:
+    // a few CUs left free are what lets the communication actually run beside the next sub-launch (distributed.py, bench.py --gpus N).
+    if (const char *e = getenv("SIMILARIPY_AMD_RESERVE_CUS")) {
+        const int r = atoi(e);
+        if (r > 0) *n_cus = std::max(1, *n_cus - r);
+    }
     return SP_OK;
 }
 
