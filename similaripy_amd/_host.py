@@ -317,6 +317,27 @@ def compute_target_columns(filter_cols, target_cols, n_cols: int) -> np.ndarray:
     return np.flatnonzero(mask).astype(np.int32, copy=False)
 
 
+def column_keep_mask(filter_cols, target_cols, n_cols: int) -> np.ndarray:
+    """The same selection as a byte mask (sp_knn_args.col_keep) — without the detour through the list of kept ids."""
+    def arr(c):
+        return isinstance(c, (list, np.ndarray)) and len(c) != 0
+
+    if not arr(filter_cols) and not arr(target_cols):
+        keep = np.zeros(n_cols, dtype=np.uint8)
+        keep[compute_target_columns(filter_cols, target_cols, n_cols)] = 1
+        return keep
+    if arr(target_cols):
+        keep = np.zeros(n_cols, dtype=np.uint8)
+        idx = np.asarray(target_cols, dtype=np.int32)
+        keep[idx[(idx >= 0) & (idx < n_cols)]] = 1
+    else:
+        keep = np.ones(n_cols, dtype=np.uint8)
+    if arr(filter_cols):
+        idx = np.asarray(filter_cols, dtype=np.int32)
+        keep[idx[(idx >= 0) & (idx < n_cols)]] = 0
+    return keep
+
+
 def filter_matrix_columns(data, indices, indptr, n_cols: int, keep_cols: np.ndarray):
     """Drop CSR entries whose column is not in keep_cols; column ids are preserved
     (s_plus_utils.pyx:424-490, the two typed loops become one mask + cumulative count)."""
@@ -539,12 +560,10 @@ def prepare(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_mat
     call.target_col_mode, call.target_col_m_indptr, call.target_col_m_indices = sel_t
     if on_dev:
         if arr_sel:
-            call.col_keep = np.zeros(n_output_cols, dtype=np.uint8)
-            call.col_keep[compute_target_columns(filter_cols, target_cols, n_output_cols)] = 1
+            call.col_keep = column_keep_mask(filter_cols, target_cols, n_output_cols)
         return call        # (the device builds m2 with ascending column ids; SP_FLAG_M1_IS_M2_T checks those of the caller's)
     if arr_sel and keep_on_device:
-        call.col_keep = np.zeros(n_output_cols, dtype=np.uint8)
-        call.col_keep[compute_target_columns(filter_cols, target_cols, n_output_cols)] = 1
+        call.col_keep = column_keep_mask(filter_cols, target_cols, n_output_cols)
     elif arr_sel:
         keep = compute_target_columns(filter_cols, target_cols, n_output_cols)
         call.m2_data, call.m2_indices, call.m2_indptr = filter_matrix_columns(
