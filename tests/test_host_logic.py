@@ -69,6 +69,16 @@ def test_matrix_selector(golden):
     assert _host.build_column_selector(sp.csr_array((3, 3)))[0] == _host.MODE_NONE      # sparse without data
     assert _host.build_column_selector([1, 2])[0] == _host.MODE_ARRAY
     assert _host.build_column_selector(np.array([4]))[0] == _host.MODE_ARRAY
+    # explicit zeros go, rows come out sorted, and the caller's matrix is left as it was (s_plus_utils.pyx:326-333 works on a copy)
+    dirty = sp.csr_array((np.array([1, 0, 2, 3], dtype=np.float32), np.array([3, 1, 0, 2], dtype=np.int32), np.array([0, 3, 4], dtype=np.int32)), shape=(2, 4))
+    before = (dirty.data.copy(), dirty.indices.copy(), dirty.indptr.copy())
+    mode, ip, ix = _host.build_column_selector(dirty)
+    assert mode == _host.MODE_MATRIX and ip.tolist() == [0, 2, 3] and ix.tolist() == [0, 3, 2]
+    for a, b in zip(before, (dirty.data, dirty.indices, dirty.indptr)):
+        np.testing.assert_array_equal(a, b)
+    # a canonical matrix is used where it lies (no copy of 64 M entries for an URM that filters itself)
+    clean = sp.csr_array((np.ones(3, dtype=np.float32), np.array([0, 2, 1], dtype=np.int32), np.array([0, 2, 3], dtype=np.int32)), shape=(2, 4))
+    assert np.shares_memory(_host.build_column_selector(clean)[2], clean.indices)
 
 
 @pytest.mark.parametrize("norm", ["l1", "l2", "max"])
