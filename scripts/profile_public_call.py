@@ -1,5 +1,5 @@
 """Where the wall clock of the public calls goes (host preparation / C-ABI call with host buffers / output assembly).
-usage: python scripts/profile_public_call.py [c2|c4]"""
+usage: python scripts/profile_public_call.py [c2|c4|c5]"""
 import sys, time, cProfile, pstats, io
 sys.path.insert(0, '.')
 import numpy as np
@@ -13,6 +13,10 @@ if which == "c2":
              ("cosine coo", lambda: sim.cosine(m, k=100, verbose=False, format_output="coo")),
              # ARRAY selector: a tenth of the columns dropped while m2 = m1^T is built on the device (sp_knn_args.col_keep)
              ("cosine csr filter_cols=list", lambda: sim.cosine(m, k=100, verbose=False, format_output="csr", filter_cols=list(range(0, 1_000_000, 10))))]
+elif which == "c5":
+    m = workloads.fixed_degree_csr(1_000_000, 100_000, 64, 12345)
+    Wt = sim.cosine(m[:200_000].T.tocsr(), k=100, verbose=False, format_output="csr").T.tocsr()
+    calls = [("dot_product(urm, W.T, filter_cols=urm)", lambda: sim.dot_product(m, Wt, k=100, filter_cols=m, verbose=False, format_output="csr"))]
 else:
     m = workloads.movielens_like_urm().T.tocsr()
     calls = [("cosine", lambda: sim.cosine(m, k=200, verbose=False, format_output="csr")),

@@ -1066,10 +1066,18 @@ int run_host(sp_knn_args *a) {
     TRY(pool.up(a->l3 != 0.f ? a->Xdepop : nullptr, (size_t)a->n_rows_m1, &d.Xdepop));
     TRY(pool.up(a->l3 != 0.f ? a->Ydepop : nullptr, (size_t)a->n_output_cols, &d.Ydepop));
     const bool fm = a->filter_mode == SP_SEL_MATRIX, tm = a->target_col_mode == SP_SEL_MATRIX;
-    TRY(pool.up(fm ? a->filter_m_indptr : nullptr, (size_t)a->n_rows_m1 + 1, &d.filter_m_indptr));
-    TRY(pool.up(fm ? a->filter_m_indices : nullptr, (size_t)a->filter_nnz, &d.filter_m_indices));
-    TRY(pool.up(tm ? a->target_col_m_indptr : nullptr, (size_t)a->n_rows_m1 + 1, &d.target_col_m_indptr));
-    TRY(pool.up(tm ? a->target_col_m_indices : nullptr, (size_t)a->target_col_nnz, &d.target_col_m_indices));
+    // a selector that IS m1's pattern (filter_cols = the URM that is being scored: the same host arrays) goes up once
+    auto selector_up = [&](bool on, const int32_t *h_ptr, const int32_t *h_idx, int64_t nnz, const int32_t **d_ptr, const int32_t **d_idx) -> int {
+        if (on && !m1t && h_ptr == a->m1_indptr && h_idx == a->m1_indices && nnz == a->nnz_m1) {
+            *d_ptr = d.m1_indptr; *d_idx = d.m1_indices;
+            return SP_OK;
+        }
+        TRY(pool.up(on ? h_ptr : nullptr, (size_t)a->n_rows_m1 + 1, d_ptr));
+        TRY(pool.up(on ? h_idx : nullptr, (size_t)nnz, d_idx));
+        return SP_OK;
+    };
+    TRY(selector_up(fm, a->filter_m_indptr, a->filter_m_indices, a->filter_nnz, &d.filter_m_indptr, &d.filter_m_indices));
+    TRY(selector_up(tm, a->target_col_m_indptr, a->target_col_m_indices, a->target_col_nnz, &d.target_col_m_indptr, &d.target_col_m_indices));
 
     trace.mark("operands to the device");
     {

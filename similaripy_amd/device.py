@@ -51,7 +51,9 @@ class DeviceProblem:
                      "Xtversky", "Ytversky", "Xcosine", "Ycosine", "Xdepop", "Ydepop",
                      "filter_m_indptr", "filter_m_indices", "target_col_m_indptr", "target_col_m_indices"):
             arr = getattr(call, name)
-            self.t[name] = up(arr) if arr.size else None
+            # one device copy per host array: a MATRIX selector that is m1's own pattern (filter_cols = the URM being scored) goes up once
+            twin = next((n for n in self.t if self.t[n] is not None and getattr(call, n) is arr), None)
+            self.t[name] = self.t[twin] if twin else (up(arr) if arr.size else None)
         self.t["col_keep"] = up(call.col_keep) if call.col_keep is not None and call.col_keep.size else None
         self._ws = None
 

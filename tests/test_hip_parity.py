@@ -177,6 +177,10 @@ def test_matrix_selectors_and_target_rows():
                dict(filter_cols=urm, target_cols=list(range(0, 1500, 3)))):
         _check(_host.prepare(urm, w, k=25, **kw), f"selectors {sorted(kw)}")
         _check(_host.prepare(urm, w, k=25, **kw), f"selectors windows {sorted(kw)}", table_slots=1024, threads_per_wg=256)
+    # the URM as its own filter reaches the boundary as the SAME arrays (no copy on the host, one upload: run_host's selector_up)
+    call = _host.prepare(urm, w, k=25, filter_cols=urm, target_cols=urm)
+    assert np.shares_memory(call.filter_m_indices, call.m1_indices) and np.shares_memory(call.target_col_m_indptr, call.m1_indptr)
+    _check(call, "selectors aliased to m1")
 
 
 def test_empty_and_ragged_inputs():
