@@ -94,6 +94,11 @@ extern "C" {
                                      must not need a larger workspace than that call had).  This is how one step over a slice of target rows
                                      is cut into sub-launches whose results travel while the next one computes (distributed.py). */
 
+#define SP_FLAG_BINARY      32768u /* host mode only: `binary=True` (s_plus.pyx:214-217, m.data = ones AFTER eliminate_zeros): the stored values of
+                                     m1 (and of an explicit m2) are replaced by 1.0 in the uploaded copies, after the SP_FLAG_CHECK_ZEROS count
+                                     has seen the caller's values.  The caller's arrays are not modified (and no array of ones is built or
+                                     uploaded: 256 MB at 64 M entries).  Device-mode callers own their buffers and fill them themselves. */
+
 typedef struct sp_knn_args {
     uint32_t struct_size;      /* = sizeof(sp_knn_args); checked */
     uint32_t flags;            /* SP_FLAG_* */

@@ -82,6 +82,7 @@ class KernelCall:
     depop_rowsum_p2: Optional[float] = None  # SP_FLAG_DEPOP_ROWSUM: Ydepop = (row sums of the raw m1)^p2, built on the device
     m1_is_m2t: bool = False    # m1 = m2^T is built on the device (SP_FLAG_M1_IS_M2_T, matrix1 came as CSC): the m1_* arrays are empty
     norms_on_device: Optional[tuple] = None  # SP_FLAG_NORMS_ON_DEVICE: (c1, c2, additive_shrink); X/Y tversky / cosine vectors are empty
+    binary_on_device: bool = False           # SP_FLAG_BINARY: the value arrays are the caller's; the library writes ones into its uploaded copies
     col_keep: Optional[np.ndarray] = None    # with m2_is_m1t: uint8 [n_rows_m1], 0 = the output column is dropped while m2 is built (ARRAY selectors)
 
     @property
@@ -458,7 +459,8 @@ def prepare(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_mat
             stabilized_shrink=0.0, bayesian_shrink=0.0, additive_shrink=0.0, threshold=0.0,
             binary=False, target_rows=None, filter_cols=None, target_cols=None,
             verbose=False, format_output='csr', m2_on_device=False, check_zeros=True,
-            p3_alpha=None, p3_depop_beta=None, norms_on_device=False, csc_direct=False, keep_on_device=False) -> KernelCall:
+            p3_alpha=None, p3_depop_beta=None, norms_on_device=False, csc_direct=False, keep_on_device=False,
+            binary_on_device=False) -> KernelCall:
     """Everything s_plus.pyx does before the `with nogil:` block (:168-353).
 
     check_zeros=False: stored zeros are looked for on the device (run_hip(check_zeros=True)) instead of here.
@@ -508,6 +510,13 @@ def prepare(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_mat
     dev_norms = on_dev and bool(norms_on_device) and (l1 != 0 or l2 != 0)
     # (a 'sum' weight of matrix1 is its ROW sums in the reference's float32 reduceat order, s_plus_utils.pyx:128-158: that needs the
     # CSR of matrix1 on the host, which the CSC route never builds)
+    # binary=True (s_plus.pyx:214-217: data = ones after eliminate_zeros): when nothing on the host reads the values (device-built m2
+    # and norms, no depop weights) they go up as they are and the library writes the ones into its copies (SP_FLAG_BINARY) — no array
+    # of ones is built or uploaded, and the stored-zero check can stay on the device.  Otherwise the ones are made here, and then the
+    # zero check has to happen here too (the device would only see ones).
+    bin_dev = bool(binary) and bool(binary_on_device) and on_dev and not p3 and l3 == 0 and (dev_norms or (l1 == 0 and l2 == 0))
+    host_binary = bool(binary) and not bin_dev
+    check_zeros = bool(check_zeros) or host_binary
     w1_rowsum = l3 != 0 and isinstance(weight_depop_matrix1, str) and weight_depop_matrix1 == 'sum'
     csc = (on_dev and bool(csc_direct) and not arr_sel and not w1_rowsum and getattr(matrix1, "format", None) == "csc" and (dev_norms or (l1 == 0 and l2 == 0))
            and matrix1.nnz <= np.iinfo(np.int32).max
@@ -517,17 +526,17 @@ def prepare(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_mat
         n_rows_m1, n_rows_m2 = matrix1.shape
         n_output_cols = n_rows_m1
         m1_data, m1_indices, m1_indptr = _EMPTY_F32, _EMPTY_I32, _EMPTY_I32
-        m2_data = np.ones(matrix1.data.shape[0], dtype=np.float32) if binary else np.ascontiguousarray(matrix1.data, dtype=np.float32)
+        m2_data = np.ones(matrix1.data.shape[0], dtype=np.float32) if host_binary else np.ascontiguousarray(matrix1.data, dtype=np.float32)
         m2_indices = np.ascontiguousarray(matrix1.indices, dtype=np.int32)
         m2_indptr = np.ascontiguousarray(matrix1.indptr, dtype=np.int32)
     else:
-        m1, m1_data, m1_indices, m1_indptr = _csr_f32_i32(matrix1, binary, check_zeros)
+        m1, m1_data, m1_indices, m1_indptr = _csr_f32_i32(matrix1, host_binary, check_zeros)
         n_rows_m1, n_rows_m2 = m1.shape
         if on_dev:
             m2_data, m2_indices, m2_indptr = _EMPTY_F32, _EMPTY_I32, _EMPTY_I32
             n_output_cols = n_rows_m1
         else:
-            m2, m2_data, m2_indices, m2_indptr = _csr_f32_i32(matrix2, binary, check_zeros)
+            m2, m2_data, m2_indices, m2_indptr = _csr_f32_i32(matrix2, host_binary, check_zeros)
             n_output_cols = m2.shape[1]
 
     # all scalar parameters are C floats in the reference (s_plus.pyx:100-113)
@@ -541,7 +550,7 @@ def prepare(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_mat
         n_rows_m1=n_rows_m1, n_rows_m2=n_rows_m2, n_output_cols=n_output_cols, k=k,
         a1=a1, l1=l1, l2=l2, l3=l3, t1=t1, t2=t2,
         stabilized_shrink=stabilized_shrink, bayesian_shrink=bayesian_shrink, threshold=threshold,
-        m2_is_m1t=on_dev and not csc, m1_is_m2t=csc)
+        m2_is_m1t=on_dev and not csc, m1_is_m2t=csc, binary_on_device=bin_dev)
     if p3:
         call.p3_alpha = f32(p3_alpha)
 
@@ -641,7 +650,8 @@ def run_hip(call: KernelCall, device: Optional[int] = None, table_slots: int = 0
     a = _abi.SpKnnArgs()
     a.flags = ((0 if want_rows else _abi.SP_FLAG_NO_ROWS_OUT) | (_abi.SP_FLAG_TIME_KERNEL | _abi.SP_FLAG_PHASE_TIMERS if time_kernel else 0) | (_abi.SP_FLAG_STATIC_SCHED if static_sched else 0)
                | (_abi.SP_FLAG_NO_SPARSE_PATH if no_sparse_path else 0) | (_abi.SP_FLAG_NO_FOLD if no_fold else 0)
-               | (_abi.SP_FLAG_CHECK_ZEROS if check_zeros else 0) | (_abi.SP_FLAG_CSR_OUT if csr_out else 0))
+               | (_abi.SP_FLAG_CHECK_ZEROS if check_zeros else 0) | (_abi.SP_FLAG_CSR_OUT if csr_out else 0)
+               | (_abi.SP_FLAG_BINARY if call.binary_on_device else 0))
     if call.p3_alpha is not None:
         a.flags |= _abi.SP_FLAG_P3_PREP
         a.p3_alpha = call.p3_alpha
@@ -798,9 +808,9 @@ def _s_plus_impl(matrix1, matrix2, weight_depop_matrix1, weight_depop_matrix2, p
         res = multi_gpu.run_call(call, route[0], format_output, chunk_rows=route[1])
         _say(verbose, "Done")
         return res
-    # stored zeros: looked for on the device, where the data goes anyway (under `binary` the uploaded data are ones: host check)
-    device_zero_check = not binary
-    opts = dict(check_zeros=not device_zero_check, csc_direct=True)
+    # stored zeros: looked for on the device, where the data goes anyway (also under `binary` when the library writes the ones into
+    # its own copies, SP_FLAG_BINARY; where prepare has to build the ones itself it checks on the host whatever is asked here)
+    opts = dict(check_zeros=False, csc_direct=True, binary_on_device=True)
     while True:
         call = prepare(*args, m2_on_device=True, norms_on_device=True, keep_on_device=True, **opts, **p3kw)
         # CSR results are assembled on the device whatever the order of target_rows (SP_FLAG_CSR_OUT: the stable counting sort of

@@ -284,8 +284,8 @@ int validate(const sp_knn_args *a) {
         return fail(SP_EINVAL, "col_keep with an explicit m2 is a host-mode option (device-resident m2 is filtered by its owner)");
     if (a->col_keep && (a->flags & SP_FLAG_P3_PREP) && !m2t)
         return fail(SP_EINVAL, "col_keep with SP_FLAG_P3_PREP needs SP_FLAG_M2_IS_M1_T (the columns are dropped from the m2 built here, after its rows were normalised)");
-    if ((a->flags & (SP_FLAG_CSR_OUT | SP_FLAG_CHECK_ZEROS)) && a->on_device)
-        return fail(SP_EINVAL, "SP_FLAG_CSR_OUT / SP_FLAG_CHECK_ZEROS are host-mode flags (on_device = 0)");
+    if ((a->flags & (SP_FLAG_CSR_OUT | SP_FLAG_CHECK_ZEROS | SP_FLAG_BINARY)) && a->on_device)
+        return fail(SP_EINVAL, "SP_FLAG_CSR_OUT / SP_FLAG_CHECK_ZEROS / SP_FLAG_BINARY are host-mode flags (on_device = 0)");
     if ((a->flags & SP_FLAG_CSR_OUT) && a->n_targets > 0 && !a->csr_indptr) return fail(SP_EINVAL, "SP_FLAG_CSR_OUT needs csr_indptr");
     if ((m2t || m1t) && a->n_output_cols != a->n_rows_m1)
         return fail(SP_EINVAL, "SP_FLAG_M2_IS_M1_T / SP_FLAG_M1_IS_M2_T: n_output_cols (%d) must equal n_rows_m1 (%d)", a->n_output_cols, a->n_rows_m1);
@@ -1131,6 +1131,13 @@ int run_host(sp_knn_args *a) {
             if (zeros) return fail(SP_EZEROS, "%llu stored entries are zero: eliminate them first (s_plus.pyx:210-211)", zeros);
         }
         if (h[18]) return fail(SP_EUNSORTED, "SP_FLAG_M1_IS_M2_T: %d rows of m2 do not have ascending column ids", h[18]);
+    }
+
+    if (a->flags & SP_FLAG_BINARY) {
+        // binary=True: ones in the uploaded copies (the zero count above has seen the caller's values, s_plus.pyx:210-217)
+        if (!m1t && a->nnz_m1 > 0) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)d.m1_data, 0x3F800000, (size_t)a->nnz_m1, nullptr));
+        if (!m2t && a->nnz_m2 > 0) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)d.m2_data, 0x3F800000, (size_t)a->nnz_m2, nullptr));
+        d.flags &= ~SP_FLAG_BINARY;
     }
 
     if (a->col_keep && !m2t && a->nnz_m2 > 0) {

@@ -1258,3 +1258,37 @@ def test_wave_and_workgroup_sparse_kernels_share_a_call():
     assert ran, "the library did not pick the wave kernel for this mix"
     assert info["phase_cycles"][9] >= 0.95 * n_users            # rows finished by the two sparse-row kernels together
     _check(call, "mixed light / long rows")
+
+
+def test_binary_calls_write_their_ones_on_the_device():
+    """binary=True (s_plus.pyx:214-217: the data become ones AFTER eliminate_zeros).  The `matrix2=None` calls hand the caller's values to the
+    library, which counts the stored zeros in them and then writes the ones into its uploaded copies (SP_FLAG_BINARY) — against the oracle
+    kernel on host-made ones, CSR and CSC matrix1, with a stored zero (the call comes back with SP_EZEROS and is repeated after the host
+    removed it), and the caller's matrix untouched."""
+    m = _rand((3000, 700), 0.02, 41)
+    m.data *= 3.0                                          # values that are not ones: a missed memset would show
+    z = m.copy()
+    z.data[::97] = 0.0                                     # stored zeros: not part of the pattern under `binary`
+    for mat, what in ((m, "plain"), (z, "stored zeros"), (m.tocsc(), "csc")):
+        before = mat.data.copy()
+        clean = mat.tocsr().copy()                         # (a copy: eliminate_zeros works in place on whatever arrays it is given)
+        clean.eliminate_zeros()
+        for fn, kw, pkw in (("cosine", dict(), dict(l2=1.0)), ("jaccard", dict(), dict(l1=1.0, t1=1.0, t2=1.0)), ("dot_product", dict(), dict()),
+                            ("tversky", dict(alpha=0.3, beta=0.6), dict(l1=1.0, t1=0.3, t2=0.6))):
+            call = _host.prepare(mat, k=15, binary=True, m2_on_device=True, norms_on_device=True, binary_on_device=True, check_zeros=False, csc_direct=True, **pkw)
+            assert call.binary_on_device
+            res = getattr(sim, fn)(mat, k=15, binary=True, verbose=False, format_output="csr", **kw)
+            ones = sp.csr_array((np.ones_like(clean.data), clean.indices, clean.indptr), shape=clean.shape)
+            want = so.canonical(*so.run_kernel(_host.prepare(ones, k=15, **pkw), "port"), np.arange(mat.shape[0], dtype=np.int32), 15)
+            want = [(c[v != 0], v[v != 0]) for c, v in want]
+            got = []
+            for t in range(mat.shape[0]):
+                c, v = res.indices[res.indptr[t]:res.indptr[t + 1]], res.data[res.indptr[t]:res.indptr[t + 1]]
+                o = np.argsort(c)
+                got.append((c[o].astype(np.int32), v[o].astype(np.float32)))
+            so.compare_topk(got, want, 15, rtol=RTOL, atol=1e-9, what=f"binary {fn} ({what})")
+        np.testing.assert_array_equal(mat.data, before)
+    # the flag belongs to host mode: a device-resident problem fills its own buffers
+    from similaripy_amd.device import DeviceProblem
+    with pytest.raises(ValueError, match="binary_on_device"):
+        DeviceProblem(_host.prepare(m, k=5, l2=1.0, binary=True, m2_on_device=True, norms_on_device=True, binary_on_device=True))

@@ -304,3 +304,20 @@ def test_csr_assembly_with_64_bit_indices():
     assert csr.indices.dtype == np.int64 and csr.indptr.dtype == np.int64 and csr.shape == (3, n_cols)
     assert csr.nnz == 3 and csr.indptr.tolist() == [0, 2, 2, 3]
     assert sorted(zip(csr.indices[:2].tolist(), csr.data[:2].tolist())) == [(1, 2.0), (5, 1.0)] and csr.indices[2] == 7
+
+
+def test_binary_values_stay_the_callers_when_the_device_writes_the_ones():
+    """prepare(binary=True, binary_on_device=True): nothing on the host reads the values of a `matrix2=None` call with device-built norms, so
+    they reach the boundary as they are (SP_FLAG_BINARY: ones written into the uploaded copies, s_plus.pyx:214-217); with depop weights, an
+    explicit matrix2 or host-built norms the ones are made here — and then the stored zeros are removed here as well."""
+    m = sp.random_array((300, 150), density=0.05, format="csr", dtype=np.float32, random_state=np.random.default_rng(1))
+    c = _host.prepare(m, k=5, l2=1, binary=True, m2_on_device=True, norms_on_device=True, binary_on_device=True, check_zeros=False)
+    assert c.binary_on_device and np.shares_memory(c.m1_data, m.data)
+    c = _host.prepare(m, k=5, l2=1, l3=1, binary=True, m2_on_device=True, norms_on_device=True, binary_on_device=True, check_zeros=False)
+    assert not c.binary_on_device and (c.m1_data == 1).all()
+    c = _host.prepare(m, k=5, l2=1, binary=True)
+    assert not c.binary_on_device and (c.m1_data == 1).all() and (c.m2_data == 1).all()
+    z = m.copy()
+    z.data[3] = 0
+    c = _host.prepare(z, z.T.tocsr(), k=5, l2=1, binary=True, binary_on_device=True, check_zeros=False)
+    assert not c.binary_on_device and c.m1_data.shape[0] == z.nnz - 1 and z.data[3] == 0
