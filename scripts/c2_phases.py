@@ -1,6 +1,6 @@
 """C2-shaped problem (1M x 100k, 64 per row, cosine k=100; `c3` = the s_plus hybrid of configs[2]) over the first N target rows,
 kernel-scope: how long the row kernels took, where the cycles of a row went (in-kernel phase timers), parity on a sample.
-`python scripts/c2_phases.py N [c3] [static] [dbg=BITS]`"""
+`python scripts/c2_phases.py N [c3|jaccard] [binary] [static] [dbg=BITS]`"""
 import sys, json, copy
 import numpy as np
 sys.path.insert(0, '.')
@@ -12,7 +12,9 @@ from oracle import splus_oracle as so
 
 n_t = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 tun = dict(dbg=next((int(a[4:]) for a in sys.argv if a.startswith("dbg=")), 0))
-kw = dict(l1=0.5, l2=0.5, stabilized_shrink=10.0) if "c3" in sys.argv else dict(l2=1, c1=0.5, c2=0.5)
+kw = dict(l1=0.5, l2=0.5, stabilized_shrink=10.0) if "c3" in sys.argv else dict(l1=1, t1=1, t2=1) if "jaccard" in sys.argv else dict(l2=1, c1=0.5, c2=0.5)
+if "binary" in sys.argv:      # (fixed-degree rows of ones: every row has the same norm, nearly every candidate of a row ties)
+    kw["binary"] = True
 static = "static" in sys.argv
 m = fixed_degree_csr(1_000_000, 100_000, 64, 12345)
 k = 100
