@@ -46,7 +46,7 @@ extern "C" {
 #define SP_ENOMEM       -4
 #define SP_EWORKSPACE   -5   /* caller workspace too small */
 #define SP_EZEROS       -6   /* SP_FLAG_CHECK_ZEROS: the matrices hold explicit zeros (see explicit_zeros); nothing was computed */
-#define SP_EUNSORTED    -7   /* SP_FLAG_M1_IS_M2_T (host mode): a row of m2 does not have ascending column ids; nothing was computed */
+#define SP_EUNSORTED    -7   /* SP_FLAG_M1_IS_M2_T / SP_FLAG_CHECK_SORTED (host mode): a row of m2 does not have ascending column ids; nothing was computed */
 
 /* flags */
 #define SP_FLAG_TIME_KERNEL   1u  /* bracket device work with hipEvents on `stream`, sync, fill kernel_ms */
@@ -83,7 +83,10 @@ extern "C" {
 #define SP_FLAG_NORMS_ON_DEVICE 8192u /* with SP_FLAG_M2_IS_M1_T or SP_FLAG_M1_IS_M2_T: the Xtversky / Ytversky (l1 != 0) and Xcosine /
                                      Ycosine (l2 != 0) pointers are ignored; the vectors are built on the device from the rows of m1
                                      (_build_squared_norms s_plus_utils.pyx:169-201 as sp_csr_row_sqsums_f32 does, sp_prep.h;
-                                     _build_cosine_normalization :204-228 with norm_c1 / norm_c2 / norm_add) */
+                                     _build_cosine_normalization :204-228 with norm_c1 / norm_c2 / norm_add).
+                                     Host mode also with an explicit m2: the row sums of m1^2 and the column sums of m2^2 are formed
+                                     from the uploaded copies (sp_csr_row_sqsums_f32 / sp_csr_col_sums_f32 on device pointers) — the
+                                     host layer uploaded m2 a second time for them */
 
 /* ABI 5 */
 #define SP_FLAG_REUSE_M2_PREP 16384u /* device mode with a caller workspace: the workspace still holds the per-call passes over m2 / Y* of an
@@ -98,6 +101,9 @@ extern "C" {
                                      m1 (and of an explicit m2) are replaced by 1.0 in the uploaded copies, after the SP_FLAG_CHECK_ZEROS count
                                      has seen the caller's values.  The caller's arrays are not modified (and no array of ones is built or
                                      uploaded: 256 MB at 64 M entries).  Device-mode callers own their buffers and fill them themselves. */
+#define SP_FLAG_CHECK_SORTED 65536u /* host mode, explicit m2: the rows of the uploaded m2 are checked for ascending column ids on the device (the
+                                     requirement above); a descent anywhere: SP_EUNSORTED, nothing computed — the caller sorts and calls again
+                                     (what the host layer did with a pass over m2's indices before every call) */
 
 typedef struct sp_knn_args {
     uint32_t struct_size;      /* = sizeof(sp_knn_args); checked */

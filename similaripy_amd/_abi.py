@@ -30,6 +30,7 @@ SP_FLAG_M1_IS_M2_T = 4096
 SP_FLAG_NORMS_ON_DEVICE = 8192
 SP_FLAG_REUSE_M2_PREP = 16384
 SP_FLAG_BINARY = 32768
+SP_FLAG_CHECK_SORTED = 65536
 SP_EZEROS = -6
 SP_EUNSORTED = -7
 SP_NORM_L1, SP_NORM_L2, SP_NORM_MAX, SP_NORM_TFIDF, SP_NORM_BM25PLUS = range(5)

@@ -82,6 +82,7 @@ class KernelCall:
     depop_rowsum_p2: Optional[float] = None  # SP_FLAG_DEPOP_ROWSUM: Ydepop = (row sums of the raw m1)^p2, built on the device
     m1_is_m2t: bool = False    # m1 = m2^T is built on the device (SP_FLAG_M1_IS_M2_T, matrix1 came as CSC): the m1_* arrays are empty
     norms_on_device: Optional[tuple] = None  # SP_FLAG_NORMS_ON_DEVICE: (c1, c2, additive_shrink); X/Y tversky / cosine vectors are empty
+    check_m2_sorted: bool = False            # SP_FLAG_CHECK_SORTED: nobody has looked at the order inside the rows of the explicit m2 yet
     binary_on_device: bool = False           # SP_FLAG_BINARY: the value arrays are the caller's; the library writes ones into its uploaded copies
     col_keep: Optional[np.ndarray] = None    # with m2_is_m1t: uint8 [n_rows_m1], 0 = the output column is dropped while m2 is built (ARRAY selectors)
 
@@ -268,6 +269,8 @@ def build_depop_normalization(m1, m2, n_rows_m1, n_cols_m2, weight_spec1, weight
             if which == 2 and m2_is_m1t:
                 d, _, ptr, _ = m1
                 row_of = np.repeat(np.arange(n_rows_m1, dtype=np.int32), np.diff(ptr))
+                if sums_on_device:      # (np.bincount's float64 pass over 64 M weights took 230 ms of such a call at the C2 size)
+                    return power(col_sums_hip(d, row_of, n_rows_m1, square=False), p)
                 return power(np.bincount(row_of, weights=d, minlength=n_rows_m1).astype(np.float32, copy=False), p)
             d, i, ptr, nc = m1 if which == 1 else m2
             if which == 2 and sums_on_device:      # column sums of m2: the device's np.bincount (sp_csr_col_sums_f32)
@@ -460,7 +463,7 @@ def prepare(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_mat
             binary=False, target_rows=None, filter_cols=None, target_cols=None,
             verbose=False, format_output='csr', m2_on_device=False, check_zeros=True,
             p3_alpha=None, p3_depop_beta=None, norms_on_device=False, csc_direct=False, keep_on_device=False,
-            binary_on_device=False) -> KernelCall:
+            binary_on_device=False, m2_sorted_on_device=False) -> KernelCall:
     """Everything s_plus.pyx does before the `with nogil:` block (:168-353).
 
     check_zeros=False: stored zeros are looked for on the device (run_hip(check_zeros=True)) instead of here.
@@ -507,14 +510,16 @@ def prepare(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_mat
     on_dev = bool(m2_on_device) and m2_from_m1 and (l3 == 0 or not p3 or p3_depop_beta is not None)
     if p3 and not on_dev:
         raise ValueError("p3_alpha needs the device-side transpose (matrix2=None)")
-    dev_norms = on_dev and bool(norms_on_device) and (l1 != 0 or l2 != 0)
+    # (norms_on_device with an explicit matrix2: host mode builds both vectors from its uploaded copies, SP_FLAG_NORMS_ON_DEVICE)
+    m2_explicit_dev = bool(m2_on_device) and not m2_from_m1
+    dev_norms = (on_dev or m2_explicit_dev) and bool(norms_on_device) and (l1 != 0 or l2 != 0)
     # (a 'sum' weight of matrix1 is its ROW sums in the reference's float32 reduceat order, s_plus_utils.pyx:128-158: that needs the
     # CSR of matrix1 on the host, which the CSC route never builds)
     # binary=True (s_plus.pyx:214-217: data = ones after eliminate_zeros): when nothing on the host reads the values (device-built m2
     # and norms, no depop weights) they go up as they are and the library writes the ones into its copies (SP_FLAG_BINARY) — no array
     # of ones is built or uploaded, and the stored-zero check can stay on the device.  Otherwise the ones are made here, and then the
     # zero check has to happen here too (the device would only see ones).
-    bin_dev = bool(binary) and bool(binary_on_device) and on_dev and not p3 and l3 == 0 and (dev_norms or (l1 == 0 and l2 == 0))
+    bin_dev = bool(binary) and bool(binary_on_device) and (on_dev or m2_explicit_dev) and not p3 and l3 == 0 and (dev_norms or (l1 == 0 and l2 == 0))
     host_binary = bool(binary) and not bin_dev
     check_zeros = bool(check_zeros) or host_binary
     w1_rowsum = l3 != 0 and isinstance(weight_depop_matrix1, str) and weight_depop_matrix1 == 'sum'
@@ -596,7 +601,9 @@ def prepare(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_mat
     # The kernel windows the columns when they exceed its LDS tile and then needs ascending column
     # ids inside each m2 row — what the reference's blocked path gets from sort_indices()
     # (s_plus_utils.pyx:562).  Transposes and scipy-built CSR already are.
-    if not _rows_sorted(call.m2_indices, call.m2_indptr):
+    # (m2_sorted_on_device: the library looks, where m2 goes anyway — SP_FLAG_CHECK_SORTED, UnsortedRowsError — instead of a pass here)
+    call.check_m2_sorted = bool(m2_sorted_on_device)
+    if not m2_sorted_on_device and not _rows_sorted(call.m2_indices, call.m2_indptr):
         tmp = sp.csr_array((call.m2_data.copy(), call.m2_indices.copy(), call.m2_indptr.copy()),
                            shape=(n_rows_m2, n_output_cols))
         tmp.sort_indices()
@@ -651,7 +658,7 @@ def run_hip(call: KernelCall, device: Optional[int] = None, table_slots: int = 0
     a.flags = ((0 if want_rows else _abi.SP_FLAG_NO_ROWS_OUT) | (_abi.SP_FLAG_TIME_KERNEL | _abi.SP_FLAG_PHASE_TIMERS if time_kernel else 0) | (_abi.SP_FLAG_STATIC_SCHED if static_sched else 0)
                | (_abi.SP_FLAG_NO_SPARSE_PATH if no_sparse_path else 0) | (_abi.SP_FLAG_NO_FOLD if no_fold else 0)
                | (_abi.SP_FLAG_CHECK_ZEROS if check_zeros else 0) | (_abi.SP_FLAG_CSR_OUT if csr_out else 0)
-               | (_abi.SP_FLAG_BINARY if call.binary_on_device else 0))
+               | (_abi.SP_FLAG_BINARY if call.binary_on_device else 0) | (_abi.SP_FLAG_CHECK_SORTED if call.check_m2_sorted else 0))
     if call.p3_alpha is not None:
         a.flags |= _abi.SP_FLAG_P3_PREP
         a.p3_alpha = call.p3_alpha
@@ -810,7 +817,7 @@ def _s_plus_impl(matrix1, matrix2, weight_depop_matrix1, weight_depop_matrix2, p
         return res
     # stored zeros: looked for on the device, where the data goes anyway (also under `binary` when the library writes the ones into
     # its own copies, SP_FLAG_BINARY; where prepare has to build the ones itself it checks on the host whatever is asked here)
-    opts = dict(check_zeros=False, csc_direct=True, binary_on_device=True)
+    opts = dict(check_zeros=False, csc_direct=True, binary_on_device=True, m2_sorted_on_device=True)
     while True:
         call = prepare(*args, m2_on_device=True, norms_on_device=True, keep_on_device=True, **opts, **p3kw)
         # CSR results are assembled on the device whatever the order of target_rows (SP_FLAG_CSR_OUT: the stable counting sort of
@@ -833,9 +840,12 @@ def _s_plus_impl(matrix1, matrix2, weight_depop_matrix1, weight_depop_matrix2, p
                 raise
             opts["check_zeros"] = True          # eliminate_zeros on the host (s_plus.pyx:210-211), then again
         except _abi.UnsortedRowsError:
-            if not opts["csc_direct"]:
+            if call.m1_is_m2t and opts["csc_direct"]:
+                opts["csc_direct"] = False          # matrix1.tocsr() on the host (s_plus.pyx:205-206), then again
+            elif call.check_m2_sorted and opts["m2_sorted_on_device"]:
+                opts["m2_sorted_on_device"] = False  # sort_indices() on a copy of matrix2 here (s_plus_utils.pyx:562), then again
+            else:
                 raise
-            opts["csc_direct"] = False          # matrix1.tocsr() on the host (s_plus.pyx:205-206), then again
     _say(verbose, f"Building {format_output} matrix")
     if csr_out:
         indptr, indices, data = out

@@ -276,16 +276,18 @@ int validate(const sp_knn_args *a) {
     const bool m1t = (a->flags & SP_FLAG_M1_IS_M2_T) != 0;     // m1 = m2^T, built on the device: the m1_* pointers and nnz_m1 are ignored
     const bool dev_norms = (a->flags & SP_FLAG_NORMS_ON_DEVICE) != 0;
     if (m2t && m1t) return fail(SP_EINVAL, "SP_FLAG_M2_IS_M1_T and SP_FLAG_M1_IS_M2_T exclude each other");
-    if ((a->flags & (SP_FLAG_P3_PREP | SP_FLAG_DEPOP_ROWSUM | SP_FLAG_NORMS_ON_DEVICE)) && !m2t && !m1t)
-        return fail(SP_EINVAL, "SP_FLAG_P3_PREP / SP_FLAG_DEPOP_ROWSUM / SP_FLAG_NORMS_ON_DEVICE need SP_FLAG_M2_IS_M1_T or SP_FLAG_M1_IS_M2_T");
+    if ((a->flags & (SP_FLAG_P3_PREP | SP_FLAG_DEPOP_ROWSUM)) && !m2t && !m1t)
+        return fail(SP_EINVAL, "SP_FLAG_P3_PREP / SP_FLAG_DEPOP_ROWSUM need SP_FLAG_M2_IS_M1_T or SP_FLAG_M1_IS_M2_T");
+    if ((a->flags & SP_FLAG_NORMS_ON_DEVICE) && !m2t && !m1t && a->on_device)
+        return fail(SP_EINVAL, "SP_FLAG_NORMS_ON_DEVICE with an explicit m2 is a host-mode option (device mode: SP_FLAG_M2_IS_M1_T or SP_FLAG_M1_IS_M2_T)");
     if ((a->flags & SP_FLAG_DEPOP_ROWSUM) && !(a->flags & SP_FLAG_P3_PREP))
         return fail(SP_EINVAL, "SP_FLAG_DEPOP_ROWSUM needs SP_FLAG_P3_PREP");
     if (a->col_keep && !m2t && (a->on_device || m1t))
         return fail(SP_EINVAL, "col_keep with an explicit m2 is a host-mode option (device-resident m2 is filtered by its owner)");
     if (a->col_keep && (a->flags & SP_FLAG_P3_PREP) && !m2t)
         return fail(SP_EINVAL, "col_keep with SP_FLAG_P3_PREP needs SP_FLAG_M2_IS_M1_T (the columns are dropped from the m2 built here, after its rows were normalised)");
-    if ((a->flags & (SP_FLAG_CSR_OUT | SP_FLAG_CHECK_ZEROS | SP_FLAG_BINARY)) && a->on_device)
-        return fail(SP_EINVAL, "SP_FLAG_CSR_OUT / SP_FLAG_CHECK_ZEROS / SP_FLAG_BINARY are host-mode flags (on_device = 0)");
+    if ((a->flags & (SP_FLAG_CSR_OUT | SP_FLAG_CHECK_ZEROS | SP_FLAG_BINARY | SP_FLAG_CHECK_SORTED)) && a->on_device)
+        return fail(SP_EINVAL, "SP_FLAG_CSR_OUT / SP_FLAG_CHECK_ZEROS / SP_FLAG_BINARY / SP_FLAG_CHECK_SORTED are host-mode flags (on_device = 0)");
     if ((a->flags & SP_FLAG_CSR_OUT) && a->n_targets > 0 && !a->csr_indptr) return fail(SP_EINVAL, "SP_FLAG_CSR_OUT needs csr_indptr");
     if ((m2t || m1t) && a->n_output_cols != a->n_rows_m1)
         return fail(SP_EINVAL, "SP_FLAG_M2_IS_M1_T / SP_FLAG_M1_IS_M2_T: n_output_cols (%d) must equal n_rows_m1 (%d)", a->n_output_cols, a->n_rows_m1);
@@ -1118,7 +1120,7 @@ int run_host(sp_knn_args *a) {
             if (e[0] & 4) return fail(SP_EINVAL, "%s: indptr[%d] differs from nnz = %lld", mats[i].what, mats[i].n_rows, (long long)mats[i].nnz);
             if (e[2] < 0 || e[3] >= mats[i].n_cols) return fail(SP_EINVAL, "%s: column index out of range [0,%d) (min %d, max %d)", mats[i].what, mats[i].n_cols, e[2], e[3]);
         }
-        if (m1t && a->nnz_m2 > 1) {
+        if ((m1t || (!m2t && (a->flags & SP_FLAG_CHECK_SORTED))) && a->nnz_m2 > 1) {
             // (only now: this kernel walks the rows of m2, whose row pointers have just been validated)
             hipLaunchKernelGGL(sp_rows_sorted_kernel, dim3(std::max(1, std::min(256 * 16, (a->n_rows_m2 + 3) / 4))), dim3(256), 0, nullptr, a->n_rows_m2, d.m2_indptr, d.m2_indices, (unsigned int *)(st + 18));
             HIP_TRY(hipGetLastError());
@@ -1130,7 +1132,7 @@ int run_host(sp_knn_args *a) {
             a->explicit_zeros = (int64_t)zeros;
             if (zeros) return fail(SP_EZEROS, "%llu stored entries are zero: eliminate them first (s_plus.pyx:210-211)", zeros);
         }
-        if (h[18]) return fail(SP_EUNSORTED, "SP_FLAG_M1_IS_M2_T: %d rows of m2 do not have ascending column ids", h[18]);
+        if (h[18]) return fail(SP_EUNSORTED, "%s: %d rows of m2 do not have ascending column ids", m1t ? "SP_FLAG_M1_IS_M2_T" : "SP_FLAG_CHECK_SORTED", h[18]);
     }
 
     if (a->flags & SP_FLAG_BINARY) {
@@ -1138,6 +1140,42 @@ int run_host(sp_knn_args *a) {
         if (!m1t && a->nnz_m1 > 0) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)d.m1_data, 0x3F800000, (size_t)a->nnz_m1, nullptr));
         if (!m2t && a->nnz_m2 > 0) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)d.m2_data, 0x3F800000, (size_t)a->nnz_m2, nullptr));
         d.flags &= ~SP_FLAG_BINARY;
+    }
+
+    d.flags &= ~SP_FLAG_CHECK_SORTED;
+    if ((a->flags & SP_FLAG_NORMS_ON_DEVICE) && !m2t && !m1t) {
+        // explicit m2: _build_squared_norms (s_plus_utils.pyx:169-201) = row sums of m1^2 (np.add.reduceat's order) and column sums of m2^2
+        // (np.bincount's float64 accumulator), then _build_cosine_normalization (:204-228) — from the copies that are here already
+        if (a->l1 != 0.f || a->l2 != 0.f) {
+            float *sq1 = nullptr, *sq2 = nullptr;
+            TRY(pool.alloc((size_t)a->n_rows_m1, &sq1));
+            TRY(pool.alloc((size_t)a->n_output_cols, &sq2));
+            if (a->n_rows_m1 > 0) {
+                sp_csr_sqsums_args q;
+                memset(&q, 0, sizeof(q));
+                q.struct_size = sizeof(q); q.on_device = 1; q.device = a->device;
+                q.n_rows = a->n_rows_m1; q.nnz = a->nnz_m1; q.data = d.m1_data; q.indptr = d.m1_indptr; q.out_rows = sq1;
+                TRY(sp_csr_row_sqsums_f32(&q));
+            }
+            if (a->n_output_cols > 0) {
+                sp_csr_colsums_args q;
+                memset(&q, 0, sizeof(q));
+                q.struct_size = sizeof(q); q.on_device = 1; q.device = a->device;
+                q.n_cols = a->n_output_cols; q.square = 1; q.nnz = a->nnz_m2; q.data = d.m2_data; q.indices = d.m2_indices; q.out = sq2;
+                TRY(sp_csr_col_sums_f32(&q));
+            }
+            if (a->l1 != 0.f) { d.Xtversky = sq1; d.Ytversky = sq2; }
+            if (a->l2 != 0.f) {
+                float *xc = nullptr, *yc = nullptr;
+                TRY(pool.alloc((size_t)a->n_rows_m1, &xc));
+                TRY(pool.alloc((size_t)a->n_output_cols, &yc));
+                if (a->n_rows_m1 > 0) hipLaunchKernelGGL(sp_add_pow_f32_kernel, dim3((a->n_rows_m1 + 255) / 256), dim3(256), 0, nullptr, a->n_rows_m1, (const float *)sq1, xc, a->norm_add, (double)a->norm_c1);
+                if (a->n_output_cols > 0) hipLaunchKernelGGL(sp_add_pow_f32_kernel, dim3((a->n_output_cols + 255) / 256), dim3(256), 0, nullptr, a->n_output_cols, (const float *)sq2, yc, a->norm_add, (double)a->norm_c2);
+                HIP_TRY(hipGetLastError());
+                d.Xcosine = xc; d.Ycosine = yc;
+            }
+        }
+        d.flags &= ~SP_FLAG_NORMS_ON_DEVICE;
     }
 
     if (a->col_keep && !m2t && a->nnz_m2 > 0) {

@@ -38,7 +38,8 @@ class DeviceProblem:
         # _host.run_hip — dropping those options silently would compute something else
         pending = [n for n, v in (("p3_alpha", call.p3_alpha), ("depop_rowsum_p2", call.depop_rowsum_p2),
                                   ("m1_is_m2t", call.m1_is_m2t or None), ("norms_on_device", call.norms_on_device),
-                                  ("binary_on_device", call.binary_on_device or None)) if v is not None]
+                                  ("binary_on_device", call.binary_on_device or None),
+                                  ("check_m2_sorted", call.check_m2_sorted or None)) if v is not None]
         if call.col_keep is not None and not call.m2_is_m1t:
             pending.append("col_keep on an explicit matrix2")
         if pending:

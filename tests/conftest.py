@@ -94,6 +94,7 @@ def oracle_backend(monkeypatch):
         import dataclasses
         import scipy.sparse as sp
         from oracle import norm_oracle
+        explicit_m2 = not call.m1_is_m2t and not call.m2_is_m1t
         if call.m1_is_m2t:
             # SP_FLAG_M1_IS_M2_T: matrix1 came as CSC; the reference converts it with scipy (s_plus.pyx:205-206)
             if call.m2_indices.shape[0] > 1 and not _host._rows_sorted(call.m2_indices, call.m2_indptr):
@@ -101,10 +102,25 @@ def oracle_backend(monkeypatch):
             m1 = sp.csr_array((call.m2_data, call.m2_indices, call.m2_indptr), shape=(call.n_rows_m2, call.n_rows_m1)).T.tocsr()
             call = dataclasses.replace(call, m1_data=np.ascontiguousarray(m1.data, dtype=np.float32), m1_indices=np.ascontiguousarray(m1.indices, dtype=np.int32),
                                        m1_indptr=np.ascontiguousarray(m1.indptr, dtype=np.int32), m1_is_m2t=False, m2_is_m1t=call.p3_alpha is not None)
+        # (the order of run_host: zero count on the caller's values, order inside the rows of an explicit m2, ones, norms)
+        if kw.get("check_zeros") and (np.count_nonzero(call.m1_data) != call.m1_data.shape[0] or np.count_nonzero(call.m2_data) != call.m2_data.shape[0]):
+            raise _abi.ExplicitZerosError("stored zeros")            # what SP_FLAG_CHECK_ZEROS reports
+        if call.check_m2_sorted:
+            # SP_FLAG_CHECK_SORTED: a descent inside a row of the explicit m2 goes back to the caller
+            if call.m2_indices.shape[0] > 1 and not _host._rows_sorted(call.m2_indices, call.m2_indptr):
+                raise _abi.UnsortedRowsError("unsorted rows")
+            call = dataclasses.replace(call, check_m2_sorted=False)
+        if call.binary_on_device:
+            # SP_FLAG_BINARY: ones in the library's copies (s_plus.pyx:214-217)
+            call = dataclasses.replace(call, m1_data=np.ones_like(call.m1_data), m2_data=np.ones_like(call.m2_data), binary_on_device=False)
         if call.norms_on_device is not None:
-            # SP_FLAG_NORMS_ON_DEVICE: s_plus_utils.pyx:169-228 from the rows of m1
+            # SP_FLAG_NORMS_ON_DEVICE: s_plus_utils.pyx:169-228 from the rows of m1 (explicit m2: rows of m1, columns of m2)
             c1, c2, add = call.norms_on_device
-            sq1, sq2 = _host.build_squared_norms_m1t(call.m1_data, call.m1_indptr)
+            if explicit_m2:
+                sq1, sq2 = _host.build_squared_norms(call.m1_data, call.m1_indices, call.m1_indptr, call.n_rows_m2,
+                                                     call.m2_data, call.m2_indices, call.m2_indptr, call.n_output_cols)
+            else:
+                sq1, sq2 = _host.build_squared_norms_m1t(call.m1_data, call.m1_indptr)
             rep = {}
             if call.l1 != 0:
                 rep.update(Xtversky=sq1, Ytversky=sq2)
@@ -112,8 +128,6 @@ def oracle_backend(monkeypatch):
                 xc, yc = _host.build_cosine_normalization(sq1, sq2, c1, c2, add)
                 rep.update(Xcosine=xc, Ycosine=yc)
             call = dataclasses.replace(call, norms_on_device=None, **rep)
-        if kw.get("check_zeros") and (np.count_nonzero(call.m1_data) != call.m1_data.shape[0] or np.count_nonzero(call.m2_data) != call.m2_data.shape[0]):
-            raise _abi.ExplicitZerosError("stored zeros")            # what SP_FLAG_CHECK_ZEROS reports
         if call.p3_alpha is not None:
             # SP_FLAG_P3_PREP / SP_FLAG_DEPOP_ROWSUM, as the reference does it on the host (similarity.py:410-415, 477-483)
             m1 = sp.csr_array((call.m1_data, call.m1_indices, call.m1_indptr), shape=(call.n_rows_m1, call.n_rows_m2))

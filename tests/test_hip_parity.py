@@ -1292,3 +1292,68 @@ def test_binary_calls_write_their_ones_on_the_device():
     from similaripy_amd.device import DeviceProblem
     with pytest.raises(ValueError, match="binary_on_device"):
         DeviceProblem(_host.prepare(m, k=5, l2=1.0, binary=True, m2_on_device=True, norms_on_device=True, binary_on_device=True))
+
+
+def _public_vs_oracle(res, call, k, what, rtol=RTOL):
+    want = so.canonical(*so.run_kernel(call, "port"), call.targets, k)
+    want = [(c[v != 0], v[v != 0]) for c, v in want]
+    got = []
+    for t in call.targets:
+        c, v = res.indices[res.indptr[t]:res.indptr[t + 1]], res.data[res.indptr[t]:res.indptr[t + 1]]
+        o = np.argsort(c)
+        got.append((c[o].astype(np.int32), v[o].astype(np.float32)))
+    so.compare_topk(got, want, k, rtol=rtol, atol=1e-9, what=what)
+
+
+def test_explicit_matrix2_stages_on_the_device():
+    """Public calls with an explicit matrix2: the norm vectors (s_plus_utils.pyx:169-228: row sums of m1^2, column sums of m2^2), the ones
+    of binary=True and the look at the order inside m2's rows now happen in the library, on its uploaded copies (SP_FLAG_NORMS_ON_DEVICE /
+    SP_FLAG_BINARY / SP_FLAG_CHECK_SORTED in host mode) — against the oracle kernel fed by the host statement of the same stages."""
+    m1 = _rand((2500, 800), 0.02, 51)
+    m2 = _rand((800, 1900), 0.015, 52)
+    m1.data *= 2.5
+    k = 12
+    cases = [("cosine", dict(), dict(l2=1.0)), ("cosine", dict(shrink=3.0), dict(l2=1.0, stabilized_shrink=3.0)),
+             ("jaccard", dict(), dict(l1=1.0)), ("tversky", dict(alpha=0.3, beta=0.6), dict(l1=1.0, t1=0.3, t2=0.6)),
+             ("asymmetric_cosine", dict(alpha=0.3), dict(l2=1.0, c1=0.3, c2=0.7)), ("dot_product", dict(), dict()),
+             ("s_plus", dict(l1=0.4, l2=0.6, c1=0.4, c2=0.6, shrink=1.0), dict(l1=0.4, l2=0.6, c1=0.4, c2=0.6, stabilized_shrink=1.0))]
+    for fn, kw, pkw in cases:
+        for binary in (False, True):
+            call = _host.prepare(m1, m2, k=k, binary=binary, m2_on_device=True, norms_on_device=True, binary_on_device=True, m2_sorted_on_device=True, check_zeros=False, **pkw)
+            assert call.check_m2_sorted and call.binary_on_device == binary and (call.norms_on_device is not None) == bool(pkw.get("l1") or pkw.get("l2"))
+            res = getattr(sim, fn)(m1, m2, k=k, binary=binary, verbose=False, format_output="csr", **kw)
+            _public_vs_oracle(res, _host.prepare(m1, m2, k=k, binary=binary, **pkw), k, f"explicit m2 {fn} binary={binary}")
+    # rows of m2 in descending order: the library reports it (SP_EUNSORTED), the host layer sorts a copy and calls again — the caller's
+    # matrix stays as it was
+    rev = m2.copy()
+    for r in range(rev.shape[0]):
+        b, e = rev.indptr[r], rev.indptr[r + 1]
+        rev.indices[b:e] = rev.indices[b:e][::-1].copy()
+        rev.data[b:e] = rev.data[b:e][::-1].copy()
+    rev.has_sorted_indices = False
+    before = rev.indices.copy()
+    with pytest.raises(_abi.UnsortedRowsError):
+        _host.run_hip(_host.prepare(m1, rev, k=k, l2=1.0, m2_on_device=True, norms_on_device=True, m2_sorted_on_device=True))
+    a = sim.cosine(m1, rev, k=k, verbose=False, format_output="csr")
+    b = sim.cosine(m1, m2, k=k, verbose=False, format_output="csr")
+    np.testing.assert_array_equal(rev.indices, before)
+    assert a.nnz == b.nnz
+    _assert_same_topk(a, b, k, rtol=RTOL)
+    # stored zeros in either matrix: counted on the device in the caller's values (SP_EZEROS), removed on the host, called again
+    z1, z2 = m1.copy(), m2.copy()
+    z1.data[::53] = 0.0
+    z2.data[::41] = 0.0
+    for binary in (False, True):
+        res = sim.cosine(z1, z2, k=k, binary=binary, verbose=False, format_output="csr")
+        _public_vs_oracle(res, _host.prepare(z1, z2, k=k, l2=1.0, binary=binary), k, f"explicit m2 with stored zeros binary={binary}")
+
+
+def test_sum_weights_of_the_transposed_call_from_the_device():
+    """s_plus(m, l3 != 0, pop1='sum', pop2='sum'): the column sums of m2 = m1^T are the row sums of m1 in np.bincount's float64 arithmetic
+    (s_plus_utils.pyx:160-164) — taken on the device (sp_csr_col_sums_f32 over the row id of every entry) instead of a 230 ms NumPy pass
+    at the C2 size.  Against the host statement (explicit transpose, np.bincount)."""
+    m = _rand((4000, 900), 0.02, 61)
+    kw = dict(l1=0.3, l2=0.7, l3=0.5, pop1="sum", pop2="sum", beta1=0.6, beta2=0.4, k=10)
+    res = sim.s_plus(m, verbose=False, format_output="csr", **kw)
+    ref = _host.prepare(m, m.T.tocsr(), k=10, l1=0.3, l2=0.7, l3=0.5, weight_depop_matrix1="sum", weight_depop_matrix2="sum", p1=0.6, p2=0.4)
+    _public_vs_oracle(res, ref, 10, "s_plus with 'sum' weights")

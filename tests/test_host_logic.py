@@ -215,7 +215,7 @@ def test_csc_matrix1_takes_the_direct_route(fn, kw, oracle_backend):
     np.testing.assert_allclose(getattr(sim, fn)(perm, k=6, verbose=False, format_output="csr", **kw).toarray(), b.toarray(), rtol=1e-6, atol=0)
 
 
-def test_array_selectors_and_depop_weights_keep_the_device_transpose(golden):
+def test_array_selectors_and_depop_weights_keep_the_device_transpose(golden, monkeypatch):
     """ARRAY filter_cols / target_cols (compute_target_columns + _filter_matrix_columns, s_plus_utils.pyx:364-490) and the
     depopularisation weights (:231-278) no longer need m2 on the host: the call carries a column mask for the device-side
     transpose, and the 'sum' weights of m2 = m1^T come from the rows of m1 with np.bincount's arithmetic."""
@@ -229,7 +229,9 @@ def test_array_selectors_and_depop_weights_keep_the_device_transpose(golden):
     # the host route (multi-GPU staging) still filters m2 itself
     host = _host.prepare(A, k=10, l2=1.0, filter_cols=fc, target_cols=tc, m2_on_device=False)
     assert not host.m2_is_m1t and host.col_keep is None and host.m2_data.size < A.nnz
-    # weights: 'sum' of m2's columns == what the reference takes from the host transpose, bit for bit
+    # weights: 'sum' of m2's columns == what the reference takes from the host transpose, bit for bit (the device's np.bincount,
+    # sp_csr_col_sums_f32 over the row id of every entry of m1, is stood in for by its NumPy statement: no GPU in this tier)
+    monkeypatch.setattr(_host, "col_sums_hip", lambda d, i, nc, square, device=None: _host.csr_sum(np.square(d, dtype=np.float32) if square else d, i, None, nc, axis=0))
     d1, i1, p1 = _csr(A)
     m2 = A.T.tocsr()
     d2, i2, p2 = _csr(m2)
