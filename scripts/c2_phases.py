@@ -15,6 +15,9 @@ tun = dict(dbg=next((int(a[4:]) for a in sys.argv if a.startswith("dbg=")), 0))
 kw = dict(l1=0.5, l2=0.5, stabilized_shrink=10.0) if "c3" in sys.argv else dict(l1=1, t1=1, t2=1) if "jaccard" in sys.argv else dict(l2=1, c1=0.5, c2=0.5)
 if "binary" in sys.argv:      # (fixed-degree rows of ones: every row has the same norm, nearly every candidate of a row ties)
     kw["binary"] = True
+thr = next((float(a[4:]) for a in sys.argv if a.startswith("thr=")), None)
+if thr is not None:
+    kw["threshold"] = thr
 static = "static" in sys.argv
 m = fixed_degree_csr(1_000_000, 100_000, 64, 12345)
 k = 100

@@ -1233,6 +1233,14 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 // after the selection-free first stage)
                 const float cnt_u = (float)max(2 * p.k, min(sh[SH_CNT], cap));
                 float ch = rc.have_thr ? fmaxf((float)ITEM, 2.f * pos * left / cnt_u) : (float)room;
+                if constexpr (MONO) {
+                    // no k-th value yet, but the `threshold` parameter prunes (cutx0): U holds what passed of the `pos` products offered so
+                    // far — the rest of the row passes at most at that rate (segments come in descending weight).  Without this a row
+                    // that never collects k values above the threshold swept `room` products per stage: 45 stages at the C2 size.
+                    if (!__builtin_amdgcn_readfirstlane((int)rc.have_thr)) {      // (a scalar branch: rows with a k-th value — the rule — skip all of it)
+                        if (cutx0 > -__builtin_inff()) ch = fmaxf(ch, 0.5f * pos * left * __builtin_amdgcn_rcpf((float)max(1, min(sh[SH_CNT], cap))));
+                    }
+                }
                 if (!MONO) ch = fmaxf(ch, (float)room);
                 chunk_items = max(1, (int)fminf(ch * (1.f / ITEM), 1e6f));
             }
