@@ -11,7 +11,7 @@ import numpy as np, scipy.sparse as sp
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 from oracle import splus_oracle as so
-from similaripy_amd import _host
+from similaripy_amd import _abi, _host
 
 
 
@@ -112,7 +112,9 @@ def one_case(i):
     if rng.random() < 0.2: tuning["table_slots"] = int(rng.choice([1024, 2048, 4096]))
     if rng.random() < 0.15: tuning["threads_per_wg"] = int(rng.choice([256, 512, 768]))
     on_dev = (m2 is None) and rng.random() < 0.6
-    desc = f"#{i} {shape_kind} {m.shape} kind={kind} m2={'explicit ' + str(m2.shape) if m2 is not None else 'm1.T' + ('(device)' if on_dev else '')} fam={fam} k={k} targets={'all' if targets is None else len(targets)} kw={ {x: (v if not hasattr(v, 'shape') and not isinstance(v, list) else type(v).__name__) for x, v in kw.items()} } tuning={tuning}"
+    # (a generator of its own: the cases of the seeds of earlier rounds stay what they were)
+    stages = bool(np.random.default_rng([a.seed, i, 7]).random() < 0.4) and not a.dbg
+    desc = f"#{i} {shape_kind} {m.shape} kind={kind} m2={'explicit ' + str(m2.shape) if m2 is not None else 'm1.T' + ('(device)' if on_dev else '')} fam={fam} k={k} targets={'all' if targets is None else len(targets)}{' host-mode stages on the device' if stages else ''} kw={ {x: (v if not hasattr(v, 'shape') and not isinstance(v, list) else type(v).__name__) for x, v in kw.items()} } tuning={tuning}"
     if a.only >= 0 and i != a.only:
         return "skipped", desc
     if a.tuning:
@@ -120,7 +122,16 @@ def one_case(i):
     call = _host.prepare(m, m2, k=k, target_rows=targets, m2_on_device=on_dev, **kw)
     # bound the oracle's work
     ref_call = call
-    if call.m2_is_m1t:
+    check_zeros = False
+    if stages:
+        # what the public calls do: norms, the ones of binary=True, ARRAY selectors, the zero count and the look at the order inside the
+        # rows of an explicit m2 are left to the library's host-mode entry (SP_FLAG_NORMS_ON_DEVICE / BINARY / CHECK_ZEROS / CHECK_SORTED,
+        # col_keep); the oracle gets the host statement of the same stages
+        call = _host.prepare(m, m2, k=k, target_rows=targets, m2_on_device=True, norms_on_device=True, binary_on_device=True, m2_sorted_on_device=True,
+                             keep_on_device=True, check_zeros=False, **kw)
+        ref_call = _host.prepare(m, m2, k=k, target_rows=targets, m2_on_device=False, **kw)
+        check_zeros = True
+    elif call.m2_is_m1t:
         import dataclasses
         t = sp.csr_array((call.m1_data, call.m1_indices, call.m1_indptr), shape=(call.n_rows_m1, call.n_rows_m2)).T.tocsr(); t.sort_indices()
         d2, i2, p2 = np.ascontiguousarray(t.data, np.float32), np.ascontiguousarray(t.indices, np.int32), np.ascontiguousarray(t.indptr, np.int32)
@@ -131,7 +142,12 @@ def one_case(i):
     macs = float(colnnz[ref_call.m1_indices].sum()) * (len(ref_call.targets) / max(1, ref_call.n_rows_m1))
     if macs > a.max_macs:
         return "skipped", desc
-    rows, cols, vals, counts = _host.run_hip(call, **tuning) if not a.dbg else _run_dbg(call, tuning, a.dbg)
+    try:
+        rows, cols, vals, counts = _host.run_hip(call, check_zeros=check_zeros, **tuning) if not a.dbg else _run_dbg(call, tuning, a.dbg)
+    except (_abi.ExplicitZerosError, _abi.UnsortedRowsError):
+        # (what the public call does next: the host removes the zeros / sorts a copy and calls again)
+        call = _host.prepare(m, m2, k=k, target_rows=targets, m2_on_device=True, norms_on_device=True, binary_on_device=True, keep_on_device=True, **kw)
+        rows, cols, vals, counts = _host.run_hip(call, **tuning)
     got = so.canonical(rows, cols, vals, call.targets, call.k)
     want = so.canonical(*so.run_kernel(ref_call, "port"), call.targets, call.k)
     # Reference quirk (s_plus.h:112-116): `add()` takes "running sum == 0" for "first touch", so a column whose partial
