@@ -1234,6 +1234,14 @@ def test_multi_device_sharding_inside_the_library(monkeypatch):
             if fmt == "csr":
                 np.testing.assert_array_equal(a.indptr, b.indptr)
             _assert_same_topk(a, b, kw["k"], rtol=1e-6, tied=True)      # (the thousand identical heavy rows tie en masse: kept VALUES are compared)
+    # the host-mode stages of every slice: ones of binary=True, norms + sortedness of an explicit matrix2 (each device's own copies)
+    m2 = m.T.tocsr()
+    for name, args, kw in (("jaccard", (m,), dict(k=10, binary=True)), ("cosine", (m, m2), dict(k=10)), ("tversky", (m, m2), dict(k=10, alpha=0.4, beta=0.7, binary=True))):
+        one = getattr(sim, name)(*args, verbose=False, format_output="csr", **kw)
+        three = sim.multi_gpu.similarity(name, *args, verbose=False, format_output="csr", devices=devs, **kw)
+        assert three.nnz == one.nnz, name
+        np.testing.assert_array_equal(three.indptr, one.indptr)
+        _assert_same_topk(three, one, 10, rtol=1e-6, tied=True)
     # a stored zero is reported from whichever slice finds it, and the caller's fallback (eliminate on the host, call again) still works
     mz = m.copy()
     mz.data[7] = 0.0
