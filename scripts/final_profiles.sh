@@ -23,5 +23,7 @@ timeout 600 bash scripts/pmc_gpu.sh ${TAG}_c5 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_
   echo "== scripts/c2_phases.py 200000 c3"; timeout 600 python scripts/c2_phases.py 200000 c3 2>&1 | grep -v amdgpu.ids | tail -3
   echo "== scripts/profile_public_call.py c2"; timeout 600 python scripts/profile_public_call.py c2 2>&1 | grep "=="
   echo "== scripts/profile_public_call.py c4"; timeout 600 python scripts/profile_public_call.py c4 2>&1 | grep "=="
+  echo "== scripts/profile_public_call.py c5"; timeout 600 python scripts/profile_public_call.py c5 2>&1 | grep "=="
+  echo "== scripts/public_variants.py"; timeout 900 python scripts/public_variants.py 2>&1 | grep -v amdgpu.ids
 } > gpurun_out/other_workloads_$TAG.txt 2>&1
 tail -8 gpurun_out/bench_$TAG.log; python scripts/show_bench.py < gpurun_out/bench_$TAG.json; cat gpurun_out/other_workloads_$TAG.txt; tail -20 gpurun_out/pmc_sq_totals_$TAG.txt; head -5 gpurun_out/prof_$TAG/kernel_stats.csv | cut -c1-160
