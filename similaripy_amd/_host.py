@@ -513,8 +513,6 @@ def prepare(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_mat
     # (norms_on_device with an explicit matrix2: host mode builds both vectors from its uploaded copies, SP_FLAG_NORMS_ON_DEVICE)
     m2_explicit_dev = bool(m2_on_device) and not m2_from_m1
     dev_norms = (on_dev or m2_explicit_dev) and bool(norms_on_device) and (l1 != 0 or l2 != 0)
-    # (a 'sum' weight of matrix1 is its ROW sums in the reference's float32 reduceat order, s_plus_utils.pyx:128-158: that needs the
-    # CSR of matrix1 on the host, which the CSC route never builds)
     # binary=True (s_plus.pyx:214-217: data = ones after eliminate_zeros): when nothing on the host reads the values (device-built m2
     # and norms, no depop weights) they go up as they are and the library writes the ones into its copies (SP_FLAG_BINARY) — no array
     # of ones is built or uploaded, and the stored-zero check can stay on the device.  Otherwise the ones are made here, and then the
@@ -522,6 +520,8 @@ def prepare(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_mat
     bin_dev = bool(binary) and bool(binary_on_device) and (on_dev or m2_explicit_dev) and not p3 and l3 == 0 and (dev_norms or (l1 == 0 and l2 == 0))
     host_binary = bool(binary) and not bin_dev
     check_zeros = bool(check_zeros) or host_binary
+    # (a 'sum' weight of matrix1 is its ROW sums in the reference's float32 reduceat order, s_plus_utils.pyx:128-158: that needs the
+    # CSR of matrix1 on the host, which the CSC route never builds)
     w1_rowsum = l3 != 0 and isinstance(weight_depop_matrix1, str) and weight_depop_matrix1 == 'sum'
     csc = (on_dev and bool(csc_direct) and not arr_sel and not w1_rowsum and getattr(matrix1, "format", None) == "csc" and (dev_norms or (l1 == 0 and l2 == 0))
            and matrix1.nnz <= np.iinfo(np.int32).max
