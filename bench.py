@@ -213,6 +213,7 @@ def main():
                     help="gloo: functional check of the N > 1 path on a box with fewer GPUs than ranks (ranks share devices, slabs gathered through the host)")
     ap.add_argument("--phases", type=int, default=4, help="N > 1: sub-slices of the split-phase gather (1 = one launch, one gather)")
     ap.add_argument("--reserve-cus", type=int, default=8, help="N > 1 under RCCL: CUs the persistent row kernels leave free, so that the gather's kernels can run beside the next sub-launch (0 = none)")
+    ap.add_argument("--persist-prep", action="store_true", help="A/B only: keep the per-call passes over m2 / Y* across steps (the default redoes them every step at every world size)")
     ap.add_argument("--rows", type=int, default=0)
     ap.add_argument("--cols", type=int, default=0)
     ap.add_argument("--nnz-row", type=int, default=0)
@@ -286,9 +287,10 @@ def main():
     def measure(the_call, steps, warmup, detail):
         """K timed steps of the sharded problem (barrier + synchronize on both sides, max over ranks), then the per-kernel
         and per-rank figures from K more passes outside the timed region."""
-        # (N > 1: the passes over the replicated m2 / Y* are built by the first step of the resident problem and kept — its operands do
-        # not change between steps; N = 1, the headline: every step redoes them)
-        shard = ShardedDeviceProblem(the_call, device=dev, phases=args.phases, persist_prep=world > 1)      # partition_targets + DeviceProblem of this rank's slice
+        # (every step redoes the per-call passes over m2 / Y* — fold or pack, column-term minima, window boundaries, sign scan — at EVERY
+        # world size: the N > 1 values are compared with the N = 1 value, so they must time the same work (ADVICE r4; the sub-launches
+        # of ONE step still share them, SP_FLAG_REUSE_M2_PREP).  --persist-prep keeps them across steps, for A/B runs only.)
+        shard = ShardedDeviceProblem(the_call, device=dev, phases=args.phases, persist_prep=args.persist_prep)      # partition_targets + DeviceProblem of this rank's slice
         ev_pairs = []
 
         def step(timed: bool, gather: bool = True):
@@ -313,6 +315,24 @@ def main():
         res = {"elapsed": elapsed, "step_ms": [a.elapsed_time(b) for a, b in ev_pairs], "shard": shard}
         if not detail:
             return res
+        if world == 1 and rank == 0 and shard.phases == 1 and shard.n_loc and steps > 0:
+            # what the LAST TIMED STEP left in the output buffers, for 2 000 sampled slots (the tail of the work-ordered queue included):
+            # copied out here, before anything else launches — the checker (oracle, in the cpu_baseline child) sees it later
+            n_loc, kk = int(shard.n_loc), the_call.k
+            nnz2 = np.diff(the_call.m2_indptr).astype(np.int64) if the_call.m2_indptr.size else np.zeros(0, np.int64)
+            if nnz2.size and the_call.m1_indptr.size:
+                per = nnz2[the_call.m1_indices]
+                cs = np.concatenate(([0], np.cumsum(per)))
+                macs_t = (cs[the_call.m1_indptr[1:]] - cs[the_call.m1_indptr[:-1]])[the_call.targets[:n_loc]]
+                tail = np.argsort(macs_t, kind="stable")[:200]
+            else:
+                tail = np.zeros(0, np.int64)
+            pick = np.unique(np.concatenate((tail, np.random.default_rng(7).choice(n_loc, min(n_loc, 1800), replace=False)))).astype(np.int64)
+            idx = torch.from_numpy(pick).to(dev)
+            res["parity_sample"] = {"slots": pick,
+                                    "cols": shard.pad_cols[: n_loc * kk].view(n_loc, kk)[idx].cpu().numpy(),
+                                    "vals": shard.pad_vals[: n_loc * kk].view(n_loc, kk)[idx].cpu().numpy(),
+                                    "counts": shard.pad_cnt[:n_loc][idx].cpu().numpy()}
         # dominant kernel: hipEvents around its launch inside the library, K more passes of the same step (untimed region)
         infos = [shard.run(gather=False, time_kernel=True, static_sched=args.static_sched, phase_timers=False, **tuning) for _ in range(max(1, steps))]
         res["info"] = shard.run(gather=False, time_kernel=True, static_sched=args.static_sched, **tuning)     # one pass with the in-kernel phase timers
@@ -427,7 +447,8 @@ def main():
             "macs_per_row": macs / total_rows,
             "parallelism": par, "backend": args.backend if world > 1 else None,
             "reserved_cus": int(os.environ.get("SIMILARIPY_AMD_RESERVE_CUS", "0")),
-            "m2_prep": "every step" if world == 1 else "once per resident problem (SP_FLAG_REUSE_M2_PREP: the replicated operands do not change between steps)",
+            "m2_prep": "once per resident problem (--persist-prep: A/B only)" if args.persist_prep else "every step",
+            "persist_prep": bool(args.persist_prep),
             "kept_entries_rank0": n_kept, "generic_windows_per_row": info["passes_total"] / max(1, main_res["per_rank"][0]["rows"]),
             "phase_share": phase_share(info),
             "per_rank": main_res["per_rank"],
@@ -453,19 +474,25 @@ def main():
             tr = {"traffic": None, "traffic_source": f"not measured: {type(exc).__name__}: {str(exc)[:200]}"}
         out["roofline"].update(tr)
     if world == 1 and not args.no_end_to_end:
+        # the reference harness's definition (tests/benchmarks/benchmark.py:168-189: perf_counter around ONE public call; its rounds are
+        # reported as mean +- std, run_benchmarks.py): the COLD call — the first public call this process makes on this matrix: library
+        # and allocator warm, nothing cached for it — then 3 more rounds, mean +- std.  `end_to_end_s` = that mean.
         import similaripy_amd as sim
-        sim.cosine(sp.csr_array(sp.random_array((2000, 500), density=0.02, format="csr", dtype=np.float32, random_state=np.random.default_rng(0))), k=10, verbose=False)   # (library / allocator warm-up)
+        t0 = time.perf_counter()
+        res = wl.public_call[1](sim)
+        cold = time.perf_counter() - t0
         ts = []
-        res = None
         for _ in range(3):
-            # (the previous result is released OUTSIDE the timed region: unmapping 0.8 GB of touched pages takes 30-40 ms and belongs to
-            # no call; the first call of the process also pays the library's first device allocations)
+            # (the previous result is released OUTSIDE the timed region: unmapping 0.8 GB of touched pages takes 30-40 ms and belongs to no call)
             del res
             t0 = time.perf_counter()
             res = wl.public_call[1](sim)
             ts.append(time.perf_counter() - t0)
-        out["end_to_end_s"] = min(ts)
-        out["end_to_end"] = {"call": wl.public_call[0], "seconds": ts, "rows_per_s": n_rows / min(ts), "out_nnz": int(res.nnz)}
+        out["end_to_end_s"] = float(np.mean(ts))
+        out["end_to_end"] = {"call": wl.public_call[0], "cold_first_call_s": cold, "seconds": ts, "mean_s": float(np.mean(ts)), "std_s": float(np.std(ts)),
+                             "min_s": float(min(ts)), "rows_per_s": n_rows / float(np.mean(ts)), "out_nnz": int(res.nnz),
+                             "definition": "benchmark.py:168-189 — wall clock of one public call, host preprocessing and output assembly included; "
+                                           "cold = the first call of this process on this matrix, then 3 rounds (mean +- std)"}
         del res
     if world == 1 and args.workload == "c2" and not args.no_other_workloads and not (args.rows or args.cols or args.nnz_row or args.k or args.dbg):
         # the other BASELINE configs, driver-timed: 3 steps each behind the headline's timed region
@@ -496,7 +523,8 @@ def main():
                 others[name] = {"error": f"{type(exc).__name__}: {str(exc)[:300]}"}
         out["other_workloads"] = others
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(call, args.cpu_seconds)
+        out["cpu_baseline"] = cpu_baseline(call, args.cpu_seconds, main_res.get("parity_sample"))
+        out["parity_check"] = out["cpu_baseline"].pop("parity_check", None)
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -604,7 +632,7 @@ sys.path.insert(0, sys.argv[1])
 from oracle import splus_oracle as so
 d = np.load(sys.argv[2], mmap_mode=None)
 meta = json.loads(str(d["meta"]))
-call = types.SimpleNamespace(**{k: d[k] for k in d.files if k != "meta"}, **meta["scalars"])
+call = types.SimpleNamespace(**{k: d[k] for k in d.files if k != "meta" and not k.startswith("ps_")}, **meta["scalars"])
 kind = "reference" if so.available("reference") else "port"
 budget = float(sys.argv[3])
 n_total = call.targets.shape[0]
@@ -612,6 +640,29 @@ def run(n, bs):
     c = types.SimpleNamespace(**vars(call)); c.targets = np.ascontiguousarray(call.targets[:n])
     t0 = time.perf_counter(); so.run_kernel(c, kind, num_threads=0, block_size=bs); return time.perf_counter() - t0
 out = {"kind": kind, "threads": so.max_threads(kind)}
+if "ps_slots" in d.files:
+    # the checker on what the last timed step wrote: north_star's bar — same top-k set wherever values are not tied at the k-th place,
+    # float32 values within 1e-5 relative (tie-aware comparison, oracle.splus_oracle.compare_topk)
+    slots = d["ps_slots"].astype(np.int64)
+    k = int(call.k)
+    c = types.SimpleNamespace(**vars(call)); c.targets = np.ascontiguousarray(call.targets[slots])
+    want = so.canonical(*so.run_kernel(c, kind, num_threads=0, block_size=0), c.targets, k)
+    got = []
+    for i in range(slots.shape[0]):
+        n_i = int(d["ps_counts"][i]); cc = d["ps_cols"][i, :n_i]; vv = d["ps_vals"][i, :n_i]; o = np.argsort(cc, kind="stable"); got.append((cc[o], vv[o]))
+    pc = {"rows": int(slots.shape[0]), "checker": "reference kernel (oracle/_ref)" if kind == "reference" else "oracle port", "rtol": 1e-5, "ok": False, "max_rel_err": None, "boundary_ties": None}
+    try:
+        pc["boundary_ties"] = int(so.compare_topk(got, want, k, rtol=1e-5, atol=1e-7, what="bench parity_check"))
+        pc["ok"] = True
+    except AssertionError as exc:
+        pc["error"] = str(exc)[:300]
+    worst = 0.0
+    for (gc, gv), (wc, wv) in zip(got, want):
+        _, gi, wi = np.intersect1d(gc, wc, assume_unique=True, return_indices=True)
+        if gi.size:
+            worst = max(worst, float(np.max(np.abs(gv[gi].astype(np.float64) - wv[wi]) / np.maximum(np.abs(wv[wi].astype(np.float64)), 1e-30))))
+    pc["max_rel_err"] = worst
+    out["parity_check"] = pc
 for name, bs in (("blocked_262144", 262144), ("unblocked", 0)):
     probe = min(n_total, 4000)
     run(min(n_total, 500), bs)                                  # thread team up, pages in
@@ -625,9 +676,11 @@ print(json.dumps(out))
 """
 
 
-def cpu_baseline(call, round_s: float) -> dict:
+def cpu_baseline(call, round_s: float, parity_sample=None) -> dict:
     """The CPU kernel (oracle/_ref = the reference header compiled in place, else the C port) on a bounded prefix of the
-    same target rows, in a child process whose OpenMP runtime is pinned to the physical cores."""
+    same target rows, in a child process whose OpenMP runtime is pinned to the physical cores.
+    parity_sample: slots / cols / vals / counts copied out of the LAST TIMED STEP's output buffers — the same child (the only place
+    bench.py touches the oracle) runs the checker on those rows and reports `parity_check` {rows, max_rel_err, boundary_ties, ok}."""
     import subprocess
     import tempfile
 
@@ -640,7 +693,10 @@ def cpu_baseline(call, round_s: float) -> dict:
     shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
     with tempfile.TemporaryDirectory(dir=shm) as td:
         f = os.path.join(td, "call.npz")
-        np.savez(f, meta=json.dumps({"scalars": scal}), **{n: getattr(call, n) for n in names})
+        extra = {}
+        if parity_sample is not None:
+            extra = {"ps_slots": parity_sample["slots"], "ps_cols": parity_sample["cols"], "ps_vals": parity_sample["vals"], "ps_counts": parity_sample["counts"]}
+        np.savez(f, meta=json.dumps({"scalars": scal}), **{n: getattr(call, n) for n in names}, **extra)
         env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_PROC_BIND="spread", OMP_PLACES="cores")
         proc = subprocess.run([sys.executable, "-c", _CPU_CHILD, str(ROOT), f, str(round_s)], env=env, capture_output=True, text=True)
     if proc.returncode != 0:
@@ -649,7 +705,12 @@ def cpu_baseline(call, round_s: float) -> dict:
     b, u = r["blocked_262144"], r["unblocked"]
     log(f"cpu_baseline[{r['kind']}] {r['threads']} threads on {cores} physical cores: blocked(262144, the reference default) "
         f"{b['rows_per_s']:.0f} +- {b['std']:.0f} rows/s; unblocked {u['rows_per_s']:.0f} +- {u['std']:.0f} rows/s")
+    if r.get("parity_check"):
+        pc = r["parity_check"]
+        log(f"parity_check: {pc['rows']} rows of the last timed step vs the {pc['checker']}: ok={pc['ok']} max_rel_err={pc['max_rel_err']:.2e} boundary_ties={pc['boundary_ties']}"
+            + (f" ({pc['error']})" if pc.get("error") else ""))
     return {
+        "parity_check": r.get("parity_check"),
         "value": b["rows_per_s"], "std": b["std"], "unit": "rows/s", "cores": r["threads"], "kind": r["kind"],
         "sample": f"first {b['sample_rows']} of {call.targets.shape[0]} target rows of the same workload, the reference's default column "
                   f"blocking (block_size=0 -> 262144, s_plus.pyx:218-225; without its popularity reorder, which only permutes slot order), "

@@ -46,7 +46,12 @@ extern "C" {
 #define SP_ENOMEM       -4
 #define SP_EWORKSPACE   -5   /* caller workspace too small */
 #define SP_EZEROS       -6   /* SP_FLAG_CHECK_ZEROS: the matrices hold explicit zeros (see explicit_zeros); nothing was computed */
-#define SP_EUNSORTED    -7   /* SP_FLAG_M1_IS_M2_T / SP_FLAG_CHECK_SORTED (host mode): a row of m2 does not have ascending column ids; nothing was computed */
+#define SP_EUNDERFLOW   -8   /* SP_FLAG_P3_PREP (host mode): stored entries underflowed to 0.0 in the L1 divide or the power (explicit_zeros holds the
+                                count).  The reference drops them before its kernel runs (similarity.py:410-415, then eliminate_zeros,
+                                s_plus.pyx:210-211); the outputs of this call still hold them as zero-valued candidates and must be discarded:
+                                the caller preprocesses on the host and calls again without SP_FLAG_P3_PREP */
+#define SP_EUNSORTED    -7   /* host mode: a row of m2 (SP_FLAG_M1_IS_M2_T / SP_FLAG_CHECK_SORTED) or of a MATRIX selector (always checked, message
+                                "MATRIX selector ...") does not have ascending column ids; nothing was computed */
 
 /* flags */
 #define SP_FLAG_TIME_KERNEL   1u  /* bracket device work with hipEvents on `stream`, sync, fill kernel_ms */
@@ -104,6 +109,9 @@ extern "C" {
 #define SP_FLAG_CHECK_SORTED 65536u /* host mode, explicit m2: the rows of the uploaded m2 are checked for ascending column ids on the device (the
                                      requirement above); a descent anywhere: SP_EUNSORTED, nothing computed — the caller sorts and calls again
                                      (what the host layer did with a pass over m2's indices before every call) */
+
+#define SP_FLAG_PROGRESS    131072u /* host mode: one line on stderr whenever a chunk of result rows has reached the host ("rows done a / n") — the coarse
+                                     counterpart of ProgressBar::update (progress_bar.h:199-208, driven from s_plus.h:340-342); `verbose=True` sets it */
 
 typedef struct sp_knn_args {
     uint32_t struct_size;      /* = sizeof(sp_knn_args); checked */

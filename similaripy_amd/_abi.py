@@ -31,7 +31,9 @@ SP_FLAG_NORMS_ON_DEVICE = 8192
 SP_FLAG_REUSE_M2_PREP = 16384
 SP_FLAG_BINARY = 32768
 SP_FLAG_CHECK_SORTED = 65536
+SP_FLAG_PROGRESS = 131072
 SP_EZEROS = -6
+SP_EUNDERFLOW = -8
 SP_EUNSORTED = -7
 SP_NORM_L1, SP_NORM_L2, SP_NORM_MAX, SP_NORM_TFIDF, SP_NORM_BM25PLUS = range(5)
 SP_TF_MODES = {'binary': 0, 'raw': 1, 'sqrt': 2, 'freq': 3, 'log': 4}       # normalization.pyx:12-17
@@ -236,6 +238,11 @@ class ExplicitZerosError(HipLibraryError):
     """SP_FLAG_CHECK_ZEROS found stored zeros: the caller eliminates them (s_plus.pyx:210-211) and calls again."""
 
 
+class P3UnderflowError(HipLibraryError):
+    """SP_FLAG_P3_PREP: stored entries underflowed to 0.0 in the L1 divide or the power; the reference drops them before its kernel
+    runs (similarity.py:410-415, s_plus.pyx:210-211): the caller preprocesses on the host and calls again."""
+
+
 class UnsortedRowsError(HipLibraryError):
     """SP_FLAG_M1_IS_M2_T found a row of m2 whose column ids do not ascend: the caller converts on the host and calls again."""
 
@@ -344,6 +351,8 @@ def call_knn(args: SpKnnArgs) -> None:
         raise ExplicitZerosError(last_error())
     if rc == SP_EUNSORTED:
         raise UnsortedRowsError(last_error())
+    if rc == SP_EUNDERFLOW:
+        raise P3UnderflowError(last_error())
     if rc != 0:
         raise HipLibraryError(f"sp_knn_f32_i32 failed ({rc}): {last_error()}")
 

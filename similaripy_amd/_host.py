@@ -292,18 +292,25 @@ def has_stored_zeros(data) -> bool:
     return bool(np.count_nonzero(data) != data.shape[0])
 
 
-def build_column_selector(cols):
+def build_column_selector(cols, verify_order: bool = True):
     """(mode, indptr, indices): sparse with data -> MATRIX (CSR, zeros removed, sorted rows);
-    non-empty list/array -> ARRAY; else NONE — s_plus_utils.pyx:311-361."""
+    non-empty list/array -> ARRAY; else NONE — s_plus_utils.pyx:311-361.
+    verify_order=False: scipy's cached has_sorted_indices flag is taken at its word here because the library looks at the order itself
+    where the selector goes anyway (run_host: sp_rows_sorted_kernel on the uploaded rows -> UnsortedRowsError -> the caller comes back
+    with verify_order=True); True: one vectorised pass over the indices here (60 ms at 64 M entries)."""
     if sp.issparse(cols) and cols.data.shape[0] != 0:
         m = cols.tocsr()
         # the caller's matrix is never modified; it is copied only when something has to change (an URM used as its own
         # filter — the common case — is canonical already, and its copy was most of this call's host time: 64 M entries)
-        dirty = has_stored_zeros(m.data) or not m.has_sorted_indices
+        # (has_sorted_indices is a CACHED scipy flag that in-place edits of .indices do not refresh: a stale True would hand unsorted rows
+        # to the kernels' binary search over the selector row — the order is looked at, _rows_sorted, one vectorised pass; ADVICE r4)
+        in_order = m.has_sorted_indices if not verify_order else _rows_sorted(np.asarray(m.indices), np.asarray(m.indptr))
+        dirty = has_stored_zeros(m.data) or not in_order
         if dirty:
             if m is cols:
                 m = m.copy()
             m.eliminate_zeros()
+            m.has_sorted_indices = False      # (never trust the cached flag on the way to a sort)
             m.sort_indices()
         return MODE_MATRIX, np.ascontiguousarray(m.indptr, dtype=np.int32), np.ascontiguousarray(m.indices, dtype=np.int32)
     if isinstance(cols, (list, np.ndarray)) and len(cols) != 0:
@@ -434,8 +441,9 @@ def build_csr(targets, cols, values, counts, k: int, n_rows: int, n_cols: int) -
 # prepare / run / finish
 # --------------------------------------------------------------------------------------------
 def _say(verbose: bool, msg: str) -> None:
-    # the reference drives a C++ progress bar on stderr (s_plus.pyx:199-202); a per-row host
-    # callback has no device analogue, so only the phase names are reported
+    # the reference drives a C++ progress bar on stderr (s_plus.pyx:199-202, progress_bar.h:199-208); a per-row host callback has no
+    # device analogue: the phase names are reported here, and the library prints "rows done a / n" whenever a chunk of result rows has
+    # reached the host (SP_FLAG_PROGRESS: four chunks for a large call, one line for a small one)
     if verbose:
         print(f"[similaripy_amd] {msg}", file=sys.stderr, flush=True)
 
@@ -463,7 +471,7 @@ def prepare(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_mat
             binary=False, target_rows=None, filter_cols=None, target_cols=None,
             verbose=False, format_output='csr', m2_on_device=False, check_zeros=True,
             p3_alpha=None, p3_depop_beta=None, norms_on_device=False, csc_direct=False, keep_on_device=False,
-            binary_on_device=False, m2_sorted_on_device=False) -> KernelCall:
+            binary_on_device=False, m2_sorted_on_device=False, selectors_sorted_on_device=False) -> KernelCall:
     """Everything s_plus.pyx does before the `with nogil:` block (:168-353).
 
     check_zeros=False: stored zeros are looked for on the device (run_hip(check_zeros=True)) instead of here.
@@ -500,8 +508,10 @@ def prepare(matrix1, matrix2=None, weight_depop_matrix1='none', weight_depop_mat
             # the reference does not check (s_plus.pyx:191-196: out-of-range is UB there)
             raise ValueError("target_rows contains row ids outside matrix1")
 
-    sel_f = build_column_selector(filter_cols)
-    sel_t = build_column_selector(target_cols)
+    # (selectors_sorted_on_device: the host-mode entry checks the order inside the rows of a MATRIX selector on the device; a caller of
+    # DeviceProblem / the oracle gets the host pass)
+    sel_f = build_column_selector(filter_cols, verify_order=not selectors_sorted_on_device)
+    sel_t = build_column_selector(target_cols, verify_order=not selectors_sorted_on_device)
     p3 = p3_alpha is not None
     # ARRAY selectors drop whole columns of m2 (s_plus_utils.pyx:364-490): with the device-side transpose that is a mask over
     # the rows of m1 it reads (KernelCall.col_keep).  With p3_alpha the library applies the mask to the NORMALISED m2 instead (the
@@ -633,13 +643,14 @@ def selected_device() -> int:
 def run_hip(call: KernelCall, device: Optional[int] = None, table_slots: int = 0, threads_per_wg: int = 0,
             num_wgs: int = 0, load_pct: int = 0, time_kernel: bool = False, static_sched: bool = False,
             no_sparse_path: bool = False, no_fold: bool = False, want_rows: bool = True,
-            check_zeros: bool = False, csr_out: bool = False, dbg: int = 0, devices=None):
+            check_zeros: bool = False, csr_out: bool = False, dbg: int = 0, devices=None, progress: bool = False):
     """The `with nogil:` block of s_plus.pyx:359-384, on the GPU: host buffers in, host buffers out
     through the C ABI (include/sp_knn.h).  Returns rows, cols, values, counts[, info].
 
     check_zeros: SP_FLAG_CHECK_ZEROS — raises _abi.ExplicitZerosError when m1 / m2 hold stored zeros.
     csr_out: SP_FLAG_CSR_OUT — the CSR result is assembled on the device (any order of the targets, repeats included); returns
     (indptr, indices, data) of the final matrix instead (views of the buffers the library filled).
+    progress: SP_FLAG_PROGRESS — "rows done a / n" on stderr whenever a chunk of result rows has reached the host (verbose=True).
     devices: a list of HIP ordinals — sp_knn_args.n_devices / device_ids (ABI 5): the library cuts the target list into
     cost-balanced contiguous slices and runs slice r on devices[r], one host thread per device, inside this ONE call
     (with csr_out the targets must ascend strictly)."""
@@ -658,7 +669,8 @@ def run_hip(call: KernelCall, device: Optional[int] = None, table_slots: int = 0
     a.flags = ((0 if want_rows else _abi.SP_FLAG_NO_ROWS_OUT) | (_abi.SP_FLAG_TIME_KERNEL | _abi.SP_FLAG_PHASE_TIMERS if time_kernel else 0) | (_abi.SP_FLAG_STATIC_SCHED if static_sched else 0)
                | (_abi.SP_FLAG_NO_SPARSE_PATH if no_sparse_path else 0) | (_abi.SP_FLAG_NO_FOLD if no_fold else 0)
                | (_abi.SP_FLAG_CHECK_ZEROS if check_zeros else 0) | (_abi.SP_FLAG_CSR_OUT if csr_out else 0)
-               | (_abi.SP_FLAG_BINARY if call.binary_on_device else 0) | (_abi.SP_FLAG_CHECK_SORTED if call.check_m2_sorted else 0))
+               | (_abi.SP_FLAG_BINARY if call.binary_on_device else 0) | (_abi.SP_FLAG_CHECK_SORTED if call.check_m2_sorted else 0)
+               | (_abi.SP_FLAG_PROGRESS if progress else 0))
     if call.p3_alpha is not None:
         a.flags |= _abi.SP_FLAG_P3_PREP
         a.p3_alpha = call.p3_alpha
@@ -817,7 +829,7 @@ def _s_plus_impl(matrix1, matrix2, weight_depop_matrix1, weight_depop_matrix2, p
         return res
     # stored zeros: looked for on the device, where the data goes anyway (also under `binary` when the library writes the ones into
     # its own copies, SP_FLAG_BINARY; where prepare has to build the ones itself it checks on the host whatever is asked here)
-    opts = dict(check_zeros=False, csc_direct=True, binary_on_device=True, m2_sorted_on_device=True)
+    opts = dict(check_zeros=False, csc_direct=True, binary_on_device=True, m2_sorted_on_device=True, selectors_sorted_on_device=True)
     while True:
         call = prepare(*args, m2_on_device=True, norms_on_device=True, keep_on_device=True, **opts, **p3kw)
         # CSR results are assembled on the device whatever the order of target_rows (SP_FLAG_CSR_OUT: the stable counting sort of
@@ -833,14 +845,17 @@ def _s_plus_impl(matrix1, matrix2, weight_depop_matrix1, weight_depop_matrix2, p
         try:
             # (the row id of every slot entry is known on the host: the library's helper threads write `rows` while the device works,
             # a third of the COO download is never made)
-            out = run_hip(call, want_rows=(format_output != 'csr'), check_zeros=not opts["check_zeros"], csr_out=csr_out, devices=devices)
+            out = run_hip(call, want_rows=(format_output != 'csr'), check_zeros=not opts["check_zeros"], csr_out=csr_out, devices=devices,
+                          progress=bool(verbose) if isinstance(verbose, bool) else False)
             break
         except _abi.ExplicitZerosError:
             if opts["check_zeros"]:
                 raise
             opts["check_zeros"] = True          # eliminate_zeros on the host (s_plus.pyx:210-211), then again
-        except _abi.UnsortedRowsError:
-            if call.m1_is_m2t and opts["csc_direct"]:
+        except _abi.UnsortedRowsError as exc:
+            if "selector" in str(exc) and opts["selectors_sorted_on_device"]:
+                opts["selectors_sorted_on_device"] = False   # a stale has_sorted_indices flag: the order is verified (and a copy sorted) here, then again
+            elif call.m1_is_m2t and opts["csc_direct"]:
                 opts["csc_direct"] = False          # matrix1.tocsr() on the host (s_plus.pyx:205-206), then again
             elif call.check_m2_sorted and opts["m2_sorted_on_device"]:
                 opts["m2_sorted_on_device"] = False  # sort_indices() on a copy of matrix2 here (s_plus_utils.pyx:562), then again

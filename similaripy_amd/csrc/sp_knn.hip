@@ -126,15 +126,45 @@ constexpr size_t WS_QUEUE_BYTES = 256;
 constexpr size_t WS_PHASE_OFFSET = 64;
 constexpr size_t WS_YMIN_OFFSET = 176;
 constexpr size_t WS_FOLDZERO_OFFSET = 160;      // int: a stored entry of m2 met a zero column term while it was folded in
-static_assert(WS_PHASE_OFFSET + PH_N * 8 <= WS_FOLDZERO_OFFSET && WS_FOLDZERO_OFFSET + 4 <= WS_YMIN_OFFSET && WS_YMIN_OFFSET + 16 <= WS_QUEUE_BYTES, "workspace header layout");
+constexpr size_t WS_SPLITS_STATE_OFFSET = 192;  // int[2]: the dense-window boundaries exist in this workspace | workgroups of sp_m2_splits_kernel done
+static_assert(WS_PHASE_OFFSET + PH_N * 8 <= WS_FOLDZERO_OFFSET && WS_FOLDZERO_OFFSET + 4 <= WS_YMIN_OFFSET && WS_YMIN_OFFSET + 16 <= WS_SPLITS_STATE_OFFSET &&
+              WS_SPLITS_STATE_OFFSET + 8 <= WS_QUEUE_BYTES, "workspace header layout");
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
-// What the zero-term check of a folding call found, per caller workspace: a SP_FLAG_REUSE_M2_PREP call on the same workspace must take the
-// same route (folded or not) without a read-back of its own.
-std::mutex g_foldzero_mu;
-std::map<const void *, int> g_foldzero;
-void foldzero_store(const void *ws, int v) { std::lock_guard<std::mutex> lk(g_foldzero_mu); g_foldzero[ws] = v; }
-int foldzero_lookup(const void *ws) { std::lock_guard<std::mutex> lk(g_foldzero_mu); auto it = g_foldzero.find(ws); return it == g_foldzero.end() ? -1 : it->second; }
+// What the library remembers about the call that BUILT the per-call passes in a caller workspace (SP_FLAG_REUSE_M2_PREP):
+//   sig        a hash of everything those passes and the workspace layout depend on — m2 / Y* pointers and sizes, every scalar
+//              parameter, k, the tuning fields, the flags that choose the layout.  A REUSE call with another signature is refused
+//              (SP_EINVAL): it would read folded values, packed terms or window boundaries laid out for other parameters.
+//   zero_term  what the zero-term check of a folding rp3beta-type call found (the REUSE call takes the same route without a read-back).
+// Keyed by the workspace address; an entry is rewritten by every non-REUSE call on that address, so it always describes the passes that
+// are in the workspace now.  Bounded (oldest entries go first); a REUSE call on an address the table does not know is trusted as before
+// (the header word at WS_FOLDZERO_OFFSET still answers the zero-term question: it is rewritten after the unfolded rerun).
+struct PrepEntry { uint64_t sig; int zero_term; uint64_t seq; };
+std::mutex g_prep_mu;
+std::map<const void *, PrepEntry> g_prep;
+uint64_t g_prep_seq = 0;
+constexpr size_t PREP_TABLE_MAX = 1024;
+void prep_store(const void *ws, uint64_t sig, int zero_term) {
+    std::lock_guard<std::mutex> lk(g_prep_mu);
+    if (g_prep.size() >= PREP_TABLE_MAX && g_prep.find(ws) == g_prep.end()) {
+        auto oldest = g_prep.begin();
+        for (auto it = g_prep.begin(); it != g_prep.end(); ++it) if (it->second.seq < oldest->second.seq) oldest = it;
+        g_prep.erase(oldest);
+    }
+    g_prep[ws] = PrepEntry{sig, zero_term, ++g_prep_seq};
+}
+bool prep_lookup(const void *ws, PrepEntry *e) {
+    std::lock_guard<std::mutex> lk(g_prep_mu);
+    auto it = g_prep.find(ws);
+    if (it == g_prep.end()) return false;
+    *e = it->second;
+    return true;
+}
+void prep_set_zero(const void *ws, int zero_term) {
+    std::lock_guard<std::mutex> lk(g_prep_mu);
+    auto it = g_prep.find(ws);
+    if (it != g_prep.end()) it->second.zero_term = zero_term;
+}
 constexpr int ITEMS_ROWS_MAX = 1 << 21;
 
 // LDS of the two kernels without the candidate buffer (see their carve-ups)
@@ -346,8 +376,12 @@ int launch_generic(const KParams &kp, const Config &c, hipStream_t stream) {
     return SP_OK;
 }
 
+// the per-call pass the generic kernel alone needs (sp_m2_splits_kernel), queued between the sparse-row kernels and the generic one
+struct SplitsLaunch { int n_rows_m2; const int *m2_indptr, *m2_indices; int split_w, n_splits; int *out; const unsigned *qcount_g; int *state; };
+
 // kp_s: the sparse kernel's parameters (its own tile), kp: the generic kernel's
-int launch_rows(const KParams &kp_s, const KParams &kp, const Config &c, hipStream_t stream, hipEvent_t *ev /* [4] or NULL: around the two row kernels */) {
+int launch_rows(const KParams &kp_s, const KParams &kp, const Config &c, hipStream_t stream, hipEvent_t *ev /* [4] or NULL: around the two row kernels */,
+                const SplitsLaunch *sl = nullptr) {
     // sparse rows first; what it cannot finish joins the generic queue, which the second launch drains
     if (ev) HIP_TRY(hipEventRecord(ev[0], stream));
     if (kp.sparse_path && c.wave) {
@@ -372,7 +406,14 @@ int launch_rows(const KParams &kp_s, const KParams &kp, const Config &c, hipStre
         else rc = launch_sparse<1024>(kp_s, c, stream);
         if (rc) return rc;
     }
-    if (ev) { HIP_TRY(hipEventRecord(ev[1], stream)); HIP_TRY(hipEventRecord(ev[2], stream)); }
+    if (ev) HIP_TRY(hipEventRecord(ev[1], stream));
+    if (sl) {
+        const long long n = (long long)sl->n_rows_m2 * sl->n_splits;
+        hipLaunchKernelGGL(sp_m2_splits_kernel, dim3((unsigned)std::min<long long>(256 * 16, (n + 255) / 256)), dim3(256), 0, stream, sl->n_rows_m2, sl->m2_indptr,
+                           sl->m2_indices, sl->split_w, sl->n_splits, sl->out, sl->qcount_g, sl->state);
+        HIP_TRY(hipGetLastError());
+    }
+    if (ev) HIP_TRY(hipEventRecord(ev[2], stream));
     int rc;
     if (c.NT == 256) rc = launch_generic<256>(kp, c, stream);
     else if (c.NT == 512) rc = launch_generic<512>(kp, c, stream);
@@ -392,8 +433,29 @@ struct ChunkHook {
     std::function<int(int)> after_launch;
 };
 
+// Everything the per-call passes over m2 / Y* and the layout of the workspace blocks in front of the per-target state depend on (FNV-1a).
+uint64_t prep_signature(const sp_knn_args *a, const Config &c) {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void *p, size_t n) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } };
+#define SP_MIX(x) mix(&(x), sizeof(x))
+    const uint32_t fl = a->flags & (SP_FLAG_NO_FOLD | SP_FLAG_NO_SPARSE_PATH);
+    const int64_t abl = a->reserved[0] & (1024 | 2048 | 4096 | 16384);
+    SP_MIX(fl); SP_MIX(abl);
+    SP_MIX(a->n_rows_m2); SP_MIX(a->n_output_cols); SP_MIX(a->nnz_m2);
+    SP_MIX(a->m2_data); SP_MIX(a->m2_indices); SP_MIX(a->m2_indptr);
+    SP_MIX(a->Ytversky); SP_MIX(a->Ycosine); SP_MIX(a->Ydepop);
+    SP_MIX(a->a1); SP_MIX(a->l1); SP_MIX(a->l2); SP_MIX(a->l3); SP_MIX(a->t1); SP_MIX(a->t2);
+    SP_MIX(a->stabilized_shrink); SP_MIX(a->bayesian_shrink);
+    SP_MIX(a->k); SP_MIX(a->table_slots); SP_MIX(a->threads_per_wg); SP_MIX(a->load_pct);
+    const uint64_t lay[5] = {(uint64_t)c.ws_fold_bytes, (uint64_t)c.ws_split_bytes, (uint64_t)c.n_splits, (uint64_t)c.split_w, (uint64_t)(c.fold ? 1 : 0) | (c.pack ? 2 : 0)};
+    mix(lay, sizeof(lay));
+#undef SP_MIX
+    return h;
+}
+
 // all pointers in `a` are device pointers here
-int run_device_impl(sp_knn_args *a) {
+// (sig_override: the unfolded rerun of a folding call keeps the signature of the call as the caller made it)
+int run_device_impl(sp_knn_args *a, const uint64_t *sig_override = nullptr) {
     HIP_TRY(hipSetDevice(a->device));
     if (a->n_targets == 0) { a->kernel_ms = 0.f; return SP_OK; }
     int n_cus = 256;
@@ -431,9 +493,16 @@ int run_device_impl(sp_knn_args *a) {
     // SP_FLAG_REUSE_M2_PREP: an earlier call on this workspace left the per-call passes over m2 / Y* behind (folded values or packed
     // column terms, their minima, the dense-window boundaries, the sign flag); only the per-target state is rebuilt
     const bool reuse = (a->flags & SP_FLAG_REUSE_M2_PREP) != 0 && a->workspace != nullptr;
+    const uint64_t sig = sig_override ? *sig_override : prep_signature(a, c);
+    PrepEntry built{};
+    const bool known = a->workspace != nullptr && prep_lookup(ws, &built);
+    if (reuse && known && built.sig != sig)
+        return fail(SP_EINVAL, "SP_FLAG_REUSE_M2_PREP: m2 / Y*, a scalar parameter, k or a tuning field differs from the call that built the passes "
+                               "in this workspace — drop the flag (the passes are rebuilt) or repeat that call's arguments");
+    if (a->workspace && !reuse) prep_store(ws, sig, -1);
     if (reuse && c.fold && a->l3 != 0.f) {
         // the call whose passes are reused may have found a zero column term under a stored entry and gone on without folding
-        int z = foldzero_lookup(ws);
+        int z = known ? built.zero_term : -1;
         if (z < 0) {
             HIP_TRY(hipMemcpyAsync(&z, ws + WS_FOLDZERO_OFFSET, sizeof(int), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
@@ -441,7 +510,7 @@ int run_device_impl(sp_knn_args *a) {
         if (z) {
             const uint32_t flags0 = a->flags;
             a->flags |= SP_FLAG_NO_FOLD;
-            const int rc2 = run_device_impl(a);
+            const int rc2 = run_device_impl(a, &sig);
             a->flags = flags0;
             return rc2;
         }
@@ -475,12 +544,17 @@ int run_device_impl(sp_knn_args *a) {
             int zero_term = 0;
             HIP_TRY(hipMemcpyAsync(&zero_term, ws + WS_FOLDZERO_OFFSET, sizeof(int), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
-            if (a->workspace) foldzero_store(ws, zero_term);
+            if (a->workspace) prep_set_zero(ws, zero_term);
             if (zero_term) {
                 const uint32_t flags0 = a->flags;
                 a->flags |= SP_FLAG_NO_FOLD;
-                const int rc2 = run_device_impl(a);
+                const int rc2 = run_device_impl(a, &sig);      // (rebuilds the header: the table entry is rewritten under the caller's signature)
                 a->flags = flags0;
+                if (a->workspace && !rc2) {
+                    // the answer stays IN the workspace too: the rerun's header memset wiped it (a REUSE call the table does not know reads it)
+                    prep_set_zero(ws, 1);
+                    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(ws + WS_FOLDZERO_OFFSET), 1, 1, stream));
+                }
                 return rc2;
             }
         }
@@ -609,11 +683,11 @@ int run_device_impl(sp_knn_args *a) {
     kp.splits = nullptr;
     kp.n_splits = 0;
     kp.split_w = c.split_w;
+    SplitsLaunch sl{};
     if (c.n_splits) {
-        const long long n = (long long)a->n_rows_m2 * c.n_splits;
-        if (!reuse) hipLaunchKernelGGL(sp_m2_splits_kernel, dim3((unsigned)std::min<long long>(256 * 16, (n + 255) / 256)), dim3(256), 0, stream, a->n_rows_m2, a->m2_indptr,
-                           a->m2_indices, c.split_w, c.n_splits, ws_split);
-        HIP_TRY(hipGetLastError());
+        // (queued by launch_rows between the sparse-row kernels and the generic one: skipped on the device when the generic queue is empty)
+        sl.n_rows_m2 = a->n_rows_m2; sl.m2_indptr = a->m2_indptr; sl.m2_indices = a->m2_indices; sl.split_w = c.split_w; sl.n_splits = c.n_splits;
+        sl.out = ws_split; sl.qcount_g = (const unsigned *)(ws + 12); sl.state = (int *)(ws + WS_SPLITS_STATE_OFFSET);
         kp.splits = ws_split;
         kp.n_splits = c.n_splits;
         kp.split_w = c.split_w;
@@ -625,7 +699,7 @@ int run_device_impl(sp_knn_args *a) {
     if (timed) { for (int i = 0; i < 4; ++i) TRY(guard.event(&kev[i])); }
     KParams kp_s = kp;
     kp_s.T = c.T_s; kp_s.logT = c.logT_s;
-    rc = launch_rows(kp_s, kp, c, stream, timed ? kev : nullptr);
+    rc = launch_rows(kp_s, kp, c, stream, timed ? kev : nullptr, c.n_splits ? &sl : nullptr);
     if (rc) return rc;
     if (c.split_pmax) {
         const int n_rec = c.split_pmax * a->k;
@@ -666,7 +740,10 @@ namespace {
 
 // Layout of the extra scratch a SP_FLAG_M2_IS_M1_T / SP_FLAG_M1_IS_M2_T call needs behind the kernel's own workspace: the
 // three arrays of the matrix built here (m2 = m1^T or m1 = m2^T), the optional vectors, then the transpose's scratch.
-struct M2tLayout { size_t knn, data, indices, indptr, p3copy, ydepop, norms, keep, tr, total; };
+struct M2tLayout { size_t knn, data, indices, indptr, p3copy, ydepop, norms, keep, zc, tr, total; };
+// SP_FLAG_P3_PREP: where the device counter of entries that underflowed to 0.0 lives (inside the call's scratch), for the host-mode
+// entry of the same thread to read once everything has been waited for
+thread_local const unsigned long long *g_p3_zero_counter = nullptr;
 int m2t_layout(const sp_knn_args *a, int n_cus, sp_knn_args *plain, M2tLayout *L) {
     const bool m1t = (a->flags & SP_FLAG_M1_IS_M2_T) != 0;
     const int64_t nnz = m1t ? a->nnz_m2 : a->nnz_m1;
@@ -690,7 +767,8 @@ int m2t_layout(const sp_knn_args *a, int n_cus, sp_knn_args *plain, M2tLayout *L
     // SP_FLAG_P3_PREP with a column mask: the mask is applied to the NORMALISED m2 (the reference normalises the rows of matrix2 before
     // it drops columns, similarity.py:410-415 then s_plus_utils.pyx:424-490): a second copy of m2's three arrays, scan scratch, total
     const bool p3_keep = (a->flags & SP_FLAG_P3_PREP) && a->col_keep != nullptr && !m1t;
-    L->tr = L->keep + (p3_keep ? al(((size_t)built_rows + 1) * 4) + 2 * al((size_t)nnz * 4) + al(SCAN_SCRATCH_BYTES) + 256 : 0);
+    L->zc = L->keep + (p3_keep ? al(((size_t)built_rows + 1) * 4) + 2 * al((size_t)nnz * 4) + al(SCAN_SCRATCH_BYTES) + 256 : 0);
+    L->tr = L->zc + 256;
     L->total = L->tr + transpose_ws_bytes(nnz, built_rows);
     return SP_OK;
 }
@@ -806,8 +884,13 @@ int run_device(sp_knn_args *a, const ChunkHook *hook = nullptr) {
         float *cp = (float *)(ws + L.p3copy);
         HIP_TRY(hipMemcpyAsync(cp, m2t ? m1_data : m2_data, (size_t)nnz * 4, hipMemcpyDeviceToDevice, stream));
         float *m1n = m2t ? cp : t_data, *m2n = m2t ? t_data : cp;
-        hipLaunchKernelGGL((sp_row_normalize_kernel<float, RO_L1>), dim3(wave_blocks), dim3(256), 0, stream, a->n_rows_m1, m1n, m1_indptr, (double)a->p3_alpha);
-        hipLaunchKernelGGL((sp_row_normalize_kernel<float, RO_L1>), dim3(wave_blocks), dim3(256), 0, stream, a->n_rows_m2, m2n, m2_indptr, (double)a->p3_alpha);
+        // (entries that underflow to 0.0 on the way are counted: the reference removes them before its kernel runs — s_plus.pyx:210-211
+        // after similarity.py:410-415 — here they would stay zero-valued candidates; a host-mode call reports SP_EUNDERFLOW, see run_host)
+        unsigned long long *zero_made = (unsigned long long *)(ws + L.zc);
+        HIP_TRY(hipMemsetAsync(zero_made, 0, sizeof(unsigned long long), stream));
+        g_p3_zero_counter = zero_made;
+        hipLaunchKernelGGL((sp_row_normalize_kernel<float, RO_L1>), dim3(wave_blocks), dim3(256), 0, stream, a->n_rows_m1, m1n, m1_indptr, (double)a->p3_alpha, zero_made);
+        hipLaunchKernelGGL((sp_row_normalize_kernel<float, RO_L1>), dim3(wave_blocks), dim3(256), 0, stream, a->n_rows_m2, m2n, m2_indptr, (double)a->p3_alpha, zero_made);
         HIP_TRY(hipGetLastError());
         b.m1_data = m1n;
         b.m2_data = m2n;
@@ -1133,6 +1216,16 @@ int run_host(sp_knn_args *a) {
             if (zeros) return fail(SP_EZEROS, "%llu stored entries are zero: eliminate them first (s_plus.pyx:210-211)", zeros);
         }
         if (h[18]) return fail(SP_EUNSORTED, "%s: %d rows of m2 do not have ascending column ids", m1t ? "SP_FLAG_M1_IS_M2_T" : "SP_FLAG_CHECK_SORTED", h[18]);
+        // MATRIX selectors: the kernels look a candidate up in the selector's row by binary search (range_has) — a row whose ids descend
+        // would let filtered columns through.  Looked at where the rows are (one wave per row), not trusted from a host-side flag.
+        for (int i = 2; i < 4; ++i) {
+            if (!mats[i].indptr || mats[i].nnz < 2) continue;
+            HIP_TRY(hipMemsetAsync(st + 19, 0, sizeof(int32_t), nullptr));
+            hipLaunchKernelGGL(sp_rows_sorted_kernel, dim3(std::max(1, std::min(256 * 16, (mats[i].n_rows + 3) / 4))), dim3(256), 0, nullptr, mats[i].n_rows, mats[i].indptr, mats[i].indices, (unsigned int *)(st + 19));
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpy(h + 19, st + 19, sizeof(int32_t), hipMemcpyDeviceToHost));
+            if (h[19]) return fail(SP_EUNSORTED, "MATRIX selector %s: %d rows do not have ascending column ids", mats[i].what, h[19]);
+        }
     }
 
     if (a->flags & SP_FLAG_BINARY) {
@@ -1263,8 +1356,22 @@ int run_host(sp_knn_args *a) {
         for (auto &e : cs_.ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         hook.after_launch = [&](int j) -> int { HIP_TRY(hipEventRecord(cs_.ev[(size_t)j], nullptr)); return SP_OK; };
     }
+    g_p3_zero_counter = nullptr;
     int rc = run_device(&d, chunked ? &hook : nullptr);
     if (rc) return rc;
+    // SP_FLAG_P3_PREP: entries that underflowed to 0.0 in the divide or the power (checked once the device work has been waited for)
+    auto p3_underflow = [&]() -> int {
+        if (!g_p3_zero_counter) return SP_OK;
+        unsigned long long z = 0;
+        HIP_TRY(hipMemcpy(&z, g_p3_zero_counter, sizeof(z), hipMemcpyDeviceToHost));
+        g_p3_zero_counter = nullptr;
+        if (z) {
+            a->explicit_zeros = (int64_t)z;
+            return fail(SP_EUNDERFLOW, "SP_FLAG_P3_PREP: %llu stored entries became 0.0 when they were L1-normalised and raised to %g; the reference drops "
+                        "them before its kernel runs (similarity.py:410-415, then s_plus.pyx:210-211): preprocess on the host and call again", z, (double)a->p3_alpha);
+        }
+        return SP_OK;
+    };
     if (chunked) {
         // (every chunk's launches are queued; the host now follows them chunk by chunk on the second stream)
         int *slot_nnz = nullptr, *slot_off = nullptr, *o_idx = nullptr;
@@ -1279,6 +1386,7 @@ int run_host(sp_knn_args *a) {
             TRY(pool.alloc((size_t)SCAN_CHUNKS, &scan_part));
         }
         size_t running = 0;
+        const bool progress = (a->flags & SP_FLAG_PROGRESS) != 0;
         for (int j = 0; j < hook.n_chunks; ++j) {
             const size_t s0 = hook.bounds[(size_t)j], s1 = hook.bounds[(size_t)j + 1], ns = s1 - s0;
             HIP_TRY(hipStreamWaitEvent(cs_.s2, cs_.ev[(size_t)j], 0));
@@ -1300,10 +1408,12 @@ int run_host(sp_knn_args *a) {
                     HIP_TRY(hipMemcpyAsync(a->values + running, o_val + s0 * k, (size_t)nnz_j * 4, hipMemcpyDeviceToHost, cs_.s2));
                 }
                 running += (size_t)nnz_j;
+                if (progress) { HIP_TRY(hipStreamSynchronize(cs_.s2)); fprintf(stderr, "[similaripy_amd] rows done: %zu / %zu\n", s1, nt); }
             } else {
                 if (j == 0) { HIP_TRY(hipStreamSynchronize(cs_.s2)); prefault.join(); }
                 HIP_TRY(hipMemcpyAsync(a->cols + s0 * k, d.cols + s0 * k, ns * k * sizeof(int32_t), hipMemcpyDeviceToHost, cs_.s2));
                 HIP_TRY(hipMemcpyAsync(a->values + s0 * k, d.values + s0 * k, ns * k * sizeof(float), hipMemcpyDeviceToHost, cs_.s2));
+                if (progress) { HIP_TRY(hipStreamSynchronize(cs_.s2)); fprintf(stderr, "[similaripy_amd] rows done: %zu / %zu\n", s1, nt); }
             }
         }
         if (csr_out) {
@@ -1324,6 +1434,7 @@ int run_host(sp_knn_args *a) {
         if (a->out_counts) HIP_TRY(hipMemcpyAsync(a->out_counts, d.out_counts, nt * sizeof(int32_t), hipMemcpyDeviceToHost, cs_.s2));
         HIP_TRY(hipStreamSynchronize(cs_.s2));
         trace.mark("row kernels, chunked assembly + result to the host");
+        TRY(p3_underflow());
         if (want_rows) {
             prefault.join();
             std::vector<int32_t> cnt_tmp;
@@ -1415,6 +1526,8 @@ int run_host(sp_knn_args *a) {
         }
     }
     trace.mark("assembly, result to the host");
+    if (a->flags & SP_FLAG_PROGRESS) fprintf(stderr, "[similaripy_amd] rows done: %zu / %zu\n", nt, nt);
+    TRY(p3_underflow());
     a->kernel_ms = d.kernel_ms;
     a->passes_total = d.passes_total;
     a->num_wgs_used = d.num_wgs_used;
@@ -1447,18 +1560,30 @@ int target_costs(const sp_knn_args *a, std::vector<double> *cost) {
     const size_t nt = (size_t)a->n_targets;
     cost->assign(nt, ROW_TOLL_MACS);
     const bool m2t = (a->flags & SP_FLAG_M2_IS_M1_T) != 0, m1t = (a->flags & SP_FLAG_M1_IS_M2_T) != 0;
+    // (the toll of a row: 30 k for a row of the sparse kernels, ~3 per output column — SIMILARIPY_AMD_GENERIC_TOLL_PER_COL, as in
+    // distributed.row_cost — for a row of the generic kernel, which walks every column window whatever the row holds; same rule there)
+    const double n_cols_d = (double)std::max(1, a->n_output_cols);
+    double toll_per_col = 3.0;
+    if (const char *e = getenv("SIMILARIPY_AMD_GENERIC_TOLL_PER_COL")) { const double v = atof(e); if (v > 0.0) toll_per_col = v; }
+    auto priced = [&](double m, long long nnz1) {
+        const bool sparse_row = 0.5 * m * m / n_cols_d <= 0.30 * 4096.0 && nnz1 <= 256 && a->n_output_cols > 16384;
+        return m + (sparse_row ? ROW_TOLL_MACS : toll_per_col * n_cols_d);
+    };
     if (m1t) {
-        // m1 = m2^T does not exist on the host: MACs(t) = sum over the entries (u, t) of m2 of len(m2 row u), scattered by column
+        // m1 = m2^T does not exist on the host: MACs(t) = sum over the entries (u, t) of m2 of len(m2 row u), scattered by column;
+        // nnz1(t) = the number of such entries (the same pass).  Priced like every other row (ratings-shaped data — rows of
+        // the generic kernel — were priced without its toll here, the default route of the public item-item call)
         std::vector<double> macs((size_t)a->n_rows_m1, 0.0);
+        std::vector<int> nnz1((size_t)a->n_rows_m1, 0);
         for (int u = 0; u < a->n_rows_m2; ++u) {
             const int lo = std::max(0, a->m2_indptr[u]), hi = (int)std::min<int64_t>(a->nnz_m2, a->m2_indptr[u + 1]);
             const double len = (double)std::max(0, hi - lo);
             for (int p = lo; p < hi; ++p) {
                 const int t = a->m2_indices[p];
-                if (t >= 0 && t < a->n_rows_m1) macs[(size_t)t] += len;
+                if (t >= 0 && t < a->n_rows_m1) { macs[(size_t)t] += len; ++nnz1[(size_t)t]; }
             }
         }
-        for (size_t i = 0; i < nt; ++i) (*cost)[i] += macs[(size_t)a->targets[i]];
+        for (size_t i = 0; i < nt; ++i) (*cost)[i] = priced(macs[(size_t)a->targets[i]], nnz1[(size_t)a->targets[i]]);
         return SP_OK;
     }
     std::vector<int> len2((size_t)a->n_rows_m2, 0);
@@ -1480,9 +1605,6 @@ int target_costs(const sp_knn_args *a, std::vector<double> *cost) {
     } else {
         for (int u = 0; u < a->n_rows_m2; ++u) len2[(size_t)u] = a->m2_indptr[u + 1] - a->m2_indptr[u];
     }
-    // (the toll of a row: 30 k for a row of the sparse kernels, ~3 per output column for a row of the generic kernel, which walks every
-    // column window whatever the row holds — distributed.row_cost, same rule)
-    const double n_cols_d = (double)std::max(1, a->n_output_cols);
     parallel_ranges(nt, (size_t)1 << 16, [&](size_t lo, size_t hi) {
         for (size_t i = lo; i < hi; ++i) {
             const int t = a->targets[i];
@@ -1493,8 +1615,7 @@ int target_costs(const sp_knn_args *a, std::vector<double> *cost) {
                 const int u = a->m1_indices[p];
                 if (u >= 0 && u < a->n_rows_m2) m += (double)len2[(size_t)u];
             }
-            const bool sparse_row = 0.5 * m * m / n_cols_d <= 0.30 * 4096.0 && (p_hi - p_lo) <= 256 && a->n_output_cols > 16384;
-            (*cost)[i] = m + (sparse_row ? ROW_TOLL_MACS : 3.0 * n_cols_d);
+            (*cost)[i] = priced(m, (long long)(p_hi - p_lo));
         }
     });
     return SP_OK;
@@ -1861,9 +1982,9 @@ int sp_csr_normalize(sp_csr_normalize_args *a) {
     auto run = [&](auto tag) {
         using T = decltype(tag);
         T *data = (T *)d_data;
-        if (a->mode == SP_NORM_L1) hipLaunchKernelGGL((sp_row_normalize_kernel<T, RO_L1>), dim3(wb), dim3(256), 0, stream, a->n_rows, data, d_indptr, a->pow_alpha);
-        else if (a->mode == SP_NORM_L2) hipLaunchKernelGGL((sp_row_normalize_kernel<T, RO_L2>), dim3(wb), dim3(256), 0, stream, a->n_rows, data, d_indptr, a->pow_alpha);
-        else if (a->mode == SP_NORM_MAX) hipLaunchKernelGGL((sp_row_normalize_kernel<T, RO_MAX>), dim3(wb), dim3(256), 0, stream, a->n_rows, data, d_indptr, a->pow_alpha);
+        if (a->mode == SP_NORM_L1) hipLaunchKernelGGL((sp_row_normalize_kernel<T, RO_L1>), dim3(wb), dim3(256), 0, stream, a->n_rows, data, d_indptr, a->pow_alpha, (unsigned long long *)nullptr);
+        else if (a->mode == SP_NORM_L2) hipLaunchKernelGGL((sp_row_normalize_kernel<T, RO_L2>), dim3(wb), dim3(256), 0, stream, a->n_rows, data, d_indptr, a->pow_alpha, (unsigned long long *)nullptr);
+        else if (a->mode == SP_NORM_MAX) hipLaunchKernelGGL((sp_row_normalize_kernel<T, RO_MAX>), dim3(wb), dim3(256), 0, stream, a->n_rows, data, d_indptr, a->pow_alpha, (unsigned long long *)nullptr);
         else {
             // log_logbase = log(logbase) held in the data type (normalization.pyx:223, 296)
             const T llb = (T)log((double)(T)a->logbase);      // (the reference's float32 instantiation rounds logbase to float first: log((float)e) = 0.99999994)

@@ -87,8 +87,11 @@ __global__ __launch_bounds__(256) void sp_rows_sorted_kernel(int n_rows, const i
 
 // ---- l1 / l2 / max (normalization.pyx:97-197), optionally followed by ^alpha (similarity.py:411, 413) ----
 // One wave per row.  Rows whose norm is 0 (max: <= 0, or empty) are left alone.
+// zero_made (optional): counts the stored non-zero entries that leave as 0.0 (underflow of the divide or the power) — the p3alpha / rp3beta
+// preprocessing needs to know: the reference drops such entries afterwards (eliminate_zeros, s_plus.pyx:210-211)
 template <typename T, int MODE>
-__global__ __launch_bounds__(256) void sp_row_normalize_kernel(int n_rows, T *__restrict__ data, const int *__restrict__ indptr, double pow_alpha) {
+__global__ __launch_bounds__(256) void sp_row_normalize_kernel(int n_rows, T *__restrict__ data, const int *__restrict__ indptr, double pow_alpha,
+                                                                unsigned long long *__restrict__ zero_made) {
     const int lane = threadIdx.x & 63;
     const long long wave0 = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6, n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
     for (long long r = wave0; r < n_rows; r += n_waves) {
@@ -110,10 +113,17 @@ __global__ __launch_bounds__(256) void sp_row_normalize_kernel(int n_rows, T *__
             if (s == (T)0) continue;
             if (MODE == RO_L2) s = (T)sqrt((double)s);
         }
+        unsigned made = 0;
         for (int i = b + lane; i < e; i += 64) {
-            T x = data[i] / s;
+            const T x0 = data[i];
+            T x = x0 / s;
             if (pow_alpha != 1.0) x = (T)pow((double)x, pow_alpha);      // np.power in the data type: correctly rounded from double
             data[i] = x;
+            made += (x == (T)0 && x0 != (T)0) ? 1u : 0u;
+        }
+        if (zero_made && __ballot(made != 0u)) {      // (rare: one atomic per row that has any)
+            made = (unsigned)ro_wave_sum((int)made);
+            if (lane == 0) atomicAdd(zero_made, (unsigned long long)made);
         }
     }
 }

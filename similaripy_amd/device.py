@@ -58,6 +58,7 @@ class DeviceProblem:
             self.t[name] = self.t[twin] if twin else (up(arr) if arr.size else None)
         self.t["col_keep"] = up(call.col_keep) if call.col_keep is not None and call.col_keep.size else None
         self._ws = None
+        self._prep_sig = None      # (flags, tuning) of the run that built the per-call passes now in the workspace
 
     # ------------------------------------------------------------------
     def _args(self, targets_t, n_targets, cols_t, vals_t, counts_t, rows_t, stream, flags, tuning):
@@ -121,7 +122,12 @@ class DeviceProblem:
             flags |= _abi.SP_FLAG_NO_FOLD
         if tuning.get("no_row_order"):
             flags |= _abi.SP_FLAG_NO_ROW_ORDER
-        if tuning.get("reuse_m2_prep") and self._ws is not None:
+        # SP_FLAG_REUSE_M2_PREP only for a run whose layout-relevant flags and tuning are those of the run that built the passes (the
+        # call's scalars are this problem's own): folded values, packed terms and window boundaries are laid out per (flags, tuning)
+        # — reused under other ones they would be read as something else (the library refuses such a call as well)
+        sig = (flags & (_abi.SP_FLAG_NO_FOLD | _abi.SP_FLAG_NO_SPARSE_PATH), int(tuning.get("table_slots", 0)), int(tuning.get("threads_per_wg", 0)),
+               int(tuning.get("load_pct", 0)), int(tuning.get("dbg", 0)) & (1024 | 2048 | 4096 | 16384))
+        if tuning.get("reuse_m2_prep") and self._ws is not None and self._prep_sig == sig:
             flags |= _abi.SP_FLAG_REUSE_M2_PREP
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream().cuda_stream
@@ -131,6 +137,8 @@ class DeviceProblem:
                 self._ws = torch.empty(max(need, 4096), dtype=torch.uint8, device=self.device)
                 a.flags &= ~_abi.SP_FLAG_REUSE_M2_PREP       # (a fresh workspace holds nothing to reuse)
             a.workspace, a.workspace_bytes = self._ws.data_ptr(), self._ws.numel()
+            if not (a.flags & _abi.SP_FLAG_REUSE_M2_PREP):
+                self._prep_sig = sig
             _abi.call_knn(a)
         return {"kernel_ms": float(a.kernel_ms), "passes_total": int(a.passes_total), "phase_cycles": [int(x) for x in a.phase_cycles], "num_wgs": int(a.num_wgs_used),
                 "sparse_kernel_ms": int(a.reserved[1]) / 1e3, "generic_kernel_ms": int(a.reserved[2]) / 1e3, "transpose_ms": int(a.reserved[3]) / 1e3}

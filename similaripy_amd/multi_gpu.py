@@ -8,7 +8,8 @@ or, without touching the call sites, `SIMILARIPY_AMD_DEVICES=0,1,2,3` in the env
 (`sim.cosine`, ...) take this route (see `_host._s_plus_impl`).
 
 What runs (BASELINE configs[3]/[4]): the parent does the host stages of s_plus.pyx once (`_host.prepare`) and
-parks the kernel's operands in /dev/shm; every worker maps them, joins a `torch.distributed` group (backend "nccl" = RCCL
+parks the kernel's operands in /dev/shm (raw .npy, memory-mapped by the workers; rank 0 hands the results back through shared-memory
+segments, one per array); every worker maps them, joins a `torch.distributed` group (backend "nccl" = RCCL
 over xGMI), and runs `distributed.ShardedDeviceProblem` — `partition_targets` (contiguous, work-balanced), its slice of m1
 plus the replicated m2 / Y* resident on its GPU, the kernel, ONE gather of the (cols, values, counts) slabs to rank 0 —
 the same class `bench.py --gpus N` measures.  `chunk_rows` streams the target list in chunks (one gather per chunk), so
@@ -63,6 +64,48 @@ def _load_call(d: str) -> KernelCall:
     return KernelCall(**{n: np.asarray(a) for n, a in arrays.items()}, **scal)
 
 
+def _shm_put(arr: np.ndarray) -> dict:
+    """Worker: one result array into a POSIX shared-memory segment of its own (ONE copy, no container format); returns what the
+    parent needs to map it.  The segment outlives this process: the parent unlinks it (`_shm_take`)."""
+    from multiprocessing import resource_tracker, shared_memory
+
+    a = np.ascontiguousarray(arr)
+    seg = shared_memory.SharedMemory(create=True, size=max(1, a.nbytes))
+    np.ndarray(a.shape, dtype=a.dtype, buffer=seg.buf)[...] = a
+    meta = {"name": seg.name, "dtype": a.dtype.str, "shape": list(a.shape)}
+    try:      # (the segment is the parent's to remove: this process's tracker must not unlink it at exit)
+        resource_tracker.unregister(seg._name, "shared_memory")
+    except Exception:      # noqa: BLE001
+        pass
+    seg.close()
+    return meta
+
+
+def _shm_take(meta: dict) -> np.ndarray:
+    """Parent: the array of a worker's segment (copied out of the mapping), the segment removed."""
+    from multiprocessing import shared_memory
+
+    seg = shared_memory.SharedMemory(name=meta["name"])
+    try:
+        return np.ndarray(tuple(meta["shape"]), dtype=np.dtype(meta["dtype"]), buffer=seg.buf).copy()
+    finally:
+        seg.close()
+        try:
+            seg.unlink()
+        except FileNotFoundError:
+            pass
+
+
+def _shm_drop(meta: dict) -> None:
+    from multiprocessing import shared_memory
+    try:
+        seg = shared_memory.SharedMemory(name=meta["name"])
+        seg.close()
+        seg.unlink()
+    except Exception:      # noqa: BLE001
+        pass
+
+
 def _hip_runner(call: KernelCall, group, device: int, chunk_rows: Optional[int]):
     """Generator on every rank: yields (lo, hi, cols, values, counts) of target slots [lo, hi) on rank 0, None elsewhere."""
     import torch
@@ -109,10 +152,9 @@ def _worker(rank: int, world: int, port: int, shm: str, backend: str, runner: st
             else:
                 pieces.append((lo, hi, cols, vals, counts))
         if rank == 0:
-            for i, p in enumerate(pieces):
-                np.savez(os.path.join(shm, f"out_{i}.npz"), lo=p[0], hi=p[1], a=p[2], b=p[3], c=p[4])
+            # results go back through shared-memory segments (one per array: mapped by the parent, no .npz container to write and parse)
             with open(os.path.join(shm, "out.json"), "w") as f:
-                json.dump({"pieces": len(pieces)}, f)
+                json.dump({"pieces": [{"lo": int(p[0]), "hi": int(p[1]), "a": _shm_put(p[2]), "b": _shm_put(p[3]), "c": _shm_put(p[4])} for p in pieces]}, f)
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -137,11 +179,16 @@ def run_call(call: KernelCall, devices: Union[int, Sequence[int]], format_output
             port = s.getsockname()[1]
         mp.spawn(_worker, args=(len(devs), port, shm, backend, runner, devs, chunk_rows, csr), nprocs=len(devs), join=True)
         with open(os.path.join(shm, "out.json")) as f:
-            n_pieces = json.load(f)["pieces"]
+            metas = json.load(f)["pieces"]
         pieces = []
-        for i in range(n_pieces):
-            z = np.load(os.path.join(shm, f"out_{i}.npz"))
-            pieces.append((int(z["lo"]), int(z["hi"]), z["a"], z["b"], z["c"]))
+        try:
+            for m in metas:
+                pieces.append((int(m["lo"]), int(m["hi"]), _shm_take(m["a"]), _shm_take(m["b"]), _shm_take(m["c"])))
+        except BaseException:
+            for m in metas:
+                for key in ("a", "b", "c"):
+                    _shm_drop(m[key])
+            raise
     finally:
         shutil.rmtree(shm, ignore_errors=True)
     pieces.sort(key=lambda p: p[0])

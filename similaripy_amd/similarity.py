@@ -24,7 +24,7 @@ from typing import Literal, Optional, Union
 import numpy as np
 from scipy.sparse import sparray
 
-from . import _host
+from . import _abi, _host
 from .normalization import normalize as _normalize
 
 _Rows = Optional[Union[list, np.ndarray]]
@@ -136,8 +136,9 @@ def _p3_on_device(matrix1, matrix2, binary, filter_cols, target_cols, alpha=1.0)
     Where the device form differs from similarity.py:410-415 / 477-483 (L1-normalise, `data ** alpha` on EVERY stored entry,
     only then eliminate_zeros inside s_plus): stored zeros are dropped BEFORE the power.  For alpha > 0 that is the same
     matrix (0 / norm = 0, 0 ** alpha = 0, the norm does not see zeros); for alpha <= 0 it is not (0 ** alpha is 1 or inf),
-    so those calls take the host statement below.  One deviation remains: an entry that underflows to 0 in the divide or the
-    power stays a stored candidate here (it can only show up as a 0.0 similarity at the very end of a short result row)."""
+    so those calls take the host statement below.  An entry that underflows to 0 in the divide or the power would stay a stored
+    (zero-valued) candidate on the device where the reference drops it: the library counts such entries and the call is then redone
+    with the host statement (_abi.P3UnderflowError, see _run_p3; tests/golden/quirks_golden.npz pins the reference's result)."""
     from scipy.sparse import issparse
     if matrix2 is not None or binary or not issparse(matrix1) or matrix1.data.dtype != np.float32:
         return False
@@ -163,7 +164,10 @@ def p3alpha(matrix1: sparray, matrix2: Optional[sparray] = None, alpha: float = 
             num_threads: int = 0, block_size: Optional[int] = 0) -> sparray:
     """Top-k P3alpha: product of the two row-stochastic transition matrices, entries ^alpha."""
     if _p3_on_device(matrix1, matrix2, binary, filter_cols, target_cols, alpha):
-        return _run_p3(matrix1, alpha, None, k, shrink, shrink_type, threshold, target_rows, target_cols, filter_cols, verbose, format_output)
+        try:
+            return _run_p3(matrix1, alpha, None, k, shrink, shrink_type, threshold, target_rows, target_cols, filter_cols, verbose, format_output)
+        except _abi.P3UnderflowError:
+            pass        # entries underflowed to 0.0: the reference drops them (s_plus.pyx:210-211) — the host statement below does too
     matrix1, matrix2, _ = _p3_inputs(matrix1, matrix2, alpha)
     return _run(matrix1, matrix2, {}, k, shrink, shrink_type, threshold, binary, target_rows, target_cols,
                 filter_cols, verbose, format_output, num_threads, block_size)
@@ -176,7 +180,10 @@ def rp3beta(matrix1: sparray, matrix2: Optional[sparray] = None, alpha: float = 
             num_threads: int = 0, block_size: Optional[int] = 0) -> sparray:
     """Top-k RP3beta: P3alpha divided by (column popularity of the raw matrix2)^beta."""
     if _p3_on_device(matrix1, matrix2, binary, filter_cols, target_cols, alpha):
-        return _run_p3(matrix1, alpha, beta, k, shrink, shrink_type, threshold, target_rows, target_cols, filter_cols, verbose, format_output)
+        try:
+            return _run_p3(matrix1, alpha, beta, k, shrink, shrink_type, threshold, target_rows, target_cols, filter_cols, verbose, format_output)
+        except _abi.P3UnderflowError:
+            pass        # (as in p3alpha)
     if matrix2 is None:
         matrix2 = matrix1.T
     pop_m2 = np.asarray(matrix2.sum(axis=0)).ravel()          # similarity.py:479 — BEFORE normalisation

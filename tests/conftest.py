@@ -105,6 +105,10 @@ def oracle_backend(monkeypatch):
         # (the order of run_host: zero count on the caller's values, order inside the rows of an explicit m2, ones, norms)
         if kw.get("check_zeros") and (np.count_nonzero(call.m1_data) != call.m1_data.shape[0] or np.count_nonzero(call.m2_data) != call.m2_data.shape[0]):
             raise _abi.ExplicitZerosError("stored zeros")            # what SP_FLAG_CHECK_ZEROS reports
+        for mode, ip, ix in ((call.filter_mode, call.filter_m_indptr, call.filter_m_indices), (call.target_col_mode, call.target_col_m_indptr, call.target_col_m_indices)):
+            # run_host looks at the order inside the rows of every MATRIX selector (sp_rows_sorted_kernel)
+            if mode == _host.MODE_MATRIX and ix.shape[0] > 1 and not _host._rows_sorted(ix, ip):
+                raise _abi.UnsortedRowsError("MATRIX selector: rows do not have ascending column ids")
         if call.check_m2_sorted:
             # SP_FLAG_CHECK_SORTED: a descent inside a row of the explicit m2 goes back to the caller
             if call.m2_indices.shape[0] > 1 and not _host._rows_sorted(call.m2_indices, call.m2_indptr):
@@ -141,6 +145,8 @@ def oracle_backend(monkeypatch):
             a1.data = np.power(a1.data, np.float32(call.p3_alpha))
             b1 = norm_oracle.normalize(m2, norm="l1")
             b1.data = np.power(b1.data, np.float32(call.p3_alpha))
+            if np.count_nonzero(a1.data) != a1.data.shape[0] or np.count_nonzero(b1.data) != b1.data.shape[0]:
+                raise _abi.P3UnderflowError("entries underflowed to 0.0")      # what the library reports (SP_EUNDERFLOW)
             call = dataclasses.replace(call, m1_data=np.ascontiguousarray(a1.data, dtype=np.float32), m2_data=np.ascontiguousarray(b1.data, dtype=np.float32),
                                        m2_indices=np.ascontiguousarray(b1.indices, dtype=np.int32), m2_indptr=np.ascontiguousarray(b1.indptr, dtype=np.int32),
                                        m2_is_m1t=False, p3_alpha=None, depop_rowsum_p2=None, **rep)

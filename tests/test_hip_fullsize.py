@@ -1,15 +1,18 @@
 """GPU tier: every BASELINE.json config at its defining shape.
 
   configs[0]  sim.cosine on sps.random 10k x 20k d=0.01 k=50            every row vs the oracle
-  configs[1]  cosine 1M x 100k, 64 nnz/row, k=100                        properties over all rows + 300 rows vs the oracle
-  configs[2]  s_plus(l1=.5, l2=.5, shrink=10) on the same matrix         300 rows vs the oracle, all rows on the sparse kernel
+  configs[1]  cosine 1M x 100k, 64 nnz/row, k=100                        properties over all rows + 20 000 rows vs the oracle
+  configs[2]  s_plus(l1=.5, l2=.5, shrink=10) on the same matrix         20 000 rows vs the oracle, all rows on the sparse kernel
   configs[3]  p3alpha + rp3beta, MovieLens-32M-shaped URM.T, k=200       through the public wrappers; 320 rows (the 20 heaviest
                                                                          included) vs the oracle
-  configs[4]  dot_product(urm, W.T, filter_cols=urm), 1M users, k=100    300 rows vs the oracle + "nothing seen is recommended"
+  configs[4]  dot_product(urm, W.T, filter_cols=urm), 1M users, k=100    20 000 rows vs the oracle + "nothing seen is recommended"
                                                                          over all rows (one GPU's slice of the 10M-user job)
 
 The oracle cannot finish these sizes in seconds, so full results are checked through size-independent properties and a
-sample of rows is compared with the oracle exactly (tie-aware, 1e-5 relative; long float32 sums: see `_rtol_for`)."""
+sample of rows is compared with the oracle exactly (tie-aware, 1e-5 relative; long float32 sums: see `_check_against_float64`).
+Samples of configs[1], [2], [4]: 18 000 random rows + the 2 000 LIGHTEST rows (fewest MACs) — rows are queued heaviest-first
+(sp_row_order_kernel), so those are the tail of the work-ordered queue, where the persistent workgroups run dry (VERDICT r4 #5a;
+the oracle does ~37 k rows/s on the box's cores)."""
 from __future__ import annotations
 
 import copy
@@ -31,14 +34,32 @@ from oracle.norm_oracle import normalize               # noqa: E402  (NumPy stat
 pytestmark = pytest.mark.gpu
 
 RTOL, ATOL = 1e-5, 1e-7       # north_star: float32 values within 1e-5 relative
+N_SAMPLE, N_TAIL = 20_000, 2_000
 
 
-def _check_against_float64(got, want, exact, k, what):
+def _macs_per_row(m1, m2_indptr):
+    per = np.diff(m2_indptr).astype(np.int64)[m1.indices]
+    csum = np.concatenate(([0], np.cumsum(per)))
+    return csum[m1.indptr[1:]] - csum[m1.indptr[:-1]]
+
+
+def _sample_with_queue_tail(macs, seed):
+    """N_SAMPLE distinct rows: the N_TAIL lightest (the end of the work-ordered queue) + random ones."""
+    n = macs.shape[0]
+    tail = np.argsort(macs, kind="stable")[:N_TAIL]
+    rnd = np.random.default_rng(seed).choice(n, N_SAMPLE, replace=False)
+    return np.unique(np.concatenate((tail, rnd)))[:N_SAMPLE + N_TAIL].astype(np.int32)
+
+
+def _check_against_float64(got, want, exact, k, what, macs=None, heavy=None):
     """Rows whose values are float32 sums of up to 10^5 products (a popular item): the HIP kernel adds them in another order than
     the reference, so the two float32 results differ by more than 1e-5 of each other WITHOUT either being wrong.  The judge here is
     the float64 value of every entry (`exact[i]`: a dense row): the HIP value may be no further from it than 1e-5 relative or
     twice the reference port's own worst error in that row, whichever is larger — no tolerance formula.  Column sets: a column
-    on one side only must sit on the k-th place within the same margin (both selections are exact on their own float32 values)."""
+    on one side only must sit on the k-th place within the same margin (both selections are exact on their own float32 values).
+    Rows of at most 10^6 MACs get north_star's plain bar: HIP within 1e-5 relative of the float64 value AND of the reference.
+    Returns the observed maxima per row class (written to profiles/ by the caller: VERDICT r4 weak #2 — "how far from 1e-5")."""
+    stats = {c: {"rows": 0, "hip_vs_f64": 0.0, "ref_vs_f64": 0.0, "hip_vs_ref": 0.0, "set_diff_rows": 0} for c in ("heavy", "light_le_1e6_macs", "other")}
     for i, ((gc, gv), (wc, wv)) in enumerate(zip(got, want)):
         assert gc.shape[0] == wc.shape[0], f"{what}: slot {i}: kept {gc.shape[0]} entries, expected {wc.shape[0]}"
         if gc.shape[0] == 0:
@@ -47,14 +68,29 @@ def _check_against_float64(got, want, exact, k, what):
         ref_err = np.abs(wv.astype(np.float64) - e[wc]) / np.abs(e[wc])
         hip_err = np.abs(gv.astype(np.float64) - e[gc]) / np.abs(e[gc])
         margin = max(RTOL, 2.0 * float(ref_err.max()))
+        light = macs is not None and macs[i] <= 1_000_000
+        cls = "heavy" if (heavy is not None and heavy[i]) else ("light_le_1e6_macs" if light else "other")
+        st = stats[cls]
+        st["rows"] += 1
+        st["hip_vs_f64"] = max(st["hip_vs_f64"], float(hip_err.max()))
+        st["ref_vs_f64"] = max(st["ref_vs_f64"], float(ref_err.max()))
+        _, gi, wi = np.intersect1d(gc, wc, assume_unique=True, return_indices=True)
+        if gi.size:
+            st["hip_vs_ref"] = max(st["hip_vs_ref"], float(np.max(np.abs(gv[gi].astype(np.float64) - wv[wi]) / np.abs(wv[wi].astype(np.float64)))))
+        if light:
+            assert hip_err.max() <= RTOL, f"{what}: slot {i} ({macs[i]} MACs): HIP values up to {hip_err.max():.2e} from the float64 value (bar: 1e-5)"
+            if gi.size:
+                np.testing.assert_allclose(gv[gi], wv[wi], rtol=RTOL, atol=ATOL, err_msg=f"{what}: slot {i} ({macs[i]} MACs) vs the reference")
         assert hip_err.max() <= margin, (f"{what}: slot {i}: HIP values up to {hip_err.max():.2e} from the float64 value, the reference port "
                                          f"{ref_err.max():.2e}")
         g_only, w_only = np.setdiff1d(gc, wc), np.setdiff1d(wc, gc)
         if g_only.size:
+            st["set_diff_rows"] += 1
             assert gc.shape[0] == k, f"{what}: slot {i}: different columns although fewer than k were kept"
             kth = min(e[gc].min(), e[wc].min())                         # the float64 value at the k-th place
             for c in np.concatenate((g_only, w_only)):
                 assert abs(e[c] - kth) <= 4.0 * margin * abs(kth), f"{what}: slot {i}: column {c} (value {e[c]}) is not on the k-th place tie ({kth})"
+    return stats
 
 
 def _slots_from_csr(res: sp.csr_array, rows):
@@ -154,7 +190,8 @@ def test_config1_full_size_properties(c2):
 def test_config1_sample_vs_oracle(c2):
     m, call, rows, cols, vals, counts, info = c2
     k = 100
-    sample = np.sort(np.random.default_rng(1).choice(1_000_000, 300, replace=False)).astype(np.int32)
+    sample = _sample_with_queue_tail(_macs_per_row(m, call.m2_indptr), 1)
+    assert sample.shape[0] >= N_SAMPLE
     want = _oracle_slots(call, sample)
     got = _slots_from_flat(cols.ravel(), vals.ravel(), counts, k, sample)
     so.compare_topk(got, want, k, rtol=RTOL, atol=ATOL, what="C2 sample")
@@ -179,7 +216,8 @@ def test_config2_splus_hybrid_full_size(c2_matrix):
     self_pos = (c2d == np.arange(n, dtype=np.int32)[:, None])
     assert self_pos.sum(axis=1).min() == 1
     np.testing.assert_allclose(v2d[self_pos], sq / (sq + np.float32(10.0)), rtol=2e-5)
-    sample = np.sort(np.random.default_rng(2).choice(n, 300, replace=False)).astype(np.int32)
+    sample = _sample_with_queue_tail(_macs_per_row(m, call.m2_indptr), 2)
+    assert sample.shape[0] >= N_SAMPLE
     want = _oracle_slots(call, sample)
     got = _slots_from_flat(cols, vals, counts, k, sample)
     so.compare_topk(got, want, k, rtol=RTOL, atol=ATOL, what="C3 sample")
@@ -237,7 +275,19 @@ def test_config3_p3_item_item_public_wrappers(c4, name):
     exact = (sp.csr_array(a, dtype=np.float64)[sample] @ sp.csr_array(b, dtype=np.float64)).toarray()
     if name == "rp3beta":
         exact = exact / (call.Xdepop.astype(np.float64)[sample, None] * call.Ydepop.astype(np.float64)[None, :])
-    _check_against_float64(got, want, exact, k, f"C4 {name}")
+    heavy_set = set(np.argsort(-macs)[:20].tolist())
+    stats = _check_against_float64(got, want, exact, k, f"C4 {name}", macs=macs[sample], heavy=[int(t) in heavy_set for t in sample])
+    # the observed maxima, for profiles/r05_c4_value_errors.txt (the GPU box merges gpurun_out/ back)
+    out_dir = ROOT / "gpurun_out"
+    out_dir.mkdir(exist_ok=True)
+    with open(out_dir / f"c4_value_errors_{name}.txt", "w") as f:
+        f.write(f"configs[3] {name}, MovieLens-32M-SHAPED stand-in URM (workloads.movielens_like_urm, seed 0: no network for the real file), k={k}, "
+                f"{len(sample)} sampled rows; relative errors of kept values, maxima per row class\n")
+        f.write("class                rows  HIP vs float64   reference vs float64   HIP vs reference   rows whose column sets differ (k-th place ties)\n")
+        for cls, st in stats.items():
+            f.write(f"{cls:20s} {st['rows']:4d}  {st['hip_vs_f64']:.3e}        {st['ref_vs_f64']:.3e}              {st['hip_vs_ref']:.3e}          {st['set_diff_rows']}\n")
+        f.write("bar: rows of <= 1e6 MACs: HIP within 1e-5 of the float64 value and of the reference (asserted); heavier rows: HIP no further from the "
+                "float64 value than max(1e-5, 2 x the reference's own worst error in that row)\n")
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -261,7 +311,8 @@ def test_config4_user_scoring_with_seen_filter():
     # scores of non-negative data are positive and sorted sets are duplicate-free (spot check)
     assert res.data.min() > 0
     call = _host.prepare(urm, Wt, k=k, filter_cols=urm)
-    sample = np.sort(np.random.default_rng(5).choice(n_users, 300, replace=False)).astype(np.int32)
+    sample = _sample_with_queue_tail(_macs_per_row(urm, Wt.indptr), 5)
+    assert sample.shape[0] >= N_SAMPLE
     want = _oracle_slots(call, sample, drop_zeros=True)
     got = _slots_from_csr(res, sample)
     so.compare_topk(got, want, k, rtol=RTOL, atol=ATOL, what="C5 sample")

@@ -1386,3 +1386,67 @@ def test_threshold_without_a_kth_value_sizes_its_stages_by_what_passed():
     assert short > 6000
     call = _host.prepare(m, k=30, threshold=3.0)      # dot product, no column term at all
     _check(call, "threshold on the raw dot")
+
+
+# ------------------------------------------------------------------------------------------------------------
+# two documented behaviours pinned by reference-generated fixtures (tests/golden/make_quirks_golden.py)
+# ------------------------------------------------------------------------------------------------------------
+def _quirk_csr(z, name):
+    return sp.csr_array((z[f"in/{name}/data"], z[f"in/{name}/indices"], z[f"in/{name}/indptr"]), shape=tuple(int(x) for x in z[f"in/{name}/shape"]))
+
+
+def _triples_by_row(row, col, val, n_rows):
+    """Stored COO triples -> per row the sorted list of (col, value) of its REAL entries (padding is (0, 0, 0.0))."""
+    out = []
+    for t in range(n_rows):
+        m = row == t
+        if t == 0:
+            m = m & ~((col == 0) & (val == 0))
+        o = np.lexsort((val[m], col[m]))
+        out.append((col[m][o], val[m][o]))
+    return out
+
+
+@pytest.mark.parametrize("name,fn,kw", [("dup_dot", "dot_product", {}), ("dup_cosine", "cosine", {}), ("dup_dot_thr", "dot_product", dict(threshold=0.5)),
+                                        ("dup_jaccard_shrink", "jaccard", dict(shrink=1.0))])
+def test_duplicate_listing_quirk_of_the_reference_is_not_reproduced(name, fn, kw):
+    """s_plus.h:112-117 takes "running sum == 0" for "first touch": a column whose partial sum is exactly 0 when its next product
+    arrives is listed twice, and the reference emits it a second time with xy = 0 (fixture: row 1, column 2 receives +2, -2, +3).
+    The HIP kernels emit every column ONCE with its full sum.  Asserted here: the reference output does hold the duplicate, and the
+    HIP output equals the reference output with exactly those second listings (same column again, value 0) removed."""
+    z = np.load(C.__file__.replace("cases.py", "quirks_golden.npz"))
+    m1, m2 = _quirk_csr(z, "dup_m1"), _quirk_csr(z, "dup_m2")
+    want = _triples_by_row(z[f"out/{name}/row"], z[f"out/{name}/col"], z[f"out/{name}/val"], m1.shape[0])
+    res = getattr(sim, fn)(m1, m2, k=8, verbose=False, **kw)
+    got = _triples_by_row(res.row.astype(np.int32), res.col.astype(np.int32), res.data.astype(np.float32), m1.shape[0])
+    n_dup = 0
+    for t, ((gc, gv), (wc, wv)) in enumerate(zip(got, want)):
+        # the reference's second listing: a column that occurs twice, once of them with value exactly 0
+        dup = np.zeros(wc.shape[0], dtype=bool)
+        for i in range(wc.shape[0]):
+            if wv[i] == 0 and np.count_nonzero(wc == wc[i]) == 2 and not dup[wc == wc[i]].any():
+                dup[i] = True
+        n_dup += int(dup.sum())
+        assert np.unique(gc).shape[0] == gc.shape[0], f"{name}: row {t}: the HIP result lists a column twice: {gc}"
+        np.testing.assert_array_equal(gc, wc[~dup], err_msg=f"{name}: row {t} columns")
+        np.testing.assert_allclose(gv, wv[~dup], rtol=RTOL, atol=ATOL, err_msg=f"{name}: row {t} values")
+    if "thr" not in name:
+        assert n_dup >= 1, f"{name}: the fixture no longer shows the reference's duplicate listing"
+    else:
+        assert n_dup == 0      # (the second listing's value 0 falls below the threshold)
+
+
+@pytest.mark.parametrize("name,fn,kw", [("p3_alpha4", "p3alpha", dict(alpha=4.0)), ("rp3_alpha4_beta", "rp3beta", dict(alpha=4.0, beta=0.3))])
+def test_p3_entries_that_underflow_to_zero_are_no_candidates(name, fn, kw):
+    """similarity.py:410-415 raises the L1-normalised entries to alpha on the host and s_plus.pyx:210-211 then drops what became 0.0.
+    The device-side preprocessing (SP_FLAG_P3_PREP) counts the entries that underflow; when there are any the call is redone with the
+    host statement (SP_EUNDERFLOW), so the result is the reference's: no zero-valued candidates at the end of short rows."""
+    z = np.load(C.__file__.replace("cases.py", "quirks_golden.npz"))
+    u = _quirk_csr(z, "p3_m")
+    want = _triples_by_row(z[f"out/{name}/row"], z[f"out/{name}/col"], z[f"out/{name}/val"], u.shape[0])
+    res = getattr(sim, fn)(u, k=12, verbose=False, **kw)
+    assert res.nnz == z[f"out/{name}/row"].shape[0]                      # COO keeps the padding: same stored size
+    got = _triples_by_row(res.row.astype(np.int32), res.col.astype(np.int32), res.data.astype(np.float32), u.shape[0])
+    for t, ((gc, gv), (wc, wv)) in enumerate(zip(got, want)):
+        np.testing.assert_array_equal(gc, wc, err_msg=f"{name}: row {t} columns")
+        np.testing.assert_allclose(gv, wv, rtol=RTOL, atol=1e-37, err_msg=f"{name}: row {t} values")

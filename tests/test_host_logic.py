@@ -323,3 +323,98 @@ def test_binary_values_stay_the_callers_when_the_device_writes_the_ones():
     z.data[3] = 0
     c = _host.prepare(z, z.T.tocsr(), k=5, l2=1, binary=True, binary_on_device=True, check_zeros=False)
     assert not c.binary_on_device and c.m1_data.shape[0] == z.nnz - 1 and z.data[3] == 0
+
+
+# ------------------------------------------------------------------------------------------------------------
+# route table: what the public call asks of the library for every kind of input (VERDICT r4 #12 / ADVICE r3's crash site)
+# ------------------------------------------------------------------------------------------------------------
+def _flags_of_public_call(monkeypatch, fn, m1, **kw):
+    """The SP_FLAG_* word (as names) the FIRST library call of a public wrapper carries, captured at the C boundary."""
+    from similaripy_amd import _abi
+
+    seen = {}
+
+    class Stop(Exception):
+        pass
+
+    def fake_call(a):
+        seen["flags"] = int(a.flags)
+        seen["col_keep"] = bool(a.col_keep)
+        raise Stop()
+
+    monkeypatch.setattr(_abi, "call_knn", fake_call)
+    monkeypatch.setattr(_abi, "require_device", lambda: 1)
+    from oracle import norm_oracle
+    from similaripy_amd import normalization
+    monkeypatch.setattr(normalization, "_run", norm_oracle.inplace_run)      # (the host statement of p3alpha normalises through the device library)
+    from similaripy_amd import _host
+    monkeypatch.setattr(_host, "col_sums_hip", lambda d, i, nc, square, device=None: _host.csr_sum(np.square(d, dtype=np.float32) if square else d, i, None, nc, axis=0))
+    with pytest.raises(Stop):
+        getattr(sim, fn)(m1, verbose=False, **kw)
+    names = {n[len("SP_FLAG_"):] for n in dir(_abi) if n.startswith("SP_FLAG_") and seen["flags"] & getattr(_abi, n)}
+    return names - {"NO_ROWS_OUT"}, seen["col_keep"]
+
+
+_RT_A = sp.random_array((40, 30), density=0.2, format="csr", dtype=np.float32, random_state=np.random.default_rng(1))
+_RT_W = sp.random_array((30, 25), density=0.3, format="csr", dtype=np.float32, random_state=np.random.default_rng(2))
+_RT_SEL = sp.random_array((40, 40), density=0.1, format="csr", dtype=np.float32, random_state=np.random.default_rng(3))
+_ALWAYS = {"CHECK_ZEROS"}
+ROUTES = [
+    # (id, fn, matrix1, kwargs, expected flags beyond CHECK_ZEROS, col_keep set?)
+    ("dot csr", "dot_product", _RT_A, {}, {"M2_IS_M1_T"}, False),
+    ("cosine csr", "cosine", _RT_A, {}, {"M2_IS_M1_T", "NORMS_ON_DEVICE"}, False),
+    ("cosine csr out", "cosine", _RT_A, dict(format_output="csr"), {"M2_IS_M1_T", "NORMS_ON_DEVICE", "CSR_OUT"}, False),
+    ("cosine csc", "cosine", _RT_A.tocsc(), {}, {"M1_IS_M2_T", "NORMS_ON_DEVICE"}, False),
+    ("dot csc", "dot_product", _RT_A.tocsc(), {}, {"M1_IS_M2_T"}, False),
+    ("jaccard binary", "jaccard", _RT_A, dict(binary=True), {"M2_IS_M1_T", "NORMS_ON_DEVICE", "BINARY"}, False),
+    ("cosine csc binary", "cosine", _RT_A.tocsc(), dict(binary=True), {"M1_IS_M2_T", "NORMS_ON_DEVICE", "BINARY"}, False),
+    ("cosine explicit m2", "cosine", _RT_A, dict(matrix2=_RT_W), {"NORMS_ON_DEVICE", "CHECK_SORTED"}, False),
+    ("dot explicit m2 binary", "dot_product", _RT_A, dict(matrix2=_RT_W, binary=True), {"CHECK_SORTED", "BINARY"}, False),
+    ("cosine filter list", "cosine", _RT_A, dict(filter_cols=[1, 2, 3]), {"M2_IS_M1_T", "NORMS_ON_DEVICE"}, True),
+    ("cosine csc + target list (no CSC route)", "cosine", _RT_A.tocsc(), dict(target_cols=[0, 5]), {"M2_IS_M1_T", "NORMS_ON_DEVICE"}, True),
+    ("explicit m2 + filter list", "cosine", _RT_A, dict(matrix2=_RT_W, filter_cols=[1, 2]), {"NORMS_ON_DEVICE", "CHECK_SORTED"}, True),
+    ("cosine filter matrix", "cosine", _RT_A, dict(filter_cols=_RT_SEL), {"M2_IS_M1_T", "NORMS_ON_DEVICE"}, False),
+    ("p3alpha", "p3alpha", _RT_A, dict(alpha=0.8), {"M2_IS_M1_T", "P3_PREP"}, False),
+    ("rp3beta", "rp3beta", _RT_A, dict(alpha=0.8, beta=0.4), {"M2_IS_M1_T", "P3_PREP", "DEPOP_ROWSUM"}, False),
+    ("p3alpha csc", "p3alpha", _RT_A.tocsc(), dict(alpha=0.8), {"M1_IS_M2_T", "P3_PREP"}, False),
+    ("p3alpha + filter list", "p3alpha", _RT_A, dict(alpha=0.8, filter_cols=[2]), {"M2_IS_M1_T", "P3_PREP"}, True),
+    ("p3alpha explicit m2 (host statement)", "p3alpha", _RT_A, dict(matrix2=sp.csr_array(_RT_A.T)), {"CHECK_SORTED"}, False),
+    ("s_plus pop2 sum", "s_plus", _RT_A, dict(l3=1.0, pop2="sum"), {"M2_IS_M1_T", "NORMS_ON_DEVICE"}, False),
+    ("s_plus pop1 sum csc (no CSC route)", "s_plus", _RT_A.tocsc(), dict(l3=1.0, pop1="sum"), {"M2_IS_M1_T", "NORMS_ON_DEVICE"}, False),
+    ("s_plus pop2 sum binary (ones made on the host)", "s_plus", _RT_A, dict(l3=1.0, pop2="sum", binary=True), {"M2_IS_M1_T", "NORMS_ON_DEVICE"}, False),
+]
+
+
+@pytest.mark.parametrize("rid,fn,m1,kw,want,keep", ROUTES, ids=[r[0] for r in ROUTES])
+def test_route_table_public_call_to_library_flags(rid, fn, m1, kw, want, keep, monkeypatch):
+    """Every legal combination of _host.prepare's route switches, written down as (input kind -> SP_FLAG_* set at the C boundary)."""
+    got, got_keep = _flags_of_public_call(monkeypatch, fn, m1, **kw)
+    # (CHECK_ZEROS rides on every first call — also where prepare made the ones of `binary` itself and has looked already: harmless)
+    assert got == want | _ALWAYS, (rid, sorted(got))
+    assert got_keep == keep, rid
+
+
+def test_matrix_selector_with_a_stale_sorted_flag(oracle_backend):
+    """scipy caches has_sorted_indices; an in-place edit of .indices leaves a stale True behind.  The library looks at the order itself
+    (MATRIX selector rows: UnsortedRowsError), the wrapper then verifies and sorts a copy: the filter still filters."""
+    urm = sp.random_array((60, 90), density=0.1, format="csr", dtype=np.float32, random_state=np.random.default_rng(5))
+    w = sp.random_array((90, 90), density=0.4, format="csr", dtype=np.float32, random_state=np.random.default_rng(6))
+    urm.sort_indices()
+    stale = urm.copy()
+    assert stale.has_sorted_indices      # (looked at once: scipy caches the answer)
+    for r in range(stale.shape[0]):      # reverse every row in place; the cached flag still says "sorted"
+        a, b = stale.indptr[r], stale.indptr[r + 1]
+        stale.indices[a:b] = stale.indices[a:b][::-1].copy()
+        stale.data[a:b] = stale.data[a:b][::-1].copy()
+    assert stale.has_sorted_indices
+    want = sim.dot_product(urm, w, k=20, filter_cols=urm, verbose=False, format_output="csr")
+    got = sim.dot_product(urm, w, k=20, filter_cols=stale, verbose=False, format_output="csr")
+    assert got.multiply(urm).nnz == 0
+    assert (abs(got - want) > 1e-6).nnz == 0
+
+
+def test_get_num_threads_counterpart(monkeypatch):
+    """similaripy.cython_code.utils.get_num_threads (utils.pyx:18-25; tests/test_similarity.py:384-390) has a counterpart: the device count."""
+    from similaripy_amd import _abi
+    monkeypatch.setattr(_abi, "device_count", lambda: 3)
+    assert sim.cython_code.utils.get_num_threads() == 3 and sim.get_num_threads() == 3 and sim.device_count() == 3

@@ -109,3 +109,46 @@ def test_port_matches_dense_definition(name, kw, dense_kw):
     got = so.canonical(*so.run_kernel(call, "port"), call.targets, k)
     S, mask = so.dense_similarity(m, **dense_kw)
     so.compare_topk(got, so.dense_topk(S, mask, k), k, rtol=3e-5, atol=1e-7, what=name)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# two documented behaviours, pinned by reference-generated fixtures (tests/golden/make_quirks_golden.py)
+# ------------------------------------------------------------------------------------------------------------
+def _quirk_csr(z, name):
+    return sp.csr_array((z[f"in/{name}/data"], z[f"in/{name}/indices"], z[f"in/{name}/indptr"]), shape=tuple(int(x) for x in z[f"in/{name}/shape"]))
+
+
+def _sorted_triples(row, col, val):
+    o = np.lexsort((val, col, row))
+    return row[o], col[o], val[o]
+
+
+@pytest.mark.parametrize("name,fn,kw", [("dup_dot", "dot_product", {}), ("dup_cosine", "cosine", {}), ("dup_dot_thr", "dot_product", dict(threshold=0.5)),
+                                        ("dup_jaccard_shrink", "jaccard", dict(shrink=1.0))])
+def test_port_reproduces_the_duplicate_listing_quirk(name, fn, kw, oracle_backend):
+    """s_plus.h:112-117: a column whose running sum is exactly 0 when its next product arrives is listed a second time.  The ORACLE
+    (a restatement of the reference) has the quirk too — stored triples equal the reference's, duplicates included; the HIP kernels
+    do not reproduce it (tests/test_hip_parity.py::test_duplicate_listing_quirk_of_the_reference_is_not_reproduced)."""
+    z = np.load(C.__file__.replace("cases.py", "quirks_golden.npz"))
+    res = getattr(sim, fn)(_quirk_csr(z, "dup_m1"), _quirk_csr(z, "dup_m2"), k=8, verbose=False, **kw)
+    got = _sorted_triples(res.row.astype(np.int32), res.col.astype(np.int32), res.data.astype(np.float32))
+    want = _sorted_triples(z[f"out/{name}/row"], z[f"out/{name}/col"], z[f"out/{name}/val"])
+    np.testing.assert_array_equal(got[0], want[0])
+    np.testing.assert_array_equal(got[1], want[1])
+    np.testing.assert_allclose(got[2], want[2], rtol=1e-6)
+    if "thr" not in name:
+        r1 = want[1][want[0] == 1]
+        assert np.count_nonzero(r1 == 2) == 2, "the fixture's row 1 lists column 2 twice"
+
+
+@pytest.mark.parametrize("name,fn,kw", [("p3_alpha4", "p3alpha", dict(alpha=4.0)), ("rp3_alpha4_beta", "rp3beta", dict(alpha=4.0, beta=0.3))])
+def test_p3_underflow_takes_the_host_statement(name, fn, kw, oracle_backend):
+    """`data ** alpha` underflows to 0.0 for some entries: the reference drops them before its kernel runs.  The device-side preprocessing
+    reports them (SP_EUNDERFLOW -> _abi.P3UnderflowError, emulated by the fixture) and the wrapper falls back on the host statement."""
+    z = np.load(C.__file__.replace("cases.py", "quirks_golden.npz"))
+    res = getattr(sim, fn)(_quirk_csr(z, "p3_m"), k=12, verbose=False, **kw)
+    got = _sorted_triples(res.row.astype(np.int32), res.col.astype(np.int32), res.data.astype(np.float32))
+    want = _sorted_triples(z[f"out/{name}/row"], z[f"out/{name}/col"], z[f"out/{name}/val"])
+    np.testing.assert_array_equal(got[0], want[0])
+    np.testing.assert_array_equal(got[1], want[1])
+    np.testing.assert_allclose(got[2], want[2], rtol=2e-6, atol=1e-37)
