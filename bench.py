@@ -365,7 +365,7 @@ def main():
     def line_of(wl, the_call, res, steps, with_phases: bool):
         """The figures of one measured workload: throughput, the dominant kernel, its roofline."""
         sparse_ms, generic_ms = res["sparse_ms"], res["generic_ms"]
-        wave = bool(res["info"].get("phase_cycles", [0] * 12)[8])
+        wave = bool(res["info"].get("phase_cycles", [0] * 12)[8] & 1)
         dominant = ("sp_knn_wave_kernel" if wave else "sp_knn_sparse_kernel") if sparse_ms >= generic_ms else "sp_knn_generic_kernel"
         kern_s = max(sparse_ms, generic_ms) / 1e3
         # (N > 1: rank 0's slice and rank 0's kernel time)
@@ -606,7 +606,8 @@ def phase_share(info) -> dict:
     cyc = info.get("phase_cycles", [0] * 12)
     tot = float(sum(cyc[:8])) or 1.0
     d = {n: round(c / tot, 4) for n, c in zip(names, cyc[:8])}
-    d["wave_per_row_kernel"] = bool(cyc[8])
+    d["wave_per_row_kernel"] = bool(cyc[8] & 1)
+    d["bounded_variant"] = bool(cyc[8] & 2)
     d["cycles_per_wg"] = tot / max(1, info.get("num_wgs", 1))
     d["rows_sparse_path"], d["generic_windows"] = cyc[9], cyc[11]
     d["rows_fallback_cs_full"], d["rows_fallback_u_overflow"] = cyc[10] & 0xFFFFFFFF, cyc[10] >> 32

@@ -184,8 +184,9 @@ typedef struct sp_knn_args {
                                   [0] row setup  [1] generic: segment scan | sparse: item list, bitmap clear + rank prefix
                                   [2] generic: accumulate | sparse: member products into the collision set
                                   [3] judge (column terms, epilogue, top-k buffer)  [4] selections  [5] write-out
-                                  [6] sparse sweep 1  [7] sparse sweep 2  [8] 1 = the sparse rows ran on the wave-per-row kernel (light rows), 0 = on the
-                                  workgroup-per-row kernel; then event counts:
+                                  [6] sparse sweep 1  [7] sparse sweep 2  [8] bit 0: the sparse rows ran on the wave-per-row kernel (light rows), else on the
+                                  workgroup-per-row kernel; bit 1: that kernel's bounded variant ran (general epilogue, column-term code in the
+                                  m2 ids); then event counts:
                                   [9] rows finished by the sparse kernel  [10] rows it handed to the generic kernel
                                   [11] generic column windows */
     int32_t num_wgs_used;      /* OUT with SP_FLAG_TIME_KERNEL */

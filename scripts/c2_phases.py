@@ -35,6 +35,8 @@ print(json.dumps({"rows": n_t, "call_ms": i1["kernel_ms"], "sparse_ms": i1["spar
                   "rows_sparse": ph[9], "given_up": ph[10]}), flush=True)
 tot = float(sum(ph[:9]))
 print("   cycles/row %.0f: " % (tot / n_t) + "  ".join(f"{n}={c / n_t:.0f}" for n, c in zip(names, ph[:9])), flush=True)
+if ph[8] & 2:      # the bounded variant ran: its counters (slot 11: selections << 32 | entries through the exact pass)
+    print(f"   bounded variant: {(ph[11] & 0xFFFFFFFF) / n_t:.0f} entries through the exact pass per row, {(ph[11] >> 32) / n_t:.2f} selections per row", flush=True)
 if tun["dbg"]:
     sys.exit(0)
 sample = np.sort(np.random.default_rng(1).choice(n_t, min(n_t, 150), replace=False)).astype(np.int32)

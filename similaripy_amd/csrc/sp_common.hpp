@@ -39,6 +39,36 @@ enum { SH_CNT = 0, SH_OVF, SH_SEL, SH_NEED, SH_EQ, SH_CNT2, SH_RETRY, SH_QA, SH_
 enum { PH_SETUP = 0, PH_SEGMENTS, PH_ACCUM, PH_DRAIN, PH_SELECT, PH_OUTPUT, PH_SWEEP1, PH_SWEEP2, PH_CSDRAIN,
        CT_ROWS_SPARSE, CT_ROWS_FALLBACK, CT_PASSES, PH_N };
 
+// ---- the bounded variant's per-call facts (written on the device by sp_bnd_range_kernel, read by the row kernel) ----
+// W[c] = rho_tv*Ytv[c] + rho_cos*Ycos[c] + rho_dep*Ydep[c] over the live column terms: with per-row multipliers r_j (r_tv = l1*t2,
+// r_cos = l2*Xcos[t], r_dep = l3*Xdep[t]) and lam = min_j r_j / rho_j the column part of the denominator obeys
+//     sum_j r_j*Y_j[c]  >=  lam*W[c] + sum_j (r_j - lam*rho_j)*ymin_j,
+// and W[c] travels with the column id: code(c) = (bits(W[c]) >> 19) - 1 — exponent and four mantissa bits, one quantum down — sits in
+// bits 20..31 of every m2 index (n_cols < 2^20), decoded by ONE shift:  as_float(id >> 1)  <= W[c]  (the id's own bits land below the
+// code and add less than the quantum the code was lowered by; the sign bit comes out 0).  The bound is 6 % below W on average, 12.5 % at
+// worst.  (Round 5 first carried an adaptive 12-bit code — up to ten mantissa bits, decoded with a shift and an add of per-call
+// constants: two more scalar registers and one more instruction per product in the sweep cost more than the tighter bound returned.)
+constexpr int BND_ID_BITS = 20;
+constexpr unsigned BND_ID_MASK = (1u << BND_ID_BITS) - 1u;
+struct BndInfo {
+    int state;             // 1 = usable; anything else: the call runs on the general variant (MODE 0)
+    float rho_tv, rho_cos, rho_dep;      // 0 = the term is not part of W (not live, or no usable reference)
+    float ymin_tv, ymin_cos, ymin_dep;   // minima over the valid columns (0 where not live)
+};
+__host__ __device__ inline constexpr size_t bnd_info_bytes() { return sizeof(BndInfo); }
+
+// the column's combined term (one expression, shared by the range and the pack pass; no contraction: both must agree to the bit)
+__device__ __forceinline__ float bnd_w(float rtv, float ytv, float rcos, float ycos, float rdep, float ydep) {
+    return __fadd_rn(__fadd_rn(__fmul_rn(rtv, ytv), __fmul_rn(rcos, ycos)), __fmul_rn(rdep, ydep));
+}
+// decode: a lower bound of W[c] from a packed id
+__device__ __forceinline__ float bnd_decode(unsigned packed) { return __uint_as_float(packed >> 1); }
+constexpr int BND_CODE_SHIFT = 19;      // code = (bits(W) >> 19) - 1, in [1, 4078]
+// can a candidate with raw dot x on packed column c still matter?  (nKw = -Kw, see the kernel's set_bnd_cut)
+__device__ __forceinline__ bool bnd_alive(unsigned packed, float x, float nKw, float Q) {
+    return !(__builtin_fmaf(bnd_decode(packed), nKw, x) <= Q);
+}
+
 struct KParams {
     int n_targets;
     const int *targets;
@@ -86,6 +116,11 @@ struct KParams {
     // block is the header {items, 0, 0, 0} (0 = the row is set up in the kernel), records 1.. are the items of the row
     const int4 *items_g;       // [items_rows][ITEMS_STRIDE]
     int items_rows;            // output slots below this have a block
+    // bounded variant of the sparse kernel (MODE 2, sp_sparse_kernel.hpp): the m2 column ids with a 12-bit code of the column's
+    // combined term W[c] in bits 20..31 (per-call pass), the same packed id per column, and the call's BndInfo
+    const unsigned *m2_packed;     // [nnz(m2)]
+    const unsigned *colpack;       // [n_cols]
+    const struct BndInfo *bnd;     // device memory (workspace header)
     unsigned long long *phase_cycles;  // optional [PH_N]
     int dbg;               // ablation bits for profiling only (results are WRONG when non-zero; 8 / 16: sweep 1 / sweep 2 of the sparse kernel
                            // load but do not process — compiled in only with -DSP_ABLATION=1: the test costs the sweeps 1 %):
@@ -790,6 +825,60 @@ __device__ __forceinline__ void s2_core(const unsigned (&c)[4], const float (&v)
           [L0] "=&s"(L[0]), [L1] "=&s"(L[1]), [L2] "=&s"(L[2]), [L3] "=&s"(L[3])
         : [c0] "v"(c[0]), [c1] "v"(c[1]), [c2] "v"(c[2]), [c3] "v"(c[3]),
           [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]), [sv] "v"(segv), [cut] "s"(cut)
+        : "memory");
+}
+
+// Sweep 2 of the bounded variant (MODE 2): the same, but the per-product test is  !(x - Kw*W(c) <= Q)  with W decoded from the code in
+// the id's upper bits (one shift) — two instructions per product more than the monotone variant's compare.
+__device__ __forceinline__ void s2_core_b(const unsigned (&c)[4], const float (&v)[4], float segv, float nKw, float Q,
+                                          float (&x)[4], u64 (&M)[4], u64 (&L)[4]) {
+    unsigned a0, a1, a2, a3, t0, t1;
+    static_assert(CBM_BYTES == 8192, "the literal below is CBM_BYTES - 4");
+    asm volatile(
+        "v_lshrrev_b32 %[a0], 3, %[c0]\n\t"
+        "v_lshrrev_b32 %[a1], 3, %[c1]\n\t"
+        "v_lshrrev_b32 %[a2], 3, %[c2]\n\t"
+        "v_lshrrev_b32 %[a3], 3, %[c3]\n\t"
+        "v_and_b32 %[a0], 0x1ffc, %[a0]\n\t"
+        "v_and_b32 %[a1], 0x1ffc, %[a1]\n\t"
+        "v_and_b32 %[a2], 0x1ffc, %[a2]\n\t"
+        "v_and_b32 %[a3], 0x1ffc, %[a3]\n\t"
+        "ds_read_b32 %[a0], %[a0]\n\t"
+        "ds_read_b32 %[a1], %[a1]\n\t"
+        "ds_read_b32 %[a2], %[a2]\n\t"
+        "ds_read_b32 %[a3], %[a3]\n\t"
+        "v_mul_f32 %[x0], %[sv], %[v0]\n\t"
+        "v_mul_f32 %[x1], %[sv], %[v1]\n\t"
+        "v_mul_f32 %[x2], %[sv], %[v2]\n\t"
+        "v_mul_f32 %[x3], %[sv], %[v3]\n\t"
+        "v_lshrrev_b32 %[t0], 1, %[c0]\n\t"
+        "v_lshrrev_b32 %[t1], 1, %[c1]\n\t"
+        "v_fma_f32 %[t0], %[t0], %[nkw], %[x0]\n\t"
+        "v_fma_f32 %[t1], %[t1], %[nkw], %[x1]\n\t"
+        "v_cmp_nle_f32_e64 %[L0], %[t0], %[q]\n\t"
+        "v_cmp_nle_f32_e64 %[L1], %[t1], %[q]\n\t"
+        "v_lshrrev_b32 %[t0], 1, %[c2]\n\t"
+        "v_lshrrev_b32 %[t1], 1, %[c3]\n\t"
+        "v_fma_f32 %[t0], %[t0], %[nkw], %[x2]\n\t"
+        "v_fma_f32 %[t1], %[t1], %[nkw], %[x3]\n\t"
+        "v_cmp_nle_f32_e64 %[L2], %[t0], %[q]\n\t"
+        "v_cmp_nle_f32_e64 %[L3], %[t1], %[q]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_bfe_u32 %[a0], %[a0], %[c0], 1\n\t"
+        "v_bfe_u32 %[a1], %[a1], %[c1], 1\n\t"
+        "v_bfe_u32 %[a2], %[a2], %[c2], 1\n\t"
+        "v_bfe_u32 %[a3], %[a3], %[c3], 1\n\t"
+        "v_cmp_ne_u32_e64 %[M0], 0, %[a0]\n\t"
+        "v_cmp_ne_u32_e64 %[M1], 0, %[a1]\n\t"
+        "v_cmp_ne_u32_e64 %[M2], 0, %[a2]\n\t"
+        "v_cmp_ne_u32_e64 %[M3], 0, %[a3]\n\t"
+        : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [t0] "=&v"(t0), [t1] "=&v"(t1),
+          [x0] "=&v"(x[0]), [x1] "=&v"(x[1]), [x2] "=&v"(x[2]), [x3] "=&v"(x[3]),
+          [M0] "=&s"(M[0]), [M1] "=&s"(M[1]), [M2] "=&s"(M[2]), [M3] "=&s"(M[3]),
+          [L0] "=&s"(L[0]), [L1] "=&s"(L[1]), [L2] "=&s"(L[2]), [L3] "=&s"(L[3])
+        : [c0] "v"(c[0]), [c1] "v"(c[1]), [c2] "v"(c[2]), [c3] "v"(c[3]),
+          [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]), [sv] "v"(segv),
+          [nkw] "s"(nKw), [q] "s"(Q)
         : "memory");
 }
 

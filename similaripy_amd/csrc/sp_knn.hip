@@ -117,6 +117,9 @@ struct Config {
     bool fold;
     bool wave;              // light rows: the wave-per-row kernel (sp_wave_kernel.hpp) runs instead of the workgroup-per-row sparse kernel
     bool mono;              // the sparse kernel's monotone variant applies (val = xy / den or the raw dot, no per-row target selector)
+    bool bnd;               // the sparse kernel's bounded variant is prepared and launched beside the general one (BndInfo::state picks on the device)
+    size_t ws_bnd_colpack;  // offsets inside the fold block: packed id per column | packed m2 ids
+    size_t ws_bnd_ids;
     bool ordered;
 };
 
@@ -127,6 +130,8 @@ constexpr size_t WS_PHASE_OFFSET = 64;
 constexpr size_t WS_YMIN_OFFSET = 176;
 constexpr size_t WS_FOLDZERO_OFFSET = 160;      // int: a stored entry of m2 met a zero column term while it was folded in
 constexpr size_t WS_SPLITS_STATE_OFFSET = 192;  // int[2]: the dense-window boundaries exist in this workspace | workgroups of sp_m2_splits_kernel done
+constexpr size_t WS_BND_OFFSET = 200;           // BndInfo (28 bytes): the bounded variant's per-call facts, kept across SP_FLAG_REUSE_M2_PREP calls
+static_assert(WS_BND_OFFSET + sizeof(BndInfo) <= 256, "workspace header layout");
 static_assert(WS_PHASE_OFFSET + PH_N * 8 <= WS_FOLDZERO_OFFSET && WS_FOLDZERO_OFFSET + 4 <= WS_YMIN_OFFSET && WS_YMIN_OFFSET + 16 <= WS_SPLITS_STATE_OFFSET &&
               WS_SPLITS_STATE_OFFSET + 8 <= WS_QUEUE_BYTES, "workspace header layout");
 constexpr size_t LDS_LIMIT = 160 * 1024;
@@ -236,6 +241,24 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
     c->mono = (c->fold || !any_norm) && a->target_col_mode != SP_SEL_MATRIX;      // (a MATRIX filter is handled through the collision bitmap)
     c->pack = !c->fold && ((a->l1 != 0.f) + (a->l2 != 0.f) + (a->l3 != 0.f) >= 2) && a->n_output_cols > 0;
     c->ws_fold_bytes = c->fold ? (((size_t)a->nnz_m2 * 4 + 255) & ~(size_t)255) : c->pack ? (((size_t)a->n_output_cols * 16 + 255) & ~(size_t)255) : 0;
+    // Bounded variant of the sparse kernel (MODE 2): a general epilogue whose value is bounded through ONE per-column term carried in the
+    // upper 12 bits of the m2 column ids.  Needs: column terms that are live and not folded, non-negative weights (the bound), a1 = 1, no
+    // Bayesian factor, a denominator that does not grow with the raw dot (t1 + t2 >= 1 whenever l1 != 0), threshold >= 0 (negative values
+    // are never wanted), no per-row selector matrices, ids that leave 12 bits free.  What it cannot serve runs on the general variant.
+    {
+        const bool live = (a->l1 != 0.f && a->t2 != 0.f) || a->l2 != 0.f || a->l3 != 0.f;
+        const bool nonneg = a->l1 >= 0.f && a->l2 >= 0.f && a->l3 >= 0.f && a->t1 >= 0.f && a->t2 >= 0.f && a->stabilized_shrink >= 0.f;
+        c->bnd = !c->mono && !c->fold && live && nonneg && a->a1 == 1.f && a->bayesian_shrink == 0.f && !(a->l1 * (1.f - a->t1 - a->t2) > 0.f) &&
+                 a->threshold >= 0.f && a->filter_mode != SP_SEL_MATRIX && a->target_col_mode != SP_SEL_MATRIX &&
+                 a->n_output_cols > 0 && (long long)a->n_output_cols < (1LL << BND_ID_BITS) && a->nnz_m2 > 0 &&
+                 !(a->flags & SP_FLAG_NO_SPARSE_PATH) && !(a->reserved[0] & 32768);      // (bit 32768 of the ablation word: off, for A/B runs)
+        c->ws_bnd_colpack = c->ws_bnd_ids = 0;
+        if (c->bnd) {
+            c->ws_bnd_colpack = c->ws_fold_bytes;
+            c->ws_bnd_ids = c->ws_bnd_colpack + (((size_t)a->n_output_cols * 4 + 255) & ~(size_t)255);
+            c->ws_fold_bytes = c->ws_bnd_ids + (((size_t)a->nnz_m2 * 4 + 255) & ~(size_t)255);
+        }
+    }
     c->ordered = !(a->flags & (SP_FLAG_STATIC_SCHED | SP_FLAG_NO_ROW_ORDER)) && a->n_targets > std::min(c->wgs_sparse, c->wgs_generic);
     // 512 B of bucket counters | work[n] | order[n] | (32-byte aligned) sparse queue n x 32 B | wave queue n x 32 B | generic queue n x 32 B
     c->ws_desc_offset = (512 + (size_t)a->n_targets * 8 + 31) & ~(size_t)31;
@@ -274,6 +297,10 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
     // variant.  (This assignment was lost in round 2's piece splitter commit: `big` was stack garbage from then on — the tests that
     // need it passed by the accident of what the stack held; round 3's cache cap changed that accident and exposed it.)
     c->big = a->nnz_m2 >= (1LL << 30) - 1024 || (a->reserved[0] & 1024);      // (bit 1024 of the ablation word: force it, for tests at small sizes)
+    if (c->big && c->bnd) {      // (no sparse kernel runs at all: nothing to prepare)
+        c->bnd = false;
+        c->ws_fold_bytes = c->ws_bnd_colpack;
+    }
     // the sparse kernel's work items, cut once per call: ITEMS_STRIDE * 16 B = 4 KB per output slot, for at most ITEMS_ROWS_MAX slots (the rows beyond
     // are set up in the kernel, as are rows of more than 64 entries or more than ITEMS_PRE items)
     c->items_rows = (!(a->flags & SP_FLAG_NO_SPARSE_PATH) && !c->big && !(a->reserved[0] & 2048) && a->nnz_m2 > 0) ? std::min(a->n_targets, ITEMS_ROWS_MAX) : 0;
@@ -290,6 +317,15 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
         c->wgs_wave = std::max(1, std::min(a->num_wgs > 0 ? a->num_wgs : n_cus * (int)(LDS_LIMIT / wv_lds_bytes(wv_a)), std::max(1, a->n_targets)));
     }
     c->ws_total = WS_QUEUE_BYTES + c->ws_gu_bytes + c->ws_fold_bytes + c->ws_rows_bytes + c->ws_split_bytes + c->ws_piece_bytes + c->ws_items_bytes;
+    if (c->fold && a->l3 != 0.f) {
+        // a folding rp3beta-type call may have to be redone WITHOUT folding (a zero column term under a stored entry, run_device_impl): the
+        // unfolded layout — packed column terms, or the bounded variant's packed ids — must fit the same workspace
+        sp_knn_args b = *a;
+        b.flags |= SP_FLAG_NO_FOLD;
+        Config c2{};
+        TRY(make_config(&b, n_cus, &c2));
+        c->ws_total = std::max(c->ws_total, c2.ws_total);
+    }
     return SP_OK;
 }
 
@@ -358,8 +394,16 @@ int device_cus(int device, int *n_cus) {
 
 template <int NT>
 int launch_sparse(const KParams &kp, const Config &c, hipStream_t stream) {
-    auto ks = c.mono ? (c.u_lds_s ? sp_knn_sparse_kernel<NT, true, true> : sp_knn_sparse_kernel<NT, false, true>)
-                     : (c.u_lds_s ? sp_knn_sparse_kernel<NT, true, false> : sp_knn_sparse_kernel<NT, false, false>);
+    if (c.bnd) {
+        // the bounded variant; BndInfo::state (written by the per-call passes on the device) decides at its first instruction whether it
+        // or the general variant launched right behind it does the rows — no read-back, no synchronisation
+        auto kb = c.u_lds_s ? sp_knn_sparse_kernel<NT, true, 2> : sp_knn_sparse_kernel<NT, false, 2>;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds_sparse));
+        hipLaunchKernelGGL(kb, dim3(c.wgs_sparse), dim3(NT), c.lds_sparse, stream, kp);
+        HIP_TRY(hipGetLastError());
+    }
+    auto ks = c.mono ? (c.u_lds_s ? sp_knn_sparse_kernel<NT, true, 1> : sp_knn_sparse_kernel<NT, false, 1>)
+                     : (c.u_lds_s ? sp_knn_sparse_kernel<NT, true, 0> : sp_knn_sparse_kernel<NT, false, 0>);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds_sparse));
     hipLaunchKernelGGL(ks, dim3(c.wgs_sparse), dim3(NT), c.lds_sparse, stream, kp);
     HIP_TRY(hipGetLastError());
@@ -439,7 +483,7 @@ uint64_t prep_signature(const sp_knn_args *a, const Config &c) {
     auto mix = [&](const void *p, size_t n) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } };
 #define SP_MIX(x) mix(&(x), sizeof(x))
     const uint32_t fl = a->flags & (SP_FLAG_NO_FOLD | SP_FLAG_NO_SPARSE_PATH);
-    const int64_t abl = a->reserved[0] & (1024 | 2048 | 4096 | 16384);
+    const int64_t abl = a->reserved[0] & (1024 | 2048 | 4096 | 16384 | 32768);
     SP_MIX(fl); SP_MIX(abl);
     SP_MIX(a->n_rows_m2); SP_MIX(a->n_output_cols); SP_MIX(a->nnz_m2);
     SP_MIX(a->m2_data); SP_MIX(a->m2_indices); SP_MIX(a->m2_indptr);
@@ -447,7 +491,7 @@ uint64_t prep_signature(const sp_knn_args *a, const Config &c) {
     SP_MIX(a->a1); SP_MIX(a->l1); SP_MIX(a->l2); SP_MIX(a->l3); SP_MIX(a->t1); SP_MIX(a->t2);
     SP_MIX(a->stabilized_shrink); SP_MIX(a->bayesian_shrink);
     SP_MIX(a->k); SP_MIX(a->table_slots); SP_MIX(a->threads_per_wg); SP_MIX(a->load_pct);
-    const uint64_t lay[5] = {(uint64_t)c.ws_fold_bytes, (uint64_t)c.ws_split_bytes, (uint64_t)c.n_splits, (uint64_t)c.split_w, (uint64_t)(c.fold ? 1 : 0) | (c.pack ? 2 : 0)};
+    const uint64_t lay[5] = {(uint64_t)c.ws_fold_bytes, (uint64_t)c.ws_split_bytes, (uint64_t)c.n_splits, (uint64_t)c.split_w, (uint64_t)(c.fold ? 1 : 0) | (c.pack ? 2 : 0) | (c.bnd ? 4 : 0)};
     mix(lay, sizeof(lay));
 #undef SP_MIX
     return h;
@@ -572,6 +616,25 @@ int run_device_impl(sp_knn_args *a, const uint64_t *sig_override = nullptr) {
         HIP_TRY(hipGetLastError());
     }
 
+    BndInfo *bnd_info = nullptr;
+    unsigned *bnd_colpack = nullptr, *bnd_ids = nullptr;
+    if (c.bnd) {
+        // the bounded variant's per-call passes (sp_prep_kernels.hpp): reference multipliers + code layout -> BndInfo, packed id per column,
+        // packed m2 ids (one streaming pass over m2's indices: 0.5 GB of traffic at the C2 size)
+        bnd_info = (BndInfo *)(ws + WS_BND_OFFSET);
+        bnd_colpack = (unsigned *)(ws_fold + c.ws_bnd_colpack);
+        bnd_ids = (unsigned *)(ws_fold + c.ws_bnd_ids);
+        if (!reuse) {
+            const float *ytv = (a->l1 != 0.f && a->t2 != 0.f) ? a->Ytversky : nullptr, *ycos = a->l2 != 0.f ? a->Ycosine : nullptr, *ydep = a->l3 != 0.f ? a->Ydepop : nullptr;
+            hipLaunchKernelGGL(sp_bnd_range_kernel, dim3(1), dim3(1024), 0, stream, a->n_output_cols, ytv, ycos, ydep, a->n_rows_m1,
+                               a->l2 != 0.f ? a->Xcosine : nullptr, a->l3 != 0.f ? a->Xdepop : nullptr, a->l1 * a->t2, a->l2, a->l3, bnd_info);
+            hipLaunchKernelGGL(sp_bnd_colpack_kernel, dim3(std::min(2048, (a->n_output_cols + 255) / 256)), dim3(256), 0, stream, a->n_output_cols, ytv, ycos, ydep,
+                               (const BndInfo *)bnd_info, bnd_colpack);
+            hipLaunchKernelGGL(sp_bnd_pack_ids_kernel, dim3(256 * 8), dim3(256), 0, stream, (long long)a->nnz_m2, a->m2_indices, (const unsigned *)bnd_colpack, bnd_ids, bnd_info);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+
     int *neg_flag = (int *)(ws + WS_YMIN_OFFSET + 12);      // (inside the zeroed header)
     const bool sign_matters = a->bayesian_shrink != 0.f || a->l1 * (1.f - a->t1 - a->t2) > 0.f;      // (see RowCtx::set_cut)
     if (sign_matters && !reuse) {
@@ -680,6 +743,7 @@ int run_device_impl(sp_knn_args *a, const uint64_t *sig_override = nullptr) {
     kp.neg_flag = sign_matters ? neg_flag : nullptr;
     kp.fold = c.fold ? 1 : 0;
     if (c.fold) kp.m2_data = folded;
+    kp.bnd = bnd_info; kp.colpack = bnd_colpack; kp.m2_packed = bnd_ids;
     kp.splits = nullptr;
     kp.n_splits = 0;
     kp.split_w = c.split_w;
@@ -722,7 +786,8 @@ int run_device_impl(sp_knn_args *a, const uint64_t *sig_override = nullptr) {
         const unsigned long long *phc = (const unsigned long long *)(qb + WS_PHASE_OFFSET);
         static_assert(PH_N == 12, "sp_knn_args::phase_cycles has 12 entries");
         for (int i = 0; i < PH_N; ++i) a->phase_cycles[i] = (int64_t)phc[i];
-        a->phase_cycles[PH_CSDRAIN] = c.wave ? 1 : 0;        // (slot 8 carries no timer: which sparse-row kernel ran)
+        // (slot 8 carries no timer: which sparse-row kernel ran — bit 0: the wave-per-row kernel, bit 1: the workgroup kernel's bounded variant)
+        a->phase_cycles[PH_CSDRAIN] = (c.wave ? 1 : 0) | ((c.bnd && ((const BndInfo *)(qb + WS_BND_OFFSET))->state == 1) ? 2 : 0);
         a->passes_total = (int32_t)phc[CT_PASSES];
         a->num_wgs_used = c.wave ? c.wgs_wave : c.wgs_sparse;
         float ks_ms = 0.f, kg_ms = 0.f;

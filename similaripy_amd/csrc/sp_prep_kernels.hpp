@@ -444,6 +444,103 @@ __global__ __launch_bounds__(1024) void sp_colterm_min_kernel(int n_cols, const 
     }
 }
 
+// ---- per-call passes of the sparse kernel's BOUNDED variant (MODE 2; BndInfo in sp_common.hpp) ----
+// a column is VALID when every live Y_j is finite and >= 0 and its W is a finite normal float well above the bottom (code >= 1)
+__device__ __forceinline__ bool bnd_valid(float ytv, float ycos, float ydep, float w) {
+    const float inf = __builtin_inff();
+    return (ytv >= 0.f) && (ycos >= 0.f) && (ydep >= 0.f) && (ytv < inf) && (ycos < inf) && (ydep < inf) && (w < inf) && ((__float_as_uint(w) >> BND_CODE_SHIFT) >= 2u) &&
+           !(__float_as_uint(w) >> 31);
+}
+// (1) one workgroup: reference multipliers rho_j (l_j x the mean of the row terms that are finite and positive) and the minima of the
+//     live Y_j over the valid columns -> BndInfo
+__global__ __launch_bounds__(1024) void sp_bnd_range_kernel(int n_cols, const float *Ytv, const float *Ycos, const float *Ydep, int n_rows_m1,
+                                                             const float *Xcos, const float *Xdep, float l1t2, float l2, float l3, BndInfo *out) {
+    __shared__ double redd[2][16];
+    __shared__ unsigned redc[3][16];
+    __shared__ float rho[3];
+    __shared__ float redm[3][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double s0 = 0.0, s1 = 0.0;
+    unsigned c0 = 0, c1 = 0;
+    for (int i = tid; i < n_rows_m1; i += 1024) {
+        if (Xcos) { const float x = Xcos[i]; if (x > 0.f && x < __builtin_inff()) { s0 += (double)x; ++c0; } }
+        if (Xdep) { const float x = Xdep[i]; if (x > 0.f && x < __builtin_inff()) { s1 += (double)x; ++c1; } }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        s0 += __shfl_xor(s0, d, 64); s1 += __shfl_xor(s1, d, 64);
+        c0 += __shfl_xor(c0, d, 64); c1 += __shfl_xor(c1, d, 64);
+    }
+    if (lane == 0) { redd[0][wave] = s0; redd[1][wave] = s1; redc[0][wave] = c0; redc[1][wave] = c1; }
+    __syncthreads();
+    if (tid == 0) {
+        double a = 0.0, b = 0.0;
+        unsigned na = 0, nb = 0;
+        for (int w = 0; w < 16; ++w) { a += redd[0][w]; b += redd[1][w]; na += redc[0][w]; nb += redc[1][w]; }
+        rho[0] = Ytv ? l1t2 : 0.f;
+        rho[1] = (Ycos && na) ? l2 * (float)(a / (double)na) : 0.f;
+        rho[2] = (Ydep && nb) ? l3 * (float)(b / (double)nb) : 0.f;
+        for (int j = 0; j < 3; ++j) if (!(rho[j] > 0.f) || !(rho[j] < __builtin_inff())) rho[j] = 0.f;
+    }
+    __syncthreads();
+    const float rtv = rho[0], rcos = rho[1], rdep = rho[2];
+    const float inf = __builtin_inff();
+    unsigned nv = 0;
+    float m0 = inf, m1 = inf, m2 = inf;
+    for (int i = tid; i < n_cols; i += 1024) {
+        const float ytv = Ytv ? Ytv[i] : 0.f, ycos = Ycos ? Ycos[i] : 0.f, ydep = Ydep ? Ydep[i] : 0.f;
+        if (bnd_valid(ytv, ycos, ydep, bnd_w(rtv, ytv, rcos, ycos, rdep, ydep))) {
+            ++nv;
+            m0 = fminf(m0, ytv); m1 = fminf(m1, ycos); m2 = fminf(m2, ydep);
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        nv += __shfl_xor(nv, d, 64);
+        m0 = fminf(m0, __shfl_xor(m0, d, 64)); m1 = fminf(m1, __shfl_xor(m1, d, 64)); m2 = fminf(m2, __shfl_xor(m2, d, 64));
+    }
+    if (lane == 0) { redc[2][wave] = nv; redm[0][wave] = m0; redm[1][wave] = m1; redm[2][wave] = m2; }
+    __syncthreads();
+    if (tid == 0) {
+        nv = 0;
+        for (int w = 0; w < 16; ++w) { nv += redc[2][w]; m0 = fminf(m0, redm[0][w]); m1 = fminf(m1, redm[1][w]); m2 = fminf(m2, redm[2][w]); }
+        BndInfo b;
+        b.rho_tv = rtv; b.rho_cos = rcos; b.rho_dep = rdep;
+        b.ymin_tv = (Ytv && m0 < inf) ? m0 : 0.f; b.ymin_cos = (Ycos && m1 < inf) ? m1 : 0.f; b.ymin_dep = (Ydep && m2 < inf) ? m2 : 0.f;
+        b.state = (nv > 0u && (rtv > 0.f || rcos > 0.f || rdep > 0.f)) ? 1 : 0;
+        *out = b;
+    }
+}
+
+// (2) the packed id of every column: id | code << 20, code = (bits(W) >> 19) - 1; a column that is not valid gets 0xFFFFFFFF (if an m2
+//     entry points at one the pack pass below takes the whole call off the bounded variant)
+__global__ __launch_bounds__(256) void sp_bnd_colpack_kernel(int n_cols, const float *__restrict__ Ytv, const float *__restrict__ Ycos, const float *__restrict__ Ydep,
+                                                              const BndInfo *__restrict__ info, unsigned *__restrict__ colpack) {
+    const BndInfo b = *info;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_cols; i += gridDim.x * blockDim.x) {
+        unsigned out = 0xFFFFFFFFu;
+        if (b.state == 1) {
+            const float ytv = Ytv ? Ytv[i] : 0.f, ycos = Ycos ? Ycos[i] : 0.f, ydep = Ydep ? Ydep[i] : 0.f;
+            const float w = bnd_w(b.rho_tv, ytv, b.rho_cos, ycos, b.rho_dep, ydep);
+            if (bnd_valid(ytv, ycos, ydep, w)) out = (unsigned)i | (((__float_as_uint(w) >> BND_CODE_SHIFT) - 1u) << BND_ID_BITS);
+        }
+        colpack[i] = out;
+    }
+}
+
+// (3) the m2 index stream with the codes in it.  An entry on an invalid column: state |= 2 (the general variant runs instead).
+__global__ __launch_bounds__(256) void sp_bnd_pack_ids_kernel(long long nnz, const int *__restrict__ indices, const unsigned *__restrict__ colpack,
+                                                               unsigned *__restrict__ out, BndInfo *__restrict__ info) {
+    bool bad = false;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nnz; i += (long long)gridDim.x * blockDim.x) {
+        const int c = indices[i];
+        const unsigned pk = colpack[c];
+        bad |= pk == 0xFFFFFFFFu;
+        out[i] = (pk == 0xFFFFFFFFu) ? (unsigned)c : pk;
+    }
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(&info->state, 2);
+}
+
 // Interleave the column terms in use into one {Ytv, Ycos, Ydep, 0} record per column (0 for a term whose weight is 0:
 // the epilogue never looks at it), so that judging a candidate costs one gather.
 __global__ __launch_bounds__(256) void sp_pack_colterms_kernel(int n_cols, const float *__restrict__ Ytv, const float *__restrict__ Ycos,

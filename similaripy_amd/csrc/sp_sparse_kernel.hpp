@@ -25,8 +25,21 @@ namespace {
 // selector is active (a per-row FILTER is: its columns are pre-marked in the collision bitmap and dropped at the scan).  Then the whole top-k runs on the raw dot: survivors go straight from the sweep into the
 // candidate buffer (no survivor pool, no judge phase), the running k-th raw dot IS the cutoff, and the epilogue is
 // applied to the k winners at write-out.
-template <int NT, bool U_LDS, bool MONO>
+// MODE 0: general variant (survivor pool + judge).  MODE 1: MONO.  MODE 2: BND, the BOUNDED variant — a general epilogue (Tversky term,
+// additive shrink, several column terms) on the monotone variant's pipeline: the m2 column ids carry a 12-bit code of the column's
+// combined term W[c] (BndInfo, sp_common.hpp), so "can this product still matter?" is  x - Kw*W(c) > Q  with two per-row scalars — no
+// gather, three instructions more than MONO's compare; what passes goes straight into U as {raw dot, packed id}; in front of every
+// selection (and at the row's end) ONE dense pass turns the new entries into {exact value, column} with the column-term gather and the
+// epilogue of s_plus.h:129-156 — a few hundred entries per row instead of the general variant's ~6 k judged candidates; cutoffs are
+// exact k-th values.  The first stage is MONO's selection-free one on EXACT values: its one trip per wave gathers the column terms of its
+// four products per lane and evaluates the epilogue right there (a bound would not do: what the stage does not keep is never offered
+// again, so its cutoff must be a value k candidates really reach).  Rows the bound cannot serve (negative row
+// terms) go to the generic queue; calls it cannot serve run MODE 0 (sp_knn.hip: both are launched, BndInfo::state picks one on the device).
+template <int NT, bool U_LDS, int MODE>
 __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
+    constexpr bool MONO = MODE == 1, BND = MODE == 2, MLIKE = MODE != 0;
+    if constexpr (BND) { if (p.bnd->state != 1) return; }                       // (uniform over the grid: written by the per-call passes)
+    else if constexpr (!MONO) { if (p.bnd != nullptr && p.bnd->state == 1) return; }   // launched beside the bounded variant: that one runs
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NW = NT / 64;
     int tid = threadIdx.x;      // (made opaque at every row top, see there)
@@ -68,13 +81,13 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
     const unsigned spool_off = (unsigned)(CBM_BYTES + PRE_BYTES + A_bytes / 4);
     const unsigned u_off = (unsigned)(CBM_BYTES + PRE_BYTES + (A_bytes / 4) * 3);
     if ((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();
-    const __amdgpu_buffer_rsrc_t rs_idx = __builtin_amdgcn_make_buffer_rsrc((void *)p.m2_indices, 0, (int)p.m2_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_idx = __builtin_amdgcn_make_buffer_rsrc(BND ? (void *)p.m2_packed : (void *)p.m2_indices, 0, (int)p.m2_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_val = __builtin_amdgcn_make_buffer_rsrc((void *)p.m2_data, 0, (int)p.m2_bytes, 0x00020000);
 
     // collision bitmap + region A all zero, histograms zero
     for (int i = tid; i < (CBM_BYTES + PRE_BYTES + A_bytes) / 16; i += NT) ((int4 *)smem)[i] = make_int4(0, 0, 0, 0);
     for (int i = tid; i < 1024; i += NT) hist4[i] = 0;
-    if (MONO && !U_LDS) { for (int i = tid; i < cap / 2; i += NT) ((int4 *)U)[i] = make_int4(0, 0, 0, 0); }
+    if (MLIKE && !U_LDS) { for (int i = tid; i < cap / 2; i += NT) ((int4 *)U)[i] = make_int4(0, 0, 0, 0); }
     if (tid < 32) sh[tid] = 0;
     if (tid < 16) ph[tid] = 0;
     __syncthreads();
@@ -92,6 +105,15 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         while ((u64)clock64() < until) __builtin_amdgcn_s_sleep(8);
     }
 #endif
+    // BND: the call's facts, in scalar registers
+    float b_rho_tv = 0.f, b_rho_cos = 0.f, b_rho_dep = 0.f, b_ymin_tv = 0.f, b_ymin_cos = 0.f, b_ymin_dep = 0.f;
+    if constexpr (BND) {
+        // (v_readfirstlane: the loads are vector loads — nothing tells the compiler that the workspace header is not written by this
+        // kernel — and their results would sit in vector registers around the whole row loop)
+        auto sf = [](float v) { return __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))); };
+        b_rho_tv = sf(p.bnd->rho_tv); b_rho_cos = sf(p.bnd->rho_cos); b_rho_dep = sf(p.bnd->rho_dep);
+        b_ymin_tv = sf(p.bnd->ymin_tv); b_ymin_cos = sf(p.bnd->ymin_cos); b_ymin_dep = sf(p.bnd->ymin_dep);
+    }
     const bool timing = (p.phase_cycles != nullptr) && tid == 0;
     u64 tmark = timing ? (u64)clock64() : 0;
 #define PHASE_END(which) do { if (timing) { const u64 _n = (u64)clock64(); ph[which] += _n - tmark; tmark = _n; } } while (0)
@@ -228,7 +250,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
 
         // (MONO: SH_PCTR is the write-out's compaction counter — zero whenever a row reaches its write-out, reset behind every stage's
         // drain — and must not be touched here: the previous row's threads may still be reading it, there is no barrier in between)
-        if (tid == 0) { if (!MONO) sh[SH_PCTR] = 0; sh[SH_MCTR] = 0; sh[SH_NITEMS] = 0; sh[SH_CNT] = 0; sh[SH_SEL] = -1; sh[SH_NEED] = 0; }
+        if (tid == 0) { if (!MLIKE) sh[SH_PCTR] = 0; sh[SH_MCTR] = 0; sh[SH_NITEMS] = 0; sh[SH_CNT] = 0; sh[SH_SEL] = -1; sh[SH_NEED] = 0; }
         // Segment order.  The heaviest segments (largest |m1 value|: each segment scales its m2 row by its own m1 value)
         // go first, so that the first stage of sweep 2 sees the large products and the running k-th value — the cutoff
         // of everything after — starts high.
@@ -363,6 +385,55 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             rc.f0 = rc.f1 = rc.g0 = rc.g1 = 0;
             if (p.filter_mode == SP_SEL_MATRIX) { rc.f0 = __builtin_amdgcn_readfirstlane(p.f_indptr[t]); rc.f1 = __builtin_amdgcn_readfirstlane(p.f_indptr[t + 1]); }
             if (p.target_mode == SP_SEL_MATRIX) { rc.g0 = __builtin_amdgcn_readfirstlane(p.t_indptr[t]); rc.g1 = __builtin_amdgcn_readfirstlane(p.t_indptr[t + 1]); }
+        }
+        // BND: den(x, c) = A + sum_j r_j*Y_j[c] + bB*x  >=  AE + lam*W[c] + bB*x   (BndInfo, sp_common.hpp; bB <= 0, threshold >= 0, a1 = 1 and
+        // no Bayesian shrink by dispatch).  A candidate is DEAD when  1.00002*x / (AE + lam*W + bB*x) <= t,  i.e. when  x - Kw*W <= Q  with
+        // Kw = t*lam/P, Q = t*AE/P, P = 1.00002 - t*bB > 0 (both shaved so that rounding can only let more through); t = the value a candidate
+        // must beat: just below `threshold`, or the running k-th EXACT value.  No t > 0 yet: only negative raw dots are dead (their value
+        // is negative, below any threshold >= 0: the row guard below makes the denominator positive for them).
+        float b_AE = 0.f, b_lam = 0.f, b_bB = 0.f, b_nKw = 0.f, b_Q = -1e-30f, b_t0 = 0.f;
+        auto bnd_cut_for = [&](float tv, float &nKw, float &Q) __attribute__((always_inline)) {      // tv: uniform
+            nKw = 0.f; Q = -1e-30f;
+            if (tv > 0.f && tv < __builtin_inff()) {
+                const float inv = 0.999996f / (1.00002f - tv * b_bB);
+                nKw = -(tv * b_lam * inv);
+                Q = tv * b_AE * inv;
+            }
+            nKw = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(nKw)));
+            Q = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(Q)));
+        };
+        auto set_bnd_cut = [&]() __attribute__((always_inline)) {
+            float tv = b_t0;
+            if (rc.have_thr) tv = fmaxf(tv, funkey(rc.thr_key));
+            bnd_cut_for(tv, b_nKw, b_Q);
+        };
+        int n_keyed = 0;       // BND: U[0, n_keyed) holds {exact value key, column}; entries behind it {raw dot, packed id}
+        bool thr_incl = false; // BND: the running k-th value comes from the first stage's statistic — the candidates that REACH it (>=) are
+                               // still waiting for the exact pass, which must keep them; after a selection the k best are in U and only
+                               // what BEATS the k-th value (>) is wanted
+        if constexpr (BND) {
+            const Epi &epi = rc.epi;
+            const float r_tv = p.l1 * p.t2, r_cos = p.l2 * epi.xcos, r_dep = p.l3 * epi.xdep;
+            float lam = __builtin_inff();
+            if (b_rho_tv > 0.f) lam = fminf(lam, r_tv / b_rho_tv);
+            if (b_rho_cos > 0.f) lam = fminf(lam, r_cos / b_rho_cos);
+            if (b_rho_dep > 0.f) lam = fminf(lam, r_dep / b_rho_dep);
+            lam *= 0.999998f;
+            const float e_tv = fmaxf(0.f, r_tv - lam * b_rho_tv) * b_ymin_tv, e_cos = fmaxf(0.f, r_cos - lam * b_rho_cos) * b_ymin_cos,
+                        e_dep = fmaxf(0.f, r_dep - lam * b_rho_dep) * b_ymin_dep;
+            const float A = p.l1 * p.t1 * epi.xtv + p.stab;
+            b_lam = lam;
+            b_AE = (A + ((e_tv + e_cos) + e_dep)) * 0.999998f;
+            b_bB = p.l1 * (1.f - p.t1 - p.t2);
+            b_t0 = __uint_as_float(RowCtx::funkey_inv_below(p.threshold));
+            // rows the bound cannot serve: a negative row term or multiplier, nothing positive in the denominator's bound
+            const bool row_ok = p.bound_ok && (r_tv >= 0.f) && (r_cos >= 0.f) && (r_dep >= 0.f) && (A >= 0.f) && (lam >= 0.f) && (lam < __builtin_inff()) &&
+                                (b_AE < __builtin_inff()) && (b_AE > 0.f || lam > 0.f) && !(b_bB > 0.f);
+            if (!row_ok) failed = true;
+            b_lam = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(b_lam)));
+            b_AE = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(b_AE)));
+            b_bB = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(b_bB)));
+            set_bnd_cut();
         }
 
         // MONO: the first stage's trips (one or two items per wave, see there) are requested in front of the bitmap's clearing loop and
@@ -545,7 +616,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             }
             wg_sync<U_LDS>();
             PHASE_END(PH_SWEEP1);
-            if constexpr (MONO) {
+            if constexpr (MLIKE) {
                 const int NA = min(n_items, NW);
                 if (NA == NW && (p.k + NA - 1) / NA + 2 <= MAXR1) {      // (the first stage's own condition)
                     fs_early = true;
@@ -662,7 +733,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             // in descending weight — so the next chunk may be 4*n*(cap-k)/k long.
             const int room = cap - min(p.k, cap - 1);
             int i0 = 0;
-            int chunk_items = max(1, (MONO ? room : min(room, spcap - 2 * ITEM)) / ITEM);     // items of the next stage
+            int chunk_items = max(1, (MLIKE ? room : min(room, spcap - 2 * ITEM)) / ITEM);     // items of the next stage
             bool last_stage = false;
             bool force_sel = false;
             WavePool wpm{0, -1};      // member-pool window: lives across the stages of the row
@@ -679,7 +750,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             // ONE barrier, and only the products that reach it enter U (a second barrier checks that at least k do and
             // that they fit; if not — sparse items, heavily tied values — the stage falls back to "accept everything
             // in fewer items, select afterwards"). ----
-            if constexpr (MONO) {
+            if constexpr (MLIKE) {
                 const int NA = min(n_items, NW);
                 const int mrounds = (p.k + NA - 1) / NA + 2;
                 // FS trips per wave in this stage.  The 256-thread shape takes two when the row has them: its four waves see 800
@@ -696,6 +767,8 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     float x[FS][4];
                     u64 M[FS][4], S[FS][4];
                     unsigned lmax = 0u;
+                    float bx = -__builtin_inff();      // BND: the lane's best single product of the stage (raw dot, packed id)
+                    unsigned bc = 0u;
 #pragma unroll
                     for (int f = 0; f < FS; ++f) {
 #pragma unroll
@@ -717,17 +790,47 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                             const u32x4 a = fsa[f], b = fsb[f];
                             c[f][0] = a.x; c[f][1] = a.y; c[f][2] = a.z; c[f][3] = a.w;
                             v[0] = __uint_as_float(b.x); v[1] = __uint_as_float(b.y); v[2] = __uint_as_float(b.z); v[3] = __uint_as_float(b.w);
-                            s2_core(c[f], v, segv, cutx, x[f], M[f], S[f]);
+                            if constexpr (BND) s2_core_b(c[f], v, segv, b_nKw, b_Q, x[f], M[f], S[f]);
+                            else s2_core(c[f], v, segv, cutx, x[f], M[f], S[f]);
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
                                 const u64 ok = (cntA == ITEM) ? ~0ull : __ballot(j < dq);
                                 M[f][j] &= ok;
                                 S[f][j] &= ok & ~M[f][j];
-                                if ((S[f][j] >> lane) & 1ull) lmax = max(lmax, fkey(x[f][j]));
+                            }
+                            if constexpr (BND) {
+                                // the lane's best single product so far (largest raw dot): the one whose EXACT value feeds the statistic below
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    if (((S[f][j] >> lane) & 1ull) && x[f][j] > bx) { bx = x[f][j]; bc = c[f][j]; }
+                            }
+                            if constexpr (!BND) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    if ((S[f][j] >> lane) & 1ull) lmax = max(lmax, fkey(x[f][j]));
                             }
                         }
                     }
-                    if (fs * NW < n_items) {      // (uniform) the next stage starts at item fs * NW if this one fits — the rule
+                    if constexpr (BND) {
+                        // EXACT value of the lane's best single product (s_plus.h:129-156: ONE column-term gather per lane): the statistic below
+                        // then says "at least m lanes of this wave hold a product whose value reaches tw" about values candidates really
+                        // have — a bound would not do: the stage's cutoff must be one that k candidates reach, or what it discards could
+                        // have been among the k best.  (All four products of a lane, first try: 4 096 gathers of a 128-byte line each per
+                        // row, as much memory traffic as the sweeps' streams — the whole kernel slowed down.)
+                        const int gc = (bx > -__builtin_inff()) ? (int)(bc & BND_ID_MASK) : 0;
+                        float ytv = 0.f, ycos = 0.f, ydep = 0.f;
+                        if (p.Ypack) { const float4 y = p.Ypack[gc]; ytv = y.x; ycos = y.y; ydep = y.z; }
+                        else {
+                            if (p.l1 != 0.f) ytv = p.Ytv[gc];
+                            if (p.l2 != 0.f) ycos = p.Ycos[gc];
+                            if (p.l3 != 0.f) ydep = p.Ydep[gc];
+                        }
+                        const float val = rc.epi(bx, ytv, ycos, ydep);
+                        if (bx > -__builtin_inff() && val >= p.threshold) lmax = fkey(val);
+                    }
+                    // (BND: no early request of the next stage's first trip — its eight registers, live across this stage's barriers beside the
+                    // gather's, cost the variant its zero-spill budget)
+                    if (!BND && fs * NW < n_items) {      // (uniform) the next stage starts at item fs * NW if this one fits — the rule
                         const int ip = fs * NW + wave;
                         const int4 d = items[(ip < n_items) ? ip : n_items];       // (beyond the end: the sentinel, nothing is fetched)
                         int vo, so = 0;
@@ -782,15 +885,22 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     if (lane == 0 && tw != 0u) atomicMin((unsigned *)&sh[SH_SEL], tw);
                     wg_sync<U_LDS>();
                     const unsigned g = (unsigned)sh[SH_SEL];            // every product pushed below has key >= g
+                    // BND: g is a value k candidates of this stage reach; what can still beat it (the bound against g) is offered to the exact pass
+                    float g_nKw = 0.f, g_Q = 0.f;
+                    if constexpr (BND) bnd_cut_for(fmaxf(b_t0, funkey(g)), g_nKw, g_Q);
                     int cw = 0;
 #pragma unroll
                     for (int f = 0; f < FS; ++f)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) cw += __popcll(S[f][j] & __ballot(fkey(x[f][j]) >= g));
+                        for (int j = 0; j < 4; ++j) cw += __popcll(S[f][j] & __ballot(BND ? bnd_alive(c[f][j], x[f][j], g_nKw, g_Q) : (fkey(x[f][j]) >= g)));
+                    // (BND: cw counts what the BOUND lets through, not what reaches g — that g is a value k candidates reach is counted on the
+                    // lanes' exact values, in the upper half of the same counter: a wave with fewer candidate lanes than rounds falls short there)
+                    if constexpr (BND) cw += __popcll(__ballot(lmax != 0u && lmax >= g)) << 16;
                     if (lane == 0 && cw) atomicAdd(&sh[SH_NEED], cw);
                     wg_sync<U_LDS>();
-                    const int totalA = sh[SH_NEED];
-                    const bool fits = totalA <= room / 2 && totalA >= p.k;   // uniform: k products reach g (so it is a valid cutoff) and they leave U half empty
+                    const int totalA = BND ? (sh[SH_NEED] & 0xFFFF) : sh[SH_NEED];
+                    const int reachA = BND ? (sh[SH_NEED] >> 16) : totalA;
+                    const bool fits = totalA <= room / 2 && reachA >= p.k;   // uniform: k products reach g (so it is a valid cutoff) and they leave U half empty
                     const int nfull = max(1, (room / 2) / ITEM);        // fallback: the first nfull items, everything accepted (U at most half full)
 #pragma unroll
                     for (int f = 0; f < FS; ++f) {
@@ -798,7 +908,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                         if (f < fs && (fits || (f == 0 && wave < nfull))) {
                             u64 G[4];
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) G[j] = fits ? (S[f][j] & __ballot(fkey(x[f][j]) >= g)) : S[f][j];
+                            for (int j = 0; j < 4; ++j) G[j] = fits ? (S[f][j] & __ballot(BND ? bnd_alive(c[f][j], x[f][j], g_nKw, g_Q) : (fkey(x[f][j]) >= g))) : S[f][j];
                             const int m0 = __popcll(M[f][0]), m1 = __popcll(M[f][1]), m2 = __popcll(M[f][2]), m3 = __popcll(M[f][3]);
                             if (m0 + m1 + m2 + m3) {
                                 if (pool_reserve(wpm, m0 + m1 + m2 + m3, &sh[SH_MCTR], mpcap, &sh[SH_OVF])) {
@@ -815,13 +925,14 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                                 int ubase = 0;
                                 if (lane == 0) ubase = atomicAdd(&sh[SH_CNT], n0 + n1 + n2 + n3);     // exact: no holes in this stage
                                 int pos = __builtin_amdgcn_readfirstlane(ubase);
-                                if ((G[0] >> lane) & 1ull) U[pos + mbcnt64(G[0])] = ((u64)fkey(x[f][0]) << 32) | (u64)c[f][0];
+                                // (BND: {raw dot, packed id} — the exact pass in front of the next selection turns it into {value, column})
+                                if ((G[0] >> lane) & 1ull) U[pos + mbcnt64(G[0])] = ((u64)(BND ? __float_as_uint(x[f][0]) : fkey(x[f][0])) << 32) | (u64)c[f][0];
                                 pos += n0;
-                                if ((G[1] >> lane) & 1ull) U[pos + mbcnt64(G[1])] = ((u64)fkey(x[f][1]) << 32) | (u64)c[f][1];
+                                if ((G[1] >> lane) & 1ull) U[pos + mbcnt64(G[1])] = ((u64)(BND ? __float_as_uint(x[f][1]) : fkey(x[f][1])) << 32) | (u64)c[f][1];
                                 pos += n1;
-                                if ((G[2] >> lane) & 1ull) U[pos + mbcnt64(G[2])] = ((u64)fkey(x[f][2]) << 32) | (u64)c[f][2];
+                                if ((G[2] >> lane) & 1ull) U[pos + mbcnt64(G[2])] = ((u64)(BND ? __float_as_uint(x[f][2]) : fkey(x[f][2])) << 32) | (u64)c[f][2];
                                 pos += n2;
-                                if ((G[3] >> lane) & 1ull) U[pos + mbcnt64(G[3])] = ((u64)fkey(x[f][3]) << 32) | (u64)c[f][3];
+                                if ((G[3] >> lane) & 1ull) U[pos + mbcnt64(G[3])] = ((u64)(BND ? __float_as_uint(x[f][3]) : fkey(x[f][3])) << 32) | (u64)c[f][3];
                             }
                         }
                     }
@@ -829,7 +940,8 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     if (fits) {
                         rc.have_thr = true;
                         rc.thr_key = g;
-                        cutx = fmaxf(cutx0, funkey(g));
+                        if constexpr (BND) { set_bnd_cut(); thr_incl = true; }
+                        else cutx = fmaxf(cutx0, funkey(g));
                     }
                     wg_sync<U_LDS>();
                     if (sh[SH_OVF]) failed = true;
@@ -904,7 +1016,8 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                         __builtin_amdgcn_s_setprio(3);
                         float x[4];
                         u64 M[4], S[4];
-                        s2_core(c, v, segv, cut, x, M, S);
+                        if constexpr (BND) s2_core_b(c, v, segv, b_nKw, b_Q, x, M, S);
+                        else s2_core(c, v, segv, cut, x, M, S);
                         if (cnt != ITEM) {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
@@ -952,27 +1065,27 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                         }
                         if ((S[0] | S[1]) | (S[2] | S[3])) {
                             const int n0 = __popcll(S[0]), n1 = __popcll(S[1]), n2 = __popcll(S[2]), n3 = __popcll(S[3]);
-                            if constexpr (MONO) {
-                                // straight into the candidate buffer, keyed by the raw dot
+                            if constexpr (MLIKE) {
+                                // straight into the candidate buffer, keyed by the raw dot (BND: the raw dot itself, keyed by the exact pass later)
                                 if (pool_reserve<16>(wps, n0 + n1 + n2 + n3, &sh[SH_CNT], cap, &sh[SH_OVF])) {     // small blocks: U is short of room
                                     int pos = __builtin_amdgcn_readfirstlane(wps.pos);
                                     if constexpr (U_LDS) {
                                         // (survivors are rare once the cutoff has settled: most of the four masks are empty)
-                                        if (n0) lds_push64(S[0], c[0], fkey(x[0]), pos, u_off);
+                                        if (n0) lds_push64(S[0], c[0], BND ? __float_as_uint(x[0]) : fkey(x[0]), pos, u_off);
                                         pos += n0;
-                                        if (n1) lds_push64(S[1], c[1], fkey(x[1]), pos, u_off);
+                                        if (n1) lds_push64(S[1], c[1], BND ? __float_as_uint(x[1]) : fkey(x[1]), pos, u_off);
                                         pos += n1;
-                                        if (n2) lds_push64(S[2], c[2], fkey(x[2]), pos, u_off);
+                                        if (n2) lds_push64(S[2], c[2], BND ? __float_as_uint(x[2]) : fkey(x[2]), pos, u_off);
                                         pos += n2;
-                                        if (n3) lds_push64(S[3], c[3], fkey(x[3]), pos, u_off);
+                                        if (n3) lds_push64(S[3], c[3], BND ? __float_as_uint(x[3]) : fkey(x[3]), pos, u_off);
                                     } else {
-                                        if ((S[0] >> lane) & 1ull) U[pos + mbcnt64(S[0])] = ((u64)fkey(x[0]) << 32) | (u64)c[0];
+                                        if ((S[0] >> lane) & 1ull) U[pos + mbcnt64(S[0])] = ((u64)(BND ? __float_as_uint(x[0]) : fkey(x[0])) << 32) | (u64)c[0];
                                         pos += n0;
-                                        if ((S[1] >> lane) & 1ull) U[pos + mbcnt64(S[1])] = ((u64)fkey(x[1]) << 32) | (u64)c[1];
+                                        if ((S[1] >> lane) & 1ull) U[pos + mbcnt64(S[1])] = ((u64)(BND ? __float_as_uint(x[1]) : fkey(x[1])) << 32) | (u64)c[1];
                                         pos += n1;
-                                        if ((S[2] >> lane) & 1ull) U[pos + mbcnt64(S[2])] = ((u64)fkey(x[2]) << 32) | (u64)c[2];
+                                        if ((S[2] >> lane) & 1ull) U[pos + mbcnt64(S[2])] = ((u64)(BND ? __float_as_uint(x[2]) : fkey(x[2])) << 32) | (u64)c[2];
                                         pos += n2;
-                                        if ((S[3] >> lane) & 1ull) U[pos + mbcnt64(S[3])] = ((u64)fkey(x[3]) << 32) | (u64)c[3];
+                                        if ((S[3] >> lane) & 1ull) U[pos + mbcnt64(S[3])] = ((u64)(BND ? __float_as_uint(x[3]) : fkey(x[3])) << 32) | (u64)c[3];
                                     }
                                     wps.pos = pos + n3;
                                 }
@@ -997,8 +1110,8 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     int trip = 0;
                     {
                         // (the wave's first item of this stage is the one requested during the first stage: same i0, and the stage is long enough)
-                        const bool use_pre = MONO && pre_i0 == i0 && i0 + wave < i1;      // uniform
-                        pre_i0 = -1;
+                        const bool use_pre = MLIKE && pre_i0 == i0 && i0 + wave < i1;      // uniform
+                        if (i1 > i0) pre_i0 = -1;      // (an empty round — a forced selection — leaves the request pending for the round behind it)
                         ld(0, cA, vA, nA, qA, sA, use_pre);
                     }
                     while (trip < n_trips) {      // two items (4 KiB) in flight per wave; bodies skip the sentinel
@@ -1042,7 +1155,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     // Three entries per thread and pass (four spill at the 128-register budget): a C2 row's ~2.3 k members are ONE pass (with two per thread the last
                     // 250 entries were a second pass of their own — three more rounds of round trips for a quarter of the waves
                     // while the others waited at the barrier below).
-                    constexpr int JA = MONO ? 3 : 2;      // (the general variant is over the register budget already: C3 180.2 against 178.3 ms with three)
+                    constexpr int JA = MLIKE ? 3 : 2;      // (the general variant is over the register budget already: C3 180.2 against 178.3 ms with three)
                     for (int base = 0; base < mext; base += JA * NT) {
                         // per entry: key, product, slot and the slot content last seen (0: none yet) — what to write is formed
                         // from those at the compare-and-swap (registers: a spill's reload would count in vmcnt and end the
@@ -1102,9 +1215,9 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 // ---- dense consumer.  General: spool[0, ext) and, in the last stage, the collision set's slots (same
                 // entry format) are judged into U.  MONO: only the collision set is left to do — sums above the cutoff
                 // go straight into U.  Consumed entries are zeroed (and the set's collision-bitmap bits cleared). ----
-                const int n_ent = (MONO ? 0 : ext) + (last_stage ? CSN : 0);
+                const int n_ent = (MLIKE ? 0 : ext) + (last_stage ? CSN : 0);
                 for (;;) {
-                    if constexpr (MONO) {
+                    if constexpr (MLIKE) {
                         // four slots per thread in flight, one reservation in U per wave and trip
                         for (int base = 0; base < n_ent; base += 4 * NT) {
                             u64 e[4];
@@ -1115,8 +1228,11 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                                 e[j] = (i < n_ent) ? cs[i] : 0ull;
                             }
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) want[j] = (e[j] != 0ull) && !(__uint_as_float((unsigned)e[j]) <= cutx);
-                            if (p.filter_mode == SP_SEL_MATRIX) {      // (uniform) excluded columns of this row: their sums are -inf ...
+                            for (int j = 0; j < 4; ++j) {
+                                if constexpr (BND) want[j] = (e[j] != 0ull) && bnd_alive((unsigned)(e[j] >> 32) - 1u, __uint_as_float((unsigned)e[j]), b_nKw, b_Q);
+                                else want[j] = (e[j] != 0ull) && !(__uint_as_float((unsigned)e[j]) <= cutx);
+                            }
+                            if (MONO && p.filter_mode == SP_SEL_MATRIX) {      // (uniform) excluded columns of this row: their sums are -inf ...
                                 bool odd = false;                      // ... unless an infinite product made one NaN: the list decides
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) odd |= want[j] && (__uint_as_float((unsigned)e[j]) != __uint_as_float((unsigned)e[j]));
@@ -1144,7 +1260,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                                     bool finished = true;
                                     if (want[j]) {
                                         const int pos = wbase + off[j] + mbcnt64(mm[j]);
-                                        if (pos < cap) U[pos] = ((u64)fkey(__uint_as_float((unsigned)e[j])) << 32) | (u64)col;
+                                        if (pos < cap) U[pos] = ((u64)(BND ? (unsigned)e[j] : fkey(__uint_as_float((unsigned)e[j]))) << 32) | (u64)col;
                                         else { sh[SH_RETRY] = 1; finished = false; }
                                     }
                                     if (finished) {
@@ -1196,18 +1312,63 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                         if (retry) { sh[SH_RETRY] = 0; if (n_now > cap) sh[SH_CNT] = cap; }   // failed appends over-counted
                     }
                     wg_sync<U_LDS>();         // counter fix-ups visible before the next pushes / the selection
-                    PHASE_END(PH_DRAIN);
+                    if constexpr (!BND) PHASE_END(PH_DRAIN);
                     // selection: forced when U overflowed; exact after the last stage (final top-k); between stages
                     // when U is filling up (it raises the running k-th value, which is the cutoff of the next stage)
                     const int n_eff = min(n_now, cap);
+                    if constexpr (BND) {
+                        // ---- the exact pass: U[n_keyed, n_eff) {raw dot, packed id} -> {key of the exact value, column}, or a hole when the value
+                        // fails `threshold` or cannot beat the running k-th value (s_plus.h:129-156, :201-208).  One gather per entry (packed
+                        // column terms), two entries per thread in flight; a few hundred entries per row. ----
+                        if (n_eff > n_keyed) {      // uniform
+                            constexpr int JK = 2;
+                            if (timing) ph[CT_PASSES] += (u64)(n_eff - n_keyed);      // (profiling: entries through the exact pass, low word)
+                            for (int base = n_keyed; base < n_eff; base += JK * NT) {
+                                u64 e[JK];
+                                int gc[JK];
+                                float ytv[JK], ycos[JK], ydep[JK];
+#pragma unroll
+                                for (int j = 0; j < JK; ++j) {
+                                    const int i = base + j * NT + tid;
+                                    e[j] = (i < n_eff) ? U[i] : 0ull;
+                                    gc[j] = (e[j] != 0ull) ? (int)((unsigned)e[j] & BND_ID_MASK) : 0;
+                                    ytv[j] = 0.f; ycos[j] = 0.f; ydep[j] = 0.f;
+                                }
+                                if (p.Ypack) {
+#pragma unroll
+                                    for (int j = 0; j < JK; ++j) { const float4 y = p.Ypack[gc[j]]; ytv[j] = y.x; ycos[j] = y.y; ydep[j] = y.z; }
+                                } else {
+#pragma unroll
+                                    for (int j = 0; j < JK; ++j) {
+                                        if (p.l1 != 0.f) ytv[j] = p.Ytv[gc[j]];
+                                        if (p.l2 != 0.f) ycos[j] = p.Ycos[gc[j]];
+                                        if (p.l3 != 0.f) ydep[j] = p.Ydep[gc[j]];
+                                    }
+                                }
+#pragma unroll
+                                for (int j = 0; j < JK; ++j) {
+                                    if (e[j] != 0ull) {
+                                        const float val = rc.epi(__uint_as_float((unsigned)(e[j] >> 32)), ytv[j], ycos[j], ydep[j]);
+                                        const unsigned key = fkey(val);
+                                        const bool ok = (val >= p.threshold) && (!rc.have_thr || key > rc.thr_key || (thr_incl && key == rc.thr_key));
+                                        U[base + j * NT + tid] = ok ? (((u64)key << 32) | (u64)(unsigned)gc[j]) : 0ull;
+                                    }
+                                }
+                            }
+                            wg_sync<U_LDS>();
+                        }
+                        n_keyed = n_eff;
+                        PHASE_END(PH_DRAIN);      // (the exact pass is this variant's judge)
+                    }
                     const bool want_sel = retry || (last_stage ? (n_eff > p.k) : (n_eff > p.k && (!rc.have_thr || force_sel || 2 * n_eff > cap + p.k)));
                     force_sel = false;
                     if (want_sel) {
+                        if (BND && timing) ph[CT_PASSES] += 1ull << 32;             // (profiling: selections, high word)
                         long long thr_new;
                         if (cap <= SEL_E * NT) thr_new = select_fast<NT, true, SEL_E, U_LDS, true>(U, hist4, sh, p.k, last_stage && !retry, rc.have_thr ? rc.thr_key : 0u);
                         else {
                             thr_new = compact_topk<NT>(U, hist4, sh, p.k);
-                            if constexpr (MONO) {     // block-wise reservations: nothing stale may stay behind the kept entries
+                            if constexpr (MLIKE) {     // block-wise reservations: nothing stale may stay behind the kept entries
                                 if (thr_new >= 0) {
                                     for (int i = sh[SH_CNT] + tid; i < n_eff; i += NT) U[i] = 0ull;
                                     wg_sync<U_LDS>();
@@ -1218,8 +1379,10 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                             rc.have_thr = true;
                             rc.thr_key = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)thr_new);
                             if constexpr (MONO) cutx = fmaxf(cutx0, funkey(rc.thr_key));
+                            else if constexpr (BND) set_bnd_cut();
                             else rc.set_cut(p.threshold);
                         }
+                        if constexpr (BND) { n_keyed = min(sh[SH_CNT], cap); if (thr_new >= 0) thr_incl = false; }      // (the selection compacted what it kept: all of it exact)
                         PHASE_END(PH_SELECT);
                     }
                     if (!retry) break;  // uniform
@@ -1233,15 +1396,15 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 // after the selection-free first stage)
                 const float cnt_u = (float)max(2 * p.k, min(sh[SH_CNT], cap));
                 float ch = rc.have_thr ? fmaxf((float)ITEM, 2.f * pos * left / cnt_u) : (float)room;
-                if constexpr (MONO) {
+                if constexpr (MLIKE) {
                     // no k-th value yet, but the `threshold` parameter prunes (cutx0): U holds what passed of the `pos` products offered so
                     // far — the rest of the row passes at most at that rate (segments come in descending weight).  Without this a row
                     // that never collects k values above the threshold swept `room` products per stage: 45 stages at the C2 size.
                     if (!__builtin_amdgcn_readfirstlane((int)rc.have_thr)) {      // (a scalar branch: rows with a k-th value — the rule — skip all of it)
-                        if (cutx0 > -__builtin_inff()) ch = fmaxf(ch, 0.5f * pos * left * __builtin_amdgcn_rcpf((float)max(1, min(sh[SH_CNT], cap))));
+                        if (BND ? (b_t0 > 0.f) : (cutx0 > -__builtin_inff())) ch = fmaxf(ch, 0.5f * pos * left * __builtin_amdgcn_rcpf((float)max(1, min(sh[SH_CNT], cap))));
                     }
                 }
-                if (!MONO) ch = fmaxf(ch, (float)room);
+                if (!MLIKE) ch = fmaxf(ch, (float)room);
                 chunk_items = max(1, (int)fminf(ch * (1.f / ITEM), 1e6f));
             }
         }
@@ -1262,8 +1425,8 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             const int n_sel = min(sh[SH_CNT], p.k);
             const long long o = (long long)slot_i * (long long)p.k;
             int n_out = n_sel;
-            if constexpr (MONO) {
-                // epilogue on the winners (s_plus.h:129-156 with the column term already folded in: val = xy / den, or
+            if constexpr (MLIKE) {
+                // (BND: the entries hold exact values already; MONO:) epilogue on the winners (s_plus.h:129-156 with the column term already folded in: val = xy / den, or
                 // the raw dot), exact threshold test, compaction of what passes to the front of the slot
                 // (compaction counter: SH_PCTR, which the monotone variant leaves at zero — no reset, no barrier in front of the loop.
                 // LDS U: every thread zeroes the entries it has read — U's storage is part of the next row's bitmap; every selection
@@ -1277,7 +1440,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     if (OWN_CLEAR && j < n_cl) U[j] = 0ull;
                     const float xv = funkey((unsigned)(it >> 32));
                     float val = xv;
-                    if (any_norm) val = (den != 0.f) ? xv / den : 0.f;
+                    if (MONO && any_norm) val = (den != 0.f) ? xv / den : 0.f;
                     const bool keep = (it != 0ull) && (val >= p.threshold);
                     const u64 m = __ballot(keep);
                     if (m) {
@@ -1317,7 +1480,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             if (tid == 0 && p.counts) p.counts[slot_i] = n_out;
             // (MATRIX filter: every excluded column has a slot in the collision set — its pseudo-member — so the set's scan has
             // cleared its mark like any other column's)
-            if ((U_LDS || MONO) && !(MONO && U_LDS)) {      // (MONO with U in LDS: cleared in the loop above)
+            if ((U_LDS || MLIKE) && !(MLIKE && U_LDS)) {      // (MONO / BND with U in LDS: cleared in the loop above)
                 // U's storage is part of the next row's bitmap (LDS) / holes must read zero (MONO).  Every selection zeroes
                 // what lies behind the entries it keeps, so only the first k entries can be non-zero here.
                 wg_sync<U_LDS>();     // U read before it is cleared
@@ -1344,7 +1507,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             }
             for (int i = tid; i < (CBM_BYTES + PRE_BYTES + A_bytes) / 16; i += NT) ((int4 *)smem)[i] = make_int4(0, 0, 0, 0);
             for (int i = tid; i < 1024; i += NT) hist4[i] = 0;
-            if (MONO && !U_LDS) { for (int i = tid; i < cap / 2; i += NT) ((int4 *)U)[i] = make_int4(0, 0, 0, 0); }
+            if (MLIKE && !U_LDS) { for (int i = tid; i < cap / 2; i += NT) ((int4 *)U)[i] = make_int4(0, 0, 0, 0); }
             if (timing) ph[CT_ROWS_FALLBACK] += 1;
         }
         // rotate the row pipeline (descriptors are wave-uniform: keep them in scalar registers)
@@ -1375,7 +1538,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
         // writes in front of that barrier — the counters of thread 0, the item records, the sort scratch — touch nothing this row's
         // tail still reads: the last reads of sh[] lie in front of a barrier of the write-out.  The one variant whose write-out has no
         // barrier behind its read of SH_CNT — general epilogue, U in global memory — keeps this one)
-        if (!(U_LDS || MONO)) wg_sync<U_LDS>();
+        if (!(U_LDS || MLIKE)) wg_sync<U_LDS>();
         PHASE_END(PH_OUTPUT);
     }
     if (timing) {
