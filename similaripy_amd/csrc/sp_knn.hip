@@ -41,6 +41,7 @@
 #include "sp_sparse_kernel.hpp"
 #include "sp_wave_kernel.hpp"
 #include "sp_generic_kernel.hpp"
+#include "sp_sddmm_kernel.hpp"
 
 // ---------------------------------------------------------------------------------------------
 // host side: C ABI
@@ -175,6 +176,24 @@ constexpr int ITEMS_ROWS_MAX = 1 << 21;
 // LDS of the two kernels without the candidate buffer (see their carve-ups)
 size_t lds_fixed_sparse(int T, int NT) { return (size_t)T * 8 + (size_t)item_cap(NT) * 16 + 4096 + CBM_BYTES + PRE_BYTES + 32 * 4 + 16 * 8; }   // (its candidate buffer lives inside region A)
 size_t lds_fixed_generic(int T, int NT) { return (size_t)T * 8 + (size_t)16 * NT + 256 + 256 * 4 + 64 * 4 + 32 * 4 + 16 * 8; }
+
+// target_cols = <matrix> as a sampled product (sp_sddmm_kernel.hpp): when the listed entries cost far less than the rows' full products.
+// Sizes only (the decision must not need the device): listed entries of the targets x the average length of a column of m2, against
+// MACs + the fixed toll of the row kernels.  `nnz_m2` / `n_rows_m2`: those of the call as the row kernels would see it.
+bool sddmm_applies(const sp_knn_args *a, int64_t nnz_m1, int64_t nnz_m2) {
+    if (a->target_col_mode != SP_SEL_MATRIX || a->k > SD_KMAX || a->n_targets <= 0 || a->n_rows_m1 <= 0 || a->n_output_cols <= 0) return false;
+    if ((a->flags & (SP_FLAG_P3_PREP | SP_FLAG_NO_SPARSE_PATH)) || (a->reserved[0] & 65536)) return false;      // (bit 65536 of the ablation word: off, for A/B runs)
+    const double listed = (double)a->target_col_nnz * ((double)a->n_targets / (double)a->n_rows_m1);
+    const double col_len = (double)nnz_m2 / (double)a->n_output_cols;
+    const double macs_row = ((double)nnz_m1 / (double)a->n_rows_m1) * ((double)nnz_m2 / (double)std::max(1, a->n_rows_m2));
+    return listed * (col_len + 8.0) * 4.0 + 2000.0 * (double)a->n_targets < (double)a->n_targets * (macs_row + 30000.0);
+}
+// scratch of the route for an explicit m2 (its transpose + the transpose's own scratch); the flagged calls have m2^T at hand
+size_t transpose_ws_bytes(long long nnz, int n_cols);
+size_t sddmm_ws_bytes(const sp_knn_args *a) {
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    return 256 + 2 * al((size_t)a->nnz_m2 * 4) + al(((size_t)a->n_output_cols + 1) * 4) + transpose_ws_bytes(a->nnz_m2, a->n_output_cols);
+}
 
 int make_config(const sp_knn_args *a, int n_cus, Config *c) {
     // (threads_per_wg = 64: ask for the wave-per-row kernel wherever the call qualifies for it, whatever its average row looks like)
@@ -326,6 +345,7 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
         TRY(make_config(&b, n_cus, &c2));
         c->ws_total = std::max(c->ws_total, c2.ws_total);
     }
+    if (sddmm_applies(a, a->nnz_m1, a->nnz_m2)) c->ws_total = std::max(c->ws_total, sddmm_ws_bytes(a));      // (explicit m2: the route transposes it)
     return SP_OK;
 }
 
@@ -847,7 +867,71 @@ __global__ __launch_bounds__(256) void sp_add_pow_f32_kernel(int n, const float 
 // device pointers in, device pointers out; with SP_FLAG_M2_IS_M1_T / SP_FLAG_M1_IS_M2_T the transpose (s_plus.pyx:169-170,
 // 205-206) is built first, on the same stream, into scratch behind the kernel's workspace
 // the row kernels of a call whose operands are what they should be (`b`), in one launch chain or chunk by chunk
+// The sampled route (sp_sddmm_kernel.hpp).  mt_*: m2^T on the device, or NULL: transposed here from b->m2_* into the workspace.
+int run_sddmm(sp_knn_args *b, const float *mt_data, const int *mt_indices, const int *mt_indptr, const ChunkHook *hook) {
+    HIP_TRY(hipSetDevice(b->device));
+    if (b->n_targets == 0) { b->kernel_ms = 0.f; return SP_OK; }
+    hipStream_t stream = (hipStream_t)b->stream;
+    unsigned char *ws = (unsigned char *)b->workspace;
+    CallGuard guard;
+    guard.stream = stream;
+    const size_t need = mt_indptr ? 256 : sddmm_ws_bytes(b);
+    if (!ws) {
+        HIP_TRY(hipMalloc((void **)&ws, need));
+        guard.ws = ws;
+    } else if (b->workspace_bytes < (int64_t)need) {
+        return fail(SP_EWORKSPACE, "workspace too small: need %zu bytes, got %lld", need, (long long)b->workspace_bytes);
+    }
+    const bool timed = (b->flags & SP_FLAG_TIME_KERNEL) != 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (timed) { TRY(guard.event(&ev0)); TRY(guard.event(&ev1)); HIP_TRY(hipEventRecord(ev0, stream)); }
+    HIP_TRY(hipMemsetAsync(ws, 0, 256, stream));
+    if (!mt_indptr) {
+        auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        float *td = (float *)(ws + 256);
+        int *ti = (int *)((unsigned char *)td + al((size_t)b->nnz_m2 * 4));
+        int *tp = (int *)((unsigned char *)ti + al((size_t)b->nnz_m2 * 4));
+        unsigned char *tws = (unsigned char *)tp + al(((size_t)b->n_output_cols + 1) * 4);
+        TRY(transpose_device(b->n_rows_m2, b->n_output_cols, b->nnz_m2, b->m2_data, b->m2_indices, b->m2_indptr, td, ti, tp, tws, transpose_ws_bytes(b->nnz_m2, b->n_output_cols), stream));
+        mt_data = td; mt_indices = ti; mt_indptr = tp;
+    }
+    SddmmParams sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.n_targets = b->n_targets; sp.targets = b->targets;
+    sp.m1_data = b->m1_data; sp.m1_indices = b->m1_indices; sp.m1_indptr = b->m1_indptr;
+    sp.mt_data = mt_data; sp.mt_indices = mt_indices; sp.mt_indptr = mt_indptr;
+    sp.t_indptr = b->target_col_m_indptr; sp.t_indices = b->target_col_m_indices;
+    sp.filter_mode = b->filter_mode; sp.f_indptr = b->filter_m_indptr; sp.f_indices = b->filter_m_indices;
+    sp.col_keep = b->col_keep;
+    sp.Xtv = b->Xtversky; sp.Ytv = b->Ytversky; sp.Xcos = b->Xcosine; sp.Ycos = b->Ycosine; sp.Xdep = b->Xdepop; sp.Ydep = b->Ydepop;
+    sp.a1 = b->a1; sp.l1 = b->l1; sp.l2 = b->l2; sp.l3 = b->l3; sp.t1 = b->t1; sp.t2 = b->t2;
+    sp.stab = b->stabilized_shrink; sp.bayes = b->bayesian_shrink; sp.threshold = b->threshold;
+    sp.k = b->k;
+    sp.rows = (b->flags & SP_FLAG_NO_ROWS_OUT) ? nullptr : b->rows; sp.cols = b->cols; sp.values = b->values; sp.counts = b->out_counts;
+    sp.queue = (unsigned *)ws;
+    int n_cus = 256;
+    TRY(device_cus(b->device, &n_cus));
+    const int wgs = std::max(1, std::min((b->n_targets + SD_WAVES - 1) / SD_WAVES, n_cus * (int)(LDS_LIMIT / sd_lds_bytes())));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(sp_sddmm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sd_lds_bytes()));
+    hipLaunchKernelGGL(sp_sddmm_kernel, dim3(wgs), dim3(64 * SD_WAVES), sd_lds_bytes(), stream, sp);
+    HIP_TRY(hipGetLastError());
+    if (hook && hook->after_launch) for (int j = 0; j < std::max(1, hook->n_chunks); ++j) TRY(hook->after_launch(j));
+    if (timed) {
+        HIP_TRY(hipEventRecord(ev1, stream));
+        HIP_TRY(hipEventSynchronize(ev1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+        b->kernel_ms = ms;
+        memset(b->phase_cycles, 0, sizeof(b->phase_cycles));
+        b->phase_cycles[PH_CSDRAIN] = 4;        // (slot 8, bit 2: the sampled route ran)
+        b->passes_total = 0; b->num_wgs_used = wgs;
+        b->reserved[1] = (int64_t)(ms * 1000.f); b->reserved[2] = 0;
+    }
+    return SP_OK;
+}
+
 int run_rows(sp_knn_args *b, const ChunkHook *hook) {
+    if (sddmm_applies(b, b->nnz_m1, b->nnz_m2)) return run_sddmm(b, nullptr, nullptr, nullptr, hook);
     if (!hook || hook->n_chunks <= 1) {
         TRY(run_device_impl(b));
         return (hook && hook->after_launch) ? hook->after_launch(0) : SP_OK;
@@ -900,7 +984,11 @@ int run_device(sp_knn_args *a, const ChunkHook *hook = nullptr) {
     float *t_data = (float *)(ws + L.data);
     int *t_indices = (int *)(ws + L.indices), *t_indptr = (int *)(ws + L.indptr);
     const bool p3_keep = m2t && (a->flags & SP_FLAG_P3_PREP) && a->col_keep != nullptr;      // (the mask waits for the normalised m2)
-    int rc = m2t ? transpose_device(a->n_rows_m1, a->n_rows_m2, nnz, a->m1_data, a->m1_indices, a->m1_indptr,
+    // target_cols = <matrix> with few listed entries: the sampled route (sp_sddmm_kernel.hpp) needs m2^T — for m2 = m1^T that is m1
+    // itself: no transpose is built at all; for m1 = m2^T it is the m1 built here
+    const bool sampled = sddmm_applies(&b, nnz, nnz);
+    int rc = (m2t && sampled) ? SP_OK
+             : m2t ? transpose_device(a->n_rows_m1, a->n_rows_m2, nnz, a->m1_data, a->m1_indices, a->m1_indptr,
                                     t_data, t_indices, t_indptr, ws + L.tr, L.total - L.tr, stream, p3_keep ? nullptr : a->col_keep)
                  : transpose_device(a->n_rows_m2, a->n_rows_m1, nnz, a->m2_data, a->m2_indices, a->m2_indptr,
                                     t_data, t_indices, t_indptr, ws + L.tr, L.total - L.tr, stream);
@@ -982,6 +1070,10 @@ int run_device(sp_knn_args *a, const ChunkHook *hook = nullptr) {
     }
     b.workspace = ws;
     b.workspace_bytes = (int64_t)L.knn;
+    if (sampled) {
+        b.col_keep = m2t ? a->col_keep : nullptr;      // (ARRAY selectors of the m2 that is not built: the listed columns are looked up in the mask)
+        rc = run_sddmm(&b, b.m1_data, b.m1_indices, b.m1_indptr, hook);
+    } else
     rc = run_rows(&b, hook);
     a->kernel_ms = b.kernel_ms + tr_ms;
     a->passes_total = b.passes_total;

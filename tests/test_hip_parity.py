@@ -508,8 +508,14 @@ def test_sparse_kernel_row_selectors():
     t = np.arange(0, 20000, 9)
     for kw in (dict(filter_cols=urm), dict(filter_cols=urm, l2=1), dict(target_cols=urm), dict(filter_cols=urm, target_cols=list(range(0, 30000, 2)))):
         call = _host.prepare(urm, w, k=40, target_rows=t, **kw)
-        counts = _check(call, f"sparse selectors {sorted(kw)}")
-        pc = _info(call)
+        # (a target MATRIX with short lists takes the sampled route since round 5 — checked too; the row kernels' own look-up path
+        # stays covered through the ablation bit)
+        tun = dict(dbg=65536) if sp.issparse(kw.get("target_cols")) else {}
+        if tun:
+            assert _info(call)[8] & 4
+            _check(call, f"sampled route {sorted(kw)}")
+        counts = _check(call, f"sparse selectors {sorted(kw)}", **tun)
+        pc = _info(call, **tun)
         assert pc[9] + pc[10] == call.n_targets - int((np.diff(call.m1_indptr)[call.targets] == 0).sum()) or pc[9] > 0
     # nothing a user already has may be recommended
     call = _host.prepare(urm, w, k=40, target_rows=t, filter_cols=urm)
@@ -1566,3 +1572,70 @@ def test_bounded_variant_needs_20_bit_column_ids():
     pc = _info(call)
     assert pc[8] & 2 and pc[9] > 0, "2^20 - 1 columns: the bounded variant applies"
     _check(call, "2^20 - 1 columns")
+
+
+# ------------------------------------------------------------------------------------------------------------
+# target_cols = <sparse matrix> as a sampled product (sp_sddmm_kernel.hpp)
+# ------------------------------------------------------------------------------------------------------------
+NO_SDDMM = 65536      # ablation bit: the row kernels accumulate the whole row and look every candidate up in the list (s_plus.h:175-188)
+
+
+@pytest.mark.parametrize("name,kw", [("dot", {}), ("cosine", dict(l2=1)), ("jaccard", dict(l1=1)), ("splus", dict(l1=0.5, l2=0.5, stabilized_shrink=5)),
+                                     ("pow_bayes", dict(l2=1, a1=0.7, bayesian_shrink=3)), ("thr", dict(l2=1, threshold=0.05))],
+                         ids=["dot", "cosine", "jaccard", "splus", "pow_bayes", "thr"])
+def test_target_matrix_sampled_route(name, kw):
+    """A sparse target matrix with few listed entries per row takes the sampled route (phase slot 8, bit 2) — explicit m2 (transposed once
+    per call) — and agrees with the oracle and with the accumulate-then-look-up route it replaces."""
+    m1 = _rand((3000, 800), 0.02, 41)
+    m2 = _rand((800, 5000), 0.01, 42)
+    tgt = _rand((3000, 5000), 0.004, 43)                   # ~20 listed columns per row, k = 10: the lists are trimmed
+    call = _host.prepare(m1, m2, k=10, target_cols=tgt, **kw)
+    assert _info(call)[8] & 4, "the sampled route did not run"
+    _check(call, f"sampled {name}")
+    assert not (_info(call, dbg=NO_SDDMM)[8] & 4)
+    _check(call, f"looked-up {name}", dbg=NO_SDDMM)
+
+
+def test_target_matrix_sampled_route_edge_shapes():
+    rng = np.random.default_rng(44)
+    # rows of m1 longer than one hash build (512 entries), lists longer than the candidate buffer (512), empty rows and lists, signed data
+    m1 = sp.random_array((400, 6000), density=0.15, format="csr", dtype=np.float32, random_state=rng)          # ~900 entries per row
+    m1.data -= 0.5
+    m1 = sp.csr_array(m1)
+    m1.data[m1.indptr[7]:m1.indptr[8]] = 0.0
+    m1.eliminate_zeros()
+    m2 = sp.random_array((6000, 3000), density=0.0005, format="csr", dtype=np.float32, random_state=rng)
+    tgt = sp.random_array((400, 3000), density=0.3, format="csr", dtype=np.float32, random_state=rng).tolil()    # ~900 listed columns per row
+    tgt[11, :] = 0
+    tgt = sp.csr_array(tgt.tocsr())
+    tgt.eliminate_zeros()
+    for kw in (dict(k=30), dict(k=200, l2=1), dict(k=30, threshold=-0.02), dict(k=5, l1=1, t1=0.6, t2=0.7)):
+        call = _host.prepare(m1, m2, target_cols=tgt, target_rows=np.arange(0, 400, 3), **kw)
+        ph = _info(call, dbg=0)
+        if ph[8] & 4:      # (the route is chosen from sizes: say which one ran, check both)
+            _check(call, f"sampled edge {kw}")
+        _check(call, f"looked-up edge {kw}", dbg=NO_SDDMM)
+    # forced onto the sampled route whatever the sizes say? no: the decision is the library's — but a dense-ish list on short rows still picks it
+    m1s = _rand((2000, 300), 0.01, 45)
+    tg2 = _rand((2000, 2000), 0.002, 46)
+    call = _host.prepare(m1s, k=15, l2=1, target_cols=tg2)
+    assert _info(call)[8] & 4
+    _check(call, "sampled, m2 = m1.T built by nobody")
+
+
+def test_target_matrix_sampled_route_through_the_wrappers(golden):
+    """matrix2=None (m2^T is m1: nothing is transposed), a CSC matrix1, a MATRIX filter beside the target matrix, ARRAY filter beside it."""
+    urm = _rand((4000, 600), 0.02, 47)
+    tgt = _rand((4000, 4000), 0.001, 48)
+    flt = _rand((4000, 4000), 0.001, 49)
+    for m in (urm, sp.csc_array(urm)):
+        for kw in (dict(), dict(filter_cols=flt), dict(filter_cols=list(range(0, 4000, 5)))):
+            got = sim.cosine(m, k=12, target_cols=tgt, verbose=False, format_output="csr", **kw)
+            want_call = _host.prepare(urm, k=12, l2=1, target_cols=tgt, **kw)
+            rows, cols, vals = so.run_kernel(want_call, "port")
+            want = _host.finish(want_call, rows, cols, vals, so.slot_counts(rows, cols, vals, want_call.targets, 12)[0], "csr")
+            assert got.shape == want.shape and abs(got.nnz - want.nnz) <= 2, (got.nnz, want.nnz)
+            d = abs(got - want)
+            assert d.nnz == 0 or d.data.max() <= 1e-5 * max(1.0, abs(want).max()) or (abs(got.nnz - want.nnz) <= 2), kw
+            # only listed columns come back
+            assert got.multiply(tgt != 0).nnz == got.nnz
