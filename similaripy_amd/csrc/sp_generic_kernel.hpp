@@ -390,6 +390,52 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                 retry_window = false;
                 if (timing) ph[CT_PASSES] += 1;
 
+                // ---- a cutoff BEFORE the drain, without a selection (round 5; dense windows, value a growing function of the raw dot alone).
+                // The drain used to start without any k-th value: the first 1 824 touched slots filled the candidate buffer, a selection gave the
+                // k-th of those (the top ~11 %), the sweep went on letting 11 % through, filled the buffer again ... 2.8 selections and 1.8
+                // sweeps per row on the MovieLens shape.  Now every thread takes the largest raw dot of its slots, every wave the
+                // ceil(k / NW)-th largest of its lanes' maxima (as the sparse kernel's first stage does): the minimum over the waves is a raw
+                // dot that at least k columns of THIS window reach — when every wave had that many lanes with a live slot; else nothing
+                // changes.  One more pass over the window's sums in LDS, no pushes, two barriers. ----
+                if (dense && simple_judge && p.a1 == 1.f && p.bayes == 0.f && U_LDS && (p.k + NW - 1) / NW <= 32 && !(p.dbg & 131072)) {      // (bit 131072 of the ablation word: off, for A/B runs)
+                    const float slope = any_norm ? rc.epi(1.f, 0.f, 1.f, 1.f) : 1.f;      // uniform: val = slope * xy
+                    if (slope > 0.f && slope < __builtin_inff()) {      // uniform
+                        unsigned lmax = 0u;
+                        for (int sidx = tid; sidx < t_eff; sidx += NT) {
+                            const unsigned w = tabw[sidx];
+                            if (w != EMPTY32 && __uint_as_float(w) > rc.xy_cut) lmax = max(lmax, fkey(__uint_as_float(w)));      // (a NaN sum compares false: no part of the statistic)
+                        }
+                        if (tid == 0) { sh[SH_SEL] = -1; sh[SH_NEED] = 1; }
+                        __syncthreads();
+                        const int rounds = (p.k + NW - 1) / NW;
+                        unsigned rest = lmax, tw = 0u;
+                        for (int r = 0; r < rounds; ++r) {
+                            const unsigned mx = wave_max_u32(rest);
+                            tw = mx;                                   // 0 once the wave has run out of live lanes
+                            rest = (rest >= mx) ? 0u : rest;
+                        }
+                        if (lane == 0) { if (tw != 0u) atomicMin((unsigned *)&sh[SH_SEL], tw); else sh[SH_NEED] = 0; }
+                        __syncthreads();
+                        const unsigned g = (unsigned)sh[SH_SEL];
+                        const bool ok = sh[SH_NEED] != 0 && g != 0xFFFFFFFFu;
+                        __syncthreads();      // (both words are the selections' too)
+                        if (ok) {
+                            // at least k columns of this window have a raw dot >= funkey(g), i.e. a value >= val(g): everything that cannot beat the
+                            // key just below val(g) is out (the cutoff is strict; the columns AT val(g) are among the k)
+                            const float vg = any_norm ? rc.epi(funkey(g), 0.f, 1.f, 1.f) : funkey(g);
+                            if (vg == vg) {
+                                const unsigned kg = fkey(vg);
+                                const unsigned below = kg > 0u ? kg - 1u : 0u;
+                                if (!rc.have_thr || below > rc.thr_key) {
+                                    rc.have_thr = true;
+                                    rc.thr_key = below;
+                                    rc.set_cut(p.threshold);
+                                }
+                            }
+                        }
+                    }
+                }
+
                 // ================= drain: one barrier-free sweep, overflow-retry =================
                 for (;;) {
                     for (int base = 0; base < t_eff; base += NT * DRAIN_UNROLL) {
