@@ -72,7 +72,9 @@ extern "C" {
                                      eliminate_zeros s_plus.pyx:424): any order of `targets`, repeats included (a row asked for twice holds its
                                      slots one after the other, as the reference's stable counting sort leaves them); csr_indptr receives the
                                      n_rows_m1 + 1 row pointers, the first csr_nnz entries of `cols` / `values` the column ids and values of
-                                     the non-zero entries in row order (slot order inside a row); rows / out_counts are not written */
+                                     the non-zero entries in row order (slot order inside a row); rows / out_counts are not written.
+                                     With a MATRIX target selector the result cannot hold more than target_col_nnz entries: `cols` / `values`
+                                     then need only min(n_targets * k, target_col_nnz) entries when the call runs on ONE device (nothing beyond csr_nnz is written or touched) */
 #define SP_FLAG_P3_PREP      1024u /* with SP_FLAG_M2_IS_M1_T or SP_FLAG_M1_IS_M2_T: the preprocessing of p3alpha / rp3beta (similarity.py:410-415, 477-483;
                                      normalization.pyx:131-161) on the device: the rows of m1 and the rows of m2 = m1^T are divided by
                                      their L1 norms, then every entry is raised to p3_alpha.  The caller's matrix is not modified. */

@@ -660,8 +660,13 @@ def run_hip(call: KernelCall, device: Optional[int] = None, table_slots: int = 0
     n, k = call.n_targets, call.k
     want_rows = want_rows and not csr_out
     rows = np.empty(n * k, dtype=np.int32) if want_rows else None      # (slot i's rows are all targets[i]: CSR assembly does not read them)
-    cols = np.empty(n * k, dtype=np.int32)
-    values = np.empty(n * k, dtype=np.float32)
+    # (CSR out with a MATRIX target selector: at most one entry per listed column — the library writes, and touches, no more than that;
+    # 800 MB of slot arrays for 200 k entries cost 40 ms of page faults and unmapping at the C2 size)
+    n_out = n * k
+    if csr_out and call.target_col_mode == MODE_MATRIX and devices is None:      # (several devices write their pieces at slot offsets)
+        n_out = min(n_out, int(call.target_col_m_indices.shape[0]))
+    cols = np.empty(n_out, dtype=np.int32)
+    values = np.empty(n_out, dtype=np.float32)
     counts = np.empty(n, dtype=np.int32) if not csr_out else None
     csr_indptr = np.zeros(call.n_rows_m1 + 1, dtype=np.int32) if csr_out else None
 

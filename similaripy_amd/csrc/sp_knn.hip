@@ -263,12 +263,12 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
     // Bounded variant of the sparse kernel (MODE 2): a general epilogue whose value is bounded through ONE per-column term carried in the
     // upper 12 bits of the m2 column ids.  Needs: column terms that are live and not folded, non-negative weights (the bound), a1 = 1, no
     // Bayesian factor, a denominator that does not grow with the raw dot (t1 + t2 >= 1 whenever l1 != 0), threshold >= 0 (negative values
-    // are never wanted), no per-row selector matrices, ids that leave 12 bits free.  What it cannot serve runs on the general variant.
+    // are never wanted), no per-row TARGET matrix (a MATRIX filter goes through the collision bitmap, as in the monotone variant), ids that leave 12 bits free.  What it cannot serve runs on the general variant.
     {
         const bool live = (a->l1 != 0.f && a->t2 != 0.f) || a->l2 != 0.f || a->l3 != 0.f;
         const bool nonneg = a->l1 >= 0.f && a->l2 >= 0.f && a->l3 >= 0.f && a->t1 >= 0.f && a->t2 >= 0.f && a->stabilized_shrink >= 0.f;
         c->bnd = !c->mono && !c->fold && live && nonneg && a->a1 == 1.f && a->bayesian_shrink == 0.f && !(a->l1 * (1.f - a->t1 - a->t2) > 0.f) &&
-                 a->threshold >= 0.f && a->filter_mode != SP_SEL_MATRIX && a->target_col_mode != SP_SEL_MATRIX &&
+                 a->threshold >= 0.f && a->target_col_mode != SP_SEL_MATRIX &&
                  a->n_output_cols > 0 && (long long)a->n_output_cols < (1LL << BND_ID_BITS) && a->nnz_m2 > 0 &&
                  !(a->flags & SP_FLAG_NO_SPARSE_PATH) && !(a->reserved[0] & 32768);      // (bit 32768 of the ablation word: off, for A/B runs)
         c->ws_bnd_colpack = c->ws_bnd_ids = 0;
@@ -742,12 +742,12 @@ int run_device_impl(sp_knn_args *a, const uint64_t *sig_override = nullptr) {
             const int item_blocks = std::max(1, std::min((a->n_targets + 3) / 4, n_cus * 32));     // 4 rows (waves) per block and trip
             hipLaunchKernelGGL(sp_row_items_kernel, dim3(item_blocks), dim3(256), 0, stream, (const unsigned *)kp.qcount, c.items_rows, (int4 *)desc_s,
                                a->m1_indices, a->m1_data, a->m2_indptr, (int4 *)ws_items, c.NT_s == 256 ? 1 : 0,
-                               (c.mono && a->filter_mode == SP_SEL_MATRIX) ? a->filter_m_indptr : nullptr);
+                               ((c.mono || c.bnd) && a->filter_mode == SP_SEL_MATRIX) ? a->filter_m_indptr : nullptr);
             HIP_TRY(hipGetLastError());
             if (c.wave) {
                 hipLaunchKernelGGL(sp_row_items_kernel, dim3(item_blocks), dim3(256), 0, stream, (const unsigned *)cp.qcount_w, c.items_rows, (int4 *)desc_w,
                                    a->m1_indices, a->m1_data, a->m2_indptr, (int4 *)ws_items, 1,
-                                   (c.mono && a->filter_mode == SP_SEL_MATRIX) ? a->filter_m_indptr : nullptr);
+                                   ((c.mono || c.bnd) && a->filter_mode == SP_SEL_MATRIX) ? a->filter_m_indptr : nullptr);
                 HIP_TRY(hipGetLastError());
             }
             kp.items_g = (const int4 *)ws_items; kp.items_rows = c.items_rows;
@@ -1485,9 +1485,12 @@ int run_host(sp_knn_args *a) {
     // output arrays so that the copies back do not pay for the page faults.  Output-only memory: writing zeros is harmless.
     HostPrefault prefault;
     if (want_rows) prefault.fill_rows(a->rows, a->targets, nt, k);
-    if (nt * k >= (size_t)1 << 22) {
-        prefault.add(a->cols, nt * k * sizeof(int32_t));
-        prefault.add(a->values, nt * k * sizeof(float));
+    // (SP_FLAG_CSR_OUT with a MATRIX target selector: a row keeps at most the columns its list names — the result has at most
+    // target_col_nnz entries, and only that much of cols / values is ever written: see sp_knn.h)
+    const size_t out_entries = (csr_out && tm) ? std::min(nt * k, (size_t)std::max<int64_t>(0, a->target_col_nnz)) : nt * k;
+    if (out_entries >= (size_t)1 << 22) {
+        prefault.add(a->cols, out_entries * sizeof(int32_t));
+        prefault.add(a->values, out_entries * sizeof(float));
         prefault.start();
     }
     // Large results leave in CHUNKS: the target list is cut into four sub-launches (the passes over m2 run once), and while chunk j + 1

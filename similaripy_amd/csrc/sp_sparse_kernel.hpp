@@ -268,7 +268,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 if (tid == NT - 1) items[n_pre] = make_int4((int)OOB_SOFFSET, 0, 0, (int)macs32);
                 if (tid >= 1 && tid <= n_rec) ((u32x4 *)items)[tid - 1] = recC;
                 if (REC2 && tid + NT <= n_rec) ((u32x4 *)items)[tid + NT - 1] = recC2;
-                if (MONO && tid == 0) { shx[0] = (int)recC.x; shx[1] = (int)recC.y; }
+                if (MLIKE && tid == 0) { shx[0] = (int)recC.x; shx[1] = (int)recC.y; }
             }
             wg_sync<U_LDS>();
             if (!p.static_sched) q_nn = sh[SH_QA];
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             // from here on; other rows read the list where they need it.
             int my_fc = -1;
             bool f_regs = false;      // uniform: the list (<= NT columns) is in my_fc
-            if constexpr (MONO) {
+            if constexpr (MLIKE) {
                 if (p.filter_mode == SP_SEL_MATRIX && n_pre > 0) {
                     const int f0 = shx[0], fl = shx[1];
                     if (fl <= NT) {
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     trip += 2;
                 }
             }
-            if constexpr (MONO) {
+            if constexpr (MLIKE) {
                 // MATRIX filter (s_plus.h:159-171): the row's excluded columns are marked in the collision bitmap, so all
                 // their products gather in the collision set, where the excluded columns are dropped at the scan
                 // (the filter row's bounds are re-read where they are needed instead of living in registers through the sweeps)
@@ -694,11 +694,15 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 }
                 if (carry > CSN / 2) failed = true;      // more marked columns than direct slots (uniform)
             }
-            if constexpr (MONO) {
+            if constexpr (MLIKE) {
                 if (p.filter_mode == SP_SEL_MATRIX && !failed) {
                     // (the member pool is part of the region just cleared: the clearing stores of all waves must be done)
                     wg_sync<U_LDS>();
                     auto pseudo = [&](unsigned c) {
+                        if constexpr (BND) {      // the collision set is keyed by the PACKED id (a column without a code has no entries: nothing to exclude)
+                            c = p.colpack[c];
+                            if (c == 0xFFFFFFFFu) return;
+                        }
                         const int pos = atomicAdd(&sh[SH_MCTR], 1);
                         if (pos < mpcap) mpool[pos] = ((u64)(c + 1u) << 32) | (u64)0xFF800000u;      // {column + 1 : -inf}
                         else sh[SH_OVF] = 1;

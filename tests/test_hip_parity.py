@@ -1500,7 +1500,7 @@ def test_bounded_variant_is_not_taken_where_it_does_not_apply():
     for what, kw in (("bayesian shrink", dict(l2=1, bayesian_shrink=3)), ("a1 != 1", dict(l1=1, a1=0.7)), ("negative threshold", dict(l1=1, threshold=-0.1)),
                      ("t1 + t2 < 1", dict(l1=1, t1=0.3, t2=0.3)), ("folded cosine", dict(l2=1)), ("additive shrink: still product form", dict(l2=1, additive_shrink=4.0)),
                      ("raw dot", {}),
-                     ("MATRIX filter", dict(l1=1, filter_cols=urm)), ("MATRIX target", dict(l1=1, target_cols=urm))):
+                     ("MATRIX target", dict(l1=1, target_cols=urm))):
         call = _host.prepare(m, k=20, target_rows=t, **kw)
         assert not (_info(call)[8] & 2), what
         _check(call, "not bounded: " + what)
@@ -1639,3 +1639,21 @@ def test_target_matrix_sampled_route_through_the_wrappers(golden):
             assert d.nnz == 0 or d.data.max() <= 1e-5 * max(1.0, abs(want).max()) or (abs(got.nnz - want.nnz) <= 2), kw
             # only listed columns come back
             assert got.multiply(tgt != 0).nnz == got.nnz
+
+
+def test_bounded_variant_with_a_matrix_filter():
+    """filter_cols = <matrix> beside a general epilogue: the excluded columns go through the collision bitmap with a -inf pseudo member,
+    keyed by the packed id (the monotone variant's mechanism)."""
+    rng = np.random.default_rng(51)
+    urm = sp.random_array((20000, 30000), density=0.002, format="csr", dtype=np.float32, random_state=rng)
+    w = sp.random_array((30000, 30000), density=0.001, format="csr", dtype=np.float32, random_state=rng)
+    t = np.arange(0, 20000, 7)
+    for kw in (dict(l1=1), dict(l2=1, stabilized_shrink=2), dict(l1=0.5, l2=0.5, stabilized_shrink=1)):
+        for tun in ({}, dict(threads_per_wg=1024, table_slots=16384)):
+            call = _host.prepare(urm, w, k=40, target_rows=t, filter_cols=urm, **kw)
+            assert _info(call, **tun)[8] & 2, "the bounded variant did not run"
+            _check(call, f"bounded + MATRIX filter {kw} {tun}", **tun)
+    rows, cols, vals, counts = _host.run_hip(_host.prepare(urm, w, k=40, target_rows=t, filter_cols=urm, l1=1))
+    for i, u in enumerate(t[:300]):
+        have = urm.indices[urm.indptr[u]:urm.indptr[u + 1]]
+        assert not np.intersect1d(cols[i * 40:i * 40 + counts[i]], have).size
