@@ -114,7 +114,8 @@ struct KParams {
     int split_w;           //   fine window width: 2T / f, f in {1, 2, 4}; standard dense windows start at multiples of 2T
     // work items of the sparse kernel's rows, cut once per call by sp_row_items_kernel (optional): record 0 of an output slot's
     // block is the header {items, 0, 0, 0} (0 = the row is set up in the kernel), records 1.. are the items of the row
-    const int4 *items_g;       // [items_rows][ITEMS_STRIDE]
+    const int4 *items_g;       // [items_rows][items_stride]
+    int items_stride;          // records per output slot: 64, 128 or ITEMS_STRIDE (chosen per call from the average row, sp_knn.hip)
     int items_rows;            // output slots below this have a block
     // bounded variant of the sparse kernel (MODE 2, sp_sparse_kernel.hpp): the m2 column ids with a 12-bit code of the column's
     // combined term W[c] in bits 20..31 (per-call pass), the same packed id per column, and the call's BndInfo

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void sp_row_desc_kernel(int n_targets, const i
 __global__ __launch_bounds__(256) void sp_row_items_kernel(const unsigned *__restrict__ qcount, int items_rows, int4 *__restrict__ desc_s,
                                                             const int *__restrict__ m1_indices, const float *__restrict__ m1_data,
                                                             const int *__restrict__ m2_indptr, int4 *__restrict__ items_g, int pack,
-                                                            const int *__restrict__ f_indptr) {
+                                                            const int *__restrict__ f_indptr, int stride) {
     const int lane = threadIdx.x & 63;
     const int n_rows = (int)qcount[0];
     const int waves_total = (int)(gridDim.x * (blockDim.x >> 6));
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void sp_row_items_kernel(const unsigned *__res
         const int slot = __builtin_amdgcn_readfirstlane(d.x), s = __builtin_amdgcn_readfirstlane(d.z), n1 = __builtin_amdgcn_readfirstlane(d.w);
         const int t_row = __builtin_amdgcn_readfirstlane(d.y);
         if (slot >= items_rows) continue;
-        int4 *row = items_g + (size_t)slot * ITEMS_STRIDE;
+        int4 *row = items_g + (size_t)slot * (size_t)stride;
         if (n1 > 64) continue;
         int r0_in = 0, len_in = 0;
         unsigned vbits_in = 0u;
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void sp_row_items_kernel(const unsigned *__res
         const int b_incl = wave_incl_scan_dpp(has_b ? 1 : 0);
         const int n_b = __builtin_amdgcn_readlane(b_incl, 63);
         const int n_rec = n_trips + 1 + n_b;
-        if (n_seg == 0 || n_rec > ITEMS_PRE || n_trips > 0x3FF || total >= (1 << 20)) continue;
+        if (n_seg == 0 || n_rec > stride - 1 || n_trips > 0x3FF || total >= (1 << 20)) continue;      // (more records than the call's stride holds: set up in the kernel)
         if (mine) {
             const int bidx = n_trips + 1 + (b_incl - 1);                // (only read when has_b)
             const int t_first = (V >> 6) + ((V & 63) != 0 ? 1 : 0);     // first window whose lane 0 lies inside this segment

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             // per-thread pointer, which at this kernel's register budget is spilled and reloaded at every row top)
             int t_o = tid;
             asm volatile("" : "+v"(t_o));
-            const u32x4 *row = (const u32x4 *)(p.items_g + (size_t)slot * ITEMS_STRIDE);
+            const u32x4 *row = (const u32x4 *)(p.items_g + (size_t)slot * (size_t)p.items_stride);
             if (t_o <= n_rec) rec = row[t_o];          // (record 0: the bounds of the row's MATRIX-filter list, see below)
             if (REC2 && t_o + NT <= n_rec) rec2 = row[t_o + NT];
         }

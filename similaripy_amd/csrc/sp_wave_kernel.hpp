@@ -296,7 +296,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         int4 recA = make_int4((int)OOB_SOFFSET, 0, 0, 0), recB = make_int4(0, 0, 0, 64);
         int f0 = 0, fl = 0;
         if (!failed) {
-            const int4 *row = p.items_g + (size_t)slot * ITEMS_STRIDE;
+            const int4 *row = p.items_g + (size_t)slot * (size_t)p.items_stride;
             if (lane < n_tr) recA = row[1 + lane];
             if (p.filter_mode == SP_SEL_MATRIX) { const int4 r0 = row[0]; f0 = __builtin_amdgcn_readfirstlane(r0.x); fl = __builtin_amdgcn_readfirstlane(r0.y); }
             const int bix = (int)((unsigned)recA.w >> ITEM_W_BITS);
