@@ -401,9 +401,13 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                     const float slope = any_norm ? rc.epi(1.f, 0.f, 1.f, 1.f) : 1.f;      // uniform: val = slope * xy
                     if (slope > 0.f && slope < __builtin_inff()) {      // uniform
                         unsigned lmax = 0u;
-                        for (int sidx = tid; sidx < t_eff; sidx += NT) {
-                            const unsigned w = tabw[sidx];
-                            if (w != EMPTY32 && __uint_as_float(w) > rc.xy_cut) lmax = max(lmax, fkey(__uint_as_float(w)));      // (a NaN sum compares false: no part of the statistic)
+                        // (four consecutive sums per 16-byte LDS read; slots behind the window's end hold EMPTY32)
+                        for (int s4 = 4 * tid; s4 < t_eff && s4 + 3 < 2 * T; s4 += 4 * NT) {
+                            const uint4 w4 = *(const uint4 *)&tabw[s4];
+                            const unsigned w[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (w[j] != EMPTY32 && __uint_as_float(w[j]) > rc.xy_cut) lmax = max(lmax, fkey(__uint_as_float(w[j])));      // (a NaN sum compares false: no part of the statistic)
                         }
                         if (tid == 0) { sh[SH_SEL] = -1; sh[SH_NEED] = 1; }
                         __syncthreads();
@@ -437,7 +441,91 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                 }
 
                 // ================= drain: one barrier-free sweep, overflow-retry =================
+                // Dense windows under the simple judge (round 5): with a cutoff in place ~250 of a window's 32 768 sums are live, one or two per
+                // wave and trip — and every trip that held ONE paid the whole judge (epilogue, key, ballots, the reservation's atomic and its
+                // round trip): 8.8 of the drain's 19 ms on the MovieLens shape (ablations in profiles/r05_exp_dropped.txt).  The sweep now only
+                // SORTS: four consecutive sums per 16-byte read, dead ones cleared by one 16-byte write, the slot numbers of live ones appended
+                // to a wave-private list (no atomics: the counter is a scalar register; 128 entries per wave in the dead seg_v1 array), and
+                // the list is judged densely — 64 entries per trip — when it fills and at the sweep's end.  A trip that is mostly live (no
+                // cutoff yet) is judged on the spot as before.
+                const bool fast_drain = dense && simple_judge && !(p.dbg & 262144);      // (bit 262144 of the ablation word: off)
                 for (;;) {
+                    if (fast_drain) {
+                        constexpr int WLCAP = 2 * NT / NW;                      // u16 entries per wave
+                        unsigned short *wl = (unsigned short *)seg_v1 + wave * WLCAP;
+                        int wn = 0;                                             // wave-uniform
+                        auto flush = [&]() __attribute__((always_inline)) {
+                            for (int b = 0; b < wn; b += 64) {
+                                if (sh[SH_RETRY]) break;                        // (U is full: what is left stays in the tile for the sweep after the selection)
+                                const int i = b + lane;
+                                int c[1];
+                                float xy[1];
+                                unsigned occ = 0;
+                                int sidx = -1;
+                                c[0] = EMPTY; xy[0] = 0.f;
+                                if (i < wn) {
+                                    sidx = (int)wl[i];
+                                    const unsigned w = tabw[sidx];
+                                    if (w != EMPTY32) { c[0] = wlo + sidx; xy[0] = __uint_as_float(w); occ = 1u; }
+                                }
+                                const unsigned done = emit_candidates<1>(p, rc, c, xy, occ, U, sh, p.cap, true);
+                                if (done & 1u) tabw[sidx] = EMPTY32;
+                            }
+                            wn = 0;
+                        };
+                        for (int base = 0; base < t_eff; base += 4 * NT) {
+                            if (sh[SH_RETRY]) break;         // (one LDS word, the same for every lane: wave-uniform)
+                            const int s4 = base + 4 * tid;
+                            const bool in = s4 < t_eff && s4 + 3 < 2 * T;
+                            uint4 w4 = make_uint4(EMPTY32, EMPTY32, EMPTY32, EMPTY32);
+                            if (in) w4 = *(const uint4 *)&tabw[s4];
+                            unsigned w[4] = {w4.x, w4.y, w4.z, w4.w};
+                            bool live[4];
+                            bool any_dead = false;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                live[j] = w[j] != EMPTY32 && !(__uint_as_float(w[j]) <= rc.xy_cut);      // (a NaN sum stays live: the exact test drops it)
+                                any_dead |= (w[j] != EMPTY32) && !live[j];
+                            }
+                            const u64 m0 = __ballot(live[0]), m1 = __ballot(live[1]), m2 = __ballot(live[2]), m3 = __ballot(live[3]);
+                            const int tot = (__popcll(m0) + __popcll(m1)) + (__popcll(m2) + __popcll(m3));
+                            if (tot > WLCAP / 2) {
+                                // mostly live (no cutoff yet): judged on the spot
+                                int c[4];
+                                float xy[4];
+                                unsigned occ = 0;
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    c[j] = (w[j] != EMPTY32) ? wlo + s4 + j : EMPTY;
+                                    xy[j] = (w[j] != EMPTY32) ? __uint_as_float(w[j]) : 0.f;
+                                    if (w[j] != EMPTY32) occ |= 1u << j;
+                                }
+                                const unsigned done = emit_candidates<4>(p, rc, c, xy, occ, U, sh, p.cap, true);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) if (done & (1u << j)) w[j] = EMPTY32;
+                                if (in && occ) *(uint4 *)&tabw[s4] = make_uint4(w[0], w[1], w[2], w[3]);
+                                continue;
+                            }
+                            if (any_dead) {      // the dead ones are consumed here: one 16-byte write (live sums are written back as they are)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) if (!live[j]) w[j] = EMPTY32;
+                                *(uint4 *)&tabw[s4] = make_uint4(w[0], w[1], w[2], w[3]);
+                            }
+                            if (tot) {
+                                if (wn + tot > WLCAP) flush();
+                                if (live[0]) wl[wn + mbcnt64(m0)] = (unsigned short)(s4);
+                                wn += __popcll(m0);
+                                if (live[1]) wl[wn + mbcnt64(m1)] = (unsigned short)(s4 + 1);
+                                wn += __popcll(m1);
+                                if (live[2]) wl[wn + mbcnt64(m2)] = (unsigned short)(s4 + 2);
+                                wn += __popcll(m2);
+                                if (live[3]) wl[wn + mbcnt64(m3)] = (unsigned short)(s4 + 3);
+                                wn += __popcll(m3);
+                                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            }
+                        }
+                        if (wn) flush();
+                    } else
                     for (int base = 0; base < t_eff; base += NT * DRAIN_UNROLL) {
                         // the candidate buffer is full: whatever is judged now cannot be stored, and it would be judged
                         // without the k-th value the selection is about to give — stop, select, sweep again (the
