@@ -29,7 +29,7 @@ for world in (1, 2, 4, 8):
         sub = slice_call(call, lo, hi, compact=True)
         prob = DeviceProblem(sub); cols, vals, counts, _ = prob.alloc_outputs()
         prob.run(cols, vals, counts); torch.cuda.synchronize()
-        t = min(prob.run(cols, vals, counts, time_kernel=True, phase_timers=False)["kernel_ms"] for _ in range(2))
+        t = min(prob.run(cols, vals, counts, time_kernel=True, phase_timers=False)["kernel_ms"] for _ in range(3))
         times.append(t)
         obs.append((float(macs[lo:hi].sum()), float(hi - lo), float(pieces_of[lo:hi].sum()), t))
         del prob

@@ -448,9 +448,14 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                 // to a wave-private list (no atomics: the counter is a scalar register; 128 entries per wave in the dead seg_v1 array), and
                 // the list is judged densely — 64 entries per trip — when it fills and at the sweep's end.  A trip that is mostly live (no
                 // cutoff yet) is judged on the spot as before.
-                const bool fast_drain = dense && simple_judge && !(p.dbg & 262144);      // (bit 262144 of the ablation word: off)
+                // (general epilogues too: the sweep's test is then the gather-free upper bound — candidate_live — and the dense pass over the
+                // list does the gathers, the selectors and the epilogue)
+                const bool fast_drain = dense && !(p.dbg & 262144);      // (bit 262144 of the ablation word: off)
                 for (;;) {
                     if (fast_drain) {
+                        // (two instantiations: the simple judge's sweep is one compare per sum and must not carry the general test's code)
+                        auto fast_sweep = [&](auto simple_c) __attribute__((always_inline)) {
+                        constexpr bool SIMPLE = decltype(simple_c)::value;
                         constexpr int WLCAP = 2 * NT / NW;                      // u16 entries per wave
                         unsigned short *wl = (unsigned short *)seg_v1 + wave * WLCAP;
                         int wn = 0;                                             // wave-uniform
@@ -468,7 +473,7 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                                     const unsigned w = tabw[sidx];
                                     if (w != EMPTY32) { c[0] = wlo + sidx; xy[0] = __uint_as_float(w); occ = 1u; }
                                 }
-                                const unsigned done = emit_candidates<1>(p, rc, c, xy, occ, U, sh, p.cap, true);
+                                const unsigned done = emit_candidates<1>(p, rc, c, xy, occ, U, sh, p.cap, SIMPLE);
                                 if (done & 1u) tabw[sidx] = EMPTY32;
                             }
                             wn = 0;
@@ -484,7 +489,8 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                             bool any_dead = false;
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
-                                live[j] = w[j] != EMPTY32 && !(__uint_as_float(w[j]) <= rc.xy_cut);      // (a NaN sum stays live: the exact test drops it)
+                                live[j] = w[j] != EMPTY32 && (SIMPLE ? !(__uint_as_float(w[j]) <= rc.xy_cut)      // (a NaN sum stays live: the exact test drops it)
+                                                                           : candidate_live(p, rc, __uint_as_float(w[j])));
                                 any_dead |= (w[j] != EMPTY32) && !live[j];
                             }
                             const u64 m0 = __ballot(live[0]), m1 = __ballot(live[1]), m2 = __ballot(live[2]), m3 = __ballot(live[3]);
@@ -500,7 +506,7 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                                     xy[j] = (w[j] != EMPTY32) ? __uint_as_float(w[j]) : 0.f;
                                     if (w[j] != EMPTY32) occ |= 1u << j;
                                 }
-                                const unsigned done = emit_candidates<4>(p, rc, c, xy, occ, U, sh, p.cap, true);
+                                const unsigned done = emit_candidates<4>(p, rc, c, xy, occ, U, sh, p.cap, SIMPLE);
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) if (done & (1u << j)) w[j] = EMPTY32;
                                 if (in && occ) *(uint4 *)&tabw[s4] = make_uint4(w[0], w[1], w[2], w[3]);
@@ -525,6 +531,8 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                             }
                         }
                         if (wn) flush();
+                        };
+                        if (simple_judge) fast_sweep(std::true_type{}); else fast_sweep(std::false_type{});
                     } else
                     for (int base = 0; base < t_eff; base += NT * DRAIN_UNROLL) {
                         // the candidate buffer is full: whatever is judged now cannot be stored, and it would be judged

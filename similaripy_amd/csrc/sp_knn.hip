@@ -293,7 +293,7 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
         const long long Td = 2LL * T;
         c->n_splits = 0; c->split_w = (int)Td;
         if ((long long)a->n_output_cols > Td && a->n_rows_m2 > 0 && a->nnz_m2 > 0) {
-            for (int f = 4; f >= 1; f >>= 1) {
+            for (int f = 8; f >= 1; f >>= 1) {      // (f = 8 since round 5: the heaviest item of the MovieLens shape in 21 pieces instead of 11 — a piece is the unit the workgroups balance with)
                 const long long G = Td / f, nsp = ((long long)a->n_output_cols + G - 1) / G - 1;
                 if (nsp >= 1 && nsp <= 31) { c->n_splits = (int)nsp; c->split_w = (int)G; break; }
             }
@@ -486,8 +486,7 @@ int launch_rows(const KParams &kp_s, const KParams &kp, const Config &c, hipStre
     }
     if (ev) HIP_TRY(hipEventRecord(ev[1], stream));
     if (sl) {
-        const long long n = (long long)sl->n_rows_m2 * sl->n_splits;
-        hipLaunchKernelGGL(sp_m2_splits_kernel, dim3((unsigned)std::min<long long>(256 * 16, (n + 255) / 256)), dim3(256), 0, stream, sl->n_rows_m2, sl->m2_indptr,
+        hipLaunchKernelGGL(sp_m2_splits_kernel, dim3((unsigned)std::max(1, std::min(256 * 16, (sl->n_rows_m2 + 3) / 4))), dim3(256), 0, stream, sl->n_rows_m2, sl->m2_indptr,
                            sl->m2_indices, sl->split_w, sl->n_splits, sl->out, sl->qcount_g, sl->state);
         HIP_TRY(hipGetLastError());
     }
@@ -735,7 +734,17 @@ int run_device_impl(sp_knn_args *a, const uint64_t *sig_override = nullptr) {
             const size_t np = (size_t)c.split_cap * (size_t)c.split_pmax;
             cp.split_fine = c.n_splits + 1;
             cp.split_pmax = c.split_pmax;
-            cp.split_macs = (a->reserved[0] & 8192) ? 1u : (1u << 21);        // (bit 8192 of the ablation word: cut every generic row as finely as allowed, for tests)
+            // A piece is what ONE workgroup cannot be interrupted in: its size bounds how unevenly the persistent workgroups finish.  2^21 MACs
+            // (~1.7 ms) is nothing against the ~38 ms of the whole MovieLens-shaped call, and a third of an N = 8 rank's slice of it (the slices
+            // of round 4's experiment took 7.7 ms where 4.7 ms of work were in them): the piece shrinks with the work a workgroup can expect —
+            // a quarter of it, from sizes alone —, between 2^18 and 2^21 MACs.
+            {
+                const double avg_macs = (a->n_rows_m1 > 0 && a->n_rows_m2 > 0) ? ((double)a->nnz_m1 / a->n_rows_m1) * ((double)a->nnz_m2 / a->n_rows_m2) : 0.0;
+                const double per_wg = avg_macs * (double)a->n_targets / (double)std::max(1, c.wgs_generic);
+                unsigned piece = 1u << 21;
+                while (piece > (1u << 18) && (double)piece > per_wg / 4.0) piece >>= 1;
+                cp.split_macs = (a->reserved[0] & 8192) ? 1u : piece;        // (bit 8192 of the ablation word: cut every generic row as finely as allowed, for tests)
+            }
             cp.split_cap = c.split_cap;
             cp.split_count = (int *)(ws + 16);                                  // two words inside the zeroed header
             cp.split_rows = (int4 *)ws_piece;
