@@ -96,71 +96,76 @@ __device__ __forceinline__ void s2_core_w(const unsigned (&c)[4], const float (&
         : "memory");
 }
 
-// Wave-local exact selection: the n (> k) entries {key : column} of U[0, n) are cut back to the k with the largest keys (ties at
-// the k-th place resolved arbitrarily, as the reference's heap does), compacted to U[0, k), the tail zeroed.  MSD radix select,
-// four 8-bit digits: every lane holds four entries in registers; one 256-counter histogram per digit in LDS (U's first KB), each lane reads four counters back, a DPP scan finds the digit of the k-th largest.  Returns its key.
-// (a real call: four or five selections per row, ten call sites in the unrolled sweeps — inlined they are 15 k lines of ISA and the
-// sweeps' load pipeline falls apart)
-__device__ __attribute__((noinline)) unsigned wave_select(u64 *U, int n, int k, int lane) {
+// Wave-local selection: the n (> k) entries {key : column} of U[0, n) are cut back to those with the largest keys, compacted to the front,
+// the tail zeroed.  Every lane holds four entries in registers; the k-th largest key is found by a BIT-WISE search — for every bit below the
+// keys' common prefix, from the top: do k entries reach the threshold with this bit set? — in compares, scalar mask counts and adds only.
+// (Round 4's MSD radix select went through an LDS histogram: four passes of atomics, fences and read-backs, 777 instructions and a dozen
+// LDS round trips per call, four or five calls per row — a quarter of the instructions of a row that is bound by instruction issue;
+// profiles/r05_exp_dropped.txt.)
+//   exact  (the row's final top-k): exactly k entries are kept (ties at the k-th place resolved arbitrarily, as the reference's heap does);
+//   !exact (a full U in mid-row): the search stops as soon as at most k + 32 entries reach the threshold and keeps all of them — a valid
+//          running cutoff (k entries reach it) for a dozen iterations instead of up to 32.
+// Returns the threshold key and the entries kept.  A real call (several call sites in the unrolled sweeps).
+struct WaveSel { unsigned key; int kept; };
+__device__ __attribute__((noinline)) WaveSel wave_select(u64 *U, int n, int k, int lane, bool exact) {
     u64 e[4];
     unsigned key[4];
     bool live[4];
+    unsigned lmax = 0u, lmin_inv = 0u;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int i = lane + 64 * j;
         live[j] = i < n;
         e[j] = live[j] ? U[i] : 0ull;
         key[j] = (unsigned)(e[j] >> 32);
+        if (live[j]) { lmax = max(lmax, key[j]); lmin_inv = max(lmin_inv, ~key[j]); }
     }
-    // the histogram lives in U's own first KB: the entries are in registers now (no other LDS of the wave is free at every call site)
-    int *hist = (int *)U;
-    ((int4 *)hist)[lane] = make_int4(0, 0, 0, 0);
+    const unsigned hi = wave_max_u32(lmax), lo = ~wave_max_u32(lmin_inv);
+    const unsigned diff = hi ^ lo;
+    unsigned T = hi;
+    int cntT = n;
+    const int slack = exact ? 0 : 32;
+    bool all_bits = true;           // the search ran to the last bit: T is the exact k-th largest key
+    if (diff != 0u) {
+        int b = 31 - __clz((int)diff);
+        T = (b == 31) ? 0u : ((hi >> (b + 1)) << (b + 1));      // the keys' common prefix
+        for (; b >= 0; --b) {
+            const unsigned cand = T | (1u << b);
+            const int cnt = (__popcll(__ballot(live[0] && key[0] >= cand)) + __popcll(__ballot(live[1] && key[1] >= cand))) +
+                            (__popcll(__ballot(live[2] && key[2] >= cand)) + __popcll(__ballot(live[3] && key[3] >= cand)));
+            if (cnt >= k) {      // uniform
+                T = cand;
+                cntT = cnt;
+                if (cnt <= k + slack) { all_bits = (b == 0); break; }
+            }
+        }
+    }
+    // cntT entries reach T (>= k of them).  They are all kept when that is few enough (inexact, or exactly k); else T is the exact k-th
+    // largest key (every bit searched, or all keys equal): the larger ones and as many of its equals as are needed
+    const bool keep_all = cntT <= k + slack;
+    int n_gt = 0;
+    if (!keep_all) n_gt = (__popcll(__ballot(live[0] && key[0] > T)) + __popcll(__ballot(live[1] && key[1] > T))) +
+                          (__popcll(__ballot(live[2] && key[2] > T)) + __popcll(__ballot(live[3] && key[3] > T)));
+    int need_eq = keep_all ? 0x7FFFFFFF : k - n_gt;
+    (void)all_bits;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    unsigned prefix = 0u, pmask = 0u;
-    int need = k;
-#pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (live[j] && (key[j] & pmask) == prefix) atomicAdd(&hist[(key[j] >> shift) & 255u], 1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        const int4 h = ((const int4 *)hist)[lane];            // counters 4*lane .. 4*lane + 3 (LDS executes a wave's accesses in order)
-        ((int4 *)hist)[lane] = make_int4(0, 0, 0, 0);
-        const int tot = (h.x + h.y) + (h.z + h.w);
-        const int incl = wave_incl_scan_dpp(tot);
-        const int total = __builtin_amdgcn_readlane(incl, 63);
-        const int a3 = total - incl, a2 = a3 + h.w, a1 = a2 + h.z, a0 = a1 + h.y;      // entries with a larger digit
-        int my_d = -1, my_above = 0;
-        if (a0 < need && need <= a0 + h.x) { my_d = 0; my_above = a0; }
-        if (a1 < need && need <= a1 + h.y) { my_d = 1; my_above = a1; }
-        if (a2 < need && need <= a2 + h.z) { my_d = 2; my_above = a2; }
-        if (a3 < need && need <= a3 + h.w) { my_d = 3; my_above = a3; }
-        const u64 ball = __ballot(my_d >= 0);                  // exactly one lane: the matching entries number >= need
-        const int src = ball ? __builtin_ctzll(ball) : 0;
-        const int d = 4 * src + __builtin_amdgcn_readlane(my_d, src);
-        need -= __builtin_amdgcn_readlane(my_above, src);
-        prefix |= (unsigned)d << shift;
-        pmask |= 0xFFu << shift;
-    }
-    // keys above the k-th largest, then `need` of its equals
     int pos = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const bool gt = live[j] && key[j] > prefix;
+        const bool gt = live[j] && key[j] > T;
         const u64 m = __ballot(gt);
         if (gt) U[pos + mbcnt64(m)] = e[j];
         pos += __popcll(m);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const bool eq = live[j] && key[j] == prefix;
+        const bool eq = live[j] && key[j] == T;
         const u64 m = __ballot(eq);
         const int r = mbcnt64(m);
-        if (eq && r < need) U[pos + r] = e[j];
-        const int taken = min(__popcll(m), need);
+        if (eq && r < need_eq) U[pos + r] = e[j];
+        const int taken = min(__popcll(m), need_eq);
         pos += taken;
-        need -= taken;
+        if (!keep_all) need_eq -= taken;
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -168,7 +173,7 @@ __device__ __attribute__((noinline)) unsigned wave_select(u64 *U, int n, int k, 
         if (i >= pos && i < n) U[i] = 0ull;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    return prefix;
+    return WaveSel{T, pos};
 }
 
 // The rare side of a sweep-2 trip: its survivors do not fit U.  U is cut back to its k largest (their smallest is the new cutoff,
@@ -184,9 +189,9 @@ __device__ __attribute__((noinline)) WaveUState wave_push_slow(u64 *U, unsigned 
     for (int j = 0; j < 4; ++j) {
         int ns = __popcll(S[j]);
         if (ns && ucnt + ns > WV_UCAP) {
-            const unsigned tk = wave_select(U, ucnt, k, lane);
-            ucnt = min(ucnt, k);
-            cutx = fmaxf(cutx0, funkey(tk));
+            const WaveSel ws = wave_select(U, ucnt, k, lane, false);
+            ucnt = ws.kept;
+            cutx = fmaxf(cutx0, funkey(ws.key));
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) if (jj >= j) S[jj] &= __ballot(!(x[jj] <= cutx));
             ns = __popcll(S[j]);
@@ -566,9 +571,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
                     u64 m = __ballot(want[j]);
                     int ns = __popcll(m);
                     if (ns && ucnt + ns > WV_UCAP) {
-                        const unsigned tk = wave_select(U, ucnt, k, lane);
-                        ucnt = min(ucnt, k);
-                        cutx = fmaxf(cutx0, funkey(tk));
+                        const WaveSel ws = wave_select(U, ucnt, k, lane, false);
+                        ucnt = ws.kept;
+                        cutx = fmaxf(cutx0, funkey(ws.key));
 #pragma unroll
                         for (int jj = 0; jj < 4; ++jj) if (jj >= j) want[jj] = want[jj] && !(__uint_as_float((unsigned)e[jj]) <= cutx);
                         m = __ballot(want[j]);
@@ -582,10 +587,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             WV_PHASE_END(PH_DRAIN);
-            if (ucnt > k) {
-                wave_select(U, ucnt, k, lane);
-                ucnt = k;
-            }
+            if (ucnt > k) ucnt = wave_select(U, ucnt, k, lane, true).kept;
             WV_PHASE_END(PH_SELECT);
 
             // ---- write-out: epilogue on the winners (s_plus.h:129-156 with the column term folded in: val = xy / den, or the raw
