@@ -55,8 +55,11 @@ static_assert(wv_mpcap(WV_A_SMALL) >= 256 + 64, "a trip's members (<= 256) fit a
 static_assert(11 * wv_lds_bytes(WV_A_SMALL) <= 160 * 1024 && 9 * wv_lds_bytes(WV_A_LARGE) <= 160 * 1024, "rows per CU");
 
 // Sweep 2 core for a collision bitmap of WV_CBM_BYTES at LDS offset 0 (sp_common.hpp's s2_core with this kernel's mask).
-__device__ __forceinline__ void s2_core_w(const unsigned (&c)[4], const float (&v)[4], float segv, float cut, float (&x)[4], u64 (&M)[4], u64 (&L)[4]) {
+// Element j of a lane is real iff j < d: both masks come out cut to the real elements (the cuts in the asm: left to the compiler they
+// end up on the VALU, a move, an and and a v_readfirstlane per mask half).
+__device__ __forceinline__ void s2_core_w(const unsigned (&c)[4], const float (&v)[4], float segv, float cut, int d, float (&x)[4], u64 (&M)[4], u64 (&L)[4]) {
     unsigned a0, a1, a2, a3;
+    u64 k0, k1, k2, k3;
     asm volatile(
         "v_lshrrev_b32 %[a0], 3, %[c0]\n\t"
         "v_lshrrev_b32 %[a1], 3, %[c1]\n\t"
@@ -78,6 +81,14 @@ __device__ __forceinline__ void s2_core_w(const unsigned (&c)[4], const float (&
         "v_cmp_nle_f32_e64 %[L1], %[x1], %[cut]\n\t"
         "v_cmp_nle_f32_e64 %[L2], %[x2], %[cut]\n\t"
         "v_cmp_nle_f32_e64 %[L3], %[x3], %[cut]\n\t"
+        "v_cmp_lt_i32_e64 %[k0], 0, %[d]\n\t"
+        "v_cmp_lt_i32_e64 %[k1], 1, %[d]\n\t"
+        "v_cmp_lt_i32_e64 %[k2], 2, %[d]\n\t"
+        "v_cmp_lt_i32_e64 %[k3], 3, %[d]\n\t"
+        "s_and_b64 %[L0], %[L0], %[k0]\n\t"
+        "s_and_b64 %[L1], %[L1], %[k1]\n\t"
+        "s_and_b64 %[L2], %[L2], %[k2]\n\t"
+        "s_and_b64 %[L3], %[L3], %[k3]\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
         "v_bfe_u32 %[a0], %[a0], %[c0], 1\n\t"
         "v_bfe_u32 %[a1], %[a1], %[c1], 1\n\t"
@@ -87,13 +98,18 @@ __device__ __forceinline__ void s2_core_w(const unsigned (&c)[4], const float (&
         "v_cmp_ne_u32_e64 %[M1], 0, %[a1]\n\t"
         "v_cmp_ne_u32_e64 %[M2], 0, %[a2]\n\t"
         "v_cmp_ne_u32_e64 %[M3], 0, %[a3]\n\t"
+        "s_and_b64 %[M0], %[M0], %[k0]\n\t"
+        "s_and_b64 %[M1], %[M1], %[k1]\n\t"
+        "s_and_b64 %[M2], %[M2], %[k2]\n\t"
+        "s_and_b64 %[M3], %[M3], %[k3]\n\t"
         : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3),
           [x0] "=&v"(x[0]), [x1] "=&v"(x[1]), [x2] "=&v"(x[2]), [x3] "=&v"(x[3]),
           [M0] "=&s"(M[0]), [M1] "=&s"(M[1]), [M2] "=&s"(M[2]), [M3] "=&s"(M[3]),
-          [L0] "=&s"(L[0]), [L1] "=&s"(L[1]), [L2] "=&s"(L[2]), [L3] "=&s"(L[3])
+          [L0] "=&s"(L[0]), [L1] "=&s"(L[1]), [L2] "=&s"(L[2]), [L3] "=&s"(L[3]),
+          [k0] "=&s"(k0), [k1] "=&s"(k1), [k2] "=&s"(k2), [k3] "=&s"(k3)
         : [c0] "v"(c[0]), [c1] "v"(c[1]), [c2] "v"(c[2]), [c3] "v"(c[3]),
-          [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]), [sv] "v"(segv), [cut] "s"(cut)
-        : "memory");
+          [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]), [sv] "v"(segv), [cut] "s"(cut), [d] "v"(d)
+        : "memory", "scc");
 }
 
 // Wave-local selection: the n (> k) entries {key : column} of U[0, n) are cut back to those with the largest keys, compacted to the front,
@@ -180,11 +196,15 @@ __device__ __attribute__((noinline)) WaveSel wave_select(u64 *U, int n, int k, i
 // applied to what is left of the trip), quad by quad: k + 64 <= WV_UCAP, so one quad always fits behind a selection.
 // A real call (one site per unrolled trip body): values in, the new {entries in U, cutoff} out.
 struct WaveUState { int ucnt; float cutx; };
+// (The survivor masks are not passed: a lane's product that is no survivor arrives as -inf.  Mask arguments would be copies SGPR -> VGPR,
+// and those make the compiler move the caller's whole mask arithmetic — every trip's, not only the rare one's — to the VALU.)
 __device__ __attribute__((noinline)) WaveUState wave_push_slow(u64 *U, unsigned u_off, unsigned c0, unsigned c1, unsigned c2, unsigned c3, float x0, float x1, float x2,
-                                                               float x3, u64 S0, u64 S1, u64 S2, u64 S3, int ucnt, float cutx, float cutx0, int k, int lane) {
+                                                               float x3, int ucnt, float cutx, float cutx0, int k, int lane) {
     const unsigned c[4] = {c0, c1, c2, c3};
     const float x[4] = {x0, x1, x2, x3};
-    u64 S[4] = {S0, S1, S2, S3};
+    u64 S[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) S[j] = __ballot(!(x[j] <= -__builtin_inff()));
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         int ns = __popcll(S[j]);
@@ -430,7 +450,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
                 for (int i0 = 0; i0 < fl && !failed; i0 += 64) {
                     const int c = (i0 == 0) ? my_fc : ((i0 + lane < fl) ? p.f_indices[f0 + i0 + lane] : -1);
                     const u64 m = __ballot(c >= 0);
-                    if (mcnt + __popcll(m) > MPCAP) { failed = wave_accumulate(cs, mpool, cbm, pre16, mcnt, lane); mcnt = 0; }
+                    if (mcnt + __popcll(m) > MPCAP) { failed = __builtin_amdgcn_readfirstlane((int)wave_accumulate(cs, mpool, cbm, pre16, mcnt, lane)) != 0; mcnt = 0; }
                     if (c >= 0) mpool[mcnt + mbcnt64(m)] = ((u64)((unsigned)c + 1u) << 32) | (u64)0xFF800000u;
                     mcnt += __popcll(m);
                 }
@@ -459,13 +479,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
                 const float v[4] = {__uint_as_float(vals.x), __uint_as_float(vals.y), __uint_as_float(vals.z), __uint_as_float(vals.w)};
                 float x[4];
                 u64 M[4], S[4];
-                s2_core_w(c, v, sv, cutx, x, M, S);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const u64 ok = __ballot(j < d);
-                    M[j] &= ok;
-                    S[j] &= ok;
-                }
+                s2_core_w(c, v, sv, cutx, d, x, M, S);
                 // products of marked columns: the member pool.  A trip nearly always holds some, a LANE rarely more than one: the first
                 // member of every lane goes out in ONE push, second and later members of a lane in the rare pushes behind it
                 const u64 Many = (M[0] | M[1]) | (M[2] | M[3]);
@@ -474,7 +488,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
                     const int n0 = __popcll(Many), n1 = __popcll(R1), n2 = __popcll(R2), n3 = __popcll(R3);
                     if (mcnt + (n0 + n1) + (n2 + n3) > MPCAP) {
                         // the pool is folded into the collision set right away and starts over
-                        failed = wave_accumulate(cs, mpool, cbm, pre16, mcnt, lane);
+                        failed = __builtin_amdgcn_readfirstlane((int)wave_accumulate(cs, mpool, cbm, pre16, mcnt, lane)) != 0;
                         mcnt = 0;
                         if (failed) return;
                     }
@@ -499,7 +513,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
                     if ((S[0] | S[1]) | (S[2] | S[3])) {
                         const int n0 = __popcll(S[0]), n1 = __popcll(S[1]), n2 = __popcll(S[2]), n3 = __popcll(S[3]);
                         if (ucnt + (n0 + n1) + (n2 + n3) > WV_UCAP) {
-                            const WaveUState r = wave_push_slow(U, U_OFF, c[0], c[1], c[2], c[3], x[0], x[1], x[2], x[3], S[0], S[1], S[2], S[3], ucnt, cutx, cutx0, k, lane);
+                            const float ninf = -__builtin_inff();
+                            const WaveUState r = wave_push_slow(U, U_OFF, c[0], c[1], c[2], c[3], __uint_as_float(mask_select(S[0], __float_as_uint(x[0]), __float_as_uint(ninf))),
+                                                                __uint_as_float(mask_select(S[1], __float_as_uint(x[1]), __float_as_uint(ninf))),
+                                                                __uint_as_float(mask_select(S[2], __float_as_uint(x[2]), __float_as_uint(ninf))),
+                                                                __uint_as_float(mask_select(S[3], __float_as_uint(x[3]), __float_as_uint(ninf))), ucnt, cutx, cutx0, k, lane);
                             ucnt = __builtin_amdgcn_readfirstlane(r.ucnt);
                             cutx = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(r.cutx)));
                         } else {
@@ -536,8 +554,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         }
 
         if (!failed) {
-            // ---- what is left in the member pool joins the collision set ----
-            failed = wave_accumulate(cs, mpool, cbm, pre16, mcnt, lane);
+            // ---- what is left in the member pool joins the collision set (the verdict is made uniform: counters and masks stay in SGPRs) ----
+            failed = __builtin_amdgcn_readfirstlane((int)wave_accumulate(cs, mpool, cbm, pre16, mcnt, lane)) != 0;
             // the member pool is consumed: its storage (and the collision bitmap) go back to zero at the row's end
             WV_PHASE_END(PH_ACCUM);
         }
@@ -572,8 +590,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
                     int ns = __popcll(m);
                     if (ns && ucnt + ns > WV_UCAP) {
                         const WaveSel ws = wave_select(U, ucnt, k, lane, false);
-                        ucnt = ws.kept;
-                        cutx = fmaxf(cutx0, funkey(ws.key));
+                        ucnt = __builtin_amdgcn_readfirstlane(ws.kept);      // (a call's results arrive in VGPRs: made uniform again, or every
+                        cutx = fmaxf(cutx0, funkey((unsigned)__builtin_amdgcn_readfirstlane((int)ws.key)));      // count and mask of the sweeps moves to the VALU)
 #pragma unroll
                         for (int jj = 0; jj < 4; ++jj) if (jj >= j) want[jj] = want[jj] && !(__uint_as_float((unsigned)e[jj]) <= cutx);
                         m = __ballot(want[j]);
@@ -587,7 +605,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             WV_PHASE_END(PH_DRAIN);
-            if (ucnt > k) ucnt = wave_select(U, ucnt, k, lane, true).kept;
+            if (ucnt > k) ucnt = __builtin_amdgcn_readfirstlane(wave_select(U, ucnt, k, lane, true).kept);
             WV_PHASE_END(PH_SELECT);
 
             // ---- write-out: epilogue on the winners (s_plus.h:129-156 with the column term folded in: val = xy / den, or the raw
