@@ -337,12 +337,15 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
         const double need = 1.5 * (packs ? 2.0 * trips_p + 2.0 : trips_u + 2.0);
         c->items_stride = need <= 63.0 ? 64 : need <= 127.0 ? 128 : ITEMS_STRIDE;
     }
-    c->ws_items_bytes = ((size_t)c->items_rows * (size_t)c->items_stride * 16 + 255) & ~(size_t)255;
     // Light rows (user scoring: a few thousand products over <= 2^17 columns, k <= 128, monotone epilogue): one WAVE per row, eight rows
     // in flight per CU (sp_wave_kernel.hpp) — when the average row fits its 63 packed trips with room to spare, or on request
     c->wave = c->items_rows > 0 && c->mono && NT_s == 256 && a->n_output_cols <= (1 << WV_BM_LOG2) && a->n_output_cols > T && a->k <= WV_KMAX &&
               !(a->reserved[0] & 16384) && (want_wave || (!a->threads_per_wg && avg_macs <= 10000.0));
     c->wgs_wave = 0;
+    // (a wave call's records are one per SEGMENT, 64 per row — sp_row_items_wave_kernel; the few rows its workgroup-per-row companion takes
+    // need more than a 64-record slot holds and are set up in the kernel)
+    if (c->wave) c->items_stride = 64;
+    c->ws_items_bytes = ((size_t)c->items_rows * (size_t)c->items_stride * 16 + 255) & ~(size_t)255;
     if (c->wave) {
         // (the workgroup-per-row kernel keeps its 256-thread shape beside it: sparse rows the wave kernel does not take — more than 64 m1
         // entries, more products than its 63 trips hold — have a queue of their own and run there, as in round 3)
@@ -768,9 +771,8 @@ int run_device_impl(sp_knn_args *a, const uint64_t *sig_override = nullptr) {
                                ((c.mono || c.bnd) && a->filter_mode == SP_SEL_MATRIX) ? a->filter_m_indptr : nullptr, c.items_stride);
             HIP_TRY(hipGetLastError());
             if (c.wave) {
-                hipLaunchKernelGGL(sp_row_items_kernel, dim3(item_blocks), dim3(256), 0, stream, (const unsigned *)cp.qcount_w, c.items_rows, (int4 *)desc_w,
-                                   a->m1_indices, a->m1_data, a->m2_indptr, (int4 *)ws_items, 1,
-                                   ((c.mono || c.bnd) && a->filter_mode == SP_SEL_MATRIX) ? a->filter_m_indptr : nullptr, c.items_stride);
+                hipLaunchKernelGGL(sp_row_items_wave_kernel, dim3(item_blocks), dim3(256), 0, stream, (const unsigned *)cp.qcount_w, c.items_rows, (int4 *)desc_w,
+                                   a->m1_indices, a->m1_data, a->m2_indptr, (int4 *)ws_items, c.items_stride);
                 HIP_TRY(hipGetLastError());
             }
             kp.items_g = (const int4 *)ws_items; kp.items_rows = c.items_rows; kp.items_stride = c.items_stride;

@@ -317,16 +317,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         const float den = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane(d1.y));
         bool failed = (n_tr <= 0 || n_tr > 63 || slot >= p.items_rows);
 
-        // trip records: lane T holds trip T (piece A) and, for a packed trip, its second piece B; lanes beyond: the sentinel
-        int4 recA = make_int4((int)OOB_SOFFSET, 0, 0, 0), recB = make_int4(0, 0, 0, 64);
+        // segment records (sp_row_items_wave_kernel): lane i holds segment i = {B, D, m1 value bits, V}.  The segments lie end to end on
+        // the virtual lane axis; lane l of trip T is place u = 64 T + l of it and belongs to segment #{i >= 1 : V_i - 1 < u}: the number of
+        // START MARKS (bit V_i - 1 of an axis-long bitmap) below u.  The bitmap is built in LDS — one ds_or per segment, region A is clean
+        // between rows —, lane T takes trip T's 64 marks and the number of marks before them, and the 512 bytes go back to zero.
+        int4 seg = make_int4(0, 0, 0, 0);
         int f0 = 0, fl = 0;
         if (!failed) {
-            const int4 *row = p.items_g + (size_t)slot * (size_t)p.items_stride;
-            if (lane < n_tr) recA = row[1 + lane];
-            if (p.filter_mode == SP_SEL_MATRIX) { const int4 r0 = row[0]; f0 = __builtin_amdgcn_readfirstlane(r0.x); fl = __builtin_amdgcn_readfirstlane(r0.y); }
-            const int bix = (int)((unsigned)recA.w >> ITEM_W_BITS);
-            if (bix) recB = row[1 + bix];
+            seg = (p.items_g + (size_t)slot * (size_t)p.items_stride)[lane];
+            if (p.filter_mode == SP_SEL_MATRIX) { f0 = p.f_indptr[t]; fl = p.f_indptr[t + 1] - f0; }
         }
+        unsigned t_mlo, t_mhi;
+        int t_cum;
+        {
+            if (lane >= 1 && seg.y != 0) { const unsigned g = (unsigned)seg.w - 1u; atomicOr((unsigned *)rA + (g >> 5), 1u << (g & 31u)); }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const uint2 m = ((const uint2 *)rA)[lane];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            ((uint2 *)rA)[lane] = make_uint2(0u, 0u);
+            t_mlo = m.x; t_mhi = m.y;
+            const int cnt = __popc(m.x) + __popc(m.y);
+            t_cum = wave_incl_scan_dpp(cnt) - cnt;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        const int lane16 = lane * 16, nlane4 = -4 * lane;
         // x <= cutx0  =>  val(x) < threshold for sure (the exact test is repeated on the winners at write-out)
         float cutx0;
         if (!any_norm) cutx0 = __uint_as_float(RowCtx::funkey_inv_below(p.threshold));
@@ -341,15 +355,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 
         // one trip of the wave: this lane's byte offset into m2, the number of its real elements (<= 0: none), its m1 value
         auto trip_lane = [&](int T, int &vo, int &d, float &sv) __attribute__((always_inline)) {
-            const int tl = min(T, 63);                 // (lane 63 always holds the sentinel: n_tr <= 63)
-            const int oA = __builtin_amdgcn_readlane(recA.x, tl), cA = __builtin_amdgcn_readlane(recA.y, tl);
-            const int oB = __builtin_amdgcn_readlane(recB.x, tl), cB = __builtin_amdgcn_readlane(recB.y, tl);
-            const int sB = __builtin_amdgcn_readlane(recB.w, tl);
-            vo = oA + lane * 16;
-            d = cA - 4 * lane;
-            sv = __uint_as_float((unsigned)__builtin_amdgcn_readlane(recA.z, tl));
-            if (lane >= sB) { vo = oB + (lane - sB) * 16; d = cB - 4 * (lane - sB); sv = __uint_as_float((unsigned)__builtin_amdgcn_readlane(recB.z, tl)); }
-            if (d <= 0) vo = (int)OOB_SOFFSET;         // lanes beyond the pieces fetch nothing
+            const int tl = min(T, 63);                 // (lane 63 never holds a trip: n_tr <= 63; trips behind the row's last find d <= 0 everywhere)
+            const unsigned mlo = (unsigned)__builtin_amdgcn_readlane((int)t_mlo, tl), mhi = (unsigned)__builtin_amdgcn_readlane((int)t_mhi, tl);
+            const int cb = __builtin_amdgcn_readlane(t_cum, tl);
+            const int j4 = ((int)__builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u)) + cb) << 2;
+            const int Bj = __builtin_amdgcn_ds_bpermute(j4, seg.x), Dj = __builtin_amdgcn_ds_bpermute(j4, seg.y);
+            sv = __uint_as_float((unsigned)__builtin_amdgcn_ds_bpermute(j4, seg.z));
+            vo = Bj + lane16 + T * 1024;
+            d = Dj + nlane4 - T * 256;
+            if (d <= 0) vo = (int)OOB_SOFFSET;         // lanes beyond the segments fetch nothing
 #if SP_ABLATION
             if ((p.dbg & 512) && d > 0) vo = lane * 16 + (T & 3) * 1024;      // ablation: every trip reads the same 4 KB (cache hits only)
 #endif
