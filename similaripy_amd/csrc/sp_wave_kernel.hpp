@@ -15,11 +15,16 @@
 //   clear + rank prefix       the bitmap's storage becomes [collision set 1024 slots | member pool | U];
 //   sweep 2 (ids + values)    x = value * m1 value; products of marked columns -> member pool; every other product is the only
 //                             one of its column and goes to the candidate buffer U (256 entries) iff x beats the running k-th
-//                             value; a full U is cut back to its k largest by a wave-local MSD radix selection;
+//                             value; a full U is cut back to its k largest by a wave-local bit-wise search (wave_select);
 //   accumulate, drain         members find their slot by the rank of their column's bit (32-bit compare-and-swap claims, float add),
 //                             complete sums above the cutoff join U; excluded (filter) columns carry a -inf pseudo member;
 //   select, write-out         exact top-k, epilogue val = xy / den (or the raw dot), threshold, compaction.
-// Work items: the packed trips sp_row_items_kernel cuts once per call (lane T of the wave holds trip T's record: at most 63 trips).
+// Work items: one record per SEGMENT (m1 entry x its m2 row), written once per call by sp_row_items_wave_kernel, 64 per row.  The segments
+// lie end to end on a virtual lane axis (a segment of `len` elements takes ceil(len / 4) lanes, NO gaps) and a trip is a window of 64 lanes
+// of it — any number of pieces per trip: a user-scoring row of 100-element segments fills 64 lanes of 64, the two-piece trips of the
+// workgroup-per-row kernel 50 (C5: 32 -> 25 trips per row, 26.1 -> 21.2 ms).  Lane i of the wave holds segment i's record; lane T holds trip T's
+// 64 start marks and the number of marks before them, and every lane of a trip finds its segment by counting marks (two v_mbcnt) and
+// fetches the segment's {B, D, m1 value} from its holder by ds_bpermute.  At most 63 trips.
 // The kernel has its own queue: sp_row_desc_kernel sends it the sparse rows with at most 64 m1 entries and 10 k products, the other
 // sparse rows run on the workgroup-per-row kernel in the same call; a row that fails here (collision set full) joins the generic queue.
 #pragma once
