@@ -1122,6 +1122,46 @@ def test_wave_kernel_hands_heavy_and_odd_rows_to_the_generic_kernel():
     _check(call, "wave kernel odd rows", threads_per_wg=64)
 
 
+def test_wave_kernel_gap_free_trips_edge_shapes():
+    """The wave kernel's trips are windows of a gap-free lane axis (sp_row_items_wave_kernel: one record per segment; a lane finds its
+    segment by counting start marks).  Rows built to hit the corners of that bookkeeping: 64 segments of 1-3 elements (every lane of one
+    trip a segment of its own), segments of exactly 64 lanes (the next one starts on a window's lane 0: its mark is bit 63 of the window
+    before), one segment over many trips beside short ones, lengths of every residue modulo 4, a single one-element segment, the last
+    segment ending on a window's last lane — all against the oracle, on the wave kernel."""
+    rng = np.random.default_rng(77)
+    n_items, n_cols = 400, 120000                           # (few collisions: the rows stay on the sparse-row path)
+
+    def m2_row(length):
+        return np.sort(rng.choice(n_cols, size=length, replace=False))
+
+    lengths = np.zeros(n_items, dtype=np.int64)
+    lengths[0:64] = rng.integers(1, 4, 64)                  # tiny segments
+    lengths[64:72] = 256                                    # exactly 64 lanes each
+    lengths[72] = 4000                                      # ~16 trips of one segment
+    lengths[73:90] = rng.integers(5, 40, 17)
+    lengths[90:154] = np.arange(64) % 7 + 1                 # every residue modulo 4
+    lengths[154] = 1
+    lengths[155:159] = [252, 4, 255, 1]                     # 63 + 1 lanes, then 64 lanes: ends on lane 63 twice
+    lengths[159:400] = rng.integers(20, 160, 241)
+    indptr = np.concatenate(([0], np.cumsum(lengths))).astype(np.int32)
+    cols = np.concatenate([m2_row(int(l)) for l in lengths]).astype(np.int32)
+    wt = sp.csr_array(((rng.random(cols.shape[0]) + 0.05).astype(np.float32), cols, indptr), shape=(n_items, n_cols))
+    rows = [np.arange(0, 64), np.arange(64, 72), np.arange(72, 90), np.arange(90, 154), np.array([154]), np.arange(155, 159),
+            np.concatenate((np.arange(64, 72), np.arange(155, 159), np.arange(0, 40))), np.concatenate(([72], np.arange(90, 150)))]
+    for _ in range(600):                                    # ordinary light rows around them
+        rows.append(np.sort(rng.choice(np.arange(159, 400), size=int(rng.integers(3, 60)), replace=False)))
+    r_indptr = np.concatenate(([0], np.cumsum([len(r) for r in rows]))).astype(np.int32)
+    r_cols = np.concatenate(rows).astype(np.int32)
+    # (distinct m1 values: the order of the segments — descending |value| — differs from the storage order)
+    urm = sp.csr_array(((rng.random(r_cols.shape[0]) + 0.1).astype(np.float32), r_cols, r_indptr), shape=(len(rows), n_items))
+    for kw in (dict(k=50), dict(k=128, threshold=0.02), dict(k=7, l2=1.0, c1=0.5, c2=0.5)):
+        call = _host.prepare(urm, wt, **kw)
+        ran, info = _ran_on_the_wave_kernel(call, threads_per_wg=64)
+        assert ran, "the wave kernel was not chosen"
+        assert info["phase_cycles"][9] >= call.n_targets - 2, f"rows finished on the sparse-row path: {info['phase_cycles'][9]} of {call.n_targets}"
+        _check(call, f"wave kernel gap-free trips {kw}", threads_per_wg=64)
+
+
 def test_wave_kernel_tied_values_and_repeated_calls():
     """Binary data: every product is 1, the k-th place is a mass tie (the selection keeps exactly k, any of the tied); and the same
     call repeated gives the same kept VALUES every time (no LDS state leaks from row to row or call to call)."""
