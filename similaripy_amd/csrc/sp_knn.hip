@@ -337,9 +337,11 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
         const double need = 1.5 * (packs ? 2.0 * trips_p + 2.0 : trips_u + 2.0);
         c->items_stride = need <= 63.0 ? 64 : need <= 127.0 ? 128 : ITEMS_STRIDE;
     }
-    // Light rows (user scoring: a few thousand products over <= 2^17 columns, k <= 128, monotone epilogue): one WAVE per row, eight rows
-    // in flight per CU (sp_wave_kernel.hpp) — when the average row fits its 63 packed trips with room to spare, or on request
-    c->wave = c->items_rows > 0 && c->mono && NT_s == 256 && a->n_output_cols <= (1 << WV_BM_LOG2) && a->n_output_cols > T && a->k <= WV_KMAX &&
+    // Light rows (user scoring: a few thousand products, k <= 128, monotone epilogue): one WAVE per row, nine or eleven rows in flight per
+    // CU (sp_wave_kernel.hpp) — when the average row fits its 63 packed trips with room to spare, or on request.  Up to 2^17 output columns
+    // the wave's column bitmap is exact; beyond, columns alias modulo 2^17 (an aliased column only takes the collision-set route, where
+    // sums are kept per column: exact) and sp_row_desc_kernel sends the kernel the rows whose expected marks fit its collision set.
+    c->wave = c->items_rows > 0 && c->mono && NT_s == 256 && a->n_output_cols > T && a->k <= WV_KMAX &&
               !(a->reserved[0] & 16384) && (want_wave || (!a->threads_per_wg && avg_macs <= 10000.0));
     c->wgs_wave = 0;
     // (a wave call's records are one per SEGMENT, 64 per row — sp_row_items_wave_kernel; the few rows its workgroup-per-row companion takes

@@ -173,6 +173,12 @@ __global__ __launch_bounds__(256) void sp_row_desc_kernel(int n_targets, const i
             sparse = expect <= 0.30f * (float)cp.cs_slots;
         }
         wavey = sparse && cp.wave && (e - s) <= 64 && macs <= cp.wave_macs_max;
+        if (wavey && cp.n_cols > (1 << 17)) {
+            // the wave kernel's column bitmap has 2^17 bits: beyond, aliased columns are marked like true collisions and must fit the 512
+            // direct slots of its collision set with room to spare
+            const float m = (float)macs;
+            wavey = 0.5f * m * m * (1.f / (float)cp.n_cols + 1.f / (float)(1 << 17)) <= 0.45f * 512.f;
+        }
     }
     // heavy generic rows: one queue entry per piece
     int split_id = -1, n_pieces = 0, per_piece = 0, piece0 = 0;

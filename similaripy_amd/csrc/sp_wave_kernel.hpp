@@ -9,7 +9,8 @@
 //
 // Same algorithm as the monotone variant of the sparse kernel (s_plus.h:71-127 dense sums[] -> column BITMAP + two sweeps;
 // s_plus.h:39-64 heap -> radix selection; s_plus.h:129-156 epilogue on the winners; s_plus.h:159-171 MATRIX filter):
-//   sweep 1 (column ids)      one bit per output column (n_cols <= 2^17: exact); a product that finds its bit set marks its
+//   sweep 1 (column ids)      one bit per output column (n_cols <= 2^17; beyond, columns alias modulo 2^17 and an aliased column is
+//                             marked like a repeated one — summed where it need not be, still exact); a product that finds its bit set marks its
 //                             column in the 8 k-bit collision bitmap (columns alias modulo its size: an aliased column is only
 //                             summed where it need not be);
 //   clear + rank prefix       the bitmap's storage becomes [collision set 1024 slots | member pool | U];
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
     const bool any_norm = (p.l1 != 0.f || p.l2 != 0.f || p.l3 != 0.f || p.stab != 0.f || p.bayes != 0.f);
-    const unsigned amask = (unsigned)((1 << (WV_BM_LOG2 - 3)) - 1) & ~3u;      // (column ids are below n_cols <= 8 * A_BYTES)
+    const unsigned amask = (unsigned)((1 << (WV_BM_LOG2 - 3)) - 1) & ~3u;      // (n_cols <= 8 * A_BYTES: every column its own bit; more columns — the 16 KB region only — alias modulo 2^17)
     // phase timers (profiling passes only): lane 0 adds every interval straight to the global counters — no registers held for them
     const bool timing = (p.phase_cycles != nullptr) && lane == 0;
     u64 tmark = timing ? (u64)clock64() : 0;

@@ -1162,6 +1162,18 @@ def test_wave_kernel_gap_free_trips_edge_shapes():
         _check(call, f"wave kernel gap-free trips {kw}", threads_per_wg=64)
 
 
+def test_wave_kernel_more_columns_than_bitmap_bits():
+    """More than 2^17 output columns: the wave kernel's column bitmap aliases modulo 2^17 — a column whose bit another column set is marked
+    like a repeated one and summed in the collision set (per column: exact).  300 k items, with and without the MATRIX filter."""
+    urm, wt = _scoring_problem(n_users=4000, n_items=300000, per_user=45, per_item=70, seed=12)
+    for kw in (dict(k=60), dict(k=25, filter_cols=urm, threshold=0.01)):
+        call = _host.prepare(urm, wt, **kw)
+        ran, info = _ran_on_the_wave_kernel(call)
+        assert ran, "the library did not pick the wave kernel"
+        assert info["phase_cycles"][9] >= 0.98 * call.n_targets, f"rows finished on the sparse-row path: {info['phase_cycles'][9]} of {call.n_targets}"
+        _check(call, f"wave kernel, 300 k columns {sorted(kw)}")
+
+
 def test_wave_kernel_tied_values_and_repeated_calls():
     """Binary data: every product is 1, the k-th place is a mass tie (the selection keeps exactly k, any of the tied); and the same
     call repeated gives the same kept VALUES every time (no LDS state leaks from row to row or call to call)."""
