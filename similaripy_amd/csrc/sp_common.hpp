@@ -576,14 +576,10 @@ __device__ __forceinline__ void s1_core(const unsigned (&c)[4], const unsigned (
             "ds_or_rtn_b32 %[b2], %[a2], %[b2] offset:%[off]\n\t"
             "ds_or_rtn_b32 %[b3], %[a3], %[b3] offset:%[off]\n\t"
             "s_waitcnt lgkmcnt(0)\n\t"
-            "v_bfe_u32 %[b0], %[b0], %[c0], 1\n\t"
-            "v_bfe_u32 %[b1], %[b1], %[c1], 1\n\t"
-            "v_bfe_u32 %[b2], %[b2], %[c2], 1\n\t"
-            "v_bfe_u32 %[b3], %[b3], %[c3], 1\n\t"
-            "v_and_b32 %[b0], %[b0], %[o0]\n\t"
-            "v_and_b32 %[b1], %[b1], %[o1]\n\t"
-            "v_and_b32 %[b2], %[b2], %[o2]\n\t"
-            "v_and_b32 %[b3], %[b3], %[o3]\n\t"
+            "v_bfe_u32 %[b0], %[b0], %[c0], %[o0]\n\t"      // (the field is `one[j]` bits wide: nothing for padding)
+            "v_bfe_u32 %[b1], %[b1], %[c1], %[o1]\n\t"
+            "v_bfe_u32 %[b2], %[b2], %[c2], %[o2]\n\t"
+            "v_bfe_u32 %[b3], %[b3], %[c3], %[o3]\n\t"
             : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [b0] "=&v"(b0), [b1] "=&v"(b1), [b2] "=&v"(b2), [b3] "=&v"(b3)
             : [c0] "v"(c[0]), [c1] "v"(c[1]), [c2] "v"(c[2]), [c3] "v"(c[3]), [o0] "v"(one[0]), [o1] "v"(one[1]), [o2] "v"(one[2]), [o3] "v"(one[3]),
               [am] "s"(amask), [off] "i"(BM_OFF)

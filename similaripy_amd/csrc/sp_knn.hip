@@ -344,9 +344,9 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
     c->wave = c->items_rows > 0 && c->mono && NT_s == 256 && a->n_output_cols > T && a->k <= WV_KMAX &&
               !(a->reserved[0] & 16384) && (want_wave || (!a->threads_per_wg && avg_macs <= 10000.0));
     c->wgs_wave = 0;
-    // (a wave call's records are one per SEGMENT, 64 per row — sp_row_items_wave_kernel; the few rows its workgroup-per-row companion takes
-    // need more than a 64-record slot holds and are set up in the kernel)
-    if (c->wave) c->items_stride = 64;
+    // (a wave call's records are one per SEGMENT, 64 x 12 bytes per row — sp_row_items_wave_kernel; the few rows its workgroup-per-row
+    // companion takes need more than such a slot holds and are set up in the kernel)
+    if (c->wave) c->items_stride = WAVE_ITEMS_STRIDE;
     c->ws_items_bytes = ((size_t)c->items_rows * (size_t)c->items_stride * 16 + 255) & ~(size_t)255;
     if (c->wave) {
         // (the workgroup-per-row kernel keeps its 256-thread shape beside it: sparse rows the wave kernel does not take — more than 64 m1

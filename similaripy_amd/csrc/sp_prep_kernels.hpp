@@ -355,15 +355,18 @@ __global__ __launch_bounds__(256) void sp_row_items_kernel(const unsigned *__res
     }
 }
 
-// Work records of the rows in the WAVE queue (sp_wave_kernel.hpp), once per call: one 16-byte record per SEGMENT, 64 per row (1 KB).
+// Work records of the rows in the WAVE queue (sp_wave_kernel.hpp), once per call: one 12-byte record per SEGMENT, 64 per row (768 B).
 // The wave kernel lays a row's segments end to end on the virtual lane axis with NO gaps — any number of pieces per trip (the
 // two-piece rule above leaves a user-scoring row of 100-element segments at 50 lanes of 64 per trip) — and finds every lane's segment
-// by counting segment starts (v_mbcnt on a per-trip start mask it builds from the V below), so a record only has to make
+// by counting segment starts (v_mbcnt on a per-trip start mask), so a record only has to say where the segment's elements are, how
+// many, and what they are scaled by: record i (position order: descending |m1 value|) = {4 r0 = byte offset of the m2 row, len, m1 value
+// bits}; the kernel's scan of ceil(len / 4) gives the segment's first lane V, and with B = 4 r0 - 16 V, D = len + 4 V
 //     byte offset into m2  = B + 16 u        elements left for the lane = D - 4 u        (u = 64 T + lane, the lane's place on the axis)
-// work for every lane of its segment: record i (position order: descending |m1 value|) = {B = 4 r0 - 16 V, D = len + 4 V, m1 value bits,
-// V = first virtual lane}; records behind the last segment are zero (D = 0: no lane ever finds elements there).  n_trips = ceil(lanes / 64)
-// and the segment count go into the row's queue descriptor; rows of more than 64 entries, more than 63 trips or 2^20 products keep 0
-// trips there and the wave kernel hands them to the generic kernel.
+// hold for every lane of the segment.  Records behind the last segment are zero.  n_trips = ceil(lanes / 64) and the segment count go
+// into the row's queue descriptor; rows of more than 64 entries, more than 63 trips or 2^20 products keep 0 trips there and the wave
+// kernel hands them to the generic kernel.
+struct __attribute__((packed, aligned(4))) WaveSegRec { int off4; int len; unsigned vbits; };
+constexpr int WAVE_ITEMS_STRIDE = 64 * (int)sizeof(WaveSegRec) / 16;      // 48 sixteen-byte units per output slot
 __global__ __launch_bounds__(256) void sp_row_items_wave_kernel(const unsigned *__restrict__ qcount, int items_rows, int4 *__restrict__ desc_w,
                                                                  const int *__restrict__ m1_indices, const float *__restrict__ m1_data,
                                                                  const int *__restrict__ m2_indptr, int4 *__restrict__ items_g, int stride) {
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(256) void sp_row_items_wave_kernel(const unsigned *
     for (int q = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); q < n_rows; q += waves_total) {
         const int4 d = desc_w[2 * (size_t)q];
         const int slot = __builtin_amdgcn_readfirstlane(d.x), s = __builtin_amdgcn_readfirstlane(d.z), n1 = __builtin_amdgcn_readfirstlane(d.w);
-        if (slot >= items_rows || n1 > 64 || stride < 64) continue;
+        if (slot >= items_rows || n1 > 64 || stride < WAVE_ITEMS_STRIDE) continue;
         int r0_in = 0, len_in = 0;
         unsigned vbits_in = 0u;
         if (lane < n1) {
@@ -382,25 +385,28 @@ __global__ __launch_bounds__(256) void sp_row_items_wave_kernel(const unsigned *
             r0_in = m2_indptr[u];
             len_in = m2_indptr[u + 1] - r0_in;
         }
-        const unsigned key = (lane < n1 && len_in > 0) ? ((vbits_in & 0x7FFFFFFFu) | 1u) : 0u;      // 0 = no segment
-        int rank = 0;                  // position in descending key order (ties: lower lane first; empty lanes last): a permutation
+        // position in descending |m1 value| order, empty lanes last.  The order is a heuristic (large products first: the running k-th value
+        // starts high), so the key keeps the value's top 24 bits and ends in 63 - lane: all 64 keys differ and a position is a plain count
+        // (a readlane, a compare and an add-with-carry per lane; the exact order with its tie rule costs five)
+        const bool real = lane < n1 && len_in > 0;
+        const unsigned key = (real ? (0x80000000u | (((vbits_in & 0x7FFFFFFFu) >> 7) << 6)) : 0u) | (unsigned)(63 - lane);
+        int rank = 0;
         for (int j = 0; j < 64; ++j) {
             const unsigned kj = (unsigned)__builtin_amdgcn_readlane((int)key, j);
-            rank += (kj > key || (kj == key && j < lane)) ? 1 : 0;
+            rank += (kj > key) ? 1 : 0;
         }
-        const int r0 = __builtin_amdgcn_ds_permute(rank * 4, key != 0u ? r0_in : 0);
-        const int len = __builtin_amdgcn_ds_permute(rank * 4, key != 0u ? len_in : 0);
-        const unsigned vbits = (unsigned)__builtin_amdgcn_ds_permute(rank * 4, key != 0u ? (int)vbits_in : 0);
-        const int n_seg = __popcll(__ballot(key != 0u));
+        const int r0 = __builtin_amdgcn_ds_permute(rank * 4, real ? r0_in : 0);
+        const int len = __builtin_amdgcn_ds_permute(rank * 4, real ? len_in : 0);
+        const unsigned vbits = (unsigned)__builtin_amdgcn_ds_permute(rank * 4, real ? (int)vbits_in : 0);
+        const int n_seg = __popcll(__ballot(real));
         const int L = (len + 3) >> 2;
         const int l_incl = wave_incl_scan_dpp(L);
-        const int V = l_incl - L;
         const int lanes = __builtin_amdgcn_readlane(l_incl, 63);
         const int total = __builtin_amdgcn_readlane(wave_incl_scan_dpp(len), 63);
         const int n_trips = (lanes + 63) >> 6;
         if (n_seg == 0 || n_trips > 63 || total >= (1 << 20)) continue;
-        int4 *row = items_g + (size_t)slot * (size_t)stride;
-        row[lane] = (lane < n_seg) ? make_int4((int)(4u * (unsigned)r0 - 16u * (unsigned)V), len + 4 * V, (int)vbits, V) : make_int4(0, 0, 0, 0);
+        WaveSegRec *row = (WaveSegRec *)(items_g + (size_t)slot * (size_t)stride);
+        row[lane] = (lane < n_seg) ? WaveSegRec{(int)(4u * (unsigned)r0), len, vbits} : WaveSegRec{0, 0, 0u};
         if (lane == 0) ((int *)&desc_w[2 * (size_t)q])[3] = n1 | (n_trips << 9) | (n_seg << 19);
     }
 }

@@ -323,15 +323,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         const float den = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane(d1.y));
         bool failed = (n_tr <= 0 || n_tr > 63 || slot >= p.items_rows);
 
-        // segment records (sp_row_items_wave_kernel): lane i holds segment i = {B, D, m1 value bits, V}.  The segments lie end to end on
-        // the virtual lane axis; lane l of trip T is place u = 64 T + l of it and belongs to segment #{i >= 1 : V_i - 1 < u}: the number of
-        // START MARKS (bit V_i - 1 of an axis-long bitmap) below u.  The bitmap is built in LDS — one ds_or per segment, region A is clean
-        // between rows —, lane T takes trip T's 64 marks and the number of marks before them, and the 512 bytes go back to zero.
-        int4 seg = make_int4(0, 0, 0, 0);
+        // segment records (sp_row_items_wave_kernel): lane i holds segment i = {byte offset of its m2 row, len, m1 value bits}, in the order the
+        // segments are visited.  The segments lie end to end on the virtual lane axis — segment i starts at lane V_i = sum of ceil(len / 4)
+        // before it — and lane l of trip T is place u = 64 T + l of it: with B = offset - 16 V and D = len + 4 V the lane's byte offset is
+        // B + 16 u and it has D - 4 u elements left.  It belongs to segment #{i >= 1 : V_i - 1 < u}: the number of START MARKS (bit V_i - 1 of
+        // an axis-long bitmap) below u.  The bitmap is built in LDS — one ds_or per segment, region A is clean between rows —, lane T takes
+        // trip T's 64 marks and the number of marks before them, and the 512 bytes go back to zero.
+        int4 seg = make_int4(0, 0, 0, 0);      // {B, D, m1 value bits, V}
         int f0 = 0, fl = 0;
         if (!failed) {
-            seg = (p.items_g + (size_t)slot * (size_t)p.items_stride)[lane];
+            const WaveSegRec r = ((const WaveSegRec *)(p.items_g + (size_t)slot * (size_t)p.items_stride))[lane];
             if (p.filter_mode == SP_SEL_MATRIX) { f0 = p.f_indptr[t]; fl = p.f_indptr[t + 1] - f0; }
+            const int L = (r.len + 3) >> 2;
+            const int V = wave_incl_scan_dpp(L) - L;
+            if (r.len > 0) seg = make_int4(r.off4 - 16 * V, r.len + 4 * V, (int)r.vbits, V);
         }
         unsigned t_mlo, t_mhi;
         int t_cum;
