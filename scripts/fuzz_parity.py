@@ -111,6 +111,9 @@ def one_case(i):
     tuning = {}
     if rng.random() < 0.2: tuning["table_slots"] = int(rng.choice([1024, 2048, 4096]))
     if rng.random() < 0.15: tuning["threads_per_wg"] = int(rng.choice([256, 512, 768]))
+    # (a generator of its own, as for `stages` below: one case in five asks for the wave-per-row kernel, which the library grants wherever the
+    # call qualifies — monotone epilogue, k <= 128 — and whose rows of more than 64 entries or 10 k products take the other queues)
+    if not tuning and np.random.default_rng([a.seed, i, 11]).random() < 0.2: tuning["threads_per_wg"] = 64
     on_dev = (m2 is None) and rng.random() < 0.6
     # (a generator of its own: the cases of the seeds of earlier rounds stay what they were)
     stages = bool(np.random.default_rng([a.seed, i, 7]).random() < 0.4) and not a.dbg
@@ -204,7 +207,15 @@ def one_case(i):
     # ... and with a Bayesian shrink b the value has a pole at raw dot = -b: near it no tolerance is meaningful
     pole = signed and (kw.get("bayesian_shrink", 0.0) != 0.0 or kw.get("l1", 0.0) != 0.0)      # (a Tversky denominator has one too)
     pole_ = pole      # (values there may differ by any factor: 1e9 = sets only)
-    so.compare_topk(got, want, call.k, rtol=(1e9 if pole else 1e-3) if signed else 1e-5, atol=1e-5 if signed else 1e-7, what=desc)
+    if pole:
+        # ... and a row that sits ON the pole on either side (a denominator of exactly 0 in one summation order: inf, or a value beyond any the data can
+        # produce away from it) has no defined top-k at all: set aside (seed 408 case 161: raw dot = -0.5 = -b exactly on one side, +inf kept first)
+        empty = (np.zeros(0, np.int32), np.zeros(0, np.float32))
+        for j in range(len(got)):
+            gv_, wv_ = got[j][1], want[j][1]
+            if (gv_.size and (~np.isfinite(gv_) | (np.abs(gv_) > 1e6)).any()) or (wv_.size and (~np.isfinite(wv_) | (np.abs(wv_) > 1e6)).any()):
+                got[j] = want[j] = empty
+    so.compare_topk(got, want, call.k, rtol=(1e9 if pole else 1e-3) if signed else 1e-5, atol=1e-5 if signed else 1e-7, what=desc, threshold=kw.get("threshold"))
     n, kk = call.n_targets, call.k
     pad = np.arange(kk)[None, :] >= counts[:, None]
     assert not rows.reshape(n, kk)[pad].any() and not cols.reshape(n, kk)[pad].any() and not vals.reshape(n, kk)[pad].any(), "padding not zero: " + desc
