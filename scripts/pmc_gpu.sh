@@ -24,6 +24,8 @@ for f in sorted(glob.glob(out + "/pass*.csv")):
     rows = list(csv.DictReader(open(f)))
     # one row per (dispatch, counter); keep the LAST dispatch of the kernel (the timed step)
     if not rows: continue
+    # (a wave call launches its workgroup-per-row companion behind the wave kernel, on a handful of rows: the wave kernel is the one to count)
+    if any("sp_knn_wave" in r["Kernel_Name"] for r in rows): rows = [r for r in rows if "sp_knn_wave" in r["Kernel_Name"]]
     last = max(int(r["Dispatch_Id"]) for r in rows)
     for r in rows:
         if int(r["Dispatch_Id"]) == last:
