@@ -261,6 +261,11 @@ __global__ __launch_bounds__(256) void sp_row_items_kernel(const unsigned *__res
                                                             const int *__restrict__ m1_indices, const float *__restrict__ m1_data,
                                                             const int *__restrict__ m2_indptr, int4 *__restrict__ items_g, int pack,
                                                             const int *__restrict__ f_indptr, int stride) {
+    // the row's records are put together in LDS and leave in 1 KB stores (lane l: records l, l + 64, ...): written in place, every lane's two or
+    // three records of a segment went out at a 48-byte stride — three partial stores per 128-byte line (C2: 1.69 -> 1.42 ms per step; the kernel
+    // is bound by its 3 GB of record writes: a cheaper ranking and a three-row load pipeline were measured at 0.0 ms, profiles/r05_exp_dropped.txt)
+    __shared__ int4 img_all[4][ITEMS_STRIDE];
+    int4 *img = img_all[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63;
     const int n_rows = (int)qcount[0];
     const int waves_total = (int)(gridDim.x * (blockDim.x >> 6));
@@ -335,11 +340,11 @@ __global__ __launch_bounds__(256) void sp_row_items_kernel(const unsigned *__res
             for (int T = t_first; T <= t_last; ++T) {
                 const int a = 64 * T - V;                               // lanes of the segment before this window
                 const int cnt = min(4 * min(64, L - a), len - 4 * a);
-                row[1 + T] = make_int4((r0 + 4 * a) * 4, cnt, (int)vbits, (E + 4 * a) | ((T == t_last && has_b) ? (bidx << 20) : 0));
+                img[1 + T] = make_int4((r0 + 4 * a) * 4, cnt, (int)vbits, (E + 4 * a) | ((T == t_last && has_b) ? (bidx << 20) : 0));
             }
             if (has_b) {
                 const int sb = Vn & 63;
-                row[1 + bidx] = make_int4(r0n * 4, min(4 * min(64 - sb, Ln), lenn), vbn, sb);
+                img[1 + bidx] = make_int4(r0n * 4, min(4 * min(64 - sb, Ln), lenn), vbn, sb);
             }
         }
         if (lane == 0) {
@@ -347,11 +352,14 @@ __global__ __launch_bounds__(256) void sp_row_items_kernel(const unsigned *__res
             // the list's columns on their way before its first sweep)
             int f0 = 0, fl = 0;
             if (f_indptr != nullptr) { f0 = f_indptr[t_row]; fl = f_indptr[t_row + 1] - f0; }
-            row[0] = make_int4(f0, fl, 0, 0);
-            row[1 + n_trips] = make_int4((int)OOB_SOFFSET, 0, 0, total);
+            img[0] = make_int4(f0, fl, 0, 0);
+            img[1 + n_trips] = make_int4((int)OOB_SOFFSET, 0, 0, total);
             // the counts travel in the row's descriptor (the row kernel has it in scalar registers two rows ahead)
             ((int *)&desc_s[2 * (size_t)q])[3] = n1 | (n_trips << 9) | (n_rec << 19);
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // (one wave owns the image: LDS runs its accesses in order)
+        for (int i = lane; i <= n_rec; i += 64) row[i] = img[i];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
 }
 
