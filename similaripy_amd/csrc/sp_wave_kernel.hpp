@@ -33,11 +33,13 @@
 
 namespace {
 
+// trips in flight per wave, sweep 1 / sweep 2.  Measured on the gap-free trips (C5 kernel ms, -DWV_D1= -DWV_D2= builds): 2/2 21.7, 3/3 20.68, 4/3 20.70,
+// 4/4 20.75, 6/5 20.85, 8/6 (round 4's choice) 21.1, 10/6 21.1; user scoring over 10^6 items (m2 streamed from HBM) 14.06 - 14.13 at every depth
 #ifndef WV_D1
-#define WV_D1 8      // trips in flight per wave, sweep 1 / sweep 2
+#define WV_D1 4
 #endif
 #ifndef WV_D2
-#define WV_D2 6
+#define WV_D2 3
 #endif
 constexpr int WV_BM_LOG2 = 17;                                  // column bitmap: up to 2^17 bits
 constexpr int WV_CBM_BYTES = 1024;                              // collision bitmap: 8192 bits
