@@ -29,7 +29,7 @@ for name, a, b, kw in cases:
     want = so.canonical(*so.run_kernel(call, "port"), call.targets, call.k)
     t0 = time.time()
     for r in range(reps):
-        for tun in ({}, {"threads_per_wg": 256}):
+        for tun in ({}, {"threads_per_wg": 256}) + (({"threads_per_wg": 64},) if name.startswith("monotone") else ()):      # (64: the wave-per-row kernel where the call qualifies)
             rows, cols, vals, counts = _host.run_hip(call, **tun)
             got = so.canonical(rows, cols, vals, call.targets, call.k)
             try:
@@ -37,5 +37,5 @@ for name, a, b, kw in cases:
             except AssertionError as e:
                 bad += 1
                 print(f"MISMATCH {name} rep {r} {tun}: {str(e)[:300]}", flush=True)
-    print(f"{name}: {reps} x 2 runs in {time.time() - t0:.1f}s", flush=True)
+    print(f"{name}: {reps} x 2 (monotone: x 3) runs in {time.time() - t0:.1f}s", flush=True)
 print("stress:", "FAILED" if bad else "ok", bad)
