@@ -36,6 +36,8 @@ for world in (1, 2, 4, 8):
     if base is None:
         base = max(times)
     print(f"N={world}: slowest slice {max(times):.2f} ms (x{base / max(times):.2f}); slices " + " ".join(f"{t:.2f}" for t in times), flush=True)
+    if world == 8:
+        print("   N=8 slices (GMACs, k rows, pieces): " + "  ".join(f"({o[0] / 1e9:.2f}, {o[1] / 1e3:.1f}, {int(o[2])})" for o in obs[-8:]), flush=True)
 A = np.array([(o[0] / 1e9, o[1] / 1e3, o[2], 1.0) for o in obs]); y = np.array([o[3] for o in obs])
 coef, *_ = np.linalg.lstsq(A, y, rcond=None)
 print(f"fit: ms = {coef[0]:.3f} * GMACs + {coef[1]:.4f} * krows + {coef[2]:.4f} * pieces + {coef[3]:.3f};  residuals (ms): "
