@@ -59,10 +59,15 @@ def row_cost(call: KernelCall) -> np.ndarray:
     n_cols = float(max(1, call.n_output_cols))
     nnz1 = np.diff(call.m1_indptr).astype(np.int64)[call.targets] if call.m1_indptr.size else np.zeros(call.n_targets, np.int64)
     sparse = (0.5 * macs * macs / n_cols <= 0.30 * 4096.0) & (nnz1 <= 256) & (call.n_output_cols > 16384)
-    return macs + np.where(sparse, ROW_TOLL_MACS, GENERIC_TOLL_PER_COL * n_cols)
+    # A HEAVY generic row (cut into column-window pieces, sp_row_desc_kernel) costs by its m1 entries, not its MACs: each of its ~21 fine windows
+    # walks all of the row's segments for a handful of elements each.  Least squares over the 15 slices of N = 1, 2, 4, 8 at the MovieLens-32M
+    # shape (profiles/r05_exp_dropped.txt): 2.1 k MAC equivalents per entry of such a row — 247 rows, 19 % of the MACs, a third of the time.
+    heavy = (~sparse) & (macs >= 2.0 * (1 << 21)) & (call.n_output_cols > 65536)
+    return macs + np.where(sparse, ROW_TOLL_MACS, GENERIC_TOLL_PER_COL * n_cols) + np.where(heavy, HEAVY_ENTRY_MACS * nnz1, 0.0)
 
 
 ROW_TOLL_MACS = 30_000.0       # fixed cost of a sparse-kernel row, in MACs
+HEAVY_ENTRY_MACS = float(os.environ.get("SIMILARIPY_AMD_HEAVY_ENTRY_MACS", "2100"))      # what an m1 entry of a heavy (piece-split) generic row costs on top of its MACs
 GENERIC_TOLL_PER_COL = float(os.environ.get("SIMILARIPY_AMD_GENERIC_TOLL_PER_COL", "3.0"))      # fixed cost of a generic-kernel row per output column
 
 
