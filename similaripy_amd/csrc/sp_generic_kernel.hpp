@@ -279,9 +279,8 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                         int r0 = p.m2_indptr[u], r1 = p.m2_indptr[u + 1];
                         if (!whole && use_splits) {
                             // both ends are multiples of the fine window width: their positions were found once per call (sp_m2_splits_kernel)
-                            const int *sp = p.splits + (size_t)u * (size_t)p.n_splits;
-                            if (wlo != 0) r0 = sp[wlo / p.split_w - 1];
-                            if (whi < p.n_cols) r1 = sp[whi / p.split_w - 1];
+                            if (wlo != 0) r0 = p.splits[(size_t)(wlo / p.split_w - 1) * (size_t)p.splits_rows + (size_t)u];
+                            if (whi < p.n_cols) r1 = p.splits[(size_t)(whi / p.split_w - 1) * (size_t)p.splits_rows + (size_t)u];
                         } else if (!whole) {
                             // slice of the sorted m2 row inside [wlo, whi)  (s_plus.h:385-394)
                             if (wlo != 0) {

@@ -646,7 +646,7 @@ __global__ __launch_bounds__(256) void sp_fold_colterm_kernel(long long nnz, con
 }
 
 // Boundaries of the generic kernel's standard dense windows [j*width, (j+1)*width) inside every (sorted) m2 row:
-// out[u*n_splits + j] = first position of row u whose column id is >= (j+1)*width  (s_plus.h:385-394 does this lower_bound
+// out[j*n_rows + u] (boundary-major) = first position of row u whose column id is >= (j+1)*width  (s_plus.h:385-394 does this lower_bound
 // per target row and block; the boundaries do not depend on the target row)
 // Launched BEHIND the sparse-row kernels, in front of the generic one: only the generic kernel reads the boundaries, and a call whose
 // generic queue is empty by then (qcount_g: rows classified generic + the sparse kernels' give-ups) skips the pass — the headline shape
@@ -659,16 +659,30 @@ __global__ __launch_bounds__(256) void sp_m2_splits_kernel(int n_rows, const int
     // One WAVE per m2 row, one coalesced pass over its (ascending) column ids: element i starts window idx[i] / width; every window that
     // begins between element i - 1 and element i has its boundary at position i (round 4 ran a lower_bound — eight dependent loads — per
     // row and boundary: 0.27 ms per call at the MovieLens shape with 10 boundaries per row, twice that with the 20 of round 5's finer pieces)
-    const int lane = threadIdx.x & 63;
-    const long long wave0 = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6, n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
-    for (long long u = wave0; u < n_rows; u += n_waves) {
-        const int r0 = indptr[u], r1 = indptr[u + 1];
-        int *o = out + (size_t)u * (size_t)n_splits;
-        for (int i = r0 + lane; i <= r1; i += 64) {
-            const int wprev = (i == r0) ? 0 : min(n_splits, indices[i - 1] / width);
-            const int wcur = (i == r1) ? n_splits : min(n_splits, indices[i] / width);
-            for (int w = wprev; w < wcur; ++w) o[w] = i;      // boundary w: the first position whose column id is >= (w + 1) * width
+    // The table is boundary-major (out[w * n_rows + u]): a heavy row's entries are ascending m2 rows, so the generic kernel's gathers of ONE boundary
+    // for them lie next to each other (row-major they were 4 bytes out of every 80).  A workgroup takes 64 consecutive rows, sixteen per wave, collects
+    // their boundaries in LDS and writes 256-byte lines.
+    __shared__ int tile[32][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long n_tiles = ((long long)n_rows + 63) >> 6;
+    for (long long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        for (int q = 0; q < 16; ++q) {
+            const int rt = wave * 16 + q;                      // row of the tile
+            const long long u = t * 64 + rt;
+            if (u >= n_rows) break;                            // (uniform per wave)
+            const int r0 = indptr[u], r1 = indptr[u + 1];
+            for (int i = r0 + lane; i <= r1; i += 64) {
+                const int wprev = (i == r0) ? 0 : min(n_splits, indices[i - 1] / width);
+                const int wcur = (i == r1) ? n_splits : min(n_splits, indices[i] / width);
+                for (int w = wprev; w < wcur; ++w) tile[w][rt] = i;      // boundary w: the first position whose column id is >= (w + 1) * width
+            }
         }
+        __syncthreads();
+        for (int w = wave; w < n_splits; w += 4) {
+            const long long u = t * 64 + lane;
+            if (u < n_rows) out[(size_t)w * (size_t)n_rows + (size_t)u] = tile[w][lane];
+        }
+        __syncthreads();
     }
     __syncthreads();
     if (threadIdx.x == 0) {
