@@ -111,6 +111,8 @@ struct KParams {
     int *part_counts;          // [piece]
     const int *splits;     // generic kernel, optional: [n_splits][splits_rows] (boundary-major) position of the first entry of m2 row u with column >= (j+1)*split_w
     int splits_rows;       //   = n_rows_m2: a heavy row's entries are ascending m2 rows, so one boundary's positions for them lie next to each other
+    const int *splits_state;   //   [0] != 0 once the table exists in this workspace: a call whose generic queue holds a handful of rows skips the pass
+                               //   over m2 (sp_m2_splits_kernel) and those rows find their window slices by lower_bound, as s_plus.h:385-394 does
     int n_splits;          //   (the boundaries of the fine windows, found once per call instead of once per use)
     int split_w;           //   fine window width: 2T / f, f in {1, 2, 4}; standard dense windows start at multiples of 2T
     // work items of the sparse kernel's rows, cut once per call by sp_row_items_kernel (optional): record 0 of an output slot's

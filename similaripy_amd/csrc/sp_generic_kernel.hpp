@@ -149,6 +149,7 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
     // rows of this kernel: descriptors [0, n_rows) of the generic queue (filled by the classification prepass and
     // by the sparse kernel's give-ups, both complete before this launch starts)
     const int n_rows = (int)p.qcount[1];
+    const bool have_splits = p.splits != nullptr && (p.splits_state == nullptr || __builtin_amdgcn_readfirstlane(p.splits_state[0]) != 0);      // (uniform; written by an earlier launch)
     const int4 *desc = p.desc_g;
     int qi = 0;
     if (tid == 0) sh[SH_QA] = p.static_sched ? (int)blockIdx.x : (int)atomicAdd(&p.queue[1], 1u);
@@ -238,6 +239,7 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
             }
 
             long long lo = 0, col_end = p.n_cols;
+            bool first_window = true;      // of this row or piece (uniform)
             if (piece >= 0) {       // (the splitter only cuts rows of a call with standard windows: n_cols > Td)
                 width = Td;
                 lo = (long long)(piece_range & 0xFFFF) * p.split_w;
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                 // Window slices chain (hi of window w == lo of window w+1), so when the m1 row fits one
                 // batch the previous slice end is kept in LDS and only one lower_bound per window is run.
                 const bool carry = (n1 <= NT);
-                const bool use_splits = p.splits != nullptr && width == Td && (lo % p.split_w) == 0 && (hi == p.n_cols || (hi % p.split_w) == 0);   // (a hashed row halved down to Td may sit elsewhere)
+                const bool use_splits = have_splits && width == Td && (lo % p.split_w) == 0 && (hi == p.n_cols || (hi % p.split_w) == 0);   // (a hashed row halved down to Td may sit elsewhere)
                 for (int b0 = 0; b0 < n1; b0 += NT) {
                     const int nb = min(NT, n1 - b0);
                     int len = 0;
@@ -284,7 +286,7 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                         } else if (!whole) {
                             // slice of the sorted m2 row inside [wlo, whi)  (s_plus.h:385-394)
                             if (wlo != 0) {
-                                if (carry) r0 = retry_window ? seg_lo[tid] : seg_hi[tid];
+                                if (carry && !first_window) r0 = retry_window ? seg_lo[tid] : seg_hi[tid];      // (a piece's first window starts inside the row: nothing to chain to)
                                 else r0 = lower_bound_g(p.m2_indices, r0, r1, wlo);
                             }
                             if (whi < p.n_cols) r1 = lower_bound_g(p.m2_indices, r0, r1, whi);
@@ -582,6 +584,7 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                 }
                 PHASE_END(PH_DRAIN);
                 lo = hi;
+                first_window = false;
             }
         }
 

@@ -792,7 +792,7 @@ int run_device_impl(sp_knn_args *a, const uint64_t *sig_override = nullptr) {
     if (c.fold) kp.m2_data = folded;
     kp.bnd = bnd_info; kp.colpack = bnd_colpack; kp.m2_packed = bnd_ids;
     kp.splits = nullptr;
-    kp.n_splits = 0;
+    kp.n_splits = 0; kp.splits_state = nullptr;
     kp.split_w = c.split_w;
     SplitsLaunch sl{};
     if (c.n_splits) {
@@ -800,7 +800,7 @@ int run_device_impl(sp_knn_args *a, const uint64_t *sig_override = nullptr) {
         sl.n_rows_m2 = a->n_rows_m2; sl.m2_indptr = a->m2_indptr; sl.m2_indices = a->m2_indices; sl.split_w = c.split_w; sl.n_splits = c.n_splits;
         sl.out = ws_split; sl.qcount_g = (const unsigned *)(ws + 12); sl.state = (int *)(ws + WS_SPLITS_STATE_OFFSET);
         kp.splits = ws_split;
-        kp.n_splits = c.n_splits; kp.splits_rows = a->n_rows_m2;
+        kp.n_splits = c.n_splits; kp.splits_rows = a->n_rows_m2; kp.splits_state = sl.state;
         kp.split_w = c.split_w;
     }
     kp.phase_cycles = (timed && (a->flags & SP_FLAG_PHASE_TIMERS)) ? (unsigned long long *)(ws + WS_PHASE_OFFSET) : nullptr;   // inside the zeroed header

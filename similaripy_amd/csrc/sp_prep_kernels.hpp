@@ -653,9 +653,11 @@ __global__ __launch_bounds__(256) void sp_fold_colterm_kernel(long long nnz, con
 // paid 0.13 ms per step for a queue that is always empty (VERDICT r4 next #2a).  state[0] = 1 once the boundaries exist in this
 // workspace (a SP_FLAG_REUSE_M2_PREP sub-launch whose predecessors all skipped builds them when it needs them), state[1] counts the
 // workgroups that are done (the last one publishes).
+constexpr unsigned SPLITS_MIN_QUEUE = 64u;      // generic-queue entries from which the window-boundary table is worth its pass over m2
 __global__ __launch_bounds__(256) void sp_m2_splits_kernel(int n_rows, const int *__restrict__ indptr, const int *__restrict__ indices, int width, int n_splits,
                                                             int *__restrict__ out, const unsigned *__restrict__ qcount_g, int *__restrict__ state) {
-    if (*(volatile const unsigned *)qcount_g == 0u || *(volatile const int *)&state[0] != 0) return;      // (uniform over the grid: nothing in this launch writes either)
+    // (a generic queue of a handful of rows — configs[4]: 12 of 10^6 — does not pay for a pass over m2: its rows find their slices by lower_bound)
+    if (*(volatile const unsigned *)qcount_g < SPLITS_MIN_QUEUE || *(volatile const int *)&state[0] != 0) return;      // (uniform over the grid: nothing in this launch writes either)
     // One WAVE per m2 row, one coalesced pass over its (ascending) column ids: element i starts window idx[i] / width; every window that
     // begins between element i - 1 and element i has its boundary at position i (round 4 ran a lower_bound — eight dependent loads — per
     // row and boundary: 0.27 ms per call at the MovieLens shape with 10 boundaries per row, twice that with the 20 of round 5's finer pieces)
