@@ -132,8 +132,9 @@ constexpr size_t WS_PHASE_OFFSET = 64;
 constexpr size_t WS_YMIN_OFFSET = 176;
 constexpr size_t WS_FOLDZERO_OFFSET = 160;      // int: a stored entry of m2 met a zero column term while it was folded in
 constexpr size_t WS_SPLITS_STATE_OFFSET = 192;  // int[2]: the dense-window boundaries exist in this workspace | workgroups of sp_m2_splits_kernel done
+constexpr size_t WS_SCRATCH_OFFSET = 228;       // 28 bytes of zeroed scratch for the per-call reductions (sp_colterm_min_kernel: done | sp_bnd_xmean / range: 5 + 1 words)
 constexpr size_t WS_BND_OFFSET = 200;           // BndInfo (28 bytes): the bounded variant's per-call facts, kept across SP_FLAG_REUSE_M2_PREP calls
-static_assert(WS_BND_OFFSET + sizeof(BndInfo) <= 256, "workspace header layout");
+static_assert(WS_BND_OFFSET + sizeof(BndInfo) <= WS_SCRATCH_OFFSET && WS_SCRATCH_OFFSET + 28 <= 256, "workspace header layout");
 static_assert(WS_PHASE_OFFSET + PH_N * 8 <= WS_FOLDZERO_OFFSET && WS_FOLDZERO_OFFSET + 4 <= WS_YMIN_OFFSET && WS_YMIN_OFFSET + 16 <= WS_SPLITS_STATE_OFFSET &&
               WS_SPLITS_STATE_OFFSET + 8 <= WS_QUEUE_BYTES, "workspace header layout");
 constexpr size_t LDS_LIMIT = 160 * 1024;
@@ -648,9 +649,9 @@ int run_device_impl(sp_knn_args *a, const uint64_t *sig_override = nullptr) {
         HIP_TRY(hipGetLastError());
     }
     if (!reuse && !c.fold && bound_ok && (a->l1 != 0.f || a->l2 != 0.f || a->l3 != 0.f)) {
-        hipLaunchKernelGGL(sp_colterm_min_kernel, dim3(1), dim3(1024), 0, stream, a->n_output_cols,
+        hipLaunchKernelGGL(sp_colterm_min_kernel, dim3((unsigned)std::max(1, std::min(256, (a->n_output_cols + 4095) / 4096))), dim3(1024), 0, stream, a->n_output_cols,
                            a->l1 != 0.f ? a->Ytversky : nullptr, a->l2 != 0.f ? a->Ycosine : nullptr,
-                           a->l3 != 0.f ? a->Ydepop : nullptr, ymin_dev);
+                           a->l3 != 0.f ? a->Ydepop : nullptr, ymin_dev, (unsigned *)(ws + WS_SCRATCH_OFFSET));
         HIP_TRY(hipGetLastError());
     }
 
@@ -664,8 +665,12 @@ int run_device_impl(sp_knn_args *a, const uint64_t *sig_override = nullptr) {
         bnd_ids = (unsigned *)(ws_fold + c.ws_bnd_ids);
         if (!reuse) {
             const float *ytv = (a->l1 != 0.f && a->t2 != 0.f) ? a->Ytversky : nullptr, *ycos = a->l2 != 0.f ? a->Ycosine : nullptr, *ydep = a->l3 != 0.f ? a->Ydepop : nullptr;
-            hipLaunchKernelGGL(sp_bnd_range_kernel, dim3(1), dim3(1024), 0, stream, a->n_output_cols, ytv, ycos, ydep, a->n_rows_m1,
-                               a->l2 != 0.f ? a->Xcosine : nullptr, a->l3 != 0.f ? a->Xdepop : nullptr, a->l1 * a->t2, a->l2, a->l3, bnd_info);
+            float *bnd_acc = (float *)(ws + WS_SCRATCH_OFFSET + 4);      // {sum cos, sum dep, n cos, n dep, done} | done of the second launch
+            hipLaunchKernelGGL(sp_bnd_xmean_kernel, dim3((unsigned)std::max(1, std::min(256, (a->n_rows_m1 + 4095) / 4096))), dim3(1024), 0, stream, a->n_rows_m1,
+                               a->l2 != 0.f ? a->Xcosine : nullptr, a->l3 != 0.f ? a->Xdepop : nullptr, ytv != nullptr, ycos != nullptr, ydep != nullptr,
+                               a->l1 * a->t2, a->l2, a->l3, bnd_acc, bnd_info);
+            hipLaunchKernelGGL(sp_bnd_range_kernel, dim3((unsigned)std::max(1, std::min(256, (a->n_output_cols + 4095) / 4096))), dim3(1024), 0, stream, a->n_output_cols,
+                               ytv, ycos, ydep, (unsigned *)(bnd_acc + 5), bnd_info);
             hipLaunchKernelGGL(sp_bnd_colpack_kernel, dim3(std::min(2048, (a->n_output_cols + 255) / 256)), dim3(256), 0, stream, a->n_output_cols, ytv, ycos, ydep,
                                (const BndInfo *)bnd_info, bnd_colpack);
             hipLaunchKernelGGL(sp_bnd_pack_ids_kernel, dim3(256 * 8), dim3(256), 0, stream, (long long)a->nnz_m2, a->m2_indices, (const unsigned *)bnd_colpack, bnd_ids, bnd_info);

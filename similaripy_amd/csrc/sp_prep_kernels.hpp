@@ -489,12 +489,17 @@ __global__ __launch_bounds__(256) void sp_merge_pieces_kernel(const int *__restr
     }
 }
 
-// Minima of the three column-term vectors over all columns (one workgroup; feeds Epi::upper).
-__global__ __launch_bounds__(1024) void sp_colterm_min_kernel(int n_cols, const float *Ytv, const float *Ycos, const float *Ydep, float *out) {
+// Minima of the three column-term vectors over all columns (feeds Epi::upper).  Many workgroups (one walked 10^6 columns in 0.57 ms): a
+// workgroup's minima go into out[] as INVERTED order keys by atomicMax — out[] is part of the zeroed workspace header, and 0 is "nothing yet" —
+// and the workgroup that arrives last (counter `done`, zeroed with the header) turns the keys back into floats.
+__device__ __forceinline__ unsigned min_key(float m) { return ~fkey(m); }            // larger key = smaller value; never 0 for a finite or infinite float
+__device__ __forceinline__ float min_unkey(unsigned k) { return funkey(~k); }
+__global__ __launch_bounds__(1024) void sp_colterm_min_kernel(int n_cols, const float *Ytv, const float *Ycos, const float *Ydep, float *out, unsigned *done) {
     __shared__ float red[3][16];
+    __shared__ bool last;
     const float inf = __builtin_inff();
     float m0 = inf, m1 = inf, m2 = inf;
-    for (int i = threadIdx.x; i < n_cols; i += 1024) {
+    for (long long i = (long long)blockIdx.x * 1024 + threadIdx.x; i < n_cols; i += (long long)gridDim.x * 1024) {
         if (Ytv) m0 = fminf(m0, Ytv[i]);
         if (Ycos) m1 = fminf(m1, Ycos[i]);
         if (Ydep) m2 = fminf(m2, Ydep[i]);
@@ -510,7 +515,16 @@ __global__ __launch_bounds__(1024) void sp_colterm_min_kernel(int n_cols, const 
     if (threadIdx.x < 3) {
         float m = inf;
         for (int w = 0; w < 16; ++w) m = fminf(m, red[threadIdx.x][w]);
-        out[threadIdx.x] = (m == inf) ? 0.f : m;   // vector not in use (or empty): its weight is 0 anyway
+        if (m < inf) atomicMax((unsigned *)out + threadIdx.x, min_key(m));
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(done, 1u) == gridDim.x - 1u;
+    __syncthreads();
+    if (last && threadIdx.x < 3) {
+        __threadfence();
+        const unsigned k = atomicMax((unsigned *)out + threadIdx.x, 0u);      // (a read that every earlier atomic is ordered before)
+        out[threadIdx.x] = k ? min_unkey(k) : 0.f;   // vector not in use (or empty): its weight is 0 anyway
     }
 }
 
@@ -521,18 +535,20 @@ __device__ __forceinline__ bool bnd_valid(float ytv, float ycos, float ydep, flo
     return (ytv >= 0.f) && (ycos >= 0.f) && (ydep >= 0.f) && (ytv < inf) && (ycos < inf) && (ydep < inf) && (w < inf) && ((__float_as_uint(w) >> BND_CODE_SHIFT) >= 2u) &&
            !(__float_as_uint(w) >> 31);
 }
-// (1) one workgroup: reference multipliers rho_j (l_j x the mean of the row terms that are finite and positive) and the minima of the
-//     live Y_j over the valid columns -> BndInfo
-__global__ __launch_bounds__(1024) void sp_bnd_range_kernel(int n_cols, const float *Ytv, const float *Ycos, const float *Ydep, int n_rows_m1,
-                                                             const float *Xcos, const float *Xdep, float l1t2, float l2, float l3, BndInfo *out) {
+// (1) reference multipliers rho_j (l_j x the mean of the row terms that are finite and positive) and the minima of the live Y_j over the
+//     valid columns -> BndInfo.  Two launches of many workgroups (one workgroup walked 10^6 rows and 10^6 columns in 0.92 ms): the row
+//     means first — partial sums by float atomics into the zeroed header words `acc` {sum cos, sum dep, n cos, n dep, done}, the workgroup
+//     that arrives last writes rho —, then the columns: the count of valid columns adds up in BndInfo::state and the minima collect as
+//     inverted order keys in the ymin fields (all zero at the start: the header is), the last workgroup makes them the final BndInfo.
+__global__ __launch_bounds__(1024) void sp_bnd_xmean_kernel(int n_rows_m1, const float *Xcos, const float *Xdep, bool has_tv, bool has_cos, bool has_dep,
+                                                             float l1t2, float l2, float l3, float *acc, BndInfo *out) {
     __shared__ double redd[2][16];
-    __shared__ unsigned redc[3][16];
-    __shared__ float rho[3];
-    __shared__ float redm[3][16];
+    __shared__ unsigned redc[2][16];
+    __shared__ bool last;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double s0 = 0.0, s1 = 0.0;
     unsigned c0 = 0, c1 = 0;
-    for (int i = tid; i < n_rows_m1; i += 1024) {
+    for (long long i = (long long)blockIdx.x * 1024 + tid; i < n_rows_m1; i += (long long)gridDim.x * 1024) {
         if (Xcos) { const float x = Xcos[i]; if (x > 0.f && x < __builtin_inff()) { s0 += (double)x; ++c0; } }
         if (Xdep) { const float x = Xdep[i]; if (x > 0.f && x < __builtin_inff()) { s1 += (double)x; ++c1; } }
     }
@@ -547,17 +563,35 @@ __global__ __launch_bounds__(1024) void sp_bnd_range_kernel(int n_cols, const fl
         double a = 0.0, b = 0.0;
         unsigned na = 0, nb = 0;
         for (int w = 0; w < 16; ++w) { a += redd[0][w]; b += redd[1][w]; na += redc[0][w]; nb += redc[1][w]; }
-        rho[0] = Ytv ? l1t2 : 0.f;
-        rho[1] = (Ycos && na) ? l2 * (float)(a / (double)na) : 0.f;
-        rho[2] = (Ydep && nb) ? l3 * (float)(b / (double)nb) : 0.f;
-        for (int j = 0; j < 3; ++j) if (!(rho[j] > 0.f) || !(rho[j] < __builtin_inff())) rho[j] = 0.f;
+        // (the mean only has to be the SAME number for every user of this BndInfo, not an exact one: float partial sums)
+        if (na) { atomicAdd(&acc[0], (float)a); atomicAdd((unsigned *)&acc[2], na); }
+        if (nb) { atomicAdd(&acc[1], (float)b); atomicAdd((unsigned *)&acc[3], nb); }
+        __threadfence();
+        last = atomicAdd((unsigned *)&acc[4], 1u) == gridDim.x - 1u;
     }
     __syncthreads();
-    const float rtv = rho[0], rcos = rho[1], rdep = rho[2];
+    if (last && tid == 0) {
+        __threadfence();
+        const float a = atomicAdd(&acc[0], 0.f), b = atomicAdd(&acc[1], 0.f);
+        const unsigned na = atomicAdd((unsigned *)&acc[2], 0u), nb = atomicAdd((unsigned *)&acc[3], 0u);
+        float rho[3];
+        rho[0] = has_tv ? l1t2 : 0.f;
+        rho[1] = (has_cos && na) ? l2 * (a / (float)na) : 0.f;
+        rho[2] = (has_dep && nb) ? l3 * (b / (float)nb) : 0.f;
+        for (int j = 0; j < 3; ++j) if (!(rho[j] > 0.f) || !(rho[j] < __builtin_inff())) rho[j] = 0.f;
+        out->rho_tv = rho[0]; out->rho_cos = rho[1]; out->rho_dep = rho[2];
+    }
+}
+__global__ __launch_bounds__(1024) void sp_bnd_range_kernel(int n_cols, const float *Ytv, const float *Ycos, const float *Ydep, unsigned *done, BndInfo *out) {
+    __shared__ unsigned redc[16];
+    __shared__ float redm[3][16];
+    __shared__ bool last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float rtv = out->rho_tv, rcos = out->rho_cos, rdep = out->rho_dep;      // (written by the launch before this one)
     const float inf = __builtin_inff();
     unsigned nv = 0;
     float m0 = inf, m1 = inf, m2 = inf;
-    for (int i = tid; i < n_cols; i += 1024) {
+    for (long long i = (long long)blockIdx.x * 1024 + tid; i < n_cols; i += (long long)gridDim.x * 1024) {
         const float ytv = Ytv ? Ytv[i] : 0.f, ycos = Ycos ? Ycos[i] : 0.f, ydep = Ydep ? Ydep[i] : 0.f;
         if (bnd_valid(ytv, ycos, ydep, bnd_w(rtv, ytv, rcos, ycos, rdep, ydep))) {
             ++nv;
@@ -569,16 +603,27 @@ __global__ __launch_bounds__(1024) void sp_bnd_range_kernel(int n_cols, const fl
         nv += __shfl_xor(nv, d, 64);
         m0 = fminf(m0, __shfl_xor(m0, d, 64)); m1 = fminf(m1, __shfl_xor(m1, d, 64)); m2 = fminf(m2, __shfl_xor(m2, d, 64));
     }
-    if (lane == 0) { redc[2][wave] = nv; redm[0][wave] = m0; redm[1][wave] = m1; redm[2][wave] = m2; }
+    if (lane == 0) { redc[wave] = nv; redm[0][wave] = m0; redm[1][wave] = m1; redm[2][wave] = m2; }
     __syncthreads();
     if (tid == 0) {
         nv = 0;
-        for (int w = 0; w < 16; ++w) { nv += redc[2][w]; m0 = fminf(m0, redm[0][w]); m1 = fminf(m1, redm[1][w]); m2 = fminf(m2, redm[2][w]); }
-        BndInfo b;
-        b.rho_tv = rtv; b.rho_cos = rcos; b.rho_dep = rdep;
-        b.ymin_tv = (Ytv && m0 < inf) ? m0 : 0.f; b.ymin_cos = (Ycos && m1 < inf) ? m1 : 0.f; b.ymin_dep = (Ydep && m2 < inf) ? m2 : 0.f;
-        b.state = (nv > 0u && (rtv > 0.f || rcos > 0.f || rdep > 0.f)) ? 1 : 0;
-        *out = b;
+        for (int w = 0; w < 16; ++w) { nv += redc[w]; m0 = fminf(m0, redm[0][w]); m1 = fminf(m1, redm[1][w]); m2 = fminf(m2, redm[2][w]); }
+        if (nv) atomicAdd((unsigned *)&out->state, nv);
+        if (m0 < inf) atomicMax((unsigned *)&out->ymin_tv, min_key(m0));
+        if (m1 < inf) atomicMax((unsigned *)&out->ymin_cos, min_key(m1));
+        if (m2 < inf) atomicMax((unsigned *)&out->ymin_dep, min_key(m2));
+        __threadfence();
+        last = atomicAdd(done, 1u) == gridDim.x - 1u;
+    }
+    __syncthreads();
+    if (last && tid == 0) {
+        __threadfence();
+        const unsigned n_valid = atomicAdd((unsigned *)&out->state, 0u);
+        const unsigned k0 = atomicMax((unsigned *)&out->ymin_tv, 0u), k1 = atomicMax((unsigned *)&out->ymin_cos, 0u), k2 = atomicMax((unsigned *)&out->ymin_dep, 0u);
+        out->ymin_tv = (Ytv && k0) ? min_unkey(k0) : 0.f;
+        out->ymin_cos = (Ycos && k1) ? min_unkey(k1) : 0.f;
+        out->ymin_dep = (Ydep && k2) ? min_unkey(k2) : 0.f;
+        out->state = (n_valid > 0u && (rtv > 0.f || rcos > 0.f || rdep > 0.f)) ? 1 : 0;
     }
 }
 
