@@ -1,6 +1,6 @@
 """C2-shaped problem (1M x 100k, 64 per row, cosine k=100; `c3` = the s_plus hybrid of configs[2]) over the first N target rows,
 kernel-scope: how long the row kernels took, where the cycles of a row went (in-kernel phase timers), parity on a sample.
-`python scripts/c2_phases.py N [c3|jaccard] [binary] [static] [dbg=BITS]`"""
+`python scripts/c2_phases.py N [c3|jaccard] [binary] [static] [dbg=BITS] [wgs=N]`  (dbg=524288: the two-per-CU shape off)"""
 import sys, json, copy
 import numpy as np
 sys.path.insert(0, '.')
@@ -12,6 +12,8 @@ from oracle import splus_oracle as so
 
 n_t = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 tun = dict(dbg=next((int(a[4:]) for a in sys.argv if a.startswith("dbg=")), 0))
+if any(a.startswith("wgs=") for a in sys.argv):      # persistent workgroups of the row kernels (default: what fills the CUs)
+    tun["num_wgs"] = next(int(a[4:]) for a in sys.argv if a.startswith("wgs="))
 kw = dict(l1=0.5, l2=0.5, stabilized_shrink=10.0) if "c3" in sys.argv else dict(l1=1, t1=1, t2=1) if "jaccard" in sys.argv else dict(l2=1, c1=0.5, c2=0.5)
 if "binary" in sys.argv:      # (fixed-degree rows of ones: every row has the same norm, nearly every candidate of a row ties)
     kw["binary"] = True
@@ -37,7 +39,7 @@ tot = float(sum(ph[:9]))
 print("   cycles/row %.0f: " % (tot / n_t) + "  ".join(f"{n}={c / n_t:.0f}" for n, c in zip(names, ph[:9])), flush=True)
 if ph[8] & 2:      # the bounded variant ran: its counters (slot 11: selections << 32 | entries through the exact pass)
     print(f"   bounded variant: {(ph[11] & 0xFFFFFFFF) / n_t:.0f} entries through the exact pass per row, {(ph[11] >> 32) / n_t:.2f} selections per row", flush=True)
-if tun["dbg"]:
+if tun["dbg"] & ~524288:
     sys.exit(0)
 sample = np.sort(np.random.default_rng(1).choice(n_t, min(n_t, 150), replace=False)).astype(np.int32)
 c2 = copy.copy(call); c2.targets = sample

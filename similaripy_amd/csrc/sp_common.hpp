@@ -479,6 +479,20 @@ constexpr int ITEM_CAP = 1008;    // work items per row (LDS: 16 B each) of a 10
 __host__ __device__ constexpr int item_cap(int NT) { return NT >= 1024 ? ITEM_CAP : (NT / 64) * 64; }
 constexpr int CBM_BYTES = 8192;   // collision bitmap of the sparse kernel (64k bits = 2048 words)
 constexpr int PRE_BYTES = 4096;   // per-word exclusive popcount prefix of the collision bitmap (u16 each)
+// the two-per-CU shape of the sparse kernel (sp_sparse_kernel.hpp, DUO): 512 threads, 80 KB of LDS —
+//   cbm 8 KB | [rank prefix 4 KB | collision set 20 KB | member pool 24 KB | U 16 KB] = the 64 KB (2^19-bit) sweep-1 bitmap | items 3 840 B | histograms 4 KB | scalars 256 B
+constexpr int DUO_NT = 512;
+constexpr int DUO_CS_DIRECT = 2048;                         // collision-set slots addressed by the rank of a column's mark (a C2 row: ~1 600 marks)
+constexpr int DUO_CS_OVER = 512;                            // ... and for columns that share a mark or a first-plane bit (~150 per C2 row)
+constexpr int DUO_CS_BYTES = (DUO_CS_DIRECT + DUO_CS_OVER) * 8;     // 20 KB
+constexpr int DUO_U_BYTES = 16384;                          // candidate buffer: 2048 entries = SEL_E * DUO_NT, what the register-resident selection handles
+constexpr int DUO_A_BYTES = 65536 - PRE_BYTES;              // what lies behind the rank prefix
+constexpr int DUO_MP_BYTES = DUO_A_BYTES - DUO_CS_BYTES - DUO_U_BYTES;      // member pool: 3072 entries
+constexpr int DUO_ICAP = 240;                               // item records (a C2 row has 193)
+constexpr int DUO_NB_LOG2 = 19;
+__host__ __device__ constexpr size_t sp_duo_lds_bytes() { return (size_t)CBM_BYTES + PRE_BYTES + DUO_A_BYTES + (size_t)DUO_ICAP * 16 + 4096 + 32 * 4 + 16 * 8; }
+static_assert(sp_duo_lds_bytes() * 2 <= 160 * 1024, "two workgroups of the DUO shape share a CU's 160 KB");
+static_assert(DUO_MP_BYTES >= 8192 && DUO_MP_BYTES % 512 == 0 && (DUO_CS_OVER & (DUO_CS_OVER - 1)) == 0, "DUO layout");
 constexpr int POOL_BLK = 64;      // pool entries a wave reserves at a time (>= 64: one trip always fits a fresh block)
 constexpr int CS_MAXPROBE = 64;   // linear-probe budget in the collision set
 constexpr unsigned OOB_SOFFSET = 0xFFFFF000u;   // buffer-load scalar offset beyond any m2 extent: every lane out of range
@@ -597,44 +611,49 @@ __device__ __forceinline__ void s1_core(const unsigned (&c)[4], const unsigned (
 // three ids behind the item's end (the next m2 row's first ids, or 0 behind the array's end) set bits nobody asked for.
 // That is safe — a column marked without a second product only takes the collision-set route, where the sum of its one
 // product is exact — and rare (<= 3 of a 256-element item).
-template <int BM_OFF>
-__device__ __forceinline__ void s1_core8q(const unsigned (&c)[8], int d0, int d1, unsigned amask, unsigned (&seen)[8]) {
+// VSH (the DUO shape's aliasing bitmap): the word address is (c >> shift) with shift = 3 + a, i.e. the bitmap index is the column WITHOUT
+// its bits 5 .. 4 + a — columns that share a bit differ in one of those bits, hence in the low 16 bits that pick their bit of the
+// collision bitmap: the two columns of an aliased pair keep separate marks (modulo aliasing gives both the same mark and the same
+// rank slot; measured on C2 rows: the collision set's overflow half 88 % full, 100 k cycles of probing per row).
+template <int BM_OFF, bool VSH = false>
+__device__ __forceinline__ void s1_core8q(const unsigned (&c)[8], int d0, int d1, unsigned amask, unsigned (&seen)[8], unsigned shift = 3u) {
     unsigned a0, a1, o0, o1;
+    if constexpr (VSH) {
     asm volatile(
         "v_cmp_lt_i32 vcc, 0, %[d0]\n\t"
         "v_cndmask_b32 %[o0], 0, 1, vcc\n\t"
         "v_cmp_lt_i32 vcc, 0, %[d1]\n\t"
         "v_cndmask_b32 %[o1], 0, 1, vcc\n\t"
         "v_lshlrev_b32 %[b0], %[c0], %[o0]\n\t"
-        "v_lshrrev_b32 %[a0], 3, %[c0]\n\t"
+        "v_lshrrev_b32 %[a0], %[sh], %[c0]\n\t"
         "v_and_b32 %[a0], %[am], %[a0]\n\t"
         "ds_or_rtn_b32 %[b0], %[a0], %[b0] offset:%[off]\n\t"
         "v_lshlrev_b32 %[b1], %[c1], %[o0]\n\t"
-        "v_lshrrev_b32 %[a1], 3, %[c1]\n\t"
+        "v_lshrrev_b32 %[a1], %[sh], %[c1]\n\t"
         "v_and_b32 %[a1], %[am], %[a1]\n\t"
         "ds_or_rtn_b32 %[b1], %[a1], %[b1] offset:%[off]\n\t"
         "v_lshlrev_b32 %[b2], %[c2], %[o0]\n\t"
-        "v_lshrrev_b32 %[a0], 3, %[c2]\n\t"
+        "v_lshrrev_b32 %[a0], %[sh], %[c2]\n\t"
         "v_and_b32 %[a0], %[am], %[a0]\n\t"
         "ds_or_rtn_b32 %[b2], %[a0], %[b2] offset:%[off]\n\t"
         "v_lshlrev_b32 %[b3], %[c3], %[o0]\n\t"
-        "v_lshrrev_b32 %[a1], 3, %[c3]\n\t"
+        "v_lshrrev_b32 %[a1], %[sh], %[c3]\n\t"
         "v_and_b32 %[a1], %[am], %[a1]\n\t"
         "ds_or_rtn_b32 %[b3], %[a1], %[b3] offset:%[off]\n\t"
         "v_lshlrev_b32 %[b4], %[c4], %[o1]\n\t"
-        "v_lshrrev_b32 %[a0], 3, %[c4]\n\t"
+        "v_lshrrev_b32 %[a0], %[sh], %[c4]\n\t"
         "v_and_b32 %[a0], %[am], %[a0]\n\t"
         "ds_or_rtn_b32 %[b4], %[a0], %[b4] offset:%[off]\n\t"
         "v_lshlrev_b32 %[b5], %[c5], %[o1]\n\t"
-        "v_lshrrev_b32 %[a1], 3, %[c5]\n\t"
+        "v_lshrrev_b32 %[a1], %[sh], %[c5]\n\t"
         "v_and_b32 %[a1], %[am], %[a1]\n\t"
         "ds_or_rtn_b32 %[b5], %[a1], %[b5] offset:%[off]\n\t"
         "v_lshlrev_b32 %[b6], %[c6], %[o1]\n\t"
-        "v_lshrrev_b32 %[a0], 3, %[c6]\n\t"
+        "v_lshrrev_b32 %[a0], %[sh], %[c6]\n\t"
         "v_and_b32 %[a0], %[am], %[a0]\n\t"
         "ds_or_rtn_b32 %[b6], %[a0], %[b6] offset:%[off]\n\t"
         "v_lshlrev_b32 %[b7], %[c7], %[o1]\n\t"
-        "v_lshrrev_b32 %[a1], 3, %[c7]\n\t"
+        "v_lshrrev_b32 %[a1], %[sh], %[c7]\n\t"
         "v_and_b32 %[a1], %[am], %[a1]\n\t"
         "ds_or_rtn_b32 %[b7], %[a1], %[b7] offset:%[off]\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
@@ -647,8 +666,59 @@ __device__ __forceinline__ void s1_core8q(const unsigned (&c)[8], int d0, int d1
         "v_bfe_u32 %[b6], %[b6], %[c6], %[o1]\n\t"
         "v_bfe_u32 %[b7], %[b7], %[c7], %[o1]\n\t"
         : [a0] "=&v"(a0), [a1] "=&v"(a1), [o0] "=&v"(o0), [o1] "=&v"(o1), [b0] "=&v"(seen[0]), [b1] "=&v"(seen[1]), [b2] "=&v"(seen[2]), [b3] "=&v"(seen[3]), [b4] "=&v"(seen[4]), [b5] "=&v"(seen[5]), [b6] "=&v"(seen[6]), [b7] "=&v"(seen[7])
-        : [c0] "v"(c[0]), [c1] "v"(c[1]), [c2] "v"(c[2]), [c3] "v"(c[3]), [c4] "v"(c[4]), [c5] "v"(c[5]), [c6] "v"(c[6]), [c7] "v"(c[7]), [d0] "v"(d0), [d1] "v"(d1), [am] "s"(amask), [off] "i"(BM_OFF)
+        : [c0] "v"(c[0]), [c1] "v"(c[1]), [c2] "v"(c[2]), [c3] "v"(c[3]), [c4] "v"(c[4]), [c5] "v"(c[5]), [c6] "v"(c[6]), [c7] "v"(c[7]), [d0] "v"(d0), [d1] "v"(d1), [am] "s"(amask), [off] "i"(BM_OFF), [sh] "s"(shift)
         : "memory", "vcc");
+    } else {
+    asm volatile(
+        "v_cmp_lt_i32 vcc, 0, %[d0]\n\t"
+        "v_cndmask_b32 %[o0], 0, 1, vcc\n\t"
+        "v_cmp_lt_i32 vcc, 0, %[d1]\n\t"
+        "v_cndmask_b32 %[o1], 0, 1, vcc\n\t"
+        "v_lshlrev_b32 %[b0], %[c0], %[o0]\n\t"
+        "v_lshrrev_b32 %[a0], %[sh], %[c0]\n\t"
+        "v_and_b32 %[a0], %[am], %[a0]\n\t"
+        "ds_or_rtn_b32 %[b0], %[a0], %[b0] offset:%[off]\n\t"
+        "v_lshlrev_b32 %[b1], %[c1], %[o0]\n\t"
+        "v_lshrrev_b32 %[a1], %[sh], %[c1]\n\t"
+        "v_and_b32 %[a1], %[am], %[a1]\n\t"
+        "ds_or_rtn_b32 %[b1], %[a1], %[b1] offset:%[off]\n\t"
+        "v_lshlrev_b32 %[b2], %[c2], %[o0]\n\t"
+        "v_lshrrev_b32 %[a0], %[sh], %[c2]\n\t"
+        "v_and_b32 %[a0], %[am], %[a0]\n\t"
+        "ds_or_rtn_b32 %[b2], %[a0], %[b2] offset:%[off]\n\t"
+        "v_lshlrev_b32 %[b3], %[c3], %[o0]\n\t"
+        "v_lshrrev_b32 %[a1], %[sh], %[c3]\n\t"
+        "v_and_b32 %[a1], %[am], %[a1]\n\t"
+        "ds_or_rtn_b32 %[b3], %[a1], %[b3] offset:%[off]\n\t"
+        "v_lshlrev_b32 %[b4], %[c4], %[o1]\n\t"
+        "v_lshrrev_b32 %[a0], %[sh], %[c4]\n\t"
+        "v_and_b32 %[a0], %[am], %[a0]\n\t"
+        "ds_or_rtn_b32 %[b4], %[a0], %[b4] offset:%[off]\n\t"
+        "v_lshlrev_b32 %[b5], %[c5], %[o1]\n\t"
+        "v_lshrrev_b32 %[a1], %[sh], %[c5]\n\t"
+        "v_and_b32 %[a1], %[am], %[a1]\n\t"
+        "ds_or_rtn_b32 %[b5], %[a1], %[b5] offset:%[off]\n\t"
+        "v_lshlrev_b32 %[b6], %[c6], %[o1]\n\t"
+        "v_lshrrev_b32 %[a0], %[sh], %[c6]\n\t"
+        "v_and_b32 %[a0], %[am], %[a0]\n\t"
+        "ds_or_rtn_b32 %[b6], %[a0], %[b6] offset:%[off]\n\t"
+        "v_lshlrev_b32 %[b7], %[c7], %[o1]\n\t"
+        "v_lshrrev_b32 %[a1], %[sh], %[c7]\n\t"
+        "v_and_b32 %[a1], %[am], %[a1]\n\t"
+        "ds_or_rtn_b32 %[b7], %[a1], %[b7] offset:%[off]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_bfe_u32 %[b0], %[b0], %[c0], %[o0]\n\t"
+        "v_bfe_u32 %[b1], %[b1], %[c1], %[o0]\n\t"
+        "v_bfe_u32 %[b2], %[b2], %[c2], %[o0]\n\t"
+        "v_bfe_u32 %[b3], %[b3], %[c3], %[o0]\n\t"
+        "v_bfe_u32 %[b4], %[b4], %[c4], %[o1]\n\t"
+        "v_bfe_u32 %[b5], %[b5], %[c5], %[o1]\n\t"
+        "v_bfe_u32 %[b6], %[b6], %[c6], %[o1]\n\t"
+        "v_bfe_u32 %[b7], %[b7], %[c7], %[o1]\n\t"
+        : [a0] "=&v"(a0), [a1] "=&v"(a1), [o0] "=&v"(o0), [o1] "=&v"(o1), [b0] "=&v"(seen[0]), [b1] "=&v"(seen[1]), [b2] "=&v"(seen[2]), [b3] "=&v"(seen[3]), [b4] "=&v"(seen[4]), [b5] "=&v"(seen[5]), [b6] "=&v"(seen[6]), [b7] "=&v"(seen[7])
+        : [c0] "v"(c[0]), [c1] "v"(c[1]), [c2] "v"(c[2]), [c3] "v"(c[3]), [c4] "v"(c[4]), [c5] "v"(c[5]), [c6] "v"(c[6]), [c7] "v"(c[7]), [d0] "v"(d0), [d1] "v"(d1), [am] "s"(amask), [off] "i"(BM_OFF), [sh] "i"(3)
+        : "memory", "vcc");
+    }
 }
 
 // The same for eight columns (two items) per lane: twice the LDS atomics in flight per wait, address registers reused
@@ -873,6 +943,142 @@ __device__ __forceinline__ void s2_core_b(const unsigned (&c)[4], const float (&
         "v_cmp_ne_u32_e64 %[M2], 0, %[a2]\n\t"
         "v_cmp_ne_u32_e64 %[M3], 0, %[a3]\n\t"
         : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [t0] "=&v"(t0), [t1] "=&v"(t1),
+          [x0] "=&v"(x[0]), [x1] "=&v"(x[1]), [x2] "=&v"(x[2]), [x3] "=&v"(x[3]),
+          [M0] "=&s"(M[0]), [M1] "=&s"(M[1]), [M2] "=&s"(M[2]), [M3] "=&s"(M[3]),
+          [L0] "=&s"(L[0]), [L1] "=&s"(L[1]), [L2] "=&s"(L[2]), [L3] "=&s"(L[3])
+        : [c0] "v"(c[0]), [c1] "v"(c[1]), [c2] "v"(c[2]), [c3] "v"(c[3]),
+          [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]), [sv] "v"(segv),
+          [nkw] "s"(nKw), [q] "s"(Q)
+        : "memory");
+}
+
+// ---- DUO: the collision bitmap as TWO planes of 32 k bits (LDS [0, 4096) and [4096, 8192)) ----
+// A column c owns bit (c & 31) of word (c >> 5) & 1023 in the first plane and bit ((c >> 15) & 31) of the SAME word index in the second;
+// marking sets both, "marked" means both are set.  With one plane of 64 k bits a C2 row in the two-per-CU shape (1.6 k marks: aliased
+// pairs mark like repeated columns) has 41 k * 1600 / 65536 = 1 000 products that hit another column's mark; every one of them is carried
+// through the member pool into the collision set, where they fill the overflow half (measured: 33 k cycles of accumulate per row, most of
+// it probing).  Two planes: (1600 / 32768)^2 = 0.24 % = ~100.  Ranks (the collision set's direct slots) count first-plane bits only.
+constexpr int DUO_PLANE_BYTES = CBM_BYTES / 2;
+__device__ __forceinline__ void duo_mark(unsigned char *cbm, unsigned c) {
+    const unsigned w = (c >> 3) & (unsigned)(DUO_PLANE_BYTES - 4);
+    atomicOr((unsigned *)(cbm + w), 1u << (c & 31u));
+    atomicOr((unsigned *)(cbm + DUO_PLANE_BYTES + w), 1u << ((c >> 15) & 31u));
+}
+__device__ __forceinline__ void duo_unmark(unsigned char *cbm, unsigned c) {
+    const unsigned w = (c >> 3) & (unsigned)(DUO_PLANE_BYTES - 4);
+    atomicAnd((unsigned *)(cbm + w), ~(1u << (c & 31u)));
+    atomicAnd((unsigned *)(cbm + DUO_PLANE_BYTES + w), ~(1u << ((c >> 15) & 31u)));
+}
+// s2_core on the two planes: two reads from one address register, the second bit extracted with the first as its WIDTH (0: not marked)
+__device__ __forceinline__ void s2_core_duo(const unsigned (&c)[4], const float (&v)[4], float segv, float cut, float (&x)[4], u64 (&M)[4], u64 (&L)[4]) {
+    unsigned a0, a1, a2, a3, h0, h1, h2, h3, u;
+    static_assert(DUO_PLANE_BYTES == 4096, "the literals below are DUO_PLANE_BYTES - 4 and DUO_PLANE_BYTES");
+    asm volatile(
+        "v_lshrrev_b32 %[a0], 3, %[c0]\n\t"
+        "v_lshrrev_b32 %[a1], 3, %[c1]\n\t"
+        "v_lshrrev_b32 %[a2], 3, %[c2]\n\t"
+        "v_lshrrev_b32 %[a3], 3, %[c3]\n\t"
+        "v_and_b32 %[a0], 0xffc, %[a0]\n\t"
+        "v_and_b32 %[a1], 0xffc, %[a1]\n\t"
+        "v_and_b32 %[a2], 0xffc, %[a2]\n\t"
+        "v_and_b32 %[a3], 0xffc, %[a3]\n\t"
+        "ds_read_b32 %[h0], %[a0] offset:4096\n\t"
+        "ds_read_b32 %[h1], %[a1] offset:4096\n\t"
+        "ds_read_b32 %[h2], %[a2] offset:4096\n\t"
+        "ds_read_b32 %[h3], %[a3] offset:4096\n\t"
+        "ds_read_b32 %[a0], %[a0]\n\t"
+        "ds_read_b32 %[a1], %[a1]\n\t"
+        "ds_read_b32 %[a2], %[a2]\n\t"
+        "ds_read_b32 %[a3], %[a3]\n\t"
+        "v_mul_f32 %[x0], %[sv], %[v0]\n\t"
+        "v_mul_f32 %[x1], %[sv], %[v1]\n\t"
+        "v_mul_f32 %[x2], %[sv], %[v2]\n\t"
+        "v_mul_f32 %[x3], %[sv], %[v3]\n\t"
+        "v_cmp_nle_f32_e64 %[L0], %[x0], %[cut]\n\t"
+        "v_cmp_nle_f32_e64 %[L1], %[x1], %[cut]\n\t"
+        "v_cmp_nle_f32_e64 %[L2], %[x2], %[cut]\n\t"
+        "v_cmp_nle_f32_e64 %[L3], %[x3], %[cut]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_bfe_u32 %[a0], %[a0], %[c0], 1\n\t"
+        "v_lshrrev_b32 %[u], 15, %[c0]\n\t"
+        "v_bfe_u32 %[a1], %[a1], %[c1], 1\n\t"
+        "v_bfe_u32 %[a0], %[h0], %[u], %[a0]\n\t"
+        "v_lshrrev_b32 %[u], 15, %[c1]\n\t"
+        "v_bfe_u32 %[a2], %[a2], %[c2], 1\n\t"
+        "v_bfe_u32 %[a1], %[h1], %[u], %[a1]\n\t"
+        "v_lshrrev_b32 %[u], 15, %[c2]\n\t"
+        "v_bfe_u32 %[a3], %[a3], %[c3], 1\n\t"
+        "v_bfe_u32 %[a2], %[h2], %[u], %[a2]\n\t"
+        "v_lshrrev_b32 %[u], 15, %[c3]\n\t"
+        "v_cmp_ne_u32_e64 %[M0], 0, %[a0]\n\t"
+        "v_bfe_u32 %[a3], %[h3], %[u], %[a3]\n\t"
+        "v_cmp_ne_u32_e64 %[M1], 0, %[a1]\n\t"
+        "v_cmp_ne_u32_e64 %[M2], 0, %[a2]\n\t"
+        "v_cmp_ne_u32_e64 %[M3], 0, %[a3]\n\t"
+        : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [h0] "=&v"(h0), [h1] "=&v"(h1), [h2] "=&v"(h2), [h3] "=&v"(h3), [u] "=&v"(u),
+          [x0] "=&v"(x[0]), [x1] "=&v"(x[1]), [x2] "=&v"(x[2]), [x3] "=&v"(x[3]),
+          [M0] "=&s"(M[0]), [M1] "=&s"(M[1]), [M2] "=&s"(M[2]), [M3] "=&s"(M[3]),
+          [L0] "=&s"(L[0]), [L1] "=&s"(L[1]), [L2] "=&s"(L[2]), [L3] "=&s"(L[3])
+        : [c0] "v"(c[0]), [c1] "v"(c[1]), [c2] "v"(c[2]), [c3] "v"(c[3]),
+          [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]), [sv] "v"(segv), [cut] "s"(cut)
+        : "memory");
+}
+// ... and the bounded variant's (s2_core_b)
+__device__ __forceinline__ void s2_core_b_duo(const unsigned (&c)[4], const float (&v)[4], float segv, float nKw, float Q,
+                                              float (&x)[4], u64 (&M)[4], u64 (&L)[4]) {
+    unsigned a0, a1, a2, a3, h0, h1, h2, h3, t0, t1;
+    asm volatile(
+        "v_lshrrev_b32 %[a0], 3, %[c0]\n\t"
+        "v_lshrrev_b32 %[a1], 3, %[c1]\n\t"
+        "v_lshrrev_b32 %[a2], 3, %[c2]\n\t"
+        "v_lshrrev_b32 %[a3], 3, %[c3]\n\t"
+        "v_and_b32 %[a0], 0xffc, %[a0]\n\t"
+        "v_and_b32 %[a1], 0xffc, %[a1]\n\t"
+        "v_and_b32 %[a2], 0xffc, %[a2]\n\t"
+        "v_and_b32 %[a3], 0xffc, %[a3]\n\t"
+        "ds_read_b32 %[h0], %[a0] offset:4096\n\t"
+        "ds_read_b32 %[h1], %[a1] offset:4096\n\t"
+        "ds_read_b32 %[h2], %[a2] offset:4096\n\t"
+        "ds_read_b32 %[h3], %[a3] offset:4096\n\t"
+        "ds_read_b32 %[a0], %[a0]\n\t"
+        "ds_read_b32 %[a1], %[a1]\n\t"
+        "ds_read_b32 %[a2], %[a2]\n\t"
+        "ds_read_b32 %[a3], %[a3]\n\t"
+        "v_mul_f32 %[x0], %[sv], %[v0]\n\t"
+        "v_mul_f32 %[x1], %[sv], %[v1]\n\t"
+        "v_mul_f32 %[x2], %[sv], %[v2]\n\t"
+        "v_mul_f32 %[x3], %[sv], %[v3]\n\t"
+        "v_lshrrev_b32 %[t0], 1, %[c0]\n\t"
+        "v_lshrrev_b32 %[t1], 1, %[c1]\n\t"
+        "v_fma_f32 %[t0], %[t0], %[nkw], %[x0]\n\t"
+        "v_fma_f32 %[t1], %[t1], %[nkw], %[x1]\n\t"
+        "v_cmp_nle_f32_e64 %[L0], %[t0], %[q]\n\t"
+        "v_cmp_nle_f32_e64 %[L1], %[t1], %[q]\n\t"
+        "v_lshrrev_b32 %[t0], 1, %[c2]\n\t"
+        "v_lshrrev_b32 %[t1], 1, %[c3]\n\t"
+        "v_fma_f32 %[t0], %[t0], %[nkw], %[x2]\n\t"
+        "v_fma_f32 %[t1], %[t1], %[nkw], %[x3]\n\t"
+        "v_cmp_nle_f32_e64 %[L2], %[t0], %[q]\n\t"
+        "v_cmp_nle_f32_e64 %[L3], %[t1], %[q]\n\t"
+        "v_lshrrev_b32 %[t0], 15, %[c0]\n\t"
+        "v_lshrrev_b32 %[t1], 15, %[c1]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_bfe_u32 %[a0], %[a0], %[c0], 1\n\t"
+        "v_bfe_u32 %[a1], %[a1], %[c1], 1\n\t"
+        "v_bfe_u32 %[a0], %[h0], %[t0], %[a0]\n\t"
+        "v_bfe_u32 %[a1], %[h1], %[t1], %[a1]\n\t"
+        "v_lshrrev_b32 %[t0], 15, %[c2]\n\t"
+        "v_lshrrev_b32 %[t1], 15, %[c3]\n\t"
+        "v_bfe_u32 %[a2], %[a2], %[c2], 1\n\t"
+        "v_bfe_u32 %[a3], %[a3], %[c3], 1\n\t"
+        "v_bfe_u32 %[a2], %[h2], %[t0], %[a2]\n\t"
+        "v_bfe_u32 %[a3], %[h3], %[t1], %[a3]\n\t"
+        "v_cmp_ne_u32_e64 %[M0], 0, %[a0]\n\t"
+        "v_cmp_ne_u32_e64 %[M1], 0, %[a1]\n\t"
+        "v_cmp_ne_u32_e64 %[M2], 0, %[a2]\n\t"
+        "v_cmp_ne_u32_e64 %[M3], 0, %[a3]\n\t"
+        : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [h0] "=&v"(h0), [h1] "=&v"(h1), [h2] "=&v"(h2), [h3] "=&v"(h3),
+          [t0] "=&v"(t0), [t1] "=&v"(t1),
           [x0] "=&v"(x[0]), [x1] "=&v"(x[1]), [x2] "=&v"(x[2]), [x3] "=&v"(x[3]),
           [M0] "=&s"(M[0]), [M1] "=&s"(M[1]), [M2] "=&s"(M[2]), [M3] "=&s"(M[3]),
           [L0] "=&s"(L[0]), [L1] "=&s"(L[1]), [L2] "=&s"(L[2]), [L3] "=&s"(L[3])

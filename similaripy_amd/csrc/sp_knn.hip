@@ -118,6 +118,8 @@ struct Config {
     size_t ws_items_bytes;
     bool fold;
     bool wave;              // light rows: the wave-per-row kernel (sp_wave_kernel.hpp) runs instead of the workgroup-per-row sparse kernel
+    bool duo;               // the sparse kernel runs in its two-per-CU shape (512 threads, 80 KB, aliasing 2^19-bit bitmap; sp_sparse_kernel.hpp)
+    size_t lds_sparse_gen;  // ... and then this is the LDS of the general variant launched beside the bounded one (the classic 512-thread layout)
     bool mono;              // the sparse kernel's monotone variant applies (val = xy / den or the raw dot, no per-row target selector)
     bool bnd;               // the sparse kernel's bounded variant is prepared and launched beside the general one (BndInfo::state picks on the device)
     size_t ws_bnd_colpack;  // offsets inside the fold block: packed id per column | packed m2 ids
@@ -197,6 +199,16 @@ size_t sddmm_ws_bytes(const sp_knn_args *a) {
     return 256 + 2 * al((size_t)a->nnz_m2 * 4) + al(((size_t)a->n_output_cols + 1) * 4) + transpose_ws_bytes(a->nnz_m2, a->n_output_cols);
 }
 
+// can the call run the sparse kernel's bounded variant (MODE 2)?  (conditions: see make_config)
+bool bnd_eligible(const sp_knn_args *a, bool mono, bool fold) {
+    const bool live = (a->l1 != 0.f && a->t2 != 0.f) || a->l2 != 0.f || a->l3 != 0.f;
+    const bool nonneg = a->l1 >= 0.f && a->l2 >= 0.f && a->l3 >= 0.f && a->t1 >= 0.f && a->t2 >= 0.f && a->stabilized_shrink >= 0.f;
+    return !mono && !fold && live && nonneg && a->a1 == 1.f && a->bayesian_shrink == 0.f && !(a->l1 * (1.f - a->t1 - a->t2) > 0.f) &&
+           a->threshold >= 0.f && a->target_col_mode != SP_SEL_MATRIX &&
+           a->n_output_cols > 0 && (long long)a->n_output_cols < (1LL << BND_ID_BITS) && a->nnz_m2 > 0 &&
+           !(a->flags & SP_FLAG_NO_SPARSE_PATH) && !(a->reserved[0] & 32768);      // (bit 32768 of the ablation word: off, for A/B runs)
+}
+
 int make_config(const sp_knn_args *a, int n_cus, Config *c) {
     // (threads_per_wg = 64: ask for the wave-per-row kernel wherever the call qualifies for it, whatever its average row looks like)
     const bool want_wave = a->threads_per_wg == 64;
@@ -236,12 +248,32 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
     if ((!a->threads_per_wg || want_wave) && !a->table_slots && (long long)a->k + 512 <= (long long)SEL_E * 256 && small_rows) {
         NT_s = 256; T_s = 4096; logT_s = 12;
     }
-    const bool u_lds_s = ((size_t)SEL_E * NT_s * 8 <= (size_t)T_s * 2) && ((long long)a->k + 512 <= (long long)SEL_E * NT_s);
-    const long long cap_s = u_lds_s ? (long long)SEL_E * NT_s : ((need_cap + 1024) & ~1LL);
+    // Rows of the headline's weight (C2: 41 k products over 10^6 columns) are too heavy for that shape and ran ONE 1024-thread workgroup per
+    // CU (128 KB exact bitmap).  Round 6: TWO 512-thread workgroups per CU with a 2^19-bit aliasing bitmap (DUO, sp_sparse_kernel.hpp) when
+    // the variant is of the monotone type (decided below), k leaves room in its 2048-entry candidate buffer and the AVERAGE row's expected
+    // marked columns  MACs^2 / (2 * bitmap bits)  fit its 2048 rank-addressed slots with room to spare (rows are classified one by one on the device).
+    // (bit 524288 of the ablation word: off, for A/B runs)
+    const bool any_norm0 = a->l1 != 0.f || a->l2 != 0.f || a->l3 != 0.f || a->stabilized_shrink != 0.f || a->bayesian_shrink != 0.f;
+    const bool fold0 = !(a->flags & SP_FLAG_NO_FOLD) && a->l1 == 0.f && a->a1 == 1.f && a->stabilized_shrink == 0.f &&
+                       a->bayesian_shrink == 0.f && ((a->l2 != 0.f) != (a->l3 != 0.f)) && a->nnz_m2 > 0;
+    const bool mono0 = (fold0 || !any_norm0) && a->target_col_mode != SP_SEL_MATRIX;
+    bool duo = false;
+    const bool big0 = a->nnz_m2 >= (1LL << 30) - 1024 || (a->reserved[0] & 1024);      // (no sparse kernel runs at all, see below)
+    if ((mono0 || bnd_eligible(a, mono0, fold0)) && !big0 && !(a->flags & SP_FLAG_NO_SPARSE_PATH) &&
+        !a->threads_per_wg && !a->table_slots && NT_s == 1024 && !(a->reserved[0] & 524288) && (long long)a->k + 512 <= (long long)(DUO_U_BYTES / 8) &&
+        a->n_output_cols > (1 << 16) && avg_macs > 0.0) {
+        const double bits = (double)std::min<long long>(a->n_output_cols, 1LL << DUO_NB_LOG2);
+        duo = avg_macs * avg_macs / (2.0 * bits) <= 0.82 * (double)DUO_CS_DIRECT;
+    }
+    if (duo) { NT_s = DUO_NT; T_s = 8192; logT_s = 13; }
+    const bool u_lds_s = duo || (((size_t)SEL_E * NT_s * 8 <= (size_t)T_s * 2) && ((long long)a->k + 512 <= (long long)SEL_E * NT_s));
+    const long long cap_s = duo ? (long long)(DUO_U_BYTES / 8) : u_lds_s ? (long long)SEL_E * NT_s : ((need_cap + 1024) & ~1LL);
     c->T = T; c->logT = logT; c->NT = NT; c->cap = (int)cap; c->u_lds = u_lds; c->cap_s = (int)cap_s; c->u_lds_s = u_lds_s;
     c->T_s = T_s; c->logT_s = logT_s; c->NT_s = NT_s;
     c->hash_fill = std::max(1, (int)((long long)T * load / 100));
-    c->lds_sparse = lds_fixed_sparse(T_s, NT_s);
+    c->lds_sparse = duo ? sp_duo_lds_bytes() : lds_fixed_sparse(T_s, NT_s);
+    c->lds_sparse_gen = lds_fixed_sparse(T_s, NT_s);
+    c->duo = duo;
     c->lds_generic = lds_fixed_generic(T, NT) + (u_lds ? (size_t)cap * 8 : 0);
     auto wgs_for = [&](size_t lds, int nt) {
         int per_cu = (int)std::max<size_t>(1, LDS_LIMIT / lds);
@@ -267,12 +299,7 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
     // Bayesian factor, a denominator that does not grow with the raw dot (t1 + t2 >= 1 whenever l1 != 0), threshold >= 0 (negative values
     // are never wanted), no per-row TARGET matrix (a MATRIX filter goes through the collision bitmap, as in the monotone variant), ids that leave 12 bits free.  What it cannot serve runs on the general variant.
     {
-        const bool live = (a->l1 != 0.f && a->t2 != 0.f) || a->l2 != 0.f || a->l3 != 0.f;
-        const bool nonneg = a->l1 >= 0.f && a->l2 >= 0.f && a->l3 >= 0.f && a->t1 >= 0.f && a->t2 >= 0.f && a->stabilized_shrink >= 0.f;
-        c->bnd = !c->mono && !c->fold && live && nonneg && a->a1 == 1.f && a->bayesian_shrink == 0.f && !(a->l1 * (1.f - a->t1 - a->t2) > 0.f) &&
-                 a->threshold >= 0.f && a->target_col_mode != SP_SEL_MATRIX &&
-                 a->n_output_cols > 0 && (long long)a->n_output_cols < (1LL << BND_ID_BITS) && a->nnz_m2 > 0 &&
-                 !(a->flags & SP_FLAG_NO_SPARSE_PATH) && !(a->reserved[0] & 32768);      // (bit 32768 of the ablation word: off, for A/B runs)
+        c->bnd = bnd_eligible(a, c->mono, c->fold);
         c->ws_bnd_colpack = c->ws_bnd_ids = 0;
         if (c->bnd) {
             c->ws_bnd_colpack = c->ws_fold_bytes;
@@ -434,6 +461,23 @@ int device_cus(int device, int *n_cus) {
 
 template <int NT>
 int launch_sparse(const KParams &kp, const Config &c, hipStream_t stream) {
+    if constexpr (NT == DUO_NT) {
+        if (c.duo) {
+            // the two-per-CU shape (monotone or bounded variant; the general variant that backs the bounded one up — BndInfo::state != 1: a
+            // zero or negative column term, rare — runs the classic 512-thread layout on the same parameters, one workgroup per CU)
+            auto kd = c.bnd ? sp_knn_sparse_kernel<DUO_NT, true, 2, true> : sp_knn_sparse_kernel<DUO_NT, true, 1, true>;
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds_sparse));
+            hipLaunchKernelGGL(kd, dim3(c.wgs_sparse), dim3(NT), c.lds_sparse, stream, kp);
+            HIP_TRY(hipGetLastError());
+            if (c.bnd) {
+                auto kg = sp_knn_sparse_kernel<DUO_NT, true, 0>;
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds_sparse_gen));
+                hipLaunchKernelGGL(kg, dim3(std::max(1, c.wgs_sparse / 2)), dim3(NT), c.lds_sparse_gen, stream, kp);
+                HIP_TRY(hipGetLastError());
+            }
+            return SP_OK;
+        }
+    }
     if (c.bnd) {
         // the bounded variant; BndInfo::state (written by the per-call passes on the device) decides at its first instruction whether it
         // or the general variant launched right behind it does the rows — no read-back, no synchronisation
@@ -522,7 +566,7 @@ uint64_t prep_signature(const sp_knn_args *a, const Config &c) {
     auto mix = [&](const void *p, size_t n) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } };
 #define SP_MIX(x) mix(&(x), sizeof(x))
     const uint32_t fl = a->flags & (SP_FLAG_NO_FOLD | SP_FLAG_NO_SPARSE_PATH);
-    const int64_t abl = a->reserved[0] & (1024 | 2048 | 4096 | 16384 | 32768);      // (items_stride follows from sizes the signature covers)
+    const int64_t abl = a->reserved[0] & (1024 | 2048 | 4096 | 16384 | 32768 | 524288);      // (items_stride follows from sizes the signature covers)
     SP_MIX(fl); SP_MIX(abl);
     SP_MIX(a->n_rows_m2); SP_MIX(a->n_output_cols); SP_MIX(a->nnz_m2);
     SP_MIX(a->m2_data); SP_MIX(a->m2_indices); SP_MIX(a->m2_indptr);
@@ -731,7 +775,8 @@ int run_device_impl(sp_knn_args *a, const uint64_t *sig_override = nullptr) {
         ClassifyParams cp;
         cp.sparse_path = kp.sparse_path;
         cp.n_cols = a->n_output_cols; cp.T = c.T; cp.nb_log2 = c.nb_log2;
-        cp.cs_slots = c.T_s / 4;
+        cp.cs_slots = c.duo ? 2 * DUO_CS_DIRECT : c.T_s / 4;      // (the rule counts the rank-addressed slots as half of the set)
+        cp.duo = c.duo ? 1 : 0;
         cp.wave = c.wave ? 1 : 0;
         cp.wave_macs_max = 10000u;
         cp.qcount_w = (unsigned *)(ws + 28);          // header words 6 / 7: head and length of the wave kernel's queue (zeroed with the header)

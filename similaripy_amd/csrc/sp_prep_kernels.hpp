@@ -122,6 +122,7 @@ struct ClassifyParams {
     int n_cols, T;
     int nb_log2;           // sparse bitmap bits
     int cs_slots;          // collision-set slots of the sparse kernel
+    int duo;               // its two-per-CU shape runs (aliasing 2^19-bit bitmap, half of the slots addressed by rank)
     int mono;              // the monotone sparse kernel runs: descriptor word 1.y carries den (val = xy / den), rows
     int any_norm;          //   with a normalised epilogue need den > 0 to be sparse
     float l2, l3;
@@ -171,6 +172,10 @@ __global__ __launch_bounds__(256) void sp_row_desc_kernel(int n_targets, const i
             const float alias = (cp.nb_log2 < 31 && (1 << cp.nb_log2) < cp.n_cols) ? 1.f / (float)(1 << cp.nb_log2) : 0.f;
             const float expect = 0.5f * m * m * (1.f / (float)cp.n_cols + alias);
             sparse = expect <= 0.30f * (float)cp.cs_slots;
+            // DUO: products that find their bit set = pairs of products on one bit, MACs^2 / (2 * bits) (a column pair on one bit counts
+            // like a column that repeats); they must fit the rank-addressed half of the set — 0.44 x 4096 = 1 802 of 2 048 (a C2 row:
+            // 1 600 +- 40; a row that does not fit after all is handed to the generic queue by the kernel)
+            if (cp.duo) sparse = 0.5f * m * m / (float)min(cp.n_cols, 1 << cp.nb_log2) <= 0.44f * (float)cp.cs_slots;
         }
         wavey = sparse && cp.wave && (e - s) <= 64 && macs <= cp.wave_macs_max;
         if (wavey && cp.n_cols > (1 << 17)) {

@@ -35,9 +35,19 @@ namespace {
 // four products per lane and evaluates the epilogue right there (a bound would not do: what the stage does not keep is never offered
 // again, so its cutoff must be a value k candidates really reach).  Rows the bound cannot serve (negative row
 // terms) go to the generic queue; calls it cannot serve run MODE 0 (sp_knn.hip: both are launched, BndInfo::state picks one on the device).
-template <int NT, bool U_LDS, int MODE>
-__global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
+// DUO (round 6): TWO 512-thread workgroups per CU for rows of the headline's weight (tens of thousands of products over ~10^6 columns).
+// One 1024-thread workgroup owns the CU through its 128 KB exact bitmap, and ~25 k of a C2 row's 62 k cycles (accumulate, selection,
+// write-out, clear, setup) run with the CU's load stream idle; with two residents the dense phases of one overlap the sweeps of the
+// other.  What makes two fit (80 KB each, sp_duo_lds_bytes): the column bitmap has 2^19 bits and ALIASES (columns modulo its size: an
+// aliased column is marked like a repeated one and summed per column in the collision set — exact), it OVERLAYS the rank prefix and
+// the storage of the collision set / member pool / U, which are all dead during sweep 1; the monotone-type variants need no survivor
+// pool, so the collision set takes half of the region (4096 slots: ~1.6 k marked columns per C2 row against 0.8 k with the exact
+// bitmap); the member pool (2560 entries against ~4.3 k members per row) is folded into the collision set BETWEEN stages whenever it
+// is half full, and a stage is sized so that its expected members fit what is left.
+template <int NT, bool U_LDS, int MODE, bool DUO = false>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DUO ? 4 : 1, DUO ? 4 : 10))) void sp_knn_sparse_kernel(const KParams p) {
     constexpr bool MONO = MODE == 1, BND = MODE == 2, MLIKE = MODE != 0;
+    static_assert(!DUO || (NT == 512 && U_LDS && MLIKE), "the two-per-CU shape: 512 threads, U in LDS, a monotone-type variant");
     if constexpr (BND) { if (p.bnd->state != 1) return; }                       // (uniform over the grid: written by the per-call passes)
     else if constexpr (!MONO) { if (p.bnd != nullptr && p.bnd->state == 1) return; }   // launched beside the bounded variant: that one runs
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -45,41 +55,62 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
     int tid = threadIdx.x;      // (made opaque at every row top, see there)
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int A_bytes = p.T * 8;
+    // region behind the rank prefix: classic T*8 bytes in four quarters; DUO: [collision set 20 KB | member pool 24 KB | U 16 KB]
+    const int A_bytes = DUO ? DUO_A_BYTES : p.T * 8;
 
     // ---- LDS carve-up (single dynamic array) ----
     // cbm[CBM_BYTES]      collision bitmap (columns seen twice in sweep 1), alive through both sweeps; at offset 0 so
     //                     that its reads need no base add;  pre16[]: its per-word popcount prefix (rank of a marked column)
-    // region A [.., +T*8) sweep 1: column bitmap (nb bits, from the start);
+    // region A [.., +A)   sweep 1: column bitmap (nb bits, from the start; DUO: from pre16 on — the prefix is built after the sweep);
     //                     afterwards: [0,A/4) collision set, [A/4,A/2) survivor pool, [A/2,3A/4) member pool, [3A/4,A) candidate buffer U
-    // items[item_cap(NT)] {m2 byte offset, count, m1 value bits, flat start};  hist4[4][256] radix histograms
+    //                     (DUO: see above)
+    // items[ICAP]         {m2 byte offset, count, m1 value bits, flat start};  hist4[4][256] radix histograms
     // sh[32], ph[16]      scalars, phase timers
     unsigned char *cbm = smem;
     unsigned short *pre16 = (unsigned short *)(smem + CBM_BYTES);      // [CBM_BYTES/4] marked columns below each bitmap word
     unsigned char *rA = smem + CBM_BYTES + PRE_BYTES;
+    constexpr int BM_OFF = DUO ? CBM_BYTES : CBM_BYTES + PRE_BYTES;      // LDS byte address of the sweep-1 bitmap
     int4 *items = (int4 *)(rA + A_bytes);
-    constexpr int ICAP = item_cap(NT);
+    constexpr int ICAP = DUO ? DUO_ICAP : item_cap(NT);
     int *hist4 = (int *)(items + ICAP);
     int *sh = hist4 + 1024;
     u64 *ph = (u64 *)(sh + 32);
     int *shx = (int *)(ph + PH_N);      // two more scalars (the phase-timer area has 16 slots, PH_N are in use)
-    u64 *U = U_LDS ? (u64 *)(rA + (A_bytes / 4) * 3) : (p.gU + (size_t)blockIdx.x * (size_t)p.cap_s);
+    const int cs_bytes = DUO ? DUO_CS_BYTES : A_bytes / 4;
+    const int mp_rel = DUO ? DUO_CS_BYTES : A_bytes / 2;                       // member pool, relative to region A
+    const int u_rel = DUO ? DUO_CS_BYTES + DUO_MP_BYTES : (A_bytes / 4) * 3;   // candidate buffer U
+    u64 *U = U_LDS ? (u64 *)(rA + u_rel) : (p.gU + (size_t)blockIdx.x * (size_t)p.cap_s);
     const int cap = p.cap_s;
 
     const unsigned amask = (unsigned)((1u << (p.nb_log2 - 3)) - 1u) & ~3u;      // column -> byte of its bitmap word
     const int nb_bytes = 1 << (p.nb_log2 - 3);
+    // DUO, more columns than bitmap bits: the bitmap index drops the column's bits 5 .. (s1_core8q); classic: columns modulo the bitmap size
+    const unsigned bm_shift = DUO ? 3u + (unsigned)max(0, (32 - __builtin_clz((unsigned)max(p.n_cols, 2) - 1u)) - p.nb_log2) : 3u;
     const unsigned cmask = (unsigned)(CBM_BYTES - 1) & ~3u;                     // column -> byte of its collision-bitmap word
+    // a column's mark in the collision bitmap (DUO: two planes, sp_common.hpp)
+    auto cbm_mark = [&](unsigned c) __attribute__((always_inline)) {
+        if constexpr (DUO) duo_mark(cbm, c);
+        else atomicOr((unsigned *)(cbm + ((c >> 3) & cmask)), 1u << (c & 31u));
+    };
+    auto cbm_unmark = [&](unsigned c) __attribute__((always_inline)) {
+        if constexpr (DUO) duo_unmark(cbm, c);
+        else atomicAnd((unsigned *)(cbm + ((c >> 3) & cmask)), ~(1u << (c & 31u)));
+    };
+    constexpr int RANK_BYTES = DUO ? DUO_PLANE_BYTES : CBM_BYTES;      // the part of the collision bitmap whose bits have ranks
     u64 *cs = (u64 *)rA;
-    const int CSN = A_bytes / 32;
-    const int cs_shift = 32 - (p.logT - 2);                                     // log2(CSN) = logT + 3 - 5
-    u64 *spool = (u64 *)(rA + A_bytes / 4);      // surviving single products of a stage
+    const int CSN = cs_bytes / 8;
+    // slots [0, CS_DIR) are addressed by rank; a column that finds its rank slot taken by another probes the CS_OVR slots behind them
+    const int CS_DIR = DUO ? DUO_CS_DIRECT : CSN / 2, CS_OVR = DUO ? DUO_CS_OVER : CSN / 2;
+    const int cs_shift = 32 - (DUO ? 9 : p.logT - 3);                          // 32 - log2(CS_OVR): the hash of a first overflow probe
+    static_assert(DUO_CS_OVER == 512, "log2 above");
+    u64 *spool = (u64 *)(rA + A_bytes / 4);      // surviving single products of a stage (general variant only)
     const int spcap = A_bytes / 32;
-    u64 *mpool = (u64 *)(rA + A_bytes / 2);      // products of marked columns, all stages
-    const int mpcap = A_bytes / 32;
+    u64 *mpool = (u64 *)(rA + mp_rel);           // products of marked columns, all stages
+    const int mpcap = DUO ? DUO_MP_BYTES / 8 : A_bytes / 32;
     // LDS byte addresses for the hand-written cores (they assume the dynamic LDS segment starts at address 0)
-    const unsigned mpool_off = (unsigned)(CBM_BYTES + PRE_BYTES + A_bytes / 2);
+    const unsigned mpool_off = (unsigned)(CBM_BYTES + PRE_BYTES + mp_rel);
     const unsigned spool_off = (unsigned)(CBM_BYTES + PRE_BYTES + A_bytes / 4);
-    const unsigned u_off = (unsigned)(CBM_BYTES + PRE_BYTES + (A_bytes / 4) * 3);
+    const unsigned u_off = (unsigned)(CBM_BYTES + PRE_BYTES + u_rel);
     if ((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();
     const __amdgpu_buffer_rsrc_t rs_idx = __builtin_amdgcn_make_buffer_rsrc(BND ? (void *)p.m2_packed : (void *)p.m2_indices, 0, (int)p.m2_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_val = __builtin_amdgcn_make_buffer_rsrc((void *)p.m2_data, 0, (int)p.m2_bytes, 0x00020000);
@@ -347,8 +378,12 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             if (tid < n1) { my_ib = ibS[tid]; my_fs = fsS[tid]; }
             n_items = sh[SH_NITEMS];
             wg_sync<U_LDS>();                    // scratch read before the items overwrite it
+            // (DUO: the item area is 240 records, the scratch 4 KB: its last 256 bytes are the head of the first radix histogram, which
+            // every selection expects to find zero — the next barrier, in front of any selection, publishes the stores)
+            if constexpr (DUO) { if (tid < (4 * SORT_MAX * 4 - ICAP * 16) / 4) hist4[tid] = 0; }
         }
         bool failed = (n_items >= ICAP) || (n_items > 63 * NW) || (n_pre > 0 && n_rec > ICAP);      // (a wave keeps its <= 63 item descriptors in one register)
+        int n_marks = 0;      // (uniform) marked bits of the collision bitmap, known behind sweep 1
         PHASE_END(PH_SETUP);
 
         RowCtx rc;
@@ -536,7 +571,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     unsigned seen[8];
                     // (padding at quad granularity, one compare per item: the per-element form cost 32 instructions more on every
                     // trip that holds a partial item — more than half of a C2 row's)
-                    s1_core8q<CBM_BYTES + PRE_BYTES>(c, d0, d1, amask, seen);
+                    s1_core8q<BM_OFF, DUO>(c, d0, d1, amask, seen, bm_shift);
                     // ~2 % of the products find their column already there: mark it in the collision bitmap.  A trip nearly always
                     // holds such products (~10 of its 512), a LANE rarely more than one: the lane's column is then the sum of
                     // seen[j] * c[j] (seen is 0 / 1; v_mad_u32_u24: the mark needs the low 16 bits of the column only) and goes out
@@ -556,12 +591,12 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                             : "=&v"(cs)
                             : "v"(seen[0]), "v"(seen[1]), "v"(seen[2]), "v"(seen[3]), "v"(seen[4]), "v"(seen[5]), "v"(seen[6]), "v"(seen[7]),
                               "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]));
-                        if (cnt == 1u) atomicOr((unsigned *)(cbm + ((cs >> 3) & cmask)), 1u << (cs & 31u));
+                        if (cnt == 1u) cbm_mark(cs);
                         if (__ballot(cnt > 1u)) {
                             if (cnt > 1u) {
 #pragma unroll
                                 for (int j = 0; j < 8; ++j)
-                                    if (seen[j]) atomicOr((unsigned *)(cbm + ((c[j] >> 3) & cmask)), 1u << (c[j] & 31u));
+                                    if (seen[j]) cbm_mark(c[j]);
                             }
                         }
                     }
@@ -604,12 +639,12 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 // (the filter row's bounds are re-read where they are needed instead of living in registers through the sweeps)
                 if (p.filter_mode == SP_SEL_MATRIX) {
                     if (f_regs) {
-                        if (my_fc >= 0) atomicOr((unsigned *)(cbm + (((unsigned)my_fc >> 3) & cmask)), 1u << ((unsigned)my_fc & 31u));
+                        if (my_fc >= 0) cbm_mark((unsigned)my_fc);
                     } else {
                         const int f0 = __builtin_amdgcn_readfirstlane(p.f_indptr[t]), f1 = __builtin_amdgcn_readfirstlane(p.f_indptr[t + 1]);
                         for (int i = f0 + tid; i < f1; i += NT) {
                             const unsigned c = (unsigned)p.f_indices[i];
-                            atomicOr((unsigned *)(cbm + ((c >> 3) & cmask)), 1u << (c & 31u));
+                            cbm_mark(c);
                         }
                     }
                 }
@@ -641,14 +676,14 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 }
             }
             // the bitmap has done its job: back to zero (16-byte stores); its storage now serves sweep 2
-            for (int i = tid; i < (nb_bytes >> 4); i += NT) ((int4 *)rA)[i] = make_int4(0, 0, 0, 0);
+            for (int i = tid; i < (nb_bytes >> 4); i += NT) ((int4 *)(smem + BM_OFF))[i] = make_int4(0, 0, 0, 0);
             // rank structure of the collision bitmap: pre16[w] = marked columns in the words below w.  The rank of a
             // marked column is its slot in the collision set: no hashing, no probing (columns that alias to one bit
             // share a rank and are told apart by their key; the loser probes an overflow area).
-            if constexpr (CBM_BYTES / 16 <= NT && NW <= 64) {
-                // one trip: CBM_BYTES / 16 threads hold four words each; the waves' totals are combined by a second DPP scan in
+            if constexpr (RANK_BYTES / 16 <= NT && NW <= 64) {
+                // one trip: RANK_BYTES / 16 threads hold four words each; the waves' totals are combined by a second DPP scan in
                 // every wave (lane w < NW reads wave w's total) instead of NW reads and adds per thread
-                const int4 w4 = (tid < CBM_BYTES / 16) ? ((const int4 *)cbm)[tid] : make_int4(0, 0, 0, 0);
+                const int4 w4 = (tid < RANK_BYTES / 16) ? ((const int4 *)cbm)[tid] : make_int4(0, 0, 0, 0);
                 const int p0 = __popc((unsigned)w4.x), p1 = p0 + __popc((unsigned)w4.y), p2 = p1 + __popc((unsigned)w4.z);
                 const int tot = p2 + __popc((unsigned)w4.w);
                 const int incl = wave_incl_scan_dpp(tot);
@@ -659,18 +694,19 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 const int all = __builtin_amdgcn_readlane(ws_incl, 63);
                 const int woff = __builtin_amdgcn_readlane(ws_incl - ws, wave);
                 const int ex = woff + incl - tot;
-                if (tid < CBM_BYTES / 16) {
+                if (tid < RANK_BYTES / 16) {
                     const u64 packed = (u64)(unsigned)(ex & 0xFFFF) | ((u64)(unsigned)((ex + p0) & 0xFFFF) << 16) |
                                        ((u64)(unsigned)((ex + p1) & 0xFFFF) << 32) | ((u64)(unsigned)((ex + p2) & 0xFFFF) << 48);
                     ((u64 *)pre16)[tid] = packed;
                 }
-                if (all > CSN / 2) failed = true;      // more marked columns than direct slots (uniform)
+                if (all > CS_DIR) failed = true;      // more marked columns than direct slots (uniform)
+                n_marks = all;
             } else
             {
                 int carry = 0;
-                for (int base = 0; base < CBM_BYTES / 16; base += NT) {            // 4 words per thread and trip
+                for (int base = 0; base < RANK_BYTES / 16; base += NT) {            // 4 words per thread and trip
                     const int i = base + tid;
-                    const int4 w4 = (i < CBM_BYTES / 16) ? ((const int4 *)cbm)[i] : make_int4(0, 0, 0, 0);
+                    const int4 w4 = (i < RANK_BYTES / 16) ? ((const int4 *)cbm)[i] : make_int4(0, 0, 0, 0);
                     const int p0 = __popc((unsigned)w4.x), p1 = p0 + __popc((unsigned)w4.y), p2 = p1 + __popc((unsigned)w4.z);
                     const int tot = p2 + __popc((unsigned)w4.w);
                     const int incl = wave_incl_scan_dpp(tot);
@@ -684,15 +720,16 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                         all += sw;
                     }
                     const int ex = woff + incl - tot;
-                    if (i < CBM_BYTES / 16) {
+                    if (i < RANK_BYTES / 16) {
                         const u64 packed = (u64)(unsigned)(ex & 0xFFFF) | ((u64)(unsigned)((ex + p0) & 0xFFFF) << 16) |
                                            ((u64)(unsigned)((ex + p1) & 0xFFFF) << 32) | ((u64)(unsigned)((ex + p2) & 0xFFFF) << 48);
                         ((u64 *)pre16)[i] = packed;
                     }
                     carry += all;
-                    if (CBM_BYTES / 16 > NT) wg_sync<U_LDS>();     // (sh[SH_WSUM] is reused by the next trip)
+                    if (RANK_BYTES / 16 > NT) wg_sync<U_LDS>();     // (sh[SH_WSUM] is reused by the next trip)
                 }
-                if (carry > CSN / 2) failed = true;      // more marked columns than direct slots (uniform)
+                if (carry > CS_DIR) failed = true;      // more marked columns than direct slots (uniform)
+                n_marks = carry;
             }
             if constexpr (MLIKE) {
                 if (p.filter_mode == SP_SEL_MATRIX && !failed) {
@@ -794,7 +831,9 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                             const u32x4 a = fsa[f], b = fsb[f];
                             c[f][0] = a.x; c[f][1] = a.y; c[f][2] = a.z; c[f][3] = a.w;
                             v[0] = __uint_as_float(b.x); v[1] = __uint_as_float(b.y); v[2] = __uint_as_float(b.z); v[3] = __uint_as_float(b.w);
-                            if constexpr (BND) s2_core_b(c[f], v, segv, b_nKw, b_Q, x[f], M[f], S[f]);
+                            if constexpr (BND && DUO) s2_core_b_duo(c[f], v, segv, b_nKw, b_Q, x[f], M[f], S[f]);
+                            else if constexpr (BND) s2_core_b(c[f], v, segv, b_nKw, b_Q, x[f], M[f], S[f]);
+                            else if constexpr (DUO) s2_core_duo(c[f], v, segv, cutx, x[f], M[f], S[f]);
                             else s2_core(c[f], v, segv, cutx, x[f], M[f], S[f]);
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
@@ -967,7 +1006,20 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             while (!last_stage && !failed) {
                 // (force_sel: the first stage's cutoff is loose — far more than k products reached it: tighten it with a
                 // selection before sweeping on, i.e. run this round with an empty sweep)
-                const int i1 = (force_sel && i0 < n_items) ? i0 : min(n_items, i0 + chunk_items);
+                // DUO: the member pool holds fewer entries than a row has members; it is folded into the collision set between stages
+                // (below), and a stage must not bring more members than the pool has room for: a product is a member when its column's bit
+                // in both planes of the collision bitmap is marked — by chance ((marks / 32768)^2 of all products) or because its column
+                // repeats or shares its bit of the sweep-1 bitmap (up to two products per mark) — hence ITEM * fp + 2 * marks / items members per item; waves reserve whole
+                // blocks, so NW blocks of the pool are slack.  (An overflow is not an error: the row goes to the generic queue.)
+                int stage_items = chunk_items;
+                if constexpr (DUO) {
+                    const float fm = (float)n_marks * (1.f / (float)(8 * DUO_PLANE_BYTES));      // marked share of a plane's bits
+                    const float per_item = 1.25f * ((float)ITEM * fm * fm + 2.f * (float)n_marks * __builtin_amdgcn_rcpf((float)max(1, n_items))) + 2.f;
+                    const int room_m = (mpcap - NW * POOL_BLK) - min(sh[SH_MCTR], mpcap);
+                    stage_items = min(stage_items, max(1, (int)((float)room_m * __builtin_amdgcn_rcpf(per_item))));
+                    stage_items = __builtin_amdgcn_readfirstlane(stage_items);
+                }
+                const int i1 = (force_sel && i0 < n_items) ? i0 : min(n_items, i0 + stage_items);
                 {
                     // ---- sweep 2 over items [i0, i1) ----
                     WavePool wps{0, -1};
@@ -1020,7 +1072,9 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                         __builtin_amdgcn_s_setprio(3);
                         float x[4];
                         u64 M[4], S[4];
-                        if constexpr (BND) s2_core_b(c, v, segv, b_nKw, b_Q, x, M, S);
+                        if constexpr (BND && DUO) s2_core_b_duo(c, v, segv, b_nKw, b_Q, x, M, S);
+                        else if constexpr (BND) s2_core_b(c, v, segv, b_nKw, b_Q, x, M, S);
+                        else if constexpr (DUO) s2_core_duo(c, v, segv, cut, x, M, S);
                         else s2_core(c, v, segv, cut, x, M, S);
                         if (cnt != ITEM) {
 #pragma unroll
@@ -1141,13 +1195,15 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                 const int mext = min(sh[SH_MCTR], mpcap);
                 if (sh[SH_OVF]) { failed = true; break; }     // a pool overflowed
                 PHASE_END(PH_SWEEP2);
-                if (last_stage) {
+                // (DUO: also between stages, as soon as the pool is half full)
+                const bool do_acc = last_stage || (DUO && 2 * mext > mpcap - NW * POOL_BLK);      // uniform
+                if (do_acc) {
                     // ---- products of marked columns: find-or-insert in the collision set.  {column+1 : sum} slots,
                     // 0 = free; see below. ----
                     // a slot taken by another column (bit aliasing): hashed start in the overflow half, then linear
                     auto next_slot = [&](unsigned h, unsigned key) __attribute__((always_inline)) -> unsigned {
-                        const unsigned half = (unsigned)(CSN / 2);
-                        return (h < half) ? half + (hash_bits((int)key, 2654435761u, cs_shift + 1)) : half + ((h + 1u) & (half - 1u));
+                        const unsigned dir = (unsigned)CS_DIR, ovr = (unsigned)CS_OVR;
+                        return (h < dir) ? dir + (hash_bits((int)key, 2654435761u, cs_shift)) : dir + ((h - dir + 1u) & (ovr - 1u));
                     };
                     // Lock-step, two entries per thread: every round issues ONE 64-bit compare-and-swap per live entry
                     // that claims a free slot with the product in it; a slot that already belongs to the column gets
@@ -1181,7 +1237,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                         for (int j = 0; j < JA; ++j) {
                             // direct slot = rank of the column's bit in the collision bitmap
                             const unsigned cm = kk[j] - 1u;
-                            const unsigned wi = (cm >> 5) & (unsigned)(CBM_BYTES / 4 - 1);
+                            const unsigned wi = (cm >> 5) & (unsigned)(RANK_BYTES / 4 - 1);
                             const unsigned bw = ((const unsigned *)cbm)[wi];
                             h[j] = (unsigned)pre16[wi] + (unsigned)__popc(bw & ((1u << (cm & 31u)) - 1u));
                             cur[j] = 0ull;
@@ -1213,6 +1269,8 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     }
                     wg_sync<U_LDS>();
                     if (sh[SH_OVF]) { failed = true; break; }     // collision set full
+                    // (the pool is empty again — every entry read was zeroed — and its counter goes back to zero below: the waves' windows too)
+                    if constexpr (DUO) wpm = WavePool{0, -1};
                     PHASE_END(PH_ACCUM);
                 }
 
@@ -1269,7 +1327,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                                     }
                                     if (finished) {
                                         cs[base + j * NT + tid] = 0ull;
-                                        atomicAnd((unsigned *)(cbm + ((col >> 3) & cmask)), ~(1u << (col & 31u)));
+                                        cbm_unmark(col);
                                     }
                                 }
                             }
@@ -1301,7 +1359,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                                 if (e[j] != 0ull && (!(occ & (1u << j)) || (done & (1u << j)))) {
                                     *src[j] = 0ull;
                                     if (base + j * NT + tid >= ext)
-                                        atomicAnd((unsigned *)(cbm + (((unsigned)c[j] >> 3) & cmask)), ~(1u << ((unsigned)c[j] & 31u)));
+                                        cbm_unmark((unsigned)c[j]);
                                 }
                             }
                         }
@@ -1312,7 +1370,7 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
                     wg_sync<U_LDS>();
                     if (tid == 0) {
                         sh[SH_PCTR] = 0;
-                        if (last_stage) sh[SH_MCTR] = 0;
+                        if (do_acc) sh[SH_MCTR] = 0;
                         if (retry) { sh[SH_RETRY] = 0; if (n_now > cap) sh[SH_CNT] = cap; }   // failed appends over-counted
                     }
                     wg_sync<U_LDS>();         // counter fix-ups visible before the next pushes / the selection
@@ -1429,6 +1487,8 @@ __global__ __launch_bounds__(NT) void sp_knn_sparse_kernel(const KParams p) {
             const int n_sel = min(sh[SH_CNT], p.k);
             const long long o = (long long)slot_i * (long long)p.k;
             int n_out = n_sel;
+            // (DUO: the rank prefix lies inside the next row's column bitmap; its last reader was the last stage's accumulate)
+            if constexpr (DUO) { if (tid < PRE_BYTES / 16) ((int4 *)pre16)[tid] = make_int4(0, 0, 0, 0); }
             if constexpr (MLIKE) {
                 // (BND: the entries hold exact values already; MONO:) epilogue on the winners (s_plus.h:129-156 with the column term already folded in: val = xy / den, or
                 // the raw dot), exact threshold test, compaction of what passes to the front of the slot
