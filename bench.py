@@ -614,7 +614,9 @@ def phase_share(info) -> dict:
     d["bounded_variant"] = bool(cyc[8] & 2)
     d["cycles_per_wg"] = tot / max(1, info.get("num_wgs", 1))
     d["rows_sparse_path"], d["generic_windows"] = cyc[9], cyc[11]
-    d["rows_fallback_cs_full"], d["rows_fallback_u_overflow"] = cyc[10] & 0xFFFFFFFF, cyc[10] >> 32
+    # rows a sparse-row kernel handed to the generic queue, and why (workgroup-per-row kernel: bytes 4..7 of the counter, modulo 256)
+    d["rows_fallback"] = cyc[10] & 0xFFFFFFFF
+    d["rows_fallback_why"] = dict(zip(("items_or_row", "collision_set", "U_full", "member_pool_full"), [(cyc[10] >> s_) & 0xFF for s_ in (32, 40, 48, 56)]))
     return d
 
 
@@ -628,6 +630,73 @@ def physical_cores() -> int:
     except Exception:
         seen = set()
     return len(seen) or (os.cpu_count() or 1)
+
+
+def host_cpu_facts() -> dict:
+    """What this PROCESS may use of the host, not what the machine has (`cores: 128` was the /sys topology; a container
+    with a cpuset or a CFS quota smaller than that runs 128 pinned threads on fewer CPUs):
+      physical_cores      distinct (package, core) pairs of the machine
+      affinity_cpus       len(os.sched_getaffinity(0)) — logical CPUs this process may run on
+      affinity_cores      distinct (package, core) pairs among those
+      cgroup_cpu_max      the CFS quota in CPUs (cgroup v2 cpu.max / v1 cpu.cfs_quota_us), None = unlimited
+      usable_cores        min(affinity_cores, floor(quota)) — the thread count the baseline uses ("threads = all", as the reference's
+                          harness and s_plus.h:313 do with what OpenMP reports)"""
+    topo = {}
+    try:
+        for d in Path("/sys/devices/system/cpu").glob("cpu[0-9]*"):
+            t = d / "topology"
+            topo[int(d.name[3:])] = ((t / "physical_package_id").read_text().strip(), (t / "core_id").read_text().strip())
+    except Exception:
+        topo = {}
+    try:
+        aff = sorted(os.sched_getaffinity(0))
+    except Exception:
+        aff = list(range(os.cpu_count() or 1))
+    phys = len(set(topo.values())) or (os.cpu_count() or 1)
+    aff_cores = len({topo[c] for c in aff if c in topo}) or len(aff)
+    quota, src = None, None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = Path(path).read_text().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota, src = float(txt[0]) / float(txt[1]), path
+                else:
+                    src = path
+            else:
+                q = float(txt[0])
+                per = float(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text().split()[0])
+                if q > 0:
+                    quota = q / per
+                src = path
+            break
+        except Exception:
+            continue
+    usable = aff_cores if quota is None else max(1, min(aff_cores, int(quota)))
+    # one logical CPU per usable core, for the child's affinity mask (the first sibling of every core, in CPU order)
+    pick, seen = [], set()
+    for c in aff:
+        key = topo.get(c, ("?", str(c)))
+        if key not in seen:
+            seen.add(key)
+            pick.append(c)
+    return {"physical_cores": phys, "affinity_cpus": len(aff), "affinity_cores": aff_cores, "cgroup_cpu_max": quota, "cgroup_source": src,
+            "usable_cores": usable, "one_cpu_per_core": pick[:usable]}
+
+
+def cgroup_cpu_stat() -> dict:
+    """nr_throttled / throttled_usec of this cgroup (v2 cpu.stat, v1 cpu/cpu.stat); {} when not readable."""
+    for path in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):
+        try:
+            d = dict(l.split()[:2] for l in Path(path).read_text().splitlines() if l.strip())
+            out = {}
+            for k_ in ("nr_periods", "nr_throttled", "throttled_usec", "throttled_time"):
+                if k_ in d:
+                    out[k_] = int(d[k_])
+            return out
+        except Exception:
+            continue
+    return {}
 
 
 _CPU_CHILD = r"""
@@ -671,15 +740,38 @@ if "ps_slots" in d.files:
     out["parity_check"] = pc
 if budget <= 0:      # (the checker only: the other workloads' lines)
     print(json.dumps(out)); sys.exit(0)
+n_thr = int(sys.argv[5]) if len(sys.argv) > 5 else so.max_threads(kind)
+out["threads"] = n_thr
+def run_t(n, bs, t):
+    c = types.SimpleNamespace(**vars(call)); c.targets = np.ascontiguousarray(call.targets[:n])
+    t0 = time.perf_counter(); so.run_kernel(c, kind, num_threads=t, block_size=bs); return time.perf_counter() - t0
+def sized_probe(bs, t, min_s=0.5):
+    # rows whose run takes at least min_s: a 4 000-row probe of 30 ms says nothing about a 3 s round (VERDICT r5: probe-implied 314 k rows/s
+    # against 41 k sustained) — thread start-up, cold pages and the first touch of the per-thread accumulators dominate it
+    n = min(n_total, 2000)
+    run_t(min(n_total, 500), bs, t)                             # thread team up, pages in
+    while True:
+        dt = run_t(n, bs, t)
+        if dt >= min_s or n >= n_total:
+            return n, dt
+        n = int(min(n_total, max(2 * n, n * min_s * 1.3 / max(dt, 1e-4))))
 for name, bs in (("blocked_262144", 262144), ("unblocked", 0)):
-    probe = min(n_total, 4000)
-    run(min(n_total, 500), bs)                                  # thread team up, pages in
-    rate = probe / run(probe, bs)
-    sample = int(max(probe, min(n_total, rate * budget)))
-    run(sample, bs)                                              # warm-up round at full sample size
-    ts = [run(sample, bs) for _ in range(3)]
+    pn, pdt = sized_probe(bs, n_thr)
+    rate = pn / pdt
+    sample = int(max(pn, min(n_total, rate * budget)))
+    run_t(sample, bs, n_thr)                                     # warm-up round at full sample size
+    ts = [run_t(sample, bs, n_thr) for _ in range(3)]
     r = [sample / t for t in ts]
-    out[name] = {"rows_per_s": float(np.mean(r)), "std": float(np.std(r)), "rounds": r, "sample_rows": sample, "seconds": ts}
+    out[name] = {"rows_per_s": float(np.mean(r)), "std": float(np.std(r)), "rounds": r, "sample_rows": sample, "seconds": ts,
+                 "probe_rows": pn, "probe_seconds": pdt, "probe_rows_per_s": rate, "probe_vs_sustained": rate / float(np.mean(r))}
+# thread-scaling ladder of the reference default (1 / 8 / 32 / all, one round each, sized for ~budget/3 s from that count's own probe)
+ladder = {}
+for t in sorted({x for x in (1, 8, 32, n_thr) if x <= n_thr}):
+    pn, pdt = sized_probe(262144, t, 0.3)
+    n = int(max(pn, min(n_total, pn / pdt * budget / 3.0)))
+    dt = run_t(n, 262144, t)
+    ladder[str(t)] = {"rows_per_s": n / dt, "rows": n, "seconds": dt}
+out["thread_ladder_blocked"] = ladder
 print(json.dumps(out))
 """
 
@@ -692,7 +784,8 @@ def cpu_baseline(call, round_s: float, parity_sample=None, rtol: float = 1e-5):
     import subprocess
     import tempfile
 
-    cores = physical_cores()
+    facts = host_cpu_facts()
+    cores = facts["usable_cores"]
     names = ("targets", "m1_data", "m1_indices", "m1_indptr", "m2_data", "m2_indices", "m2_indptr",
              "Xtversky", "Ytversky", "Xcosine", "Ycosine", "Xdepop", "Ydepop",
              "filter_m_indptr", "filter_m_indices", "target_col_m_indptr", "target_col_m_indices")
@@ -705,16 +798,30 @@ def cpu_baseline(call, round_s: float, parity_sample=None, rtol: float = 1e-5):
         if parity_sample is not None:
             extra = {"ps_slots": parity_sample["slots"], "ps_cols": parity_sample["cols"], "ps_vals": parity_sample["vals"], "ps_counts": parity_sample["counts"]}
         np.savez(f, meta=json.dumps({"scalars": scal}), **{n: getattr(call, n) for n in names}, **extra)
-        env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_PROC_BIND="spread", OMP_PLACES="cores")
-        proc = subprocess.run([sys.executable, "-c", _CPU_CHILD, str(ROOT), f, str(round_s), str(rtol)], env=env, capture_output=True, text=True)
+        # threads = the cores this process may use (affinity and CFS quota respected); the child is bound to one logical CPU per such
+        # core and OpenMP spreads its team over them (OMP_PLACES=cores would count the machine's cores, not the cpuset's)
+        env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_PROC_BIND="spread", OMP_PLACES="threads")
+        stat0 = cgroup_cpu_stat()
+
+        def bind():
+            try:
+                os.sched_setaffinity(0, facts["one_cpu_per_core"])
+            except Exception:
+                pass
+        proc = subprocess.run([sys.executable, "-c", _CPU_CHILD, str(ROOT), f, str(round_s), str(rtol), str(cores)], env=env, capture_output=True, text=True,
+                              preexec_fn=bind)
+        stat1 = cgroup_cpu_stat()
     if proc.returncode != 0:
         raise RuntimeError("cpu_baseline child failed:\n" + proc.stderr[-2000:])
     r = json.loads(proc.stdout.strip().splitlines()[-1])
     if round_s <= 0:      # the checker only (other_workloads' lines): no timing rounds
         return r.get("parity_check")
     b, u = r["blocked_262144"], r["unblocked"]
-    log(f"cpu_baseline[{r['kind']}] {r['threads']} threads on {cores} physical cores: blocked(262144, the reference default) "
-        f"{b['rows_per_s']:.0f} +- {b['std']:.0f} rows/s; unblocked {u['rows_per_s']:.0f} +- {u['std']:.0f} rows/s")
+    throttle = {k_: stat1.get(k_, 0) - stat0.get(k_, 0) for k_ in stat1} if stat1 else None
+    log(f"cpu_baseline[{r['kind']}] {r['threads']} threads (machine: {facts['physical_cores']} physical cores; this process: {facts['affinity_cpus']} CPUs = "
+        f"{facts['affinity_cores']} cores in its affinity mask, cgroup cpu.max {facts['cgroup_cpu_max']}): blocked(262144, the reference default) "
+        f"{b['rows_per_s']:.0f} +- {b['std']:.0f} rows/s (probe-implied {b['probe_rows_per_s']:.0f}); unblocked {u['rows_per_s']:.0f} +- {u['std']:.0f} rows/s; "
+        f"ladder {json.dumps({t: round(v['rows_per_s']) for t, v in r['thread_ladder_blocked'].items()})}; throttling during the rounds {throttle}")
     if r.get("parity_check"):
         pc = r["parity_check"]
         log(f"parity_check: {pc['rows']} rows of the last timed step vs the {pc['checker']}: ok={pc['ok']} max_rel_err={pc['max_rel_err']:.2e} boundary_ties={pc['boundary_ties']}"
@@ -724,8 +831,17 @@ def cpu_baseline(call, round_s: float, parity_sample=None, rtol: float = 1e-5):
         "value": b["rows_per_s"], "std": b["std"], "unit": "rows/s", "cores": r["threads"], "kind": r["kind"],
         "sample": f"first {b['sample_rows']} of {call.targets.shape[0]} target rows of the same workload, the reference's default column "
                   f"blocking (block_size=0 -> 262144, s_plus.pyx:218-225; without its popularity reorder, which only permutes slot order), "
-                  f"1 warm-up + 3 rounds of {np.mean(b['seconds']):.1f}s, {r['threads']} OpenMP threads = physical cores, "
-                  f"OMP_PROC_BIND=spread OMP_PLACES=cores, dynamic schedule",
+                  f"1 warm-up + 3 rounds of {np.mean(b['seconds']):.1f}s sized from a >= 0.5 s probe, {r['threads']} OpenMP threads = the cores this "
+                  f"process may use (min of physical cores in its affinity mask and its cgroup CPU quota), one thread per core, "
+                  f"OMP_PROC_BIND=spread, dynamic schedule",
+        "physical_cores": facts["physical_cores"], "affinity_cpus": facts["affinity_cpus"], "affinity_cores": facts["affinity_cores"],
+        "cgroup_cpu_max": facts["cgroup_cpu_max"], "cgroup_cpu_stat_delta": throttle,
+        "probe_vs_sustained": b["probe_vs_sustained"],
+        "probe_note": (None if 0.8 <= b["probe_vs_sustained"] <= 1.25 else
+                       "the probe-implied rate and the sustained rate differ by more than 20 %: "
+                       + ("the cgroup throttled the rounds" if throttle and throttle.get("nr_throttled", 0) > 0 else
+                          "no cgroup throttling was recorded; the longer rounds run at another rate (frequency, memory placement)")),
+        "thread_ladder_blocked": r["thread_ladder_blocked"],
         "blocked_262144": b, "unblocked": u,
     }
 

@@ -73,8 +73,10 @@ extern "C" {
                                      slots one after the other, as the reference's stable counting sort leaves them); csr_indptr receives the
                                      n_rows_m1 + 1 row pointers, the first csr_nnz entries of `cols` / `values` the column ids and values of
                                      the non-zero entries in row order (slot order inside a row); rows / out_counts are not written.
-                                     With a MATRIX target selector the result cannot hold more than target_col_nnz entries: `cols` / `values`
-                                     then need only min(n_targets * k, target_col_nnz) entries when the call runs on ONE device (nothing beyond csr_nnz is written or touched) */
+                                     With a MATRIX target selector AND strictly ascending `targets` the result cannot hold more than target_col_nnz
+                                     entries: `cols` / `values` then need only min(n_targets * k, target_col_nnz) entries when the call runs on ONE
+                                     device (nothing beyond csr_nnz is written or touched).  Any other order of `targets` — a repeated target emits
+                                     its row once per repeat — needs the full n_targets * k. */
 #define SP_FLAG_P3_PREP      1024u /* with SP_FLAG_M2_IS_M1_T or SP_FLAG_M1_IS_M2_T: the preprocessing of p3alpha / rp3beta (similarity.py:410-415, 477-483;
                                      normalization.pyx:131-161) on the device: the rows of m1 and the rows of m2 = m1^T are divided by
                                      their L1 norms, then every entry is raised to p3_alpha.  The caller's matrix is not modified. */
@@ -238,6 +240,16 @@ int sp_knn_f32_i32(sp_knn_args *args);
 
 /* Device scratch the call needs for these args (device mode with caller workspace). */
 int64_t sp_knn_workspace_bytes(const sp_knn_args *args);
+
+/* The partition cost model of the multi-GPU routes, in ONE place ("contiguous ranges balanced by sum MACs(t)"; the row loop
+   being cut is s_plus.h:313, 337).  Host-mode args (on_device = 0); only the CSR STRUCTURE of m1 / m2, `targets`, the sizes and the flags
+   SP_FLAG_M2_IS_M1_T / SP_FLAG_M1_IS_M2_T are read — no device is needed.
+   sp_knn_target_costs: cost[i] of target slot i in MAC equivalents = MACs + a per-row toll (30 k for a row of the sparse kernels, 3 per
+   output column for a row of the generic kernel) + a price per m1 entry of a heavy row the launch cuts into pieces.
+   sp_knn_partition: bounds[0 .. n_parts] of contiguous slices of equal cumulative cost — what n_devices > 1 cuts `targets` by, and what
+   similaripy_amd/distributed.py (one process per GPU) calls for its ranks. */
+int sp_knn_target_costs(const sp_knn_args *args, double *cost /* [n_targets] */);
+int sp_knn_partition(const sp_knn_args *args, int n_parts, int64_t *bounds /* [n_parts + 1] */);
 
 /* Number of usable HIP devices (0 when there is none).  Counterpart of
    get_num_threads() -> omp_get_max_threads()  (similaripy/cython_code/utils.pyx:18-25). */

@@ -34,12 +34,13 @@ i2 = prob.run(cols, vals, counts, time_kernel=True, static_sched=static, **tun)
 ph = i2["phase_cycles"]
 names = ("setup", "segments", "accumulate", "drain", "select", "output", "sweep1", "sweep2", "csdrain")
 print(json.dumps({"rows": n_t, "call_ms": i1["kernel_ms"], "sparse_ms": i1["sparse_kernel_ms"], "generic_ms": i1["generic_kernel_ms"],
-                  "rows_sparse": ph[9], "given_up": ph[10]}), flush=True)
+                  "rows_sparse": ph[9], "given_up": ph[10] & 0xFFFFFFFF,
+                  "given_up_why": dict(zip(("items_or_row", "collision_set", "U_full", "member_pool_full"), [(ph[10] >> s) & 0xFF for s in (32, 40, 48, 56)]))}), flush=True)
 tot = float(sum(ph[:9]))
 print("   cycles/row %.0f: " % (tot / n_t) + "  ".join(f"{n}={c / n_t:.0f}" for n, c in zip(names, ph[:9])), flush=True)
 if ph[8] & 2:      # the bounded variant ran: its counters (slot 11: selections << 32 | entries through the exact pass)
     print(f"   bounded variant: {(ph[11] & 0xFFFFFFFF) / n_t:.0f} entries through the exact pass per row, {(ph[11] >> 32) / n_t:.2f} selections per row", flush=True)
-if tun["dbg"] & ~524288:
+if tun["dbg"] & ~(524288 | 1048576):
     sys.exit(0)
 sample = np.sort(np.random.default_rng(1).choice(n_t, min(n_t, 150), replace=False)).astype(np.int32)
 c2 = copy.copy(call); c2.targets = sample

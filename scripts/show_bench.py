@@ -15,4 +15,4 @@ for line in sys.stdin:
     tot_share = sum(ps[n] for n in names) or 1.0
     print(f"kernel {r['kernel_ms_avg']:.2f} ms  frac {r['frac']:.3f}  step {d['ms_per_step']:.2f} ms  value {d['value']:.3e}  "
           f"cycles/wg {wgs_cycles:.3e}  " + " ".join(f"{n}={ps[n]:.3f}" for n in names) +
-          f"  sparse_rows={ps['rows_sparse_path']} fallback={ps['rows_fallback_cs_full']}")
+          f"  sparse_rows={ps['rows_sparse_path']} fallback={ps.get('rows_fallback', ps.get('rows_fallback_cs_full'))}")

@@ -227,6 +227,8 @@ EXPORTED_SYMBOLS = (
     "sp_csr_normalize",
     "sp_csr_col_sums_f32",
     "sp_device_cache_trim",
+    "sp_knn_target_costs",
+    "sp_knn_partition",
 )
 
 
@@ -307,6 +309,10 @@ def load(build_if_missing: bool = True):
     lib.sp_csr_col_sums_f32.restype = C.c_int
     lib.sp_device_cache_trim.argtypes = []
     lib.sp_device_cache_trim.restype = C.c_int64
+    lib.sp_knn_target_costs.argtypes = [C.POINTER(SpKnnArgs), C.c_void_p]
+    lib.sp_knn_target_costs.restype = C.c_int
+    lib.sp_knn_partition.argtypes = [C.POINTER(SpKnnArgs), C.c_int, C.c_void_p]
+    lib.sp_knn_partition.restype = C.c_int
     _lib = lib
     return lib
 
@@ -387,6 +393,51 @@ def call_col_sums(args: SpCsrColsumsArgs) -> None:
     rc = lib.sp_csr_col_sums_f32(C.byref(args))
     if rc != 0:
         raise HipLibraryError(f"sp_csr_col_sums_f32 failed ({rc}): {last_error()}")
+
+
+def _cost_args(call):
+    """sp_knn_args for the partition cost model: the CSR STRUCTURE of the call, its sizes and flags (host pointers; no device needed).
+    Returns (args, keep-alive list)."""
+    a = SpKnnArgs()
+    keep = []
+
+    def i32(x):
+        x = as_i32(x); keep.append(x); return x.ctypes.data if x.size else None
+    a.on_device = 0
+    a.n_targets, a.n_rows_m1, a.n_rows_m2, a.n_output_cols = int(call.targets.shape[0]), call.n_rows_m1, call.n_rows_m2, call.n_output_cols
+    a.nnz_m1, a.nnz_m2 = int(call.m1_indices.shape[0]), int(call.m2_indices.shape[0])
+    a.flags = (SP_FLAG_M2_IS_M1_T if getattr(call, "m2_is_m1t", False) else 0) | (SP_FLAG_M1_IS_M2_T if getattr(call, "m1_is_m2t", False) else 0)
+    a.targets = i32(call.targets)
+    a.m1_indices, a.m1_indptr = i32(call.m1_indices), i32(call.m1_indptr)
+    a.m2_indices, a.m2_indptr = i32(call.m2_indices), i32(call.m2_indptr)
+    a.k = int(call.k)
+    a.a1, a.l1, a.l2, a.l3, a.t1, a.t2 = call.a1, call.l1, call.l2, call.l3, call.t1, call.t2
+    a.stabilized_shrink, a.bayesian_shrink, a.threshold = call.stabilized_shrink, call.bayesian_shrink, call.threshold
+    a.filter_mode, a.target_col_mode = call.filter_mode, call.target_col_mode
+    a.struct_size = C.sizeof(SpKnnArgs)
+    return a, keep
+
+
+def target_costs(call) -> np.ndarray:
+    """sp_knn_target_costs: what every target slot of the call costs a GPU, in MAC equivalents (the library's ONE partition cost model)."""
+    a, keep = _cost_args(call)
+    out = np.empty(int(a.n_targets), dtype=np.float64)
+    rc = load().sp_knn_target_costs(C.byref(a), out.ctypes.data if out.size else None)
+    if rc != 0:
+        raise HipLibraryError(f"sp_knn_target_costs failed ({rc}): {last_error()}")
+    del keep
+    return out
+
+
+def partition(call, n_parts: int) -> np.ndarray:
+    """sp_knn_partition: bounds[0 .. n_parts] of the contiguous cost-balanced slices the library itself cuts `targets` into."""
+    a, keep = _cost_args(call)
+    out = np.zeros(int(n_parts) + 1, dtype=np.int64)
+    rc = load().sp_knn_partition(C.byref(a), int(n_parts), out.ctypes.data)
+    if rc != 0:
+        raise HipLibraryError(f"sp_knn_partition failed ({rc}): {last_error()}")
+    del keep
+    return out
 
 
 def device_cache_trim() -> int:

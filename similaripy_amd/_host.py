@@ -662,8 +662,11 @@ def run_hip(call: KernelCall, device: Optional[int] = None, table_slots: int = 0
     rows = np.empty(n * k, dtype=np.int32) if want_rows else None      # (slot i's rows are all targets[i]: CSR assembly does not read them)
     # (CSR out with a MATRIX target selector: at most one entry per listed column — the library writes, and touches, no more than that;
     # 800 MB of slot arrays for 200 k entries cost 40 ms of page faults and unmapping at the C2 size)
+    # — when the targets ascend strictly: a target that repeats emits its row once per repeat (target_rows=[7, 7, 7] against a
+    # list of 5 columns in row 7 is 15 entries), so any other order keeps the full n * k, as include/sp_knn.h says)
     n_out = n * k
-    if csr_out and call.target_col_mode == MODE_MATRIX and devices is None:      # (several devices write their pieces at slot offsets)
+    if (csr_out and call.target_col_mode == MODE_MATRIX and devices is None      # (several devices write their pieces at slot offsets)
+            and (n < 2 or bool(np.all(np.diff(np.asarray(call.targets, dtype=np.int64)) > 0)))):
         n_out = min(n_out, int(call.target_col_m_indices.shape[0]))
     cols = np.empty(n_out, dtype=np.int32)
     values = np.empty(n_out, dtype=np.float32)

@@ -199,6 +199,19 @@ size_t sddmm_ws_bytes(const sp_knn_args *a) {
     return 256 + 2 * al((size_t)a->nnz_m2 * 4) + al(((size_t)a->n_output_cols + 1) * 4) + transpose_ws_bytes(a->nnz_m2, a->n_output_cols);
 }
 
+// Heavy rows of the generic kernel are queued in pieces of this many MACs (a row is cut from twice that on).  A piece is what ONE workgroup
+// cannot be interrupted in: its size bounds how unevenly the persistent workgroups finish.  2^21 MACs (~1.7 ms) is nothing against the
+// ~38 ms of the whole MovieLens-shaped call, and a third of an N = 8 rank's slice of it: the piece shrinks with the work a workgroup can
+// expect — a quarter of it, from sizes alone —, between 2^18 and 2^21 MACs.  ONE function: the launch (sp_row_desc_kernel's split_macs) and
+// the partition cost model (target_costs) must agree on which rows are cut.
+unsigned split_piece_macs(const sp_knn_args *a, int wgs_generic) {
+    const double avg_macs = (a->n_rows_m1 > 0 && a->n_rows_m2 > 0) ? ((double)a->nnz_m1 / a->n_rows_m1) * ((double)a->nnz_m2 / a->n_rows_m2) : 0.0;
+    const double per_wg = avg_macs * (double)a->n_targets / (double)std::max(1, wgs_generic);
+    unsigned piece = 1u << 21;
+    while (piece > (1u << 18) && (double)piece > per_wg / 4.0) piece >>= 1;
+    return piece;
+}
+
 // can the call run the sparse kernel's bounded variant (MODE 2)?  (conditions: see make_config)
 bool bnd_eligible(const sp_knn_args *a, bool mono, bool fold) {
     const bool live = (a->l1 != 0.f && a->t2 != 0.f) || a->l2 != 0.f || a->l3 != 0.f;
@@ -789,17 +802,7 @@ int run_device_impl(sp_knn_args *a, const uint64_t *sig_override = nullptr) {
             const size_t np = (size_t)c.split_cap * (size_t)c.split_pmax;
             cp.split_fine = c.n_splits + 1;
             cp.split_pmax = c.split_pmax;
-            // A piece is what ONE workgroup cannot be interrupted in: its size bounds how unevenly the persistent workgroups finish.  2^21 MACs
-            // (~1.7 ms) is nothing against the ~38 ms of the whole MovieLens-shaped call, and a third of an N = 8 rank's slice of it (the slices
-            // of round 4's experiment took 7.7 ms where 4.7 ms of work were in them): the piece shrinks with the work a workgroup can expect —
-            // a quarter of it, from sizes alone —, between 2^18 and 2^21 MACs.
-            {
-                const double avg_macs = (a->n_rows_m1 > 0 && a->n_rows_m2 > 0) ? ((double)a->nnz_m1 / a->n_rows_m1) * ((double)a->nnz_m2 / a->n_rows_m2) : 0.0;
-                const double per_wg = avg_macs * (double)a->n_targets / (double)std::max(1, c.wgs_generic);
-                unsigned piece = 1u << 21;
-                while (piece > (1u << 18) && (double)piece > per_wg / 4.0) piece >>= 1;
-                cp.split_macs = (a->reserved[0] & 8192) ? 1u : piece;        // (bit 8192 of the ablation word: cut every generic row as finely as allowed, for tests)
-            }
+            cp.split_macs = (a->reserved[0] & 8192) ? 1u : split_piece_macs(a, c.wgs_generic);      // (bit 8192 of the ablation word: cut every generic row as finely as allowed, for tests)
             cp.split_cap = c.split_cap;
             cp.split_count = (int *)(ws + 16);                                  // two words inside the zeroed header
             cp.split_rows = (int4 *)ws_piece;
@@ -1562,9 +1565,11 @@ int run_host(sp_knn_args *a) {
     // output arrays so that the copies back do not pay for the page faults.  Output-only memory: writing zeros is harmless.
     HostPrefault prefault;
     if (want_rows) prefault.fill_rows(a->rows, a->targets, nt, k);
-    // (SP_FLAG_CSR_OUT with a MATRIX target selector: a row keeps at most the columns its list names — the result has at most
-    // target_col_nnz entries, and only that much of cols / values is ever written: see sp_knn.h)
-    const size_t out_entries = (csr_out && tm) ? std::min(nt * k, (size_t)std::max<int64_t>(0, a->target_col_nnz)) : nt * k;
+    // (SP_FLAG_CSR_OUT with a MATRIX target selector and STRICTLY ASCENDING targets: a row keeps at most the columns its list names and
+    // is asked for once — the result has at most target_col_nnz entries, and only that much of cols / values is ever written: see
+    // sp_knn.h.  A target that repeats emits its row once per repeat ([7, 7, 7] against a list of 5 columns in row 7 is 15
+    // entries): such calls keep the full n_targets * k capacity)
+    const size_t out_entries = (csr_out && tm && targets_ascend) ? std::min(nt * k, (size_t)std::max<int64_t>(0, a->target_col_nnz)) : nt * k;
     if (out_entries >= (size_t)1 << 22) {
         prefault.add(a->cols, out_entries * sizeof(int32_t));
         prefault.add(a->values, out_entries * sizeof(float));
@@ -1640,6 +1645,7 @@ int run_host(sp_knn_args *a) {
                 HIP_TRY(hipMemcpyAsync(&nnz_j, totals + j, sizeof(nnz_j), hipMemcpyDeviceToHost, cs_.s2));
                 HIP_TRY(hipStreamSynchronize(cs_.s2));
                 if (j == 0) prefault.join();
+                if (running + (size_t)nnz_j > out_entries) return fail(SP_EINVAL, "internal: the CSR result (%zu entries so far) exceeds the documented capacity of cols / values (%zu)", running + (size_t)nnz_j, out_entries);
                 if (nnz_j > 0) {
                     HIP_TRY(hipMemcpyAsync(a->cols + running, o_idx + s0 * k, (size_t)nnz_j * 4, hipMemcpyDeviceToHost, cs_.s2));
                     HIP_TRY(hipMemcpyAsync(a->values + running, o_val + s0 * k, (size_t)nnz_j * 4, hipMemcpyDeviceToHost, cs_.s2));
@@ -1738,6 +1744,7 @@ int run_host(sp_knn_args *a) {
         long long nnz = 0;
         HIP_TRY(hipMemcpy(&nnz, total, sizeof(nnz), hipMemcpyDeviceToHost));
         a->csr_nnz = nnz;
+        if ((size_t)std::max<long long>(0, nnz) > out_entries) return fail(SP_EINVAL, "internal: the CSR result (%lld entries) exceeds the documented capacity of cols / values (%zu)", nnz, out_entries);
         HIP_TRY(hipMemcpy(a->csr_indptr, indptr, ((size_t)n_rows + 1) * 4, hipMemcpyDeviceToHost));
         if (nnz > 0) {
             HIP_TRY(hipMemcpy(a->cols, o_idx, (size_t)nnz * 4, hipMemcpyDeviceToHost));
@@ -1790,21 +1797,45 @@ void parallel_ranges(size_t n, size_t min_chunk, F &&f) {
     for (auto &t : th) t.join();
 }
 
-// cost[i] of target slot i in MAC equivalents: MACs(targets[i]) + a fixed toll per row — the quantity the row kernels schedule on and
-// what the one-process-per-GPU driver balances (distributed.row_cost)
+// THE partition cost model (one place: the in-library "threads" route below, and — through sp_knn_target_costs / sp_knn_partition — the
+// one-process-per-GPU route of similaripy_amd/distributed.py; VERDICT r5 #6: two copies had diverged).  cost[i] of target slot i, in MAC
+// equivalents:
+//     MACs(targets[i])
+//   + a fixed toll per row: 30 k for a row of the sparse kernels (queue, setup, bitmap clear, selection, write-out whatever its length:
+//     profiles/r03_c2_phases.txt), 3 per output column for a row of the generic kernel, which walks every column window whatever the row
+//     holds (SIMILARIPY_AMD_GENERIC_TOLL_PER_COL; profiles/r04_exp_strong_scaling_c4.txt)
+//   + for a HEAVY generic row — one the launch cuts into column-window pieces: MACs >= 2 x split_piece_macs, the launch's own rule — a
+//     price per m1 ENTRY (SIMILARIPY_AMD_HEAVY_ENTRY_MACS, default 2 100: every fine window of such a row walks all of its segments for a
+//     handful of elements; least squares over the slices of N = 1 .. 8 at the MovieLens-32M shape, profiles/r05_exp_dropped.txt).
+// Which rows are "sparse" restates sp_row_desc_kernel's rule from sizes.
 constexpr double ROW_TOLL_MACS = 30000.0;
 int target_costs(const sp_knn_args *a, std::vector<double> *cost) {
     const size_t nt = (size_t)a->n_targets;
     cost->assign(nt, ROW_TOLL_MACS);
     const bool m2t = (a->flags & SP_FLAG_M2_IS_M1_T) != 0, m1t = (a->flags & SP_FLAG_M1_IS_M2_T) != 0;
-    // (the toll of a row: 30 k for a row of the sparse kernels, ~3 per output column — SIMILARIPY_AMD_GENERIC_TOLL_PER_COL, as in
-    // distributed.row_cost — for a row of the generic kernel, which walks every column window whatever the row holds; same rule there)
     const double n_cols_d = (double)std::max(1, a->n_output_cols);
-    double toll_per_col = 3.0;
+    double toll_per_col = 3.0, heavy_entry = 2100.0;
     if (const char *e = getenv("SIMILARIPY_AMD_GENERIC_TOLL_PER_COL")) { const double v = atof(e); if (v > 0.0) toll_per_col = v; }
+    if (const char *e = getenv("SIMILARIPY_AMD_HEAVY_ENTRY_MACS")) { const double v = atof(e); if (v >= 0.0) heavy_entry = v; }
+    // the piece size the launch will use for these sizes (the persistent generic workgroups of a 256-CU device when none is visible)
+    double heavy_from = 1e300;
+    {
+        sp_knn_args b = *a;
+        if (m2t) { b.nnz_m2 = a->nnz_m1; }
+        if (m1t) { b.nnz_m1 = a->nnz_m2; }
+        int n_cus = 256;
+        if (sp_device_count() > 0) {
+            hipDeviceProp_t prop;
+            int dev = 0;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n_cus = prop.multiProcessorCount;
+        }
+        Config c{};
+        if (make_config(&b, n_cus, &c) == SP_OK && c.split_pmax >= 2 && c.n_splits >= 1) heavy_from = 2.0 * (double)split_piece_macs(&b, c.wgs_generic);
+    }
     auto priced = [&](double m, long long nnz1) {
         const bool sparse_row = 0.5 * m * m / n_cols_d <= 0.30 * 4096.0 && nnz1 <= 256 && a->n_output_cols > 16384;
-        return m + (sparse_row ? ROW_TOLL_MACS : toll_per_col * n_cols_d);
+        const bool heavy = !sparse_row && m >= heavy_from;
+        return m + (sparse_row ? ROW_TOLL_MACS : toll_per_col * n_cols_d) + (heavy ? heavy_entry * (double)nnz1 : 0.0);
     };
     if (m1t) {
         // m1 = m2^T does not exist on the host: MACs(t) = sum over the entries (u, t) of m2 of len(m2 row u), scattered by column;
@@ -1858,6 +1889,38 @@ int target_costs(const sp_knn_args *a, std::vector<double> *cost) {
     return SP_OK;
 }
 
+// bounds[0 .. n_parts] of contiguous slices of equal cumulative cost: slice r starts behind the first slot at which the running cost
+// reaches r / n_parts of the total
+void partition_by_cost(const std::vector<double> &cost, int n_parts, std::vector<size_t> *bounds) {
+    const size_t nt = cost.size();
+    bounds->assign((size_t)n_parts + 1, 0);
+    double total = 0.0;
+    for (double c : cost) total += c;
+    double run = 0.0;
+    size_t i = 0;
+    for (int r = 1; r < n_parts; ++r) {
+        const double want = total * (double)r / (double)n_parts;
+        while (i < nt && run < want) run += cost[i++];
+        (*bounds)[(size_t)r] = i;
+    }
+    (*bounds)[(size_t)n_parts] = nt;
+}
+
+int check_cost_args(const sp_knn_args *a) {
+    if (!a) return fail(SP_EINVAL, "args is NULL");
+    if (a->struct_size != sizeof(sp_knn_args)) return fail(SP_EINVAL, "sp_knn_args size mismatch: caller %u, library %zu", a->struct_size, sizeof(sp_knn_args));
+    if (a->on_device) return fail(SP_EINVAL, "the cost model reads the CSR structure on the host (on_device must be 0)");
+    if (a->n_targets < 0 || a->n_rows_m1 < 0 || a->n_rows_m2 < 0) return fail(SP_EINVAL, "negative dimension");
+    const bool m2t = (a->flags & SP_FLAG_M2_IS_M1_T) != 0, m1t = (a->flags & SP_FLAG_M1_IS_M2_T) != 0;
+    if (a->n_targets > 0 && !a->targets) return fail(SP_EINVAL, "targets is NULL");
+    if (!m1t && (!a->m1_indptr || (a->nnz_m1 > 0 && !a->m1_indices))) return fail(SP_EINVAL, "m1 structure pointers are NULL");
+    if (!m2t && !a->m2_indptr) return fail(SP_EINVAL, "m2_indptr is NULL");
+    if (m1t && a->nnz_m2 > 0 && !a->m2_indices) return fail(SP_EINVAL, "m2_indices is NULL");
+    for (int i = 0; i < a->n_targets; ++i)
+        if (a->targets[i] < 0 || a->targets[i] >= a->n_rows_m1) return fail(SP_EINVAL, "targets[%d]=%d out of range [0,%d)", i, a->targets[i], a->n_rows_m1);
+    return SP_OK;
+}
+
 int run_host_multi(sp_knn_args *a) {
     const int nd = a->n_devices;
     const size_t nt = (size_t)a->n_targets, k = (size_t)a->k;
@@ -1878,22 +1941,11 @@ int run_host_multi(sp_knn_args *a) {
         for (size_t i = 1; i < nt; ++i)
             if (a->targets[i] <= a->targets[i - 1])
                 return fail(SP_EINVAL, "SP_FLAG_CSR_OUT over several devices needs strictly increasing targets (targets[%zu] = %d follows %d)", i, a->targets[i], a->targets[i - 1]);
-    // contiguous slices of equal cumulative cost (distributed.partition_targets)
+    // contiguous slices of equal cumulative cost
     std::vector<double> cost;
     TRY(target_costs(a, &cost));
-    std::vector<size_t> bounds((size_t)nd + 1, 0);
-    {
-        double total = 0.0;
-        for (double c : cost) total += c;
-        double run = 0.0;
-        size_t i = 0;
-        for (int r = 1; r < nd; ++r) {
-            const double want = total * (double)r / (double)nd;
-            while (i < nt && run < want) run += cost[i++];
-            bounds[(size_t)r] = i;
-        }
-        bounds[(size_t)nd] = nt;
-    }
+    std::vector<size_t> bounds;
+    partition_by_cost(cost, nd, &bounds);
     struct Part { sp_knn_args args; int rc = SP_OK; std::string err; std::vector<int32_t> indptr; };
     std::vector<Part> parts((size_t)nd);
     std::vector<std::thread> th;
@@ -1969,6 +2021,28 @@ int run_host_multi(sp_knn_args *a) {
 extern "C" {
 
 int sp_abi_version(void) { return SP_KNN_ABI_VERSION; }
+
+int sp_knn_target_costs(const sp_knn_args *a, double *cost) {
+    g_err[0] = 0;
+    TRY(check_cost_args(a));
+    if (a->n_targets > 0 && !cost) return fail(SP_EINVAL, "cost is NULL");
+    std::vector<double> c;
+    TRY(target_costs(a, &c));
+    for (size_t i = 0; i < c.size(); ++i) cost[i] = c[i];
+    return SP_OK;
+}
+
+int sp_knn_partition(const sp_knn_args *a, int n_parts, int64_t *bounds) {
+    g_err[0] = 0;
+    TRY(check_cost_args(a));
+    if (n_parts < 1 || !bounds) return fail(SP_EINVAL, "n_parts must be >= 1 and bounds non-NULL");
+    std::vector<double> c;
+    TRY(target_costs(a, &c));
+    std::vector<size_t> b;
+    partition_by_cost(c, n_parts, &b);
+    for (int r = 0; r <= n_parts; ++r) bounds[r] = (int64_t)b[(size_t)r];
+    return SP_OK;
+}
 
 const char *sp_last_error(void) { return g_err; }
 

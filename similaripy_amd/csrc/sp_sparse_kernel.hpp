@@ -96,6 +96,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DUO ? 4 : 1,
         if constexpr (DUO) duo_unmark(cbm, c);
         else atomicAnd((unsigned *)(cbm + ((c >> 3) & cmask)), ~(1u << (c & 31u)));
     };
+    // stage length factor (see the chunk rule at the end of a stage: what an exchangeable stream would let into U against what is left of it;
+    // far less passes when the segments come in descending weight, the rule).  DUO: its U is half the classic one's and its selection-free
+    // first stage sees half the products — with the classic factor one row in 30 000 of configs[1] (one in 7 500 of configs[2]) overflowed
+    // U and went to the generic queue: half the factor
+    const float STAGE_FILL = (DUO && (p.dbg & 1048576)) ? 1.f : 2.f;      // (experiment switch)
     constexpr int RANK_BYTES = DUO ? DUO_PLANE_BYTES : CBM_BYTES;      // the part of the collision bitmap whose bits have ranks
     u64 *cs = (u64 *)rA;
     const int CSN = cs_bytes / 8;
@@ -384,6 +389,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DUO ? 4 : 1,
         }
         bool failed = (n_items >= ICAP) || (n_items > 63 * NW) || (n_pre > 0 && n_rec > ICAP);      // (a wave keeps its <= 63 item descriptors in one register)
         int n_marks = 0;      // (uniform) marked bits of the collision bitmap, known behind sweep 1
+        // why a row is handed to the generic queue (profiling: the upper bytes of the fallback counter — 32..39 too many items / a row the
+        // variant cannot serve, 40..47 collision set (marks beyond its rank slots, or full), 48..55 candidate buffer U full, 56..63 member pool full)
+        int why = failed ? 0 : -1;
         PHASE_END(PH_SETUP);
 
         RowCtx rc;
@@ -464,7 +472,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DUO ? 4 : 1,
             // rows the bound cannot serve: a negative row term or multiplier, nothing positive in the denominator's bound
             const bool row_ok = p.bound_ok && (r_tv >= 0.f) && (r_cos >= 0.f) && (r_dep >= 0.f) && (A >= 0.f) && (lam >= 0.f) && (lam < __builtin_inff()) &&
                                 (b_AE < __builtin_inff()) && (b_AE > 0.f || lam > 0.f) && !(b_bB > 0.f);
-            if (!row_ok) failed = true;
+            if (!row_ok) { failed = true; why = 0; }
             b_lam = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(b_lam)));
             b_AE = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(b_AE)));
             b_bB = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(b_bB)));
@@ -474,7 +482,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DUO ? 4 : 1,
         // MONO: the first stage's trips (one or two items per wave, see there) are requested in front of the bitmap's clearing loop and
         // the rank prefix: the round trip (~3.5 k cycles, in which no wave had anything else to do) runs under those ~3.6 k cycles
         // (zero-initialised: undefined on some path, the registers' last contents would be live around the whole row loop)
-        constexpr int FS1 = (NT == 256) ? 2 : 1;
+        constexpr int FS1 = (NT == 256 || DUO) ? 2 : 1;      // (DUO: eight waves — two trips each show the stage the 4 096 products the classic shape's sixteen waves see)
         constexpr int MAXR1 = (NT == 256) ? 32 : 16;
         u32x4 fsa[FS1], fsb[FS1];
 #pragma unroll
@@ -699,7 +707,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DUO ? 4 : 1,
                                        ((u64)(unsigned)((ex + p1) & 0xFFFF) << 32) | ((u64)(unsigned)((ex + p2) & 0xFFFF) << 48);
                     ((u64 *)pre16)[tid] = packed;
                 }
-                if (all > CS_DIR) failed = true;      // more marked columns than direct slots (uniform)
+                if (all > CS_DIR) { failed = true; why = 1; }      // more marked columns than direct slots (uniform)
                 n_marks = all;
             } else
             {
@@ -728,7 +736,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DUO ? 4 : 1,
                     carry += all;
                     if (RANK_BYTES / 16 > NT) wg_sync<U_LDS>();     // (sh[SH_WSUM] is reused by the next trip)
                 }
-                if (carry > CS_DIR) failed = true;      // more marked columns than direct slots (uniform)
+                if (carry > CS_DIR) { failed = true; why = 1; }      // more marked columns than direct slots (uniform)
                 n_marks = carry;
             }
             if constexpr (MLIKE) {
@@ -987,13 +995,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DUO ? 4 : 1,
                         else cutx = fmaxf(cutx0, funkey(g));
                     }
                     wg_sync<U_LDS>();
-                    if (sh[SH_OVF]) failed = true;
+                    if (sh[SH_OVF]) { failed = true; why = (sh[SH_CNT] > cap) ? 2 : 3; }
                     // (not fitting: U now holds everything of the first nfull items; the next stage's selection trims it)
                     {
                         // (float arithmetic: a 64-bit integer division is ~100 instructions on every wave)
                         const float left = (float)(cap - min(sh[SH_CNT], cap));
                         const float pos = (float)(items[min(i0, n_items)].w & ((1 << ITEM_W_BITS) - 1));
-                        const float ch = fits ? 2.f * pos * left / (float)max(2 * p.k, totalA) : 0.5f * left;      // !fits: no cutoff yet, everything is accepted
+                        const float ch = fits ? STAGE_FILL * pos * left / (float)max(2 * p.k, totalA) : 0.5f * left;      // !fits: no cutoff yet, everything is accepted
                         chunk_items = max(1, (int)fminf(ch * (1.f / ITEM), 1e6f));
                         force_sel = fits && totalA > 8 * p.k;
                     }
@@ -1193,7 +1201,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DUO ? 4 : 1,
                 wg_sync<U_LDS>();
                 const int ext = min(sh[SH_PCTR], spcap);
                 const int mext = min(sh[SH_MCTR], mpcap);
-                if (sh[SH_OVF]) { failed = true; break; }     // a pool overflowed
+                if (sh[SH_OVF]) { failed = true; why = (sh[SH_CNT] > cap) ? 2 : 3; break; }     // a pool overflowed
                 PHASE_END(PH_SWEEP2);
                 // (DUO: also between stages, as soon as the pool is half full)
                 const bool do_acc = last_stage || (DUO && 2 * mext > mpcap - NW * POOL_BLK);      // uniform
@@ -1268,7 +1276,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DUO ? 4 : 1,
                         }
                     }
                     wg_sync<U_LDS>();
-                    if (sh[SH_OVF]) { failed = true; break; }     // collision set full
+                    if (sh[SH_OVF]) { failed = true; why = 1; break; }     // collision set full
                     // (the pool is empty again — every entry read was zeroed — and its counter goes back to zero below: the waves' windows too)
                     if constexpr (DUO) wpm = WavePool{0, -1};
                     PHASE_END(PH_ACCUM);
@@ -1457,7 +1465,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DUO ? 4 : 1,
                 // (the cutoff is the value that `cnt` of the `pos` products offered so far reach: cnt ~ k after a selection, more
                 // after the selection-free first stage)
                 const float cnt_u = (float)max(2 * p.k, min(sh[SH_CNT], cap));
-                float ch = rc.have_thr ? fmaxf((float)ITEM, 2.f * pos * left / cnt_u) : (float)room;
+                float ch = rc.have_thr ? fmaxf((float)ITEM, STAGE_FILL * pos * left / cnt_u) : (float)room;
                 if constexpr (MLIKE) {
                     // no k-th value yet, but the `threshold` parameter prunes (cutx0): U holds what passed of the `pos` products offered so
                     // far — the rest of the row passes at most at that rate (segments come in descending weight).  Without this a row
@@ -1572,7 +1580,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DUO ? 4 : 1,
             for (int i = tid; i < (CBM_BYTES + PRE_BYTES + A_bytes) / 16; i += NT) ((int4 *)smem)[i] = make_int4(0, 0, 0, 0);
             for (int i = tid; i < 1024; i += NT) hist4[i] = 0;
             if (MLIKE && !U_LDS) { for (int i = tid; i < cap / 2; i += NT) ((int4 *)U)[i] = make_int4(0, 0, 0, 0); }
-            if (timing) ph[CT_ROWS_FALLBACK] += 1;
+            if (timing) ph[CT_ROWS_FALLBACK] += 1ull + (1ull << (32 + 8 * max(0, why)));
         }
         // rotate the row pipeline (descriptors are wave-uniform: keep them in scalar registers)
         dC = dN; wC = wN;

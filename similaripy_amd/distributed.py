@@ -49,26 +49,14 @@ def row_work(call: KernelCall) -> np.ndarray:
 def row_cost(call: KernelCall) -> np.ndarray:
     """What a target slot costs a GPU, in MAC equivalents — the quantity `partition_targets` balances.
 
-    MACs alone under-price light rows: every row pays a fixed toll whatever its length.  For a row of the SPARSE kernels (few
-    colliding products: the classification of sp_row_desc_kernel, restated from sizes) that is queue, setup, bitmap clear, selection,
-    write-out: ~30 k MAC equivalents (profiles/r03_c2_phases.txt).  A row of the GENERIC kernel walks every column window of the
-    output whatever it holds: segment slices, the drain over 32 k slots per window, its selections — half of such a row's time on
-    the MovieLens-32M shape, where the average row has 140 k MACs over 84 k columns: ~3 MAC equivalents per output column
-    (profiles/r04_exp_strong_scaling_c4.txt: tolls of 0.8 ... 9 per column timed; the slices are balanced to +-8 % from 1.6 up)."""
-    macs = row_work(call).astype(np.float64)
-    n_cols = float(max(1, call.n_output_cols))
-    nnz1 = np.diff(call.m1_indptr).astype(np.int64)[call.targets] if call.m1_indptr.size else np.zeros(call.n_targets, np.int64)
-    sparse = (0.5 * macs * macs / n_cols <= 0.30 * 4096.0) & (nnz1 <= 256) & (call.n_output_cols > 16384)
-    # A HEAVY generic row (cut into column-window pieces, sp_row_desc_kernel) costs by its m1 entries, not its MACs: each of its ~21 fine windows
-    # walks all of the row's segments for a handful of elements each.  Least squares over the 15 slices of N = 1, 2, 4, 8 at the MovieLens-32M
-    # shape (profiles/r05_exp_dropped.txt): 2.1 k MAC equivalents per entry of such a row — 247 rows, 19 % of the MACs, a third of the time.
-    heavy = (~sparse) & (macs >= 2.0 * (1 << 21)) & (call.n_output_cols > 65536)
-    return macs + np.where(sparse, ROW_TOLL_MACS, GENERIC_TOLL_PER_COL * n_cols) + np.where(heavy, HEAVY_ENTRY_MACS * nnz1, 0.0)
-
-
-ROW_TOLL_MACS = 30_000.0       # fixed cost of a sparse-kernel row, in MACs
-HEAVY_ENTRY_MACS = float(os.environ.get("SIMILARIPY_AMD_HEAVY_ENTRY_MACS", "2100"))      # what an m1 entry of a heavy (piece-split) generic row costs on top of its MACs
-GENERIC_TOLL_PER_COL = float(os.environ.get("SIMILARIPY_AMD_GENERIC_TOLL_PER_COL", "3.0"))      # fixed cost of a generic-kernel row per output column
+    ONE cost model for both multi-GPU routes, and it lives in the library (`target_costs` in csrc/sp_knn.hip, exported as
+    `sp_knn_target_costs`; VERDICT r5 #6: the copy that stood here priced the m1 entries of heavy rows, the library's did not, and the
+    default in-call route got the worse balance): MACs + a per-row toll (30 k for a row of the sparse kernels, 3 per output column —
+    SIMILARIPY_AMD_GENERIC_TOLL_PER_COL — for a row of the generic kernel) + SIMILARIPY_AMD_HEAVY_ENTRY_MACS (2 100) per m1 entry of a
+    heavy row, where "heavy" is the launch's own rule for cutting a row into column-window pieces.  The constants' provenance is
+    documented there.  `tests/test_distributed.py::test_both_routes_cut_the_same_bounds` pins the two routes to identical slices."""
+    from . import _abi
+    return _abi.target_costs(call)
 
 
 def partition_targets(work: np.ndarray, world_size: int) -> np.ndarray:
