@@ -50,8 +50,9 @@ extern "C" {
                                 count).  The reference drops them before its kernel runs (similarity.py:410-415, then eliminate_zeros,
                                 s_plus.pyx:210-211); the outputs of this call still hold them as zero-valued candidates and must be discarded:
                                 the caller preprocesses on the host and calls again without SP_FLAG_P3_PREP */
-#define SP_EUNSORTED    -7   /* host mode: a row of m2 (SP_FLAG_M1_IS_M2_T / SP_FLAG_CHECK_SORTED) or of a MATRIX selector (always checked, message
-                                "MATRIX selector ...") does not have ascending column ids; nothing was computed */
+#define SP_EUNSORTED    -7   /* host mode: a row of m2 (SP_FLAG_M1_IS_M2_T / SP_FLAG_CHECK_SORTED) does not have ascending column ids; nothing was computed */
+#define SP_EUNSORTED_SELECTOR -9  /* host mode: a row of a MATRIX selector (always checked) does not have ascending column ids; nothing was computed.
+                                (A code of its own since round 6: the caller's remedy differs — sort the selector, not m2 — and must not hang on the message text) */
 
 /* flags */
 #define SP_FLAG_TIME_KERNEL   1u  /* bracket device work with hipEvents on `stream`, sync, fill kernel_ms */

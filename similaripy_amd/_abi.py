@@ -35,6 +35,7 @@ SP_FLAG_PROGRESS = 131072
 SP_EZEROS = -6
 SP_EUNDERFLOW = -8
 SP_EUNSORTED = -7
+SP_EUNSORTED_SELECTOR = -9
 SP_NORM_L1, SP_NORM_L2, SP_NORM_MAX, SP_NORM_TFIDF, SP_NORM_BM25PLUS = range(5)
 SP_TF_MODES = {'binary': 0, 'raw': 1, 'sqrt': 2, 'freq': 3, 'log': 4}       # normalization.pyx:12-17
 SP_IDF_MODES = {'unary': 0, 'base': 1, 'smooth': 2, 'prob': 3, 'bm25': 4}   # normalization.pyx:19-24
@@ -249,6 +250,11 @@ class UnsortedRowsError(HipLibraryError):
     """SP_FLAG_M1_IS_M2_T found a row of m2 whose column ids do not ascend: the caller converts on the host and calls again."""
 
 
+class UnsortedSelectorError(UnsortedRowsError):
+    """SP_EUNSORTED_SELECTOR: a row of a MATRIX selector does not have ascending column ids (a stale has_sorted_indices flag): the caller
+    verifies and sorts a copy of the SELECTOR and calls again."""
+
+
 _lib = None
 
 
@@ -355,6 +361,8 @@ def call_knn(args: SpKnnArgs) -> None:
     rc = lib.sp_knn_f32_i32(C.byref(args))
     if rc == SP_EZEROS:
         raise ExplicitZerosError(last_error())
+    if rc == SP_EUNSORTED_SELECTOR:
+        raise UnsortedSelectorError(last_error())
     if rc == SP_EUNSORTED:
         raise UnsortedRowsError(last_error())
     if rc == SP_EUNDERFLOW:

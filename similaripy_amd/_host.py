@@ -861,7 +861,7 @@ def _s_plus_impl(matrix1, matrix2, weight_depop_matrix1, weight_depop_matrix2, p
                 raise
             opts["check_zeros"] = True          # eliminate_zeros on the host (s_plus.pyx:210-211), then again
         except _abi.UnsortedRowsError as exc:
-            if "selector" in str(exc) and opts["selectors_sorted_on_device"]:
+            if isinstance(exc, _abi.UnsortedSelectorError) and opts["selectors_sorted_on_device"]:      # (its own return code: SP_EUNSORTED_SELECTOR)
                 opts["selectors_sorted_on_device"] = False   # a stale has_sorted_indices flag: the order is verified (and a copy sorted) here, then again
             elif call.m1_is_m2t and opts["csc_direct"]:
                 opts["csc_direct"] = False          # matrix1.tocsr() on the host (s_plus.pyx:205-206), then again

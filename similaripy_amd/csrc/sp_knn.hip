@@ -579,7 +579,7 @@ uint64_t prep_signature(const sp_knn_args *a, const Config &c) {
     auto mix = [&](const void *p, size_t n) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } };
 #define SP_MIX(x) mix(&(x), sizeof(x))
     const uint32_t fl = a->flags & (SP_FLAG_NO_FOLD | SP_FLAG_NO_SPARSE_PATH);
-    const int64_t abl = a->reserved[0] & (1024 | 2048 | 4096 | 16384 | 32768 | 524288);      // (items_stride follows from sizes the signature covers)
+    const int64_t abl = a->reserved[0] & (1024 | 2048 | 4096 | 16384 | 32768 | 65536 | 524288);      // (items_stride follows from sizes the signature covers)
     SP_MIX(fl); SP_MIX(abl);
     SP_MIX(a->n_rows_m2); SP_MIX(a->n_output_cols); SP_MIX(a->nnz_m2);
     SP_MIX(a->m2_data); SP_MIX(a->m2_indices); SP_MIX(a->m2_indptr);
@@ -965,6 +965,9 @@ int run_sddmm(sp_knn_args *b, const float *mt_data, const int *mt_indices, const
     const bool timed = (b->flags & SP_FLAG_TIME_KERNEL) != 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (timed) { TRY(guard.event(&ev0)); TRY(guard.event(&ev1)); HIP_TRY(hipEventRecord(ev0, stream)); }
+    // (the sampled route builds none of the per-call passes and overwrites the workspace's header — and, for an explicit m2, the blocks behind
+    // it: whatever an earlier call left there is gone, so a later SP_FLAG_REUSE_M2_PREP call on this address must not find its signature)
+    if (b->workspace) prep_store(ws, ~0ull, -1);
     HIP_TRY(hipMemsetAsync(ws, 0, 256, stream));
     if (!mt_indptr) {
         auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -1461,7 +1464,7 @@ int run_host(sp_knn_args *a) {
             hipLaunchKernelGGL(sp_rows_sorted_kernel, dim3(std::max(1, std::min(256 * 16, (mats[i].n_rows + 3) / 4))), dim3(256), 0, nullptr, mats[i].n_rows, mats[i].indptr, mats[i].indices, (unsigned int *)(st + 19));
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpy(h + 19, st + 19, sizeof(int32_t), hipMemcpyDeviceToHost));
-            if (h[19]) return fail(SP_EUNSORTED, "MATRIX selector %s: %d rows do not have ascending column ids", mats[i].what, h[19]);
+            if (h[19]) return fail(SP_EUNSORTED_SELECTOR, "MATRIX selector %s: %d rows do not have ascending column ids", mats[i].what, h[19]);
         }
     }
 

@@ -1021,9 +1021,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DUO ? 4 : 1,
                 // blocks, so NW blocks of the pool are slack.  (An overflow is not an error: the row goes to the generic queue.)
                 int stage_items = chunk_items;
                 if constexpr (DUO) {
+                    // Every wave sizes the stage from the pool counters it reads itself (here, and `chunk_items` at the end of the stage before):
+                    // they must all have read them before any wave's sweep pushes again.  With ONE workgroup per CU the waves leave the
+                    // barrier in front of those reads together and the first push is a memory round trip away; with two, the other
+                    // workgroup's sweep bodies run at raised priority and can hold a wave of this one back for longer than that — one wave
+                    // then cut the stage elsewhere than its siblings (found by the full-size test: one row in 10^6 with a product counted twice).
+                    const int m_seen = min(sh[SH_MCTR], mpcap);
+                    wg_sync<U_LDS>();
                     const float fm = (float)n_marks * (1.f / (float)(8 * DUO_PLANE_BYTES));      // marked share of a plane's bits
                     const float per_item = 1.25f * ((float)ITEM * fm * fm + 2.f * (float)n_marks * __builtin_amdgcn_rcpf((float)max(1, n_items))) + 2.f;
-                    const int room_m = (mpcap - NW * POOL_BLK) - min(sh[SH_MCTR], mpcap);
+                    const int room_m = (mpcap - NW * POOL_BLK) - m_seen;
                     stage_items = min(stage_items, max(1, (int)((float)room_m * __builtin_amdgcn_rcpf(per_item))));
                     stage_items = __builtin_amdgcn_readfirstlane(stage_items);
                 }

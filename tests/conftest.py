@@ -108,7 +108,7 @@ def oracle_backend(monkeypatch):
         for mode, ip, ix in ((call.filter_mode, call.filter_m_indptr, call.filter_m_indices), (call.target_col_mode, call.target_col_m_indptr, call.target_col_m_indices)):
             # run_host looks at the order inside the rows of every MATRIX selector (sp_rows_sorted_kernel)
             if mode == _host.MODE_MATRIX and ix.shape[0] > 1 and not _host._rows_sorted(ix, ip):
-                raise _abi.UnsortedRowsError("MATRIX selector: rows do not have ascending column ids")
+                raise _abi.UnsortedSelectorError("MATRIX selector: rows do not have ascending column ids")
         if call.check_m2_sorted:
             # SP_FLAG_CHECK_SORTED: a descent inside a row of the explicit m2 goes back to the caller
             if call.m2_indices.shape[0] > 1 and not _host._rows_sorted(call.m2_indices, call.m2_indptr):

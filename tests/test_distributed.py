@@ -43,6 +43,42 @@ def test_partition_is_contiguous_and_work_balanced():
     assert D.partition_targets(np.zeros(0), 4).tolist() == [0, 0, 0, 0, 0]
 
 
+def test_both_routes_cut_the_same_bounds():
+    """ONE partition cost model.  `distributed.row_cost` IS the library's (`sp_knn_target_costs`), so the slices the
+    one-process-per-GPU route cuts (`partition_targets(row_cost(call), N)`) are the slices the in-library route (`n_devices = N`,
+    `sp_knn_partition`) cuts — on a ratings-shaped item-item call (the configs[3] stand-in at a tenth of its size: skewed rows, heavy
+    rows that the launch cuts into pieces and the model prices by their entries), host-built and device-built m2 alike."""
+    from similaripy_amd import _abi
+    from similaripy_amd.workloads import movielens_like_urm
+    urm = movielens_like_urm(30_000, 40_000, 3_000_000, seed=3)
+    m1 = sp.csr_array(urm.T.tocsr())
+    for kw in (dict(), dict(m2_on_device=True)):
+        call = _host.prepare(m1, k=50, **kw)
+        cost = D.row_cost(call)
+        macs = D.row_work(call).astype(np.float64) - 1.0
+        assert cost.shape == (call.n_targets,) and np.all(cost >= macs)
+        nnz1 = np.diff(call.m1_indptr)[call.targets]
+        # generic rows pay 3 per output column; the heaviest rows also pay per entry (the launch cuts them into pieces)
+        top = np.argsort(macs)[-5:]
+        np.testing.assert_allclose(cost[top] - macs[top] - 3.0 * call.n_output_cols, 2100.0 * nnz1[top], rtol=1e-9)
+        light = np.argsort(macs)[:5]
+        assert np.all(cost[light] - macs[light] <= 30_000.0 + 1e-6)
+        for world in (2, 4, 8):
+            np.testing.assert_array_equal(D.partition_targets(cost, world), _abi.partition(call, world))
+    # the prices are the library's: an override reaches both routes at once
+    os.environ["SIMILARIPY_AMD_HEAVY_ENTRY_MACS"] = "0"
+    try:
+        c0 = D.row_cost(call)
+        assert np.all(c0[top] - macs[top] == 3.0 * call.n_output_cols)
+        np.testing.assert_array_equal(D.partition_targets(c0, 8), _abi.partition(call, 8))
+    finally:
+        del os.environ["SIMILARIPY_AMD_HEAVY_ENTRY_MACS"]
+    with pytest.raises(_abi.HipLibraryError):
+        bad = _host.prepare(m1, k=5, target_rows=[1, 2])
+        bad.targets = np.array([1, 10 ** 6], dtype=np.int32)
+        D.row_cost(bad)
+
+
 def _worker(rank, world, port, q):
     import torch.distributed as dist
     from oracle import splus_oracle as so
