@@ -349,6 +349,23 @@ def main():
             compute_only_ms = max_over_ranks(time.perf_counter() - t1) / steps * 1e3
             res["gather_exposed_ms"] = elapsed / steps * 1e3 - compute_only_ms
             res["compute_only_ms_per_step"] = compute_only_ms
+            # END-TO-END delivery of one step's results to host memory, outside the timed region (the step's definition ends with the
+            # results resident on the root GPU; VERDICT r5 #7 asked for the cost behind it):
+            #   own_link   every rank copies its OWN slab down over its own PCIe link (ShardedDeviceProblem.own_result; the default of the
+            #              one-process entry multi_gpu.run_call since round 6) — max over ranks
+            #   via_root   the gathered slabs leave through the root's one link (ShardedDeviceProblem.result)
+            shard.run(gather=True, static_sched=args.static_sched, **tuning)
+            fence()
+            t2 = time.perf_counter()
+            shard.own_result()
+            own_ms = max_over_ranks(time.perf_counter() - t2) * 1e3
+            fence()
+            t3 = time.perf_counter()
+            if rank == 0:
+                shard.result()
+            root_ms = max_over_ranks(time.perf_counter() - t3) * 1e3
+            fence()
+            res["result_to_host_ms"] = {"own_link": own_ms, "via_root": root_ms}
         local_bytes, local_macs = algorithmic_bytes(shard.prob.call)
         mine = {"rank": rank, "device": f"cuda:{dev.index} {torch.cuda.get_device_name(dev)}", "rows": int(shard.n_loc), "macs": int(local_macs),
                 "algorithmic_bytes": int(local_bytes), "call_ms": res["call_ms"],
@@ -457,6 +474,7 @@ def main():
     }
     if world > 1:
         out["gather_exposed_ms"] = main_res.get("gather_exposed_ms")
+        out["result_to_host_ms"] = main_res.get("result_to_host_ms")      # one step's results to host memory: over every rank's own link / through the root
         out["compute_only_ms_per_step"] = main_res.get("compute_only_ms_per_step")
     if other is not None:
         out["other_scaling"] = other
@@ -517,8 +535,8 @@ def main():
                     pres["shard"] = None
                 if not args.no_cpu_baseline and r2.get("parity_sample") is not None:
                     # the same check as the headline's, on what this workload's last timed step wrote (configs[3]: float32 sums of up to 2e5 products
-                    # in another order — its bar is the per-row float64 judge of tests/test_hip_fullsize.py; here 1e-4 on the values (observed maxima: profiles/r05_c4_value_errors.txt), sets tie-aware)
-                    d["parity_check"] = cpu_baseline(c2_, 0.0, r2["parity_sample"], rtol=1e-4 if name == "c4" else 1e-5)
+                    # in another order — its bar is the per-row float64 judge of tests/test_hip_fullsize.py; here 3e-5 on the values against the reference (observed maximum 1.9e-5 on the heaviest rows: two float32 sums of 2e5 products in different orders, profiles/r06_c4_value_errors.txt), sets tie-aware)
+                    d["parity_check"] = cpu_baseline(c2_, 0.0, r2["parity_sample"], rtol=3e-5 if name == "c4" else 1e-5)
                 others[name] = d
                 log(f"other workload {name}: {d['ms_per_step']:.2f} ms/step, {d['roofline']['kernel']} {d['roofline']['kernel_ms_avg']:.2f} ms, frac {d['roofline']['frac']:.3f}")
                 r2["shard"] = None

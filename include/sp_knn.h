@@ -123,11 +123,10 @@ typedef struct sp_knn_args {
     uint32_t flags;            /* SP_FLAG_* */
     int32_t  on_device;        /* 0: every pointer below is host memory (the drop-in call: H2D, compute, D2H)
                                   1: every pointer is device memory on `device`, resident before the call; the launches are queued on
-                                     `stream` and the call returns without waiting — with ONE exception: a depopularisation-only epilogue
-                                     (l3 != 0, l1 = l2 = 0, no shrink: rp3beta) folds the column term into a copy of m2 and reads a 4-byte
-                                     flag back first (a stored entry over a zero term forces the unfolded route, s_plus.h:144-150), i.e.
-                                     such a call synchronises `stream` once and cannot be stream-captured; SP_FLAG_NO_FOLD avoids the fold
-                                     and the wait, SP_FLAG_REUSE_M2_PREP calls reuse the answer without waiting */
+                                     `stream` and the call returns without waiting (every call: the one exception of rounds 3-5 — a
+                                     depopularisation-only epilogue read a 4-byte flag back before going on — is gone since round 6, the
+                                     fold itself writes the zero the reference's zero denominator gives, s_plus.h:144-150): the call can be
+                                     stream-captured */
     int32_t  device;           /* HIP device ordinal */
 
     /* problem shape (the reference infers these from NumPy arrays it never passes down) */
@@ -196,7 +195,27 @@ typedef struct sp_knn_args {
                                   [11] generic column windows */
     int32_t num_wgs_used;      /* OUT with SP_FLAG_TIME_KERNEL */
     int32_t _pad1;
-    int64_t reserved[4];       /* [0] IN: kernel ablation bits, profiling only (0 in production)
+    int64_t reserved[4];       /* [0] IN: kernel ablation bits, profiling / tests only (0 in production) — THE table (one place):
+                                    ROUTE switches (results stay correct; tests use them to keep the other route covered):
+                                       1024  force the generic kernel's 64-bit-offset variant for every row (as nnz(m2) >= 2^30 does;
+                                             tests/test_hip_parity.py::test_generic_kernel_64bit_offset_variant)
+                                       2048  no per-call work-item prepass (rows are set up in the kernel; test_sparse_kernel_packed_trips*)
+                                       4096  heavy generic rows are NOT queued in pieces
+                                       8192  cut EVERY generic row into pieces as finely as allowed (test_generic_kernel_heavy_rows_in_pieces)
+                                      16384  no wave-per-row kernel
+                                      32768  no bounded variant: general epilogues on the general variant (test_bounded_variant_* A/B)
+                                      65536  no sampled (SDDMM) route for target_cols = <matrix> (test_target_matrix_sampled_route*,
+                                             test_repeated_targets_with_a_target_matrix_and_csr_out)
+                                     131072  generic kernel: no selection-free cutoff in front of a dense window's drain
+                                     262144  generic kernel: the drain judges in the sweep (round-4 form) instead of sorting live slots first
+                                     524288  sparse kernel: no two-per-CU (DUO) shape (scripts/c2_phases.py A/B; test_duo_shape_against_the_oracle_and_the_classic_shape)
+                                    PROFILING ablations (results are WRONG; the sweep-body ones compiled in only with -DSP_ABLATION=1):
+                                          1  generic accumulate without LDS inserts      4  no column-term gathers
+                                          8 / 16  sweep 1 / sweep 2 load but do not process      32 / 64  members / survivors dropped
+                                        128  sparse kernel: workgroups start staggered; emit_candidates: no epilogue
+                                        256  sparse kernel: a loads-only pass in front of sweep 1; generic kernel: no simple judge
+                                        512  generic kernel: no register selection; wave kernel: every trip reads the same 4 KB
+                                      32768  (wave kernel) sweep 2's id loads hit the cache
                                   [1], [2] OUT with SP_FLAG_TIME_KERNEL: duration of the sparse / generic row kernel of this
                                   call in microseconds (hipEvents on `stream` around each launch)
                                   [3] OUT with SP_FLAG_TIME_KERNEL | SP_FLAG_M2_IS_M1_T: duration of the transpose, microseconds

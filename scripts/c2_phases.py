@@ -40,7 +40,7 @@ tot = float(sum(ph[:9]))
 print("   cycles/row %.0f: " % (tot / n_t) + "  ".join(f"{n}={c / n_t:.0f}" for n, c in zip(names, ph[:9])), flush=True)
 if ph[8] & 2:      # the bounded variant ran: its counters (slot 11: selections << 32 | entries through the exact pass)
     print(f"   bounded variant: {(ph[11] & 0xFFFFFFFF) / n_t:.0f} entries through the exact pass per row, {(ph[11] >> 32) / n_t:.2f} selections per row", flush=True)
-if tun["dbg"] & ~(524288 | 1048576):
+if tun["dbg"] & ~524288:
     sys.exit(0)
 sample = np.sort(np.random.default_rng(1).choice(n_t, min(n_t, 150), replace=False)).astype(np.int32)
 c2 = copy.copy(call); c2.targets = sample

@@ -145,7 +145,7 @@ constexpr size_t LDS_LIMIT = 160 * 1024;
 //   sig        a hash of everything those passes and the workspace layout depend on — m2 / Y* pointers and sizes, every scalar
 //              parameter, k, the tuning fields, the flags that choose the layout.  A REUSE call with another signature is refused
 //              (SP_EINVAL): it would read folded values, packed terms or window boundaries laid out for other parameters.
-//   zero_term  what the zero-term check of a folding rp3beta-type call found (the REUSE call takes the same route without a read-back).
+//   zero_term  unused since round 6 (the zero-term rerun of folding rp3beta-type calls is gone, see run_device_impl); kept for the table's layout.
 // Keyed by the workspace address; an entry is rewritten by every non-REUSE call on that address, so it always describes the passes that
 // are in the workspace now.  Bounded (oldest entries go first); a REUSE call on an address the table does not know is trusted as before
 // (the header word at WS_FOLDZERO_OFFSET still answers the zero-term question: it is rewritten after the unfolded rerun).
@@ -396,15 +396,6 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
         c->wgs_wave = std::max(1, std::min(a->num_wgs > 0 ? a->num_wgs : n_cus * (int)(LDS_LIMIT / wv_lds_bytes(wv_a)), std::max(1, a->n_targets)));
     }
     c->ws_total = WS_QUEUE_BYTES + c->ws_gu_bytes + c->ws_fold_bytes + c->ws_rows_bytes + c->ws_split_bytes + c->ws_piece_bytes + c->ws_items_bytes;
-    if (c->fold && a->l3 != 0.f) {
-        // a folding rp3beta-type call may have to be redone WITHOUT folding (a zero column term under a stored entry, run_device_impl): the
-        // unfolded layout — packed column terms, or the bounded variant's packed ids — must fit the same workspace
-        sp_knn_args b = *a;
-        b.flags |= SP_FLAG_NO_FOLD;
-        Config c2{};
-        TRY(make_config(&b, n_cus, &c2));
-        c->ws_total = std::max(c->ws_total, c2.ws_total);
-    }
     if (sddmm_applies(a, a->nnz_m1, a->nnz_m2)) c->ws_total = std::max(c->ws_total, sddmm_ws_bytes(a));      // (explicit m2: the route transposes it)
     return SP_OK;
 }
@@ -640,21 +631,6 @@ int run_device_impl(sp_knn_args *a, const uint64_t *sig_override = nullptr) {
         return fail(SP_EINVAL, "SP_FLAG_REUSE_M2_PREP: m2 / Y*, a scalar parameter, k or a tuning field differs from the call that built the passes "
                                "in this workspace — drop the flag (the passes are rebuilt) or repeat that call's arguments");
     if (a->workspace && !reuse) prep_store(ws, sig, -1);
-    if (reuse && c.fold && a->l3 != 0.f) {
-        // the call whose passes are reused may have found a zero column term under a stored entry and gone on without folding
-        int z = known ? built.zero_term : -1;
-        if (z < 0) {
-            HIP_TRY(hipMemcpyAsync(&z, ws + WS_FOLDZERO_OFFSET, sizeof(int), hipMemcpyDeviceToHost, stream));
-            HIP_TRY(hipStreamSynchronize(stream));
-        }
-        if (z) {
-            const uint32_t flags0 = a->flags;
-            a->flags |= SP_FLAG_NO_FOLD;
-            const int rc2 = run_device_impl(a, &sig);
-            a->flags = flags0;
-            return rc2;
-        }
-    }
     HIP_TRY(hipMemsetAsync(ws, 0, reuse ? WS_FOLDZERO_OFFSET : WS_QUEUE_BYTES, stream));
     // header | blocks that depend on m2 and the parameters only (same offsets whatever the target list) | blocks sized by n_targets
     unsigned char *ws_fold = ws + WS_QUEUE_BYTES;
@@ -673,31 +649,17 @@ int run_device_impl(sp_knn_args *a, const uint64_t *sig_override = nullptr) {
     float4 *ypack = nullptr;
     if (c.fold) {
         folded = (float *)ws_fold;
-        // (a depopularisation weight can be exactly 0 on a column that has entries — a 'sum' weight of signed data — and the reference
-        // then reports value 0 for every column a product touches, s_plus.h:144-150: the folded stream cannot, see the kernel; the
-        // call is redone without folding.  One 4-byte read-back per rp3beta-type call; a cosine term is 0 for empty columns only)
-        const bool check_zero = a->l3 != 0.f && !reuse;
+        // (a depopularisation weight can be exactly 0 on a column that has entries — a 'sum' weight of signed data.  The reference then
+        // reports value 0 for every such column a product touches (zero denominator -> 0, s_plus.h:144-150); the fold writes 0.0 for the
+        // entries of such a column, so every product on it is 0, its sum is 0 and the epilogue's xy / den gives the same 0 — the column
+        // is touched, hence a candidate, in both.  Until round 5 the call read a 4-byte flag back here and reran WITHOUT folding when a
+        // stored entry had met a zero term: the one device-mode call that synchronised the caller's stream.  Round 6
+        // ran the parity suite, the dedicated case (test_zero_depop_weight_on_a_column_with_entries: sparse, wave and generic kernels,
+        // threshold 0 and negative) and 1 200 fuzz cases with the rerun switched off: no difference — the rerun and its wait are gone,
+        // the call is asynchronous and stream-capturable like every other)
         if (!reuse) hipLaunchKernelGGL(sp_fold_colterm_kernel, dim3(256 * 8), dim3(256), 0, stream, (long long)a->nnz_m2, a->m2_indices,
-                           a->m2_data, a->l2 != 0.f ? a->Ycosine : a->Ydepop, folded, check_zero ? (int *)(ws + WS_FOLDZERO_OFFSET) : (int *)nullptr);
+                           a->m2_data, a->l2 != 0.f ? a->Ycosine : a->Ydepop, folded, (int *)nullptr);
         HIP_TRY(hipGetLastError());
-        if (check_zero) {
-            int zero_term = 0;
-            HIP_TRY(hipMemcpyAsync(&zero_term, ws + WS_FOLDZERO_OFFSET, sizeof(int), hipMemcpyDeviceToHost, stream));
-            HIP_TRY(hipStreamSynchronize(stream));
-            if (a->workspace) prep_set_zero(ws, zero_term);
-            if (zero_term) {
-                const uint32_t flags0 = a->flags;
-                a->flags |= SP_FLAG_NO_FOLD;
-                const int rc2 = run_device_impl(a, &sig);      // (rebuilds the header: the table entry is rewritten under the caller's signature)
-                a->flags = flags0;
-                if (a->workspace && !rc2) {
-                    // the answer stays IN the workspace too: the rerun's header memset wiped it (a REUSE call the table does not know reads it)
-                    prep_set_zero(ws, 1);
-                    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(ws + WS_FOLDZERO_OFFSET), 1, 1, stream));
-                }
-                return rc2;
-            }
-        }
     } else if (c.pack) {
         ypack = (float4 *)ws_fold;
         if (!reuse) hipLaunchKernelGGL(sp_pack_colterms_kernel, dim3(std::min(2048, (a->n_output_cols + 255) / 256)), dim3(256), 0, stream, a->n_output_cols,

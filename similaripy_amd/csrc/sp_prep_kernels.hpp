@@ -678,10 +678,10 @@ __global__ __launch_bounds__(256) void sp_any_negative_kernel(long long nnz, con
 
 // Fold the column term of a product-form epilogue into the m2 stream:  out[i] = data[i] / Y[indices[i]]
 // (0 where Y is 0: the reference returns 0 for a zero denominator, s_plus.h:147-150).  One streaming pass.
-// *zero_term (optional) is raised when a STORED entry meets a zero column term: the reference then reports the column with value 0
-// (the column is a candidate as soon as one product touches it), the folded stream would lose it (all its products become 0, the
-// column looks untouched) — the caller redoes the call without folding.  Only the depopularisation term can do that (a 'sum'
-// weight of signed data that cancels to exactly 0); a cosine term is 0 for empty columns only.
+// A STORED entry over a zero column term (a 'sum' depopularisation weight of signed data that cancels to exactly 0; a cosine term is 0
+// for empty columns only): the reference reports such a column with value 0 whenever a product touches it; here every product on it is
+// 0.0, the column is touched like any other (a sum of 0.0 is not "untouched": free slots are marked otherwise in every accumulator) and
+// comes out with value 0 — the same.  *zero_term (optional) still reports that it happened (rounds 3-5 reran such calls unfolded).
 __global__ __launch_bounds__(256) void sp_fold_colterm_kernel(long long nnz, const int *__restrict__ indices,
                                                                const float *__restrict__ data, const float *__restrict__ Y,
                                                                float *__restrict__ out, int *__restrict__ zero_term) {

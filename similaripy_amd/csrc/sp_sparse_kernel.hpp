@@ -97,10 +97,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DUO ? 4 : 1,
         else atomicAnd((unsigned *)(cbm + ((c >> 3) & cmask)), ~(1u << (c & 31u)));
     };
     // stage length factor (see the chunk rule at the end of a stage: what an exchangeable stream would let into U against what is left of it;
-    // far less passes when the segments come in descending weight, the rule).  DUO: its U is half the classic one's and its selection-free
-    // first stage sees half the products — with the classic factor one row in 30 000 of configs[1] (one in 7 500 of configs[2]) overflowed
-    // U and went to the generic queue: half the factor
-    const float STAGE_FILL = (DUO && (p.dbg & 1048576)) ? 1.f : 2.f;      // (experiment switch)
+    // far less passes when the segments come in descending weight, the rule).  (Measured for the DUO shape, whose U is half the classic
+    // one's: with ONE first-stage trip per wave one row in 30 000 of configs[1] — one in 7 500 of configs[2] — overflowed U and went to the
+    // generic queue; a factor of 1 removed them and cost 6 % (one more stage and accumulate pass per row: 85.3 -> 90.3 ms); two first-stage
+    // trips per wave — the 4 096 products the classic shape's sixteen waves see — removed them at the factor of 2 for nothing.)
+    constexpr float STAGE_FILL = 2.f;
     constexpr int RANK_BYTES = DUO ? DUO_PLANE_BYTES : CBM_BYTES;      // the part of the collision bitmap whose bits have ranks
     u64 *cs = (u64 *)rA;
     const int CSN = cs_bytes / 8;

@@ -303,6 +303,7 @@ class ShardedDeviceProblem:
         self.comm_stream = torch.cuda.Stream(device=self.device) if (self.gathers and not self.host_gather) else None
         self._pending = []
         self.gather_exposed_ms = None
+        self._own_host = None      # pinned host image of this rank's slab (own_result)
 
     # ---- one step -----------------------------------------------------------------------------------------------------
     def _sub_range(self, j: int):
@@ -393,10 +394,10 @@ class ShardedDeviceProblem:
             return [(0, self.call.n_targets)]
         return sorted(self._chunk_bounds)
 
-    def run_chunk(self, lo: int, hi: int, **kw):
-        """Kernel over this rank's share of target slots [lo, hi), then the gather of that chunk's slabs."""
+    def run_chunk(self, lo: int, hi: int, gather: bool = True, **kw):
+        """Kernel over this rank's share of target slots [lo, hi), then (gather=True) the gather of that chunk's slabs."""
         if self.chunk_rows is None:
-            return self.run(**kw)
+            return self.run(gather=gather, **kw)
         b = self._chunk_bounds[(lo, hi)]
         a0, a1 = int(b[self.rank]), int(b[self.rank + 1])
         k = self.call.k
@@ -404,8 +405,47 @@ class ShardedDeviceProblem:
         if a1 > a0:
             info = self.prob.run(self.pad_cols[: (a1 - a0) * k], self.pad_vals[: (a1 - a0) * k], self.pad_cnt[: a1 - a0],
                                  targets=self.prob.t["targets"][a0:a1], **kw)
-        self.gather()
+        if gather:
+            self.gather()
         return info
+
+    def own_result(self, lo: Optional[int] = None, hi: Optional[int] = None):
+        """ROOT-FREE delivery: this rank's OWN slots of the last step — of chunk [lo, hi) in the streaming form — as
+        host arrays, copied down over the rank's own PCIe link: (first slot, one past the last, cols, values, counts).  Every rank calls
+        it; nothing passes through rank `dst` (the gathered form — `run(gather=True)` + `result()` — funnels N slabs through the root's one
+        link: 0.8 GB at configs[1], 8 GB at configs[4]).  The RCCL gather stays what leaves the results RESIDENT on one device."""
+        import torch
+
+        k = self.call.k
+        if self.chunk_rows is None:
+            a0, a1 = self.lo, self.hi
+        else:
+            b = self._chunk_bounds[(int(lo), int(hi))]
+            a0, a1 = int(b[self.rank]), int(b[self.rank + 1])
+        n = a1 - a0
+        if self._own_host is None:
+            pin = self.slab.is_cuda
+            self._own_host = torch.empty(self.slab.numel(), dtype=torch.int32, pin_memory=pin)
+        host = self._own_host
+        if self.slab.is_cuda:
+            host.copy_(self.slab, non_blocking=True)
+            torch.cuda.synchronize(self.device)
+        else:
+            host.copy_(self.slab)
+        h = host.numpy()
+        w, ns = slab_words(self.n_sub, k), self.n_sub
+        cols = np.empty(n * k, dtype=np.int32)
+        vals = np.empty(n * k, dtype=np.float32)
+        cnt = np.empty(n, dtype=np.int32)
+        for j in range(self.phases):          # (the sub-slabs of the split-phase form back into slot order)
+            s0 = min(n, j * ns)
+            s1 = min(n, s0 + ns)
+            if s1 > s0:
+                part = h[j * w: (j + 1) * w]
+                cols[s0 * k: s1 * k] = part[: (s1 - s0) * k]
+                vals[s0 * k: s1 * k] = part[ns * k: ns * k + (s1 - s0) * k].view(np.float32)
+                cnt[s0:s1] = part[2 * ns * k: 2 * ns * k + (s1 - s0)]
+        return a0, a1, cols, vals, cnt
 
     def _slabs(self):
         """Root: one (cols, values, counts)-layout slab per rank with the sub-slabs folded back into slot order."""

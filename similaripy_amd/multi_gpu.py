@@ -117,10 +117,19 @@ def _hip_runner(call: KernelCall, group, device: int, chunk_rows: Optional[int])
     chunk = n if not chunk_rows else int(chunk_rows)
     # the operands go up once; every chunk is the same resident problem with another slice of the target list
     shard = ShardedDeviceProblem(call, group=group, device=torch.device("cuda", device), chunk_rows=chunk)
+    root_free = os.environ.get("SIMILARIPY_AMD_GATHER_TO_ROOT", "0") in ("", "0")
     for lo, hi in shard.chunks():
-        shard.run_chunk(lo, hi)
-        out = shard.chunk_result(lo, hi)
-        yield (lo, hi) + tuple(out) if out is not None else None
+        if root_free:
+            # every rank brings its OWN slots to the host over its own PCIe link and hands them to the parent itself (round 6): no slab
+            # crosses xGMI only to queue at the root's one link (the RCCL gather — SIMILARIPY_AMD_GATHER_TO_ROOT=1, and what
+            # `bench.py --gpus N` times — is the form that leaves the results resident on one device)
+            shard.run_chunk(lo, hi, gather=False)
+            a0, a1, cols, vals, cnt = shard.own_result(lo, hi)
+            yield (a0, a1, cols, vals, cnt) if a1 > a0 else None
+        else:
+            shard.run_chunk(lo, hi)
+            out = shard.chunk_result(lo, hi)
+            yield (lo, hi) + tuple(out) if out is not None else None
 
 
 def _worker(rank: int, world: int, port: int, shm: str, backend: str, runner: str, devices: Sequence[int], chunk_rows: Optional[int], csr: bool):
@@ -142,7 +151,7 @@ def _worker(rank: int, world: int, port: int, shm: str, backend: str, runner: st
         run = getattr(importlib.import_module(mod), fn)
         pieces = []
         for item in run(call, None, devices[rank], chunk_rows):
-            if rank != 0 or item is None:
+            if item is None:      # (a runner that gathers yields the chunk on rank 0 only; a root-free one yields every rank's own slots)
                 continue
             lo, hi, cols, vals, counts = item
             if csr:
@@ -151,10 +160,10 @@ def _worker(rank: int, world: int, port: int, shm: str, backend: str, runner: st
                 pieces.append((lo, hi, piece.indptr.astype(np.int64), piece.indices, piece.data))
             else:
                 pieces.append((lo, hi, cols, vals, counts))
-        if rank == 0:
-            # results go back through shared-memory segments (one per array: mapped by the parent, no .npz container to write and parse)
-            with open(os.path.join(shm, "out.json"), "w") as f:
-                json.dump({"pieces": [{"lo": int(p[0]), "hi": int(p[1]), "a": _shm_put(p[2]), "b": _shm_put(p[3]), "c": _shm_put(p[4])} for p in pieces]}, f)
+        # results go back through shared-memory segments (one per array: mapped by the parent, no .npz container to write and parse);
+        # every rank hands over its own pieces
+        with open(os.path.join(shm, f"out_{rank}.json"), "w") as f:
+            json.dump({"pieces": [{"lo": int(p[0]), "hi": int(p[1]), "a": _shm_put(p[2]), "b": _shm_put(p[3]), "c": _shm_put(p[4])} for p in pieces]}, f)
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -178,8 +187,10 @@ def run_call(call: KernelCall, devices: Union[int, Sequence[int]], format_output
             s.bind(("127.0.0.1", 0))
             port = s.getsockname()[1]
         mp.spawn(_worker, args=(len(devs), port, shm, backend, runner, devs, chunk_rows, csr), nprocs=len(devs), join=True)
-        with open(os.path.join(shm, "out.json")) as f:
-            metas = json.load(f)["pieces"]
+        metas = []
+        for r in range(len(devs)):
+            with open(os.path.join(shm, f"out_{r}.json")) as f:
+                metas += json.load(f)["pieces"]
         pieces = []
         try:
             for m in metas:

@@ -210,15 +210,17 @@ def test_sharded_device_problem_nccl_world1_equals_single_call():
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("runner", ["oracle_runner", "oracle_runner_root_free"])
 @pytest.mark.parametrize("fmt,chunk", [("csr", None), ("csr", 100), ("coo", 64)])
-def test_multi_gpu_entry_spawns_ranks_and_assembles_gloo(fmt, chunk):
+def test_multi_gpu_entry_spawns_ranks_and_assembles_gloo(fmt, chunk, runner):
     """similaripy_amd.multi_gpu.run_call — the one-process entry that spawns a worker per device — over gloo with the
     oracle kernel (tests/mgpu_oracle_runner.py): shm hand-over, chunked streaming, CSR / COO assembly equal the
-    single-process result."""
+    single-process result.  Both delivery protocols: the chunk gathered on rank 0, and ROOT-FREE — every rank hands the parent its
+    own slots (what multi_gpu._hip_runner does by default since round 6: each rank's slab comes down over its own PCIe link)."""
     from oracle import splus_oracle as so
     from similaripy_amd import multi_gpu
     call = _problem()
-    res = multi_gpu.run_call(call, devices=2, format_output=fmt, chunk_rows=chunk, backend="gloo", runner="tests.mgpu_oracle_runner:oracle_runner")
+    res = multi_gpu.run_call(call, devices=2, format_output=fmt, chunk_rows=chunk, backend="gloo", runner=f"tests.mgpu_oracle_runner:{runner}")
     rows, cols, vals = so.run_kernel(call, "port", num_threads=1)
     counts = so.slot_counts(rows, cols, vals, call.targets, call.k)[0]
     want = _host.finish(call, rows, cols, vals, counts, fmt)

@@ -51,15 +51,22 @@ def _sample_with_queue_tail(macs, seed):
     return np.unique(np.concatenate((tail, rnd)))[:N_SAMPLE + N_TAIL].astype(np.int32)
 
 
-def _check_against_float64(got, want, exact, k, what, macs=None, heavy=None):
-    """Rows whose values are float32 sums of up to 10^5 products (a popular item): the HIP kernel adds them in another order than
-    the reference, so the two float32 results differ by more than 1e-5 of each other WITHOUT either being wrong.  The judge here is
-    the float64 value of every entry (`exact[i]`: a dense row): the HIP value may be no further from it than 1e-5 relative or
-    twice the reference port's own worst error in that row, whichever is larger — no tolerance formula.  Column sets: a column
-    on one side only must sit on the k-th place within the same margin (both selections are exact on their own float32 values).
-    Rows of at most 10^6 MACs get north_star's plain bar: HIP within 1e-5 relative of the float64 value AND of the reference.
-    Returns the observed maxima per row class (written to profiles/ by the caller: VERDICT r4 weak #2 — "how far from 1e-5")."""
-    stats = {c: {"rows": 0, "hip_vs_f64": 0.0, "ref_vs_f64": 0.0, "hip_vs_ref": 0.0, "set_diff_rows": 0} for c in ("heavy", "light_le_1e6_macs", "other")}
+# configs[3]'s bar, stated (DESIGN §5 "configs[3] parity" carries the same text for readers of BASELINE.md):
+#   rows of <= 10^6 MACs (94 % of the rows): north_star's own — HIP within 1e-5 relative of the float64 value AND of the reference.
+#   heavier rows: their values are float32 sums of 10^5 .. 10^6 products; the REFERENCE's float32 result is itself up to 1.4e-5 from the
+#   float64 value there (sqrt(n) * 2^-24 for n = 2e5 is 2.7e-5), so "within 1e-5 of the reference" cannot be asked of two float32 sums in
+#   different orders.  What is asked instead, as a fixed regression bound and not a formula over the reference's error: HIP within
+#   HEAVY_F64_BOUND = 1.5e-5 of the FLOAT64 value (observed over 5 020 rows of each call: profiles/r06_c4_value_errors.txt).
+#   Column sets: a column on one side only must lie within 2.5 x the row's bar of the k-th place (both selections are exact on their own
+#   float32 values, each within the bar of the float64 one).
+HEAVY_F64_BOUND = 1.5e-5
+LIGHT_MACS = 1_000_000
+
+
+def _check_against_float64(got, want, exact, k, what, macs=None, heavy=None, stats=None):
+    """`exact[i]`: the float64 dense row of sampled row i.  Returns the observed maxima per row class (written to profiles/ by the caller)."""
+    if stats is None:
+        stats = {c: {"rows": 0, "hip_vs_f64": 0.0, "ref_vs_f64": 0.0, "hip_vs_ref": 0.0, "set_diff_rows": 0} for c in ("heavy", "light_le_1e6_macs", "other")}
     for i, ((gc, gv), (wc, wv)) in enumerate(zip(got, want)):
         assert gc.shape[0] == wc.shape[0], f"{what}: slot {i}: kept {gc.shape[0]} entries, expected {wc.shape[0]}"
         if gc.shape[0] == 0:
@@ -67,8 +74,8 @@ def _check_against_float64(got, want, exact, k, what, macs=None, heavy=None):
         e = exact[i]
         ref_err = np.abs(wv.astype(np.float64) - e[wc]) / np.abs(e[wc])
         hip_err = np.abs(gv.astype(np.float64) - e[gc]) / np.abs(e[gc])
-        margin = max(RTOL, 2.0 * float(ref_err.max()))
-        light = macs is not None and macs[i] <= 1_000_000
+        light = macs is not None and macs[i] <= LIGHT_MACS
+        bar = RTOL if light else HEAVY_F64_BOUND
         cls = "heavy" if (heavy is not None and heavy[i]) else ("light_le_1e6_macs" if light else "other")
         st = stats[cls]
         st["rows"] += 1
@@ -77,19 +84,18 @@ def _check_against_float64(got, want, exact, k, what, macs=None, heavy=None):
         _, gi, wi = np.intersect1d(gc, wc, assume_unique=True, return_indices=True)
         if gi.size:
             st["hip_vs_ref"] = max(st["hip_vs_ref"], float(np.max(np.abs(gv[gi].astype(np.float64) - wv[wi]) / np.abs(wv[wi].astype(np.float64)))))
-        if light:
-            assert hip_err.max() <= RTOL, f"{what}: slot {i} ({macs[i]} MACs): HIP values up to {hip_err.max():.2e} from the float64 value (bar: 1e-5)"
-            if gi.size:
-                np.testing.assert_allclose(gv[gi], wv[wi], rtol=RTOL, atol=ATOL, err_msg=f"{what}: slot {i} ({macs[i]} MACs) vs the reference")
-        assert hip_err.max() <= margin, (f"{what}: slot {i}: HIP values up to {hip_err.max():.2e} from the float64 value, the reference port "
-                                         f"{ref_err.max():.2e}")
+        assert hip_err.max() <= bar, (f"{what}: slot {i} ({macs[i] if macs is not None else '?'} MACs): HIP values up to {hip_err.max():.2e} from the float64 value "
+                                      f"(bar {bar:.1e}; the reference port {ref_err.max():.2e})")
+        if light and gi.size:
+            np.testing.assert_allclose(gv[gi], wv[wi], rtol=RTOL, atol=ATOL, err_msg=f"{what}: slot {i} ({macs[i]} MACs) vs the reference")
         g_only, w_only = np.setdiff1d(gc, wc), np.setdiff1d(wc, gc)
         if g_only.size:
             st["set_diff_rows"] += 1
             assert gc.shape[0] == k, f"{what}: slot {i}: different columns although fewer than k were kept"
             kth = min(e[gc].min(), e[wc].min())                         # the float64 value at the k-th place
+            tie = 2.5 * max(bar, float(ref_err.max()))                  # (the reference's side of the tie carries the reference's own error)
             for c in np.concatenate((g_only, w_only)):
-                assert abs(e[c] - kth) <= 4.0 * margin * abs(kth), f"{what}: slot {i}: column {c} (value {e[c]}) is not on the k-th place tie ({kth})"
+                assert abs(e[c] - kth) <= tie * abs(kth), f"{what}: slot {i}: column {c} (value {e[c]}) is not on the k-th place tie ({kth})"
     return stats
 
 
@@ -239,13 +245,13 @@ def c4():
     a.data = np.power(a.data, 0.8)
     b = normalize(m2, norm="l1", axis=1)
     b.data = np.power(b.data, 0.8)
-    # sample: the 20 heaviest rows (most MACs: popular items, they reach nearly every column) + 300 random ones
+    # sample: the 20 heaviest rows (most MACs: popular items, they reach nearly every column) + 5 000 random ones (320 rows until round 5)
     nnz2 = np.diff(b.indptr).astype(np.int64)
     per = nnz2[a.indices]
     csum = np.concatenate(([0], np.cumsum(per)))
     macs = csum[a.indptr[1:]] - csum[a.indptr[:-1]]
     heavy = np.argsort(-macs)[:20]
-    rnd = np.random.default_rng(4).choice(m1.shape[0], 300, replace=False)
+    rnd = np.random.default_rng(4).choice(m1.shape[0], 5000, replace=False)
     sample = np.unique(np.concatenate((heavy, rnd))).astype(np.int32)
     return m1, a, b, pop_m2, sample, macs
 
@@ -272,12 +278,18 @@ def test_config3_p3_item_item_public_wrappers(c4, name):
     got = _slots_from_csr(res, sample)
     # float64 statement of the sampled rows: xy = a[t] . b[:, c]; p3alpha returns it, rp3beta divides by l3 * Xdepop[t] * Ydepop[c]
     # with the float32 column terms the kernel is handed (s_plus.h:129-156)
-    exact = (sp.csr_array(a, dtype=np.float64)[sample] @ sp.csr_array(b, dtype=np.float64)).toarray()
-    if name == "rp3beta":
-        exact = exact / (call.Xdepop.astype(np.float64)[sample, None] * call.Ydepop.astype(np.float64)[None, :])
+    # (the dense float64 judge in chunks of 256 rows: 256 x 84 432 x 8 B at a time)
+    a64, b64 = sp.csr_array(a, dtype=np.float64), sp.csr_array(b, dtype=np.float64)
     heavy_set = set(np.argsort(-macs)[:20].tolist())
-    stats = _check_against_float64(got, want, exact, k, f"C4 {name}", macs=macs[sample], heavy=[int(t) in heavy_set for t in sample])
-    # the observed maxima, for profiles/r05_c4_value_errors.txt (the GPU box merges gpurun_out/ back)
+    stats = None
+    for c0 in range(0, len(sample), 256):
+        sl = slice(c0, min(len(sample), c0 + 256))
+        exact = (a64[sample[sl]] @ b64).toarray()
+        if name == "rp3beta":
+            exact = exact / (call.Xdepop.astype(np.float64)[sample[sl], None] * call.Ydepop.astype(np.float64)[None, :])
+        stats = _check_against_float64(got[sl], want[sl], exact, k, f"C4 {name}", macs=macs[sample[sl]], heavy=[int(t) in heavy_set for t in sample[sl]], stats=stats)
+        del exact
+    # the observed maxima, for profiles/r06_c4_value_errors.txt (the GPU box merges gpurun_out/ back)
     out_dir = ROOT / "gpurun_out"
     out_dir.mkdir(exist_ok=True)
     with open(out_dir / f"c4_value_errors_{name}.txt", "w") as f:
@@ -286,8 +298,8 @@ def test_config3_p3_item_item_public_wrappers(c4, name):
         f.write("class                rows  HIP vs float64   reference vs float64   HIP vs reference   rows whose column sets differ (k-th place ties)\n")
         for cls, st in stats.items():
             f.write(f"{cls:20s} {st['rows']:4d}  {st['hip_vs_f64']:.3e}        {st['ref_vs_f64']:.3e}              {st['hip_vs_ref']:.3e}          {st['set_diff_rows']}\n")
-        f.write("bar: rows of <= 1e6 MACs: HIP within 1e-5 of the float64 value and of the reference (asserted); heavier rows: HIP no further from the "
-                "float64 value than max(1e-5, 2 x the reference's own worst error in that row)\n")
+        f.write(f"bar (asserted): rows of <= 1e6 MACs: HIP within 1e-5 of the float64 value and of the reference; heavier rows: HIP within {HEAVY_F64_BOUND:.1e} of the "
+                "float64 value (float32 sums of 1e5 .. 1e6 products: the reference itself is up to 1.4e-5 from it)\n")
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -297,6 +297,59 @@ def _info(call, **tuning):
     return _host.run_hip(call, time_kernel=True, **tuning)[4]["phase_cycles"]
 
 
+def _duo_matrix(seed=31):
+    """200 k rows x 10 k columns, 32 per row: m2 = m.T has 200 k columns and rows of ~640 entries, a row's ~20 k products collide
+    often enough to leave the three-per-CU shape (small_rows) and rarely enough for the two-per-CU one (sp_knn.hip: make_config)."""
+    from similaripy_amd.workloads import fixed_degree_csr
+    return fixed_degree_csr(200_000, 10_000, 32, seed)
+
+
+@pytest.mark.parametrize("name,kw", [("cosine", dict(l2=1)), ("dot", {}), ("rp3like", dict(l3=1, weight_depop_matrix2="sum", p2=0.6)),
+                                     ("jaccard", dict(l1=1, t1=1, t2=1)), ("splus", dict(l1=0.5, l2=0.5, stabilized_shrink=10)),
+                                     ("cosine_thr", dict(l2=1, threshold=0.12))],
+                         ids=["cosine", "dot", "rp3like", "jaccard", "splus", "cosine_thr"])
+def test_duo_shape_against_the_oracle_and_the_classic_shape(name, kw):
+    """Round 6: rows of the headline's weight run TWO 512-thread workgroups per CU (aliasing 2^19-bit sweep-1 bitmap — here exact, 200 k
+    columns —, two-plane collision bitmap, the member pool folded into the collision set between stages).  Monotone and bounded variants
+    against the oracle; the same call on the classic one-per-CU shape (ablation bit 524288) must give the same rows; twice the persistent
+    workgroups prove which shape ran."""
+    m = _duo_matrix()
+    t = np.arange(0, 200_000, 53).astype(np.int32)
+    call = _host.prepare(m, k=60, target_rows=t, **kw)
+    _check(call, "duo " + name)
+    info_d = _host.run_hip(call, time_kernel=True)[4]
+    info_c = _host.run_hip(call, time_kernel=True, dbg=524288)[4]
+    assert info_d["num_wgs"] == 2 * info_c["num_wgs"], (info_d["num_wgs"], info_c["num_wgs"])
+    pd, pc = info_d["phase_cycles"], info_c["phase_cycles"]
+    assert pd[9] + (pd[10] & 0xFFFFFFFF) == call.n_targets and (pd[10] & 0xFFFFFFFF) <= 2, (pd[9], pd[10] & 0xFFFFFFFF)
+    assert bool(pd[8] & 2) == bool(pc[8] & 2) == (name in ("jaccard", "splus"))      # the bounded variant ran where it applies
+    _check(call, "classic " + name, dbg=524288)
+
+
+def test_duo_shape_more_columns_than_bitmap_bits_and_a_matrix_filter():
+    """The aliasing case: 700 k output columns on the 2^19-bit sweep-1 bitmap (the index drops bit 5 of the column: s1_core8q), with a
+    MATRIX filter (its excluded columns are marked in BOTH planes of the collision bitmap and carry -inf pseudo members)."""
+    from similaripy_amd.workloads import fixed_degree_csr
+    m = fixed_degree_csr(700_000, 60_000, 48, 33)          # m2 = m.T: 60 k rows of ~560 entries; ~27 k products per row over 700 k columns
+    t = np.arange(0, 700_000, 211).astype(np.int32)
+    call = _host.prepare(m, k=50, l2=1, target_rows=t)
+    info = _host.run_hip(call, time_kernel=True)[4]
+    assert info["num_wgs"] == 2 * _host.run_hip(call, time_kernel=True, dbg=524288)[4]["num_wgs"]
+    _check(call, "duo aliasing cosine")
+    _check(_host.prepare(m, k=50, l1=1, t1=0.6, t2=0.4, stabilized_shrink=3, target_rows=t), "duo aliasing bounded")
+    # explicit m2 with a MATRIX filter: user scoring shaped rows heavy enough for the shape
+    rng = np.random.default_rng(34)
+    w = sp.random_array((60_000, 700_000), density=560 / 700_000, format="csr", dtype=np.float32, random_state=rng)
+    urm = fixed_degree_csr(4_000, 60_000, 48, 35)
+    flt = sp.random_array((4_000, 700_000), density=40 / 700_000, format="csr", dtype=np.float32, random_state=rng)
+    call = _host.prepare(urm, w, k=50, filter_cols=flt)
+    assert _host.run_hip(call, time_kernel=True)[4]["num_wgs"] > 256
+    rows, cols, vals, counts = _host.run_hip(call)
+    _check(call, "duo + MATRIX filter")
+    for i in range(0, 4000, 97):
+        assert not np.intersect1d(cols[i * 50:i * 50 + counts[i]], flt.indices[flt.indptr[i]:flt.indptr[i + 1]]).size
+
+
 @pytest.mark.parametrize("name,kw", [("dot", {}), ("cosine", dict(l2=1)), ("asym", dict(l2=1, c1=0.3, c2=0.7)),
                                      ("rp3like", dict(l3=1, weight_depop_matrix2="sum", p2=0.6)),
                                      ("tversky", dict(l1=1, t1=0.7, t2=0.3)), ("splus", dict(l1=0.5, l2=0.5, stabilized_shrink=5))],
@@ -407,8 +460,8 @@ def _f64_value_bounds(m, rows, kw):
 def test_zero_depop_weight_on_a_column_with_entries(shape, density, k):
     """A 'sum' depopularisation weight of signed data can cancel to exactly 0 on a column that HAS entries.  The reference then
     reports the column with value 0 whenever a product touches it (s_plus.h:112-150: candidate on first touch, zero denominator
-    -> 0).  A column term folded into the m2 stream would lose those columns (all their products become 0): the library sees
-    the zero term while folding and redoes the call without folding."""
+    -> 0).  The fold writes 0.0 for the entries of such a column: every product on it is 0, the column is touched and comes out with
+    value 0 like the reference's (rounds 3-5 reran such calls without folding, behind a read-back that synchronised the stream)."""
     rng = np.random.default_rng(7)
     m = _rand(shape, density, 7).tolil()
     zero_rows = rng.choice(shape[0], size=shape[0] // 10, replace=False)
@@ -818,6 +871,20 @@ def test_repeated_targets_with_a_target_matrix_and_csr_out():
             assert set(indices[indptr[r]:indptr[r + 1]].tolist()) <= set(listed.tolist())
         res = sim.cosine(m, k=60, target_cols=tgt, target_rows=tr, verbose=False, format_output="csr")
         assert res.nnz == want.nnz
+
+
+def test_device_mode_rp3beta_is_stream_capturable():
+    """the depopularisation-only epilogue was the one on_device = 1 call that synchronised the caller's stream (a 4-byte
+    read-back in front of the fold).  Now every launch of the call is queued: it is captured in a HIP graph and the replay reproduces the
+    eager result.  (In a child process, ONE replay: a second graph launch of ANY call of the library faults on this runtime — cosine
+    included, see scripts/graph_capture_probe.py — which must not take the test session down and is not what this test is about.)"""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    for which in ("rp3", "cos"):
+        proc = subprocess.run([sys.executable, str(root / "scripts" / "graph_capture_probe.py"), which, "once"], capture_output=True, text=True, cwd=str(root), timeout=600)
+        assert "captured" in proc.stdout and "replayed 0 ; counts equal: True" in proc.stdout, (which, proc.stdout[-400:], proc.stderr[-400:])
 
 
 def test_stored_zeros_found_on_device_and_eliminated():
