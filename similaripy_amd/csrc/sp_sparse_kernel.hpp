@@ -554,7 +554,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DUO ? 4 : 1,
                         if (lane >= sb0) { vo0 = ob0 + (lane - sb0) * 16; d0 = cb0 - 4 * (lane - sb0); }
                         if (lane >= sb1) { vo1 = ob1 + (lane - sb1) * 16; d1 = cb1 - 4 * (lane - sb1); }
                     }
-                    // lanes beyond a partial item's end get an out-of-range offset: they fetch nothing (instead of the next m2 row)
+                    // (round 6, on the two-per-CU shape, which runs at the memory system's rate: out-of-range offsets for those lanes took the
+                    // ~30 GB per launch of over-fetch away as expected — 538.8 -> 509.0 GB by the counters — and made sweep 1 slower by 14 k cycles
+                    // per row, 85.3 -> 104.7 ms: dropped again, as in round 1)
                     // (lanes beyond a partial item's end read on into the next m2 row: in sweep 1 that over-fetch is cheaper than
                     // the instructions the out-of-range trick of sweep 2 costs here — measured 14.5k -> 15.6k cycles per row at C2.
                     // Also measured and dropped, C2 cycles per row for sweep 1 / sweep 2 against 14.5k / 30.0k: requesting all the
@@ -1021,14 +1023,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DUO ? 4 : 1,
                 // repeats or shares its bit of the sweep-1 bitmap (up to two products per mark) — hence ITEM * fp + 2 * marks / items members per item; waves reserve whole
                 // blocks, so NW blocks of the pool are slack.  (An overflow is not an error: the row goes to the generic queue.)
                 int stage_items = chunk_items;
+                // Every wave sizes the stage from the pool counters it reads itself (here, and `chunk_items` at the end of the stage before):
+                // they must all have read them before any wave's sweep pushes again.  With ONE workgroup per CU the waves leave the
+                // barrier in front of those reads together and the first push is a memory round trip away; with two or three, the other
+                // workgroups' sweep bodies run at raised priority and can hold a wave of this one back for longer than that — one wave
+                // then cut the stage elsewhere than its siblings (round 6, found by the full-size test on the two-per-CU shape: one row in
+                // 10^6 with a product counted twice; the three-per-CU 256-thread shape showed it once in a fuzz case of tied values,
+                // tests/test_hip_stress.py seed 34 case 48 — not reproducible in six reruns).  Every shape that shares a CU gets the barrier.
+                const int m_seen = min(sh[SH_MCTR], mpcap);
+                if constexpr (NT < 1024) wg_sync<U_LDS>();
                 if constexpr (DUO) {
-                    // Every wave sizes the stage from the pool counters it reads itself (here, and `chunk_items` at the end of the stage before):
-                    // they must all have read them before any wave's sweep pushes again.  With ONE workgroup per CU the waves leave the
-                    // barrier in front of those reads together and the first push is a memory round trip away; with two, the other
-                    // workgroup's sweep bodies run at raised priority and can hold a wave of this one back for longer than that — one wave
-                    // then cut the stage elsewhere than its siblings (found by the full-size test: one row in 10^6 with a product counted twice).
-                    const int m_seen = min(sh[SH_MCTR], mpcap);
-                    wg_sync<U_LDS>();
                     const float fm = (float)n_marks * (1.f / (float)(8 * DUO_PLANE_BYTES));      // marked share of a plane's bits
                     const float per_item = 1.25f * ((float)ITEM * fm * fm + 2.f * (float)n_marks * __builtin_amdgcn_rcpf((float)max(1, n_items))) + 2.f;
                     const int room_m = (mpcap - NW * POOL_BLK) - m_seen;
