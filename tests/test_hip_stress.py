@@ -59,6 +59,9 @@ def _matrix(name):
             _M[name] = _rand((55193, 3850), 0.005, 1)
         elif name == "mid":
             _M[name] = _rand((40000, 2000), 0.004, 3)
+        elif name == "duo":      # 200 k output columns, ~20 k products per row: the two-per-CU shape of the sparse kernel (round 6)
+            from similaripy_amd.workloads import fixed_degree_csr
+            _M[name] = fixed_degree_csr(200_000, 10_000, 32, 31)
         else:
             _M[name] = sp.random_array((40000, 40000), density=30.0 / 40000, format="csr", dtype=np.float32, random_state=np.random.default_rng(4))
     return _M[name]
@@ -72,6 +75,10 @@ CASES = [
     ("monotone dot k=1000", "wide", dict(k=1000), ({}, {"threads_per_wg": 256})),
     ("monotone cosine + MATRIX filter", "mid", dict(k=50, l2=1.0, c1=0.5, c2=0.5, filter_cols="filter"), ({}, {"threads_per_wg": 256})),
     ("general tversky + shrink", "mid", dict(k=100, l1=1.0, t1=0.4, t2=0.7, stabilized_shrink=3.0), ({}, {"threads_per_wg": 256}, {"table_slots": 4096})),
+    # round 6: two 512-thread workgroups per CU (the race of its first build — waves sizing a stage from counters a sibling already pushed to —
+    # showed once in 10^6 rows; 100 repeats x 3 000 rows here), monotone and bounded variant; dbg 524288: the classic shape on the same rows
+    ("duo monotone cosine k=100", "duo", dict(k=100, l2=1.0, c1=0.5, c2=0.5), ({}, {"dbg": 524288})),
+    ("duo bounded splus k=60", "duo", dict(k=60, l1=0.5, l2=0.5, stabilized_shrink=10.0), ({},)),
 ]
 
 
