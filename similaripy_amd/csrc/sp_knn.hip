@@ -831,7 +831,7 @@ int run_device_impl(sp_knn_args *a, const uint64_t *sig_override = nullptr) {
         const int n_rec = c.split_pmax * a->k;
         // (up to 8192 records of 8 bytes + the kernel's own static word: more than the 64 KiB a launch gets without asking)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(sp_merge_pieces_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, n_rec * 8));
-        hipLaunchKernelGGL(sp_merge_pieces_kernel, dim3(std::min(c.split_cap, 1024)), dim3(256), (size_t)n_rec * 8, stream, (const int *)(ws + 16), c.split_cap,
+        hipLaunchKernelGGL(sp_merge_pieces_kernel, dim3(std::min(c.split_cap, 1024)), dim3(MERGE_NT), (size_t)n_rec * 8, stream, (const int *)(ws + 16), c.split_cap,
                            (const int4 *)ws_piece, a->k, a->targets, (const int *)kp.part_cols, (const float *)kp.part_vals, (const int *)kp.part_counts,
                            a->rows, a->cols, a->values, a->out_counts);
         HIP_TRY(hipGetLastError());

@@ -427,7 +427,8 @@ __global__ __launch_bounds__(256) void sp_row_items_wave_kernel(const unsigned *
 // The top-k of a split row from its pieces' results (each a top-k of its own column window, threshold applied):
 // ascending sort of the pieces' {value key, column} records in LDS, the k largest go to the row's output slot.
 // One workgroup per split row; at most split_pmax * k <= 8192 records.
-__global__ __launch_bounds__(256) void sp_merge_pieces_kernel(const int *__restrict__ split_count, int split_cap, const int4 *__restrict__ split_rows, int k,
+constexpr int MERGE_NT = 1024;      // (round 6: 256 threads took 152 us per split row — a latency chain of ~90 barrier steps, sixteen trips each)
+__global__ __launch_bounds__(MERGE_NT) void sp_merge_pieces_kernel(const int *__restrict__ split_count, int split_cap, const int4 *__restrict__ split_rows, int k,
                                                                const int *__restrict__ targets, const int *__restrict__ part_cols, const float *__restrict__ part_vals,
                                                                const int *__restrict__ part_counts, int *__restrict__ rows, int *__restrict__ cols,
                                                                float *__restrict__ values, int *__restrict__ counts) {
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(256) void sp_merge_pieces_kernel(const int *__restr
             if (tid == 0) { base = mg_n; mg_n = base + n; }
             __syncthreads();
             base = mg_n - n;
-            for (int i = tid; i < n; i += 256)
+            for (int i = tid; i < n; i += MERGE_NT)
                 mg_buf[base + i] = ((unsigned long long)fkey(part_vals[(size_t)piece * k + i]) << 32) | (unsigned long long)(unsigned)part_cols[(size_t)piece * k + i];
             __syncthreads();
         }
@@ -458,14 +459,14 @@ __global__ __launch_bounds__(256) void sp_merge_pieces_kernel(const int *__restr
             const int half = 1 << (lp - 1);
             for (int lk = 1; lk <= lp; ++lk) {
                 const int kk = 1 << lk, hk = kk >> 1;
-                for (int t = tid; t < half; t += 256) {
+                for (int t = tid; t < half; t += MERGE_NT) {
                     const int blk = t >> (lk - 1), off = t & (hk - 1);
                     const int lo = (blk << lk) + off, hi = (blk << lk) + (kk - 1 - off);
                     if (hi < n) { const unsigned long long a = mg_buf[lo], c = mg_buf[hi]; if (a > c) { mg_buf[lo] = c; mg_buf[hi] = a; } }
                 }
                 __syncthreads();
                 for (int j = kk >> 2; j > 0; j >>= 1) {
-                    for (int t = tid; t < half; t += 256) {
+                    for (int t = tid; t < half; t += MERGE_NT) {
                         const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
                         if (hi < n) { const unsigned long long a = mg_buf[lo], c = mg_buf[hi]; if (a > c) { mg_buf[lo] = c; mg_buf[hi] = a; } }
                     }
@@ -476,7 +477,7 @@ __global__ __launch_bounds__(256) void sp_merge_pieces_kernel(const int *__restr
         const int slot = sr.x;
         const int n_out = min(n, k);
         const long long o = (long long)slot * (long long)k;
-        for (int j = tid; j < k; j += 256) {
+        for (int j = tid; j < k; j += MERGE_NT) {
             int r = 0, c = 0;
             float v = 0.f;
             if (j < n_out) {
@@ -686,7 +687,26 @@ __global__ __launch_bounds__(256) void sp_fold_colterm_kernel(long long nnz, con
                                                                const float *__restrict__ data, const float *__restrict__ Y,
                                                                float *__restrict__ out, int *__restrict__ zero_term) {
     bool bad = false;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nnz; i += (long long)gridDim.x * blockDim.x) {
+    // four entries per thread and trip (16-byte loads and stores: the pass ran at 2 TB/s with one — 0.47 ms of a configs[1] step);
+    // the arrays start 16-byte aligned whenever they come from an allocator, anything else takes the scalar loop
+    long long done = 0;
+    if ((((size_t)indices | (size_t)data | (size_t)out) & 15u) == 0) {
+        const long long n4 = nnz >> 2;
+        for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+            const int4 c = ((const int4 *)indices)[i];
+            const float4 d = ((const float4 *)data)[i];
+            const float y0 = Y[c.x], y1 = Y[c.y], y2 = Y[c.z], y3 = Y[c.w];
+            float4 o;
+            o.x = (y0 != 0.f) ? d.x / y0 : 0.f;
+            o.y = (y1 != 0.f) ? d.y / y1 : 0.f;
+            o.z = (y2 != 0.f) ? d.z / y2 : 0.f;
+            o.w = (y3 != 0.f) ? d.w / y3 : 0.f;
+            ((float4 *)out)[i] = o;
+            bad |= ((y0 == 0.f) && (d.x != 0.f)) || ((y1 == 0.f) && (d.y != 0.f)) || ((y2 == 0.f) && (d.z != 0.f)) || ((y3 == 0.f) && (d.w != 0.f));
+        }
+        done = n4 << 2;
+    }
+    for (long long i = done + blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nnz; i += (long long)gridDim.x * blockDim.x) {
         const float y = Y[indices[i]];
         const float d = data[i];
         out[i] = (y != 0.f) ? d / y : 0.f;
@@ -717,15 +737,23 @@ __global__ __launch_bounds__(256) void sp_m2_splits_kernel(int n_rows, const int
     __shared__ int tile[32][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long n_tiles = ((long long)n_rows + 63) >> 6;
+    // (round 6: the pass took 0.37 ms of a 7.4 ms N = 8 slice of configs[3] — a wave walked its sixteen rows one behind the other, two dependent
+    // row-pointer loads in front of each, and divided every column id by the window width twice: the width is a power of two (2T / f) — a shift —,
+    // and the wave's seventeen row pointers come with ONE load)
+    const bool pow2 = (width & (width - 1)) == 0;
+    const int wshift = pow2 ? 31 - __builtin_clz((unsigned)max(width, 1)) : 0;
+    auto win = [&](int col) { return min(n_splits, pow2 ? (col >> wshift) : col / width); };
     for (long long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const long long ub = t * 64 + wave * 16;
+        const int my_ptr = (lane <= 16 && ub + lane <= n_rows) ? indptr[ub + lane] : 0;
         for (int q = 0; q < 16; ++q) {
             const int rt = wave * 16 + q;                      // row of the tile
-            const long long u = t * 64 + rt;
+            const long long u = ub + q;
             if (u >= n_rows) break;                            // (uniform per wave)
-            const int r0 = indptr[u], r1 = indptr[u + 1];
+            const int r0 = __builtin_amdgcn_readlane(my_ptr, q), r1 = __builtin_amdgcn_readlane(my_ptr, q + 1);
             for (int i = r0 + lane; i <= r1; i += 64) {
-                const int wprev = (i == r0) ? 0 : min(n_splits, indices[i - 1] / width);
-                const int wcur = (i == r1) ? n_splits : min(n_splits, indices[i] / width);
+                const int wprev = (i == r0) ? 0 : win(indices[i - 1]);
+                const int wcur = (i == r1) ? n_splits : win(indices[i]);
                 for (int w = wprev; w < wcur; ++w) tile[w][rt] = i;      // boundary w: the first position whose column id is >= (w + 1) * width
             }
         }
