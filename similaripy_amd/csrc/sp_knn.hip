@@ -271,21 +271,27 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
                        a->bayesian_shrink == 0.f && ((a->l2 != 0.f) != (a->l3 != 0.f)) && a->nnz_m2 > 0;
     const bool mono0 = (fold0 || !any_norm0) && a->target_col_mode != SP_SEL_MATRIX;
     bool duo = false;
+    int duo_direct = DUO_CS_DIRECT;
     const bool big0 = a->nnz_m2 >= (1LL << 30) - 1024 || (a->reserved[0] & 1024);      // (no sparse kernel runs at all, see below)
     if ((mono0 || bnd_eligible(a, mono0, fold0)) && !big0 && !(a->flags & SP_FLAG_NO_SPARSE_PATH) &&
         !a->threads_per_wg && !a->table_slots && NT_s == 1024 && !(a->reserved[0] & 524288) && (long long)a->k + 512 <= (long long)(DUO_U_BYTES / 8) &&
         a->n_output_cols > (1 << 16) && avg_macs > 0.0) {
         const double bits = (double)std::min<long long>(a->n_output_cols, 1LL << DUO_NB_LOG2);
-        duo = avg_macs * avg_macs / (2.0 * bits) <= 0.82 * (double)DUO_CS_DIRECT;
+        const double marks = avg_macs * avg_macs / (2.0 * bits);
+        duo = marks <= 0.82 * (double)DUO_CS_DIRECT_L;
+        // (T_s of this shape = the rank-addressed slots of its collision set: 2048, or — between 1.7 k and 2.9 k expected marks per row, where
+        // every row used to go to the generic kernel: 109 ms against 20 per 200 k rows of 41 k products over 400 k columns — 3584 with a
+        // member pool of 1536 entries instead of 3072)
+        duo_direct = marks <= 0.82 * (double)DUO_CS_DIRECT ? DUO_CS_DIRECT : DUO_CS_DIRECT_L;
     }
-    if (duo) { NT_s = DUO_NT; T_s = 8192; logT_s = 13; }
+    if (duo) { NT_s = DUO_NT; T_s = duo_direct; logT_s = 13; }
     const bool u_lds_s = duo || (((size_t)SEL_E * NT_s * 8 <= (size_t)T_s * 2) && ((long long)a->k + 512 <= (long long)SEL_E * NT_s));
     const long long cap_s = duo ? (long long)(DUO_U_BYTES / 8) : u_lds_s ? (long long)SEL_E * NT_s : ((need_cap + 1024) & ~1LL);
     c->T = T; c->logT = logT; c->NT = NT; c->cap = (int)cap; c->u_lds = u_lds; c->cap_s = (int)cap_s; c->u_lds_s = u_lds_s;
     c->T_s = T_s; c->logT_s = logT_s; c->NT_s = NT_s;
     c->hash_fill = std::max(1, (int)((long long)T * load / 100));
     c->lds_sparse = duo ? sp_duo_lds_bytes() : lds_fixed_sparse(T_s, NT_s);
-    c->lds_sparse_gen = lds_fixed_sparse(T_s, NT_s);
+    c->lds_sparse_gen = lds_fixed_sparse(duo ? 8192 : T_s, NT_s);
     c->duo = duo;
     c->lds_generic = lds_fixed_generic(T, NT) + (u_lds ? (size_t)cap * 8 : 0);
     auto wgs_for = [&](size_t lds, int nt) {
@@ -475,8 +481,10 @@ int launch_sparse(const KParams &kp, const Config &c, hipStream_t stream) {
             HIP_TRY(hipGetLastError());
             if (c.bnd) {
                 auto kg = sp_knn_sparse_kernel<DUO_NT, true, 0>;
+                KParams kpg = kp;      // (the classic layout reads its region size from T: 64 KB = the 2^19-bit bitmap; the DUO kernel keeps its slot count there)
+                kpg.T = 8192; kpg.logT = 13;
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds_sparse_gen));
-                hipLaunchKernelGGL(kg, dim3(std::max(1, c.wgs_sparse / 2)), dim3(NT), c.lds_sparse_gen, stream, kp);
+                hipLaunchKernelGGL(kg, dim3(std::max(1, c.wgs_sparse / 2)), dim3(NT), c.lds_sparse_gen, stream, kpg);
                 HIP_TRY(hipGetLastError());
             }
             return SP_OK;
@@ -750,7 +758,7 @@ int run_device_impl(sp_knn_args *a, const uint64_t *sig_override = nullptr) {
         ClassifyParams cp;
         cp.sparse_path = kp.sparse_path;
         cp.n_cols = a->n_output_cols; cp.T = c.T; cp.nb_log2 = c.nb_log2;
-        cp.cs_slots = c.duo ? 2 * DUO_CS_DIRECT : c.T_s / 4;      // (the rule counts the rank-addressed slots as half of the set)
+        cp.cs_slots = c.duo ? 2 * c.T_s : c.T_s / 4;      // (the rule counts the rank-addressed slots as half of the set)
         cp.duo = c.duo ? 1 : 0;
         cp.wave = c.wave ? 1 : 0;
         cp.wave_macs_max = 10000u;

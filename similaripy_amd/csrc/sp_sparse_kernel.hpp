@@ -76,9 +76,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DUO ? 4 : 1,
     int *sh = hist4 + 1024;
     u64 *ph = (u64 *)(sh + 32);
     int *shx = (int *)(ph + PH_N);      // two more scalars (the phase-timer area has 16 slots, PH_N are in use)
-    const int cs_bytes = DUO ? DUO_CS_BYTES : A_bytes / 4;
-    const int mp_rel = DUO ? DUO_CS_BYTES : A_bytes / 2;                       // member pool, relative to region A
-    const int u_rel = DUO ? DUO_CS_BYTES + DUO_MP_BYTES : (A_bytes / 4) * 3;   // candidate buffer U
+    // (DUO: p.T carries the rank-addressed slots of the collision set — 2048, or 3584 for rows with more expected marks, the member pool
+    // shrinking accordingly: sp_knn.hip make_config)
+    const int cs_bytes = DUO ? (p.T + DUO_CS_OVER) * 8 : A_bytes / 4;
+    const int mp_rel = DUO ? cs_bytes : A_bytes / 2;                           // member pool, relative to region A
+    const int u_rel = DUO ? DUO_A_BYTES - DUO_U_BYTES : (A_bytes / 4) * 3;     // candidate buffer U
     u64 *U = U_LDS ? (u64 *)(rA + u_rel) : (p.gU + (size_t)blockIdx.x * (size_t)p.cap_s);
     const int cap = p.cap_s;
 
@@ -106,13 +108,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DUO ? 4 : 1,
     u64 *cs = (u64 *)rA;
     const int CSN = cs_bytes / 8;
     // slots [0, CS_DIR) are addressed by rank; a column that finds its rank slot taken by another probes the CS_OVR slots behind them
-    const int CS_DIR = DUO ? DUO_CS_DIRECT : CSN / 2, CS_OVR = DUO ? DUO_CS_OVER : CSN / 2;
+    const int CS_DIR = DUO ? p.T : CSN / 2, CS_OVR = DUO ? DUO_CS_OVER : CSN / 2;
     const int cs_shift = 32 - (DUO ? 9 : p.logT - 3);                          // 32 - log2(CS_OVR): the hash of a first overflow probe
     static_assert(DUO_CS_OVER == 512, "log2 above");
     u64 *spool = (u64 *)(rA + A_bytes / 4);      // surviving single products of a stage (general variant only)
     const int spcap = A_bytes / 32;
     u64 *mpool = (u64 *)(rA + mp_rel);           // products of marked columns, all stages
-    const int mpcap = DUO ? DUO_MP_BYTES / 8 : A_bytes / 32;
+    const int mpcap = DUO ? (u_rel - cs_bytes) / 8 : A_bytes / 32;
     // LDS byte addresses for the hand-written cores (they assume the dynamic LDS segment starts at address 0)
     const unsigned mpool_off = (unsigned)(CBM_BYTES + PRE_BYTES + mp_rel);
     const unsigned spool_off = (unsigned)(CBM_BYTES + PRE_BYTES + A_bytes / 4);

@@ -326,6 +326,20 @@ def test_duo_shape_against_the_oracle_and_the_classic_shape(name, kw):
     _check(call, "classic " + name, dbg=524288)
 
 
+def test_duo_shape_with_the_larger_collision_set():
+    """Between ~1.7 k and ~2.9 k expected marked columns per row the two-per-CU shape runs with 3584 rank-addressed slots and a member pool
+    of 1536 entries (several folds per row); before round 6 such rows — 41 k products over 300 k columns here — all went to the generic kernel."""
+    from similaripy_amd.workloads import fixed_degree_csr
+    m = fixed_degree_csr(300_000, 30_000, 64, 41)
+    t = np.arange(0, 300_000, 101).astype(np.int32)
+    for kw in (dict(l2=1), dict(l1=0.5, l2=0.5, stabilized_shrink=10), dict(l2=1, threshold=0.1)):
+        call = _host.prepare(m, k=80, target_rows=t, **kw)
+        info = _host.run_hip(call, time_kernel=True)[4]
+        pc = info["phase_cycles"]
+        assert info["num_wgs"] == 512 and pc[9] >= 0.99 * call.n_targets, (info["num_wgs"], pc[9], pc[10] & 0xFFFFFFFF)
+        _check(call, f"duo, larger collision set {kw}")
+
+
 def test_duo_shape_more_columns_than_bitmap_bits_and_a_matrix_filter():
     """The aliasing case: 700 k output columns on the 2^19-bit sweep-1 bitmap (the index drops bit 5 of the column: s1_core8q), with a
     MATRIX filter (its excluded columns are marked in BOTH planes of the collision bitmap and carry -inf pseudo members)."""
