@@ -483,7 +483,8 @@ constexpr int PRE_BYTES = 4096;   // per-word exclusive popcount prefix of the c
 //   cbm 8 KB | [rank prefix 4 KB | collision set 20 KB | member pool 24 KB | U 16 KB] = the 64 KB (2^19-bit) sweep-1 bitmap | items 3 840 B | histograms 4 KB | scalars 256 B
 constexpr int DUO_NT = 512;
 constexpr int DUO_CS_DIRECT = 2048;                         // collision-set slots addressed by the rank of a column's mark (a C2 row: ~1 600 marks)
-constexpr int DUO_CS_DIRECT_L = 3584;                       // ... for calls whose average row expects more marks than that (the member pool gives the 12 KB: 1536 entries, more passes)
+constexpr int DUO_CS_DIRECT_L = 3072, DUO_CS_OVER_L = 1024, DUO_U_ENTRIES_L = 1536;      // ... for calls whose average row expects more marks than that: 32 KB of
+                                                            // collision set (the overflow area doubles with the marks: at 82 % full it probes forever), 12 KB of U, a member pool of 2048 entries
 constexpr int DUO_CS_OVER = 512;                            // ... and for columns that share a mark or a first-plane bit (~150 per C2 row)
 constexpr int DUO_CS_BYTES = (DUO_CS_DIRECT + DUO_CS_OVER) * 8;     // 20 KB
 constexpr int DUO_U_BYTES = 16384;                          // candidate buffer: 2048 entries = SEL_E * DUO_NT, what the register-resident selection handles

@@ -278,15 +278,15 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
         a->n_output_cols > (1 << 16) && avg_macs > 0.0) {
         const double bits = (double)std::min<long long>(a->n_output_cols, 1LL << DUO_NB_LOG2);
         const double marks = avg_macs * avg_macs / (2.0 * bits);
-        duo = marks <= 0.82 * (double)DUO_CS_DIRECT_L;
-        // (T_s of this shape = the rank-addressed slots of its collision set: 2048, or — between 1.7 k and 2.9 k expected marks per row, where
-        // every row used to go to the generic kernel: 109 ms against 20 per 200 k rows of 41 k products over 400 k columns — 3584 with a
-        // member pool of 1536 entries instead of 3072)
+        duo = marks <= 0.82 * (double)DUO_CS_DIRECT || (marks <= 0.82 * (double)DUO_CS_DIRECT_L && (long long)a->k + 512 <= (long long)DUO_U_ENTRIES_L);
+        // (T_s of this shape = the rank-addressed slots of its collision set: 2048, or — between 1.7 k and 2.5 k expected marks per row, where
+        // every row used to go to the generic kernel: 109 ms against 21.6 per 200 k rows of 41 k products over 400 k columns — 3072 with 1024
+        // overflow slots, a member pool of 2048 entries instead of 3072 and 1536 entries of U instead of 2048)
         duo_direct = marks <= 0.82 * (double)DUO_CS_DIRECT ? DUO_CS_DIRECT : DUO_CS_DIRECT_L;
     }
-    if (duo) { NT_s = DUO_NT; T_s = duo_direct; logT_s = 13; }
+    if (duo) { NT_s = DUO_NT; T_s = duo_direct; logT_s = 13; }      // (logT_s = 13: the 2^19-bit bitmap; the kernel's own logT is set where its parameters are filled)
     const bool u_lds_s = duo || (((size_t)SEL_E * NT_s * 8 <= (size_t)T_s * 2) && ((long long)a->k + 512 <= (long long)SEL_E * NT_s));
-    const long long cap_s = duo ? (long long)(DUO_U_BYTES / 8) : u_lds_s ? (long long)SEL_E * NT_s : ((need_cap + 1024) & ~1LL);
+    const long long cap_s = duo ? (long long)(duo_direct == DUO_CS_DIRECT ? DUO_U_BYTES / 8 : DUO_U_ENTRIES_L) : u_lds_s ? (long long)SEL_E * NT_s : ((need_cap + 1024) & ~1LL);
     c->T = T; c->logT = logT; c->NT = NT; c->cap = (int)cap; c->u_lds = u_lds; c->cap_s = (int)cap_s; c->u_lds_s = u_lds_s;
     c->T_s = T_s; c->logT_s = logT_s; c->NT_s = NT_s;
     c->hash_fill = std::max(1, (int)((long long)T * load / 100));
@@ -832,7 +832,8 @@ int run_device_impl(sp_knn_args *a, const uint64_t *sig_override = nullptr) {
     hipEvent_t kev[4] = {nullptr, nullptr, nullptr, nullptr};
     if (timed) { for (int i = 0; i < 4; ++i) TRY(guard.event(&kev[i])); }
     KParams kp_s = kp;
-    kp_s.T = c.T_s; kp_s.logT = c.logT_s;
+    kp_s.T = c.T_s; kp_s.logT = c.duo ? (c.T_s == DUO_CS_DIRECT ? 9 : 10) : c.logT_s;      // (DUO: log2 of the collision set's overflow slots — 512 / 1024)
+    static_assert(DUO_CS_OVER == 512 && DUO_CS_OVER_L == 1024, "log2 above");
     rc = launch_rows(kp_s, kp, c, stream, timed ? kev : nullptr, c.n_splits ? &sl : nullptr);
     if (rc) return rc;
     if (c.split_pmax) {

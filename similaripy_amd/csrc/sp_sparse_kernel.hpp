@@ -76,11 +76,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DUO ? 4 : 1,
     int *sh = hist4 + 1024;
     u64 *ph = (u64 *)(sh + 32);
     int *shx = (int *)(ph + PH_N);      // two more scalars (the phase-timer area has 16 slots, PH_N are in use)
-    // (DUO: p.T carries the rank-addressed slots of the collision set — 2048, or 3584 for rows with more expected marks, the member pool
-    // shrinking accordingly: sp_knn.hip make_config)
-    const int cs_bytes = DUO ? (p.T + DUO_CS_OVER) * 8 : A_bytes / 4;
+    // (DUO: p.T carries the rank-addressed slots of the collision set, p.logT the log2 of its overflow slots, p.cap_s the entries of U —
+    // 2048 + 512 | 3072-entry pool | 2048, or, for calls whose rows expect more marks, 3072 + 1024 | 2048-entry pool | 1536: sp_knn.hip make_config)
+    const int cs_bytes = DUO ? (p.T + (1 << p.logT)) * 8 : A_bytes / 4;
     const int mp_rel = DUO ? cs_bytes : A_bytes / 2;                           // member pool, relative to region A
-    const int u_rel = DUO ? DUO_A_BYTES - DUO_U_BYTES : (A_bytes / 4) * 3;     // candidate buffer U
+    const int u_rel = DUO ? DUO_A_BYTES - p.cap_s * 8 : (A_bytes / 4) * 3;     // candidate buffer U
     u64 *U = U_LDS ? (u64 *)(rA + u_rel) : (p.gU + (size_t)blockIdx.x * (size_t)p.cap_s);
     const int cap = p.cap_s;
 
@@ -108,9 +108,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DUO ? 4 : 1,
     u64 *cs = (u64 *)rA;
     const int CSN = cs_bytes / 8;
     // slots [0, CS_DIR) are addressed by rank; a column that finds its rank slot taken by another probes the CS_OVR slots behind them
-    const int CS_DIR = DUO ? p.T : CSN / 2, CS_OVR = DUO ? DUO_CS_OVER : CSN / 2;
-    const int cs_shift = 32 - (DUO ? 9 : p.logT - 3);                          // 32 - log2(CS_OVR): the hash of a first overflow probe
-    static_assert(DUO_CS_OVER == 512, "log2 above");
+    const int CS_DIR = DUO ? p.T : CSN / 2, CS_OVR = DUO ? (1 << p.logT) : CSN / 2;
+    const int cs_shift = 32 - (DUO ? p.logT : p.logT - 3);                     // 32 - log2(CS_OVR): the hash of a first overflow probe
     u64 *spool = (u64 *)(rA + A_bytes / 4);      // surviving single products of a stage (general variant only)
     const int spcap = A_bytes / 32;
     u64 *mpool = (u64 *)(rA + mp_rel);           // products of marked columns, all stages

@@ -327,11 +327,12 @@ def test_duo_shape_against_the_oracle_and_the_classic_shape(name, kw):
 
 
 def test_duo_shape_with_the_larger_collision_set():
-    """Between ~1.7 k and ~2.9 k expected marked columns per row the two-per-CU shape runs with 3584 rank-addressed slots and a member pool
-    of 1536 entries (several folds per row); before round 6 such rows — 41 k products over 300 k columns here — all went to the generic kernel."""
+    """Between ~1.7 k and ~2.5 k expected marked columns per row the two-per-CU shape runs with 3072 + 1024 collision-set slots, a member pool
+    of 2048 entries (several folds per row) and 1536 entries of U; before round 6 such rows — 41 k products over 350 k columns here — all went
+    to the generic kernel."""
     from similaripy_amd.workloads import fixed_degree_csr
-    m = fixed_degree_csr(300_000, 30_000, 64, 41)
-    t = np.arange(0, 300_000, 101).astype(np.int32)
+    m = fixed_degree_csr(350_000, 35_000, 64, 41)
+    t = np.arange(0, 350_000, 101).astype(np.int32)
     for kw in (dict(l2=1), dict(l1=0.5, l2=0.5, stabilized_shrink=10), dict(l2=1, threshold=0.1)):
         call = _host.prepare(m, k=80, target_rows=t, **kw)
         info = _host.run_hip(call, time_kernel=True)[4]
