@@ -407,6 +407,9 @@ def test_bench_self_launch_two_ranks_over_gloo_on_one_gpu():
     per = out["config"]["per_rank"]
     assert len(per) == 2 and all(p["rows"] > 0 for p in per) and sum(p["rows"] for p in per) == 60000
     assert out.get("gather_exposed_ms") is not None and out["value"] > 0
+    # one step's results to HOST memory, both ways (round 6): over every rank's own link, and through the root
+    r2h = out["result_to_host_ms"]
+    assert r2h["own_link"] > 0 and r2h["via_root"] > 0
     # every world size times the same work: the per-call passes over m2 are redone by every step
     assert out["config"]["persist_prep"] is False and out["config"]["m2_prep"] == "every step"
     assert out["other_scaling"]["scaling"] == "weak" and out["other_scaling"]["value"] > 0
