@@ -24,6 +24,7 @@ def _parser():
     ap.add_argument("--tuning", default="", help="with --only: override the case's tuning, e.g. table_slots=2048,no_sparse_path=1")
     ap.add_argument("--dbg", type=int, default=0)
     ap.add_argument("--huge", action="store_true", help="add shapes with more than 2^18 output columns (changes the case sequence of a seed)")
+    ap.add_argument("--duo", action="store_true", help="add shapes whose rows have the headline's weight — 15 k to 40 k products over 4e5 .. 1.5e6 columns: the two-per-CU shape of the sparse kernel (changes the case sequence of a seed)")
     ap.add_argument("--max-macs", type=float, default=4e8, help="skip cases whose oracle run would take too long")
     return ap
 
@@ -58,26 +59,34 @@ def rand_matrix(n_rows, n_cols, density, kind):
 
 
 def one_case(i):
-    shape_kind = rng.choice(["small", "wide_out", "tall", "dense_rows", "huge_out"] if a.huge else ["small", "wide_out", "tall", "dense_rows"])
+    kinds = ["small", "wide_out", "tall", "dense_rows"] + (["huge_out"] if a.huge else []) + (["duo_out", "duo_out"] if getattr(a, "duo", False) else [])
+    shape_kind = rng.choice(kinds)
     if shape_kind == "small":
         n_rows, n_cols, dens = int(rng.integers(1, 400)), int(rng.integers(1, 300)), float(rng.choice([0.02, 0.1, 0.4]))
     elif shape_kind == "wide_out":          # m2 = m.T has many columns: the sparse kernel
         n_rows, n_cols, dens = int(rng.integers(20000, 60000)), int(rng.integers(500, 4000)), float(rng.choice([0.002, 0.005, 0.01]))
     elif shape_kind == "huge_out":          # explicit m2 with more than 2^18 columns: the aliasing bitmap of the small shape
         n_rows, n_cols, dens = int(rng.integers(3000, 8000)), int(rng.integers(300, 800)), float(rng.choice([0.01, 0.03]))
+    elif shape_kind == "duo_out":           # explicit m2 with 4e5 .. 1.5e6 columns and rows of 300 .. 700 entries: 15 k .. 40 k products per target row
+        n_rows, n_cols = int(rng.integers(1500, 4000)), int(rng.integers(2000, 4000))
+        dens = float(rng.integers(40, 65)) / n_cols
     elif shape_kind == "tall":
         n_rows, n_cols, dens = int(rng.integers(3000, 9000)), int(rng.integers(50, 400)), float(rng.choice([0.02, 0.08]))
     else:
         n_rows, n_cols, dens = int(rng.integers(200, 1500)), int(rng.integers(2000, 8000)), float(rng.choice([0.02, 0.05]))
     kind = str(rng.choice(["plain", "plain", "binary", "quant", "signed", "skewed"]))
     m = rand_matrix(n_rows, n_cols, dens, kind)
-    explicit_m2 = rng.random() < 0.3 or shape_kind == "huge_out"
+    explicit_m2 = rng.random() < 0.3 or shape_kind in ("huge_out", "duo_out")
     m2 = None
     if explicit_m2:
         nc2 = int(rng.integers(1, 5000)) if shape_kind != "wide_out" else int(rng.integers(20000, 50000))
         if shape_kind == "huge_out":
             nc2 = int(rng.integers(300_000, 900_000))
-        m2 = rand_matrix(n_cols, nc2, (float(rng.choice([0.00005, 0.0002, 0.0005])) if nc2 > 100_000 else float(rng.choice([0.002, 0.01, 0.05]))) if nc2 > 1000 else 0.1, str(rng.choice(["plain", "signed", "quant"])))
+        if shape_kind == "duo_out":
+            nc2 = int(rng.integers(400_000, 1_500_000))
+            m2 = rand_matrix(n_cols, nc2, float(rng.integers(300, 700)) / nc2, str(rng.choice(["plain", "plain", "signed", "quant"])))
+        else:
+          m2 = rand_matrix(n_cols, nc2, (float(rng.choice([0.00005, 0.0002, 0.0005])) if nc2 > 100_000 else float(rng.choice([0.002, 0.01, 0.05]))) if nc2 > 1000 else 0.1, str(rng.choice(["plain", "signed", "quant"])))
     n_out = m.shape[0] if m2 is None else m2.shape[1]
     fam = str(rng.choice(["dot", "cosine", "asym", "tversky", "jaccard", "dice", "splus", "depop", "rp3like"]))
     kw = {}
@@ -100,9 +109,11 @@ def one_case(i):
         kw.pop("threshold", None)          # (binary data: values sit on round thresholds, see above)
     k = int(rng.choice([1, 5, 10, 50, 100, 200, 1000]))
     n_t = int(min(m.shape[0], rng.choice([m.shape[0], 50, 300, 1500])))
+    if shape_kind == "duo_out":
+        n_t = min(n_t, 600)                 # (bounds the oracle: 600 rows x 40 k products)
     targets = None if n_t == m.shape[0] and rng.random() < 0.5 else np.sort(rng.choice(m.shape[0], size=n_t, replace=False)).astype(np.int32)
     sel = rng.random()
-    if shape_kind == "huge_out" and sel >= 0.2:
+    if shape_kind in ("huge_out", "duo_out") and sel >= 0.2:
         sel = 1.0            # (no MATRIX selectors over ~1e6 columns x ~1e4 rows here)
     if sel < 0.12: kw["filter_cols"] = rng.choice(n_out, size=max(1, n_out // 7), replace=False).tolist()
     elif sel < 0.2: kw["target_cols"] = rng.choice(n_out, size=max(1, n_out // 3), replace=False).tolist()
@@ -250,7 +261,7 @@ def run_seed(seed, cases, verbose=True, **opts):
 def main():
     o = _parser().parse_args()
     t0 = time.time()
-    stats, _ = run_seed(o.seed, o.cases, only=o.only, dump_slot=o.dump_slot, tuning=o.tuning, dbg=o.dbg, huge=o.huge, max_macs=o.max_macs)
+    stats, _ = run_seed(o.seed, o.cases, only=o.only, dump_slot=o.dump_slot, tuning=o.tuning, dbg=o.dbg, huge=o.huge, duo=o.duo, max_macs=o.max_macs)
     print(f"fuzz: {stats} in {time.time() - t0:.0f}s (seed {o.seed})")
     sys.exit(1 if stats["failed"] else 0)
 

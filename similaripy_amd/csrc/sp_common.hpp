@@ -44,12 +44,13 @@ enum { PH_SETUP = 0, PH_SEGMENTS, PH_ACCUM, PH_DRAIN, PH_SELECT, PH_OUTPUT, PH_S
 // r_cos = l2*Xcos[t], r_dep = l3*Xdep[t]) and lam = min_j r_j / rho_j the column part of the denominator obeys
 //     sum_j r_j*Y_j[c]  >=  lam*W[c] + sum_j (r_j - lam*rho_j)*ymin_j,
 // and W[c] travels with the column id: code(c) = (bits(W[c]) >> 19) - 1 — exponent and four mantissa bits, one quantum down — sits in
-// bits 20..31 of every m2 index (n_cols < 2^20), decoded by ONE shift:  as_float(id >> 1)  <= W[c]  (the id's own bits land below the
+// bits 20..31 of every m2 index (n_cols <= 2^20; 21 / 22 id bits and a shorter code up to 2^22 columns, round 6), decoded by ONE shift:  as_float(id >> 1)  <= W[c]  (the id's own bits land below the
 // code and add less than the quantum the code was lowered by; the sign bit comes out 0).  The bound is 6 % below W on average, 12.5 % at
 // worst.  (Round 5 first carried an adaptive 12-bit code — up to ten mantissa bits, decoded with a shift and an add of per-call
 // constants: two more scalar registers and one more instruction per product in the sweep cost more than the tighter bound returned.)
-constexpr int BND_ID_BITS = 20;
-constexpr unsigned BND_ID_MASK = (1u << BND_ID_BITS) - 1u;
+constexpr int BND_ID_BITS = 20;          // ... at least: a call with more output columns takes 21 or 22 (round 6) and gives the code's last mantissa bits up
+constexpr int BND_ID_BITS_MAX = 22;      //     — the decode is the same shift: code(c) = (bits(W[c]) >> (id_bits - 1)) - 1 sits at bit id_bits, as_float(id >> 1) <= W[c]
+__host__ __device__ constexpr int bnd_id_bits(long long n_cols) { return n_cols <= (1LL << 20) ? 20 : n_cols <= (1LL << 21) ? 21 : 22; }
 struct BndInfo {
     int state;             // 1 = usable; anything else: the call runs on the general variant (MODE 0)
     float rho_tv, rho_cos, rho_dep;      // 0 = the term is not part of W (not live, or no usable reference)
@@ -63,7 +64,7 @@ __device__ __forceinline__ float bnd_w(float rtv, float ytv, float rcos, float y
 }
 // decode: a lower bound of W[c] from a packed id
 __device__ __forceinline__ float bnd_decode(unsigned packed) { return __uint_as_float(packed >> 1); }
-constexpr int BND_CODE_SHIFT = 19;      // code = (bits(W) >> 19) - 1, in [1, 4078]
+// (code = (bits(W) >> (id_bits - 1)) - 1: with 20-bit ids exponent and four mantissa bits, in [1, 4078])
 // can a candidate with raw dot x on packed column c still matter?  (nKw = -Kw, see the kernel's set_bnd_cut)
 __device__ __forceinline__ bool bnd_alive(unsigned packed, float x, float nKw, float Q) {
     return !(__builtin_fmaf(bnd_decode(packed), nKw, x) <= Q);
@@ -124,6 +125,7 @@ struct KParams {
     // combined term W[c] in bits 20..31 (per-call pass), the same packed id per column, and the call's BndInfo
     const unsigned *m2_packed;     // [nnz(m2)]
     const unsigned *colpack;       // [n_cols]
+    unsigned bnd_id_mask;          // (1 << id bits of this call) - 1: the column of a packed id
     const struct BndInfo *bnd;     // device memory (workspace header)
     unsigned long long *phase_cycles;  // optional [PH_N]
     int dbg;               // ablation bits for profiling only (results are WRONG when non-zero; 8 / 16: sweep 1 / sweep 2 of the sparse kernel

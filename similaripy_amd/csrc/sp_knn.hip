@@ -218,7 +218,7 @@ bool bnd_eligible(const sp_knn_args *a, bool mono, bool fold) {
     const bool nonneg = a->l1 >= 0.f && a->l2 >= 0.f && a->l3 >= 0.f && a->t1 >= 0.f && a->t2 >= 0.f && a->stabilized_shrink >= 0.f;
     return !mono && !fold && live && nonneg && a->a1 == 1.f && a->bayesian_shrink == 0.f && !(a->l1 * (1.f - a->t1 - a->t2) > 0.f) &&
            a->threshold >= 0.f && a->target_col_mode != SP_SEL_MATRIX &&
-           a->n_output_cols > 0 && (long long)a->n_output_cols < (1LL << BND_ID_BITS) && a->nnz_m2 > 0 &&
+           a->n_output_cols > 0 && (long long)a->n_output_cols <= (1LL << BND_ID_BITS_MAX) && a->nnz_m2 > 0 &&
            !(a->flags & SP_FLAG_NO_SPARSE_PATH) && !(a->reserved[0] & 32768);      // (bit 32768 of the ablation word: off, for A/B runs)
 }
 
@@ -316,7 +316,7 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
     // Bounded variant of the sparse kernel (MODE 2): a general epilogue whose value is bounded through ONE per-column term carried in the
     // upper 12 bits of the m2 column ids.  Needs: column terms that are live and not folded, non-negative weights (the bound), a1 = 1, no
     // Bayesian factor, a denominator that does not grow with the raw dot (t1 + t2 >= 1 whenever l1 != 0), threshold >= 0 (negative values
-    // are never wanted), no per-row TARGET matrix (a MATRIX filter goes through the collision bitmap, as in the monotone variant), ids that leave 12 bits free.  What it cannot serve runs on the general variant.
+    // are never wanted), no per-row TARGET matrix (a MATRIX filter goes through the collision bitmap, as in the monotone variant), ids of at most 22 bits (the code keeps 12 / 11 / 10 bits).  What it cannot serve runs on the general variant.
     {
         c->bnd = bnd_eligible(a, c->mono, c->fold);
         c->ws_bnd_colpack = c->ws_bnd_ids = 0;
@@ -697,9 +697,9 @@ int run_device_impl(sp_knn_args *a, const uint64_t *sig_override = nullptr) {
                                a->l2 != 0.f ? a->Xcosine : nullptr, a->l3 != 0.f ? a->Xdepop : nullptr, ytv != nullptr, ycos != nullptr, ydep != nullptr,
                                a->l1 * a->t2, a->l2, a->l3, bnd_acc, bnd_info);
             hipLaunchKernelGGL(sp_bnd_range_kernel, dim3((unsigned)std::max(1, std::min(256, (a->n_output_cols + 4095) / 4096))), dim3(1024), 0, stream, a->n_output_cols,
-                               ytv, ycos, ydep, (unsigned *)(bnd_acc + 5), bnd_info);
+                               ytv, ycos, ydep, (unsigned *)(bnd_acc + 5), bnd_info, bnd_id_bits(a->n_output_cols));
             hipLaunchKernelGGL(sp_bnd_colpack_kernel, dim3(std::min(2048, (a->n_output_cols + 255) / 256)), dim3(256), 0, stream, a->n_output_cols, ytv, ycos, ydep,
-                               (const BndInfo *)bnd_info, bnd_colpack);
+                               (const BndInfo *)bnd_info, bnd_colpack, bnd_id_bits(a->n_output_cols));
             hipLaunchKernelGGL(sp_bnd_pack_ids_kernel, dim3(256 * 8), dim3(256), 0, stream, (long long)a->nnz_m2, a->m2_indices, (const unsigned *)bnd_colpack, bnd_ids, bnd_info);
             HIP_TRY(hipGetLastError());
         }
@@ -814,6 +814,7 @@ int run_device_impl(sp_knn_args *a, const uint64_t *sig_override = nullptr) {
     kp.fold = c.fold ? 1 : 0;
     if (c.fold) kp.m2_data = folded;
     kp.bnd = bnd_info; kp.colpack = bnd_colpack; kp.m2_packed = bnd_ids;
+    kp.bnd_id_mask = (1u << bnd_id_bits(a->n_output_cols)) - 1u;
     kp.splits = nullptr;
     kp.n_splits = 0; kp.splits_state = nullptr;
     kp.split_w = c.split_w;

@@ -536,9 +536,9 @@ __global__ __launch_bounds__(1024) void sp_colterm_min_kernel(int n_cols, const 
 
 // ---- per-call passes of the sparse kernel's BOUNDED variant (MODE 2; BndInfo in sp_common.hpp) ----
 // a column is VALID when every live Y_j is finite and >= 0 and its W is a finite normal float well above the bottom (code >= 1)
-__device__ __forceinline__ bool bnd_valid(float ytv, float ycos, float ydep, float w) {
+__device__ __forceinline__ bool bnd_valid(float ytv, float ycos, float ydep, float w, int id_bits) {
     const float inf = __builtin_inff();
-    return (ytv >= 0.f) && (ycos >= 0.f) && (ydep >= 0.f) && (ytv < inf) && (ycos < inf) && (ydep < inf) && (w < inf) && ((__float_as_uint(w) >> BND_CODE_SHIFT) >= 2u) &&
+    return (ytv >= 0.f) && (ycos >= 0.f) && (ydep >= 0.f) && (ytv < inf) && (ycos < inf) && (ydep < inf) && (w < inf) && ((__float_as_uint(w) >> (id_bits - 1)) >= 2u) &&
            !(__float_as_uint(w) >> 31);
 }
 // (1) reference multipliers rho_j (l_j x the mean of the row terms that are finite and positive) and the minima of the live Y_j over the
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(1024) void sp_bnd_xmean_kernel(int n_rows_m1, const
         out->rho_tv = rho[0]; out->rho_cos = rho[1]; out->rho_dep = rho[2];
     }
 }
-__global__ __launch_bounds__(1024) void sp_bnd_range_kernel(int n_cols, const float *Ytv, const float *Ycos, const float *Ydep, unsigned *done, BndInfo *out) {
+__global__ __launch_bounds__(1024) void sp_bnd_range_kernel(int n_cols, const float *Ytv, const float *Ycos, const float *Ydep, unsigned *done, BndInfo *out, int id_bits) {
     __shared__ unsigned redc[16];
     __shared__ float redm[3][16];
     __shared__ bool last;
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(1024) void sp_bnd_range_kernel(int n_cols, const fl
     float m0 = inf, m1 = inf, m2 = inf;
     for (long long i = (long long)blockIdx.x * 1024 + tid; i < n_cols; i += (long long)gridDim.x * 1024) {
         const float ytv = Ytv ? Ytv[i] : 0.f, ycos = Ycos ? Ycos[i] : 0.f, ydep = Ydep ? Ydep[i] : 0.f;
-        if (bnd_valid(ytv, ycos, ydep, bnd_w(rtv, ytv, rcos, ycos, rdep, ydep))) {
+        if (bnd_valid(ytv, ycos, ydep, bnd_w(rtv, ytv, rcos, ycos, rdep, ydep), id_bits)) {
             ++nv;
             m0 = fminf(m0, ytv); m1 = fminf(m1, ycos); m2 = fminf(m2, ydep);
         }
@@ -633,17 +633,17 @@ __global__ __launch_bounds__(1024) void sp_bnd_range_kernel(int n_cols, const fl
     }
 }
 
-// (2) the packed id of every column: id | code << 20, code = (bits(W) >> 19) - 1; a column that is not valid gets 0xFFFFFFFF (if an m2
+// (2) the packed id of every column: id | code << id_bits, code = (bits(W) >> (id_bits - 1)) - 1 (id_bits = 20 up to 2^20 columns, 21 / 22 beyond); a column that is not valid gets 0xFFFFFFFF (if an m2
 //     entry points at one the pack pass below takes the whole call off the bounded variant)
 __global__ __launch_bounds__(256) void sp_bnd_colpack_kernel(int n_cols, const float *__restrict__ Ytv, const float *__restrict__ Ycos, const float *__restrict__ Ydep,
-                                                              const BndInfo *__restrict__ info, unsigned *__restrict__ colpack) {
+                                                              const BndInfo *__restrict__ info, unsigned *__restrict__ colpack, int id_bits) {
     const BndInfo b = *info;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_cols; i += gridDim.x * blockDim.x) {
         unsigned out = 0xFFFFFFFFu;
         if (b.state == 1) {
             const float ytv = Ytv ? Ytv[i] : 0.f, ycos = Ycos ? Ycos[i] : 0.f, ydep = Ydep ? Ydep[i] : 0.f;
             const float w = bnd_w(b.rho_tv, ytv, b.rho_cos, ycos, b.rho_dep, ydep);
-            if (bnd_valid(ytv, ycos, ydep, w)) out = (unsigned)i | (((__float_as_uint(w) >> BND_CODE_SHIFT) - 1u) << BND_ID_BITS);
+            if (bnd_valid(ytv, ycos, ydep, w, id_bits)) out = (unsigned)i | (((__float_as_uint(w) >> (id_bits - 1)) - 1u) << id_bits);
         }
         colpack[i] = out;
     }

@@ -872,7 +872,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DUO ? 4 : 1,
                         // have — a bound would not do: the stage's cutoff must be one that k candidates reach, or what it discards could
                         // have been among the k best.  (All four products of a lane, first try: 4 096 gathers of a 128-byte line each per
                         // row, as much memory traffic as the sweeps' streams — the whole kernel slowed down.)
-                        const int gc = (bx > -__builtin_inff()) ? (int)(bc & BND_ID_MASK) : 0;
+                        const int gc = (bx > -__builtin_inff()) ? (int)(bc & p.bnd_id_mask) : 0;
                         float ytv = 0.f, ycos = 0.f, ydep = 0.f;
                         if (p.Ypack) { const float4 y = p.Ypack[gc]; ytv = y.x; ycos = y.y; ydep = y.z; }
                         else {
@@ -1414,7 +1414,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DUO ? 4 : 1,
                                 for (int j = 0; j < JK; ++j) {
                                     const int i = base + j * NT + tid;
                                     e[j] = (i < n_eff) ? U[i] : 0ull;
-                                    gc[j] = (e[j] != 0ull) ? (int)((unsigned)e[j] & BND_ID_MASK) : 0;
+                                    gc[j] = (e[j] != 0ull) ? (int)((unsigned)e[j] & p.bnd_id_mask) : 0;
                                     ytv[j] = 0.f; ycos[j] = 0.f; ydep[j] = 0.f;
                                 }
                                 if (p.Ypack) {
