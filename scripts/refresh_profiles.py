@@ -35,7 +35,7 @@ f, w = last_value(src / "pmc_FETCH_SIZE.csv", "FETCH_SIZE"), last_value(src / "p
 out = {"c2:1000000x100000x64:k100": {
     "bytes_per_launch": f * 1024 * 2 + w * 1024, "fetch_size_kib": round(f, 2), "write_size_kib": round(w, 2),
     "formula": "FETCH_SIZE*1024*2 + WRITE_SIZE*1024 (gfx950: FETCH_SIZE reports half of a coalesced stream, see profiles/README.md)",
-    "kernel": "sp_knn_sparse_kernel<1024,true,1> (MODE 1 = the monotone variant)", "lib_source_sha": lib_source_sha(),
+    "kernel": "sp_knn_sparse_kernel<512,true,1,true> (MODE 1 = the monotone variant, DUO = the two-per-CU shape of round 6)", "lib_source_sha": lib_source_sha(),
     "source": f"profiles/{tag}_pmc_FETCH_SIZE.csv, profiles/{tag}_pmc_WRITE_SIZE.csv"}}
 (dst / "hbm_traffic.json").write_text(json.dumps(out, indent=1))
 for line in open(dst / f"{tag}_kernel_stats.csv").read().splitlines()[:3]:
