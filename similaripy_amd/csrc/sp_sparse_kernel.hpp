@@ -605,6 +605,36 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DUO ? 4 : 1,
                               "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]));
                         if (cnt == 1u) cbm_mark(cs);
                         if (__ballot(cnt > 1u)) {
+                            if constexpr (DUO) {
+                                // The two-per-CU shape's aliasing bitmap doubles the marks: nine pair-trips of ten hold a lane with TWO marked columns,
+                                // and the per-element route below — eight exec-masked tests and branches — ran on all of them (~50 instructions a
+                                // pair-trip, 7 % of a row's).  Two columns of a lane are their sum and their maximum: mx = max_j seen[j] * c[j]
+                                // (24-bit products: the mark needs the column's low 20 bits), the other one cs - mx.  Three or more: the old route.
+                                unsigned mx, t1, t2;
+                                asm("v_mul_u32_u24 %0, %3, %11\n\t"
+                                    "v_mul_u32_u24 %1, %4, %12\n\t"
+                                    "v_mul_u32_u24 %2, %5, %13\n\t"
+                                    "v_max3_u32 %0, %0, %1, %2\n\t"
+                                    "v_mul_u32_u24 %1, %6, %14\n\t"
+                                    "v_mul_u32_u24 %2, %7, %15\n\t"
+                                    "v_max3_u32 %0, %0, %1, %2\n\t"
+                                    "v_mul_u32_u24 %1, %8, %16\n\t"
+                                    "v_mul_u32_u24 %2, %9, %17\n\t"
+                                    "v_max3_u32 %0, %0, %1, %2\n\t"
+                                    "v_mul_u32_u24 %1, %10, %18\n\t"
+                                    "v_max_u32 %0, %0, %1"
+                                    : "=&v"(mx), "=&v"(t1), "=&v"(t2)
+                                    : "v"(seen[0]), "v"(seen[1]), "v"(seen[2]), "v"(seen[3]), "v"(seen[4]), "v"(seen[5]), "v"(seen[6]), "v"(seen[7]),
+                                      "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]));
+                                if (cnt == 2u) { cbm_mark(mx); cbm_mark(cs - mx); }
+                                if (__ballot(cnt > 2u)) {
+                                    if (cnt > 2u) {
+#pragma unroll
+                                        for (int j = 0; j < 8; ++j)
+                                            if (seen[j]) cbm_mark(c[j]);
+                                    }
+                                }
+                            } else
                             if (cnt > 1u) {
 #pragma unroll
                                 for (int j = 0; j < 8; ++j)
