@@ -326,6 +326,26 @@ def test_duo_shape_against_the_oracle_and_the_classic_shape(name, kw):
     _check(call, "classic " + name, dbg=524288)
 
 
+def test_duo_shape_rows_set_up_in_the_kernel():
+    """The two-per-CU shape's item area is 240 records and the 4 KB sort scratch of rows with more than 64 entries runs into the first radix
+    histogram (re-zeroed behind it).  Rows of ~100 entries (set up in the kernel: all-pairs order) and the prepass switched off (ablation bit
+    2048: rows of <= 64 entries set up by one wave), both on the shape (twice the workgroups prove it)."""
+    rng = np.random.default_rng(61)
+    m1 = sp.random_array((3000, 4000), density=100 / 4000, format="csr", dtype=np.float32, random_state=rng)
+    m2 = sp.random_array((4000, 600_000), density=300 / 600_000, format="csr", dtype=np.float32, random_state=rng)
+    assert np.diff(m1.indptr).max() > 64
+    for kw in (dict(l2=1), dict(l1=1, t1=0.7, t2=0.5)):
+        call = _host.prepare(m1, m2, k=70, **kw)
+        info = _host.run_hip(call, time_kernel=True)[4]
+        assert info["num_wgs"] == 512 and info["phase_cycles"][9] >= 0.9 * call.n_targets, (info["num_wgs"], info["phase_cycles"][9], info["phase_cycles"][10] & 0xFFFFFFFF)
+        _check(call, f"duo, rows of ~100 entries {kw}")
+    m = _duo_matrix()
+    call = _host.prepare(m, k=60, l2=1, target_rows=np.arange(0, 200_000, 97).astype(np.int32))
+    info = _host.run_hip(call, time_kernel=True, dbg=2048)[4]
+    assert info["num_wgs"] == 512 and info["phase_cycles"][9] == call.n_targets
+    _check(call, "duo, no prepass", dbg=2048)
+
+
 def test_duo_shape_with_the_larger_collision_set():
     """Between ~1.7 k and ~2.5 k expected marked columns per row the two-per-CU shape runs with 3072 + 1024 collision-set slots, a member pool
     of 2048 entries (several folds per row) and 1536 entries of U; before round 6 such rows — 41 k products over 350 k columns here — all went
