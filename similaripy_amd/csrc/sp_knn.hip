@@ -118,6 +118,7 @@ struct Config {
     size_t ws_items_bytes;
     bool fold;
     bool wave;              // light rows: the wave-per-row kernel (sp_wave_kernel.hpp) runs instead of the workgroup-per-row sparse kernel
+    bool duo_l;             // ... and a SECOND launch of it, in the layout with the larger collision set, takes the rows whose expected marks exceed the first's (their own queue)
     bool duo;               // the sparse kernel runs in its two-per-CU shape (512 threads, 80 KB, aliasing 2^19-bit bitmap; sp_sparse_kernel.hpp)
     size_t lds_sparse_gen;  // ... and then this is the LDS of the general variant launched beside the bounded one (the classic 512-thread layout)
     bool mono;              // the sparse kernel's monotone variant applies (val = xy / den or the raw dot, no per-row target selector)
@@ -293,6 +294,11 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
     c->lds_sparse = duo ? sp_duo_lds_bytes() : lds_fixed_sparse(T_s, NT_s);
     c->lds_sparse_gen = lds_fixed_sparse(duo ? 8192 : T_s, NT_s);
     c->duo = duo;
+    // Rows are classified one by one: a call whose AVERAGE row fits the 2048 rank-addressed slots still has rows that do not (real data has
+    // row degrees: a binary matrix with Poisson(64) rows sent a quarter of them — 43 k to 53 k products — to the generic kernel, 32 of the
+    // call's 54 ms).  Those rows get a queue of their own (the wave kernel's: it never runs beside this shape) and a second launch of the
+    // same kernel in the larger layout.
+    c->duo_l = duo && duo_direct == DUO_CS_DIRECT && (long long)a->k + 512 <= (long long)DUO_U_ENTRIES_L && !(a->reserved[0] & 1048576);      // (bit 1048576 of the ablation word: off)
     c->lds_generic = lds_fixed_generic(T, NT) + (u_lds ? (size_t)cap * 8 : 0);
     auto wgs_for = [&](size_t lds, int nt) {
         int per_cu = (int)std::max<size_t>(1, LDS_LIMIT / lds);
@@ -475,17 +481,31 @@ int launch_sparse(const KParams &kp, const Config &c, hipStream_t stream) {
         if (c.duo) {
             // the two-per-CU shape (monotone or bounded variant; the general variant that backs the bounded one up — BndInfo::state != 1: a
             // zero or negative column term, rare — runs the classic 512-thread layout on the same parameters, one workgroup per CU)
-            auto kd = c.bnd ? sp_knn_sparse_kernel<DUO_NT, true, 2, true> : sp_knn_sparse_kernel<DUO_NT, true, 1, true>;
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds_sparse));
-            hipLaunchKernelGGL(kd, dim3(c.wgs_sparse), dim3(NT), c.lds_sparse, stream, kp);
-            HIP_TRY(hipGetLastError());
-            if (c.bnd) {
-                auto kg = sp_knn_sparse_kernel<DUO_NT, true, 0>;
-                KParams kpg = kp;      // (the classic layout reads its region size from T: 64 KB = the 2^19-bit bitmap; the DUO kernel keeps its slot count there)
-                kpg.T = 8192; kpg.logT = 13;
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds_sparse_gen));
-                hipLaunchKernelGGL(kg, dim3(std::max(1, c.wgs_sparse / 2)), dim3(NT), c.lds_sparse_gen, stream, kpg);
+            auto one = [&](const KParams &kq) -> int {
+                auto kd = c.bnd ? sp_knn_sparse_kernel<DUO_NT, true, 2, true> : sp_knn_sparse_kernel<DUO_NT, true, 1, true>;
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds_sparse));
+                hipLaunchKernelGGL(kd, dim3(c.wgs_sparse), dim3(NT), c.lds_sparse, stream, kq);
                 HIP_TRY(hipGetLastError());
+                if (c.bnd) {
+                    auto kg = sp_knn_sparse_kernel<DUO_NT, true, 0>;
+                    KParams kpg = kq;      // (the classic layout reads its region size from T: 64 KB = the 2^19-bit bitmap; the DUO kernel keeps its slot count there)
+                    kpg.T = 8192; kpg.logT = 13;
+                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds_sparse_gen));
+                    hipLaunchKernelGGL(kg, dim3(std::max(1, c.wgs_sparse / 2)), dim3(NT), c.lds_sparse_gen, stream, kpg);
+                    HIP_TRY(hipGetLastError());
+                }
+                return SP_OK;
+            };
+            TRY(one(kp));
+            if (c.duo_l) {
+                // the rows whose expected marks need the larger collision set: their own queue (head, length, descriptors: the wave kernel's
+                // words of the workspace), the same kernel in its other layout — 3072 + 1024 slots, a 2048-entry pool, 1536 entries of U
+                KParams kl = kp;
+                kl.T = DUO_CS_DIRECT_L; kl.logT = 10; kl.cap_s = DUO_U_ENTRIES_L;
+                kl.queue = kp.queue + 6;
+                kl.qcount = kp.queue + 7;
+                kl.desc = kp.desc + 2 * (size_t)kp.n_targets;
+                TRY(one(kl));
             }
             return SP_OK;
         }
@@ -578,7 +598,7 @@ uint64_t prep_signature(const sp_knn_args *a, const Config &c) {
     auto mix = [&](const void *p, size_t n) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } };
 #define SP_MIX(x) mix(&(x), sizeof(x))
     const uint32_t fl = a->flags & (SP_FLAG_NO_FOLD | SP_FLAG_NO_SPARSE_PATH);
-    const int64_t abl = a->reserved[0] & (1024 | 2048 | 4096 | 16384 | 32768 | 65536 | 524288);      // (items_stride follows from sizes the signature covers)
+    const int64_t abl = a->reserved[0] & (1024 | 2048 | 4096 | 16384 | 32768 | 65536 | 524288 | 1048576);      // (items_stride follows from sizes the signature covers)
     SP_MIX(fl); SP_MIX(abl);
     SP_MIX(a->n_rows_m2); SP_MIX(a->n_output_cols); SP_MIX(a->nnz_m2);
     SP_MIX(a->m2_data); SP_MIX(a->m2_indices); SP_MIX(a->m2_indptr);
@@ -760,6 +780,7 @@ int run_device_impl(sp_knn_args *a, const uint64_t *sig_override = nullptr) {
         cp.n_cols = a->n_output_cols; cp.T = c.T; cp.nb_log2 = c.nb_log2;
         cp.cs_slots = c.duo ? 2 * c.T_s : c.T_s / 4;      // (the rule counts the rank-addressed slots as half of the set)
         cp.duo = c.duo ? 1 : 0;
+        cp.duo_l = c.duo_l ? 1 : 0;
         cp.wave = c.wave ? 1 : 0;
         cp.wave_macs_max = 10000u;
         cp.qcount_w = (unsigned *)(ws + 28);          // header words 6 / 7: head and length of the wave kernel's queue (zeroed with the header)
@@ -795,6 +816,12 @@ int run_device_impl(sp_knn_args *a, const uint64_t *sig_override = nullptr) {
                                a->m1_indices, a->m1_data, a->m2_indptr, (int4 *)ws_items, c.NT_s == 256 ? 1 : 0,
                                ((c.mono || c.bnd) && a->filter_mode == SP_SEL_MATRIX) ? a->filter_m_indptr : nullptr, c.items_stride);
             HIP_TRY(hipGetLastError());
+            if (c.duo_l) {      // the rows of the second two-per-CU launch: same records, their own queue
+                hipLaunchKernelGGL(sp_row_items_kernel, dim3(item_blocks), dim3(256), 0, stream, (const unsigned *)cp.qcount_w, c.items_rows, (int4 *)desc_w,
+                                   a->m1_indices, a->m1_data, a->m2_indptr, (int4 *)ws_items, 0,
+                                   ((c.mono || c.bnd) && a->filter_mode == SP_SEL_MATRIX) ? a->filter_m_indptr : nullptr, c.items_stride);
+                HIP_TRY(hipGetLastError());
+            }
             if (c.wave) {
                 hipLaunchKernelGGL(sp_row_items_wave_kernel, dim3(item_blocks), dim3(256), 0, stream, (const unsigned *)cp.qcount_w, c.items_rows, (int4 *)desc_w,
                                    a->m1_indices, a->m1_data, a->m2_indptr, (int4 *)ws_items, c.items_stride);

@@ -123,6 +123,7 @@ struct ClassifyParams {
     int nb_log2;           // sparse bitmap bits
     int cs_slots;          // collision-set slots of the sparse kernel
     int duo;               // its two-per-CU shape runs (aliasing 2^19-bit bitmap, half of the slots addressed by rank)
+    int duo_l;             // ... and a second launch in the larger layout takes the rows between the two limits (the wave kernel's queue)
     int mono;              // the monotone sparse kernel runs: descriptor word 1.y carries den (val = xy / den), rows
     int any_norm;          //   with a normalised epilogue need den > 0 to be sparse
     float l2, l3;
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256) void sp_row_desc_kernel(int n_targets, const i
     const int lane = threadIdx.x & 63;
     const bool valid = pos < n_targets;
     int4 d0 = make_int4(0, 0, 0, 0), d1 = d0;
-    bool sparse = false, wavey = false;
+    bool sparse = false, wavey = false, duo_l_row = false;
     if (valid) {
         const int slot = (ordered_flag != nullptr && ordered_flag[0] != 0u) ? order[pos] : pos;
         const int t = targets[slot];
@@ -175,10 +176,14 @@ __global__ __launch_bounds__(256) void sp_row_desc_kernel(int n_targets, const i
             // DUO: products that find their bit set = pairs of products on one bit, MACs^2 / (2 * bits) (a column pair on one bit counts
             // like a column that repeats); they must fit the rank-addressed half of the set — 0.44 x 4096 = 1 802 of 2 048 (a C2 row:
             // 1 600 +- 40; a row that does not fit after all is handed to the generic queue by the kernel)
-            if (cp.duo) sparse = 0.5f * m * m / (float)min(cp.n_cols, 1 << cp.nb_log2) <= 0.44f * (float)cp.cs_slots;
+            if (cp.duo) {
+                const float est = 0.5f * m * m / (float)min(cp.n_cols, 1 << cp.nb_log2);
+                sparse = est <= 0.44f * (float)cp.cs_slots;
+                if (!sparse && cp.duo_l && est <= 0.88f * (float)DUO_CS_DIRECT_L) { sparse = true; duo_l_row = true; }
+            }
         }
-        wavey = sparse && cp.wave && (e - s) <= 64 && macs <= cp.wave_macs_max;
-        if (wavey && cp.n_cols > (1 << 17)) {
+        wavey = (sparse && cp.wave && (e - s) <= 64 && macs <= cp.wave_macs_max) || duo_l_row;
+        if (wavey && !duo_l_row && cp.n_cols > (1 << 17)) {
             // the wave kernel's column bitmap has 2^17 bits: beyond, aliased columns are marked like true collisions and must fit the 512
             // direct slots of its collision set with room to spare
             const float m = (float)macs;

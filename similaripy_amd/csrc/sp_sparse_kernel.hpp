@@ -820,6 +820,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DUO ? 4 : 1,
             bool last_stage = false;
             bool force_sel = false;
             WavePool wpm{0, -1};      // member-pool window: lives across the stages of the row
+            int stage_retries = 5;    // (uniform) stages that may be taken back and offered again shorter when a pool overflows, see there
             // MONO: the first trip of the stage BEHIND the selection-free first stage (item pre_i0 + wave) is requested as soon as that
             // stage's own data has arrived, i.e. in front of its statistics rounds and three barriers: the sweep that follows is
             // bound by its bodies, so a trip that is there when it starts moves the whole stage forward by one body
@@ -1062,6 +1063,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DUO ? 4 : 1,
                 // 10^6 with a product counted twice; the three-per-CU 256-thread shape showed it once in a fuzz case of tied values,
                 // tests/test_hip_stress.py seed 34 case 48 — not reproducible in six reruns).  Every shape that shares a CU gets the barrier.
                 const int m_seen = min(sh[SH_MCTR], mpcap);
+                const int u_seen = min(sh[SH_CNT], cap);      // (MLIKE: U and the member pool as the stage finds them — what a retry goes back to)
+                const WavePool wpm0 = wpm;
                 if constexpr (NT < 1024) wg_sync<U_LDS>();
                 if constexpr (DUO) {
                     const float fm = (float)n_marks * (1.f / (float)(8 * DUO_PLANE_BYTES));      // marked share of a plane's bits
@@ -1239,12 +1242,39 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DUO ? 4 : 1,
                         trip += 2;
                     }
                 }
+                wg_sync<U_LDS>();
+                if (sh[SH_OVF]) {     // a pool overflowed
+                    // Monotone-type variants: the stage is TAKEN BACK and offered again at a quarter of its length (round 6).  Stage lengths
+                    // come from what an exchangeable stream would let through; heavily tied data — binary matrices: every product of a row
+                    // is one of a few dozen values — lets far more through, U or the member pool fills, and the row used to go to the
+                    // generic queue: 148 k of 200 k rows of a binary matrix with Poisson degrees under Jaccard on the two-per-CU shape
+                    // (161 ms against the classic shape's 45: its U is twice the size).  Everything the stage pushed lies behind the
+                    // counters' values at its start (U: fresh blocks only; the pool: fresh blocks, and the tail of every wave's own window,
+                    // empty then), the cutoff has not moved: zero it, put the counters back, go again.
+                    if (MLIKE && stage_retries > 0 && i1 - i0 > 1) {      // (uniform)
+                        const int u_now = min(sh[SH_CNT], cap), m_now = min(sh[SH_MCTR], mpcap);
+                        wg_sync<U_LDS>();      // every wave has read the counters
+                        for (int i = u_seen + tid; i < u_now; i += NT) U[i] = 0ull;
+                        for (int i = m_seen + tid; i < m_now; i += NT) mpool[i] = 0ull;
+                        {
+                            const int wp0 = __builtin_amdgcn_readfirstlane(wpm0.pos), we0 = __builtin_amdgcn_readfirstlane(wpm0.end);
+                            if (wp0 + lane < we0) mpool[wp0 + lane] = 0ull;      // (a window is at most POOL_BLK = 64 entries... of what is left of it)
+                            for (int i = wp0 + 64 + lane; i < we0; i += 64) mpool[i] = 0ull;
+                        }
+                        if (tid == 0) { sh[SH_CNT] = u_seen; sh[SH_MCTR] = m_seen; sh[SH_OVF] = 0; }
+                        wpm = wpm0;
+                        wg_sync<U_LDS>();
+                        chunk_items = max(1, (i1 - i0) / 4);
+                        --stage_retries;
+                        if (timing) ph[CT_PASSES] += 1ull << 53;      // (profiling: stages taken back, bits 53..63 of the counter — modulo 2048; the bounded variant keeps its own counts below)
+                        continue;
+                    }
+                    failed = true; why = (sh[SH_CNT] > cap) ? 2 : 3; break;
+                }
                 i0 = i1;
                 last_stage = (i0 >= n_items);      // (an empty first round with i0 < n_items is never the last)
-                wg_sync<U_LDS>();
                 const int ext = min(sh[SH_PCTR], spcap);
                 const int mext = min(sh[SH_MCTR], mpcap);
-                if (sh[SH_OVF]) { failed = true; why = (sh[SH_CNT] > cap) ? 2 : 3; break; }     // a pool overflowed
                 PHASE_END(PH_SWEEP2);
                 // (DUO: also between stages, as soon as the pool is half full)
                 const bool do_acc = last_stage || (DUO && 2 * mext > mpcap - NW * POOL_BLK);      // uniform

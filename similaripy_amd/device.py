@@ -126,7 +126,7 @@ class DeviceProblem:
         # call's scalars are this problem's own): folded values, packed terms and window boundaries are laid out per (flags, tuning)
         # — reused under other ones they would be read as something else (the library refuses such a call as well)
         sig = (flags & (_abi.SP_FLAG_NO_FOLD | _abi.SP_FLAG_NO_SPARSE_PATH), int(tuning.get("table_slots", 0)), int(tuning.get("threads_per_wg", 0)),
-               int(tuning.get("load_pct", 0)), int(tuning.get("dbg", 0)) & (1024 | 2048 | 4096 | 16384 | 32768 | 65536 | 524288))
+               int(tuning.get("load_pct", 0)), int(tuning.get("dbg", 0)) & (1024 | 2048 | 4096 | 16384 | 32768 | 65536 | 524288 | 1048576))
         if tuning.get("reuse_m2_prep") and self._ws is not None and self._prep_sig == sig:
             flags |= _abi.SP_FLAG_REUSE_M2_PREP
         with torch.cuda.device(self.device):
