@@ -1065,7 +1065,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DUO ? 4 : 1,
                 const int m_seen = min(sh[SH_MCTR], mpcap);
                 const int u_seen = min(sh[SH_CNT], cap);      // (MLIKE: U and the member pool as the stage finds them — what a retry goes back to)
                 const WavePool wpm0 = wpm;
-                if constexpr (NT < 1024) wg_sync<U_LDS>();
+                // (the monotone-type variants of EVERY shape: a stage that overflows is taken back to u_seen / m_seen, which must be the same
+                // in every wave — the one-per-CU shape's waves may differ by a memory round trip's worth too, rarely: the race hunt of
+                // tests/test_hip_stress.py found one wrong row in 3 000 x 100 on the 1024-thread shape with U in global memory the first
+                // time the retry ran without this)
+                if constexpr (NT < 1024 || MLIKE) wg_sync<U_LDS>();
                 if constexpr (DUO) {
                     const float fm = (float)n_marks * (1.f / (float)(8 * DUO_PLANE_BYTES));      // marked share of a plane's bits
                     const float per_item = 1.25f * ((float)ITEM * fm * fm + 2.f * (float)n_marks * __builtin_amdgcn_rcpf((float)max(1, n_items))) + 2.f;

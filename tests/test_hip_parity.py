@@ -346,6 +346,32 @@ def test_duo_shape_rows_set_up_in_the_kernel():
     _check(call, "duo, no prepass", dbg=2048)
 
 
+def test_duo_shape_rows_of_two_weights_and_binary_data():
+    """Real matrices have row degrees.  A call whose AVERAGE row fits the two-per-CU shape's 2048 rank-addressed slots has rows that do not:
+    they get a queue of their own and a second launch of the same kernel in the larger layout (3072 + 1024 slots) instead of the generic
+    kernel.  And binary data ties heavily: a stage whose pools overflow is taken back and offered again at a quarter of its length instead of
+    sending the row to the generic queue.  Rows of ~40 and of ~75 entries (23 k and 43 k products over 400 k columns), plain and binary values,
+    monotone and bounded variant; ablation bit 1048576 switches the second launch off (the heavy half then goes to the generic kernel)."""
+    # (Poisson degrees around 40 and 75: with ONE fixed degree every single product of a binary row ties exactly under a general epilogue,
+    # the case DESIGN 4.9 lists as still open)
+    a = sp.random_array((200_000, 40_000), density=40 / 40_000, format="csr", dtype=np.float32, random_state=np.random.default_rng(51))
+    b = sp.random_array((200_000, 40_000), density=75 / 40_000, format="csr", dtype=np.float32, random_state=np.random.default_rng(52))
+    m = sp.vstack([a, b]).tocsr()
+    m = m[np.random.default_rng(53).permutation(m.shape[0])]           # (the two kinds interleaved)
+    m = sp.csr_array(m); m.sort_indices()
+    t = np.arange(0, 400_000, 131).astype(np.int32)
+    for kw in (dict(l2=1), dict(l2=1, binary=True), dict(l1=1, t1=1, t2=1, binary=True), dict(l1=0.5, l2=0.5, stabilized_shrink=5)):
+        call = _host.prepare(m, k=50, target_rows=t, **kw)
+        info = _host.run_hip(call, time_kernel=True)[4]
+        pc = info["phase_cycles"]
+        assert info["num_wgs"] == 512 and pc[9] >= 0.8 * call.n_targets, (kw, info["num_wgs"], pc[9], pc[10] & 0xFFFFFFFF)      # (rows of 80 entries and more have too many items for the shape)
+        _check(call, f"duo, two row weights {kw}")
+    call = _host.prepare(m, k=50, target_rows=t, l2=1)
+    pc = _host.run_hip(call, time_kernel=True, dbg=1048576)[4]["phase_cycles"]
+    assert 0.3 * call.n_targets <= pc[9] <= 0.7 * call.n_targets, pc[9]      # without the second launch the heavy half is the generic kernel's
+    _check(call, "duo, two row weights, no second launch", dbg=1048576)
+
+
 def test_duo_shape_with_the_larger_collision_set():
     """Between ~1.7 k and ~2.5 k expected marked columns per row the two-per-CU shape runs with 3072 + 1024 collision-set slots, a member pool
     of 2048 entries (several folds per row) and 1536 entries of U; before round 6 such rows — 41 k products over 350 k columns here — all went
