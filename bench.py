@@ -611,8 +611,9 @@ def measure_traffic(call, kernel_name: str, tuning: dict) -> dict:
             rows = [r for r in csv.DictReader(open(files[0])) if r["Counter_Name"] == counter and kernel_name in r["Kernel_Name"]]
             if not rows:
                 raise RuntimeError(f"no {counter} rows for {kernel_name}")
-            last = max(int(r["Dispatch_Id"]) for r in rows)
-            vals[counter] = sum(float(r["Counter_Value"]) for r in rows if int(r["Dispatch_Id"]) == last)
+            # (the child runs ONE step; the kernel may be launched more than once in it — round 6: a second launch of the two-per-CU shape over
+            # the queue of heavier rows, empty for this workload — so every dispatch of the name belongs to the step: all of them count)
+            vals[counter] = sum(float(r["Counter_Value"]) for r in rows)
     traffic = vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024
     log(f"traffic: FETCH_SIZE {vals['FETCH_SIZE']:.0f} KiB, WRITE_SIZE {vals['WRITE_SIZE']:.0f} KiB -> {traffic / 1e9:.1f} GB per launch ({time.perf_counter() - t0:.0f}s)")
     return {"traffic": traffic, "traffic_fetch_size_kib": vals["FETCH_SIZE"], "traffic_write_size_kib": vals["WRITE_SIZE"],

@@ -26,10 +26,15 @@ for f in sorted(glob.glob(out + "/pass*.csv")):
     if not rows: continue
     # (a wave call launches its workgroup-per-row companion behind the wave kernel, on a handful of rows: the wave kernel is the one to count)
     if any("sp_knn_wave" in r["Kernel_Name"] for r in rows): rows = [r for r in rows if "sp_knn_wave" in r["Kernel_Name"]]
-    last = max(int(r["Dispatch_Id"]) for r in rows)
+    # the dispatch that did the work: the one with the most of this pass's first counter (round 6: the two-per-CU shape is launched a second
+    # time over the queue of heavier rows — empty for configs[1] — so the LAST dispatch of the name is no longer the step's kernel)
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
     for r in rows:
-        if int(r["Dispatch_Id"]) == last:
-            tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        per[int(r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
+    first = rows[0]["Counter_Name"]
+    best = max(per, key=lambda d: (per[d].get(first, 0.0), d))
+    for name, v in per[best].items():
+        tot[name] = tot.get(name, 0.0) + v
 for k, v in tot.items():
     print(f"{k:32s} {v:20.0f}")
 PY

@@ -26,9 +26,13 @@ if bench.exists():
 
 
 def last_value(path, counter):
+    # the dispatch of the kernel that did the step's work: the one with the largest value (round 6 launches the two-per-CU shape a second time
+    # over the queue of heavier rows — empty for configs[1]: 33 us, a few hundred KiB)
     rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
-    last = max(int(r["Dispatch_Id"]) for r in rows)
-    return sum(float(r["Counter_Value"]) for r in rows if int(r["Dispatch_Id"]) == last)
+    per = {}
+    for r in rows:
+        per[int(r["Dispatch_Id"])] = per.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])
+    return max(per.values())
 
 
 f, w = last_value(src / "pmc_FETCH_SIZE.csv", "FETCH_SIZE"), last_value(src / "pmc_WRITE_SIZE.csv", "WRITE_SIZE")
