@@ -481,8 +481,9 @@ int launch_sparse(const KParams &kp, const Config &c, hipStream_t stream) {
         if (c.duo) {
             // the two-per-CU shape (monotone or bounded variant; the general variant that backs the bounded one up — BndInfo::state != 1: a
             // zero or negative column term, rare — runs the classic 512-thread layout on the same parameters, one workgroup per CU)
-            auto one = [&](const KParams &kq) -> int {
-                auto kd = c.bnd ? sp_knn_sparse_kernel<DUO_NT, true, 2, true> : sp_knn_sparse_kernel<DUO_NT, true, 1, true>;
+            auto one = [&](const KParams &kq, bool second) -> int {
+                auto kd = second ? (c.bnd ? sp_knn_sparse_kernel<DUO_NT, true, 2, true, true> : sp_knn_sparse_kernel<DUO_NT, true, 1, true, true>)
+                                 : (c.bnd ? sp_knn_sparse_kernel<DUO_NT, true, 2, true> : sp_knn_sparse_kernel<DUO_NT, true, 1, true>);
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds_sparse));
                 hipLaunchKernelGGL(kd, dim3(c.wgs_sparse), dim3(NT), c.lds_sparse, stream, kq);
                 HIP_TRY(hipGetLastError());
@@ -496,7 +497,7 @@ int launch_sparse(const KParams &kp, const Config &c, hipStream_t stream) {
                 }
                 return SP_OK;
             };
-            TRY(one(kp));
+            TRY(one(kp, false));
             if (c.duo_l) {
                 // the rows whose expected marks need the larger collision set: their own queue (head, length, descriptors: the wave kernel's
                 // words of the workspace), the same kernel in its other layout — 3072 + 1024 slots, a 2048-entry pool, 1536 entries of U
@@ -505,7 +506,7 @@ int launch_sparse(const KParams &kp, const Config &c, hipStream_t stream) {
                 kl.queue = kp.queue + 6;
                 kl.qcount = kp.queue + 7;
                 kl.desc = kp.desc + 2 * (size_t)kp.n_targets;
-                TRY(one(kl));
+                TRY(one(kl, true));
             }
             return SP_OK;
         }

@@ -44,8 +44,11 @@ namespace {
 // pool, so the collision set takes half of the region (4096 slots: ~1.6 k marked columns per C2 row against 0.8 k with the exact
 // bitmap); the member pool (2560 entries against ~4.3 k members per row) is folded into the collision set BETWEEN stages whenever it
 // is half full, and a stage is sized so that its expected members fit what is left.
-template <int NT, bool U_LDS, int MODE, bool DUO = false>
+// (SECOND: the same code under a second symbol — the launch of the two-per-CU shape over the queue of heavier rows, in its larger layout (the layout
+// itself travels in KParams): profilers then list the two launches of a step apart instead of averaging an 86 ms kernel with an empty 33 us one)
+template <int NT, bool U_LDS, int MODE, bool DUO = false, bool SECOND = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DUO ? 4 : 1, DUO ? 4 : 10))) void sp_knn_sparse_kernel(const KParams p) {
+    static_assert(!SECOND || DUO, "only the two-per-CU shape is launched twice");
     constexpr bool MONO = MODE == 1, BND = MODE == 2, MLIKE = MODE != 0;
     static_assert(!DUO || (NT == 512 && U_LDS && MLIKE), "the two-per-CU shape: 512 threads, U in LDS, a monotone-type variant");
     if constexpr (BND) { if (p.bnd->state != 1) return; }                       // (uniform over the grid: written by the per-call passes)
