@@ -17,6 +17,9 @@
 // Rows whose collision set or pool overflow are handed to the generic kernel through its queue (never to a CPU path).
 #pragma once
 #include "sp_common.hpp"
+#ifndef SP_DUO_FS2
+#define SP_DUO_FS2 1
+#endif
 
 namespace {
 
@@ -487,7 +490,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DUO ? 4 : 1,
         // MONO: the first stage's trips (one or two items per wave, see there) are requested in front of the bitmap's clearing loop and
         // the rank prefix: the round trip (~3.5 k cycles, in which no wave had anything else to do) runs under those ~3.6 k cycles
         // (zero-initialised: undefined on some path, the registers' last contents would be live around the whole row loop)
-        constexpr int FS1 = (NT == 256 || DUO) ? 2 : 1;      // (DUO: eight waves — two trips each show the stage the 4 096 products the classic shape's sixteen waves see)
+        constexpr int FS1 = (NT == 256 || (DUO && SP_DUO_FS2)) ? 2 : 1;      // (DUO: eight waves — two trips each show the stage the 4 096 products the classic shape's sixteen waves see)
         constexpr int MAXR1 = (NT == 256) ? 32 : 16;
         u32x4 fsa[FS1], fsb[FS1];
 #pragma unroll
