@@ -1,6 +1,6 @@
 #!/bin/bash
 # bash scripts/pmc_gpu.sh <tag> "<counters pass 1>" "<counters pass 2>" ... -- [bench args]
-# Each quoted group is one rocprofv3 --pmc pass (hardware limits: SQ 8, TCC 4 per pass).
+# Each quoted group is one rocprofv3 --pmc pass (hardware limits: SQ 8, TCC 4 per pass).  KERNEL_RE (env): the kernels counted, default the sparse-row kernels.
 set -u
 TAG=$1; shift
 REPO=$(pwd); OUT=$REPO/gpurun_out/pmc_$TAG; mkdir -p "$OUT"
@@ -14,7 +14,7 @@ for G in "${PMCG[@]}"; do
   i=$((i+1))
   rocprofv3 --pmc $G --kernel-trace --output-format csv -d /tmp/rp_${TAG}_$i -o pmc -- $BENCH > /dev/null 2> "$OUT/pass$i.log"
   f=$(find /tmp/rp_${TAG}_$i -name "*counter_collection.csv" | head -1)
-  if [ -n "$f" ]; then (head -1 "$f"; grep -E "sp_knn_(sparse|wave)" "$f") > "$OUT/pass$i.csv"; fi
+  if [ -n "$f" ]; then (head -1 "$f"; grep -E "${KERNEL_RE:-sp_knn_(sparse|wave)}" "$f") > "$OUT/pass$i.csv"; fi
 done
 python - "$OUT" <<'PY'
 import csv, sys, glob, collections

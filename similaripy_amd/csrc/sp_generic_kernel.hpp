@@ -62,8 +62,8 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
     // (nb segments, prefix in seg_pre): wave w owns a contiguous 64-aligned chunk, every lane handles AU
     // stride-64 elements per trip (coalesced loads), all lanes of a wave make the same number of trips, and the
     // loads of trip i+1 are issued before trip i is processed (two register sets, no copies).
-    // Per lane the current segment is cached in registers (end of segment, flat->m2 index delta, m1 value):
-    // the common element costs one compare and one add.  m2 is addressed with 32-bit byte offsets from the
+    // The current segment is the WAVE's (end of segment, flat->m2 index delta, m1 value in scalar registers, see below):
+    // the common step costs one scalar compare and one add.  m2 is addressed with 32-bit byte offsets from the
     // scalar base pointers (64-bit ones in the BIG variant, which the host launches for nnz(m2) >= 2^30).
     // body(c[], x[], v1[], valid): c = column id, x = m2 value (0 unless loadx), v1 = m1 value of the
     // element's segment; padding elements (bit clear in `valid`) repeat a real element of the lane, v1 = 0.
@@ -78,34 +78,48 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
         const int e0 = eb + wave * chunk;
         const int e1 = min(e0 + chunk, ee);
         if (e0 >= e1) return;  // wave-uniform
-        const int efirst = min(e0 + lane, e1 - 1);
-        int sl = 0, sr = nb;  // last s in [0,nb) with seg_pre[s] <= efirst (seg_pre[0] = 0)
-        while (sr - sl > 1) {
-            const int mid = (sl + sr) >> 1;
-            if (seg_pre[mid] <= efirst) sl = mid; else sr = mid;
+        // The segment of an element.  A wave's trip covers 64 CONSECUTIVE flat elements per unrolled step, so the walk along the segment
+        // list is the WAVE's, not the lane's (round 6): `sc` is the last segment reached, `b` its end, {cur_delta, cur_v} its flat->m2 index
+        // delta and m1 value — all wave-uniform, read from LDS at one address for the whole wave and kept in scalar registers; a boundary
+        // inside the step's 64 elements hands the lanes behind it to the next segment (one compare, two selects).  Until round 6 every LANE
+        // kept its own segment and walked on its own (exec-masked loops of dependent LDS gathers: with ~130-element slices and a stride of
+        // 64 some lane crossed in nearly every step — more LDS instructions than the accumulation itself, 4 dependent round trips a step).
+        auto rfl = [](int v) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(v); };
+        int sc = 0;
+        {
+            int sr = nb;      // last s in [0, nb) with seg_pre[s] <= e0 (seg_pre[0] = 0): uniform reads
+            while (sr - sc > 1) {
+                const int mid = (sc + sr) >> 1;
+                if (rfl(seg_pre[mid]) <= e0) sc = mid; else sr = mid;
+            }
         }
-        int seg = sl;
-        int seg_end = (seg + 1 < nb) ? seg_pre[seg + 1] : 0x7FFFFFFF;   // first flat index beyond the segment
-        int delta = seg_lo[seg] - seg_pre[seg];                          // m2 position = flat index + delta
-        float segv = seg_v1[seg];
-        const int idx_safe = efirst + delta;
+        int b = (sc + 1 < nb) ? rfl(seg_pre[sc + 1]) : 0x7FFFFFFF;      // first flat index beyond segment sc
+        int cur_delta = rfl(seg_lo[sc] - seg_pre[sc]);                   // m2 position = flat index + delta
+        float cur_v = __uint_as_float((unsigned)rfl((int)__float_as_uint(seg_v1[sc])));
+        const int idx_safe = e0 + cur_delta;                             // (element e0 is real)
         auto fetch = [&](int ebase, int (&c)[AU], float (&x)[AU], float (&v1)[AU], unsigned &valid) {
             typename std::conditional<BIG, unsigned long long, unsigned>::type off[AU];
             valid = 0;
 #pragma unroll
             for (int j = 0; j < AU; ++j) {
-                const int ej = ebase + 64 * j + lane;
+                const int rs = ebase + 64 * j;             // uniform
+                const int ej = rs + lane;
                 const bool ok = ej < e1;
-                if (ok && ej >= seg_end) {                 // rare: crossed into a later segment (skips empty ones)
-                    do {
-                        ++seg;
-                        seg_end = (seg + 1 < nb) ? seg_pre[seg + 1] : 0x7FFFFFFF;
-                    } while (ej >= seg_end);
-                    delta = seg_lo[seg] - seg_pre[seg];
-                    segv = seg_v1[seg];
+                const int last = min(rs + 63, e1 - 1);     // uniform
+                int my_delta = cur_delta;
+                float my_v = cur_v;
+                while (b <= last) {                        // uniform: a boundary at or before the step's last element (skips empty segments)
+                    ++sc;
+                    const int d_ = seg_lo[sc] - seg_pre[sc];
+                    const float v_ = seg_v1[sc];
+                    const int nxt = (sc + 1 < nb) ? seg_pre[sc + 1] : 0x7FFFFFFF;
+                    cur_delta = rfl(d_);
+                    cur_v = __uint_as_float((unsigned)rfl((int)__float_as_uint(v_)));
+                    if (ej >= b) { my_delta = cur_delta; my_v = cur_v; }
+                    b = rfl(nxt);
                 }
-                off[j] = (decltype(off[0] + 0))(unsigned)(ok ? ej + delta : idx_safe) << 2;
-                v1[j] = ok ? segv : 0.f;
+                off[j] = (decltype(off[0] + 0))(unsigned)(ok ? ej + my_delta : idx_safe) << 2;
+                v1[j] = ok ? my_v : 0.f;
                 valid |= ok ? (1u << j) : 0u;
             }
 #pragma unroll
@@ -398,7 +412,7 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                 // ceil(k / NW)-th largest of its lanes' maxima (as the sparse kernel's first stage does): the minimum over the waves is a raw
                 // dot that at least k columns of THIS window reach — when every wave had that many lanes with a live slot; else nothing
                 // changes.  One more pass over the window's sums in LDS, no pushes, two barriers. ----
-                if (dense && simple_judge && p.a1 == 1.f && p.bayes == 0.f && U_LDS && (p.k + NW - 1) / NW <= 32 && !(p.dbg & 131072)) {      // (bit 131072 of the ablation word: off, for A/B runs)
+                if (dense && simple_judge && p.a1 == 1.f && p.bayes == 0.f && U_LDS && (p.k + NW - 1) / NW <= 32 && !(p.dbg & 131072) && (!rc.have_thr || (p.dbg & 2097152))) {      // (bit 131072 of the ablation word: off, for A/B runs)
                     const float slope = any_norm ? rc.epi(1.f, 0.f, 1.f, 1.f) : 1.f;      // uniform: val = slope * xy
                     if (slope > 0.f && slope < __builtin_inff()) {      // uniform
                         unsigned lmax = 0u;
@@ -464,6 +478,31 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                             for (int b = 0; b < wn; b += 64) {
                                 if (sh[SH_RETRY]) break;                        // (U is full: what is left stays in the tile for the sweep after the selection)
                                 const int i = b + lane;
+                                if constexpr (SIMPLE) {
+                                    // an entry is a GROUP of four consecutive sums, dead ones already cleared by the sweep
+                                    int c[4];
+                                    float xy[4];
+                                    unsigned occ = 0;
+                                    int g4 = -1;
+                                    unsigned w[4] = {EMPTY32, EMPTY32, EMPTY32, EMPTY32};
+                                    if (i < wn) {
+                                        g4 = 4 * (int)wl[i];
+                                        const uint4 w4 = *(const uint4 *)&tabw[g4];
+                                        w[0] = w4.x; w[1] = w4.y; w[2] = w4.z; w[3] = w4.w;
+                                    }
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) {
+                                        c[j] = (w[j] != EMPTY32) ? wlo + g4 + j : EMPTY;
+                                        xy[j] = (w[j] != EMPTY32) ? __uint_as_float(w[j]) : 0.f;
+                                        if (w[j] != EMPTY32) occ |= 1u << j;
+                                    }
+                                    const unsigned done = emit_candidates<4>(p, rc, c, xy, occ, U, sh, p.cap, true);
+                                    if (occ) {
+#pragma unroll
+                                        for (int j = 0; j < 4; ++j) if (done & (1u << j)) w[j] = EMPTY32;
+                                        *(uint4 *)&tabw[g4] = make_uint4(w[0], w[1], w[2], w[3]);
+                                    }
+                                } else {
                                 int c[1];
                                 float xy[1];
                                 unsigned occ = 0;
@@ -476,6 +515,7 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                                 }
                                 const unsigned done = emit_candidates<1>(p, rc, c, xy, occ, U, sh, p.cap, SIMPLE);
                                 if (done & 1u) tabw[sidx] = EMPTY32;
+                                }
                             }
                             wn = 0;
                         };
@@ -486,6 +526,32 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                             uint4 w4 = make_uint4(EMPTY32, EMPTY32, EMPTY32, EMPTY32);
                             if (in) w4 = *(const uint4 *)&tabw[s4];
                             unsigned w[4] = {w4.x, w4.y, w4.z, w4.w};
+                            if constexpr (SIMPLE) {
+                                // (round 6) one compare per sum — an untouched slot's pattern and a NaN sum compare false (the exact test would drop
+                                // the NaN anyway) —, ONE ballot per trip: the lanes that hold a live sum append their GROUP of four to the wave's
+                                // list, everything else of the group is cleared by one 16-byte write.  More than half of the lanes live (no cutoff
+                                // yet): judged on the spot, below.
+                                bool lv[4];
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) lv[j] = __uint_as_float(w[j]) > rc.xy_cut;
+                                const bool any = (lv[0] | lv[1]) | (lv[2] | lv[3]);
+                                const u64 ma = __ballot(any);
+                                const int na = __popcll(ma);
+                                if (na <= 32) {
+                                    if (in) {
+#pragma unroll
+                                        for (int j = 0; j < 4; ++j) w[j] = lv[j] ? w[j] : EMPTY32;
+                                        *(uint4 *)&tabw[s4] = make_uint4(w[0], w[1], w[2], w[3]);
+                                    }
+                                    if (na) {
+                                        if (wn + na > WLCAP) flush();
+                                        if (any) wl[wn + mbcnt64(ma)] = (unsigned short)(s4 >> 2);
+                                        wn += na;
+                                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                                    }
+                                    continue;
+                                }
+                            }
                             bool live[4];
                             bool any_dead = false;
 #pragma unroll
@@ -496,7 +562,7 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                             }
                             const u64 m0 = __ballot(live[0]), m1 = __ballot(live[1]), m2 = __ballot(live[2]), m3 = __ballot(live[3]);
                             const int tot = (__popcll(m0) + __popcll(m1)) + (__popcll(m2) + __popcll(m3));
-                            if (tot > WLCAP / 2) {
+                            if (SIMPLE || tot > WLCAP / 2) {
                                 // mostly live (no cutoff yet): judged on the spot
                                 int c[4];
                                 float xy[4];
