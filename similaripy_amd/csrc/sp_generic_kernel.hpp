@@ -241,28 +241,34 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
 
             // dense windows can never overflow (one slot per column); hash windows are sized from the
             // MACs bound and split on overflow.  Window width w; windows are [lo, lo+w).
-            const long long Td = 2LL * T;       // columns of a dense window (32-bit sums)
-            long long width;
+            // (All of this is 32-bit arithmetic with shifts for the powers of two — T, the fine window width — since round 6: the 64-bit divisions
+            // and remainders it used to be are ~100 VALU instructions each, every wave computes them, and with four waves on a SIMD the
+            // dozen of them per row and window were ~5 k cycles of every window: most of what the phase counter calls "segments".)
+            const int Td = 2 * T;               // columns of a dense window (32-bit sums)
+            int width;
             if (p.n_cols <= Td) {
                 width = p.n_cols;
             } else {
-                const long long p_dense = ((long long)p.n_cols + Td - 1) / Td;
-                const long long p_hash = (long long)((macs + (u64)p.hash_fill - 1) / (u64)p.hash_fill);
-                if (p_hash < 1 || p_dense <= p_hash) width = Td;
-                else width = ((long long)p.n_cols + p_hash - 1) / p_hash;
+                const unsigned p_dense = ((unsigned)p.n_cols + (unsigned)Td - 1u) >> (p.logT + 1);
+                const unsigned m32 = (unsigned)macs, hf = (unsigned)max(1, p.hash_fill);      // (macs: saturated at 2^32 - 1 by the work prepass)
+                const unsigned q = m32 / hf;
+                const unsigned p_hash = q + ((m32 - q * hf) != 0u ? 1u : 0u);
+                if (p_hash < 1u || p_dense <= p_hash) width = Td;
+                else width = (int)(((unsigned)p.n_cols + p_hash - 1u) / p_hash);
             }
+            const int split_shift = 31 - __builtin_clz((unsigned)max(1, p.split_w));      // (the fine window width is a power of two: 2T / f, make_config)
+            const int split_mask = (1 << split_shift) - 1;
 
-            long long lo = 0, col_end = p.n_cols;
+            int lo = 0, col_end = p.n_cols;
             bool first_window = true;      // of this row or piece (uniform)
             if (piece >= 0) {       // (the splitter only cuts rows of a call with standard windows: n_cols > Td)
                 width = Td;
-                lo = (long long)(piece_range & 0xFFFF) * p.split_w;
-                col_end = min((long long)p.n_cols, (long long)(piece_range >> 16) * p.split_w);
+                lo = (int)min((long long)p.n_cols, (long long)(piece_range & 0xFFFF) << split_shift);
+                col_end = (int)min((long long)p.n_cols, (long long)(piece_range >> 16) << split_shift);
             }
             while (lo < col_end) {
-                long long hi = lo + width;
-                if (hi > col_end) hi = col_end;
-                const int wlo = (int)lo, whi = (int)hi;
+                const int hi = (col_end - lo <= width) ? col_end : lo + width;
+                const int wlo = lo, whi = hi;
                 const bool dense = (hi - lo) <= Td;
                 const bool whole = (wlo == 0 && whi == p.n_cols);
                 if (dense != tab32) {           // (uniform; the previous drain ended with a barrier)
@@ -286,7 +292,7 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                 // Window slices chain (hi of window w == lo of window w+1), so when the m1 row fits one
                 // batch the previous slice end is kept in LDS and only one lower_bound per window is run.
                 const bool carry = (n1 <= NT);
-                const bool use_splits = have_splits && width == Td && (lo % p.split_w) == 0 && (hi == p.n_cols || (hi % p.split_w) == 0);   // (a hashed row halved down to Td may sit elsewhere)
+                const bool use_splits = have_splits && width == Td && (lo & split_mask) == 0 && (hi == p.n_cols || (hi & split_mask) == 0);   // (a hashed row halved down to Td may sit elsewhere)
                 for (int b0 = 0; b0 < n1; b0 += NT) {
                     const int nb = min(NT, n1 - b0);
                     int len = 0;
@@ -295,8 +301,8 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                         int r0 = p.m2_indptr[u], r1 = p.m2_indptr[u + 1];
                         if (!whole && use_splits) {
                             // both ends are multiples of the fine window width: their positions were found once per call (sp_m2_splits_kernel)
-                            if (wlo != 0) r0 = p.splits[(size_t)(wlo / p.split_w - 1) * (size_t)p.splits_rows + (size_t)u];
-                            if (whi < p.n_cols) r1 = p.splits[(size_t)(whi / p.split_w - 1) * (size_t)p.splits_rows + (size_t)u];
+                            if (wlo != 0) r0 = p.splits[(size_t)((wlo >> split_shift) - 1) * (size_t)p.splits_rows + (size_t)u];
+                            if (whi < p.n_cols) r1 = p.splits[(size_t)((whi >> split_shift) - 1) * (size_t)p.splits_rows + (size_t)u];
                         } else if (!whole) {
                             // slice of the sorted m2 row inside [wlo, whi)  (s_plus.h:385-394)
                             if (wlo != 0) {
@@ -396,7 +402,7 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                     if (ovf) {
                         for (int i = tid; i < t_eff; i += NT) tab[i] = EMPTY64;
                         if (tid == 0) sh[SH_OVF] = 0;
-                        width = max((long long)T, (width + 1) / 2);
+                        width = max(T, (width >> 1) + (width & 1));
                         retry_window = true;  // same lo again: slice starts are still in seg_lo
                         __syncthreads();
                         continue;
