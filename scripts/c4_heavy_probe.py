@@ -33,7 +33,7 @@ print(f"rows {macs.shape[0]}, MACs {macs.sum() / 1e9:.2f} G; heavy rows {int(hea
       f"{n1[heavy].sum() / 1e6:.2f} M m1 entries (of {n1.sum() / 1e6:.2f} M); MACs per m1 entry heavy {macs[heavy].sum() / n1[heavy].sum():.0f} light {macs[~heavy].sum() / n1[~heavy].sum():.0f}", flush=True)
 prob = DeviceProblem(call)
 cols, vals, counts, _ = prob.alloc_outputs()
-names = ("setup", "segments", "accumulate", "drain", "select", "output")
+names = ("setup", "segments", "accumulate", "drain", "select", "output", "sweep1", "sweep2")
 for label, sel in (("all", np.ones_like(heavy)), ("heavy", heavy), ("light", ~heavy)):
     t = torch.from_numpy(np.nonzero(sel)[0].astype(np.int32)).cuda()
     kw = dict(tune, **(dict(dbg=dbg) if dbg else {}))
@@ -41,6 +41,6 @@ for label, sel in (("all", np.ones_like(heavy)), ("heavy", heavy), ("light", ~he
     ms = min(prob.run(cols, vals, counts, targets=t, time_kernel=True, phase_timers=False, **kw)["kernel_ms"] for _ in range(3))
     info = prob.run(cols, vals, counts, targets=t, time_kernel=True, **kw)
     cyc = info.get("phase_cycles", [0] * 12)
-    tot = float(sum(cyc[:6])) or 1.0
-    print(f"{label:6s} rows {int(sel.sum()):6d}  kernel {ms:7.2f} ms   " + "  ".join(f"{n} {c / tot:.3f}" for n, c in zip(names, cyc[:6])) +
+    tot = float(sum(cyc[:8])) or 1.0
+    print(f"{label:6s} rows {int(sel.sum()):6d}  kernel {ms:7.2f} ms   " + "  ".join(f"{n} {c / tot:.3f}" for n, c in zip(names, cyc[:8])) +
           f"   windows {cyc[11] & 0xFFFFFFFF}  wgs {info.get('num_wgs')}   MACs/clk/CU {macs[sel].sum() / (ms * 1e-3 * 2.4e9 * 256):.2f}", flush=True)

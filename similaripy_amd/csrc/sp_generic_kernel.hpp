@@ -266,6 +266,13 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                 lo = (int)min((long long)p.n_cols, (long long)(piece_range & 0xFFFF) << split_shift);
                 col_end = (int)min((long long)p.n_cols, (long long)(piece_range >> 16) << split_shift);
             }
+            // A light row's NEXT window (round 6): the m1 row fits one batch, so thread i keeps segment i's m2 row, m1 value and this window's
+            // end — the next window's start — in registers and asks for the next window's end (one gather from the boundary table) while
+            // this window is accumulated and drained: the window after the first starts without a load (the two dependent round trips, m1
+            // entry -> boundary positions, were 1.3 k + 3.7 k cycles of every window, and the waves' skew on them most of the scan's barrier).
+            int pf_u = 0, pf_r0 = 0, pf_r1 = 0;
+            float pf_v = 0.f;
+            bool pf_have = false;          // (uniform) the registers hold the window that comes now
             while (lo < col_end) {
                 const int hi = (col_end - lo <= width) ? col_end : lo + width;
                 const int wlo = lo, whi = hi;
@@ -296,9 +303,27 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                 for (int b0 = 0; b0 < n1; b0 += NT) {
                     const int nb = min(NT, n1 - b0);
                     int len = 0;
+                    // the window after this one, when it is a standard dense window of the boundary table too (dense windows never overflow:
+                    // the loop below arrives at exactly these bounds)
+                    const int nhi = (col_end - hi <= width) ? col_end : hi + width;
+                    const bool pf_next = carry && use_splits && dense && hi < col_end && (hi & split_mask) == 0 && (nhi == p.n_cols || (nhi & split_mask) == 0) &&
+                                         !(p.dbg & 4194304);      // (bit 4194304 of the ablation word: off, for A/B runs)
+                    if (pf_have) {
+                        if (tid < nb) {
+                            seg_lo[tid] = pf_r0;
+                            seg_v1[tid] = pf_v;
+                            len = pf_r1 - pf_r0;
+                            pf_r0 = pf_r1;
+                            if (pf_next) pf_r1 = (nhi < p.n_cols) ? p.splits[(size_t)((nhi >> split_shift) - 1) * (size_t)p.splits_rows + (size_t)pf_u] : p.m2_indptr[pf_u + 1];
+                        }
+                    } else
                     if (tid < nb) {
                         const int u = p.m1_indices[s1 + b0 + tid];
                         int r0 = p.m2_indptr[u], r1 = p.m2_indptr[u + 1];
+                        if (pf_next) {
+                            pf_u = u;
+                            pf_r1 = (nhi < p.n_cols) ? p.splits[(size_t)((nhi >> split_shift) - 1) * (size_t)p.splits_rows + (size_t)u] : r1;
+                        }
                         if (!whole && use_splits) {
                             // both ends are multiples of the fine window width: their positions were found once per call (sp_m2_splits_kernel)
                             if (wlo != 0) r0 = p.splits[(size_t)((wlo >> split_shift) - 1) * (size_t)p.splits_rows + (size_t)u];
@@ -313,9 +338,12 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                             if (carry) seg_hi[tid] = r1;
                         }
                         seg_lo[tid] = r0;
-                        seg_v1[tid] = p.m1_data[s1 + b0 + tid];
+                        const float v = p.m1_data[s1 + b0 + tid];
+                        seg_v1[tid] = v;
                         len = r1 - r0;
+                        pf_r0 = r1; pf_v = v;
                     }
+                    pf_have = pf_next;
                     const int total = scan_segments(len);
                     PHASE_END(PH_SEGMENTS);
 
@@ -525,12 +553,8 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                             }
                             wn = 0;
                         };
-                        for (int base = 0; base < t_eff; base += 4 * NT) {
-                            if (sh[SH_RETRY]) break;         // (one LDS word, the same for every lane: wave-uniform)
-                            const int s4 = base + 4 * tid;
-                            const bool in = s4 < t_eff && s4 + 3 < 2 * T;
-                            uint4 w4 = make_uint4(EMPTY32, EMPTY32, EMPTY32, EMPTY32);
-                            if (in) w4 = *(const uint4 *)&tabw[s4];
+                        // one step of the sweep: a thread's four consecutive sums (already read)
+                        auto step = [&](int s4, bool in, const uint4 &w4) __attribute__((always_inline)) {
                             unsigned w[4] = {w4.x, w4.y, w4.z, w4.w};
                             if constexpr (SIMPLE) {
                                 // (round 6) one compare per sum — an untouched slot's pattern and a NaN sum compare false (the exact test would drop
@@ -555,7 +579,7 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                                         wn += na;
                                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                                     }
-                                    continue;
+                                    return;
                                 }
                             }
                             bool live[4];
@@ -583,7 +607,7 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) if (done & (1u << j)) w[j] = EMPTY32;
                                 if (in && occ) *(uint4 *)&tabw[s4] = make_uint4(w[0], w[1], w[2], w[3]);
-                                continue;
+                                return;
                             }
                             if (any_dead) {      // the dead ones are consumed here: one 16-byte write (live sums are written back as they are)
 #pragma unroll
@@ -602,6 +626,14 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                                 wn += __popcll(m3);
                                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                             }
+                        };
+                        for (int base = 0; base < t_eff; base += 4 * NT) {
+                            if (sh[SH_RETRY]) break;         // (one LDS word, the same for every lane: wave-uniform)
+                            const int s4 = base + 4 * tid;
+                            const bool in = s4 < t_eff && s4 + 3 < 2 * T;
+                            uint4 w4 = make_uint4(EMPTY32, EMPTY32, EMPTY32, EMPTY32);
+                            if (in) w4 = *(const uint4 *)&tabw[s4];
+                            step(s4, in, w4);
                         }
                         if (wn) flush();
                         };
