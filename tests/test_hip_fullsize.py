@@ -56,10 +56,12 @@ def _sample_with_queue_tail(macs, seed):
 #   heavier rows: their values are float32 sums of 10^5 .. 10^6 products; the REFERENCE's float32 result is itself up to 1.4e-5 from the
 #   float64 value there (sqrt(n) * 2^-24 for n = 2e5 is 2.7e-5), so "within 1e-5 of the reference" cannot be asked of two float32 sums in
 #   different orders.  What is asked instead, as a fixed regression bound and not a formula over the reference's error: HIP within
-#   HEAVY_F64_BOUND = 1.5e-5 of the FLOAT64 value (observed over 5 020 rows of each call: profiles/r06_c4_value_errors.txt).
+#   HEAVY_F64_BOUND = 2e-5 of the FLOAT64 value.  The HIP sums are LDS atomics in whatever order the waves arrive: the same build gives
+#   1.27e-5 .. 1.52e-5 on the heaviest rows from run to run (the sequential reference: 1.40e-5 every time; observed over 5 018 rows of each
+#   call: profiles/r06_c4_value_errors.txt) — a bound of 1.5e-5, the round's first choice, failed one run in about ten.
 #   Column sets: a column on one side only must lie within 2.5 x the row's bar of the k-th place (both selections are exact on their own
 #   float32 values, each within the bar of the float64 one).
-HEAVY_F64_BOUND = 1.5e-5
+HEAVY_F64_BOUND = 2e-5
 LIGHT_MACS = 1_000_000
 
 
