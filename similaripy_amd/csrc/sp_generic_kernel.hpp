@@ -460,12 +460,14 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                         }
                         if (tid == 0) { sh[SH_SEL] = -1; sh[SH_NEED] = 1; }
                         __syncthreads();
+                        // the wave's ceil(k / NW)-th largest lane maximum, from below: the largest T (of the keys' upper 24 bits) that so many
+                        // lanes reach — a bit-wise search, one compare and a scalar count per bit (round 6; it was `rounds` extractions of the
+                        // wave's maximum, ~220 vector instructions on a SIMD that four waves share); 0 when the wave has too few live lanes
                         const int rounds = (p.k + NW - 1) / NW;
-                        unsigned rest = lmax, tw = 0u;
-                        for (int r = 0; r < rounds; ++r) {
-                            const unsigned mx = wave_max_u32(rest);
-                            tw = mx;                                   // 0 once the wave has run out of live lanes
-                            rest = (rest >= mx) ? 0u : rest;
+                        unsigned tw = 0u;
+                        for (int bit = 31; bit >= 8; --bit) {
+                            const unsigned cand = tw | (1u << bit);
+                            if (__popcll(__ballot(lmax >= cand)) >= rounds) tw = cand;      // uniform
                         }
                         if (lane == 0) { if (tw != 0u) atomicMin((unsigned *)&sh[SH_SEL], tw); else sh[SH_NEED] = 0; }
                         __syncthreads();
