@@ -404,7 +404,7 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
     if (c->wave) {
         // (the workgroup-per-row kernel keeps its 256-thread shape beside it: sparse rows the wave kernel does not take — more than 64 m1
         // entries, more products than its 63 trips hold — have a queue of their own and run there, as in round 3)
-        const int wv_a = a->n_output_cols <= 8 * WV_A_SMALL ? WV_A_SMALL : WV_A_LARGE;      // the column bitmap: eleven or nine rows in flight per CU
+        const int wv_a = wv_region_bytes(a->n_output_cols);      // the column bitmap: twelve, eleven or nine rows in flight per CU
         c->wgs_wave = std::max(1, std::min(a->num_wgs > 0 ? a->num_wgs : n_cus * (int)(LDS_LIMIT / wv_lds_bytes(wv_a)), std::max(1, a->n_targets)));
     }
     c->ws_total = WS_QUEUE_BYTES + c->ws_gu_bytes + c->ws_fold_bytes + c->ws_rows_bytes + c->ws_split_bytes + c->ws_piece_bytes + c->ws_items_bytes;
@@ -550,7 +550,10 @@ int launch_rows(const KParams &kp_s, const KParams &kp, const Config &c, hipStre
         kp_w.queue = kp_s.queue + 6;
         kp_w.qcount = kp_s.queue + 7;
         kp_w.desc = kp_s.desc + 2 * (size_t)kp_s.n_targets;
-        if (kp_s.n_cols <= 8 * WV_A_SMALL) {
+        if (wv_region_bytes(kp_s.n_cols) == WV_A_TIGHT) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(sp_knn_wave_kernel<WV_A_TIGHT>), hipFuncAttributeMaxDynamicSharedMemorySize, wv_lds_bytes(WV_A_TIGHT)));
+            hipLaunchKernelGGL(sp_knn_wave_kernel<WV_A_TIGHT>, dim3(c.wgs_wave), dim3(64), wv_lds_bytes(WV_A_TIGHT), stream, kp_w);
+        } else if (wv_region_bytes(kp_s.n_cols) == WV_A_SMALL) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(sp_knn_wave_kernel<WV_A_SMALL>), hipFuncAttributeMaxDynamicSharedMemorySize, wv_lds_bytes(WV_A_SMALL)));
             hipLaunchKernelGGL(sp_knn_wave_kernel<WV_A_SMALL>, dim3(c.wgs_wave), dim3(64), wv_lds_bytes(WV_A_SMALL), stream, kp_w);
         } else {

@@ -183,11 +183,13 @@ __global__ __launch_bounds__(256) void sp_row_desc_kernel(int n_targets, const i
             }
         }
         wavey = (sparse && cp.wave && (e - s) <= 64 && macs <= cp.wave_macs_max) || duo_l_row;
-        if (wavey && !duo_l_row && cp.n_cols > (1 << 17)) {
-            // the wave kernel's column bitmap has 2^17 bits: beyond, aliased columns are marked like true collisions and must fit the 512
-            // direct slots of its collision set with room to spare
+        if (wavey && !duo_l_row) {
+            // the wave kernel's collision set has 384 rank-addressed slots (sp_wave_kernel.hpp WV_CS_DIRECT): the row's expected marks must fit
+            // with room to spare (307 is also what the 256-thread shape's own rule admits).  Its column bitmap has 2^17 bits: beyond,
+            // aliased columns are marked like true collisions (and the bar is lower: 230).
             const float m = (float)macs;
-            wavey = 0.5f * m * m * (1.f / (float)cp.n_cols + 1.f / (float)(1 << 17)) <= 0.45f * 512.f;
+            const bool alias = cp.n_cols > (1 << 17);
+            wavey = 0.5f * m * m * (1.f / (float)cp.n_cols + (alias ? 1.f / (float)(1 << 17) : 0.f)) <= (alias ? 0.6f : 0.8f) * 384.f;
         }
     }
     // heavy generic rows: one queue entry per piece

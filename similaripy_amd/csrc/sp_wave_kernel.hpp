@@ -44,23 +44,31 @@ namespace {
 constexpr int WV_BM_LOG2 = 17;                                  // column bitmap: up to 2^17 bits
 constexpr int WV_CBM_BYTES = 1024;                              // collision bitmap: 8192 bits
 constexpr int WV_PRE_BYTES = 512;                               // u16 rank prefix per collision-bitmap word
-constexpr int WV_CSN = 1024;                                    // collision-set slots: [0, 512) by rank, [512, 1024) overflow
+constexpr int WV_CS_DIRECT = 384, WV_CS_OVER = 512;             // collision-set slots: [0, 384) by rank, 512 overflow slots behind them
+constexpr int WV_CSN = WV_CS_DIRECT + WV_CS_OVER;
 constexpr int WV_UCAP = 256;                                    // candidate buffer entries (four per lane)
 constexpr int WV_KMAX = 128;                                    // k + 64 <= UCAP must hold with room to spare
-constexpr int WV_OFF_PRE = WV_CBM_BYTES;
-constexpr int WV_OFF_A = WV_CBM_BYTES + WV_PRE_BYTES;
-constexpr int WV_OFF_MP = WV_OFF_A + WV_CSN * 8;
-// Region A is the column bitmap during sweep 1 and afterwards [collision set 8 KB | member pool | U 2 KB].  Two sizes:
-//   12 800 B (102 400 columns): member pool 320 entries, 14 336 B of LDS per wave = ELEVEN rows in flight per CU;
-//   16 384 B (131 072 columns): member pool 768 entries, 17 920 B per wave = nine rows per CU.
+constexpr int WV_OFF_A = WV_CBM_BYTES;
+constexpr int WV_OFF_PRE = WV_OFF_A + WV_CSN * 8;               // the rank prefix lies INSIDE region A (it is built after sweep 1, when the bitmap is gone)
+constexpr int WV_OFF_MP = WV_OFF_PRE + WV_PRE_BYTES;
+// Region A is the column bitmap during sweep 1 and afterwards [collision set 7 KB | rank prefix 512 B | member pool | U 2 KB].  Three sizes:
+//   12 512 B (100 096 columns): member pool 348 entries, 13 536 B of LDS per wave = TWELVE rows in flight per CU;
+//   12 800 B (102 400 columns): member pool 384 entries, 13 824 B per wave = eleven rows per CU;
+//   16 384 B (131 072 columns): member pool 832 entries, 17 408 B per wave = nine rows per CU.
+// (Round 6, late: rows in flight are what this kernel's time follows — padding its LDS to ten / eight rows per CU cost 8.7 % / 20 % — and
+// 14 336 B per wave were eleven.  The twelfth comes from the rank prefix moving into region A and 128 rank-addressed slots less: a row
+// of this kernel marks ~200 columns, the classification admits an expectation of 307.)
 // The member pool is small on purpose: when a trip's members do not fit, the pool is folded into the collision set right away
 // (wave_accumulate) and starts over — LDS per wave is what bounds the rows in flight, and those are what hides this kernel's latencies.
-constexpr int WV_A_SMALL = 12800, WV_A_LARGE = 16384;
-__host__ __device__ constexpr int wv_mpcap(int a_bytes) { return (a_bytes - WV_CSN * 8 - WV_UCAP * 8) / 8; }
+constexpr int WV_A_TIGHT = 12512, WV_A_SMALL = 12800, WV_A_LARGE = 16384;
+__host__ __device__ constexpr int wv_mpcap(int a_bytes) { return (a_bytes - WV_CSN * 8 - WV_PRE_BYTES - WV_UCAP * 8) / 8; }
 __host__ __device__ constexpr int wv_off_u(int a_bytes) { return WV_OFF_A + a_bytes - WV_UCAP * 8; }
 __host__ __device__ constexpr int wv_lds_bytes(int a_bytes) { return WV_OFF_A + a_bytes; }
-static_assert(wv_mpcap(WV_A_SMALL) >= 256 + 64, "a trip's members (<= 256) fit an empty pool, the filter's pseudo members a fresh one");
-static_assert(11 * wv_lds_bytes(WV_A_SMALL) <= 160 * 1024 && 9 * wv_lds_bytes(WV_A_LARGE) <= 160 * 1024, "rows per CU");
+static_assert(wv_mpcap(WV_A_TIGHT) >= 256 + 64, "a trip's members (<= 256) fit an empty pool, the filter's pseudo members a fresh one");
+static_assert(12 * wv_lds_bytes(WV_A_TIGHT) <= 160 * 1024 && 11 * wv_lds_bytes(WV_A_SMALL) <= 160 * 1024 && 9 * wv_lds_bytes(WV_A_LARGE) <= 160 * 1024, "rows per CU");
+static_assert((WV_CS_OVER & (WV_CS_OVER - 1)) == 0 && WV_OFF_PRE % 16 == 0 && WV_A_TIGHT % 16 == 0, "layout");
+// the host's choice of the region (make_config, the launch)
+__host__ __device__ constexpr int wv_region_bytes(int n_cols) { return n_cols <= 8 * WV_A_TIGHT ? WV_A_TIGHT : n_cols <= 8 * WV_A_SMALL ? WV_A_SMALL : WV_A_LARGE; }
 
 // Sweep 2 core for a collision bitmap of WV_CBM_BYTES at LDS offset 0 (sp_common.hpp's s2_core with this kernel's mask).
 // Element j of a lane is real iff j < d: both masks come out cut to the real elements (the cuts in the asm: left to the compiler they
@@ -237,8 +245,8 @@ __device__ __attribute__((noinline)) WaveUState wave_push_slow(u64 *U, unsigned 
 // kernel needs (its slots are contended).  Returns true when the set is full (the row goes to the generic kernel).
 __device__ __attribute__((noinline)) bool wave_accumulate(u64 *cs, const u64 *mpool, const unsigned char *cbm, const unsigned short *pre16, int mcnt, int lane) {
     auto next_slot = [&](unsigned h, unsigned key) __attribute__((always_inline)) -> unsigned {
-        const unsigned half = (unsigned)(WV_CSN / 2);
-        return (h < half) ? half + hash_bits((int)key, 2654435761u, 32 - 9) : half + ((h + 1u) & (half - 1u));
+        const unsigned dir = (unsigned)WV_CS_DIRECT, ovr = (unsigned)WV_CS_OVER;      // (512 overflow slots: a 9-bit hash)
+        return (h < dir) ? dir + hash_bits((int)key, 2654435761u, 32 - 9) : dir + ((h - dir + 1u) & (ovr - 1u));
     };
     constexpr int JA = 4;
     unsigned *csw = (unsigned *)cs;                      // word 2h: the sum, word 2h + 1: the key
@@ -469,7 +477,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
                 const int ex = incl - tot;
                 ((u64 *)pre16)[lane] = (u64)(unsigned)(ex & 0xFFFF) | ((u64)(unsigned)((ex + p0) & 0xFFFF) << 16) |
                                        ((u64)(unsigned)((ex + p1) & 0xFFFF) << 32) | ((u64)(unsigned)((ex + p2) & 0xFFFF) << 48);
-                if (__builtin_amdgcn_readlane(incl, 63) > WV_CSN / 2) failed = true;      // more marked columns than direct slots
+                if (__builtin_amdgcn_readlane(incl, 63) > WV_CS_DIRECT) failed = true;      // more marked columns than direct slots
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             // every excluded column gets a pseudo member of value -inf: its sum is then below any cutoff
@@ -594,10 +602,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
                 u64 e[4];
                 bool want[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) e[j] = cs[base + j * 64 + lane];
+                for (int j = 0; j < 4; ++j) e[j] = (base + j * 64 < WV_CSN) ? cs[base + j * 64 + lane] : 0ull;      // (the set's 896 slots: the last trip holds two quads)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    cs[base + j * 64 + lane] = 0ull;
+                    if (base + j * 64 < WV_CSN) cs[base + j * 64 + lane] = 0ull;
                     want[j] = (e[j] != 0ull) && !(__uint_as_float((unsigned)e[j]) <= cutx);
                 }
                 if (p.filter_mode == SP_SEL_MATRIX) {
