@@ -143,6 +143,18 @@ def test_generic_kernel_heavy_rows_in_pieces(name, kw):
     _check(_host.prepare(_rand((9000, 300), 0.05, 9), k=700, **kw), name + "/k700", table_slots=1024, dbg=8192)
 
 
+@pytest.mark.parametrize("name,kw", KERNEL_PARAMS, ids=[p[0] for p in KERNEL_PARAMS])
+def test_generic_kernel_window_chain_ablations(name, kw):
+    """Dense windows of the generic kernel chain: a light row (its m1 entries fit one batch) asks for its NEXT window's bounds one window
+    ahead, and the selection-free cutoff pass in front of the drain stops once the row has a cutoff (round 6).  Both against the oracle
+    with the step switched off (bits 4194304 / 2097152 of the ablation word) and on, on a shape of five windows per row — tile 1024,
+    dense windows of 2048 columns — with the boundary table in use (more than 64 generic rows), and with target rows out of order."""
+    m = _rand((9000, 500), 0.06, 17)          # m2 = m.T: 500 x 9000
+    for dbg in (0, 4194304, 2097152, 4194304 | 2097152):
+        _check(_host.prepare(m, k=40, **kw), f"{name}/dbg={dbg}", table_slots=1024, dbg=dbg)
+    _check(_host.prepare(m, k=40, target_rows=np.array([8999, 5, 5, 4100, 77, 3000], dtype=np.int32), **kw), name + "/targets", table_slots=1024)
+
+
 def test_hash_overflow_retry():
     """Candidates concentrated in a narrow column range defeat the MACs-based window estimate: the
     hashed window overflows its probe budget, is discarded, halved and retried (several times, down
