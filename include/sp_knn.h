@@ -209,7 +209,8 @@ typedef struct sp_knn_args {
                                      131072  generic kernel: no selection-free cutoff in front of a dense window's drain
                                      262144  generic kernel: the drain judges in the sweep (round-4 form) instead of sorting live slots first
                                     2097152  generic kernel: the selection-free cutoff pass runs in front of EVERY dense window's drain (it stops once the row has a cutoff)
-                                    4194304  generic kernel: a light row's next window is NOT requested one window ahead (scripts/c4_heavy_probe.py A/B)
+                                    4194304  generic kernel: a light row's next window / a heavy row's next batch of m1 entries is NOT requested ahead (scripts/c4_heavy_probe.py A/B;
+                                             test_generic_kernel_window_chain_ablations)
                                     1048576  sparse kernel, two-per-CU shape: no second launch in the larger layout (rows over the first's limit go to the generic kernel)
                                      524288  sparse kernel: no two-per-CU (DUO) shape (scripts/c2_phases.py A/B; test_duo_shape_against_the_oracle_and_the_classic_shape)
                                     PROFILING ablations (results are WRONG; the sweep-body ones compiled in only with -DSP_ABLATION=1):

@@ -300,9 +300,31 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                 // batch the previous slice end is kept in LDS and only one lower_bound per window is run.
                 const bool carry = (n1 <= NT);
                 const bool use_splits = have_splits && width == Td && (lo & split_mask) == 0 && (hi == p.n_cols || (hi & split_mask) == 0);   // (a hashed row halved down to Td may sit elsewhere)
+                // A row of SEVERAL batches (more m1 entries than threads: the heavy rows and their pieces) on the boundary table: the NEXT batch's
+                // entry, slice bounds and m1 value are requested while this batch is scanned and accumulated (in the registers a light row keeps its
+                // next window in: a row is one or the other) — the two dependent round trips in front of every batch of ~14 k products were a
+                // seventh of a heavy row's time.
+                const bool bpf = !carry && (use_splits || whole) && !(p.dbg & 4194304);
+                auto batch_request = [&](int bq) __attribute__((always_inline)) {
+                    if (tid < min(NT, n1 - bq)) {
+                        const int u = p.m1_indices[s1 + bq + tid];
+                        pf_r0 = (wlo != 0) ? p.splits[(size_t)((wlo >> split_shift) - 1) * (size_t)p.splits_rows + (size_t)u] : p.m2_indptr[u];
+                        pf_r1 = (whi < p.n_cols) ? p.splits[(size_t)((whi >> split_shift) - 1) * (size_t)p.splits_rows + (size_t)u] : p.m2_indptr[u + 1];
+                        pf_v = p.m1_data[s1 + bq + tid];
+                    }
+                };
+                if (bpf) batch_request(0);
                 for (int b0 = 0; b0 < n1; b0 += NT) {
                     const int nb = min(NT, n1 - b0);
                     int len = 0;
+                    if (bpf) {
+                        if (tid < nb) {
+                            seg_lo[tid] = pf_r0;
+                            seg_v1[tid] = pf_v;
+                            len = pf_r1 - pf_r0;
+                        }
+                        if (b0 + NT < n1) batch_request(b0 + NT);
+                    } else {
                     // the window after this one, when it is a standard dense window of the boundary table too (dense windows never overflow:
                     // the loop below arrives at exactly these bounds)
                     const int nhi = (col_end - hi <= width) ? col_end : hi + width;
@@ -344,6 +366,7 @@ __global__ __launch_bounds__(NT) void sp_knn_generic_kernel(const KParams p) {
                         pf_r0 = r1; pf_v = v;
                     }
                     pf_have = pf_next;
+                    }
                     const int total = scan_segments(len);
                     PHASE_END(PH_SEGMENTS);
 
