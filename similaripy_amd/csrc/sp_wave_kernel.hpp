@@ -52,7 +52,7 @@ constexpr int WV_OFF_A = WV_CBM_BYTES;
 constexpr int WV_OFF_PRE = WV_OFF_A + WV_CSN * 8;               // the rank prefix lies INSIDE region A (it is built after sweep 1, when the bitmap is gone)
 constexpr int WV_OFF_MP = WV_OFF_PRE + WV_PRE_BYTES;
 // Region A is the column bitmap during sweep 1 and afterwards [collision set 7 KB | rank prefix 512 B | member pool | U 2 KB].  Three sizes:
-//   12 512 B (100 096 columns): member pool 348 entries, 13 536 B of LDS per wave = TWELVE rows in flight per CU;
+//   12 624 B (100 992 columns): member pool 362 entries, 13 648 B of LDS per wave = TWELVE rows in flight per CU (12 x 13 648 = 163 776 of 163 840);
 //   12 800 B (102 400 columns): member pool 384 entries, 13 824 B per wave = eleven rows per CU;
 //   16 384 B (131 072 columns): member pool 832 entries, 17 408 B per wave = nine rows per CU.
 // (Round 6, late: rows in flight are what this kernel's time follows — padding its LDS to ten / eight rows per CU cost 8.7 % / 20 % — and
@@ -60,7 +60,7 @@ constexpr int WV_OFF_MP = WV_OFF_PRE + WV_PRE_BYTES;
 // of this kernel marks ~200 columns, the classification admits an expectation of 307.)
 // The member pool is small on purpose: when a trip's members do not fit, the pool is folded into the collision set right away
 // (wave_accumulate) and starts over — LDS per wave is what bounds the rows in flight, and those are what hides this kernel's latencies.
-constexpr int WV_A_TIGHT = 12512, WV_A_SMALL = 12800, WV_A_LARGE = 16384;
+constexpr int WV_A_TIGHT = 12624, WV_A_SMALL = 12800, WV_A_LARGE = 16384;
 __host__ __device__ constexpr int wv_mpcap(int a_bytes) { return (a_bytes - WV_CSN * 8 - WV_PRE_BYTES - WV_UCAP * 8) / 8; }
 __host__ __device__ constexpr int wv_off_u(int a_bytes) { return WV_OFF_A + a_bytes - WV_UCAP * 8; }
 __host__ __device__ constexpr int wv_lds_bytes(int a_bytes) { return WV_OFF_A + a_bytes; }

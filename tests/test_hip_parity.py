@@ -1234,10 +1234,10 @@ def _ran_on_the_wave_kernel(call, **tuning):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_items", [100_096, 100_097, 102_400, 102_401])
+@pytest.mark.parametrize("n_items", [100_992, 100_993, 102_400, 102_401])
 def test_wave_kernel_region_sizes(n_items):
-    """The wave kernel's LDS region comes in three sizes (sp_wave_kernel.hpp: 12 512 / 12 800 / 16 384 bytes = twelve / eleven / nine rows in
-    flight per CU, one bit per column up to 100 096 / 102 400 columns): catalogues at both sides of each limit, with the last columns of
+    """The wave kernel's LDS region comes in three sizes (sp_wave_kernel.hpp: 12 624 / 12 800 / 16 384 bytes = twelve / eleven / nine rows in
+    flight per CU, one bit per column up to 100 992 / 102 400 columns): catalogues at both sides of each limit, with the last columns of
     the catalogue in use (the bitmap's last bytes, next to the candidate buffer at the region's end), against the oracle."""
     urm, wt = _scoring_problem(n_users=3000, n_items=n_items, per_user=40, per_item=60, seed=21)
     rng = np.random.default_rng(5)
@@ -1252,7 +1252,7 @@ def test_wave_kernel_region_sizes(n_items):
         ran, info = _ran_on_the_wave_kernel(call, threads_per_wg=64)
         assert ran, f"the wave kernel was not chosen ({info['num_wgs']} workgroups)"
         cus = int(_abi.backend_info(0).split("CUs=")[1].split()[0])
-        want = 12 if n_items <= 100_096 else 11 if n_items <= 102_400 else 9
+        want = 12 if n_items <= 100_992 else 11 if n_items <= 102_400 else 9
         assert info["num_wgs"] == min(call.n_targets, want * cus), (n_items, info["num_wgs"])
         _check(call, f"wave kernel, {n_items} columns", threads_per_wg=64)
 
