@@ -404,7 +404,7 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
     if (c->wave) {
         // (the workgroup-per-row kernel keeps its 256-thread shape beside it: sparse rows the wave kernel does not take — more than 64 m1
         // entries, more products than its 63 trips hold — have a queue of their own and run there, as in round 3)
-        const int wv_a = wv_region_bytes(a->n_output_cols);      // the column bitmap: twelve, eleven or nine rows in flight per CU
+        const int wv_a = wv_region_bytes(a->n_output_cols);      // the column bitmap: twelve, eleven, ten or nine rows in flight per CU
         c->wgs_wave = std::max(1, std::min(a->num_wgs > 0 ? a->num_wgs : n_cus * (int)(LDS_LIMIT / wv_lds_bytes(wv_a)), std::max(1, a->n_targets)));
     }
     c->ws_total = WS_QUEUE_BYTES + c->ws_gu_bytes + c->ws_fold_bytes + c->ws_rows_bytes + c->ws_split_bytes + c->ws_piece_bytes + c->ws_items_bytes;
@@ -556,6 +556,9 @@ int launch_rows(const KParams &kp_s, const KParams &kp, const Config &c, hipStre
         } else if (wv_region_bytes(kp_s.n_cols) == WV_A_SMALL) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(sp_knn_wave_kernel<WV_A_SMALL>), hipFuncAttributeMaxDynamicSharedMemorySize, wv_lds_bytes(WV_A_SMALL)));
             hipLaunchKernelGGL(sp_knn_wave_kernel<WV_A_SMALL>, dim3(c.wgs_wave), dim3(64), wv_lds_bytes(WV_A_SMALL), stream, kp_w);
+        } else if (wv_region_bytes(kp_s.n_cols) == WV_A_MID) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(sp_knn_wave_kernel<WV_A_MID>), hipFuncAttributeMaxDynamicSharedMemorySize, wv_lds_bytes(WV_A_MID)));
+            hipLaunchKernelGGL(sp_knn_wave_kernel<WV_A_MID>, dim3(c.wgs_wave), dim3(64), wv_lds_bytes(WV_A_MID), stream, kp_w);
         } else {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(sp_knn_wave_kernel<WV_A_LARGE>), hipFuncAttributeMaxDynamicSharedMemorySize, wv_lds_bytes(WV_A_LARGE)));
             hipLaunchKernelGGL(sp_knn_wave_kernel<WV_A_LARGE>, dim3(c.wgs_wave), dim3(64), wv_lds_bytes(WV_A_LARGE), stream, kp_w);

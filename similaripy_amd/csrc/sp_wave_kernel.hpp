@@ -51,24 +51,25 @@ constexpr int WV_KMAX = 128;                                    // k + 64 <= UCA
 constexpr int WV_OFF_A = WV_CBM_BYTES;
 constexpr int WV_OFF_PRE = WV_OFF_A + WV_CSN * 8;               // the rank prefix lies INSIDE region A (it is built after sweep 1, when the bitmap is gone)
 constexpr int WV_OFF_MP = WV_OFF_PRE + WV_PRE_BYTES;
-// Region A is the column bitmap during sweep 1 and afterwards [collision set 7 KB | rank prefix 512 B | member pool | U 2 KB].  Three sizes:
+// Region A is the column bitmap during sweep 1 and afterwards [collision set 7 KB | rank prefix 512 B | member pool | U 2 KB].  Four sizes:
 //   12 624 B (100 992 columns): member pool 362 entries, 13 648 B of LDS per wave = TWELVE rows in flight per CU (12 x 13 648 = 163 776 of 163 840);
 //   12 800 B (102 400 columns): member pool 384 entries, 13 824 B per wave = eleven rows per CU;
+//   15 360 B (122 880 columns): member pool 704 entries, 16 384 B per wave = ten rows per CU;
 //   16 384 B (131 072 columns): member pool 832 entries, 17 408 B per wave = nine rows per CU.
 // (Round 6, late: rows in flight are what this kernel's time follows — padding its LDS to ten / eight rows per CU cost 8.7 % / 20 % — and
 // 14 336 B per wave were eleven.  The twelfth comes from the rank prefix moving into region A and 128 rank-addressed slots less: a row
 // of this kernel marks ~200 columns, the classification admits an expectation of 307.)
 // The member pool is small on purpose: when a trip's members do not fit, the pool is folded into the collision set right away
 // (wave_accumulate) and starts over — LDS per wave is what bounds the rows in flight, and those are what hides this kernel's latencies.
-constexpr int WV_A_TIGHT = 12624, WV_A_SMALL = 12800, WV_A_LARGE = 16384;
+constexpr int WV_A_TIGHT = 12624, WV_A_SMALL = 12800, WV_A_MID = 15360, WV_A_LARGE = 16384;
 __host__ __device__ constexpr int wv_mpcap(int a_bytes) { return (a_bytes - WV_CSN * 8 - WV_PRE_BYTES - WV_UCAP * 8) / 8; }
 __host__ __device__ constexpr int wv_off_u(int a_bytes) { return WV_OFF_A + a_bytes - WV_UCAP * 8; }
 __host__ __device__ constexpr int wv_lds_bytes(int a_bytes) { return WV_OFF_A + a_bytes; }
 static_assert(wv_mpcap(WV_A_TIGHT) >= 256 + 64, "a trip's members (<= 256) fit an empty pool, the filter's pseudo members a fresh one");
-static_assert(12 * wv_lds_bytes(WV_A_TIGHT) <= 160 * 1024 && 11 * wv_lds_bytes(WV_A_SMALL) <= 160 * 1024 && 9 * wv_lds_bytes(WV_A_LARGE) <= 160 * 1024, "rows per CU");
+static_assert(12 * wv_lds_bytes(WV_A_TIGHT) <= 160 * 1024 && 11 * wv_lds_bytes(WV_A_SMALL) <= 160 * 1024 && 10 * wv_lds_bytes(WV_A_MID) <= 160 * 1024 && 9 * wv_lds_bytes(WV_A_LARGE) <= 160 * 1024, "rows per CU");
 static_assert((WV_CS_OVER & (WV_CS_OVER - 1)) == 0 && WV_OFF_PRE % 16 == 0 && WV_A_TIGHT % 16 == 0, "layout");
 // the host's choice of the region (make_config, the launch)
-__host__ __device__ constexpr int wv_region_bytes(int n_cols) { return n_cols <= 8 * WV_A_TIGHT ? WV_A_TIGHT : n_cols <= 8 * WV_A_SMALL ? WV_A_SMALL : WV_A_LARGE; }
+__host__ __device__ constexpr int wv_region_bytes(int n_cols) { return n_cols <= 8 * WV_A_TIGHT ? WV_A_TIGHT : n_cols <= 8 * WV_A_SMALL ? WV_A_SMALL : n_cols <= 8 * WV_A_MID ? WV_A_MID : WV_A_LARGE; }
 
 // Sweep 2 core for a collision bitmap of WV_CBM_BYTES at LDS offset 0 (sp_common.hpp's s2_core with this kernel's mask).
 // Element j of a lane is real iff j < d: both masks come out cut to the real elements (the cuts in the asm: left to the compiler they

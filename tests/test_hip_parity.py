@@ -1230,14 +1230,14 @@ def _scoring_problem(n_users=6000, n_items=40000, per_user=40, per_item=60, seed
 def _ran_on_the_wave_kernel(call, **tuning):
     info = _host.run_hip(call, time_kernel=True, **tuning)[4]
     cus = int(_abi.backend_info(0).split("CUs=")[1].split()[0])
-    return info["num_wgs"] in tuple(min(call.n_targets, r * cus) for r in (12, 11, 9)), info      # (twelve / eleven / nine single-wave workgroups per CU: sp_wave_kernel.hpp's three regions)
+    return info["num_wgs"] in tuple(min(call.n_targets, r * cus) for r in (12, 11, 10, 9)), info      # (twelve / eleven / ten / nine single-wave workgroups per CU: sp_wave_kernel.hpp's four regions)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_items", [100_992, 100_993, 102_400, 102_401])
+@pytest.mark.parametrize("n_items", [100_992, 100_993, 102_400, 102_401, 122_880, 122_881])
 def test_wave_kernel_region_sizes(n_items):
-    """The wave kernel's LDS region comes in three sizes (sp_wave_kernel.hpp: 12 624 / 12 800 / 16 384 bytes = twelve / eleven / nine rows in
-    flight per CU, one bit per column up to 100 992 / 102 400 columns): catalogues at both sides of each limit, with the last columns of
+    """The wave kernel's LDS region comes in three sizes (sp_wave_kernel.hpp: 12 624 / 12 800 / 15 360 / 16 384 bytes = twelve / eleven / ten / nine rows in
+    flight per CU, one bit per column up to 100 992 / 102 400 / 122 880 / 131 072 columns): catalogues at both sides of each limit, with the last columns of
     the catalogue in use (the bitmap's last bytes, next to the candidate buffer at the region's end), against the oracle."""
     urm, wt = _scoring_problem(n_users=3000, n_items=n_items, per_user=40, per_item=60, seed=21)
     rng = np.random.default_rng(5)
@@ -1252,7 +1252,7 @@ def test_wave_kernel_region_sizes(n_items):
         ran, info = _ran_on_the_wave_kernel(call, threads_per_wg=64)
         assert ran, f"the wave kernel was not chosen ({info['num_wgs']} workgroups)"
         cus = int(_abi.backend_info(0).split("CUs=")[1].split()[0])
-        want = 12 if n_items <= 100_992 else 11 if n_items <= 102_400 else 9
+        want = 12 if n_items <= 100_992 else 11 if n_items <= 102_400 else 10 if n_items <= 122_880 else 9
         assert info["num_wgs"] == min(call.n_targets, want * cus), (n_items, info["num_wgs"])
         _check(call, f"wave kernel, {n_items} columns", threads_per_wg=64)
 
