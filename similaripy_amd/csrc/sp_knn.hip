@@ -390,7 +390,7 @@ int make_config(const sp_knn_args *a, int n_cus, Config *c) {
         const double need = 1.5 * (packs ? 2.0 * trips_p + 2.0 : trips_u + 2.0);
         c->items_stride = need <= 63.0 ? 64 : need <= 127.0 ? 128 : ITEMS_STRIDE;
     }
-    // Light rows (user scoring: a few thousand products, k <= 128, monotone epilogue): one WAVE per row, nine or eleven rows in flight per
+    // Light rows (user scoring: a few thousand products, k <= 128, monotone epilogue): one WAVE per row, nine to twelve rows in flight per
     // CU (sp_wave_kernel.hpp) — when the average row fits its 63 packed trips with room to spare, or on request.  Up to 2^17 output columns
     // the wave's column bitmap is exact; beyond, columns alias modulo 2^17 (an aliased column only takes the collision-set route, where
     // sums are kept per column: exact) and sp_row_desc_kernel sends the kernel the rows whose expected marks fit its collision set.

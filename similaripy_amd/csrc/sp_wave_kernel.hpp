@@ -4,7 +4,7 @@
 // The workgroup-per-row kernel (sp_sparse_kernel.hpp) spends a light row's time at barriers and on memory round trips nobody
 // overlaps: 59 k cycles for 6.4 k products, three 4-wave workgroups per CU (round 3: 3.9 B/clk/CU against the 13-16 B/clk a CU
 // can pull).  Here a row belongs to ONE wave64 and the workgroup IS that wave: no barrier anywhere, every counter a scalar
-// register, 14 KB of LDS per wave, i.e. ELEVEN independent rows in flight per CU, and each wave keeps several trips of its row in
+// register, 13.3 KB of LDS per wave, i.e. TWELVE independent rows in flight per CU (eleven until round 6), and each wave keeps several trips of its row in
 // flight.
 //
 // Same algorithm as the monotone variant of the sparse kernel (s_plus.h:71-127 dense sums[] -> column BITMAP + two sweeps;
