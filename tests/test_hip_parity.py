@@ -155,6 +155,24 @@ def test_generic_kernel_window_chain_ablations(name, kw):
     _check(_host.prepare(m, k=40, target_rows=np.array([8999, 5, 5, 4100, 77, 3000], dtype=np.int32), **kw), name + "/targets", table_slots=1024)
 
 
+def test_generic_kernel_rows_of_several_batches():
+    """Rows with more m1 entries than the workgroup has threads are walked in batches of 1024 segments, and the next batch's entries and
+    slice bounds are requested while the current one is accumulated (round 6): rows of exactly 1024, 1025, 2048, 2500 and 3000 entries
+    among ordinary ones, two dense windows per row (tile 1024), the boundary table in use; with the request-ahead off and on, whole rows
+    and rows cut into pieces."""
+    rng = np.random.default_rng(23)
+    n = 3000
+    m = _rand((n, n), 0.01, 23).tolil()
+    for r, cnt in ((5, 1024), (700, 1025), (1500, 2048), (2200, 2500), (2999, 3000)):
+        cols = np.sort(rng.choice(n, size=cnt, replace=False))
+        m[r, :] = 0
+        m[r, cols] = (rng.random(cnt) + 0.05).astype(np.float32)
+    m = sp.csr_array(m.tocsr(), dtype=np.float32)
+    m.sort_indices()
+    for dbg in (0, 4194304, 8192, 8192 | 4194304):
+        _check(_host.prepare(m, k=30, l2=1.0), f"several batches/dbg={dbg}", table_slots=1024, dbg=dbg)
+
+
 def test_hash_overflow_retry():
     """Candidates concentrated in a narrow column range defeat the MACs-based window estimate: the
     hashed window overflows its probe budget, is discarded, halved and retried (several times, down
