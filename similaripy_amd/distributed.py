@@ -49,7 +49,7 @@ def row_work(call: KernelCall) -> np.ndarray:
 def row_cost(call: KernelCall) -> np.ndarray:
     """What a target slot costs a GPU, in MAC equivalents — the quantity `partition_targets` balances.
 
-    ONE cost model for both multi-GPU routes, and it lives in the library (`target_costs` in csrc/sp_knn.hip, exported as
+    ONE cost model for both multi-GPU routes, and it lives in the library (`target_costs` in csrc/sp_host_multi.hpp — part of the one translation unit sp_knn.hip —, exported as
     `sp_knn_target_costs`; VERDICT r5 #6: the copy that stood here priced the m1 entries of heavy rows, the library's did not, and the
     default in-call route got the worse balance): MACs + a per-row toll (30 k for a row of the sparse kernels, 3 per output column —
     SIMILARIPY_AMD_GENERIC_TOLL_PER_COL — for a row of the generic kernel) + SIMILARIPY_AMD_HEAVY_ENTRY_MACS (2 100) per m1 entry of a

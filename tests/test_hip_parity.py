@@ -329,7 +329,7 @@ def _info(call, **tuning):
 
 def _duo_matrix(seed=31):
     """200 k rows x 10 k columns, 32 per row: m2 = m.T has 200 k columns and rows of ~640 entries, a row's ~20 k products collide
-    often enough to leave the three-per-CU shape (small_rows) and rarely enough for the two-per-CU one (sp_knn.hip: make_config)."""
+    often enough to leave the three-per-CU shape (small_rows) and rarely enough for the two-per-CU one (sp_host_config.hpp: make_config)."""
     from similaripy_amd.workloads import fixed_degree_csr
     return fixed_degree_csr(200_000, 10_000, 32, seed)
 
