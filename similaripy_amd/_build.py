@@ -18,7 +18,7 @@ LIB_DIR = PKG_DIR / "lib"
 LIB_PATH = LIB_DIR / "libsimilaripy_hip.so"
 
 SOURCES = [CSRC_DIR / "sp_knn.hip"]
-HEADERS = [REPO_DIR / "include" / "sp_knn.h", REPO_DIR / "include" / "sp_prep.h", *sorted(CSRC_DIR.glob("*.hpp"))]
+HEADERS = [REPO_DIR / "include" / "sp_knn.h", REPO_DIR / "include" / "sp_prep.h", *sorted(CSRC_DIR.glob("*.hpp")), *sorted(CSRC_DIR.glob("*.inc"))]
 
 HIPCC_FLAGS = [
     "--offload-arch=gfx950",

@@ -17,6 +17,10 @@
 // Rows whose collision set or pool overflow are handed to the generic kernel through its queue (never to a CPU path).
 #pragma once
 #include "sp_common.hpp"
+// The kernel's body is read in eight files: this one (parameters, LDS carve-up, row pipeline and setup, the stage loop's skeleton) and the seven
+// phases it includes where they stood — sp_sparse_phase_{sweep1, rank, first_stage, sweep2, accumulate, consume, writeout}.inc.  They are TEXT, not
+// functions: same scopes, same locals, and the compiled kernel is byte-identical to the one-file form (round 6: the device code object's .text was
+// compared before and after the cut).
 #ifndef SP_DUO_FS2
 #define SP_DUO_FS2 1
 #endif
@@ -525,281 +529,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DUO ? 4 : 1,
                     }
                 }
             }
-            // ---- sweep 1: column ids only.  Branch-free: every product ORs its bit into the bitmap; the returned
-            // word tells whether the column was there already, in which case (only then a non-zero operand) the
-            // column's bit is ORed into the collision bitmap as well. ----
-            {
-                // One 16-byte buffer load per lane fetches a whole item (lane l: elements 4l..4l+3); the range check
-                // of the buffer resource is per dword (scripts/buffer_oob_probe.hip), so an item at the very end of
-                // the array is safe, and a prefetch past the last item reads the sentinel: an all-out-of-range load
-                // (no memory traffic) instead of a branch, so the loads in flight are countable (s_waitcnt vmcnt(N)).
-                // The wave's item descriptors are read ONCE, item wave + NW*i into lane i (beyond the end: the sentinel);
-                // a trip then gets its scalars with v_readlane instead of an LDS round trip.
-                // visited back to front: what sweep 1 reads last is what sweep 2 reads first (L2 still holds it)
-                const int n_mine = (n_items - wave + NW - 1) / NW;       // items wave, wave+NW, ...
-                const int4 myd = items[(lane < n_mine) ? wave + NW * (n_mine - 1 - lane) : n_items];
-                // second piece of the item (packed trips of the prepass: lanes [sB, 64) belong to the NEXT segment); none: sB = 64
-                int3 mydB = make_int3(0, 0, 64);
-                if (two_piece) {
-                    const int bix = (int)((unsigned)myd.w >> ITEM_W_BITS);
-                    if (bix) { const int4 b = items[bix]; mydB = make_int3(b.x, b.y, b.w); }
-                }
-                // a trip = two items (eight columns per lane): twice the loads and twice the LDS atomics in flight per wait.
-                // d0 / d1: elements of this lane's quad that are real (<= 0: none)
-                auto ld = [&](int trip, unsigned (&c)[8], int &cnt0, int &cnt1, int &d0, int &d1) __attribute__((always_inline)) {
-                    const int t0 = min(2 * trip, 63), t1 = min(2 * trip + 1, 63);
-                    const int off0 = __builtin_amdgcn_readlane(myd.x, t0), off1 = __builtin_amdgcn_readlane(myd.x, t1);
-                    cnt0 = __builtin_amdgcn_readlane(myd.y, t0);
-                    cnt1 = __builtin_amdgcn_readlane(myd.y, t1);
-                    int vo0 = off0 + lane * 16, vo1 = off1 + lane * 16;
-                    d0 = cnt0 - 4 * lane;
-                    d1 = cnt1 - 4 * lane;
-                    if (two_piece) {
-                        const int sb0 = __builtin_amdgcn_readlane(mydB.z, t0), sb1 = __builtin_amdgcn_readlane(mydB.z, t1);
-                        const int ob0 = __builtin_amdgcn_readlane(mydB.x, t0), ob1 = __builtin_amdgcn_readlane(mydB.x, t1);
-                        const int cb0 = __builtin_amdgcn_readlane(mydB.y, t0), cb1 = __builtin_amdgcn_readlane(mydB.y, t1);
-                        if (lane >= sb0) { vo0 = ob0 + (lane - sb0) * 16; d0 = cb0 - 4 * (lane - sb0); }
-                        if (lane >= sb1) { vo1 = ob1 + (lane - sb1) * 16; d1 = cb1 - 4 * (lane - sb1); }
-                    }
-                    // (round 6, on the two-per-CU shape, which runs at the memory system's rate: out-of-range offsets for those lanes took the
-                    // ~30 GB per launch of over-fetch away as expected — 538.8 -> 509.0 GB by the counters — and made sweep 1 slower by 14 k cycles
-                    // per row, 85.3 -> 104.7 ms: dropped again, as in round 1)
-                    // (lanes beyond a partial item's end read on into the next m2 row: in sweep 1 that over-fetch is cheaper than
-                    // the instructions the out-of-range trick of sweep 2 costs here — measured 14.5k -> 15.6k cycles per row at C2.
-                    // Also measured and dropped, C2 cycles per row for sweep 1 / sweep 2 against 14.5k / 30.0k: requesting all the
-                    // row's lines up front with one-dword "touch" loads 20.8k / -; 768 threads with 3 pairs / 4 items in flight
-                    // 16.2k / 35.8k (two in flight there: 15.5k / 33.6k); pairs handed out by an LDS counter instead of the
-                    // static share 15.4k / 31.3k (it halves the 3.5k cycles the waves wait at the closing barrier, and spends
-                    // more than that on the counter and descriptor round trips).  With the sweep bodies removed (dbg bits 8 | 16)
-                    // the loads alone take 10.4k / 24.4k: the bodies do not overlap with the loads of the other waves.)
-                    const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, vo0, 0, 0);
-                    const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, vo1, 0, 0);
-                    c[0] = v0.x; c[1] = v0.y; c[2] = v0.z; c[3] = v0.w;
-                    c[4] = v1.x; c[5] = v1.y; c[6] = v1.z; c[7] = v1.w;
-                };
-                auto body = [&](const unsigned (&c)[8], int cnt0, int cnt1, int d0, int d1) __attribute__((always_inline)) {
-                    if (cnt0 == 0) return;                 // sentinel pair (wave-uniform; the second item of a pair may be the sentinel)
-#if SP_ABLATION
-                    if (p.dbg & 8) { asm volatile("" ::"v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7])); return; }   // ablation: loads only
-#endif
-                    // (the bodies run at raised wave priority: a wave that holds its data finishes and re-issues its loads
-                    // before waves that merely issue theirs — measured 124.7 -> 121.4 ms at C2; raising the load issue instead, or
-                    // both at two levels, gains half of that)
-                    __builtin_amdgcn_s_setprio(3);
-                    unsigned seen[8];
-                    // (padding at quad granularity, one compare per item: the per-element form cost 32 instructions more on every
-                    // trip that holds a partial item — more than half of a C2 row's)
-                    s1_core8q<BM_OFF, DUO>(c, d0, d1, amask, seen, bm_shift);
-                    // ~2 % of the products find their column already there: mark it in the collision bitmap.  A trip nearly always
-                    // holds such products (~10 of its 512), a LANE rarely more than one: the lane's column is then the sum of
-                    // seen[j] * c[j] (seen is 0 / 1; v_mad_u32_u24: the mark needs the low 16 bits of the column only) and goes out
-                    // in ONE masked atomic; lanes with two or more (about every third trip has one) take the per-element path.
-                    // (eight exec-masked tests and branches per trip before: as many instructions as the sweep's core)
-                    const unsigned cnt = ((seen[0] + seen[1]) + (seen[2] + seen[3])) + ((seen[4] + seen[5]) + (seen[6] + seen[7]));
-                    if (__ballot(cnt != 0u)) {
-                        unsigned cs;      // (one asm statement: the compiler's own form is v_mul_lo_u32, quarter rate)
-                        asm("v_mul_u32_u24 %0, %1, %9\n\t"
-                            "v_mad_u32_u24 %0, %2, %10, %0\n\t"
-                            "v_mad_u32_u24 %0, %3, %11, %0\n\t"
-                            "v_mad_u32_u24 %0, %4, %12, %0\n\t"
-                            "v_mad_u32_u24 %0, %5, %13, %0\n\t"
-                            "v_mad_u32_u24 %0, %6, %14, %0\n\t"
-                            "v_mad_u32_u24 %0, %7, %15, %0\n\t"
-                            "v_mad_u32_u24 %0, %8, %16, %0"
-                            : "=&v"(cs)
-                            : "v"(seen[0]), "v"(seen[1]), "v"(seen[2]), "v"(seen[3]), "v"(seen[4]), "v"(seen[5]), "v"(seen[6]), "v"(seen[7]),
-                              "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]));
-                        if (cnt == 1u) cbm_mark(cs);
-                        if (__ballot(cnt > 1u)) {
-                            if constexpr (DUO) {
-                                // The two-per-CU shape's aliasing bitmap doubles the marks: nine pair-trips of ten hold a lane with TWO marked columns,
-                                // and the per-element route below — eight exec-masked tests and branches — ran on all of them (~50 instructions a
-                                // pair-trip, 7 % of a row's).  Two columns of a lane are their sum and their maximum: mx = max_j seen[j] * c[j]
-                                // (24-bit products: the mark needs the column's low 20 bits), the other one cs - mx.  Three or more: the old route.
-                                unsigned mx, t1, t2;
-                                asm("v_mul_u32_u24 %0, %3, %11\n\t"
-                                    "v_mul_u32_u24 %1, %4, %12\n\t"
-                                    "v_mul_u32_u24 %2, %5, %13\n\t"
-                                    "v_max3_u32 %0, %0, %1, %2\n\t"
-                                    "v_mul_u32_u24 %1, %6, %14\n\t"
-                                    "v_mul_u32_u24 %2, %7, %15\n\t"
-                                    "v_max3_u32 %0, %0, %1, %2\n\t"
-                                    "v_mul_u32_u24 %1, %8, %16\n\t"
-                                    "v_mul_u32_u24 %2, %9, %17\n\t"
-                                    "v_max3_u32 %0, %0, %1, %2\n\t"
-                                    "v_mul_u32_u24 %1, %10, %18\n\t"
-                                    "v_max_u32 %0, %0, %1"
-                                    : "=&v"(mx), "=&v"(t1), "=&v"(t2)
-                                    : "v"(seen[0]), "v"(seen[1]), "v"(seen[2]), "v"(seen[3]), "v"(seen[4]), "v"(seen[5]), "v"(seen[6]), "v"(seen[7]),
-                                      "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]));
-                                if (cnt == 2u) { cbm_mark(mx); cbm_mark(cs - mx); }
-                                if (__ballot(cnt > 2u)) {
-                                    if (cnt > 2u) {
-#pragma unroll
-                                        for (int j = 0; j < 8; ++j)
-                                            if (seen[j]) cbm_mark(c[j]);
-                                    }
-                                }
-                            } else
-                            if (cnt > 1u) {
-#pragma unroll
-                                for (int j = 0; j < 8; ++j)
-                                    if (seen[j]) cbm_mark(c[j]);
-                            }
-                        }
-                    }
-                    __builtin_amdgcn_s_setprio(0);
-                };
-                unsigned cA[8], cB[8];
-                int nA0 = 0, nA1 = 0, nB0 = 0, nB1 = 0, dA0 = 0, dA1 = 0, dB0 = 0, dB1 = 0;
-                const int n_trips = (n_mine + 1) / 2;
-                int trip = 0;
-#if SP_ABLATION
-                if (p.dbg & 256) {      // ablation: a loads-only pass first — what does the sweep cost when its lines are warm in L2 / MALL?
-                    for (int w = 0; w < n_trips; ++w) {
-                        ld(w, cA, nA0, nA1, dA0, dA1);
-                        asm volatile("" ::"v"(cA[0]), "v"(cA[1]), "v"(cA[2]), "v"(cA[3]), "v"(cA[4]), "v"(cA[5]), "v"(cA[6]), "v"(cA[7]));
-                    }
-                    wg_sync<U_LDS>();
-                    PHASE_END(PH_CSDRAIN);
-                }
-#endif
-                ld(0, cA, nA0, nA1, dA0, dA1);
-                while (trip < n_trips) {      // two pairs (4 KiB) in flight per wave (a third measured slower); bodies skip the sentinel
-                    ld(trip + 1, cB, nB0, nB1, dB0, dB1);
-                    __builtin_amdgcn_sched_barrier(0);     // the prefetch is issued before the current pair is waited for
-#if SP_TRIPTIMERS
-                    { const u64 w0 = clock64(); asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); const u64 w1 = clock64(); if (timing) ph[CT_PASSES] += w1 - w0; }
-#endif
-                    body(cA, nA0, nA1, dA0, dA1);
-                    ld(trip + 2, cA, nA0, nA1, dA0, dA1);
-                    __builtin_amdgcn_sched_barrier(0);
-#if SP_TRIPTIMERS
-                    { const u64 w0 = clock64(); asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); const u64 w1 = clock64(); if (timing) ph[CT_PASSES] += w1 - w0; }
-#endif
-                    body(cB, nB0, nB1, dB0, dB1);
-                    trip += 2;
-                }
-            }
-            if constexpr (MLIKE) {
-                // MATRIX filter (s_plus.h:159-171): the row's excluded columns are marked in the collision bitmap, so all
-                // their products gather in the collision set, where the excluded columns are dropped at the scan
-                // (the filter row's bounds are re-read where they are needed instead of living in registers through the sweeps)
-                if (p.filter_mode == SP_SEL_MATRIX) {
-                    if (f_regs) {
-                        if (my_fc >= 0) cbm_mark((unsigned)my_fc);
-                    } else {
-                        const int f0 = __builtin_amdgcn_readfirstlane(p.f_indptr[t]), f1 = __builtin_amdgcn_readfirstlane(p.f_indptr[t + 1]);
-                        for (int i = f0 + tid; i < f1; i += NT) {
-                            const unsigned c = (unsigned)p.f_indices[i];
-                            cbm_mark(c);
-                        }
-                    }
-                }
-            }
-            wg_sync<U_LDS>();
-            PHASE_END(PH_SWEEP1);
-            if constexpr (MLIKE) {
-                const int NA = min(n_items, NW);
-                if (NA == NW && (p.k + NA - 1) / NA + 2 <= MAXR1) {      // (the first stage's own condition)
-                    fs_early = true;
-                    const int fs = (FS1 == 2 && n_items >= 2 * NW) ? 2 : 1;      // uniform
-#pragma unroll
-                    for (int f = 0; f < FS1; ++f) {
-                        if (f < fs) {
-                            const int4 d = items[wave + f * NW];
-                            int4 b4 = make_int4(0, 0, 0, 64);
-                            const int bix = two_piece ? (int)((unsigned)__builtin_amdgcn_readfirstlane(d.w) >> ITEM_W_BITS) : 0;
-                            if (bix) b4 = items[bix];
-                            int vo, dq;
-                            float segv;
-                            trip_lane(__builtin_amdgcn_readfirstlane(d.x), __builtin_amdgcn_readfirstlane(d.y), (unsigned)__builtin_amdgcn_readfirstlane(d.z),
-                                      __builtin_amdgcn_readfirstlane(b4.x), __builtin_amdgcn_readfirstlane(b4.y), (unsigned)__builtin_amdgcn_readfirstlane(b4.z),
-                                      __builtin_amdgcn_readfirstlane(b4.w), vo, dq, segv);
-                            fsa[f] = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, vo, 0, 0);
-                            fsb[f] = __builtin_amdgcn_raw_buffer_load_b128(rs_val, vo, 0, 0);
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            // the bitmap has done its job: back to zero (16-byte stores); its storage now serves sweep 2
-            for (int i = tid; i < (nb_bytes >> 4); i += NT) ((int4 *)(smem + BM_OFF))[i] = make_int4(0, 0, 0, 0);
-            // rank structure of the collision bitmap: pre16[w] = marked columns in the words below w.  The rank of a
-            // marked column is its slot in the collision set: no hashing, no probing (columns that alias to one bit
-            // share a rank and are told apart by their key; the loser probes an overflow area).
-            if constexpr (RANK_BYTES / 16 <= NT && NW <= 64) {
-                // one trip: RANK_BYTES / 16 threads hold four words each; the waves' totals are combined by a second DPP scan in
-                // every wave (lane w < NW reads wave w's total) instead of NW reads and adds per thread
-                const int4 w4 = (tid < RANK_BYTES / 16) ? ((const int4 *)cbm)[tid] : make_int4(0, 0, 0, 0);
-                const int p0 = __popc((unsigned)w4.x), p1 = p0 + __popc((unsigned)w4.y), p2 = p1 + __popc((unsigned)w4.z);
-                const int tot = p2 + __popc((unsigned)w4.w);
-                const int incl = wave_incl_scan_dpp(tot);
-                if (lane == 63) sh[SH_WSUM + wave] = incl;
-                wg_sync<U_LDS>();
-                const int ws = (lane < NW) ? sh[SH_WSUM + lane] : 0;
-                const int ws_incl = wave_incl_scan_dpp(ws);
-                const int all = __builtin_amdgcn_readlane(ws_incl, 63);
-                const int woff = __builtin_amdgcn_readlane(ws_incl - ws, wave);
-                const int ex = woff + incl - tot;
-                if (tid < RANK_BYTES / 16) {
-                    const u64 packed = (u64)(unsigned)(ex & 0xFFFF) | ((u64)(unsigned)((ex + p0) & 0xFFFF) << 16) |
-                                       ((u64)(unsigned)((ex + p1) & 0xFFFF) << 32) | ((u64)(unsigned)((ex + p2) & 0xFFFF) << 48);
-                    ((u64 *)pre16)[tid] = packed;
-                }
-                if (all > CS_DIR) { failed = true; why = 1; }      // more marked columns than direct slots (uniform)
-                n_marks = all;
-            } else
-            {
-                int carry = 0;
-                for (int base = 0; base < RANK_BYTES / 16; base += NT) {            // 4 words per thread and trip
-                    const int i = base + tid;
-                    const int4 w4 = (i < RANK_BYTES / 16) ? ((const int4 *)cbm)[i] : make_int4(0, 0, 0, 0);
-                    const int p0 = __popc((unsigned)w4.x), p1 = p0 + __popc((unsigned)w4.y), p2 = p1 + __popc((unsigned)w4.z);
-                    const int tot = p2 + __popc((unsigned)w4.w);
-                    const int incl = wave_incl_scan_dpp(tot);
-                    if (lane == 63) sh[SH_WSUM + wave] = incl;
-                    wg_sync<U_LDS>();
-                    int woff = carry, all = 0;
-#pragma unroll
-                    for (int w = 0; w < NW; ++w) {
-                        const int sw = sh[SH_WSUM + w];
-                        if (w < wave) woff += sw;
-                        all += sw;
-                    }
-                    const int ex = woff + incl - tot;
-                    if (i < RANK_BYTES / 16) {
-                        const u64 packed = (u64)(unsigned)(ex & 0xFFFF) | ((u64)(unsigned)((ex + p0) & 0xFFFF) << 16) |
-                                           ((u64)(unsigned)((ex + p1) & 0xFFFF) << 32) | ((u64)(unsigned)((ex + p2) & 0xFFFF) << 48);
-                        ((u64 *)pre16)[i] = packed;
-                    }
-                    carry += all;
-                    if (RANK_BYTES / 16 > NT) wg_sync<U_LDS>();     // (sh[SH_WSUM] is reused by the next trip)
-                }
-                if (carry > CS_DIR) { failed = true; why = 1; }      // more marked columns than direct slots (uniform)
-                n_marks = carry;
-            }
-            if constexpr (MLIKE) {
-                if (p.filter_mode == SP_SEL_MATRIX && !failed) {
-                    // (the member pool is part of the region just cleared: the clearing stores of all waves must be done)
-                    wg_sync<U_LDS>();
-                    auto pseudo = [&](unsigned c) {
-                        if constexpr (BND) {      // the collision set is keyed by the PACKED id (a column without a code has no entries: nothing to exclude)
-                            c = p.colpack[c];
-                            if (c == 0xFFFFFFFFu) return;
-                        }
-                        const int pos = atomicAdd(&sh[SH_MCTR], 1);
-                        if (pos < mpcap) mpool[pos] = ((u64)(c + 1u) << 32) | (u64)0xFF800000u;      // {column + 1 : -inf}
-                        else sh[SH_OVF] = 1;
-                    };
-                    if (f_regs) { if (my_fc >= 0) pseudo((unsigned)my_fc); }
-                    else {
-                        const int f0 = __builtin_amdgcn_readfirstlane(p.f_indptr[t]), f1 = __builtin_amdgcn_readfirstlane(p.f_indptr[t + 1]);
-                        for (int i = f0 + tid; i < f1; i += NT) pseudo((unsigned)p.f_indices[i]);
-                    }
-                }
-            }
-            PHASE_END(PH_SEGMENTS);  // (bitmap clear)
+            // ==== phase: sweep 1 — column ids only (column bitmap, collision bitmap, the MATRIX filter's marks) ====
+#include "sp_sparse_phase_sweep1.inc"
+            // ==== phase: bitmap storage back to zero, rank prefix of the collision bitmap ====
+#include "sp_sparse_phase_rank.inc"
         }
         // next row's m2 row bounds (its m1 entries were requested at the top of this row).  Requested here, behind the bitmap's
         // clearing loop: in front of it the compiler drained vmcnt at the loop's exit, i.e. wave 0 waited out the round trip
@@ -833,222 +566,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DUO ? 4 : 1,
             u32x4 pre_a = u32x4{0u, 0u, 0u, 0u}, pre_b = u32x4{0u, 0u, 0u, 0u};
             int pre_i0 = -1;          // uniform; -1: nothing requested
 
-            // ---- MONO, first stage without any selection.  One item per wave (the first NW items: the heaviest
-            // segments).  Every wave finds, among the per-lane maxima of its single products, the m-th largest
-            // (m*NW >= k, m wave-max rounds): at least m of its products reach that value.  The minimum over the
-            // waves is therefore a value that at least k products of the stage reach — a valid cutoff, known after
-            // ONE barrier, and only the products that reach it enter U (a second barrier checks that at least k do and
-            // that they fit; if not — sparse items, heavily tied values — the stage falls back to "accept everything
-            // in fewer items, select afterwards"). ----
-            if constexpr (MLIKE) {
-                const int NA = min(n_items, NW);
-                const int mrounds = (p.k + NA - 1) / NA + 2;
-                // FS trips per wave in this stage.  The 256-thread shape takes two when the row has them: its four waves see 800
-                // products of a user-scoring row with one trip each, the 100th largest of which is a loose cutoff — the rest of
-                // the row then half-fills U two or three times, each time a selection (a fifth of the row's cycles); with 1 600
-                // products the cutoff lets a few hundred through and the row needs its final selection only.
-                constexpr int FS = FS1;
-                const int fs = (FS == 2 && n_items >= 2 * NW) ? 2 : 1;      // uniform
-                // (k <= 14*NW, for the four waves of the 256-thread shape k <= 30*NW: there a round costs less than the extra selections;
-                // larger k: the accept-everything first stage of the loop below)
-                constexpr int MAXR = MAXR1;
-                if (fs_early) {      // (= NA == NW && mrounds <= MAXR, decided where the stage's loads were issued)
-                    unsigned c[FS][4];
-                    float x[FS][4];
-                    u64 M[FS][4], S[FS][4];
-                    unsigned lmax = 0u;
-                    float bx = -__builtin_inff();      // BND: the lane's best single product of the stage (raw dot, packed id)
-                    unsigned bc = 0u;
-#pragma unroll
-                    for (int f = 0; f < FS; ++f) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) { c[f][j] = 0u; x[f][j] = 0.f; M[f][j] = 0ull; S[f][j] = 0ull; }
-                        if (f < fs) {
-                            float v[4];
-                            const int4 d = items[wave + f * NW];
-                            const int cntA = __builtin_amdgcn_readfirstlane(d.y);
-                            int dq;      // real elements of this lane's quad
-                            int4 b4 = make_int4(0, 0, 0, 64);
-                            const int bix = two_piece ? (int)((unsigned)__builtin_amdgcn_readfirstlane(d.w) >> ITEM_W_BITS) : 0;
-                            if (bix) b4 = items[bix];
-                            int vo;
-                            float segv;
-                            trip_lane(__builtin_amdgcn_readfirstlane(d.x), cntA, (unsigned)__builtin_amdgcn_readfirstlane(d.z),
-                                      __builtin_amdgcn_readfirstlane(b4.x), __builtin_amdgcn_readfirstlane(b4.y), (unsigned)__builtin_amdgcn_readfirstlane(b4.z),
-                                      __builtin_amdgcn_readfirstlane(b4.w), vo, dq, segv);
-                            (void)vo;      // (requested in front of the bitmap's clearing loop)
-                            const u32x4 a = fsa[f], b = fsb[f];
-                            c[f][0] = a.x; c[f][1] = a.y; c[f][2] = a.z; c[f][3] = a.w;
-                            v[0] = __uint_as_float(b.x); v[1] = __uint_as_float(b.y); v[2] = __uint_as_float(b.z); v[3] = __uint_as_float(b.w);
-                            if constexpr (BND && DUO) s2_core_b_duo(c[f], v, segv, b_nKw, b_Q, x[f], M[f], S[f]);
-                            else if constexpr (BND) s2_core_b(c[f], v, segv, b_nKw, b_Q, x[f], M[f], S[f]);
-                            else if constexpr (DUO) s2_core_duo(c[f], v, segv, cutx, x[f], M[f], S[f]);
-                            else s2_core(c[f], v, segv, cutx, x[f], M[f], S[f]);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const u64 ok = (cntA == ITEM) ? ~0ull : __ballot(j < dq);
-                                M[f][j] &= ok;
-                                S[f][j] &= ok & ~M[f][j];
-                            }
-                            if constexpr (BND) {
-                                // the lane's best single product so far (largest raw dot): the one whose EXACT value feeds the statistic below
-#pragma unroll
-                                for (int j = 0; j < 4; ++j)
-                                    if (((S[f][j] >> lane) & 1ull) && x[f][j] > bx) { bx = x[f][j]; bc = c[f][j]; }
-                            }
-                            if constexpr (!BND) {
-#pragma unroll
-                                for (int j = 0; j < 4; ++j)
-                                    if ((S[f][j] >> lane) & 1ull) lmax = max(lmax, fkey(x[f][j]));
-                            }
-                        }
-                    }
-                    if constexpr (BND) {
-                        // EXACT value of the lane's best single product (s_plus.h:129-156: ONE column-term gather per lane): the statistic below
-                        // then says "at least m lanes of this wave hold a product whose value reaches tw" about values candidates really
-                        // have — a bound would not do: the stage's cutoff must be one that k candidates reach, or what it discards could
-                        // have been among the k best.  (All four products of a lane, first try: 4 096 gathers of a 128-byte line each per
-                        // row, as much memory traffic as the sweeps' streams — the whole kernel slowed down.)
-                        const int gc = (bx > -__builtin_inff()) ? (int)(bc & p.bnd_id_mask) : 0;
-                        float ytv = 0.f, ycos = 0.f, ydep = 0.f;
-                        if (p.Ypack) { const float4 y = p.Ypack[gc]; ytv = y.x; ycos = y.y; ydep = y.z; }
-                        else {
-                            if (p.l1 != 0.f) ytv = p.Ytv[gc];
-                            if (p.l2 != 0.f) ycos = p.Ycos[gc];
-                            if (p.l3 != 0.f) ydep = p.Ydep[gc];
-                        }
-                        const float val = rc.epi(bx, ytv, ycos, ydep);
-                        if (bx > -__builtin_inff() && val >= p.threshold) lmax = fkey(val);
-                    }
-                    // (BND: no early request of the next stage's first trip — its eight registers, live across this stage's barriers beside the
-                    // gather's, cost the variant its zero-spill budget)
-                    if (!BND && fs * NW < n_items) {      // (uniform) the next stage starts at item fs * NW if this one fits — the rule
-                        const int ip = fs * NW + wave;
-                        const int4 d = items[(ip < n_items) ? ip : n_items];       // (beyond the end: the sentinel, nothing is fetched)
-                        int vo, so = 0;
-                        if (two_piece) {
-                            int4 b4 = make_int4(0, 0, 0, 64);
-                            const int bix = (int)((unsigned)__builtin_amdgcn_readfirstlane(d.w) >> ITEM_W_BITS);
-                            if (bix) b4 = items[bix];
-                            int dq_;
-                            float sv_;
-                            trip_lane(__builtin_amdgcn_readfirstlane(d.x), __builtin_amdgcn_readfirstlane(d.y), (unsigned)__builtin_amdgcn_readfirstlane(d.z),
-                                      __builtin_amdgcn_readfirstlane(b4.x), __builtin_amdgcn_readfirstlane(b4.y), (unsigned)__builtin_amdgcn_readfirstlane(b4.z),
-                                      __builtin_amdgcn_readfirstlane(b4.w), vo, dq_, sv_);
-                        } else {
-                            so = __builtin_amdgcn_readfirstlane(d.x);
-                            vo = (__builtin_amdgcn_readfirstlane(d.y) - 4 * lane > 0) ? lane * 16 : (int)(OOB_SOFFSET - (unsigned)so);
-                        }
-                        pre_a = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, vo, so, 0);
-                        pre_b = __builtin_amdgcn_raw_buffer_load_b128(rs_val, vo, so, 0);
-                        pre_i0 = fs * NW;
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    // m-th largest (distinct) lane maximum of this wave — fewer rounds for a wave with fewer candidate lanes
-                    // (a partial item), so that its looser statistics do not drag the common cutoff down; whether k
-                    // products reach the cutoff is counted exactly below
-                    // rounds in proportion to the wave's share of the stage's lanes (item lengths are in the descriptors:
-                    // no reduction needed), k ranks in total
-                    int my_rounds;
-                    {
-                        int lw = 0;                                                            // lanes of the trips of wave `lane`
-                        if (lane < NW) {
-                            for (int f = 0; f < fs; ++f) {
-                                const int4 it = items[lane + f * NW];
-                                lw += (it.y + 3) / 4;
-                                const int bix = two_piece ? (int)((unsigned)it.w >> ITEM_W_BITS) : 0;
-                                if (bix) lw += (items[bix].y + 3) / 4;
-                            }
-                        }
-                        const int lanes_all = wave_incl_scan_dpp(lw);                          // lane 63: the sum
-                        const int L = max(1, __builtin_amdgcn_readlane(lanes_all, 63));
-                        const int mine = max(1, __builtin_amdgcn_readlane(lw, wave));
-                        // (exactly k ranks, each wave's share rounded up: every rank beyond them loosens the cutoff — with k + 2*NW ranks a
-                        // C2 row spent 1.6 % more cycles on survivors and their selection; a wave with fewer candidate lanes than rounds only
-                        // makes the count below fall short, i.e. the stage falls back)
-                        my_rounds = max(1, min(MAXR + 8, (p.k * mine + L - 1) / L));
-                    }
-                    unsigned rest = lmax, tw = 0u;
-                    for (int r = 0; r < my_rounds; ++r) {
-                        const unsigned mx = wave_max_u32(rest);
-                        if (mx != 0u) tw = mx;
-                        rest = (rest >= mx) ? 0u : rest;
-                    }
-                    if (lane == 0 && tw != 0u) atomicMin((unsigned *)&sh[SH_SEL], tw);
-                    wg_sync<U_LDS>();
-                    const unsigned g = (unsigned)sh[SH_SEL];            // every product pushed below has key >= g
-                    // BND: g is a value k candidates of this stage reach; what can still beat it (the bound against g) is offered to the exact pass
-                    float g_nKw = 0.f, g_Q = 0.f;
-                    if constexpr (BND) bnd_cut_for(fmaxf(b_t0, funkey(g)), g_nKw, g_Q);
-                    int cw = 0;
-#pragma unroll
-                    for (int f = 0; f < FS; ++f)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) cw += __popcll(S[f][j] & __ballot(BND ? bnd_alive(c[f][j], x[f][j], g_nKw, g_Q) : (fkey(x[f][j]) >= g)));
-                    // (BND: cw counts what the BOUND lets through, not what reaches g — that g is a value k candidates reach is counted on the
-                    // lanes' exact values, in the upper half of the same counter: a wave with fewer candidate lanes than rounds falls short there)
-                    if constexpr (BND) cw += __popcll(__ballot(lmax != 0u && lmax >= g)) << 16;
-                    if (lane == 0 && cw) atomicAdd(&sh[SH_NEED], cw);
-                    wg_sync<U_LDS>();
-                    const int totalA = BND ? (sh[SH_NEED] & 0xFFFF) : sh[SH_NEED];
-                    const int reachA = BND ? (sh[SH_NEED] >> 16) : totalA;
-                    const bool fits = totalA <= room / 2 && reachA >= p.k;   // uniform: k products reach g (so it is a valid cutoff) and they leave U half empty
-                    const int nfull = max(1, (room / 2) / ITEM);        // fallback: the first nfull items, everything accepted (U at most half full)
-#pragma unroll
-                    for (int f = 0; f < FS; ++f) {
-                        // (not fitting: only the waves' FIRST trips are items [0, nfull); the others are offered again by the loop below)
-                        if (f < fs && (fits || (f == 0 && wave < nfull))) {
-                            u64 G[4];
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) G[j] = fits ? (S[f][j] & __ballot(BND ? bnd_alive(c[f][j], x[f][j], g_nKw, g_Q) : (fkey(x[f][j]) >= g))) : S[f][j];
-                            const int m0 = __popcll(M[f][0]), m1 = __popcll(M[f][1]), m2 = __popcll(M[f][2]), m3 = __popcll(M[f][3]);
-                            if (m0 + m1 + m2 + m3) {
-                                if (pool_reserve(wpm, m0 + m1 + m2 + m3, &sh[SH_MCTR], mpcap, &sh[SH_OVF])) {
-                                    int pos = wpm.pos;
-                                    lds_push64(M[f][0], __float_as_uint(x[f][0]), c[f][0] + 1u, pos, mpool_off); pos += m0;
-                                    lds_push64(M[f][1], __float_as_uint(x[f][1]), c[f][1] + 1u, pos, mpool_off); pos += m1;
-                                    lds_push64(M[f][2], __float_as_uint(x[f][2]), c[f][2] + 1u, pos, mpool_off); pos += m2;
-                                    lds_push64(M[f][3], __float_as_uint(x[f][3]), c[f][3] + 1u, pos, mpool_off);
-                                    wpm.pos = pos + m3;
-                                }
-                            }
-                            const int n0 = __popcll(G[0]), n1 = __popcll(G[1]), n2 = __popcll(G[2]), n3 = __popcll(G[3]);
-                            if (n0 + n1 + n2 + n3) {
-                                int ubase = 0;
-                                if (lane == 0) ubase = atomicAdd(&sh[SH_CNT], n0 + n1 + n2 + n3);     // exact: no holes in this stage
-                                int pos = __builtin_amdgcn_readfirstlane(ubase);
-                                // (BND: {raw dot, packed id} — the exact pass in front of the next selection turns it into {value, column})
-                                if ((G[0] >> lane) & 1ull) U[pos + mbcnt64(G[0])] = ((u64)(BND ? __float_as_uint(x[f][0]) : fkey(x[f][0])) << 32) | (u64)c[f][0];
-                                pos += n0;
-                                if ((G[1] >> lane) & 1ull) U[pos + mbcnt64(G[1])] = ((u64)(BND ? __float_as_uint(x[f][1]) : fkey(x[f][1])) << 32) | (u64)c[f][1];
-                                pos += n1;
-                                if ((G[2] >> lane) & 1ull) U[pos + mbcnt64(G[2])] = ((u64)(BND ? __float_as_uint(x[f][2]) : fkey(x[f][2])) << 32) | (u64)c[f][2];
-                                pos += n2;
-                                if ((G[3] >> lane) & 1ull) U[pos + mbcnt64(G[3])] = ((u64)(BND ? __float_as_uint(x[f][3]) : fkey(x[f][3])) << 32) | (u64)c[f][3];
-                            }
-                        }
-                    }
-                    i0 = fits ? fs * NW : nfull;
-                    if (fits) {
-                        rc.have_thr = true;
-                        rc.thr_key = g;
-                        if constexpr (BND) { set_bnd_cut(); thr_incl = true; }
-                        else cutx = fmaxf(cutx0, funkey(g));
-                    }
-                    wg_sync<U_LDS>();
-                    if (sh[SH_OVF]) { failed = true; why = (sh[SH_CNT] > cap) ? 2 : 3; }
-                    // (not fitting: U now holds everything of the first nfull items; the next stage's selection trims it)
-                    {
-                        // (float arithmetic: a 64-bit integer division is ~100 instructions on every wave)
-                        const float left = (float)(cap - min(sh[SH_CNT], cap));
-                        const float pos = (float)(items[min(i0, n_items)].w & ((1 << ITEM_W_BITS) - 1));
-                        const float ch = fits ? STAGE_FILL * pos * left / (float)max(2 * p.k, totalA) : 0.5f * left;      // !fits: no cutoff yet, everything is accepted
-                        chunk_items = max(1, (int)fminf(ch * (1.f / ITEM), 1e6f));
-                        force_sel = fits && totalA > 8 * p.k;
-                    }
-                    PHASE_END(PH_SWEEP2);
-                }
-            }
+            // ==== phase: the monotone-type variants' first stage (no selection; cutoff from the waves' per-lane maxima) ====
+#include "sp_sparse_phase_first_stage.inc"
             if (i0 >= n_items && !failed && i0 > 0) {
                 // (all items went through the first stage: let the loop run its last-stage part with an empty sweep)
             }
@@ -1085,172 +604,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DUO ? 4 : 1,
                 }
                 const int i1 = (force_sel && i0 < n_items) ? i0 : min(n_items, i0 + stage_items);
                 {
-                    // ---- sweep 2 over items [i0, i1) ----
-                    WavePool wps{0, -1};
-                    // item i0 + wave + NW*i of this stage in lane i (beyond the stage: the sentinel)
-                    int4 myd;
-                    int4 mydB = make_int4(0, 0, 0, 64);       // second piece of the item (packed trips of the prepass); none: sB = 64
-                    {
-                        const int mine = i0 + wave + NW * lane;
-                        myd = items[(mine < i1) ? mine : n_items];
-                        if (two_piece) {
-                            const int bix = (int)((unsigned)myd.w >> ITEM_W_BITS);
-                            if (bix) mydB = items[bix];
-                        }
-                    }
-                    // cnt: elements of piece A (0: the sentinel; ITEM: the trip is full, no masks); dq: real elements of this lane's quad
-                    // (pre: the trip's data was requested during the first stage)
-                    auto ld = [&](int trip, unsigned (&c)[4], float (&v)[4], int &cnt, int &dq, float &segv, bool pre = false) __attribute__((always_inline)) {
-                        const int tl = min(trip, 63);
-                        cnt = __builtin_amdgcn_readlane(myd.y, tl);
-                        int vo;
-                        if (two_piece) {
-                            trip_lane(__builtin_amdgcn_readlane(myd.x, tl), cnt, (unsigned)__builtin_amdgcn_readlane(myd.z, tl),
-                                      __builtin_amdgcn_readlane(mydB.x, tl), __builtin_amdgcn_readlane(mydB.y, tl), (unsigned)__builtin_amdgcn_readlane(mydB.z, tl),
-                                      __builtin_amdgcn_readlane(mydB.w, tl), vo, dq, segv);
-                        }
-                        int so = 0;
-                        if (!two_piece) {
-                            // one piece: its offset stays scalar; lanes beyond a partial item's end get an out-of-range offset (they fetch nothing)
-                            so = __builtin_amdgcn_readlane(myd.x, tl);
-                            dq = cnt - 4 * lane;
-                            segv = __uint_as_float((unsigned)__builtin_amdgcn_readlane(myd.z, tl));
-                            vo = (dq > 0) ? lane * 16 : (int)(OOB_SOFFSET - (unsigned)so);
-                        }
-                        u32x4 a = pre_a, b = pre_b;
-                        if (!pre) {
-                            a = __builtin_amdgcn_raw_buffer_load_b128(rs_idx, vo, so, 0);
-                            b = __builtin_amdgcn_raw_buffer_load_b128(rs_val, vo, so, 0);
-                        }
-                        c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w;
-                        v[0] = __uint_as_float(b.x); v[1] = __uint_as_float(b.y); v[2] = __uint_as_float(b.z); v[3] = __uint_as_float(b.w);
-                    };
-                    const float cut = MONO ? cutx : rc.xy_cut;
-                    auto body = [&](const unsigned (&c)[4], const float (&v)[4], int cnt, int dq, float segv) __attribute__((always_inline)) {
-                        if (cnt == 0) return;                  // sentinel (wave-uniform)
-#if SP_ABLATION
-                        if (p.dbg & 16) { asm volatile("" ::"v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); return; }   // ablation: loads only
-#endif
-                        // M: product of a marked column; S: otherwise the product is the only one of its column and
-                        // matters only if its raw dot can still enter the top-k (NaN stays: the exact judge drops it)
-                        __builtin_amdgcn_s_setprio(3);
-                        float x[4];
-                        u64 M[4], S[4];
-                        if constexpr (BND && DUO) s2_core_b_duo(c, v, segv, b_nKw, b_Q, x, M, S);
-                        else if constexpr (BND) s2_core_b(c, v, segv, b_nKw, b_Q, x, M, S);
-                        else if constexpr (DUO) s2_core_duo(c, v, segv, cut, x, M, S);
-                        else s2_core(c, v, segv, cut, x, M, S);
-                        if (cnt != ITEM) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const u64 ok = __ballot(j < dq);
-                                M[j] &= ok;
-                                S[j] &= ok;
-                            }
-                        }
-#if SP_ABLATION
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) S[j] &= ~M[j];
-                        if (p.dbg & 32) { M[0] = M[1] = M[2] = M[3] = 0ull; }      // ablation: members are dropped
-                        if (p.dbg & 64) { S[0] = S[1] = S[2] = S[3] = 0ull; }      // ablation: survivors are dropped
-                        asm volatile("" ::"v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]));
-#endif
-                        const u64 Many = (M[0] | M[1]) | (M[2] | M[3]);
-                        if (Many) {
-                            // A trip nearly always holds members (~14 of its 256 products at C2), a LANE rarely more than one: the
-                            // first member of every lane goes out in ONE push (picked with three v_cndmask on the masks), second and
-                            // later members of a lane (R1..R3) in the rare pushes behind it — the instructions of a trip, not its bytes,
-                            // are what the sweep's time follows
-                            const u64 R1 = M[1] & M[0], R2 = M[2] & (M[0] | M[1]), R3 = M[3] & ((M[0] | M[1]) | M[2]);
-                            const int n0 = __popcll(Many), n1 = __popcll(R1), n2 = __popcll(R2), n3 = __popcll(R3);
-                            if (pool_reserve(wpm, n0 + n1 + n2 + n3, &sh[SH_MCTR], mpcap, &sh[SH_OVF])) {
-                                int pos = __builtin_amdgcn_readfirstlane(wpm.pos);
-                                const unsigned xm = mask_select(M[0], __float_as_uint(x[0]), mask_select(M[1], __float_as_uint(x[1]), mask_select(M[2], __float_as_uint(x[2]), __float_as_uint(x[3]))));
-                                const unsigned cm = mask_select(M[0], c[0], mask_select(M[1], c[1], mask_select(M[2], c[2], c[3])));
-                                lds_push64(Many, xm, cm + 1u, pos, mpool_off);
-                                pos += n0;
-                                if ((R1 | R2) | R3) {
-                                    if (n1) lds_push64(R1, __float_as_uint(x[1]), c[1] + 1u, pos, mpool_off);
-                                    pos += n1;
-                                    if (n2) lds_push64(R2, __float_as_uint(x[2]), c[2] + 1u, pos, mpool_off);
-                                    pos += n2;
-                                    if (n3) lds_push64(R3, __float_as_uint(x[3]), c[3] + 1u, pos, mpool_off);
-                                    pos += n3;
-                                }
-                                wpm.pos = pos;
-                            }
-                        }
-                        // (a product of a marked column is no survivor; the masks are only cut when there is something to cut)
-                        if ((S[0] | S[1]) | (S[2] | S[3])) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) S[j] &= ~M[j];
-                        }
-                        if ((S[0] | S[1]) | (S[2] | S[3])) {
-                            const int n0 = __popcll(S[0]), n1 = __popcll(S[1]), n2 = __popcll(S[2]), n3 = __popcll(S[3]);
-                            if constexpr (MLIKE) {
-                                // straight into the candidate buffer, keyed by the raw dot (BND: the raw dot itself, keyed by the exact pass later)
-                                if (pool_reserve<16>(wps, n0 + n1 + n2 + n3, &sh[SH_CNT], cap, &sh[SH_OVF])) {     // small blocks: U is short of room
-                                    int pos = __builtin_amdgcn_readfirstlane(wps.pos);
-                                    if constexpr (U_LDS) {
-                                        // (survivors are rare once the cutoff has settled: most of the four masks are empty)
-                                        if (n0) lds_push64(S[0], c[0], BND ? __float_as_uint(x[0]) : fkey(x[0]), pos, u_off);
-                                        pos += n0;
-                                        if (n1) lds_push64(S[1], c[1], BND ? __float_as_uint(x[1]) : fkey(x[1]), pos, u_off);
-                                        pos += n1;
-                                        if (n2) lds_push64(S[2], c[2], BND ? __float_as_uint(x[2]) : fkey(x[2]), pos, u_off);
-                                        pos += n2;
-                                        if (n3) lds_push64(S[3], c[3], BND ? __float_as_uint(x[3]) : fkey(x[3]), pos, u_off);
-                                    } else {
-                                        if ((S[0] >> lane) & 1ull) U[pos + mbcnt64(S[0])] = ((u64)(BND ? __float_as_uint(x[0]) : fkey(x[0])) << 32) | (u64)c[0];
-                                        pos += n0;
-                                        if ((S[1] >> lane) & 1ull) U[pos + mbcnt64(S[1])] = ((u64)(BND ? __float_as_uint(x[1]) : fkey(x[1])) << 32) | (u64)c[1];
-                                        pos += n1;
-                                        if ((S[2] >> lane) & 1ull) U[pos + mbcnt64(S[2])] = ((u64)(BND ? __float_as_uint(x[2]) : fkey(x[2])) << 32) | (u64)c[2];
-                                        pos += n2;
-                                        if ((S[3] >> lane) & 1ull) U[pos + mbcnt64(S[3])] = ((u64)(BND ? __float_as_uint(x[3]) : fkey(x[3])) << 32) | (u64)c[3];
-                                    }
-                                    wps.pos = pos + n3;
-                                }
-                            } else {
-                                if (pool_reserve(wps, n0 + n1 + n2 + n3, &sh[SH_PCTR], spcap, &sh[SH_OVF])) {
-                                    int pos = wps.pos;
-                                    lds_push64(S[0], __float_as_uint(x[0]), c[0] + 1u, pos, spool_off); pos += n0;
-                                    lds_push64(S[1], __float_as_uint(x[1]), c[1] + 1u, pos, spool_off); pos += n1;
-                                    lds_push64(S[2], __float_as_uint(x[2]), c[2] + 1u, pos, spool_off); pos += n2;
-                                    lds_push64(S[3], __float_as_uint(x[3]), c[3] + 1u, pos, spool_off);
-                                    wps.pos = pos + n3;
-                                }
-                            }
-                        }
-                        __builtin_amdgcn_s_setprio(0);
-                    };
-                    unsigned cA[4], cB[4];
-                    float vA[4], vB[4];
-                    int nA = 0, nB = 0, qA = 0, qB = 0;
-                    float sA = 0.f, sB = 0.f;
-                    const int n_trips = (i1 - i0 - wave + NW - 1) / NW;
-                    int trip = 0;
-                    {
-                        // (the wave's first item of this stage is the one requested during the first stage: same i0, and the stage is long enough)
-                        const bool use_pre = MLIKE && pre_i0 == i0 && i0 + wave < i1;      // uniform
-                        if (i1 > i0) pre_i0 = -1;      // (an empty round — a forced selection — leaves the request pending for the round behind it)
-                        ld(0, cA, vA, nA, qA, sA, use_pre);
-                    }
-                    while (trip < n_trips) {      // two items (4 KiB) in flight per wave; bodies skip the sentinel
-                        ld(trip + 1, cB, vB, nB, qB, sB);
-                        __builtin_amdgcn_sched_barrier(0);     // the prefetch is issued before the current item is waited for
-#if SP_TRIPTIMERS
-                        { const u64 w0 = clock64(); asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); const u64 w1 = clock64(); if (timing) ph[PH_CSDRAIN] += w1 - w0; }
-#endif
-                        body(cA, vA, nA, qA, sA);
-                        ld(trip + 2, cA, vA, nA, qA, sA);
-                        __builtin_amdgcn_sched_barrier(0);
-#if SP_TRIPTIMERS
-                        { const u64 w0 = clock64(); asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); const u64 w1 = clock64(); if (timing) ph[PH_CSDRAIN] += w1 - w0; }
-#endif
-                        body(cB, vB, nB, qB, sB);
-                        trip += 2;
-                    }
+                    // ==== phase: sweep 2 over the stage's items (ids + values) ====
+#include "sp_sparse_phase_sweep2.inc"
                 }
                 wg_sync<U_LDS>();
                 if (sh[SH_OVF]) {     // a pool overflowed
@@ -1289,360 +644,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(DUO ? 4 : 1,
                 // (DUO: also between stages, as soon as the pool is half full)
                 const bool do_acc = last_stage || (DUO && 2 * mext > mpcap - NW * POOL_BLK);      // uniform
                 if (do_acc) {
-                    // ---- products of marked columns: find-or-insert in the collision set.  {column+1 : sum} slots,
-                    // 0 = free; see below. ----
-                    // a slot taken by another column (bit aliasing): hashed start in the overflow half, then linear
-                    auto next_slot = [&](unsigned h, unsigned key) __attribute__((always_inline)) -> unsigned {
-                        const unsigned dir = (unsigned)CS_DIR, ovr = (unsigned)CS_OVR;
-                        return (h < dir) ? dir + (hash_bits((int)key, 2654435761u, cs_shift)) : dir + ((h - dir + 1u) & (ovr - 1u));
-                    };
-                    // Lock-step, two entries per thread: every round issues ONE 64-bit compare-and-swap per live entry
-                    // that claims a free slot with the product in it; a slot that already belongs to the column gets
-                    // the product through the hardware float add (slow on gfx950, 3 clk per lane, but a column with
-                    // many products — the row itself in m * m^T — would make a compare-and-swap add retry once per
-                    // product); another column's slot sends the entry to the next slot.
-                    // (Round 3 tried "32-bit compare-and-swap on the key word, then ALWAYS the hardware float add": one round
-                    // trip less per two-product column, but ds_add_f32 runs at 0.33 lanes/clk: 9.1k -> 11.6k cycles per C2 row.)
-                    // Three entries per thread and pass (four spill at the 128-register budget): a C2 row's ~2.3 k members are ONE pass (with two per thread the last
-                    // 250 entries were a second pass of their own — three more rounds of round trips for a quarter of the waves
-                    // while the others waited at the barrier below).
-                    constexpr int JA = MLIKE ? 3 : 2;      // (the general variant is over the register budget already: C3 180.2 against 178.3 ms with three)
-                    for (int base = 0; base < mext; base += JA * NT) {
-                        // per entry: key, product, slot and the slot content last seen (0: none yet) — what to write is formed
-                        // from those at the compare-and-swap (registers: a spill's reload would count in vmcnt and end the
-                        // row pipeline's pending loads)
-                        u64 cur[JA];
-                        unsigned kk[JA], h[JA];
-                        float xx[JA];
-                        bool act[JA];
-#pragma unroll
-                        for (int j = 0; j < JA; ++j) {
-                            const int i = base + j * NT + tid;
-                            const u64 e = (i < mext) ? mpool[i] : 0ull;
-                            if (e != 0ull) mpool[i] = 0ull;
-                            kk[j] = (unsigned)(e >> 32);
-                            xx[j] = __uint_as_float((unsigned)e);
-                            act[j] = (e != 0ull);
-                        }
-#pragma unroll
-                        for (int j = 0; j < JA; ++j) {
-                            // direct slot = rank of the column's bit in the collision bitmap
-                            const unsigned cm = kk[j] - 1u;
-                            const unsigned wi = (cm >> 5) & (unsigned)(RANK_BYTES / 4 - 1);
-                            const unsigned bw = ((const unsigned *)cbm)[wi];
-                            h[j] = (unsigned)pre16[wi] + (unsigned)__popc(bw & ((1u << (cm & 31u)) - 1u));
-                            cur[j] = 0ull;
-                        }
-                        int rounds = 0;
-                        while (__ballot((act[0] | act[1]) | act[JA - 1])) {
-                            u64 r[JA];
-#pragma unroll
-                            for (int j = 0; j < JA; ++j) {
-                                r[j] = 0ull;
-                                if (act[j]) {
-                                    // empty slot expected: claim it with the product; the column's slot with sum s expected: s + x
-                                    const float add = (cur[j] == 0ull) ? xx[j] : __uint_as_float((unsigned)cur[j]) + xx[j];
-                                    r[j] = atomicCAS(&cs[h[j]], cur[j], ((u64)kk[j] << 32) | (u64)__float_as_uint(add));
-                                }
-                            }
-#pragma unroll
-                            for (int j = 0; j < JA; ++j) {
-                                if (act[j]) {
-                                    if (r[j] == cur[j]) act[j] = false;                          // claimed (cur = 0) or added (cur = the sum seen)
-                                    else if ((unsigned)(r[j] >> 32) == kk[j]) {
-                                        if (cur[j] == 0ull) cur[j] = r[j];                       // the column's slot: one compare-and-swap add
-                                        else { atomicAdd((float *)&cs[h[j]], xx[j]); act[j] = false; }  // contended (a column with many products): hardware add
-                                    } else { h[j] = next_slot(h[j], kk[j]); cur[j] = 0ull; }     // another column's slot
-                                }
-                            }
-                            if (++rounds > 4 * CS_MAXPROBE) { sh[SH_OVF] = 1; break; }     // set full
-                        }
-                    }
-                    wg_sync<U_LDS>();
-                    if (sh[SH_OVF]) { failed = true; why = 1; break; }     // collision set full
-                    // (the pool is empty again — every entry read was zeroed — and its counter goes back to zero below: the waves' windows too)
-                    if constexpr (DUO) wpm = WavePool{0, -1};
-                    PHASE_END(PH_ACCUM);
+                    // ==== phase: member pool -> collision set ====
+#include "sp_sparse_phase_accumulate.inc"
                 }
 
-                // ---- dense consumer.  General: spool[0, ext) and, in the last stage, the collision set's slots (same
-                // entry format) are judged into U.  MONO: only the collision set is left to do — sums above the cutoff
-                // go straight into U.  Consumed entries are zeroed (and the set's collision-bitmap bits cleared). ----
-                const int n_ent = (MLIKE ? 0 : ext) + (last_stage ? CSN : 0);
-                for (;;) {
-                    if constexpr (MLIKE) {
-                        // four slots per thread in flight, one reservation in U per wave and trip
-                        for (int base = 0; base < n_ent; base += 4 * NT) {
-                            u64 e[4];
-                            bool want[4];
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const int i = base + j * NT + tid;
-                                e[j] = (i < n_ent) ? cs[i] : 0ull;
-                            }
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                if constexpr (BND) want[j] = (e[j] != 0ull) && bnd_alive((unsigned)(e[j] >> 32) - 1u, __uint_as_float((unsigned)e[j]), b_nKw, b_Q);
-                                else want[j] = (e[j] != 0ull) && !(__uint_as_float((unsigned)e[j]) <= cutx);
-                            }
-                            if (MONO && p.filter_mode == SP_SEL_MATRIX) {      // (uniform) excluded columns of this row: their sums are -inf ...
-                                bool odd = false;                      // ... unless an infinite product made one NaN: the list decides
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) odd |= want[j] && (__uint_as_float((unsigned)e[j]) != __uint_as_float((unsigned)e[j]));
-                                if (__ballot(odd)) {
-                                    const int f0 = __builtin_amdgcn_readfirstlane(p.f_indptr[t]), f1 = __builtin_amdgcn_readfirstlane(p.f_indptr[t + 1]);
-#pragma unroll
-                                    for (int j = 0; j < 4; ++j)
-                                        if (want[j] && (__uint_as_float((unsigned)e[j]) != __uint_as_float((unsigned)e[j])) &&
-                                            range_has(p.f_indices, f0, f1, (int)((unsigned)(e[j] >> 32) - 1u))) want[j] = false;
-                                }
-                            }
-                            const u64 m0 = __ballot(want[0]), m1 = __ballot(want[1]), m2 = __ballot(want[2]), m3 = __ballot(want[3]);
-                            const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
-                            int wbase = 0;
-                            if ((m0 | m1) | (m2 | m3)) {
-                                if (lane == 0) wbase = atomicAdd(&sh[SH_CNT], n0 + n1 + n2 + n3);
-                                wbase = __builtin_amdgcn_readfirstlane(wbase);
-                            }
-                            const int off[4] = {0, n0, n0 + n1, n0 + n1 + n2};
-                            const u64 mm[4] = {m0, m1, m2, m3};
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                if (e[j] != 0ull) {
-                                    const unsigned col = (unsigned)(e[j] >> 32) - 1u;
-                                    bool finished = true;
-                                    if (want[j]) {
-                                        const int pos = wbase + off[j] + mbcnt64(mm[j]);
-                                        if (pos < cap) U[pos] = ((u64)(BND ? (unsigned)e[j] : fkey(__uint_as_float((unsigned)e[j]))) << 32) | (u64)col;
-                                        else { sh[SH_RETRY] = 1; finished = false; }
-                                    }
-                                    if (finished) {
-                                        cs[base + j * NT + tid] = 0ull;
-                                        cbm_unmark(col);
-                                    }
-                                }
-                            }
-                        }
-                    } else {
-                        // four entries per thread and trip: the gathers of their column terms (one each: packed) are in flight together
-                        constexpr int JN = 2;
-                        for (int base = 0; base < n_ent; base += JN * NT) {
-                            u64 e[JN];
-                            u64 *src[JN];
-                            int c[JN];
-                            float xy[JN];
-                            unsigned occ = 0;
-#pragma unroll
-                            for (int j = 0; j < JN; ++j) {
-                                const int i = base + j * NT + tid;
-                                src[j] = (i < ext) ? &spool[i] : &cs[i - ext];
-                                e[j] = (i < n_ent) ? *src[j] : 0ull;
-                            }
-#pragma unroll
-                            for (int j = 0; j < JN; ++j) {
-                                c[j] = (int)((unsigned)(e[j] >> 32) - 1u);
-                                xy[j] = __uint_as_float((unsigned)e[j]);
-                                if (e[j] != 0ull && !(xy[j] <= rc.xy_cut)) occ |= 1u << j;
-                            }
-                            const unsigned done = emit_candidates<JN>(p, rc, c, xy, occ, U, sh, cap);
-#pragma unroll
-                            for (int j = 0; j < JN; ++j) {
-                                if (e[j] != 0ull && (!(occ & (1u << j)) || (done & (1u << j)))) {
-                                    *src[j] = 0ull;
-                                    if (base + j * NT + tid >= ext)
-                                        cbm_unmark((unsigned)c[j]);
-                                }
-                            }
-                        }
-                    }
-                    wg_sync<U_LDS>();
-                    const int retry = sh[SH_RETRY];
-                    const int n_now = sh[SH_CNT];
-                    wg_sync<U_LDS>();
-                    if (tid == 0) {
-                        sh[SH_PCTR] = 0;
-                        if (do_acc) sh[SH_MCTR] = 0;
-                        if (retry) { sh[SH_RETRY] = 0; if (n_now > cap) sh[SH_CNT] = cap; }   // failed appends over-counted
-                    }
-                    wg_sync<U_LDS>();         // counter fix-ups visible before the next pushes / the selection
-                    if constexpr (!BND) PHASE_END(PH_DRAIN);
-                    // selection: forced when U overflowed; exact after the last stage (final top-k); between stages
-                    // when U is filling up (it raises the running k-th value, which is the cutoff of the next stage)
-                    const int n_eff = min(n_now, cap);
-                    if constexpr (BND) {
-                        // ---- the exact pass: U[n_keyed, n_eff) {raw dot, packed id} -> {key of the exact value, column}, or a hole when the value
-                        // fails `threshold` or cannot beat the running k-th value (s_plus.h:129-156, :201-208).  One gather per entry (packed
-                        // column terms), two entries per thread in flight; a few hundred entries per row. ----
-                        if (n_eff > n_keyed) {      // uniform
-                            constexpr int JK = 2;
-                            if (timing) ph[CT_PASSES] += (u64)(n_eff - n_keyed);      // (profiling: entries through the exact pass, low word)
-                            for (int base = n_keyed; base < n_eff; base += JK * NT) {
-                                u64 e[JK];
-                                int gc[JK];
-                                float ytv[JK], ycos[JK], ydep[JK];
-#pragma unroll
-                                for (int j = 0; j < JK; ++j) {
-                                    const int i = base + j * NT + tid;
-                                    e[j] = (i < n_eff) ? U[i] : 0ull;
-                                    gc[j] = (e[j] != 0ull) ? (int)((unsigned)e[j] & p.bnd_id_mask) : 0;
-                                    ytv[j] = 0.f; ycos[j] = 0.f; ydep[j] = 0.f;
-                                }
-                                if (p.Ypack) {
-#pragma unroll
-                                    for (int j = 0; j < JK; ++j) { const float4 y = p.Ypack[gc[j]]; ytv[j] = y.x; ycos[j] = y.y; ydep[j] = y.z; }
-                                } else {
-#pragma unroll
-                                    for (int j = 0; j < JK; ++j) {
-                                        if (p.l1 != 0.f) ytv[j] = p.Ytv[gc[j]];
-                                        if (p.l2 != 0.f) ycos[j] = p.Ycos[gc[j]];
-                                        if (p.l3 != 0.f) ydep[j] = p.Ydep[gc[j]];
-                                    }
-                                }
-#pragma unroll
-                                for (int j = 0; j < JK; ++j) {
-                                    if (e[j] != 0ull) {
-                                        const float val = rc.epi(__uint_as_float((unsigned)(e[j] >> 32)), ytv[j], ycos[j], ydep[j]);
-                                        const unsigned key = fkey(val);
-                                        const bool ok = (val >= p.threshold) && (!rc.have_thr || key > rc.thr_key || (thr_incl && key == rc.thr_key));
-                                        U[base + j * NT + tid] = ok ? (((u64)key << 32) | (u64)(unsigned)gc[j]) : 0ull;
-                                    }
-                                }
-                            }
-                            wg_sync<U_LDS>();
-                        }
-                        n_keyed = n_eff;
-                        PHASE_END(PH_DRAIN);      // (the exact pass is this variant's judge)
-                    }
-                    const bool want_sel = retry || (last_stage ? (n_eff > p.k) : (n_eff > p.k && (!rc.have_thr || force_sel || 2 * n_eff > cap + p.k)));
-                    force_sel = false;
-                    if (want_sel) {
-                        if (BND && timing) ph[CT_PASSES] += 1ull << 32;             // (profiling: selections, high word)
-                        long long thr_new;
-                        if (cap <= SEL_E * NT) thr_new = select_fast<NT, true, SEL_E, U_LDS, true>(U, hist4, sh, p.k, last_stage && !retry, rc.have_thr ? rc.thr_key : 0u);
-                        else {
-                            thr_new = compact_topk<NT>(U, hist4, sh, p.k);
-                            if constexpr (MLIKE) {     // block-wise reservations: nothing stale may stay behind the kept entries
-                                if (thr_new >= 0) {
-                                    for (int i = sh[SH_CNT] + tid; i < n_eff; i += NT) U[i] = 0ull;
-                                    wg_sync<U_LDS>();
-                                }
-                            }
-                        }
-                        if (thr_new >= 0) {
-                            rc.have_thr = true;
-                            rc.thr_key = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)thr_new);
-                            if constexpr (MONO) cutx = fmaxf(cutx0, funkey(rc.thr_key));
-                            else if constexpr (BND) set_bnd_cut();
-                            else rc.set_cut(p.threshold);
-                        }
-                        if constexpr (BND) { n_keyed = min(sh[SH_CNT], cap); if (thr_new >= 0) thr_incl = false; }      // (the selection compacted what it kept: all of it exact)
-                        PHASE_END(PH_SELECT);
-                    }
-                    if (!retry) break;  // uniform
-                }
-                // next chunk: with the k-th best of `pos` products as cutoff, an exchangeable stream lets k*m/pos of the
-                // next m products through; keep that below half of the room left in U (far fewer pass when the
-                // segments come in descending weight)
-                const float pos = (i0 < n_items) ? (float)(items[i0].w & ((1 << ITEM_W_BITS) - 1)) : (float)macs32;
-                const float left = (float)max(64, cap - min(sh[SH_CNT], cap));
-                // (the cutoff is the value that `cnt` of the `pos` products offered so far reach: cnt ~ k after a selection, more
-                // after the selection-free first stage)
-                const float cnt_u = (float)max(2 * p.k, min(sh[SH_CNT], cap));
-                float ch = rc.have_thr ? fmaxf((float)ITEM, STAGE_FILL * pos * left / cnt_u) : (float)room;
-                if constexpr (MLIKE) {
-                    // no k-th value yet, but the `threshold` parameter prunes (cutx0): U holds what passed of the `pos` products offered so
-                    // far — the rest of the row passes at most at that rate (segments come in descending weight).  Without this a row
-                    // that never collects k values above the threshold swept `room` products per stage: 45 stages at the C2 size.
-                    if (!__builtin_amdgcn_readfirstlane((int)rc.have_thr)) {      // (a scalar branch: rows with a k-th value — the rule — skip all of it)
-                        if (BND ? (b_t0 > 0.f) : (cutx0 > -__builtin_inff())) ch = fmaxf(ch, 0.5f * pos * left * __builtin_amdgcn_rcpf((float)max(1, min(sh[SH_CNT], cap))));
-                    }
-                }
-                if (!MLIKE) ch = fmaxf(ch, (float)room);
-                chunk_items = max(1, (int)fminf(ch * (1.f / ITEM), 1e6f));
+                // ==== phase: dense consumer, exact pass (bounded variant), selections, next stage's length ====
+#include "sp_sparse_phase_consume.inc"
             }
         }
 
         if (!failed) {
-            // ================= write-out =================
-            wg_sync<U_LDS>();
-            // Everything prefetched during this row is consumed HERE — where it arrived long ago, and BEFORE the write-out's stores are
-            // issued: across the loop's back edge the compiler cannot count what was issued since and waits with vmcnt(0) at the
-            // first use in the next row, i.e. for that row's fresh loads (the item records' copy into LDS and the queue slot's store
-            // waited ~2 k cycles) or, consumed at the very end of this row, for its result stores.
-            asm volatile("" : "+v"(recN), "+v"(nx_v), "+v"(pend_q), "+v"(nx_r0), "+v"(nx_r1), "+v"(dNN));
-            if constexpr (REC2) asm volatile("" : "+v"(recN2));
-            dR = make_int4(__builtin_amdgcn_readlane((int)dNN, 0), __builtin_amdgcn_readlane((int)dNN, 1),
-                           __builtin_amdgcn_readlane((int)dNN, 2), __builtin_amdgcn_readlane((int)dNN, 3));
-            wR = make_int4(__builtin_amdgcn_readlane((int)dNN, 4), __builtin_amdgcn_readlane((int)dNN, 5),
-                           __builtin_amdgcn_readlane((int)dNN, 6), __builtin_amdgcn_readlane((int)dNN, 7));
-            const int n_sel = min(sh[SH_CNT], p.k);
-            const long long o = (long long)slot_i * (long long)p.k;
-            int n_out = n_sel;
-            // (DUO: the rank prefix lies inside the next row's column bitmap; its last reader was the last stage's accumulate)
-            if constexpr (DUO) { if (tid < PRE_BYTES / 16) ((int4 *)pre16)[tid] = make_int4(0, 0, 0, 0); }
-            if constexpr (MLIKE) {
-                // (BND: the entries hold exact values already; MONO:) epilogue on the winners (s_plus.h:129-156 with the column term already folded in: val = xy / den, or
-                // the raw dot), exact threshold test, compaction of what passes to the front of the slot
-                // (compaction counter: SH_PCTR, which the monotone variant leaves at zero — no reset, no barrier in front of the loop.
-                // LDS U: every thread zeroes the entries it has read — U's storage is part of the next row's bitmap; every selection
-                // zeroes what lies behind the entries it keeps, so only the first k (+2) entries can be non-zero — no barrier between
-                // "U read" and "U cleared" either)
-                constexpr bool OWN_CLEAR = U_LDS;      // (cap <= SEL_E * NT there)
-                const int n_cl = OWN_CLEAR ? min(cap, p.k + 2) : n_sel;
-                for (int base = 0; base < n_cl; base += NT) {
-                    const int j = base + tid;
-                    const u64 it = (j < n_sel) ? U[j] : 0ull;
-                    if (OWN_CLEAR && j < n_cl) U[j] = 0ull;
-                    const float xv = funkey((unsigned)(it >> 32));
-                    float val = xv;
-                    if (MONO && any_norm) val = (den != 0.f) ? xv / den : 0.f;
-                    const bool keep = (it != 0ull) && (val >= p.threshold);
-                    const u64 m = __ballot(keep);
-                    if (m) {
-                        int wbase = 0;
-                        if (lane == 0) wbase = atomicAdd(&sh[SH_PCTR], __popcll(m));
-                        wbase = __builtin_amdgcn_readfirstlane(wbase);
-                        if (keep) {
-                            const long long q = o + wbase + mbcnt64(m);
-                            if (p.rows) p.rows[q] = t;
-                            p.cols[q] = (int)(unsigned)(it & 0xFFFFFFFFull);
-                            p.values[q] = val;
-                        }
-                    }
-                }
-                wg_sync<U_LDS>();
-                n_out = sh[SH_PCTR];
-                for (int j = n_out + tid; j < p.k; j += NT) {
-                    if (p.rows) p.rows[o + j] = 0;
-                    p.cols[o + j] = 0;
-                    p.values[o + j] = 0.f;
-                }
-            } else {
-                for (int j = tid; j < p.k; j += NT) {
-                    int r = 0, c = 0;
-                    float v = 0.f;
-                    if (j < n_out) {
-                        const u64 it = U[j];
-                        r = t;
-                        c = (int)(unsigned)(it & 0xFFFFFFFFull);
-                        v = funkey((unsigned)(it >> 32));
-                    }
-                    if (p.rows) p.rows[o + j] = r;
-                    p.cols[o + j] = c;
-                    p.values[o + j] = v;
-                }
-            }
-            if (tid == 0 && p.counts) p.counts[slot_i] = n_out;
-            // (MATRIX filter: every excluded column has a slot in the collision set — its pseudo-member — so the set's scan has
-            // cleared its mark like any other column's)
-            if ((U_LDS || MLIKE) && !(MLIKE && U_LDS)) {      // (MONO / BND with U in LDS: cleared in the loop above)
-                // U's storage is part of the next row's bitmap (LDS) / holes must read zero (MONO).  Every selection zeroes
-                // what lies behind the entries it keeps, so only the first k entries can be non-zero here.
-                wg_sync<U_LDS>();     // U read before it is cleared
-                const int dirty = (cap <= SEL_E * NT) ? min(cap, p.k + 2) : cap;
-                for (int i = tid; i < (dirty + 1) / 2; i += NT) ((int4 *)U)[i] = make_int4(0, 0, 0, 0);
-            }
-            if (timing) ph[CT_ROWS_SPARSE] += 1;
+            // ==== phase: write-out ====
+#include "sp_sparse_phase_writeout.inc"
         } else {
             // a pool or the collision set overflowed (or the row has too many items): hand the row to the generic
             // kernel's queue and put the LDS state back to clean
